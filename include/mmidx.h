@@ -1,0 +1,165 @@
+/*
+ * mmidx.h -- C ABI of the MI355X-native PQ / IVFPQ search engine (libmmidx_hip.so).
+ *
+ * This is the drop-in boundary for the search path of MKLab-ITI/multimedia-indexing
+ * (gr.iti.mklab.visual.datastructures.{PQ,IVFPQ}).  The reference is pure Java and has no FFI
+ * layer; its seam is the Template-Method contract of AbstractSearchStructure (5 protected hooks,
+ * AbstractSearchStructure.java:267,305,342,729,755).  Each entry point below states the
+ * reference method(s) whose body it replaces.  Citations are relative to the reference root,
+ * J/ = src/main/java/gr/iti/mklab/visual/.  INTEGRATION.md shows the JNI stub and the Java
+ * subclasses (GpuIVFPQ / GpuPQ) that bind these symbols.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ or torch types.  Every call returns an int status
+ *     (MMIDX_OK == 0); mmidx_last_error() returns the message for the calling thread.  Status
+ *     codes map 1:1 onto the reference's exceptions (see the enum).  Native code never exits.
+ *   - vectors are row-major IEEE binary64, exactly the Java double[] contents.
+ *   - PQ codes cross the boundary in the reference's stored form: for numProductCentroids <= 256
+ *     one int8 per sub-quantizer holding (index - 128) (PQ.transformToByte, J/datastructures/
+ *     PQ.java:552-558); otherwise one int16 per sub-quantizer holding the index
+ *     (PQ.transformToShort, PQ.java:544-550).
+ *   - internal ids (iid) are int32, as in the reference (loadCounter, ASS:65).
+ *   - "_device" variants take pointers into the HBM of the handle's GPU and run asynchronously on
+ *     the given hipStream_t (passed as void*; NULL = the handle's own stream).  Host variants
+ *     stage through HBM and are synchronous.
+ *   - threading: adds are serialised per handle (indexVector / indexPQCode are `synchronized`,
+ *     ASS:229, IVFPQ.java:357); searches may run concurrently with each other but not with adds
+ *     (the reference offers no reader/writer exclusion either).
+ *   - arithmetic: all distances are fp64, accumulated in the reference's left-to-right order
+ *     without FMA contraction; returned ids are bit-exact w.r.t. the reference restatement and
+ *     distances are bit-equal (tolerance promised to callers: 1e-5).
+ */
+#ifndef MMIDX_H
+#define MMIDX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMIDX_ABI_VERSION 1
+
+typedef struct mmidx_index mmidx_index; /* opaque handle: one index on one GPU */
+
+enum mmidx_status {
+    MMIDX_OK = 0,
+    MMIDX_ERR_INVALID_SUBVECTORS = 1, /* "The given number of subvectors is not valid!"  IVFPQ.java:181-183, PQ.java:148-150 */
+    MMIDX_ERR_WRONG_DIM = 2,          /* "The dimensionality of the vector is wrong!"    IVFPQ.java:310-312, PQ.java:233-235 */
+    MMIDX_ERR_NOT_IN_MEMORY = 3,      /* "Cannot execute query because the index is not loaded in memory!" ASS:282-284 */
+    MMIDX_ERR_BYTE_OVERFLOW = 4,      /* "Byte is not sufficient to enumerate the centroids of the product quantizer!" IVFPQ.java:358-361 */
+    MMIDX_ERR_CAPACITY = 5,           /* "Maximum index capacity reached..." (return false) ASS:232-235 */
+    MMIDX_ERR_INVALID_ARG = 6,        /* null pointer, k < 1 (LingPipe queue ctor), w outside 1..C (NPE at IVFPQ.java:597-599) */
+    MMIDX_ERR_NOT_READY = 7,          /* quantizers not loaded (NullPointerException in the reference) */
+    MMIDX_ERR_NO_DEVICE = 8,          /* no usable MI355X / HIP runtime: the product path has NO CPU fallback */
+    MMIDX_ERR_HIP = 9,                /* HIP runtime error; message carries hipGetErrorString */
+    MMIDX_ERR_UNSUPPORTED = 10        /* configuration outside the kernel envelope (see DESIGN.md limits) */
+};
+
+enum mmidx_kind { MMIDX_KIND_PQ = 1, MMIDX_KIND_IVFPQ = 2 };
+/* PQ.TransformationType ordinals, J/datastructures/PQ.java:78-80 */
+enum mmidx_transform { MMIDX_TR_NONE = 0, MMIDX_TR_ROTATION = 1, MMIDX_TR_PERMUTATION = 2 };
+
+const char *mmidx_last_error(void);
+int mmidx_abi_version(void);
+/* number of visible HIP devices (0 when there is no GPU / runtime) */
+int mmidx_device_count(void);
+
+/* ---- lifecycle ------------------------------------------------------------------------------
+ * Replaces the in-memory half of the constructors IVFPQ.java:174-237 / PQ.java:142-174 (the
+ * BDB half stays in Java).  D = vectorLength, m = numSubVectors, ks = numProductCentroids,
+ * C = numCoarseCentroids (ignored for PQ).  transform PERMUTATION: perm = D int32 indices
+ * (RandomPermutation, J/utilities/RandomPermutation.java:29-56; pass NULL to have the library
+ * derive RandomPermutation(seed = 1, D) with the JDK LCG, IVFPQ.java:136,193).  transform
+ * ROTATION: rot = D*D row-major doubles computed by the Java side with EJML
+ * (J/utilities/RandomRotation.java:30-35; the EJML stream cannot be re-derived natively).
+ * Default w = (int)(0.1 * C), IVFPQ.java:188. */
+int mmidx_create(int kind, int D, int m, int ks, int C, int transform, const int32_t *perm,
+                 const double *rot, int device, mmidx_index **out);
+int mmidx_destroy(mmidx_index *h); /* closeInternal, IVFPQ.java:888-890 */
+
+/* loadCoarseQuantizer IVFPQ.java:297-300 : coarse[C][D] */
+int mmidx_set_coarse(mmidx_index *h, const double *coarse);
+/* loadProductQuantizer IVFPQ.java:275-288 / PQ.java:210-223 : pq[m][ks][D/m], file order */
+int mmidx_set_pq(mmidx_index *h, const double *pq);
+/* setW IVFPQ.java:95-97 */
+int mmidx_set_w(mmidx_index *h, int w);
+int mmidx_get_w(const mmidx_index *h, int *w_out);
+/* loadCounter (ASS:65): number of indexed codes */
+int mmidx_size(const mmidx_index *h, int64_t *n_out);
+/* outputItemsPerList IVFPQ.java:654-673 : sizes[C] (sizes[1] for PQ) */
+int mmidx_list_sizes(mmidx_index *h, int32_t *sizes_out);
+
+/* ---- indexing -------------------------------------------------------------------------------
+ * mmidx_encode: the arithmetic of indexVectorInternal, IVFPQ.java:309-335 (+computeNearest-
+ * CoarseIndex :547-564, computeResidualVector :642-648, computeNearestProductIndex :613-631) /
+ * PQ.java:232-252, for n vectors X[n][D], WITHOUT appending.  cell_out[n] (-1 for PQ),
+ * code_out[n][m] in stored form (int8 or int16, see above).  Lets the Java side persist the
+ * record to BDB exactly as appendPersistentIndex does (IVFPQ.java:760-792). */
+int mmidx_encode(mmidx_index *h, int64_t n, const double *X, int32_t *cell_out, void *code_out);
+/* mmidx_add_vectors: indexVectorInternal for a batch: encode + append with the given iids
+ * (iids == NULL: iid = current size + i, i.e. loadCounter semantics ASS:244-251).  cell_out /
+ * code_out may be NULL. */
+int mmidx_add_vectors(mmidx_index *h, int64_t n, const double *X, const int32_t *iids,
+                      int32_t *cell_out, void *code_out);
+/* mmidx_add_codes: append precomputed records -- serves indexPQCode (IVFPQ.java:357-386) and
+ * loadIndexInMemory (IVFPQ.java:680-728, PQ.java:436-483).  cells may be NULL for PQ. */
+int mmidx_add_codes(mmidx_index *h, int64_t n, const int32_t *iids, const int32_t *cells,
+                    const void *codes);
+/* device-resident bulk variants (X, iids, cells, codes in HBM). */
+int mmidx_add_vectors_device(mmidx_index *h, int64_t n, const double *dX, const int32_t *d_iids,
+                             int32_t iid0, void *stream);
+int mmidx_add_codes_device(mmidx_index *h, int64_t n, const int32_t *d_iids,
+                           const int32_t *d_cells, const void *d_codes, void *stream);
+int mmidx_encode_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_cell_out,
+                        void *d_code_out, void *stream);
+/* build the device-side inverted-list layout now (otherwise done lazily by the next search) */
+int mmidx_sync_index(mmidx_index *h);
+
+/* ---- search ---------------------------------------------------------------------------------
+ * computeNearestNeighborsInternal(k, double[]) : computeKnnIVFADC IVFPQ.java:408-450 /
+ * computeKnnADC PQ.java:290-322, for nq queries Q[nq][D].  Row i of iid_out / dist_out holds
+ * count_out[i] = min(k, #candidates) results, best first: ascending squared distance, equal
+ * distances in the bounded queue's order (ASS.lookUp, ASS:345-358).  Unused tail entries are
+ * iid -1 / +inf.  k must be in 1..1023. */
+int mmidx_search(mmidx_index *h, int k, int64_t nq, const double *Q, int32_t *iid_out,
+                 double *dist_out, int32_t *count_out);
+int mmidx_search_device(mmidx_index *h, int k, int64_t nq, const double *dQ, int32_t *d_iid_out,
+                        double *d_dist_out, int32_t *d_count_out, void *stream);
+
+/* ---- sharded search (one process per GPU; lists partitioned across ranks) ---------------------
+ * mmidx_coarse_device: computeNearestCoarseIndices IVFPQ.java:575-601 for nq queries ->
+ *   d_cells_out[nq][w] (nearest first).
+ * mmidx_search_partial_device: scan of this shard's lists for the given probe cells; writes the
+ *   shard's best k+1 candidates per query, sorted: d_pdist[nq][k+1] (fp64), d_pkey[nq][k+1]
+ *   (int64 = probe_rank << 32 | iid -- the reference's offer order), d_pcount[nq].
+ * mmidx_merge_partials_device: merges nshards partial lists laid out [nshards][nq][k+1] (as an
+ *   all-gather delivers them) into final results; no index handle needed. */
+int mmidx_coarse_device(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells_out,
+                        void *stream);
+int mmidx_search_partial_device(mmidx_index *h, int k, int64_t nq, const double *dQ,
+                                const int32_t *d_cells, double *d_pdist, int64_t *d_pkey,
+                                int32_t *d_pcount, void *stream);
+int mmidx_merge_partials_device(int device, int k, int64_t nq, int nshards, const double *d_pdist,
+                                const int64_t *d_pkey, const int32_t *d_pcount,
+                                int32_t *d_iid_out, double *d_dist_out, int32_t *d_count_out,
+                                void *stream);
+
+/* ---- instrumentation -------------------------------------------------------------------------
+ * Per-handle statistics of the most recent search call, measured with HIP events on the stream
+ * the kernels were launched on.  scan_ms = time inside the list-scan kernel (the HBM-bound
+ * kernel of the path), scan_codes = sum over (query, probed list) of list lengths (algorithmic
+ * bytes = m * scan_codes), launches = number of scan launches. */
+typedef struct mmidx_stats {
+    double total_ms, coarse_ms, scan_ms, merge_ms;
+    int64_t scan_codes;
+    int32_t scan_launches;
+    int32_t tie_fallbacks;
+} mmidx_stats;
+int mmidx_set_profiling(mmidx_index *h, int enabled);
+int mmidx_get_stats(mmidx_index *h, mmidx_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

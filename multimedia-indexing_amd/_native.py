@@ -1,0 +1,104 @@
+"""ctypes binding of libmmidx_hip.so (the C ABI of include/mmidx.h).
+
+The product path has no CPU fallback: if the HIP library is missing or no MI355X is visible,
+every operation raises.  torch is NOT needed here; it is only used by callers that want their
+inputs resident in HBM (bench, multi-GPU).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libmmidx_hip.so")
+
+OK = 0
+STATUS_NAMES = {
+    1: "INVALID_SUBVECTORS", 2: "WRONG_DIM", 3: "NOT_IN_MEMORY", 4: "BYTE_OVERFLOW", 5: "CAPACITY",
+    6: "INVALID_ARG", 7: "NOT_READY", 8: "NO_DEVICE", 9: "HIP", 10: "UNSUPPORTED",
+}
+ERR_INVALID_SUBVECTORS, ERR_WRONG_DIM, ERR_NOT_IN_MEMORY, ERR_BYTE_OVERFLOW = 1, 2, 3, 4
+ERR_CAPACITY, ERR_INVALID_ARG, ERR_NOT_READY, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED = 5, 6, 7, 8, 9, 10
+
+KIND_PQ, KIND_IVFPQ = 1, 2
+TR_NONE, TR_ROTATION, TR_PERMUTATION = 0, 1, 2
+
+
+class MmidxError(Exception):
+    """Mirrors the reference's `throw new Exception(msg)`; .status carries the C status code."""
+
+    def __init__(self, status, msg):
+        super().__init__(msg)
+        self.status = status
+
+
+class Stats(C.Structure):
+    _fields_ = [("total_ms", C.c_double), ("coarse_ms", C.c_double), ("scan_ms", C.c_double),
+                ("merge_ms", C.c_double), ("scan_codes", C.c_int64), ("scan_launches", C.c_int32),
+                ("tie_fallbacks", C.c_int32)]
+
+
+def build(force=False):
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in ("mmidx_api.hip", "mmidx_kernels.h")]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "mmidx.h"))
+    stale = not os.path.exists(SO_PATH) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-s"] + (["-B"] if force else []))
+    return SO_PATH
+
+
+_lib = None
+
+_vp, _i32p, _dp = C.c_void_p, C.c_void_p, C.c_void_p
+SIGNATURES = {
+    "mmidx_last_error": (C.c_char_p, []),
+    "mmidx_abi_version": (C.c_int, []),
+    "mmidx_device_count": (C.c_int, []),
+    "mmidx_create": (C.c_int, [C.c_int] * 6 + [_vp, _vp, C.c_int, C.POINTER(C.c_void_p)]),
+    "mmidx_destroy": (C.c_int, [_vp]),
+    "mmidx_set_coarse": (C.c_int, [_vp, _dp]),
+    "mmidx_set_pq": (C.c_int, [_vp, _dp]),
+    "mmidx_set_w": (C.c_int, [_vp, C.c_int]),
+    "mmidx_get_w": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "mmidx_size": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    "mmidx_list_sizes": (C.c_int, [_vp, _i32p]),
+    "mmidx_encode": (C.c_int, [_vp, C.c_int64, _dp, _i32p, _vp]),
+    "mmidx_add_vectors": (C.c_int, [_vp, C.c_int64, _dp, _i32p, _i32p, _vp]),
+    "mmidx_add_codes": (C.c_int, [_vp, C.c_int64, _i32p, _i32p, _vp]),
+    "mmidx_add_vectors_device": (C.c_int, [_vp, C.c_int64, _dp, _i32p, C.c_int32, _vp]),
+    "mmidx_add_codes_device": (C.c_int, [_vp, C.c_int64, _i32p, _i32p, _vp, _vp]),
+    "mmidx_encode_device": (C.c_int, [_vp, C.c_int64, _dp, _i32p, _vp, _vp]),
+    "mmidx_sync_index": (C.c_int, [_vp]),
+    "mmidx_search": (C.c_int, [_vp, C.c_int, C.c_int64, _dp, _i32p, _dp, _i32p]),
+    "mmidx_search_device": (C.c_int, [_vp, C.c_int, C.c_int64, _dp, _i32p, _dp, _i32p, _vp]),
+    "mmidx_coarse_device": (C.c_int, [_vp, C.c_int64, _dp, _i32p, _vp]),
+    "mmidx_search_partial_device": (C.c_int, [_vp, C.c_int, C.c_int64, _dp, _i32p, _dp, _vp, _i32p, _vp]),
+    "mmidx_merge_partials_device": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, _dp, _vp, _i32p, _i32p, _dp, _i32p, _vp]),
+    "mmidx_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "mmidx_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
+}
+
+
+def lib():
+    """Load libmmidx_hip.so; raises loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        f = getattr(L, name)  # AttributeError if the symbol is not exported
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != OK:
+        msg = lib().mmidx_last_error().decode("utf-8", "replace")
+        raise MmidxError(status, msg)

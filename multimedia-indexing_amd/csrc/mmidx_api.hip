@@ -1,0 +1,946 @@
+// mmidx_api.hip -- host side of libmmidx_hip.so: the C ABI of include/mmidx.h.
+//
+// One handle = one PQ / IVFPQ index resident in the HBM of one MI355X.  There is no CPU
+// fallback: without a HIP device every entry point fails with MMIDX_ERR_NO_DEVICE.
+//
+// HBM layout (per handle)
+//   coarse   [C][D]  f64   + coarseT [D][C]        (transposed copy: coalesced per-centroid reads)
+//   pq       [m][ks][dsub] + pqT [m][dsub][ks]     (transposed copy: coalesced per-entry reads)
+//   list_off [nlists+1] i64, codes [n][m] u8|u16 (list-major, arrival order inside a list),
+//   ids      [n] i32                               (CSR form of invertedLists / pqByteCodes,
+//                                                   IVFPQ.java:72-83)
+//   pending  (cells, ids, codes) of records added since the last CSR build
+#include "../../include/mmidx.h"
+#include "mmidx_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCK(expr)                                                                          \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return fail(MMIDX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+// ---- java.util.Random + Collections.shuffle (RandomPermutation.java:29-40) --------------------
+struct JRandom {
+    uint64_t s;
+    explicit JRandom(int64_t seed) : s(((uint64_t)seed ^ 0x5DEECE66DULL) & ((1ULL << 48) - 1)) {}
+    int32_t next(int bits) {
+        s = (s * 0x5DEECE66DULL + 0xBULL) & ((1ULL << 48) - 1);
+        return (int32_t)((int64_t)s >> (48 - bits));
+    }
+    int32_t nextInt(int32_t bound) {
+        if ((bound & (-bound)) == bound) return (int32_t)(((int64_t)bound * (int64_t)next(31)) >> 31);
+        int32_t bits, val;
+        do {
+            bits = next(31);
+            val = bits % bound;
+        } while ((int32_t)((uint32_t)bits - (uint32_t)val + (uint32_t)(bound - 1)) < 0);
+        return val;
+    }
+};
+void jdk_random_permutation(int64_t seed, int dim, int32_t *perm) {
+    JRandom r(seed);
+    for (int i = 0; i < dim; i++) perm[i] = i;
+    for (int i = dim; i > 1; i--) std::swap(perm[i - 1], perm[r.nextInt(i)]);
+}
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;  // elements
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct mmidx_index {
+    int kind = 0, D = 0, m = 0, ks = 0, dsub = 0, C = 0, transform = 0, w = 0, device = 0;
+    int nlists = 1;
+    size_t code_bytes = 1;  // per sub-quantizer
+    bool coarse_set = false, pq_set = false;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+
+    double *d_coarse = nullptr, *d_coarseT = nullptr, *d_pq = nullptr, *d_pqT = nullptr,
+           *d_rot = nullptr;
+    int32_t *d_perm = nullptr;
+
+    // CSR
+    int64_t n_csr = 0;
+    std::vector<int64_t> h_off;  // [nlists+1]
+    int64_t max_list_len = 0;
+    int64_t *d_off = nullptr;
+    void *d_codes = nullptr;
+    int32_t *d_ids = nullptr;
+    // pending (device, arrival order)
+    int64_t n_pend = 0, cap_pend = 0;
+    int32_t *d_pcell = nullptr, *d_pid = nullptr;
+    void *d_pcodes = nullptr;
+
+    // workspaces
+    DevBuf<double> ws_Q, ws_cdist, ws_odist, ws_X;
+    DevBuf<int32_t> ws_cells, ws_oiid, ws_ocnt, ws_flag, ws_ecell;
+    DevBuf<u64> ws_T, ws_pkey, ws_pval;
+    DevBuf<u32> ws_pcnt;
+    DevBuf<unsigned char> ws_ecode, ws_tmp;
+    DevBuf<long long> ws_dest;
+
+    bool profiling = false;
+    mmidx_stats stats{};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+namespace {
+
+int set_device(const mmidx_index *h) {
+    HIPCK(hipSetDevice(h->device));
+    return MMIDX_OK;
+}
+
+int64_t total_size(const mmidx_index *h) { return h->n_csr + h->n_pend; }
+
+int ensure_pending(mmidx_index *h, int64_t extra) {
+    int64_t need = h->n_pend + extra;
+    if (need <= h->cap_pend) return MMIDX_OK;
+    int64_t cap = std::max<int64_t>(need, h->cap_pend * 2);
+    cap = std::max<int64_t>(cap, 1024);
+    int32_t *ncell = nullptr, *nid = nullptr;
+    void *ncodes = nullptr;
+    HIPCK(hipMalloc((void **)&ncell, cap * sizeof(int32_t)));
+    HIPCK(hipMalloc((void **)&nid, cap * sizeof(int32_t)));
+    HIPCK(hipMalloc(&ncodes, (size_t)cap * h->m * h->code_bytes));
+    if (h->n_pend) {
+        HIPCK(hipMemcpyAsync(ncell, h->d_pcell, h->n_pend * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+        HIPCK(hipMemcpyAsync(nid, h->d_pid, h->n_pend * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+        HIPCK(hipMemcpyAsync(ncodes, h->d_pcodes, (size_t)h->n_pend * h->m * h->code_bytes,
+                             hipMemcpyDeviceToDevice, h->stream));
+        HIPCK(hipStreamSynchronize(h->stream));
+    }
+    if (h->d_pcell) (void)hipFree(h->d_pcell);
+    if (h->d_pid) (void)hipFree(h->d_pid);
+    if (h->d_pcodes) (void)hipFree(h->d_pcodes);
+    h->d_pcell = ncell;
+    h->d_pid = nid;
+    h->d_pcodes = ncodes;
+    h->cap_pend = cap;
+    return MMIDX_OK;
+}
+
+// Fold the pending records into the CSR layout (stable: arrival order inside every list, as
+// invertedLists[c].add / pqByteCodes[c].add do, IVFPQ.java:337-346, :376-377, :700-715).
+int build_csr(mmidx_index *h) {
+    if (h->n_pend == 0 && h->d_off) return MMIDX_OK;
+    const int nl = h->nlists;
+    const int64_t np = h->n_pend, nold = h->n_csr, ntot = np + nold;
+    std::vector<int32_t> pcell((size_t)np);
+    if (np) {
+        HIPCK(hipMemcpyAsync(pcell.data(), h->d_pcell, np * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCK(hipStreamSynchronize(h->stream));
+    }
+    std::vector<int64_t> cnt((size_t)nl, 0), off_new((size_t)nl + 1, 0), cursor((size_t)nl);
+    for (int64_t i = 0; i < np; i++) {
+        int c = pcell[(size_t)i];
+        if (c < 0 || c >= nl) return fail(MMIDX_ERR_INVALID_ARG, "list id %d outside 0..%d", c, nl - 1);
+        cnt[(size_t)c]++;
+    }
+    if (h->h_off.empty()) h->h_off.assign((size_t)nl + 1, 0);
+    for (int c = 0; c < nl; c++) {
+        const int64_t len_old = h->h_off[(size_t)c + 1] - h->h_off[(size_t)c];
+        off_new[(size_t)c + 1] = off_new[(size_t)c] + len_old + cnt[(size_t)c];
+        cursor[(size_t)c] = off_new[(size_t)c] + len_old;
+    }
+    std::vector<long long> dest((size_t)np);
+    for (int64_t i = 0; i < np; i++) dest[(size_t)i] = cursor[(size_t)pcell[(size_t)i]]++;
+
+    int64_t *d_off_new = nullptr;
+    void *d_codes_new = nullptr;
+    int32_t *d_ids_new = nullptr;
+    HIPCK(hipMalloc((void **)&d_off_new, ((size_t)nl + 1) * sizeof(int64_t)));
+    HIPCK(hipMalloc(&d_codes_new, std::max<size_t>((size_t)ntot * h->m * h->code_bytes, 16)));
+    HIPCK(hipMalloc((void **)&d_ids_new, std::max<size_t>((size_t)ntot * sizeof(int32_t), 16)));
+    HIPCK(hipMemcpyAsync(d_off_new, off_new.data(), ((size_t)nl + 1) * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    if (nold) {
+        const unsigned grid = (unsigned)((nold + 255) / 256);
+        if (h->code_bytes == 1)
+            hipLaunchKernelGGL(k_move_old<unsigned char>, dim3(grid), dim3(256), 0, h->stream, h->d_off, d_off_new, nl,
+                               (const unsigned char *)h->d_codes, h->d_ids, (unsigned char *)d_codes_new, d_ids_new, h->m, (long long)nold);
+        else
+            hipLaunchKernelGGL(k_move_old<unsigned short>, dim3(grid), dim3(256), 0, h->stream, h->d_off, d_off_new, nl,
+                               (const unsigned short *)h->d_codes, h->d_ids, (unsigned short *)d_codes_new, d_ids_new, h->m, (long long)nold);
+    }
+    if (np) {
+        HIPCK(h->ws_dest.reserve((size_t)np));
+        HIPCK(hipMemcpyAsync(h->ws_dest.p, dest.data(), (size_t)np * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+        const unsigned grid = (unsigned)((np + 255) / 256);
+        if (h->code_bytes == 1)
+            hipLaunchKernelGGL(k_place_new<unsigned char>, dim3(grid), dim3(256), 0, h->stream, h->ws_dest.p,
+                               (const unsigned char *)h->d_pcodes, h->d_pid, (unsigned char *)d_codes_new, d_ids_new, h->m, (long long)np);
+        else
+            hipLaunchKernelGGL(k_place_new<unsigned short>, dim3(grid), dim3(256), 0, h->stream, h->ws_dest.p,
+                               (const unsigned short *)h->d_pcodes, h->d_pid, (unsigned short *)d_codes_new, d_ids_new, h->m, (long long)np);
+    }
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(h->stream));
+    if (h->d_off) (void)hipFree(h->d_off);
+    if (h->d_codes) (void)hipFree(h->d_codes);
+    if (h->d_ids) (void)hipFree(h->d_ids);
+    h->d_off = d_off_new;
+    h->d_codes = d_codes_new;
+    h->d_ids = d_ids_new;
+    h->h_off = off_new;
+    h->n_csr = ntot;
+    h->n_pend = 0;
+    // release the pending buffers of a bulk load (they can be as large as the index)
+    if (h->cap_pend > (1 << 20)) {
+        (void)hipFree(h->d_pcell);
+        (void)hipFree(h->d_pid);
+        (void)hipFree(h->d_pcodes);
+        h->d_pcell = h->d_pid = nullptr;
+        h->d_pcodes = nullptr;
+        h->cap_pend = 0;
+        h->ws_dest.release();
+    }
+    h->max_list_len = 0;
+    for (int c = 0; c < nl; c++) h->max_list_len = std::max(h->max_list_len, off_new[(size_t)c + 1] - off_new[(size_t)c]);
+    return MMIDX_OK;
+}
+
+int check_ready(const mmidx_index *h) {
+    if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    if (!h->pq_set) return fail(MMIDX_ERR_NOT_READY, "product quantizer not loaded (loadProductQuantizer)");
+    if (h->kind == MMIDX_KIND_IVFPQ && !h->coarse_set)
+        return fail(MMIDX_ERR_NOT_READY, "coarse quantizer not loaded (loadCoarseQuantizer)");
+    return MMIDX_OK;
+}
+
+size_t scan_lds_bytes(const mmidx_index *h, int cap) {
+    return (size_t)h->m * h->ks * 8 + 2 * (size_t)h->D * 8 + (size_t)cap * 12 + 16;
+}
+
+// encode n device-resident vectors into (cell, code); code_out holds centroid indices (CodeT)
+int encode_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_cell, void *d_code, hipStream_t st) {
+    if (n == 0) return MMIDX_OK;
+    const int ivf = h->kind == MMIDX_KIND_IVFPQ;
+    if (ivf) {
+        constexpr int QT = 16;
+        const unsigned grid = (unsigned)((n + QT - 1) / QT);
+        hipLaunchKernelGGL(k_assign_coarse<QT>, dim3(grid), dim3(MMIDX_BLOCK), 0, st, h->d_coarseT, dX, d_cell, h->C, h->D, (long long)n);
+    } else {
+        HIPCK(hipMemsetAsync(d_cell, 0xFF, (size_t)n * sizeof(int32_t), st));  // -1
+    }
+    constexpr int VT = 8;
+    const size_t lds = 2 * (size_t)VT * h->D * 8 + (size_t)h->m * VT * 4 * 12;
+    if (lds > 160 * 1024) return fail(MMIDX_ERR_UNSUPPORTED, "vector length %d too large for the encode kernel", h->D);
+    const unsigned grid = (unsigned)((n + VT - 1) / VT);
+    if (h->code_bytes == 1) {
+        HIPCK(hipFuncSetAttribute((const void *)k_encode_pq<VT, unsigned char>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_encode_pq<VT, unsigned char>), dim3(grid), dim3(MMIDX_BLOCK), lds, st, dX, d_cell, h->d_coarse, h->d_pqT,
+                           h->d_perm, h->d_rot, (unsigned char *)d_code, h->D, h->m, h->ks, h->dsub, h->transform, ivf, (long long)n);
+    } else {
+        HIPCK(hipFuncSetAttribute((const void *)k_encode_pq<VT, unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_encode_pq<VT, unsigned short>), dim3(grid), dim3(MMIDX_BLOCK), lds, st, dX, d_cell, h->d_coarse, h->d_pqT,
+                           h->d_perm, h->d_rot, (unsigned short *)d_code, h->D, h->m, h->ks, h->dsub, h->transform, ivf, (long long)n);
+    }
+    HIPCK(hipGetLastError());
+    return MMIDX_OK;
+}
+
+template <int M, typename CodeT>
+int launch_scan_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t st) {
+    HIPCK(hipFuncSetAttribute((const void *)k_scan<M, CodeT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_scan<M, CodeT>), grid, dim3(MMIDX_BLOCK), lds, st, P);
+    HIPCK(hipGetLastError());
+    return MMIDX_OK;
+}
+
+int launch_scan(const mmidx_index *h, const ScanParams &P, dim3 grid, size_t lds, hipStream_t st) {
+    if (h->code_bytes == 1) {
+        switch (h->m) {
+            case 4: return launch_scan_t<4, unsigned char>(P, grid, lds, st);
+            case 8: return launch_scan_t<8, unsigned char>(P, grid, lds, st);
+            case 16: return launch_scan_t<16, unsigned char>(P, grid, lds, st);
+            case 32: return launch_scan_t<32, unsigned char>(P, grid, lds, st);
+            case 64: return launch_scan_t<64, unsigned char>(P, grid, lds, st);
+            default: return launch_scan_t<0, unsigned char>(P, grid, lds, st);
+        }
+    }
+    switch (h->m) {
+        case 8: return launch_scan_t<8, unsigned short>(P, grid, lds, st);
+        case 16: return launch_scan_t<16, unsigned short>(P, grid, lds, st);
+        default: return launch_scan_t<0, unsigned short>(P, grid, lds, st);
+    }
+}
+
+struct SearchPlan {
+    int K1, cap, chunk, nchunks, nitems, poolq;
+    size_t lds;
+    int64_t qb;  // queries per sub-batch
+};
+
+int make_plan(mmidx_index *h, int k, int64_t nq, SearchPlan &pl) {
+    if (k < 1 || k > 1023) return fail(MMIDX_ERR_INVALID_ARG, "k must be in 1..1023 (got %d)", k);
+    pl.K1 = k + 1;
+    int cap = 1;
+    while (cap < pl.K1 + MMIDX_SEG) cap <<= 1;
+    pl.cap = cap;
+    pl.lds = scan_lds_bytes(h, cap);
+    if (pl.lds > 160 * 1024)
+        return fail(MMIDX_ERR_UNSUPPORTED, "lookup table of %d x %d doubles does not fit the 160 KiB LDS", h->m, h->ks);
+    const int ivf = h->kind == MMIDX_KIND_IVFPQ;
+    const int nprobe = ivf ? h->w : 1;
+    int64_t chunk = ivf ? 16384 : 32768;
+    const int64_t maxlen = std::max<int64_t>(h->max_list_len, 1);
+    pl.chunk = (int)chunk;
+    pl.nchunks = (int)((maxlen + chunk - 1) / chunk);
+    pl.nitems = nprobe * pl.nchunks;
+    // a work item emits at most K1 survivors, but no query can emit more than its candidates
+    int64_t poolq = (int64_t)pl.nitems * pl.K1;
+    pl.poolq = (int)std::min<int64_t>(poolq, std::max<int64_t>(h->n_csr, pl.K1));
+    // sub-batch so that the pool stays <= 2 GiB and the coarse matrix <= 1 GiB
+    int64_t qb = std::min<int64_t>(nq, 65535);
+    const int64_t pool_bytes_q = (int64_t)pl.poolq * 16;
+    qb = std::min<int64_t>(qb, std::max<int64_t>(1, (2ll << 30) / std::max<int64_t>(pool_bytes_q, 1)));
+    if (ivf) qb = std::min<int64_t>(qb, std::max<int64_t>(1, (1ll << 30) / ((int64_t)h->C * 8)));
+    pl.qb = qb;
+    return MMIDX_OK;
+}
+
+int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, hipStream_t st) {
+    constexpr int QT = 8;
+    HIPCK(h->ws_cdist.reserve((size_t)nq * h->C));
+    dim3 g1((unsigned)((h->C + MMIDX_BLOCK - 1) / MMIDX_BLOCK), (unsigned)((nq + QT - 1) / QT));
+    hipLaunchKernelGGL(k_coarse_dist<QT>, g1, dim3(MMIDX_BLOCK), 0, st, h->d_coarseT, dQ, h->ws_cdist.p, h->C, h->D, (int)nq);
+    const size_t lds = (size_t)(h->w + 1) * 12 + 16;
+    if (lds > 64 * 1024) return fail(MMIDX_ERR_UNSUPPORTED, "w = %d too large", h->w);
+    hipLaunchKernelGGL(k_coarse_select, dim3((unsigned)nq), dim3(MMIDX_BLOCK), lds, st, h->ws_cdist.p, h->C, h->w, d_cells);
+    HIPCK(hipGetLastError());
+    return MMIDX_OK;
+}
+
+// one sub-batch (nq <= plan.qb) entirely on device
+int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq, const double *dQ, const int32_t *d_cells_in,
+                        int mode, int32_t *d_iid, double *d_dist, int32_t *d_cnt, double *d_pdist, long long *d_pkey,
+                        hipStream_t st) {
+    const int ivf = h->kind == MMIDX_KIND_IVFPQ;
+    const bool prof = h->profiling;
+    if (prof) HIPCK(hipEventRecord(h->ev[0], st));
+    const int32_t *d_cells = d_cells_in;
+    if (ivf && !d_cells) {
+        HIPCK(h->ws_cells.reserve((size_t)nq * h->w));
+        int rc = run_coarse(h, nq, dQ, h->ws_cells.p, st);
+        if (rc) return rc;
+        d_cells = h->ws_cells.p;
+    }
+    if (prof) HIPCK(hipEventRecord(h->ev[1], st));
+    HIPCK(h->ws_T.reserve((size_t)nq));
+    HIPCK(h->ws_pcnt.reserve((size_t)nq));
+    HIPCK(h->ws_pkey.reserve((size_t)nq * pl.poolq));
+    HIPCK(h->ws_pval.reserve((size_t)nq * pl.poolq));
+    HIPCK(h->ws_flag.reserve((size_t)nq));
+    HIPCK(hipMemsetAsync(h->ws_T.p, 0xFF, (size_t)nq * sizeof(u64), st));
+    HIPCK(hipMemsetAsync(h->ws_pcnt.p, 0, (size_t)nq * sizeof(u32), st));
+
+    ScanParams P{};
+    P.Q = dQ;
+    P.coarse = h->d_coarse;
+    P.pqT = h->d_pqT;
+    P.perm = h->d_perm;
+    P.rot = h->d_rot;
+    P.cells = ivf ? d_cells : nullptr;
+    P.list_off = h->d_off;
+    P.codes = h->d_codes;
+    P.T = h->ws_T.p;
+    P.pool_cnt = h->ws_pcnt.p;
+    P.pool_key = h->ws_pkey.p;
+    P.pool_val = h->ws_pval.p;
+    P.D = h->D;
+    P.m = h->m;
+    P.ks = h->ks;
+    P.dsub = h->dsub;
+    P.w = ivf ? h->w : 1;
+    P.transform = h->transform;
+    P.ivf = ivf;
+    P.chunk = pl.chunk;
+    P.K1 = pl.K1;
+    P.cap = pl.cap;
+    P.poolq = pl.poolq;
+    if (h->n_csr > 0) {
+        dim3 grid((unsigned)pl.nchunks, (unsigned)P.w, (unsigned)nq);
+        if (prof) HIPCK(hipEventRecord(h->ev[2], st));
+        int rc = launch_scan(h, P, grid, pl.lds, st);
+        if (rc) return rc;
+        if (prof) HIPCK(hipEventRecord(h->ev[3], st));
+    }
+    MergeParams M{};
+    M.pool_cnt = h->ws_pcnt.p;
+    M.pool_key = h->ws_pkey.p;
+    M.pool_val = h->ws_pval.p;
+    M.poolq = pl.poolq;
+    M.cells = ivf ? d_cells : nullptr;
+    M.list_off = h->d_off;
+    M.ids = h->d_ids;
+    M.w = P.w;
+    M.k = k;
+    M.mode = mode;
+    M.iid_out = d_iid;
+    M.dist_out = d_dist;
+    M.count_out = d_cnt;
+    M.flag_out = h->ws_flag.p;
+    M.pdist = d_pdist;
+    M.pkey = d_pkey;
+    const size_t mlds = (size_t)MMIDX_MCAP * 16;
+    HIPCK(hipFuncSetAttribute((const void *)k_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+    hipLaunchKernelGGL(k_merge, dim3((unsigned)nq), dim3(MMIDX_BLOCK), mlds, st, M);
+    HIPCK(hipGetLastError());
+    if (mode == 0 && h->n_csr > 0) {
+        // exact replay for queries whose k-th / (k+1)-th distances tie (rare)
+        TieParams TP{};
+        TP.S = P;
+        TP.flag = h->ws_flag.p;
+        TP.ids = h->d_ids;
+        TP.iid_out = d_iid;
+        TP.dist_out = d_dist;
+        TP.k = k;
+        const size_t tlds = (size_t)h->m * h->ks * 8 + 2 * (size_t)h->D * 8;
+        if (h->code_bytes == 1) {
+            HIPCK(hipFuncSetAttribute((const void *)k_tie_resolve<unsigned char>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+            hipLaunchKernelGGL(k_tie_resolve<unsigned char>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), tlds, st, TP);
+        } else {
+            HIPCK(hipFuncSetAttribute((const void *)k_tie_resolve<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+            hipLaunchKernelGGL(k_tie_resolve<unsigned short>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), tlds, st, TP);
+        }
+        HIPCK(hipGetLastError());
+    }
+    if (prof) {
+        HIPCK(hipEventRecord(h->ev[4], st));
+        HIPCK(hipEventSynchronize(h->ev[4]));
+        float a = 0, b = 0, c = 0, t = 0;
+        HIPCK(hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
+        if (h->n_csr > 0) {
+            HIPCK(hipEventElapsedTime(&b, h->ev[2], h->ev[3]));
+            HIPCK(hipEventElapsedTime(&c, h->ev[3], h->ev[4]));
+        }
+        HIPCK(hipEventElapsedTime(&t, h->ev[0], h->ev[4]));
+        h->stats.coarse_ms += a;
+        h->stats.scan_ms += b;
+        h->stats.merge_ms += c;
+        h->stats.total_ms += t;
+        h->stats.scan_launches += (h->n_csr > 0) ? 1 : 0;
+        // algorithmic work: sum over (query, probed list) of list lengths
+        std::vector<int32_t> hc;
+        int64_t codes = 0;
+        if (ivf) {
+            hc.resize((size_t)nq * h->w);
+            HIPCK(hipMemcpy(hc.data(), d_cells, hc.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            for (int32_t c : hc)
+                if (c >= 0) codes += h->h_off[(size_t)c + 1] - h->h_off[(size_t)c];
+        } else {
+            codes = nq * h->n_csr;
+        }
+        h->stats.scan_codes += codes;
+        if (mode == 0) {
+            std::vector<int32_t> hf((size_t)nq);
+            HIPCK(hipMemcpy(hf.data(), h->ws_flag.p, hf.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            for (int32_t f : hf) h->stats.tie_fallbacks += f ? 1 : 0;
+        }
+    }
+    return MMIDX_OK;
+}
+
+int search_common(mmidx_index *h, int k, int64_t nq, const double *dQ, const int32_t *d_cells, int mode, int32_t *d_iid,
+                  double *d_dist, int32_t *d_cnt, double *d_pdist, long long *d_pkey, hipStream_t st) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (nq < 0) return fail(MMIDX_ERR_INVALID_ARG, "nq < 0");
+    const int ivf = h->kind == MMIDX_KIND_IVFPQ;
+    if (ivf && (h->w < 1 || h->w > h->C))
+        return fail(MMIDX_ERR_INVALID_ARG, "w = %d outside 1..%d (setW)", h->w, h->C);
+    rc = set_device(h);
+    if (rc) return rc;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        rc = build_csr(h);
+        if (rc) return rc;
+    }
+    SearchPlan pl;
+    rc = make_plan(h, k, nq, pl);
+    if (rc) return rc;
+    if (h->profiling) h->stats = mmidx_stats{};
+    for (int64_t q0 = 0; q0 < nq; q0 += pl.qb) {
+        const int64_t nb = std::min<int64_t>(pl.qb, nq - q0);
+        rc = search_batch_device(h, pl, k, nb, dQ + (size_t)q0 * h->D, d_cells ? d_cells + (size_t)q0 * h->w : nullptr, mode,
+                                 d_iid ? d_iid + (size_t)q0 * k : nullptr, d_dist ? d_dist + (size_t)q0 * k : nullptr,
+                                 d_cnt + q0, d_pdist ? d_pdist + (size_t)q0 * pl.K1 : nullptr,
+                                 d_pkey ? d_pkey + (size_t)q0 * pl.K1 : nullptr, st);
+        if (rc) return rc;
+    }
+    return MMIDX_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char *mmidx_last_error(void) { return g_err.c_str(); }
+int mmidx_abi_version(void) { return MMIDX_ABI_VERSION; }
+
+int mmidx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mmidx_create(int kind, int D, int m, int ks, int C, int transform, const int32_t *perm, const double *rot, int device,
+                 mmidx_index **out) {
+    if (!out) return fail(MMIDX_ERR_INVALID_ARG, "null out pointer");
+    *out = nullptr;
+    if (kind != MMIDX_KIND_PQ && kind != MMIDX_KIND_IVFPQ) return fail(MMIDX_ERR_INVALID_ARG, "unknown index kind %d", kind);
+    if (D < 1 || m < 1 || D % m > 0) return fail(MMIDX_ERR_INVALID_SUBVECTORS, "The given number of subvectors is not valid!");
+    if (ks < 1 || ks > 65536) return fail(MMIDX_ERR_UNSUPPORTED, "numProductCentroids %d outside 1..65536", ks);
+    if (kind == MMIDX_KIND_IVFPQ && C < 1) return fail(MMIDX_ERR_INVALID_ARG, "numCoarseCentroids must be >= 1");
+    if (transform < 0 || transform > 2) return fail(MMIDX_ERR_INVALID_ARG, "unknown transformation %d", transform);
+    if (transform == MMIDX_TR_ROTATION && !rot)
+        return fail(MMIDX_ERR_INVALID_ARG, "RandomRotation needs the D x D matrix computed by the Java side");
+    const int ndev = mmidx_device_count();
+    if (ndev < 1) return fail(MMIDX_ERR_NO_DEVICE, "no HIP device: libmmidx_hip has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(MMIDX_ERR_NO_DEVICE, "device %d outside 0..%d", device, ndev - 1);
+    HIPCK(hipSetDevice(device));
+    mmidx_index *h = new mmidx_index();
+    h->kind = kind;
+    h->D = D;
+    h->m = m;
+    h->ks = ks;
+    h->dsub = D / m;
+    h->C = kind == MMIDX_KIND_IVFPQ ? C : 0;
+    h->transform = transform;
+    h->w = (int)(C * 0.1);  // IVFPQ.java:188
+    h->device = device;
+    h->nlists = kind == MMIDX_KIND_IVFPQ ? C : 1;
+    h->code_bytes = ks <= 256 ? 1 : 2;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(MMIDX_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    for (auto &ev : h->ev) (void)hipEventCreate(&ev);
+    if (transform == MMIDX_TR_PERMUTATION) {
+        std::vector<int32_t> p((size_t)D);
+        if (perm) {
+            for (int i = 0; i < D; i++) {
+                if (perm[i] < 0 || perm[i] >= D) {
+                    mmidx_destroy(h);
+                    return fail(MMIDX_ERR_INVALID_ARG, "permutation index out of range");
+                }
+                p[(size_t)i] = perm[i];
+            }
+        } else {
+            jdk_random_permutation(1, D, p.data());  // seed = 1: IVFPQ.java:136, PQ.java:108
+        }
+        HIPCK(hipMalloc((void **)&h->d_perm, (size_t)D * sizeof(int32_t)));
+        HIPCK(hipMemcpy(h->d_perm, p.data(), (size_t)D * sizeof(int32_t), hipMemcpyHostToDevice));
+    } else if (transform == MMIDX_TR_ROTATION) {
+        HIPCK(hipMalloc((void **)&h->d_rot, (size_t)D * D * sizeof(double)));
+        HIPCK(hipMemcpy(h->d_rot, rot, (size_t)D * D * sizeof(double), hipMemcpyHostToDevice));
+    }
+    h->h_off.assign((size_t)h->nlists + 1, 0);
+    *out = h;
+    return MMIDX_OK;
+}
+
+int mmidx_destroy(mmidx_index *h) {
+    if (!h) return MMIDX_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void *ptrs[] = {h->d_coarse, h->d_coarseT, h->d_pq, h->d_pqT, h->d_rot, h->d_perm, h->d_off, h->d_codes,
+                    h->d_ids,    h->d_pcell,   h->d_pid, h->d_pcodes};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    h->ws_Q.release();
+    h->ws_cdist.release();
+    h->ws_odist.release();
+    h->ws_X.release();
+    h->ws_cells.release();
+    h->ws_oiid.release();
+    h->ws_ocnt.release();
+    h->ws_flag.release();
+    h->ws_ecell.release();
+    h->ws_T.release();
+    h->ws_pkey.release();
+    h->ws_pval.release();
+    h->ws_pcnt.release();
+    h->ws_ecode.release();
+    h->ws_tmp.release();
+    h->ws_dest.release();
+    for (auto &ev : h->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return MMIDX_OK;
+}
+
+int mmidx_set_coarse(mmidx_index *h, const double *coarse) {
+    if (!h || !coarse) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (h->kind != MMIDX_KIND_IVFPQ) return fail(MMIDX_ERR_INVALID_ARG, "PQ index has no coarse quantizer");
+    int rc = set_device(h);
+    if (rc) return rc;
+    const size_t n = (size_t)h->C * h->D;
+    std::vector<double> T(n);
+    for (int c = 0; c < h->C; c++)
+        for (int j = 0; j < h->D; j++) T[(size_t)j * h->C + c] = coarse[(size_t)c * h->D + j];
+    if (!h->d_coarse) HIPCK(hipMalloc((void **)&h->d_coarse, n * sizeof(double)));
+    if (!h->d_coarseT) HIPCK(hipMalloc((void **)&h->d_coarseT, n * sizeof(double)));
+    HIPCK(hipMemcpy(h->d_coarse, coarse, n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(h->d_coarseT, T.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    h->coarse_set = true;
+    return MMIDX_OK;
+}
+
+int mmidx_set_pq(mmidx_index *h, const double *pq) {
+    if (!h || !pq) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    int rc = set_device(h);
+    if (rc) return rc;
+    const size_t n = (size_t)h->m * h->ks * h->dsub;
+    std::vector<double> T(n);
+    for (int s = 0; s < h->m; s++)
+        for (int j = 0; j < h->ks; j++)
+            for (int t = 0; t < h->dsub; t++)
+                T[((size_t)s * h->dsub + t) * h->ks + j] = pq[((size_t)s * h->ks + j) * h->dsub + t];
+    if (!h->d_pq) HIPCK(hipMalloc((void **)&h->d_pq, n * sizeof(double)));
+    if (!h->d_pqT) HIPCK(hipMalloc((void **)&h->d_pqT, n * sizeof(double)));
+    HIPCK(hipMemcpy(h->d_pq, pq, n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(h->d_pqT, T.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    h->pq_set = true;
+    return MMIDX_OK;
+}
+
+int mmidx_set_w(mmidx_index *h, int w) {
+    if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    h->w = w;  // validated at search time, as the reference does (IVFPQ.java:95-97)
+    return MMIDX_OK;
+}
+int mmidx_get_w(const mmidx_index *h, int *w_out) {
+    if (!h || !w_out) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    *w_out = h->w;
+    return MMIDX_OK;
+}
+int mmidx_size(const mmidx_index *h, int64_t *n_out) {
+    if (!h || !n_out) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    *n_out = total_size(h);
+    return MMIDX_OK;
+}
+
+int mmidx_sync_index(mmidx_index *h) {
+    if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    int rc = set_device(h);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    return build_csr(h);
+}
+
+int mmidx_list_sizes(mmidx_index *h, int32_t *sizes_out) {
+    if (!h || !sizes_out) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    int rc = mmidx_sync_index(h);
+    if (rc) return rc;
+    for (int c = 0; c < h->nlists; c++) sizes_out[c] = (int32_t)(h->h_off[(size_t)c + 1] - h->h_off[(size_t)c]);
+    return MMIDX_OK;
+}
+
+int mmidx_encode_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_cell_out, void *d_code_out, void *stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!dX || !d_cell_out || !d_code_out))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    rc = set_device(h);
+    if (rc) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    if (n == 0) return MMIDX_OK;
+    if (h->code_bytes == 1) {
+        // kernels produce centroid indices; the boundary carries the stored form idx - 128
+        HIPCK(h->ws_tmp.reserve((size_t)n * h->m));
+        rc = encode_device(h, n, dX, d_cell_out, h->ws_tmp.p, st);
+        if (rc) return rc;
+        const long long tot = (long long)n * h->m;
+        hipLaunchKernelGGL(k_bias_codes, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->ws_tmp.p, (signed char *)d_code_out, tot);
+        HIPCK(hipGetLastError());
+        return MMIDX_OK;
+    }
+    return encode_device(h, n, dX, d_cell_out, d_code_out, st);
+}
+
+int mmidx_encode(mmidx_index *h, int64_t n, const double *X, int32_t *cell_out, void *code_out) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!X || !code_out))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (n == 0) return MMIDX_OK;
+    rc = set_device(h);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    const size_t cb = (size_t)h->m * h->code_bytes;
+    const int64_t B = 1 << 18;
+    for (int64_t i0 = 0; i0 < n; i0 += B) {
+        const int64_t nb = std::min(B, n - i0);
+        HIPCK(h->ws_X.reserve((size_t)nb * h->D));
+        HIPCK(h->ws_ecell.reserve((size_t)nb));
+        HIPCK(h->ws_ecode.reserve((size_t)nb * cb));
+        HIPCK(hipMemcpyAsync(h->ws_X.p, X + (size_t)i0 * h->D, (size_t)nb * h->D * 8, hipMemcpyHostToDevice, h->stream));
+        rc = mmidx_encode_device(h, nb, h->ws_X.p, h->ws_ecell.p, h->ws_ecode.p, h->stream);
+        if (rc) return rc;
+        if (cell_out) HIPCK(hipMemcpyAsync(cell_out + i0, h->ws_ecell.p, (size_t)nb * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(hipMemcpyAsync((char *)code_out + (size_t)i0 * cb, h->ws_ecode.p, (size_t)nb * cb, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(hipStreamSynchronize(h->stream));
+    }
+    return MMIDX_OK;
+}
+
+// append n device-resident records; codes in stored form (int8 biased / int16)
+int mmidx_add_codes_device(mmidx_index *h, int64_t n, const int32_t *d_iids, const int32_t *d_cells, const void *d_codes, void *stream) {
+    if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    if (n < 0 || (n > 0 && (!d_iids || !d_codes))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (h->kind == MMIDX_KIND_IVFPQ && n > 0 && !d_cells) return fail(MMIDX_ERR_INVALID_ARG, "IVFPQ needs list ids");
+    if (n == 0) return MMIDX_OK;
+    if (total_size(h) + n > 2147483647LL) return fail(MMIDX_ERR_CAPACITY, "Maximum index capacity reached, no more vectors can be indexed!");
+    int rc = set_device(h);
+    if (rc) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (st != h->stream) HIPCK(hipStreamSynchronize(st));
+    rc = ensure_pending(h, n);
+    if (rc) return rc;
+    const int64_t o = h->n_pend;
+    HIPCK(hipMemcpyAsync(h->d_pid + o, d_iids, (size_t)n * 4, hipMemcpyDeviceToDevice, h->stream));
+    if (h->kind == MMIDX_KIND_IVFPQ)
+        HIPCK(hipMemcpyAsync(h->d_pcell + o, d_cells, (size_t)n * 4, hipMemcpyDeviceToDevice, h->stream));
+    else
+        HIPCK(hipMemsetAsync(h->d_pcell + o, 0, (size_t)n * 4, h->stream));
+    const long long tot = (long long)n * h->m;
+    if (h->code_bytes == 1) {
+        hipLaunchKernelGGL(k_unbias_codes, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, (const signed char *)d_codes,
+                           (unsigned char *)h->d_pcodes + (size_t)o * h->m, tot);
+        HIPCK(hipGetLastError());
+    } else {
+        HIPCK(hipMemcpyAsync((char *)h->d_pcodes + (size_t)o * h->m * 2, d_codes, (size_t)tot * 2, hipMemcpyDeviceToDevice, h->stream));
+    }
+    HIPCK(hipStreamSynchronize(h->stream));
+    h->n_pend += n;
+    return MMIDX_OK;
+}
+
+int mmidx_add_codes(mmidx_index *h, int64_t n, const int32_t *iids, const int32_t *cells, const void *codes) {
+    if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    if (n < 0 || (n > 0 && (!iids || !codes))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (h->kind == MMIDX_KIND_IVFPQ && n > 0 && !cells) return fail(MMIDX_ERR_INVALID_ARG, "IVFPQ needs list ids");
+    if (n == 0) return MMIDX_OK;
+    if (h->kind == MMIDX_KIND_IVFPQ)
+        for (int64_t i = 0; i < n; i++)
+            if (cells[i] < 0 || cells[i] >= h->C) return fail(MMIDX_ERR_INVALID_ARG, "list id %d outside 0..%d", cells[i], h->C - 1);
+    int rc = set_device(h);
+    if (rc) return rc;
+    const size_t cb = (size_t)h->m * h->code_bytes;
+    int32_t *d_i = nullptr, *d_c = nullptr;
+    void *d_k = nullptr;
+    HIPCK(hipMalloc((void **)&d_i, (size_t)n * 4));
+    HIPCK(hipMalloc((void **)&d_c, (size_t)n * 4));
+    HIPCK(hipMalloc(&d_k, (size_t)n * cb));
+    HIPCK(hipMemcpy(d_i, iids, (size_t)n * 4, hipMemcpyHostToDevice));
+    if (cells) HIPCK(hipMemcpy(d_c, cells, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(d_k, codes, (size_t)n * cb, hipMemcpyHostToDevice));
+    rc = mmidx_add_codes_device(h, n, d_i, cells ? d_c : nullptr, d_k, nullptr);
+    (void)hipFree(d_i);
+    (void)hipFree(d_c);
+    (void)hipFree(d_k);
+    return rc;
+}
+
+int mmidx_add_vectors_device(mmidx_index *h, int64_t n, const double *dX, const int32_t *d_iids, int32_t iid0, void *stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && !dX)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (n == 0) return MMIDX_OK;
+    if (total_size(h) + n > 2147483647LL) return fail(MMIDX_ERR_CAPACITY, "Maximum index capacity reached, no more vectors can be indexed!");
+    rc = set_device(h);
+    if (rc) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (st != h->stream) HIPCK(hipStreamSynchronize(st));
+    rc = ensure_pending(h, n);
+    if (rc) return rc;
+    const int64_t o = h->n_pend;
+    rc = encode_device(h, n, dX, h->d_pcell + o, (char *)h->d_pcodes + (size_t)o * h->m * h->code_bytes, h->stream);
+    if (rc) return rc;
+    if (h->kind == MMIDX_KIND_PQ) HIPCK(hipMemsetAsync(h->d_pcell + o, 0, (size_t)n * 4, h->stream));
+    if (d_iids)
+        HIPCK(hipMemcpyAsync(h->d_pid + o, d_iids, (size_t)n * 4, hipMemcpyDeviceToDevice, h->stream));
+    else
+        hipLaunchKernelGGL(k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_pid + o, iid0, (long long)n);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(h->stream));
+    h->n_pend += n;
+    return MMIDX_OK;
+}
+
+int mmidx_add_vectors(mmidx_index *h, int64_t n, const double *X, const int32_t *iids, int32_t *cell_out, void *code_out) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && !X)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (n == 0) return MMIDX_OK;
+    rc = set_device(h);
+    if (rc) return rc;
+    const size_t cb = (size_t)h->m * h->code_bytes;
+    const int64_t B = 1 << 18;
+    for (int64_t i0 = 0; i0 < n; i0 += B) {
+        const int64_t nb = std::min(B, n - i0);
+        double *dX = nullptr;
+        int32_t *d_i = nullptr;
+        HIPCK(hipMalloc((void **)&dX, (size_t)nb * h->D * 8));
+        HIPCK(hipMemcpy(dX, X + (size_t)i0 * h->D, (size_t)nb * h->D * 8, hipMemcpyHostToDevice));
+        if (iids) {
+            HIPCK(hipMalloc((void **)&d_i, (size_t)nb * 4));
+            HIPCK(hipMemcpy(d_i, iids + i0, (size_t)nb * 4, hipMemcpyHostToDevice));
+        }
+        const int64_t o = h->n_pend;
+        rc = mmidx_add_vectors_device(h, nb, dX, d_i, (int32_t)total_size(h), nullptr);
+        if (!rc && cell_out) {
+            if (h->kind == MMIDX_KIND_IVFPQ) HIPCK(hipMemcpy(cell_out + i0, h->d_pcell + o, (size_t)nb * 4, hipMemcpyDeviceToHost));
+            else std::fill(cell_out + i0, cell_out + i0 + nb, -1);
+        }
+        if (!rc && code_out) {
+            HIPCK(hipMemcpy((char *)code_out + (size_t)i0 * cb, (char *)h->d_pcodes + (size_t)o * cb, (size_t)nb * cb, hipMemcpyDeviceToHost));
+            if (h->code_bytes == 1) {  // stored form idx - 128 (PQ.java:555)
+                signed char *c = (signed char *)code_out + (size_t)i0 * cb;
+                for (size_t t = 0; t < (size_t)nb * cb; t++) c[t] = (signed char)((int)(unsigned char)c[t] - 128);
+            }
+        }
+        (void)hipFree(dX);
+        if (d_i) (void)hipFree(d_i);
+        if (rc) return rc;
+    }
+    return MMIDX_OK;
+}
+
+int mmidx_search_device(mmidx_index *h, int k, int64_t nq, const double *dQ, int32_t *d_iid_out, double *d_dist_out,
+                        int32_t *d_count_out, void *stream) {
+    if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    if (nq > 0 && (!dQ || !d_iid_out || !d_dist_out || !d_count_out)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    return search_common(h, k, nq, dQ, nullptr, 0, d_iid_out, d_dist_out, d_count_out, nullptr, nullptr, st);
+}
+
+int mmidx_search(mmidx_index *h, int k, int64_t nq, const double *Q, int32_t *iid_out, double *dist_out, int32_t *count_out) {
+    if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    if (nq > 0 && (!Q || !iid_out || !dist_out || !count_out)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (k < 1 || k > 1023) return fail(MMIDX_ERR_INVALID_ARG, "k must be in 1..1023 (got %d)", k);
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (nq == 0) return MMIDX_OK;
+    rc = set_device(h);
+    if (rc) return rc;
+    HIPCK(h->ws_Q.reserve((size_t)nq * h->D));
+    HIPCK(h->ws_oiid.reserve((size_t)nq * k));
+    HIPCK(h->ws_odist.reserve((size_t)nq * k));
+    HIPCK(h->ws_ocnt.reserve((size_t)nq));
+    HIPCK(hipMemcpyAsync(h->ws_Q.p, Q, (size_t)nq * h->D * 8, hipMemcpyHostToDevice, h->stream));
+    rc = search_common(h, k, nq, h->ws_Q.p, nullptr, 0, h->ws_oiid.p, h->ws_odist.p, h->ws_ocnt.p, nullptr, nullptr, h->stream);
+    if (rc) return rc;
+    HIPCK(hipMemcpyAsync(iid_out, h->ws_oiid.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipMemcpyAsync(dist_out, h->ws_odist.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipMemcpyAsync(count_out, h->ws_ocnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    return MMIDX_OK;
+}
+
+int mmidx_coarse_device(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells_out, void *stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (h->kind != MMIDX_KIND_IVFPQ) return fail(MMIDX_ERR_INVALID_ARG, "PQ index has no coarse quantizer");
+    if (h->w < 1 || h->w > h->C) return fail(MMIDX_ERR_INVALID_ARG, "w = %d outside 1..%d (setW)", h->w, h->C);
+    if (nq > 0 && (!dQ || !d_cells_out)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    rc = set_device(h);
+    if (rc) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    const int64_t qb = std::max<int64_t>(1, (1ll << 30) / ((int64_t)h->C * 8));
+    for (int64_t q0 = 0; q0 < nq; q0 += qb) {
+        const int64_t nb = std::min(qb, nq - q0);
+        rc = run_coarse(h, nb, dQ + (size_t)q0 * h->D, d_cells_out + (size_t)q0 * h->w, st);
+        if (rc) return rc;
+    }
+    return MMIDX_OK;
+}
+
+int mmidx_search_partial_device(mmidx_index *h, int k, int64_t nq, const double *dQ, const int32_t *d_cells, double *d_pdist,
+                                int64_t *d_pkey, int32_t *d_pcount, void *stream) {
+    if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    if (nq > 0 && (!dQ || !d_pdist || !d_pkey || !d_pcount)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (h->kind == MMIDX_KIND_IVFPQ && nq > 0 && !d_cells) return fail(MMIDX_ERR_INVALID_ARG, "IVFPQ partial search needs the probe cells");
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    return search_common(h, k, nq, dQ, h->kind == MMIDX_KIND_IVFPQ ? d_cells : nullptr, 1, nullptr, nullptr, d_pcount, d_pdist,
+                         (long long *)d_pkey, st);
+}
+
+int mmidx_merge_partials_device(int device, int k, int64_t nq, int nshards, const double *d_pdist, const int64_t *d_pkey,
+                                const int32_t *d_pcount, int32_t *d_iid_out, double *d_dist_out, int32_t *d_count_out, void *stream) {
+    if (k < 1 || k > 1023) return fail(MMIDX_ERR_INVALID_ARG, "k must be in 1..1023 (got %d)", k);
+    if (nshards < 1 || nq < 0) return fail(MMIDX_ERR_INVALID_ARG, "bad shard / query count");
+    if (nq > 0 && (!d_pdist || !d_pkey || !d_pcount || !d_iid_out || !d_dist_out || !d_count_out))
+        return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (mmidx_device_count() < 1) return fail(MMIDX_ERR_NO_DEVICE, "no HIP device: libmmidx_hip has no CPU fallback");
+    if (nq == 0) return MMIDX_OK;
+    HIPCK(hipSetDevice(device));
+    const size_t mlds = (size_t)MMIDX_MCAP * 16;
+    HIPCK(hipFuncSetAttribute((const void *)k_merge_partials, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+    hipLaunchKernelGGL(k_merge_partials, dim3((unsigned)nq), dim3(MMIDX_BLOCK), mlds, (hipStream_t)stream, k, (int)nq, nshards, d_pdist,
+                       (const long long *)d_pkey, d_pcount, d_iid_out, d_dist_out, d_count_out);
+    HIPCK(hipGetLastError());
+    return MMIDX_OK;
+}
+
+int mmidx_set_profiling(mmidx_index *h, int enabled) {
+    if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    h->profiling = enabled != 0;
+    h->stats = mmidx_stats{};
+    return MMIDX_OK;
+}
+int mmidx_get_stats(mmidx_index *h, mmidx_stats *out) {
+    if (!h || !out) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    *out = h->stats;
+    return MMIDX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,988 @@
+// mmidx_kernels.h -- gfx950 (MI355X / CDNA4) device kernels of the PQ / IVFPQ search path.
+//
+// Everything here computes in IEEE binary64 in the reference's left-to-right order (build with
+// -ffp-contract=off): the returned distances are bit-equal to the Java arithmetic of
+//   J/datastructures/IVFPQ.java:408-450, :525-538, :547-601, :613-648 and
+//   J/datastructures/PQ.java:290-322, :387-429          (J/ = src/main/java/gr/iti/mklab/visual/)
+// Distances are non-negative sums of squares, so their binary64 bit patterns order exactly like
+// the values; kernels compare / sort them as u64 keys.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+#define MMIDX_BLOCK 256
+#define MMIDX_KEY_MAX 0xFFFFFFFFFFFFFFFFull
+
+__device__ __forceinline__ u64 dkey(double d) { return (u64)__double_as_longlong(d); }
+__device__ __forceinline__ double keyd(u64 k) { return __longlong_as_double((long long)k); }
+
+// ------------------------------------------------------------------------------------------------
+// Block-wide bitonic sort of (key, val) pairs held in LDS, ascending by (key, val).  n must be a
+// power of two; every thread of the block must call it.
+// ------------------------------------------------------------------------------------------------
+template <typename V>
+__device__ __forceinline__ void block_bitonic_sort(u64 *key, V *val, int n) {
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < (n >> 1); t += blockDim.x) {
+                int lo = 2 * t - (t & (stride - 1));  // index with the `stride` bit clear
+                int hi = lo + stride;
+                bool up = ((lo & size) == 0);
+                u64 ka = key[lo], kb = key[hi];
+                V va = val[lo], vb = val[hi];
+                bool gt = (ka > kb) || (ka == kb && va > vb);
+                if (gt == up) {
+                    key[lo] = kb;
+                    key[hi] = ka;
+                    val[lo] = vb;
+                    val[hi] = va;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ int pow2ceil(int n) {
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1a: coarse distances.  dist[q][c] = sum_j (coarse[c][j] - Q[q][j])^2, j ascending
+// (computeNearestCoarseIndices IVFPQ.java:579-588; the early-abandon at :584 only skips
+// candidates the bounded queue would reject, so the full sum is equivalent).
+// One thread per centroid (coalesced over the transposed table), QT queries per block; the
+// query values are wave-uniform and travel through scalar loads.
+// ------------------------------------------------------------------------------------------------
+template <int QT>
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_dist(const double *__restrict__ coarseT,
+                                                             const double *__restrict__ Q,
+                                                             double *__restrict__ out, int C, int D,
+                                                             int nq) {
+    const int c = blockIdx.x * MMIDX_BLOCK + threadIdx.x;
+    const int q0 = blockIdx.y * QT;
+    const int cc = c < C ? c : C - 1;
+    double acc[QT];
+#pragma unroll
+    for (int t = 0; t < QT; t++) acc[t] = 0.0;
+    for (int j = 0; j < D; j++) {
+        const double cj = coarseT[(size_t)j * C + cc];
+#pragma unroll
+        for (int t = 0; t < QT; t++) {
+            const int q = (q0 + t < nq) ? q0 + t : nq - 1;
+            const double df = cj - Q[(size_t)q * D + j];
+            acc[t] += df * df;
+        }
+    }
+    if (c < C) {
+#pragma unroll
+        for (int t = 0; t < QT; t++)
+            if (q0 + t < nq) out[(size_t)(q0 + t) * C + c] = acc[t];
+    }
+}
+
+// lexicographic (key, idx) min across the block; result broadcast to every thread
+__device__ __forceinline__ void block_min_pair(u64 &k, int &i, u64 *s_k, int *s_i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        u64 ok = __shfl_xor(k, off);
+        int oi = __shfl_xor(i, off);
+        if (ok < k || (ok == k && oi < i)) {
+            k = ok;
+            i = oi;
+        }
+    }
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();  // protect s_k / s_i reuse
+    if ((threadIdx.x & 63) == 0) {
+        s_k[wave] = k;
+        s_i[wave] = i;
+    }
+    __syncthreads();
+    k = s_k[0];
+    i = s_i[0];
+    for (int wv = 1; wv < (int)(blockDim.x >> 6); wv++) {
+        u64 ok = s_k[wv];
+        int oi = s_i[wv];
+        if (ok < k || (ok == k && oi < i)) {
+            k = ok;
+            i = oi;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1b: top-w selection with the bounded queue's semantics (IVFPQ.java:576-600; LingPipe queue,
+// assumption A1).  One block per query.  w+1 rounds of lexicographic (dist, index) argmin give
+// the sorted head; a tie straddling position w is resolved by the queue's closed form (see
+// DESIGN.md "bounded queue"): with tau the w-th distance, p = ties among the first w arrivals
+// with d <= tau, e = (#d < tau) - (w - p); kept ties are those with tie rank e..p-1 in arrival
+// (= index) order.  Output nearest first; equal distances later-arrival first.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select(const double *__restrict__ dist, int C,
+                                                               int w, int32_t *__restrict__ cells) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *sel_k = (u64 *)smem;                   // [w+1]
+    int *sel_i = (int *)(sel_k + (w + 1));      // [w+1]
+    __shared__ u64 s_k[MMIDX_BLOCK / 64];
+    __shared__ int s_i[MMIDX_BLOCK / 64];
+    const int q = blockIdx.x;
+    const double *row = dist + (size_t)q * C;
+    const int rounds = (w + 1 < C) ? w + 1 : C;
+    u64 lastk = 0;
+    int lasti = -1;
+    for (int r = 0; r < rounds; r++) {
+        u64 bk = MMIDX_KEY_MAX;
+        int bi = 0x7fffffff;
+        for (int c = threadIdx.x; c < C; c += MMIDX_BLOCK) {
+            const u64 k = dkey(row[c]);
+            const bool elig = (k > lastk) || (k == lastk && c > lasti);
+            if (elig && (k < bk || (k == bk && c < bi))) {
+                bk = k;
+                bi = c;
+            }
+        }
+        block_min_pair(bk, bi, s_k, s_i);
+        lastk = bk;
+        lasti = bi;
+        if (threadIdx.x == 0) {
+            sel_k[r] = bk;
+            sel_i[r] = bi;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t *out = cells + (size_t)q * w;
+        int n = rounds < w ? rounds : w;
+        if (rounds == w + 1 && sel_k[w - 1] == sel_k[w]) {
+            // tie straddles the boundary: closed-form replay of the bounded queue
+            const u64 tau = sel_k[w - 1];
+            int b = 0;
+            while (b < w && sel_k[b] < tau) b++;
+            int nonjunk = 0, p = 0;
+            for (int c = 0; c < C; c++) {
+                const u64 k = dkey(row[c]);
+                if (k <= tau) {
+                    nonjunk++;
+                    if (k == tau) p++;
+                    if (nonjunk == w) break;
+                }
+            }
+            const int e = b - (w - p);
+            int rank = 0, pos = b;
+            for (int c = 0; c < C && rank < p; c++) {
+                if (dkey(row[c]) == tau) {
+                    if (rank >= e) sel_i[pos++] = c;  // kept ties, arrival order
+                    rank++;
+                }
+            }
+        }
+        // emit nearest first; inside a run of equal distances later arrival (larger index) first
+        int a = 0;
+        while (a < n) {
+            int bnd = a;
+            while (bnd + 1 < n && sel_k[bnd + 1] == sel_k[a]) bnd++;
+            for (int t = a; t <= bnd; t++) out[t] = sel_i[bnd - (t - a)];
+            a = bnd + 1;
+        }
+        for (int t = n; t < w; t++) out[t] = -1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 + K3: per (query, probe, chunk) work item: residual -> transform -> ADC lookup table in LDS
+// -> coalesced scan of the list's PQ codes -> threshold-filtered candidate buffer.
+//
+//   residual  r = centroid - q                    computeResidualVector IVFPQ.java:642-648
+//   transform permute / rotate                    IVFPQ.java:420-424, PQ.java:294-298
+//   LUT[s][j] = sum_t (r[s*dsub+t]-pq[s][j][t])^2  computeLookupADC IVFPQ.java:525-538
+//   d(code)   = sum_s LUT[s][code[s]], s ascending IVFPQ.java:435-438 / PQ.java:308-311
+//
+// Candidates: the bounded queue (IVFPQ.java:445) is replaced by an exact selection.  Each query
+// owns a global threshold T (u64 bits of a distance that is provably >= its (k+1)-th smallest
+// candidate distance); a code survives when d <= T.  Survivors go to a block-local LDS buffer,
+// which is pruned to the K1 = k+1 smallest by (distance, position) when it fills; every prune
+// publishes a tighter T with atomicMin.  At the end the block appends its <= K1 survivors to the
+// query's pool; k_merge sorts the pool.  Stale T only costs work, never correctness.
+// ------------------------------------------------------------------------------------------------
+struct ScanParams {
+    const double *Q;         // [nq][D]
+    const double *coarse;    // [C][D] (IVFPQ)
+    const double *pqT;       // [m][dsub][ks]
+    const int32_t *perm;     // [D] or null
+    const double *rot;       // [D][D] or null
+    const int32_t *cells;    // [nq][w] (IVFPQ) or null (PQ)
+    const int64_t *list_off; // [nlists+1]
+    const void *codes;       // [n][m] CodeT
+    u64 *T;                  // [nq]
+    u32 *pool_cnt;           // [nq]
+    u64 *pool_key;           // [nq][poolq]
+    u64 *pool_val;           // [nq][poolq]  probe_rank << 32 | position in list
+    int D, m, ks, dsub, w, transform, ivf;
+    int chunk;               // codes per work item
+    int K1;                  // k + 1
+    int cap;                 // LDS candidate capacity (power of two, >= K1 + SEG)
+    int poolq;
+};
+
+#define MMIDX_SEGU 4  // codes per thread per segment
+#define MMIDX_SEG (MMIDX_BLOCK * MMIDX_SEGU)
+
+template <int M, typename CodeT>
+struct CodeVec {
+    static constexpr int BYTES = M * (int)sizeof(CodeT);
+    static constexpr int WORDS = (BYTES + 3) / 4;
+    u32 wd[WORDS];
+    __device__ __forceinline__ void load(const CodeT *p) {
+        if constexpr (BYTES % 16 == 0) {
+            const uint4 *s = (const uint4 *)p;
+#pragma unroll
+            for (int i = 0; i < BYTES / 16; i++) {
+                uint4 v = s[i];
+                wd[4 * i] = v.x;
+                wd[4 * i + 1] = v.y;
+                wd[4 * i + 2] = v.z;
+                wd[4 * i + 3] = v.w;
+            }
+        } else if constexpr (BYTES % 8 == 0) {
+            const uint2 *s = (const uint2 *)p;
+#pragma unroll
+            for (int i = 0; i < BYTES / 8; i++) {
+                uint2 v = s[i];
+                wd[2 * i] = v.x;
+                wd[2 * i + 1] = v.y;
+            }
+        } else if constexpr (BYTES % 4 == 0) {
+            const u32 *s = (const u32 *)p;
+#pragma unroll
+            for (int i = 0; i < BYTES / 4; i++) wd[i] = s[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < WORDS; i++) wd[i] = 0;
+            const unsigned char *s = (const unsigned char *)p;
+#pragma unroll
+            for (int i = 0; i < BYTES; i++) wd[i >> 2] |= (u32)s[i] << (8 * (i & 3));
+        }
+    }
+    __device__ __forceinline__ int get(int s) const {
+        if constexpr (sizeof(CodeT) == 1) return (wd[s >> 2] >> (8 * (s & 3))) & 0xff;
+        else return (wd[s >> 1] >> (16 * (s & 1))) & 0xffff;
+    }
+};
+
+// prune the block's candidate buffer to the K1 smallest by (key, position); publishes T
+__device__ __forceinline__ void scan_prune(u64 *bkey, u32 *bval, u32 *s_cnt, int K1, u64 *Tq) {
+    __syncthreads();
+    const int n = (int)*s_cnt;
+    const int P = pow2ceil(n < 2 ? 2 : n);
+    for (int i = n + threadIdx.x; i < P; i += blockDim.x) {
+        bkey[i] = MMIDX_KEY_MAX;
+        bval[i] = 0xFFFFFFFFu;
+    }
+    block_bitonic_sort<u32>(bkey, bval, P);
+    if (threadIdx.x == 0) {
+        if (n >= K1) {
+            *s_cnt = (u32)K1;
+            atomicMin(Tq, bkey[K1 - 1]);
+        }
+    }
+    __syncthreads();
+}
+
+template <int M, typename CodeT>
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_scan(const ScanParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int m = (M > 0) ? M : P.m;
+    const int ks = P.ks, D = P.D, dsub = P.dsub;
+    double *lut = (double *)smem;                 // [m*ks]
+    double *vec = lut + (size_t)m * ks;           // [2*D]
+    u64 *bkey = (u64 *)(vec + 2 * (size_t)D);     // [cap]
+    u32 *bval = (u32 *)(bkey + P.cap);            // [cap]
+    u32 *s_cnt = bval + P.cap;                    // [4]
+
+    const int q = blockIdx.z, pr = blockIdx.y, ch = blockIdx.x;
+    int cell = 0;
+    if (P.ivf) {
+        cell = P.cells[(size_t)q * P.w + pr];
+        if (cell < 0) return;
+    }
+    const int64_t beg = P.list_off[cell];
+    const int64_t len = P.list_off[cell + 1] - beg;
+    const int64_t c0 = (int64_t)ch * P.chunk;
+    if (c0 >= len) return;
+    const int64_t c1 = (c0 + P.chunk < len) ? c0 + P.chunk : len;
+    const int tid = threadIdx.x;
+
+    // ---- residual + transform --------------------------------------------------------------
+    double *r = vec, *tr = vec + D;
+    for (int i = tid; i < D; i += MMIDX_BLOCK) {
+        const double qv = P.Q[(size_t)q * D + i];
+        r[i] = P.ivf ? (P.coarse[(size_t)cell * D + i] - qv) : qv;
+    }
+    if (tid == 0) s_cnt[0] = 0;
+    __syncthreads();
+    if (P.transform == 2) {
+        for (int i = tid; i < D; i += MMIDX_BLOCK) tr[i] = r[P.perm[i]];
+        __syncthreads();
+    } else if (P.transform == 1) {
+        for (int j = tid; j < D; j += MMIDX_BLOCK) {
+            double total = 0.0;
+            for (int i = 0; i < D; i++) total += r[i] * P.rot[(size_t)i * D + j];
+            tr[j] = total;
+        }
+        __syncthreads();
+    } else {
+        tr = r;
+    }
+    // ---- lookup table ------------------------------------------------------------------------
+    for (int idx = tid; idx < m * ks; idx += MMIDX_BLOCK) {
+        const int s = idx / ks, j = idx - s * ks;
+        const double *pp = P.pqT + (size_t)s * dsub * ks + j;
+        const double *tv = tr + s * dsub;
+        double acc = 0.0;
+        for (int t = 0; t < dsub; t++) {
+            const double df = tv[t] - pp[(size_t)t * ks];
+            acc += df * df;
+        }
+        lut[idx] = acc;
+    }
+    u64 *Tq = P.T + q;
+    u64 T = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+
+    // ---- scan -----------------------------------------------------------------------------------
+    const CodeT *codes = (const CodeT *)P.codes + (size_t)beg * m;
+    const int limit = P.cap - MMIDX_SEG;
+    const u64 lane_lt = (1ull << (tid & 63)) - 1ull;
+    for (int64_t seg = c0; seg < c1; seg += MMIDX_SEG) {
+        double d[MMIDX_SEGU];
+        bool valid[MMIDX_SEGU];
+        if constexpr (M > 0) {
+            CodeVec<M, CodeT> cv[MMIDX_SEGU];
+#pragma unroll
+            for (int u = 0; u < MMIDX_SEGU; u++) {
+                const int64_t i = seg + u * MMIDX_BLOCK + tid;
+                valid[u] = i < c1;
+                const int64_t ii = valid[u] ? i : c1 - 1;
+                cv[u].load(codes + (size_t)ii * M);
+            }
+#pragma unroll
+            for (int u = 0; u < MMIDX_SEGU; u++) d[u] = 0.0;
+#pragma unroll
+            for (int s = 0; s < M; s++) {
+#pragma unroll
+                for (int u = 0; u < MMIDX_SEGU; u++) d[u] += lut[s * ks + cv[u].get(s)];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < MMIDX_SEGU; u++) {
+                const int64_t i = seg + u * MMIDX_BLOCK + tid;
+                valid[u] = i < c1;
+                const int64_t ii = valid[u] ? i : c1 - 1;
+                const CodeT *cp = codes + (size_t)ii * m;
+                double a = 0.0;
+                for (int s = 0; s < m; s++) a += lut[s * ks + (int)cp[s]];
+                d[u] = a;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < MMIDX_SEGU; u++) {
+            const u64 key = dkey(d[u]);
+            const bool pass = valid[u] && key <= T;
+            const u64 mask = __ballot(pass);
+            if (mask) {
+                u32 base = 0;
+                const int leader = __ffsll((long long)mask) - 1;
+                if ((tid & 63) == leader) base = atomicAdd(s_cnt, (u32)__popcll(mask));
+                base = __shfl(base, leader);
+                if (pass) {
+                    const u32 slot = base + (u32)__popcll(mask & lane_lt);
+                    bkey[slot] = key;
+                    bval[slot] = (u32)(seg + u * MMIDX_BLOCK + tid);
+                }
+            }
+        }
+        __syncthreads();
+        const bool need = (int)*s_cnt > limit;  // uniform: nobody writes s_cnt until the barrier below
+        __syncthreads();
+        if (need) {
+            scan_prune(bkey, bval, s_cnt, P.K1, Tq);
+            T = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // ---- hand the survivors to the query's pool ------------------------------------------------
+    __syncthreads();
+    if ((int)*s_cnt > P.K1) scan_prune(bkey, bval, s_cnt, P.K1, Tq);
+    T = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int n = (int)*s_cnt;
+    for (int base0 = 0; base0 < n; base0 += MMIDX_BLOCK) {
+        const int i = base0 + tid;
+        const bool pass = (i < n) && bkey[i] <= T;
+        const u64 mask = __ballot(pass);
+        if (mask) {
+            u32 base = 0;
+            const int leader = __ffsll((long long)mask) - 1;
+            if ((tid & 63) == leader) base = atomicAdd(P.pool_cnt + q, (u32)__popcll(mask));
+            base = __shfl(base, leader);
+            if (pass) {
+                const u32 slot = base + (u32)__popcll(mask & lane_lt);
+                if (slot < (u32)P.poolq) {
+                    P.pool_key[(size_t)q * P.poolq + slot] = bkey[i];
+                    P.pool_val[(size_t)q * P.poolq + slot] = ((u64)pr << 32) | (u64)bval[i];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: per-query merge of the candidate pool: exact k+1 smallest by (distance, offer order), then
+// ASS.lookUp order (ASS:345-358): ascending distance, equal distances later-offered first.
+// mode 0: final results (iid / dist / count / tie flag); mode 1: sorted partial list for the
+// cross-shard merge (pdist, pkey = probe_rank << 32 | iid, pcount).
+// ------------------------------------------------------------------------------------------------
+#define MMIDX_MCAP 4096
+struct MergeParams {
+    const u32 *pool_cnt;
+    const u64 *pool_key;
+    const u64 *pool_val;
+    int poolq;
+    const int32_t *cells;    // [nq][w] or null
+    const int64_t *list_off;
+    const int32_t *ids;
+    int w, k, mode;
+    int32_t *iid_out;        // [nq][k]
+    double *dist_out;        // [nq][k]
+    int32_t *count_out;      // [nq]
+    int32_t *flag_out;       // [nq] tie straddles k (mode 0)
+    double *pdist;           // [nq][k+1] (mode 1)
+    long long *pkey;         // [nq][k+1]
+};
+
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_merge(const MergeParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *key = (u64 *)smem;          // [MCAP]
+    u64 *val = key + MMIDX_MCAP;     // [MCAP]
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int K1 = P.k + 1;
+    int n = (int)P.pool_cnt[q];
+    if (n > P.poolq) n = P.poolq;
+    const u64 *pk = P.pool_key + (size_t)q * P.poolq;
+    const u64 *pv = P.pool_val + (size_t)q * P.poolq;
+    int kept = 0, consumed = 0;
+    do {
+        int take = n - consumed;
+        if (take > MMIDX_MCAP - kept) take = MMIDX_MCAP - kept;
+        for (int i = tid; i < take; i += MMIDX_BLOCK) {
+            key[kept + i] = pk[consumed + i];
+            val[kept + i] = pv[consumed + i];
+        }
+        const int filled = kept + take;
+        const int Pn = pow2ceil(filled < 2 ? 2 : filled);
+        for (int i = filled + tid; i < Pn; i += MMIDX_BLOCK) {
+            key[i] = MMIDX_KEY_MAX;
+            val[i] = MMIDX_KEY_MAX;
+        }
+        block_bitonic_sort<u64>(key, val, Pn);
+        consumed += take;
+        kept = filled < K1 ? filled : K1;
+    } while (consumed < n);
+    const int total = kept;  // min(n, K1), sorted by (key, offer order)
+    const int cnt = total < P.k ? total : P.k;
+    if (P.mode == 1) {
+        for (int i = tid; i < K1; i += MMIDX_BLOCK) {
+            double dd = __longlong_as_double(0x7FF0000000000000ll);
+            long long kk = -1;
+            if (i < total) {
+                const u64 v = val[i];
+                const int rank = (int)(v >> 32);
+                const u32 pos = (u32)v;
+                const int cell = P.cells ? P.cells[(size_t)q * P.w + rank] : 0;
+                const int iid = P.ids[P.list_off[cell] + pos];
+                dd = keyd(key[i]);
+                kk = (long long)(((u64)rank << 32) | (u32)iid);
+            }
+            P.pdist[(size_t)q * K1 + i] = dd;
+            P.pkey[(size_t)q * K1 + i] = kk;
+        }
+        if (tid == 0) P.count_out[q] = total;
+        return;
+    }
+    for (int i = tid; i < P.k; i += MMIDX_BLOCK) {
+        int iid = -1;
+        double dd = __longlong_as_double(0x7FF0000000000000ll);
+        if (i < cnt) {
+            // run of equal distances [a, b] inside the first cnt entries: reverse it
+            int a = i, b = i;
+            const u64 ki = key[i];
+            while (a > 0 && key[a - 1] == ki) a--;
+            while (b + 1 < cnt && key[b + 1] == ki) b++;
+            const int src = a + (b - i);
+            const u64 v = val[src];
+            const int rank = (int)(v >> 32);
+            const u32 pos = (u32)v;
+            const int cell = P.cells ? P.cells[(size_t)q * P.w + rank] : 0;
+            iid = P.ids[P.list_off[cell] + pos];
+            dd = keyd(ki);
+        }
+        P.iid_out[(size_t)q * P.k + i] = iid;
+        P.dist_out[(size_t)q * P.k + i] = dd;
+    }
+    if (tid == 0) {
+        P.count_out[q] = cnt;
+        P.flag_out[q] = (total > P.k && key[P.k - 1] == key[P.k]) ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: cross-shard merge of sorted partial lists [nshards][nq][K1] -> final results.  Offer order
+// across shards is (probe_rank, iid): inside one inverted list the reference appends in iid order
+// (IVFPQ.java:339, :699-700), so this equals the single-queue offer order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_merge_partials(int k, int nq, int nshards,
+                                                                const double *__restrict__ pdist,
+                                                                const long long *__restrict__ pkey,
+                                                                const int32_t *__restrict__ pcount,
+                                                                int32_t *iid_out, double *dist_out,
+                                                                int32_t *count_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *key = (u64 *)smem;
+    u64 *val = key + MMIDX_MCAP;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int K1 = k + 1;
+    int kept = 0;
+    for (int s = 0; s < nshards;) {
+        // pack as many shards as fit
+        int filled = kept;
+        while (s < nshards) {
+            int c = pcount[(size_t)s * nq + q];
+            if (c > K1) c = K1;
+            if (filled + c > MMIDX_MCAP) break;
+            const size_t base = ((size_t)s * nq + q) * K1;
+            for (int i = tid; i < c; i += MMIDX_BLOCK) {
+                key[filled + i] = dkey(pdist[base + i]);
+                val[filled + i] = (u64)pkey[base + i];
+            }
+            filled += c;
+            s++;
+        }
+        const int Pn = pow2ceil(filled < 2 ? 2 : filled);
+        for (int i = filled + tid; i < Pn; i += MMIDX_BLOCK) {
+            key[i] = MMIDX_KEY_MAX;
+            val[i] = MMIDX_KEY_MAX;
+        }
+        block_bitonic_sort<u64>(key, val, Pn);
+        kept = filled < K1 ? filled : K1;
+    }
+    const int cnt = kept < k ? kept : k;
+    for (int i = tid; i < k; i += MMIDX_BLOCK) {
+        int iid = -1;
+        double dd = __longlong_as_double(0x7FF0000000000000ll);
+        if (i < cnt) {
+            int a = i, b = i;
+            const u64 ki = key[i];
+            while (a > 0 && key[a - 1] == ki) a--;
+            while (b + 1 < cnt && key[b + 1] == ki) b++;
+            iid = (int)(u32)val[a + (b - i)];
+            dd = keyd(ki);
+        }
+        iid_out[(size_t)q * k + i] = iid;
+        dist_out[(size_t)q * k + i] = dd;
+    }
+    if (tid == 0) count_out[q] = cnt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4b: exact replay for queries whose k-th and (k+1)-th distances are equal (tie straddling the
+// queue boundary).  One block per flagged query re-scans the probed lists in the reference's offer
+// order and applies the bounded queue's closed form: with tau the k-th distance,
+// b = #(d < tau) (already final, sorted, in the first b output slots), p = ties among the first k
+// offers with d <= tau, e = b - (k - p): the kept ties are those with tie rank e..p-1 in offer
+// order.  Output tail = kept ties, later-offered first.
+// ------------------------------------------------------------------------------------------------
+struct TieParams {
+    ScanParams S;
+    const int32_t *flag;   // [nq]
+    const int32_t *ids;
+    int32_t *iid_out;      // [nq][k]
+    double *dist_out;      // [nq][k]
+    int k;
+};
+
+template <typename CodeT>
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_tie_resolve(const TieParams TP) {
+    const ScanParams &P = TP.S;
+    const int q = blockIdx.x, tid = threadIdx.x, k = TP.k;
+    if (!TP.flag[q]) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int m = P.m, ks = P.ks, D = P.D, dsub = P.dsub;
+    double *lut = (double *)smem;
+    double *vec = lut + (size_t)m * ks;
+    __shared__ int s_wsum[MMIDX_BLOCK / 64][2];
+    __shared__ int s_state[4];  // nonjunk, ties, p (or -1), emitted
+    const u64 tau = dkey(TP.dist_out[(size_t)q * k + (k - 1)]);
+    int b = 0;
+    while (b < k && dkey(TP.dist_out[(size_t)q * k + b]) < tau) b++;  // uniform per thread
+    const u64 lane_lt = (1ull << (tid & 63)) - 1ull;
+    const int nprobe = P.ivf ? P.w : 1;
+    int e = 0, pfin = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        if (tid == 0) {
+            s_state[0] = 0;
+            s_state[1] = 0;
+            s_state[2] = -1;
+            s_state[3] = 0;
+        }
+        __syncthreads();
+        bool done = false;
+        for (int pr = 0; pr < nprobe && !done; pr++) {
+            int cell = 0;
+            if (P.ivf) {
+                cell = P.cells[(size_t)q * P.w + pr];
+                if (cell < 0) break;
+            }
+            const int64_t beg = P.list_off[cell];
+            const int64_t len = P.list_off[cell + 1] - beg;
+            if (len == 0) continue;
+            double *r = vec, *tr = vec + D;
+            __syncthreads();
+            for (int i = tid; i < D; i += MMIDX_BLOCK) {
+                const double qv = P.Q[(size_t)q * D + i];
+                r[i] = P.ivf ? (P.coarse[(size_t)cell * D + i] - qv) : qv;
+            }
+            __syncthreads();
+            if (P.transform == 2) {
+                for (int i = tid; i < D; i += MMIDX_BLOCK) tr[i] = r[P.perm[i]];
+                __syncthreads();
+            } else if (P.transform == 1) {
+                for (int j = tid; j < D; j += MMIDX_BLOCK) {
+                    double total = 0.0;
+                    for (int i = 0; i < D; i++) total += r[i] * P.rot[(size_t)i * D + j];
+                    tr[j] = total;
+                }
+                __syncthreads();
+            } else {
+                tr = r;
+            }
+            for (int idx = tid; idx < m * ks; idx += MMIDX_BLOCK) {
+                const int s = idx / ks, j = idx - s * ks;
+                const double *pp = P.pqT + (size_t)s * dsub * ks + j;
+                const double *tv = tr + s * dsub;
+                double acc = 0.0;
+                for (int t = 0; t < dsub; t++) {
+                    const double df = tv[t] - pp[(size_t)t * ks];
+                    acc += df * df;
+                }
+                lut[idx] = acc;
+            }
+            __syncthreads();
+            const CodeT *codes = (const CodeT *)P.codes + (size_t)beg * m;
+            for (int64_t base = 0; base < len && !done; base += MMIDX_BLOCK) {
+                const int64_t i = base + tid;
+                bool nonjunk = false, tie = false;
+                if (i < len) {
+                    const CodeT *cp = codes + (size_t)i * m;
+                    double a = 0.0;
+                    for (int s = 0; s < m; s++) a += lut[s * ks + (int)cp[s]];
+                    const u64 key = dkey(a);
+                    nonjunk = key <= tau;
+                    tie = key == tau;
+                }
+                // block-wide exclusive prefix of (nonjunk, tie) in offer order
+                const u64 mj = __ballot(nonjunk), mt = __ballot(tie);
+                const int wave = tid >> 6;
+                if ((tid & 63) == 0) {
+                    s_wsum[wave][0] = __popcll(mj);
+                    s_wsum[wave][1] = __popcll(mt);
+                }
+                __syncthreads();
+                int pj = s_state[0], pt = s_state[1];
+                for (int wv = 0; wv < wave; wv++) {
+                    pj += s_wsum[wv][0];
+                    pt += s_wsum[wv][1];
+                }
+                pj += __popcll(mj & lane_lt);
+                pt += __popcll(mt & lane_lt);
+                if (pass == 0) {
+                    // the k-th non-junk offer fixes p = ties offered up to and including it
+                    if (nonjunk && pj + 1 == k) s_state[2] = pt + (tie ? 1 : 0);
+                } else {
+                    if (tie && pt >= e && pt < pfin) {
+                        // kept tie with rank pt: later-offered first -> slot k-1-(pt-e)
+                        const int slot = k - 1 - (pt - e);
+                        TP.iid_out[(size_t)q * k + slot] = TP.ids[beg + i];
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    int tj = 0, tt = 0;
+                    for (int wv = 0; wv < MMIDX_BLOCK / 64; wv++) {
+                        tj += s_wsum[wv][0];
+                        tt += s_wsum[wv][1];
+                    }
+                    s_state[0] += tj;
+                    s_state[1] += tt;
+                }
+                __syncthreads();
+                if (pass == 0 && s_state[2] >= 0) done = true;
+                if (pass == 1 && s_state[1] >= pfin) done = true;
+            }
+        }
+        __syncthreads();
+        if (pass == 0) {
+            pfin = s_state[2];
+            e = b - (k - pfin);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6a: coarse assignment for encoding.  cell[v] = argmin_c sum_j (coarse[c][j]-x[j])^2, first
+// index wins ties (computeNearestCoarseIndex IVFPQ.java:547-564; the early break at :554 cannot
+// change the argmin because partial sums are non-decreasing).
+// ------------------------------------------------------------------------------------------------
+template <int QT>
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_assign_coarse(const double *__restrict__ coarseT,
+                                                               const double *__restrict__ X,
+                                                               int32_t *__restrict__ cell_out,
+                                                               int C, int D, long long n) {
+    __shared__ u64 s_k[MMIDX_BLOCK / 64][QT];
+    __shared__ int s_i[MMIDX_BLOCK / 64][QT];
+    const long long v0 = (long long)blockIdx.x * QT;
+    u64 bk[QT];
+    int bi[QT];
+#pragma unroll
+    for (int t = 0; t < QT; t++) {
+        bk[t] = MMIDX_KEY_MAX;
+        bi[t] = 0x7fffffff;
+    }
+    for (int c = threadIdx.x; c < C; c += MMIDX_BLOCK) {
+        double acc[QT];
+#pragma unroll
+        for (int t = 0; t < QT; t++) acc[t] = 0.0;
+        for (int j = 0; j < D; j++) {
+            const double cj = coarseT[(size_t)j * C + c];
+#pragma unroll
+            for (int t = 0; t < QT; t++) {
+                const long long v = (v0 + t < n) ? v0 + t : n - 1;
+                const double df = cj - X[(size_t)v * D + j];
+                acc[t] += df * df;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < QT; t++) {
+            const u64 k = dkey(acc[t]);
+            if (k < bk[t]) {  // strict: first index wins inside a thread (c ascending)
+                bk[t] = k;
+                bi[t] = c;
+            }
+        }
+    }
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < QT; t++) {
+        u64 k = bk[t];
+        int i = bi[t];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const u64 ok = __shfl_xor(k, off);
+            const int oi = __shfl_xor(i, off);
+            if (ok < k || (ok == k && oi < i)) {
+                k = ok;
+                i = oi;
+            }
+        }
+        if ((threadIdx.x & 63) == 0) {
+            s_k[wave][t] = k;
+            s_i[wave][t] = i;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < QT && v0 + threadIdx.x < n) {
+        const int t = threadIdx.x;
+        u64 k = s_k[0][t];
+        int i = s_i[0][t];
+        for (int wv = 1; wv < MMIDX_BLOCK / 64; wv++) {
+            if (s_k[wv][t] < k || (s_k[wv][t] == k && s_i[wv][t] < i)) {
+                k = s_k[wv][t];
+                i = s_i[wv][t];
+            }
+        }
+        // Double.MAX_VALUE start + strict '<' : a vector whose every distance is >= MAX_VALUE
+        // (inf / NaN) gets -1 in the reference
+        cell_out[v0 + t] = (k < dkey(1.7976931348623157e308)) ? i : -1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6b: product quantisation.  Per vector: residual (centroid - x) -> transform -> for every
+// sub-quantizer the first-minimum centroid (IVFPQ.java:316-335, :613-631; PQ.java:237-252).
+// VT vectors per block; thread j owns centroid j of every sub-quantizer.
+// ------------------------------------------------------------------------------------------------
+template <int VT, typename CodeT>
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_encode_pq(const double *__restrict__ X,
+                                                           const int32_t *__restrict__ cell,
+                                                           const double *__restrict__ coarse,
+                                                           const double *__restrict__ pqT,
+                                                           const int32_t *__restrict__ perm,
+                                                           const double *__restrict__ rot,
+                                                           CodeT *__restrict__ code_out, int D, int m,
+                                                           int ks, int dsub, int transform, int ivf,
+                                                           long long n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *r = (double *)smem;            // [VT][D]
+    double *tr = r + (size_t)VT * D;       // [VT][D]
+    u64 *red_k = (u64 *)(tr + (size_t)VT * D);       // [m][VT][4]
+    int *red_i = (int *)(red_k + (size_t)m * VT * 4);
+    const long long v0 = (long long)blockIdx.x * VT;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < VT * D; idx += MMIDX_BLOCK) {
+        const int t = idx / D, i = idx - t * D;
+        const long long v = (v0 + t < n) ? v0 + t : n - 1;
+        const double xv = X[(size_t)v * D + i];
+        double val = xv;
+        if (ivf) {
+            int c = cell[v];
+            if (c < 0) c = 0;
+            val = coarse[(size_t)c * D + i] - xv;
+        }
+        r[idx] = val;
+    }
+    __syncthreads();
+    if (transform == 2) {
+        for (int idx = tid; idx < VT * D; idx += MMIDX_BLOCK) {
+            const int t = idx / D, i = idx - t * D;
+            tr[idx] = r[t * D + perm[i]];
+        }
+        __syncthreads();
+    } else if (transform == 1) {
+        for (int idx = tid; idx < VT * D; idx += MMIDX_BLOCK) {
+            const int t = idx / D, j = idx - t * D;
+            double total = 0.0;
+            for (int i = 0; i < D; i++) total += r[t * D + i] * rot[(size_t)i * D + j];
+            tr[idx] = total;
+        }
+        __syncthreads();
+    } else {
+        tr = r;
+    }
+    const int wave = tid >> 6;
+    for (int s = 0; s < m; s++) {
+        u64 bk[VT];
+        int bi[VT];
+#pragma unroll
+        for (int t = 0; t < VT; t++) {
+            bk[t] = MMIDX_KEY_MAX;
+            bi[t] = 0x7fffffff;
+        }
+        for (int j = tid; j < ks; j += MMIDX_BLOCK) {
+            double acc[VT];
+#pragma unroll
+            for (int t = 0; t < VT; t++) acc[t] = 0.0;
+            for (int tt = 0; tt < dsub; tt++) {
+                const double pv = pqT[((size_t)s * dsub + tt) * ks + j];
+#pragma unroll
+                for (int t = 0; t < VT; t++) {
+                    const double df = pv - tr[t * D + s * dsub + tt];
+                    acc[t] += df * df;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < VT; t++) {
+                const u64 k = dkey(acc[t]);
+                if (k < bk[t]) {
+                    bk[t] = k;
+                    bi[t] = j;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < VT; t++) {
+            u64 k = bk[t];
+            int i = bi[t];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const u64 ok = __shfl_xor(k, off);
+                const int oi = __shfl_xor(i, off);
+                if (ok < k || (ok == k && oi < i)) {
+                    k = ok;
+                    i = oi;
+                }
+            }
+            if ((tid & 63) == 0) {
+                red_k[((size_t)s * VT + t) * 4 + wave] = k;
+                red_i[((size_t)s * VT + t) * 4 + wave] = i;
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < m * VT; idx += MMIDX_BLOCK) {
+        const int s = idx / VT, t = idx - s * VT;
+        if (v0 + t >= n) continue;
+        u64 k = red_k[(size_t)idx * 4];
+        int i = red_i[(size_t)idx * 4];
+        for (int wv = 1; wv < MMIDX_BLOCK / 64; wv++) {
+            const u64 ok = red_k[(size_t)idx * 4 + wv];
+            const int oi = red_i[(size_t)idx * 4 + wv];
+            if (ok < k || (ok == k && oi < i)) {
+                k = ok;
+                i = oi;
+            }
+        }
+        code_out[(size_t)(v0 + t) * m + s] = (CodeT)i;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// inverted-list maintenance: move the existing CSR entries / place the new ones
+// ------------------------------------------------------------------------------------------------
+template <typename CodeT>
+__global__ void k_move_old(const int64_t *__restrict__ off_old, const int64_t *__restrict__ off_new,
+                           int nlists, const CodeT *__restrict__ codes_old,
+                           const int32_t *__restrict__ ids_old, CodeT *__restrict__ codes_new,
+                           int32_t *__restrict__ ids_new, int m, long long n_old) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_old) return;
+    int lo = 0, hi = nlists;  // largest c with off_old[c] <= e
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (off_old[mid] <= e) lo = mid;
+        else hi = mid;
+    }
+    const long long dst = off_new[lo] + (e - off_old[lo]);
+    ids_new[dst] = ids_old[e];
+    for (int s = 0; s < m; s++) codes_new[(size_t)dst * m + s] = codes_old[(size_t)e * m + s];
+}
+
+template <typename CodeT>
+__global__ void k_place_new(const long long *__restrict__ dest, const CodeT *__restrict__ codes_p,
+                            const int32_t *__restrict__ ids_p, CodeT *__restrict__ codes_new,
+                            int32_t *__restrict__ ids_new, int m, long long n_new) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_new) return;
+    const long long dst = dest[e];
+    ids_new[dst] = ids_p[e];
+    for (int s = 0; s < m; s++) codes_new[(size_t)dst * m + s] = codes_p[(size_t)e * m + s];
+}
+
+__global__ void k_iota(int32_t *out, int32_t start, long long n) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) out[e] = start + (int32_t)e;
+}
+
+// stored form <-> centroid index (PQ.transformToByte PQ.java:552-558: stored = idx - 128)
+__global__ void k_bias_codes(const unsigned char *in, signed char *out, long long n) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) out[e] = (signed char)((int)in[e] - 128);
+}
+__global__ void k_unbias_codes(const signed char *in, unsigned char *out, long long n) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) out[e] = (unsigned char)((int)in[e] + 128);
+}

@@ -1,0 +1,279 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Bar: neighbour ids bit-exact, distances bit-equal (the promise to callers is 1e-5; the kernels
+keep the reference's fp64 operation order, so equality is the test).  Fixtures are tie-free except
+the explicitly flagged tie fixtures, which pin the bounded-queue rule (assumption A1).
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # stated tolerance (north star); asserted bit-equal below, TOL is the documented bound
+
+
+@pytest.fixture(scope="module")
+def mi():
+    m = importlib.import_module("multimedia-indexing_amd")
+    if m.lib().mmidx_device_count() < 1:
+        pytest.fail("libmmidx_hip.so found no HIP device: GPU tests must run the native path")
+    return m
+
+
+def oracle_ivfpq(o, p, D, m, ks, C, w, tr=0, perm=None, rot=None):
+    ref = o.OracleIndex(o.KIND_IVFPQ, D, m, ks, C, transform=tr, perm=perm, rot=rot)
+    ref.set_coarse(p["coarse"])
+    ref.set_pq(p["pq"])
+    ref.set_w(w)
+    return ref
+
+
+def assert_same(res, ref, bit_exact=True):
+    iids, dists, counts = res
+    rid, rd, rc = ref
+    assert np.array_equal(counts, rc)
+    assert np.array_equal(iids, rid)
+    if bit_exact:
+        assert np.array_equal(dists, rd)
+    else:
+        fin = np.isfinite(rd)
+        assert np.array_equal(np.isfinite(dists), fin)
+        assert np.max(np.abs(dists[fin] - rd[fin]), initial=0.0) <= TOL
+
+
+@pytest.mark.parametrize("D,C,m,ks,n,w,k", [
+    (32, 16, 8, 256, 5000, 4, 10),     # dsub 4
+    (128, 64, 16, 256, 20000, 8, 100), # cfg3 shape, scaled down
+    (64, 32, 8, 64, 3000, 32, 5),      # w == C, ks < 256
+    (24, 8, 6, 256, 2000, 3, 50),      # m not a template instance (generic kernel)
+])
+def test_ivfpq_encode_and_search(mi, oracle, D, C, m, ks, n, w, k):
+    p = synth.make_ivfpq_problem(n=n, D=D, C=C, m=m, ks=ks, nq=64, seed=D + C)
+    ix = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    ix.loadCoarseQuantizer(p["coarse"])
+    ix.loadProductQuantizer(p["pq"])
+    assert ix.getW() == int(C * 0.1)  # IVFPQ.java:188
+    ix.setW(w)
+    ref = oracle_ivfpq(oracle, p, D, m, ks, C, w)
+    # encode parity (IVFPQ.java:309-335)
+    cells, codes = ix.encode(p["base"][:1500])
+    rcell, rcode = ref.encode_batch(p["base"][:1500])
+    assert np.array_equal(cells, rcell)
+    assert np.array_equal(codes.astype(np.int32) + 128, rcode)
+    # index through indexVector (batched) and search
+    assert ix.indexVectors([str(i) for i in range(n)], p["base"]) == n
+    ref.add_vectors(p["base"])
+    assert np.array_equal(ix.listSizes(), ref.list_sizes())
+    assert_same(ix.search_batch(k, p["queries"]), ref.search_batch(p["queries"], k))
+    # single-query surface: Answer with external ids
+    a = ix.computeNearestNeighbors(k, p["queries"][0])
+    rid, rd = ref.search(p["queries"][0], k)
+    assert a.getIds() == [str(i) for i in rid] and np.array_equal(a.getDistances(), rd)
+    ix.close()
+
+
+@pytest.mark.parametrize("tr", [1, 2])
+def test_ivfpq_transforms(mi, oracle, tr):
+    D, C, m, ks, n, w, k = 32, 16, 8, 256, 4000, 5, 20
+    p = synth.make_ivfpq_problem(n=n, D=D, C=C, m=m, ks=ks, nq=32, seed=77 + tr)
+    rot = np.linalg.qr(np.random.default_rng(5).standard_normal((D, D)))[0] if tr == 1 else None
+    ix = mi.IVFPQ(D, n, False, "", m, ks, tr, C, 512, rot=rot)
+    ix.loadCoarseQuantizer(p["coarse"])
+    ix.loadProductQuantizer(p["pq"])
+    ix.setW(w)
+    ref = oracle_ivfpq(oracle, p, D, m, ks, C, w, tr=tr, rot=rot)  # perm=None -> RandomPermutation(1, D)
+    ix.indexVectors([str(i) for i in range(n)], p["base"])
+    ref.add_vectors(p["base"])
+    assert np.array_equal(ix.listSizes(), ref.list_sizes())
+    # rotation: same sequential order on both sides (EJML order itself is assumption A2)
+    assert_same(ix.search_batch(k, p["queries"]), ref.search_batch(p["queries"], k))
+    ix.close()
+
+
+@pytest.mark.parametrize("D,m,ks,n,k", [(128, 8, 256, 40000, 100), (32, 4, 256, 70000, 10), (16, 16, 16, 1000, 3)])
+def test_pq_adc(mi, oracle, D, m, ks, n, k):
+    o = oracle
+    p = synth.make_pq_problem(n=min(n, 20000), D=D, m=m, ks=ks, nq=16, seed=n)
+    rng = np.random.default_rng(1)
+    base = rng.standard_normal((n, D))
+    ix = mi.PQ(D, n, False, "", m, ks, 0, 512)
+    ix.loadProductQuantizer(p["pq"])
+    ref = o.OracleIndex(o.KIND_PQ, D, m, ks)
+    ref.set_pq(p["pq"])
+    cells, codes = ix.encode(base)
+    assert np.all(cells == -1)
+    sample = rng.choice(n, size=800, replace=False)
+    _, rcode = ref.encode_batch(base[sample])
+    assert np.array_equal(codes[sample].astype(np.int32) + 128, rcode)
+    # bulk-load path (loadIndexInMemory, PQ.java:436-483) with GPU-produced codes
+    ix.loadIndex(codes)
+    ref.add_codes(np.arange(n), None, codes.astype(np.int32) + 128)
+    assert ix.size() == n
+    assert_same(ix.search_batch(k, p["queries"]), ref.search_batch(p["queries"], k))
+    ix.close()
+
+
+def test_short_codes(mi, oracle):
+    """numProductCentroids > 256 -> int16 codes (PQ.transformToShort, PQ.java:544-550)."""
+    D, C, m, ks, n, w, k = 32, 8, 8, 512, 6000, 3, 10
+    p = synth.make_ivfpq_problem(n=n, D=D, C=C, m=m, ks=ks, nq=16, seed=4)
+    ix = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    ix.loadCoarseQuantizer(p["coarse"])
+    ix.loadProductQuantizer(p["pq"])
+    ix.setW(w)
+    ref = oracle_ivfpq(oracle, p, D, m, ks, C, w)
+    cells, codes = ix.encode(p["base"][:500])
+    rcell, rcode = ref.encode_batch(p["base"][:500])
+    assert codes.dtype == np.int16 and np.array_equal(codes, rcode) and np.array_equal(cells, rcell)
+    ix.indexVectors([str(i) for i in range(n)], p["base"])
+    ref.add_vectors(p["base"])
+    assert_same(ix.search_batch(k, p["queries"]), ref.search_batch(p["queries"], k))
+    with pytest.raises(mi.MmidxError) as ei:
+        ix.indexPQCode("x", 0, np.zeros(m, np.int8))
+    assert ei.value.status == 4  # IVFPQ.java:358-361
+    ix.close()
+
+
+def test_index_pq_code_roundtrip_and_incremental(mi, oracle):
+    """encode -> indexPQCode == indexVector (IVFPQ.java:357-386), adds interleaved with searches."""
+    D, C, m, ks, n, w, k = 32, 8, 8, 256, 1200, 8, 7
+    p = synth.make_ivfpq_problem(n=n, D=D, C=C, m=m, ks=ks, nq=12, seed=8)
+    a = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    b = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    ref = oracle_ivfpq(oracle, p, D, m, ks, C, w)
+    for ix in (a, b):
+        ix.loadCoarseQuantizer(p["coarse"])
+        ix.loadProductQuantizer(p["pq"])
+        ix.setW(w)
+    cells, codes = a.encode(p["base"])
+    for lo, hi in ((0, 300), (300, 301), (301, 1200)):
+        a.indexVectors([str(i) for i in range(lo, hi)], p["base"][lo:hi])
+        for i in range(lo, hi):
+            assert b.indexPQCode(str(i), int(cells[i]), codes[i])
+            ref.add_vector(p["base"][i])
+        r = ref.search_batch(p["queries"], k)
+        assert_same(a.search_batch(k, p["queries"]), r)
+        assert_same(b.search_batch(k, p["queries"]), r)
+    # duplicate id / capacity -> False, nothing indexed (ASS:232-240)
+    assert a.indexVector("0", p["base"][0]) is False
+    assert a.indexVector("new", p["base"][0]) is False  # capacity n reached
+    assert a.size() == n
+    with pytest.raises(mi.MmidxError) as ei:
+        b.indexVector("zz", np.zeros(D + 1))
+    assert ei.value.status == 2
+    a.close()
+    b.close()
+
+
+def test_edge_cases(mi, oracle):
+    D, C, m, ks, w = 16, 8, 4, 256, 3
+    p = synth.make_ivfpq_problem(n=400, D=D, C=C, m=m, ks=ks, nq=6, seed=2)
+    ix = mi.IVFPQ(D, 1000, False, "", m, ks, 0, C, 512)
+    # quantizers not loaded -> NOT_READY (NullPointerException in the reference)
+    with pytest.raises(mi.MmidxError) as ei:
+        ix.search_batch(1, p["queries"])
+    assert ei.value.status == 7
+    ix.loadCoarseQuantizer(p["coarse"])
+    ix.loadProductQuantizer(p["pq"])
+    ix.setW(w)
+    ref = oracle_ivfpq(oracle, p, D, m, ks, C, w)
+    # empty index: every answer is empty
+    iids, dists, counts = ix.search_batch(5, p["queries"])
+    assert np.all(counts == 0) and np.all(iids == -1)
+    # ragged: only a few vectors, most probed lists empty, k larger than the candidates
+    ix.indexVectors([str(i) for i in range(5)], p["base"][:5])
+    ref.add_vectors(p["base"][:5])
+    assert_same(ix.search_batch(50, p["queries"]), ref.search_batch(p["queries"], 50))
+    ix.indexVectors([str(i) for i in range(5, 400)], p["base"][5:400])
+    ref.add_vectors(p["base"][5:400])
+    for k in (1, 399, 1023):
+        assert_same(ix.search_batch(k, p["queries"]), ref.search_batch(p["queries"], k))
+    # invalid k / w (LingPipe ctor rejects 0; w > C is an NPE at IVFPQ.java:597-599)
+    for bad_k in (0, 1024):
+        with pytest.raises(mi.MmidxError) as ei:
+            ix.search_batch(bad_k, p["queries"])
+        assert ei.value.status == 6
+    for bad_w in (0, C + 1):
+        ix.setW(bad_w)
+        with pytest.raises(mi.MmidxError) as ei:
+            ix.search_batch(1, p["queries"])
+        assert ei.value.status == 6
+    ix.setW(C)
+    ref.set_w(C)
+    assert_same(ix.search_batch(10, p["queries"]), ref.search_batch(p["queries"], 10))
+    # zero queries
+    iids, dists, counts = ix.search_batch(3, np.zeros((0, D)))
+    assert iids.shape == (0, 3)
+    ix.close()
+
+
+def test_flagged_ties(mi, oracle):
+    """FLAGGED tie fixture: duplicate codes create exact distance ties straddling k; the GPU path
+    must reproduce the bounded queue's order (assumption A1, replayed by the oracle)."""
+    D, C, m, ks, w = 16, 4, 4, 256, 4
+    p = synth.make_ivfpq_problem(n=600, D=D, C=C, m=m, ks=ks, nq=8, seed=12)
+    base = np.concatenate([p["base"][:200]] * 3 + [p["base"][200:260]])  # every code three times
+    rng = np.random.default_rng(0)
+    base = base[rng.permutation(base.shape[0])]
+    ix = mi.IVFPQ(D, len(base), False, "", m, ks, 0, C, 512)
+    ix.loadCoarseQuantizer(p["coarse"])
+    ix.loadProductQuantizer(p["pq"])
+    ix.setW(w)
+    ref = oracle_ivfpq(oracle, p, D, m, ks, C, w)
+    ix.indexVectors([str(i) for i in range(len(base))], base)
+    ref.add_vectors(base)
+    ix.set_profiling(True)
+    total_fallbacks = 0
+    for k in (1, 2, 4, 5, 10, 31):
+        res = ix.search_batch(k, p["queries"])
+        total_fallbacks += ix.get_stats()["tie_fallbacks"]
+        assert_same(res, ref.search_batch(p["queries"], k))
+    assert total_fallbacks > 0, "fixture did not exercise the tie replay"
+    ix.close()
+    # flat PQ variant: heavy ties (tight clusters -> few distinct codes)
+    base, _ = synth.mixture(3000, 16, 6, sigma=0.01, seed=3)
+    pp = synth.make_pq_problem(n=2000, D=16, m=4, ks=16, nq=8, seed=3)
+    pq = mi.PQ(16, 3000, False, "", 4, 16, 0, 512)
+    pq.loadProductQuantizer(pp["pq"])
+    rpq = oracle.OracleIndex(oracle.KIND_PQ, 16, 4, 16)
+    rpq.set_pq(pp["pq"])
+    pq.indexVectors([str(i) for i in range(3000)], base)
+    rpq.add_vectors(base)
+    q = base[:8] + 0.001
+    for k in (1, 7, 100):
+        assert_same(pq.search_batch(k, q), rpq.search_batch(q, k))
+    pq.close()
+
+
+def test_large_batch_properties(mi):
+    """Size-independent properties at a larger size (no oracle): sortedness, idempotence,
+    self-query hits itself, k-prefix consistency."""
+    D, C, m, ks, n, w = 64, 128, 8, 256, 200000, 8
+    rng = np.random.default_rng(6)
+    base, mu = synth.mixture(n, D, C, seed=6)
+    coarse = mu
+    resid_pq = np.stack([synth.kmeans((0.15 * rng.standard_normal((4000, D)))[:, s * 8:(s + 1) * 8], ks, iters=3, seed=s)
+                         for s in range(m)])
+    ix = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    ix.loadCoarseQuantizer(coarse)
+    ix.loadProductQuantizer(resid_pq)
+    ix.setW(w)
+    ix.indexVectors(list(range(n)), base)
+    sizes = ix.listSizes()
+    assert sizes.sum() == n
+    qi = rng.choice(n, 2048, replace=False)
+    Q = base[qi] + 0.01 * rng.standard_normal((2048, D))
+    i1, d1, c1 = ix.search_batch(100, Q)
+    i2, d2, c2 = ix.search_batch(100, Q)
+    assert np.array_equal(i1, i2) and np.array_equal(d1, d2)  # deterministic despite atomics
+    assert np.all(np.diff(d1, axis=1) >= 0)
+    i10, d10, _ = ix.search_batch(10, Q)
+    assert np.array_equal(d10, d1[:, :10])  # k-prefix (tie-free data)
+    assert np.array_equal(i10, i1[:, :10])
+    recall1 = np.mean(i1[:, 0] == qi)
+    assert recall1 > 0.8, recall1
+    ix.close()
