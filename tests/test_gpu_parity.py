@@ -143,7 +143,7 @@ def test_index_pq_code_roundtrip_and_incremental(mi, oracle):
     D, C, m, ks, n, w, k = 32, 8, 8, 256, 1200, 8, 7
     p = synth.make_ivfpq_problem(n=n, D=D, C=C, m=m, ks=ks, nq=12, seed=8)
     a = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
-    b = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    b = mi.IVFPQ(D, n + 10, False, "", m, ks, 0, C, 512)
     ref = oracle_ivfpq(oracle, p, D, m, ks, C, w)
     for ix in (a, b):
         ix.loadCoarseQuantizer(p["coarse"])
