@@ -1,0 +1,341 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: queries/sec of IVFPQ search (IVFADC) on MI355X.
+
+Workload (BASELINE.json configs[3], the configuration the metric is quoted on): IVFPQ over a
+synthetic 100M x 128-d Gaussian-mixture base, 8192 coarse cells, nprobe w = 32, m = 16 x 256
+sub-quantizers, k = 100.  One "step" = one pass of the hot path (coarse top-w -> residual LUTs ->
+list scan -> top-k merge) over one batch of queries already resident in HBM.
+
+  python bench.py --gpus 1 --steps K --warmup W            (defaults finish in a few minutes)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU; inverted lists are partitioned whole-list across ranks (cell mod N),
+queries are replicated, the coarse assignment is split across ranks and all-gathered, the
+per-shard top-(k+1) lists are all-gathered (RCCL over xGMI) and merged.  The index and the batch
+are the same for every N, so the scaling reported is "strong".
+
+The JSON line carries `roofline` (dominant kernel = k_scan, algorithmic bytes = m x scanned codes,
+timed with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle -- a C restatement
+of the Java reference, kind "port" -- timed on this host's cores on a bounded query sample).
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def torch_kmeans(X, k, iters, gen):
+    """Lloyd in torch fp32 (codebook learning is offline in the reference, J/quantization/*)."""
+    import torch
+
+    n = X.shape[0]
+    cent = X[torch.randperm(n, device=X.device, generator=gen)[:k]].clone()
+    for _ in range(iters):
+        d = (X * X).sum(1, keepdim=True) - 2.0 * X @ cent.T + (cent * cent).sum(1)[None, :]
+        a = d.argmin(1)
+        sums = torch.zeros_like(cent).index_add_(0, a, X)
+        cnt = torch.zeros(k, device=X.device, dtype=X.dtype).index_add_(0, a, torch.ones(n, device=X.device, dtype=X.dtype))
+        nz = cnt > 0
+        cent[nz] = sums[nz] / cnt[nz, None]
+    return cent
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=100_000_000)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--cells", type=int, default=8192)
+    ap.add_argument("--w", type=int, default=32)
+    ap.add_argument("--m", type=int, default=16)
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--batch", type=int, default=8192)
+    ap.add_argument("--nbatches", type=int, default=4)
+    ap.add_argument("--chunk", type=int, default=2_000_000)
+    ap.add_argument("--gt", type=int, default=1024, help="queries with exact ground truth (recall@1)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    mi = importlib.import_module("multimedia-indexing_amd")
+    nat = importlib.import_module("multimedia-indexing_amd._native")
+    L = mi.lib()
+    if not torch.cuda.is_available() or L.mmidx_device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: libmmidx_hip has no CPU fallback")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    N, D, Cc, w, m, k, B = args.n, args.dim, args.cells, args.w, args.m, args.k, args.batch
+    ks, dsub, K1 = 256, D // m, args.k + 1
+    f64 = torch.float64
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def chk(st):
+        nat.check(st)
+
+    # ---------------------------------------------------------------- codebooks (offline learning)
+    t0 = time.time()
+    g0 = torch.Generator(device=dev)
+    g0.manual_seed(1234)
+    mu = torch.randn(Cc, D, generator=g0, device=dev, dtype=f64)
+    ns = min(N, 1 << 20)
+    gs = torch.randint(0, Cc, (ns,), generator=g0, device=dev)
+    Xs = (mu[gs] + 0.15 * torch.randn(ns, D, generator=g0, device=dev, dtype=f64)).float()
+    # one Lloyd refinement of the mixture means = the coarse quantizer
+    cent = mu.float().clone()
+    dmat_arg = torch.empty(ns, dtype=torch.long, device=dev)
+    for i0 in range(0, ns, 1 << 17):
+        xs = Xs[i0:i0 + (1 << 17)]
+        dmat_arg[i0:i0 + (1 << 17)] = ((xs * xs).sum(1, keepdim=True) - 2.0 * xs @ cent.T + (cent * cent).sum(1)[None]).argmin(1)
+    sums = torch.zeros_like(cent).index_add_(0, dmat_arg, Xs)
+    cnt = torch.zeros(Cc, device=dev).index_add_(0, dmat_arg, torch.ones(ns, device=dev))
+    nz = cnt > 0
+    cent[nz] = sums[nz] / cnt[nz, None]
+    coarse = cent.double().contiguous()
+    # residual PQ codebooks: k-means per sub-space on centroid - vector (ResidualVectorComputation.java:34)
+    nr = min(ns, 1 << 18)
+    resid = (cent[dmat_arg[:nr]] - Xs[:nr])
+    pq = torch.empty(m, ks, dsub, device=dev, dtype=f64)
+    for s in range(m):
+        pq[s] = torch_kmeans(resid[:, s * dsub:(s + 1) * dsub].contiguous(), ks, 8, g0).double()
+    del Xs, resid, sums
+    log(f"codebooks learned in {time.time() - t0:.1f}s")
+
+    # ---------------------------------------------------------------- index
+    h = C.c_void_p()
+    chk(L.mmidx_create(nat.KIND_IVFPQ, D, m, ks, Cc, 0, None, None, local, C.byref(h)))
+    coarse_h = coarse.cpu().numpy()
+    pq_h = pq.cpu().numpy()
+    chk(L.mmidx_set_coarse(h, coarse_h.ctypes.data))
+    chk(L.mmidx_set_pq(h, pq_h.ctypes.data))
+    chk(L.mmidx_set_w(h, w))
+
+    nq_total = B * args.nbatches
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(4321)
+    qsrc = torch.randint(0, N, (nq_total,), generator=gq, device=dev)
+    Qsrc = torch.zeros(nq_total, D, device=dev, dtype=f64)
+    ngt = min(args.gt, B)
+    gt_best = torch.full((ngt,), float("inf"), device=dev, dtype=f64)
+    gt_arg = torch.full((ngt,), -1, device=dev, dtype=torch.long)
+
+    t0 = time.time()
+    t_enc = 0.0
+    for c0 in range(0, N, args.chunk):
+        n = min(args.chunk, N - c0)
+        gc = torch.Generator(device=dev)
+        gc.manual_seed(10_000 + c0 // args.chunk)
+        g = torch.randint(0, Cc, (n,), generator=gc, device=dev)
+        X = mu[g]
+        X += 0.15 * torch.randn(n, D, generator=gc, device=dev, dtype=f64)
+        sel = (qsrc >= c0) & (qsrc < c0 + n)
+        if sel.any():
+            Qsrc[sel] = X[qsrc[sel] - c0]
+        torch.cuda.synchronize()
+        te = time.time()
+        if world == 1:
+            chk(L.mmidx_add_vectors_device(h, n, X.data_ptr(), None, c0, stream))
+        else:
+            cells = torch.empty(n, dtype=torch.int32, device=dev)
+            codes = torch.empty(n, m, dtype=torch.int8, device=dev)
+            chk(L.mmidx_encode_device(h, n, X.data_ptr(), cells.data_ptr(), codes.data_ptr(), stream))
+            own = (cells % world) == rank
+            iids = (torch.arange(n, device=dev, dtype=torch.int32) + c0)[own].contiguous()
+            oc = cells[own].contiguous()
+            ok = codes[own].contiguous()
+            torch.cuda.synchronize()
+            chk(L.mmidx_add_codes_device(h, iids.numel(), iids.data_ptr(), oc.data_ptr(), ok.data_ptr(), stream))
+        torch.cuda.synchronize()
+        t_enc += time.time() - te
+        del g, X
+    chk(L.mmidx_sync_index(h))
+    torch.cuda.synchronize()
+    log(f"index built: {N} vectors in {time.time() - t0:.1f}s (encode+append {t_enc:.1f}s)")
+
+    Q = Qsrc + 0.01 * torch.randn(nq_total, D, generator=gq, device=dev, dtype=f64)
+    Qb = [Q[i * B:(i + 1) * B].contiguous() for i in range(args.nbatches)]
+
+    # exact fp64 brute-force ground truth (Linear semantics) for recall@1: regenerate the chunks
+    t0 = time.time()
+    if rank == 0 and ngt > 0:
+        Qg = Qb[0][:ngt]
+        qn = (Qg * Qg).sum(1)
+        for c0 in range(0, N, args.chunk):
+            n = min(args.chunk, N - c0)
+            gc = torch.Generator(device=dev)
+            gc.manual_seed(10_000 + c0 // args.chunk)
+            g = torch.randint(0, Cc, (n,), generator=gc, device=dev)
+            X = mu[g]
+            X += 0.15 * torch.randn(n, D, generator=gc, device=dev, dtype=f64)
+            dm = (X * X).sum(1)[None, :] - 2.0 * (Qg @ X.T) + qn[:, None]
+            bv, bi = dm.min(1)
+            upd = bv < gt_best
+            gt_best[upd] = bv[upd]
+            gt_arg[upd] = bi[upd] + c0
+            del X, dm, g
+        log(f"ground truth for {ngt} queries in {time.time() - t0:.1f}s")
+
+    # ---------------------------------------------------------------- the step
+    iid_out = torch.empty(B, k, dtype=torch.int32, device=dev)
+    dist_out = torch.empty(B, k, dtype=f64, device=dev)
+    cnt_out = torch.empty(B, dtype=torch.int32, device=dev)
+    if world > 1:
+        per = (B + world - 1) // world
+        Bp = per * world
+        cells_sl = torch.empty(per, w, dtype=torch.int32, device=dev)
+        cells_all = torch.empty(Bp, w, dtype=torch.int32, device=dev)
+        pd = torch.empty(B, K1, dtype=f64, device=dev)
+        pk = torch.empty(B, K1, dtype=torch.int64, device=dev)
+        pc = torch.empty(B, dtype=torch.int32, device=dev)
+        pd_all = torch.empty(world, B, K1, dtype=f64, device=dev)
+        pk_all = torch.empty(world, B, K1, dtype=torch.int64, device=dev)
+        pc_all = torch.empty(world, B, dtype=torch.int32, device=dev)
+
+    def step(Qx):
+        if world == 1:
+            chk(L.mmidx_search_device(h, k, B, Qx.data_ptr(), iid_out.data_ptr(), dist_out.data_ptr(), cnt_out.data_ptr(), stream))
+            return
+        q0 = min(rank * per, B)
+        nsl = max(0, min(per, B - q0))
+        if nsl:
+            chk(L.mmidx_coarse_device(h, nsl, Qx[q0:q0 + nsl].data_ptr(), cells_sl.data_ptr(), stream))
+        dist.all_gather_into_tensor(cells_all, cells_sl)
+        chk(L.mmidx_search_partial_device(h, k, B, Qx.data_ptr(), cells_all.data_ptr(), pd.data_ptr(), pk.data_ptr(), pc.data_ptr(), stream))
+        dist.all_gather_into_tensor(pd_all, pd)
+        dist.all_gather_into_tensor(pk_all, pk)
+        dist.all_gather_into_tensor(pc_all, pc)
+        chk(L.mmidx_merge_partials_device(local, k, B, world, pd_all.data_ptr(), pk_all.data_ptr(), pc_all.data_ptr(),
+                                          iid_out.data_ptr(), dist_out.data_ptr(), cnt_out.data_ptr(), stream))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(Qb[i % args.nbatches])
+    barrier()
+    chk(L.mmidx_set_profiling(h, 1))  # HIP events on the launch stream; resolved after the timed region
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(Qb[i % args.nbatches])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    st = nat.Stats()
+    chk(L.mmidx_get_stats(h, C.byref(st)))
+    chk(L.mmidx_set_profiling(h, 0))
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=f64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    qps = B * args.steps / elapsed
+
+    # recall@1 and results of batch 0 (for the parity gate)
+    step(Qb[0])
+    torch.cuda.synchronize()
+    res_iid = iid_out.cpu().numpy().copy()
+    res_dist = dist_out.cpu().numpy().copy()
+    recall1 = None
+    if rank == 0 and ngt > 0:
+        recall1 = float((iid_out[:ngt, 0].long() == gt_arg).double().mean().item())
+
+    launches = max(1, st.scan_launches)
+    scan_ms = st.scan_ms / launches
+    alg_bytes = float(m) * st.scan_codes / launches
+    achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_scan", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(scan_ms, 4),
+                "bytes_per_query": alg_bytes / B, "scan_launches": int(st.scan_launches),
+                "coarse_ms_per_step": round(st.coarse_ms / launches, 4), "merge_ms_per_step": round(st.merge_ms / launches, 4)}
+
+    # ---------------------------------------------------------------- CPU baseline + parity gate
+    cpu_baseline, parity = None, None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import oracle as o
+
+        t0 = time.time()
+        off = np.zeros(Cc + 1, np.int64)
+        chk(L.mmidx_export(h, off.ctypes.data, None, None))
+        n_exp = int(off[-1])
+        iids = np.empty(n_exp, np.int32)
+        codes = np.empty((n_exp, m), np.int8)
+        chk(L.mmidx_export(h, off.ctypes.data, iids.ctypes.data, codes.ctypes.data))
+        ref = o.OracleIndex(o.KIND_IVFPQ, D, m, ks, Cc)
+        ref.set_coarse(coarse_h)
+        ref.set_pq(pq_h)
+        ref.set_w(w)
+        ref.load_lists(off, iids, codes)
+        del iids, codes
+        cores = os.cpu_count() or 1
+        Qh = Qb[0].cpu().numpy()
+        tc = time.perf_counter()
+        ref.search_batch(Qh[:cores], k, nthreads=cores)  # calibration
+        per_round = max(time.perf_counter() - tc, 1e-4)
+        nsamp = int(min(B, max(cores, cores * int(args.cpu_seconds / per_round))))
+        tc = time.perf_counter()
+        rid, rd, rc = ref.search_batch(Qh[:nsamp], k, nthreads=cores)
+        cpu_t = time.perf_counter() - tc
+        cpu_baseline = {"value": round(nsamp / cpu_t, 2), "unit": "queries/s", "cores": cores, "kind": "port",
+                        "sample": f"{nsamp} queries of batch 0 (same index, k={k}, w={w}), C restatement of "
+                                  f"IVFPQ.computeKnnIVFADC, {cores} concurrent reader threads, {cpu_t:.1f}s"}
+        ids_match = bool(np.array_equal(res_iid[:nsamp], rid))
+        fin = np.isfinite(rd)
+        maxd = float(np.max(np.abs(res_dist[:nsamp][fin] - rd[fin]), initial=0.0))
+        parity = {"queries": nsamp, "ids_match": ids_match, "max_abs_ddist": maxd}
+        log(f"cpu baseline + parity in {time.time() - t0:.1f}s: {cpu_baseline['value']} q/s on {cores} cores; parity {parity}")
+
+    if rank == 0:
+        out = {
+            "metric": "queries/sec @ recall@1, IVFPQ 100Mx128-d nprobe=32",
+            "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"IVFPQ {N}x{D}-d, {Cc} coarse cells, nprobe w={w}, m={m}x{ks}, k={k}, batch {B} queries/step",
+                       "n": N, "dim": D, "cells": Cc, "nprobe": w, "m": m, "ks": ks, "k": k, "batch": B,
+                       "sharding": "single GPU" if world == 1 else f"whole inverted lists, cell mod {world}; RCCL all-gather top-k merge"},
+            "recall_at_1": recall1, "recall_queries": ngt,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
+        }
+        print(json.dumps(out), flush=True)
+    chk(L.mmidx_destroy(h))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

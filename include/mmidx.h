@@ -115,6 +115,11 @@ int mmidx_encode_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_
                         void *d_code_out, void *stream);
 /* build the device-side inverted-list layout now (otherwise done lazily by the next search) */
 int mmidx_sync_index(mmidx_index *h);
+/* snapshot of the in-memory index in list-major order -- the arrays loadIndexInMemory builds
+ * (invertedLists / pqByteCodes, IVFPQ.java:680-728; the per-id getters getPQCodeByte :801,
+ * getInvertedListId :865 read the same records from BDB): list_off_out[nlists+1],
+ * iids_out[n], codes_out[n][m] in stored form.  iids_out / codes_out may be NULL. */
+int mmidx_export(mmidx_index *h, int64_t *list_off_out, int32_t *iids_out, void *codes_out);
 
 /* ---- search ---------------------------------------------------------------------------------
  * computeNearestNeighborsInternal(k, double[]) : computeKnnIVFADC IVFPQ.java:408-450 /
@@ -146,8 +151,9 @@ int mmidx_merge_partials_device(int device, int k, int64_t nq, int nshards, cons
                                 void *stream);
 
 /* ---- instrumentation -------------------------------------------------------------------------
- * Per-handle statistics of the most recent search call, measured with HIP events on the stream
- * the kernels were launched on.  scan_ms = time inside the list-scan kernel (the HBM-bound
+ * Per-handle statistics accumulated over the search calls since the last mmidx_get_stats, measured
+ * with HIP events recorded on the stream the kernels are launched on (no host synchronisation
+ * until mmidx_get_stats).  scan_ms = time inside the list-scan kernel (the HBM-bound
  * kernel of the path), scan_codes = sum over (query, probed list) of list lengths (algorithmic
  * bytes = m * scan_codes), launches = number of scan launches. */
 typedef struct mmidx_stats {

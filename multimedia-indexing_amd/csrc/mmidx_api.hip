@@ -123,9 +123,14 @@ struct mmidx_index {
     DevBuf<unsigned char> ws_ecode, ws_tmp;
     DevBuf<long long> ws_dest;
 
+    // profiling: HIP events recorded on the launch stream, resolved lazily by mmidx_get_stats
     bool profiling = false;
     mmidx_stats stats{};
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> evpool;  // groups of 5: start, coarse end, scan start, scan end, end
+    size_t ev_used = 0;
+    u64 *d_counters = nullptr;       // [0] scan codes, [1] tie fallbacks
+    int64_t host_codes = 0;          // PQ: nq * n, known on the host
+    int32_t launches = 0;
 };
 
 namespace {
@@ -360,8 +365,22 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
                         int mode, int32_t *d_iid, double *d_dist, int32_t *d_cnt, double *d_pdist, long long *d_pkey,
                         hipStream_t st) {
     const int ivf = h->kind == MMIDX_KIND_IVFPQ;
-    const bool prof = h->profiling;
-    if (prof) HIPCK(hipEventRecord(h->ev[0], st));
+    bool prof = h->profiling;
+    hipEvent_t *ev = nullptr;
+    if (prof) {
+        if (h->ev_used + 5 > 5 * 4096) {
+            prof = false;  // event pool exhausted: call mmidx_get_stats to drain it
+        } else {
+            while (h->evpool.size() < h->ev_used + 5) {
+                hipEvent_t e;
+                HIPCK(hipEventCreate(&e));
+                h->evpool.push_back(e);
+            }
+            ev = h->evpool.data() + h->ev_used;
+            h->ev_used += 5;
+            HIPCK(hipEventRecord(ev[0], st));
+        }
+    }
     const int32_t *d_cells = d_cells_in;
     if (ivf && !d_cells) {
         HIPCK(h->ws_cells.reserve((size_t)nq * h->w));
@@ -369,7 +388,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
         if (rc) return rc;
         d_cells = h->ws_cells.p;
     }
-    if (prof) HIPCK(hipEventRecord(h->ev[1], st));
+    if (prof) HIPCK(hipEventRecord(ev[1], st));
     HIPCK(h->ws_T.reserve((size_t)nq));
     HIPCK(h->ws_pcnt.reserve((size_t)nq));
     HIPCK(h->ws_pkey.reserve((size_t)nq * pl.poolq));
@@ -404,10 +423,13 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
     P.poolq = pl.poolq;
     if (h->n_csr > 0) {
         dim3 grid((unsigned)pl.nchunks, (unsigned)P.w, (unsigned)nq);
-        if (prof) HIPCK(hipEventRecord(h->ev[2], st));
+        if (prof) HIPCK(hipEventRecord(ev[2], st));
         int rc = launch_scan(h, P, grid, pl.lds, st);
         if (rc) return rc;
-        if (prof) HIPCK(hipEventRecord(h->ev[3], st));
+        if (prof) HIPCK(hipEventRecord(ev[3], st));
+    } else if (prof) {
+        HIPCK(hipEventRecord(ev[2], st));
+        HIPCK(hipEventRecord(ev[3], st));
     }
     MergeParams M{};
     M.pool_cnt = h->ws_pcnt.p;
@@ -450,37 +472,17 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
         HIPCK(hipGetLastError());
     }
     if (prof) {
-        HIPCK(hipEventRecord(h->ev[4], st));
-        HIPCK(hipEventSynchronize(h->ev[4]));
-        float a = 0, b = 0, c = 0, t = 0;
-        HIPCK(hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
-        if (h->n_csr > 0) {
-            HIPCK(hipEventElapsedTime(&b, h->ev[2], h->ev[3]));
-            HIPCK(hipEventElapsedTime(&c, h->ev[3], h->ev[4]));
-        }
-        HIPCK(hipEventElapsedTime(&t, h->ev[0], h->ev[4]));
-        h->stats.coarse_ms += a;
-        h->stats.scan_ms += b;
-        h->stats.merge_ms += c;
-        h->stats.total_ms += t;
-        h->stats.scan_launches += (h->n_csr > 0) ? 1 : 0;
-        // algorithmic work: sum over (query, probed list) of list lengths
-        std::vector<int32_t> hc;
-        int64_t codes = 0;
+        HIPCK(hipEventRecord(ev[4], st));
+        h->launches += (h->n_csr > 0) ? 1 : 0;
         if (ivf) {
-            hc.resize((size_t)nq * h->w);
-            HIPCK(hipMemcpy(hc.data(), d_cells, hc.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-            for (int32_t c : hc)
-                if (c >= 0) codes += h->h_off[(size_t)c + 1] - h->h_off[(size_t)c];
+            const long long tot = (long long)nq * h->w;
+            hipLaunchKernelGGL(k_count_codes, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_cells, h->d_off, tot, h->d_counters);
         } else {
-            codes = nq * h->n_csr;
+            h->host_codes += nq * h->n_csr;
         }
-        h->stats.scan_codes += codes;
-        if (mode == 0) {
-            std::vector<int32_t> hf((size_t)nq);
-            HIPCK(hipMemcpy(hf.data(), h->ws_flag.p, hf.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-            for (int32_t f : hf) h->stats.tie_fallbacks += f ? 1 : 0;
-        }
+        if (mode == 0)
+            hipLaunchKernelGGL(k_count_flags, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, h->ws_flag.p, (long long)nq, h->d_counters + 1);
+        HIPCK(hipGetLastError());
     }
     return MMIDX_OK;
 }
@@ -503,7 +505,6 @@ int search_common(mmidx_index *h, int k, int64_t nq, const double *dQ, const int
     SearchPlan pl;
     rc = make_plan(h, k, nq, pl);
     if (rc) return rc;
-    if (h->profiling) h->stats = mmidx_stats{};
     for (int64_t q0 = 0; q0 < nq; q0 += pl.qb) {
         const int64_t nb = std::min<int64_t>(pl.qb, nq - q0);
         rc = search_batch_device(h, pl, k, nb, dQ + (size_t)q0 * h->D, d_cells ? d_cells + (size_t)q0 * h->w : nullptr, mode,
@@ -561,7 +562,10 @@ int mmidx_create(int kind, int D, int m, int ks, int C, int transform, const int
         delete h;
         return fail(MMIDX_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
     }
-    for (auto &ev : h->ev) (void)hipEventCreate(&ev);
+    if (hipMalloc((void **)&h->d_counters, 2 * sizeof(u64)) != hipSuccess || hipMemset(h->d_counters, 0, 2 * sizeof(u64)) != hipSuccess) {
+        delete h;
+        return fail(MMIDX_ERR_HIP, "hipMalloc failed");
+    }
     if (transform == MMIDX_TR_PERMUTATION) {
         std::vector<int32_t> p((size_t)D);
         if (perm) {
@@ -610,8 +614,9 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_ecode.release();
     h->ws_tmp.release();
     h->ws_dest.release();
-    for (auto &ev : h->ev)
+    for (auto &ev : h->evpool)
         if (ev) (void)hipEventDestroy(ev);
+    if (h->d_counters) (void)hipFree(h->d_counters);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MMIDX_OK;
@@ -933,13 +938,69 @@ int mmidx_merge_partials_device(int device, int k, int64_t nq, int nshards, cons
 
 int mmidx_set_profiling(mmidx_index *h, int enabled) {
     if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    int rc = set_device(h);
+    if (rc) return rc;
+    HIPCK(hipDeviceSynchronize());
     h->profiling = enabled != 0;
     h->stats = mmidx_stats{};
+    h->ev_used = 0;
+    h->host_codes = 0;
+    h->launches = 0;
+    HIPCK(hipMemset(h->d_counters, 0, 2 * sizeof(u64)));
     return MMIDX_OK;
 }
+
+// Resolves every event recorded since the last call (synchronises with the launch stream) and
+// returns the accumulated statistics; the accumulation restarts afterwards.
 int mmidx_get_stats(mmidx_index *h, mmidx_stats *out) {
     if (!h || !out) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
-    *out = h->stats;
+    int rc = set_device(h);
+    if (rc) return rc;
+    mmidx_stats s{};
+    if (h->ev_used) HIPCK(hipEventSynchronize(h->evpool[h->ev_used - 1]));
+    HIPCK(hipDeviceSynchronize());
+    for (size_t g = 0; g + 5 <= h->ev_used; g += 5) {
+        hipEvent_t *ev = h->evpool.data() + g;
+        float a = 0, b = 0, c = 0, t = 0;
+        HIPCK(hipEventElapsedTime(&a, ev[0], ev[1]));
+        HIPCK(hipEventElapsedTime(&b, ev[2], ev[3]));
+        HIPCK(hipEventElapsedTime(&c, ev[3], ev[4]));
+        HIPCK(hipEventElapsedTime(&t, ev[0], ev[4]));
+        s.coarse_ms += a;
+        s.scan_ms += b;
+        s.merge_ms += c;
+        s.total_ms += t;
+    }
+    u64 cnt[2] = {0, 0};
+    HIPCK(hipMemcpy(cnt, h->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));
+    s.scan_codes = (int64_t)cnt[0] + h->host_codes;
+    s.tie_fallbacks = (int32_t)cnt[1];
+    s.scan_launches = h->launches;
+    *out = s;
+    h->ev_used = 0;
+    h->host_codes = 0;
+    h->launches = 0;
+    HIPCK(hipMemset(h->d_counters, 0, 2 * sizeof(u64)));
+    return MMIDX_OK;
+}
+
+/* snapshot of the in-memory index, list-major (the layout loadIndexInMemory builds) */
+int mmidx_export(mmidx_index *h, int64_t *list_off_out, int32_t *iids_out, void *codes_out) {
+    if (!h || !list_off_out) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    int rc = mmidx_sync_index(h);
+    if (rc) return rc;
+    for (int c = 0; c <= h->nlists; c++) list_off_out[c] = h->h_off[(size_t)c];
+    const int64_t n = h->n_csr;
+    if (n == 0) return MMIDX_OK;
+    if (iids_out) HIPCK(hipMemcpy(iids_out, h->d_ids, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (codes_out) {
+        const size_t bytes = (size_t)n * h->m * h->code_bytes;
+        HIPCK(hipMemcpy(codes_out, h->d_codes, bytes, hipMemcpyDeviceToHost));
+        if (h->code_bytes == 1) {  // stored form idx - 128 (PQ.java:555)
+            unsigned char *c = (unsigned char *)codes_out;
+            for (size_t t = 0; t < bytes; t++) c[t] = (unsigned char)(c[t] ^ 0x80);
+        }
+    }
     return MMIDX_OK;
 }
 

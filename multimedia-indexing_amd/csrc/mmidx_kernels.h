@@ -986,3 +986,27 @@ __global__ void k_unbias_codes(const signed char *in, unsigned char *out, long l
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < n) out[e] = (unsigned char)((int)in[e] + 128);
 }
+
+// ------------------------------------------------------------------------------------------------
+// instrumentation (profiling mode only): algorithmic work of a launch = sum over (query, probe) of
+// the probed list lengths; number of queries that needed the tie replay.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_count_codes(const int32_t *__restrict__ cells, const int64_t *__restrict__ list_off,
+                              long long n, u64 *__restrict__ total) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 v = 0;
+    if (e < n) {
+        const int c = cells[e];
+        if (c >= 0) v = (u64)(list_off[c + 1] - list_off[c]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(total, v);
+}
+__global__ void k_count_flags(const int32_t *__restrict__ flag, long long n, u64 *__restrict__ total) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 v = (e < n && flag[e]) ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(total, v);
+}

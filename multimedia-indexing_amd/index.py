@@ -252,6 +252,17 @@ class _PQBase(AbstractSearchStructure):
         # computeKnnIVFSDC returns null in the reference (IVFPQ.java:509-511).
         raise MmidxError(N.ERR_UNSUPPORTED, "id queries (SDC) are not implemented on the GPU path yet")
 
+    def export(self):
+        """List-major snapshot (list_off [nlists+1], iids [n], codes [n][m] stored form)."""
+        nl = self.numCoarseCentroids if self._kind == N.KIND_IVFPQ else 1
+        off = np.zeros(nl + 1, np.int64)
+        N.check(N.lib().mmidx_export(self._h, off.ctypes.data, None, None))
+        n = int(off[-1])
+        iids = np.zeros(n, np.int32)
+        codes = np.zeros((n, self.numSubVectors), self._code_dtype)
+        N.check(N.lib().mmidx_export(self._h, off.ctypes.data, iids.ctypes.data, codes.ctypes.data))
+        return off, iids, codes
+
     def size(self):
         n = C.c_int64()
         N.check(N.lib().mmidx_size(self._h, C.byref(n)))

@@ -407,6 +407,32 @@ int mmo_index_add_code(mmo_index *ix, int iid, int cell, const int *code) {
     return iid;
 }
 
+int mmo_index_load_lists(mmo_index *ix, int nlists, const int64_t *off, const int32_t *iids,
+                         const void *codes) {
+    if (nlists != ix->nlists) return -1;
+    for (int c = 0; c < nlists; c++) {
+        mmo_list *L = &ix->lists[c];
+        const int64_t b = off[c], n = off[c + 1] - off[c];
+        if (n == 0) continue;
+        const int64_t need = L->len + n;
+        L->iids = (int *)realloc(L->iids, sizeof(int) * (size_t)need);
+        memcpy(L->iids + L->len, iids + b, sizeof(int) * (size_t)n);
+        if (ix->ks <= 256) {
+            L->bcodes = (int8_t *)realloc(L->bcodes, (size_t)need * ix->m);
+            memcpy(L->bcodes + (size_t)L->len * ix->m, (const int8_t *)codes + (size_t)b * ix->m,
+                   (size_t)n * ix->m);
+        } else {
+            L->scodes = (int16_t *)realloc(L->scodes, sizeof(int16_t) * (size_t)need * ix->m);
+            memcpy(L->scodes + (size_t)L->len * ix->m, (const int16_t *)codes + (size_t)b * ix->m,
+                   sizeof(int16_t) * (size_t)n * ix->m);
+        }
+        L->len = (int)need;
+        L->cap = (int)need;
+        ix->load_counter += (int)n;
+    }
+    return 0;
+}
+
 int mmo_index_add_vector(mmo_index *ix, const double *v) {
     int cell;
     int *code = (int *)malloc(sizeof(int) * (size_t)ix->m);

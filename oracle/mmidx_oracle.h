@@ -88,6 +88,10 @@ int mmo_index_add_vector(mmo_index *ix, const double *v);
 /* indexPQCode (IVFPQ.java:357-386) / loadIndexInMemory (:680-728): append a precomputed code.
  * code = centroid indices 0..ks-1. */
 int mmo_index_add_code(mmo_index *ix, int iid, int cell, const int *code);
+/* bulk form of loadIndexInMemory (IVFPQ.java:680-728 / PQ.java:436-483): nlists lists given
+ * list-major: off[nlists+1], iids[n], codes[n][m] in the STORED form (int8 idx-128 / int16). */
+int mmo_index_load_lists(mmo_index *ix, int nlists, const int64_t *off, const int32_t *iids,
+                         const void *codes);
 /* Java-side stored byte of centroid index idx: PQ.transformToByte, PQ.java:552-558 */
 int8_t mmo_transform_to_byte(int idx);
 

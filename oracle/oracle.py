@@ -62,6 +62,7 @@ def lib():
         "mmo_index_add_vector": (C.c_int, [vp, dp]),
         "mmo_index_add_code": (C.c_int, [vp, C.c_int, C.c_int, ip]),
         "mmo_transform_to_byte": (C.c_int8, [C.c_int]),
+        "mmo_index_load_lists": (C.c_int, [vp, C.c_int, vp, vp, vp]),
         "mmo_index_search": (C.c_int, [vp, C.c_int, dp, ip, dp]),
         "mmo_index_nearest_coarse": (None, [vp, dp, C.c_int, ip]),
         "mmo_index_lookup_adc": (None, [vp, dp, dp]),
@@ -267,6 +268,17 @@ class OracleIndex:
         codes = np.ascontiguousarray(codes, np.int32)
         for i in range(len(iids)):
             self.add_code(iids[i], cells[i] if cells is not None else -1, codes[i])
+
+    def load_lists(self, off, iids, codes_stored):
+        """Bulk loadIndexInMemory: list-major arrays, codes in the stored form."""
+        off = np.ascontiguousarray(off, np.int64)
+        iids = np.ascontiguousarray(iids, np.int32)
+        dt = np.int8 if self.ks <= 256 else np.int16
+        codes = np.ascontiguousarray(codes_stored, dt)
+        rc = lib().mmo_index_load_lists(self._h, len(off) - 1, off.ctypes.data, iids.ctypes.data,
+                                        codes.ctypes.data)
+        if rc:
+            raise ValueError("list count mismatch")
 
     def search(self, q, k):
         q, qp = _d(q)
