@@ -117,7 +117,7 @@ struct mmidx_index {
 
     // workspaces
     DevBuf<double> ws_Q, ws_cdist, ws_odist, ws_X;
-    DevBuf<int32_t> ws_cells, ws_oiid, ws_ocnt, ws_flag, ws_ecell;
+    DevBuf<int32_t> ws_cells, ws_oiid, ws_ocnt, ws_flag, ws_ecell, ws_pcount, ws_pstart, ws_pcursor, ws_order;
     DevBuf<u64> ws_T, ws_pkey, ws_pval;
     DevBuf<u32> ws_pcnt;
     DevBuf<unsigned char> ws_ecode, ws_tmp;
@@ -340,7 +340,7 @@ int make_plan(mmidx_index *h, int k, int64_t nq, SearchPlan &pl) {
     int64_t poolq = (int64_t)pl.nitems * pl.K1;
     pl.poolq = (int)std::min<int64_t>(poolq, std::max<int64_t>(h->n_csr, pl.K1));
     // sub-batch so that the pool stays <= 2 GiB and the coarse matrix <= 1 GiB
-    int64_t qb = std::min<int64_t>(nq, 65535);
+    int64_t qb = std::min<int64_t>(nq, (int64_t)(1 << 30) / std::max(nprobe, 1));
     const int64_t pool_bytes_q = (int64_t)pl.poolq * 16;
     qb = std::min<int64_t>(qb, std::max<int64_t>(1, (2ll << 30) / std::max<int64_t>(pool_bytes_q, 1)));
     if (ivf) qb = std::min<int64_t>(qb, std::max<int64_t>(1, (1ll << 30) / ((int64_t)h->C * 8)));
@@ -422,11 +422,44 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
     P.cap = pl.cap;
     P.poolq = pl.poolq;
     if (h->n_csr > 0) {
-        dim3 grid((unsigned)pl.nchunks, (unsigned)P.w, (unsigned)nq);
+        // pass B order: pairs with probe rank >= 1 sorted by cell (device counting sort)
+        const long long npairs = (long long)nq * P.w;
+        const bool two_pass = ivf && P.w > 1;
+        if (two_pass) {
+            HIPCK(h->ws_pcount.reserve((size_t)h->C));
+            HIPCK(h->ws_pstart.reserve((size_t)h->C + 1));
+            HIPCK(h->ws_pcursor.reserve((size_t)h->C));
+            HIPCK(h->ws_order.reserve((size_t)npairs));
+            HIPCK(hipMemsetAsync(h->ws_pcount.p, 0, (size_t)h->C * sizeof(int32_t), st));
+            const unsigned g = (unsigned)((npairs + 255) / 256);
+            hipLaunchKernelGGL(k_pair_hist, dim3(g), dim3(256), 0, st, d_cells, P.w, 1, npairs, h->ws_pcount.p);
+            hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, h->C, h->ws_pstart.p, h->ws_pcursor.p);
+            hipLaunchKernelGGL(k_pair_scatter, dim3(g), dim3(256), 0, st, d_cells, P.w, 1, npairs, h->ws_pstart.p, h->ws_pcursor.p,
+                               h->ws_order.p);
+            HIPCK(hipGetLastError());
+        }
         if (prof) HIPCK(hipEventRecord(ev[2], st));
-        int rc = launch_scan(h, P, grid, pl.lds, st);
+        // pass A: probe rank 0 of every query (all of them for PQ) -- fixes a tight threshold
+        P.order = nullptr;
+        P.rank_lo = 0;
+        P.nrank = two_pass ? 1 : P.w;
+        P.n_items = (int)(nq * P.nrank);
+        P.xcd_remap = 0;
+        int rc = launch_scan(h, P, dim3((unsigned)P.n_items, (unsigned)pl.nchunks), pl.lds, st);
         if (rc) return rc;
+        if (two_pass) {
+            // pass B: the other pairs, list-major.  Empty probe slots (cell < 0) are not in the
+            // order array; the tail items read stale ids only past n_items -> bounded by count.
+            P.order = h->ws_order.p;
+            P.n_order = h->ws_pstart.p + h->C;
+            P.n_items = (int)(nq * (P.w - 1));
+            P.xcd_remap = 1;
+            const unsigned gx = (unsigned)(((P.n_items + 7) / 8) * 8);
+            rc = launch_scan(h, P, dim3(gx, (unsigned)pl.nchunks), pl.lds, st);
+            if (rc) return rc;
+        }
         if (prof) HIPCK(hipEventRecord(ev[3], st));
+        if (prof) h->launches += two_pass ? 2 : 1;
     } else if (prof) {
         HIPCK(hipEventRecord(ev[2], st));
         HIPCK(hipEventRecord(ev[3], st));
@@ -473,7 +506,6 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
     }
     if (prof) {
         HIPCK(hipEventRecord(ev[4], st));
-        h->launches += (h->n_csr > 0) ? 1 : 0;
         if (ivf) {
             const long long tot = (long long)nq * h->w;
             hipLaunchKernelGGL(k_count_codes, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_cells, h->d_off, tot, h->d_counters);
@@ -607,6 +639,10 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_ocnt.release();
     h->ws_flag.release();
     h->ws_ecell.release();
+    h->ws_pcount.release();
+    h->ws_pstart.release();
+    h->ws_pcursor.release();
+    h->ws_order.release();
     h->ws_T.release();
     h->ws_pkey.release();
     h->ws_pval.release();

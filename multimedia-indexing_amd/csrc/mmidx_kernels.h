@@ -210,6 +210,12 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select(const double *__r
 // which is pruned to the K1 = k+1 smallest by (distance, position) when it fills; every prune
 // publishes a tighter T with atomicMin.  At the end the block appends its <= K1 survivors to the
 // query's pool; k_merge sorts the pool.  Stale T only costs work, never correctness.
+//
+// Work order: items are (query, probe) pairs.  Pass A takes probe rank 0 of every query (the
+// nearest cell, which fixes a tight T); pass B takes the remaining pairs sorted by cell
+// (k_pair_*), so that the blocks scanning one inverted list run back to back and re-read its
+// codes from the XCD's L2 instead of HBM; the block -> item map sends consecutive items to the
+// same XCD (blocks are dispatched round-robin over the 8 XCDs).
 // ------------------------------------------------------------------------------------------------
 struct ScanParams {
     const double *Q;         // [nq][D]
@@ -220,18 +226,23 @@ struct ScanParams {
     const int32_t *cells;    // [nq][w] (IVFPQ) or null (PQ)
     const int64_t *list_off; // [nlists+1]
     const void *codes;       // [n][m] CodeT
+    const int32_t *order;    // sorted pair ids (q*w + rank) or null = natural order
+    const int32_t *n_order;  // device count of valid entries in order[]
     u64 *T;                  // [nq]
     u32 *pool_cnt;           // [nq]
     u64 *pool_key;           // [nq][poolq]
     u64 *pool_val;           // [nq][poolq]  probe_rank << 32 | position in list
     int D, m, ks, dsub, w, transform, ivf;
+    int n_items;             // items of this launch
+    int rank_lo, nrank;      // natural order: item -> (q = item / nrank, rank = rank_lo + item % nrank)
+    int xcd_remap;           // 1: consecutive items -> same XCD
     int chunk;               // codes per work item
     int K1;                  // k + 1
-    int cap;                 // LDS candidate capacity (power of two, >= K1 + SEG)
+    int cap;                 // LDS candidate capacity (>= K1 + SEG, power of two)
     int poolq;
 };
 
-#define MMIDX_SEGU 4  // codes per thread per segment
+#define MMIDX_SEGU 2  // codes per thread per segment
 #define MMIDX_SEG (MMIDX_BLOCK * MMIDX_SEGU)
 
 template <int M, typename CodeT>
@@ -295,18 +306,122 @@ __device__ __forceinline__ void scan_prune(u64 *bkey, u32 *bval, u32 *s_cnt, int
     __syncthreads();
 }
 
+// LUT[s][j] for idx = s*ks + j; the dsub loads of an entry are issued together (they are
+// L2-resident: the transposed codebook is 256 KiB) and two entries are in flight per thread.
+template <int DSUB>
+__device__ __forceinline__ void build_lut(double *lut, const double *tr, const double *__restrict__ pqT, int m,
+                                          int ks, int dsub_rt) {
+    const int total = m * ks;
+    if constexpr (DSUB > 0) {
+#pragma unroll 2
+        for (int idx = threadIdx.x; idx < total; idx += MMIDX_BLOCK) {
+            const int s = idx / ks, j = idx - s * ks;
+            const double *pp = pqT + (size_t)s * DSUB * ks + j;
+            double pv[DSUB];
+#pragma unroll
+            for (int t = 0; t < DSUB; t++) pv[t] = pp[(size_t)t * ks];
+            const double *tv = tr + s * DSUB;
+            double acc = 0.0;
+#pragma unroll
+            for (int t = 0; t < DSUB; t++) {
+                const double df = tv[t] - pv[t];
+                acc += df * df;
+            }
+            lut[idx] = acc;
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < total; idx += MMIDX_BLOCK) {
+            const int s = idx / ks, j = idx - s * ks;
+            const double *pp = pqT + (size_t)s * dsub_rt * ks + j;
+            const double *tv = tr + s * dsub_rt;
+            double acc = 0.0;
+            int t = 0;
+            for (; t + 4 <= dsub_rt; t += 4) {
+                const double p0 = pp[(size_t)t * ks], p1 = pp[(size_t)(t + 1) * ks], p2 = pp[(size_t)(t + 2) * ks],
+                             p3 = pp[(size_t)(t + 3) * ks];
+                double df = tv[t] - p0;
+                acc += df * df;
+                df = tv[t + 1] - p1;
+                acc += df * df;
+                df = tv[t + 2] - p2;
+                acc += df * df;
+                df = tv[t + 3] - p3;
+                acc += df * df;
+            }
+            for (; t < dsub_rt; t++) {
+                const double df = tv[t] - pp[(size_t)t * ks];
+                acc += df * df;
+            }
+            lut[idx] = acc;
+        }
+    }
+}
+
+__device__ __forceinline__ void build_lut_any(double *lut, const double *tr, const double *pqT, int m, int ks,
+                                              int dsub) {
+    switch (dsub) {
+        case 4: build_lut<4>(lut, tr, pqT, m, ks, dsub); break;
+        case 8: build_lut<8>(lut, tr, pqT, m, ks, dsub); break;
+        case 16: build_lut<16>(lut, tr, pqT, m, ks, dsub); break;
+        default: build_lut<0>(lut, tr, pqT, m, ks, dsub); break;
+    }
+}
+
+// residual (centroid - q, IVFPQ.java:645) or the query itself (PQ), then permute / rotate
+__device__ __forceinline__ double *query_vector(const ScanParams &P, int q, int cell, double *vec) {
+    const int D = P.D, tid = threadIdx.x;
+    double *r = vec, *tr = vec + D;
+    for (int i = tid; i < D; i += MMIDX_BLOCK) {
+        const double qv = P.Q[(size_t)q * D + i];
+        r[i] = P.ivf ? (P.coarse[(size_t)cell * D + i] - qv) : qv;
+    }
+    __syncthreads();
+    if (P.transform == 2) {
+        for (int i = tid; i < D; i += MMIDX_BLOCK) tr[i] = r[P.perm[i]];
+        __syncthreads();
+        return tr;
+    }
+    if (P.transform == 1) {
+        for (int j = tid; j < D; j += MMIDX_BLOCK) {
+            double total = 0.0;
+            for (int i = 0; i < D; i++) total += r[i] * P.rot[(size_t)i * D + j];
+            tr[j] = total;
+        }
+        __syncthreads();
+        return tr;
+    }
+    return r;
+}
+
 template <int M, typename CodeT>
 __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan(const ScanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int m = (M > 0) ? M : P.m;
-    const int ks = P.ks, D = P.D, dsub = P.dsub;
+    const int ks = P.ks, D = P.D;
     double *lut = (double *)smem;                 // [m*ks]
     double *vec = lut + (size_t)m * ks;           // [2*D]
     u64 *bkey = (u64 *)(vec + 2 * (size_t)D);     // [cap]
     u32 *bval = (u32 *)(bkey + P.cap);            // [cap]
     u32 *s_cnt = bval + P.cap;                    // [4]
 
-    const int q = blockIdx.z, pr = blockIdx.y, ch = blockIdx.x;
+    // ---- block -> work item ---------------------------------------------------------------------
+    int item = blockIdx.x;
+    if (P.xcd_remap) {
+        const int per = (P.n_items + 7) >> 3;
+        item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    }
+    if (item >= P.n_items) return;
+    int q, pr;
+    if (P.order) {
+        if (item >= *P.n_order) return;
+        const int e = P.order[item];
+        q = e / P.w;
+        pr = e - q * P.w;
+    } else {
+        q = item / P.nrank;
+        pr = P.rank_lo + (item - q * P.nrank);
+    }
+    const int ch = blockIdx.y;
     int cell = 0;
     if (P.ivf) {
         cell = P.cells[(size_t)q * P.w + pr];
@@ -318,74 +433,51 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan(const ScanParams P) {
     if (c0 >= len) return;
     const int64_t c1 = (c0 + P.chunk < len) ? c0 + P.chunk : len;
     const int tid = threadIdx.x;
+    const CodeT *codes = (const CodeT *)P.codes + (size_t)beg * m;
 
-    // ---- residual + transform --------------------------------------------------------------
-    double *r = vec, *tr = vec + D;
-    for (int i = tid; i < D; i += MMIDX_BLOCK) {
-        const double qv = P.Q[(size_t)q * D + i];
-        r[i] = P.ivf ? (P.coarse[(size_t)cell * D + i] - qv) : qv;
+    // first segment's codes: issued before the LUT build so that HBM latency hides under it
+    CodeVec<(M > 0 ? M : 4), CodeT> cur[MMIDX_SEGU], nxt[MMIDX_SEGU];
+    if constexpr (M > 0) {
+#pragma unroll
+        for (int u = 0; u < MMIDX_SEGU; u++) {
+            const int64_t i = c0 + u * MMIDX_BLOCK + tid;
+            cur[u].load(codes + (size_t)(i < c1 ? i : c1 - 1) * M);
+        }
     }
+
     if (tid == 0) s_cnt[0] = 0;
-    __syncthreads();
-    if (P.transform == 2) {
-        for (int i = tid; i < D; i += MMIDX_BLOCK) tr[i] = r[P.perm[i]];
-        __syncthreads();
-    } else if (P.transform == 1) {
-        for (int j = tid; j < D; j += MMIDX_BLOCK) {
-            double total = 0.0;
-            for (int i = 0; i < D; i++) total += r[i] * P.rot[(size_t)i * D + j];
-            tr[j] = total;
-        }
-        __syncthreads();
-    } else {
-        tr = r;
-    }
-    // ---- lookup table ------------------------------------------------------------------------
-    for (int idx = tid; idx < m * ks; idx += MMIDX_BLOCK) {
-        const int s = idx / ks, j = idx - s * ks;
-        const double *pp = P.pqT + (size_t)s * dsub * ks + j;
-        const double *tv = tr + s * dsub;
-        double acc = 0.0;
-        for (int t = 0; t < dsub; t++) {
-            const double df = tv[t] - pp[(size_t)t * ks];
-            acc += df * df;
-        }
-        lut[idx] = acc;
-    }
+    const double *tr = query_vector(P, q, cell, vec);
+    build_lut_any(lut, tr, P.pqT, m, ks, P.dsub);
     u64 *Tq = P.T + q;
     u64 T = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
 
     // ---- scan -----------------------------------------------------------------------------------
-    const CodeT *codes = (const CodeT *)P.codes + (size_t)beg * m;
     const int limit = P.cap - MMIDX_SEG;
     const u64 lane_lt = (1ull << (tid & 63)) - 1ull;
     for (int64_t seg = c0; seg < c1; seg += MMIDX_SEG) {
         double d[MMIDX_SEGU];
-        bool valid[MMIDX_SEGU];
+        const bool more = seg + MMIDX_SEG < c1;
         if constexpr (M > 0) {
-            CodeVec<M, CodeT> cv[MMIDX_SEGU];
+            if (more) {
 #pragma unroll
-            for (int u = 0; u < MMIDX_SEGU; u++) {
-                const int64_t i = seg + u * MMIDX_BLOCK + tid;
-                valid[u] = i < c1;
-                const int64_t ii = valid[u] ? i : c1 - 1;
-                cv[u].load(codes + (size_t)ii * M);
+                for (int u = 0; u < MMIDX_SEGU; u++) {
+                    const int64_t i = seg + MMIDX_SEG + u * MMIDX_BLOCK + tid;
+                    nxt[u].load(codes + (size_t)(i < c1 ? i : c1 - 1) * M);
+                }
             }
 #pragma unroll
             for (int u = 0; u < MMIDX_SEGU; u++) d[u] = 0.0;
 #pragma unroll
             for (int s = 0; s < M; s++) {
 #pragma unroll
-                for (int u = 0; u < MMIDX_SEGU; u++) d[u] += lut[s * ks + cv[u].get(s)];
+                for (int u = 0; u < MMIDX_SEGU; u++) d[u] += lut[s * ks + cur[u].get(s)];
             }
         } else {
 #pragma unroll
             for (int u = 0; u < MMIDX_SEGU; u++) {
                 const int64_t i = seg + u * MMIDX_BLOCK + tid;
-                valid[u] = i < c1;
-                const int64_t ii = valid[u] ? i : c1 - 1;
-                const CodeT *cp = codes + (size_t)ii * m;
+                const CodeT *cp = codes + (size_t)(i < c1 ? i : c1 - 1) * m;
                 double a = 0.0;
                 for (int s = 0; s < m; s++) a += lut[s * ks + (int)cp[s]];
                 d[u] = a;
@@ -393,8 +485,9 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan(const ScanParams P) {
         }
 #pragma unroll
         for (int u = 0; u < MMIDX_SEGU; u++) {
+            const int64_t i = seg + u * MMIDX_BLOCK + tid;
             const u64 key = dkey(d[u]);
-            const bool pass = valid[u] && key <= T;
+            const bool pass = (i < c1) && key <= T;
             const u64 mask = __ballot(pass);
             if (mask) {
                 u32 base = 0;
@@ -404,7 +497,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan(const ScanParams P) {
                 if (pass) {
                     const u32 slot = base + (u32)__popcll(mask & lane_lt);
                     bkey[slot] = key;
-                    bval[slot] = (u32)(seg + u * MMIDX_BLOCK + tid);
+                    bval[slot] = (u32)i;
                 }
             }
         }
@@ -414,6 +507,12 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan(const ScanParams P) {
         if (need) {
             scan_prune(bkey, bval, s_cnt, P.K1, Tq);
             T = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if constexpr (M > 0) {
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < MMIDX_SEGU; u++) cur[u] = nxt[u];
+            }
         }
     }
     // ---- hand the survivors to the query's pool ------------------------------------------------
@@ -439,6 +538,55 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan(const ScanParams P) {
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-batch ordering of the (query, probe rank >= rank_lo) pairs by cell: counting sort with
+// atomics.  The order inside a cell is arbitrary -- it only decides which block runs when.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pair_hist(const int32_t *__restrict__ cells, int w, int rank_lo, long long npairs,
+                            int32_t *__restrict__ cnt) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= npairs) return;
+    if ((int)(e % w) < rank_lo) return;
+    const int c = cells[e];
+    if (c >= 0) atomicAdd(cnt + c, 1);
+}
+// single block: exclusive scan of cnt[C] -> start[C]; start[C] = total; cursor zeroed
+__global__ __launch_bounds__(1024) void k_pair_scan(const int32_t *__restrict__ cnt, int C, int32_t *__restrict__ start,
+                                                    int32_t *__restrict__ cursor) {
+    __shared__ int s_part[1024];
+    const int tid = threadIdx.x;
+    const int per = (C + 1023) / 1024;
+    const int lo = tid * per, hi = (lo + per < C) ? lo + per : C;
+    int sum = 0;
+    for (int c = lo; c < hi; c++) sum += cnt[c];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = (tid >= off) ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = s_part[tid] - sum;  // exclusive prefix of this thread's range
+    for (int c = lo; c < hi; c++) {
+        start[c] = run;
+        cursor[c] = 0;
+        run += cnt[c];
+    }
+    if (tid == 1023) start[C] = s_part[1023];
+}
+__global__ void k_pair_scatter(const int32_t *__restrict__ cells, int w, int rank_lo, long long npairs,
+                               const int32_t *__restrict__ start, int32_t *__restrict__ cursor,
+                               int32_t *__restrict__ order) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= npairs) return;
+    if ((int)(e % w) < rank_lo) return;
+    const int c = cells[e];
+    if (c < 0) return;
+    const int pos = start[c] + atomicAdd(cursor + c, 1);
+    order[pos] = (int32_t)e;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -621,7 +769,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_tie_resolve(const TieParams TP)
     const int q = blockIdx.x, tid = threadIdx.x, k = TP.k;
     if (!TP.flag[q]) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int m = P.m, ks = P.ks, D = P.D, dsub = P.dsub;
+    const int m = P.m, ks = P.ks;
     double *lut = (double *)smem;
     double *vec = lut + (size_t)m * ks;
     __shared__ int s_wsum[MMIDX_BLOCK / 64][2];
@@ -650,37 +798,9 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_tie_resolve(const TieParams TP)
             const int64_t beg = P.list_off[cell];
             const int64_t len = P.list_off[cell + 1] - beg;
             if (len == 0) continue;
-            double *r = vec, *tr = vec + D;
             __syncthreads();
-            for (int i = tid; i < D; i += MMIDX_BLOCK) {
-                const double qv = P.Q[(size_t)q * D + i];
-                r[i] = P.ivf ? (P.coarse[(size_t)cell * D + i] - qv) : qv;
-            }
-            __syncthreads();
-            if (P.transform == 2) {
-                for (int i = tid; i < D; i += MMIDX_BLOCK) tr[i] = r[P.perm[i]];
-                __syncthreads();
-            } else if (P.transform == 1) {
-                for (int j = tid; j < D; j += MMIDX_BLOCK) {
-                    double total = 0.0;
-                    for (int i = 0; i < D; i++) total += r[i] * P.rot[(size_t)i * D + j];
-                    tr[j] = total;
-                }
-                __syncthreads();
-            } else {
-                tr = r;
-            }
-            for (int idx = tid; idx < m * ks; idx += MMIDX_BLOCK) {
-                const int s = idx / ks, j = idx - s * ks;
-                const double *pp = P.pqT + (size_t)s * dsub * ks + j;
-                const double *tv = tr + s * dsub;
-                double acc = 0.0;
-                for (int t = 0; t < dsub; t++) {
-                    const double df = tv[t] - pp[(size_t)t * ks];
-                    acc += df * df;
-                }
-                lut[idx] = acc;
-            }
+            const double *tr = query_vector(P, q, cell, vec);
+            build_lut_any(lut, tr, P.pqT, m, ks, P.dsub);
             __syncthreads();
             const CodeT *codes = (const CodeT *)P.codes + (size_t)beg * m;
             for (int64_t base = 0; base < len && !done; base += MMIDX_BLOCK) {
