@@ -355,7 +355,14 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
     hipLaunchKernelGGL(k_coarse_dist<QT>, g1, dim3(MMIDX_BLOCK), 0, st, h->d_coarseT, dQ, h->ws_cdist.p, h->C, h->D, (int)nq);
     const size_t lds = (size_t)(h->w + 1) * 12 + 16;
     if (lds > 64 * 1024) return fail(MMIDX_ERR_UNSUPPORTED, "w = %d too large", h->w);
-    hipLaunchKernelGGL(k_coarse_select, dim3((unsigned)nq), dim3(MMIDX_BLOCK), lds, st, h->ws_cdist.p, h->C, h->w, d_cells);
+    if (h->C <= 8 * MMIDX_BLOCK)
+        hipLaunchKernelGGL(k_coarse_select_reg<8>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), lds, st, h->ws_cdist.p, h->C, h->w, d_cells);
+    else if (h->C <= 32 * MMIDX_BLOCK)
+        hipLaunchKernelGGL(k_coarse_select_reg<32>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), lds, st, h->ws_cdist.p, h->C, h->w, d_cells);
+    else if (h->C <= 64 * MMIDX_BLOCK)
+        hipLaunchKernelGGL(k_coarse_select_reg<64>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), lds, st, h->ws_cdist.p, h->C, h->w, d_cells);
+    else
+        hipLaunchKernelGGL(k_coarse_select, dim3((unsigned)nq), dim3(MMIDX_BLOCK), lds, st, h->ws_cdist.p, h->C, h->w, d_cells);
     HIPCK(hipGetLastError());
     return MMIDX_OK;
 }

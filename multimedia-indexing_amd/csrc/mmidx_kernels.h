@@ -117,6 +117,44 @@ __device__ __forceinline__ void block_min_pair(u64 &k, int &i, u64 *s_k, int *s_
     }
 }
 
+// final step of K1b (one thread): bounded-queue tie rule + output order
+__device__ __forceinline__ void coarse_emit(const double *row, int C, int w, int rounds, u64 *sel_k, int *sel_i,
+                                            int32_t *out) {
+    int n = rounds < w ? rounds : w;
+    if (rounds == w + 1 && sel_k[w - 1] == sel_k[w]) {
+        // tie straddles the boundary: closed-form replay of the bounded queue
+        const u64 tau = sel_k[w - 1];
+        int b = 0;
+        while (b < w && sel_k[b] < tau) b++;
+        int nonjunk = 0, p = 0;
+        for (int c = 0; c < C; c++) {
+            const u64 k = dkey(row[c]);
+            if (k <= tau) {
+                nonjunk++;
+                if (k == tau) p++;
+                if (nonjunk == w) break;
+            }
+        }
+        const int e = b - (w - p);
+        int rank = 0, pos = b;
+        for (int c = 0; c < C && rank < p; c++) {
+            if (dkey(row[c]) == tau) {
+                if (rank >= e) sel_i[pos++] = c;  // kept ties, arrival order
+                rank++;
+            }
+        }
+    }
+    // emit nearest first; inside a run of equal distances later arrival (larger index) first
+    int a = 0;
+    while (a < n) {
+        int bnd = a;
+        while (bnd + 1 < n && sel_k[bnd + 1] == sel_k[a]) bnd++;
+        for (int t = a; t <= bnd; t++) out[t] = sel_i[bnd - (t - a)];
+        a = bnd + 1;
+    }
+    for (int t = n; t < w; t++) out[t] = -1;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1b: top-w selection with the bounded queue's semantics (IVFPQ.java:576-600; LingPipe queue,
 // assumption A1).  One block per query.  w+1 rounds of lexicographic (dist, index) argmin give
@@ -157,42 +195,54 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select(const double *__r
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int32_t *out = cells + (size_t)q * w;
-        int n = rounds < w ? rounds : w;
-        if (rounds == w + 1 && sel_k[w - 1] == sel_k[w]) {
-            // tie straddles the boundary: closed-form replay of the bounded queue
-            const u64 tau = sel_k[w - 1];
-            int b = 0;
-            while (b < w && sel_k[b] < tau) b++;
-            int nonjunk = 0, p = 0;
-            for (int c = 0; c < C; c++) {
-                const u64 k = dkey(row[c]);
-                if (k <= tau) {
-                    nonjunk++;
-                    if (k == tau) p++;
-                    if (nonjunk == w) break;
-                }
-            }
-            const int e = b - (w - p);
-            int rank = 0, pos = b;
-            for (int c = 0; c < C && rank < p; c++) {
-                if (dkey(row[c]) == tau) {
-                    if (rank >= e) sel_i[pos++] = c;  // kept ties, arrival order
-                    rank++;
-                }
-            }
-        }
-        // emit nearest first; inside a run of equal distances later arrival (larger index) first
-        int a = 0;
-        while (a < n) {
-            int bnd = a;
-            while (bnd + 1 < n && sel_k[bnd + 1] == sel_k[a]) bnd++;
-            for (int t = a; t <= bnd; t++) out[t] = sel_i[bnd - (t - a)];
-            a = bnd + 1;
-        }
-        for (int t = n; t < w; t++) out[t] = -1;
+    if (threadIdx.x == 0) coarse_emit(row, C, w, rounds, sel_k, sel_i, cells + (size_t)q * w);
+}
+
+// Register-resident variant of K1b for C <= 256 * PER: every thread keeps its PER distances in
+// VGPRs (coalesced load, once), so a selection round is PER compares + one block reduction instead
+// of a sweep over global memory.  Same result, including the tie rule (the rare straddling-tie
+// replay re-reads the row from memory).
+template <int PER>
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_reg(const double *__restrict__ dist, int C, int w,
+                                                                   int32_t *__restrict__ cells) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *sel_k = (u64 *)smem;                   // [w+1]
+    int *sel_i = (int *)(sel_k + (w + 1));      // [w+1]
+    __shared__ u64 s_k[MMIDX_BLOCK / 64];
+    __shared__ int s_i[MMIDX_BLOCK / 64];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const double *row = dist + (size_t)q * C;
+    u64 key[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int c = tid + i * MMIDX_BLOCK;
+        key[i] = (c < C) ? dkey(row[c]) : MMIDX_KEY_MAX;
     }
+    const int rounds = (w + 1 < C) ? w + 1 : C;
+    for (int r = 0; r < rounds; r++) {
+        u64 bk = MMIDX_KEY_MAX;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int c = tid + i * MMIDX_BLOCK;
+            if (c < C && key[i] < bk) {  // c ascending in i: strict '<' keeps the lowest index among equals
+                bk = key[i];
+                bi = c;
+            }
+        }
+        // a selected entry is retired by setting its key to KEY_MAX; a genuine KEY_MAX distance
+        // (NaN with all mantissa bits) cannot be told apart and is never selected
+        block_min_pair(bk, bi, s_k, s_i);
+#pragma unroll
+        for (int i = 0; i < PER; i++)
+            if (tid + i * MMIDX_BLOCK == bi) key[i] = MMIDX_KEY_MAX;
+        if (tid == 0) {
+            sel_k[r] = bk;
+            sel_i[r] = bi;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) coarse_emit(row, C, w, rounds, sel_k, sel_i, cells + (size_t)q * w);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,206 @@
+package gr.iti.mklab.visual.datastructures;
+
+import gr.iti.mklab.visual.aggregation.AbstractFeatureAggregator;
+import gr.iti.mklab.visual.datastructures.PQ.TransformationType;
+import gr.iti.mklab.visual.utilities.Result;
+
+import java.io.BufferedReader;
+import java.io.File;
+import java.io.FileReader;
+
+import com.aliasi.util.BoundedPriorityQueue;
+import com.sleepycat.bind.tuple.IntegerBinding;
+import com.sleepycat.bind.tuple.TupleBinding;
+import com.sleepycat.bind.tuple.TupleInput;
+import com.sleepycat.bind.tuple.TupleOutput;
+import com.sleepycat.je.Cursor;
+import com.sleepycat.je.Database;
+import com.sleepycat.je.DatabaseConfig;
+import com.sleepycat.je.DatabaseEntry;
+import com.sleepycat.je.LockMode;
+import com.sleepycat.je.OperationStatus;
+
+/**
+ * Drop-in for {@link IVFPQ}: same constructors and public methods, identity (ids, BDB) stays in
+ * Java, vectors-as-codes and search live in the HBM of an MI355X behind libmmidx_hip.so. The five
+ * template-method hooks of AbstractSearchStructure (ASS:267, 305, 342, 729, 755) are the only
+ * places that differ from IVFPQ.java; each one is a single native call.
+ */
+public class GpuIVFPQ extends AbstractSearchStructure {
+
+	private final long handle;
+	private final int numSubVectors, numProductCentroids, numCoarseCentroids;
+	private final Database iidToIvfpqDB;
+
+	public GpuIVFPQ(int vectorLength, int maxNumVectors, boolean readOnly, String BDBEnvHome, int numSubVectors,
+			int numProductCentroids, TransformationType transformation, int numCoarseCentroids,
+			boolean countSizeOnLoad, int loadCounter, boolean loadIndexInMemory, long cacheSize) throws Exception {
+		super(vectorLength, maxNumVectors, readOnly, countSizeOnLoad, loadCounter, loadIndexInMemory, cacheSize);
+		if (vectorLength % numSubVectors > 0) { // IVFPQ.java:181-183 (also checked natively)
+			throw new Exception("The given number of subvectors is not valid!");
+		}
+		this.numSubVectors = numSubVectors;
+		this.numProductCentroids = numProductCentroids;
+		this.numCoarseCentroids = numCoarseCentroids;
+		double[] rotation = null;
+		if (transformation == TransformationType.RandomRotation) {
+			// EJML's createOrthogonal stream cannot be re-derived natively: compute it here, as
+			// RandomRotation.java:30-35 does, and hand the D x D matrix over once.
+			rotation = org.ejml.ops.RandomMatrices.createOrthogonal(vectorLength, vectorLength,
+					new java.util.Random(1)).getData();
+		}
+		// RandomPermutation(seed = 1, D) is derived natively with the JDK LCG (permutation == null)
+		handle = MmidxNative.create(MmidxNative.KIND_IVFPQ, vectorLength, numSubVectors, numProductCentroids,
+				numCoarseCentroids, transformation.ordinal(), null, rotation, Integer.getInteger("mmidx.device", 0));
+		createOrOpenBDBEnvAndDbs(BDBEnvHome);
+		DatabaseConfig dbConf = new DatabaseConfig();
+		dbConf.setReadOnly(readOnly);
+		dbConf.setTransactional(transactional);
+		dbConf.setAllowCreate(true);
+		iidToIvfpqDB = dbEnv.openDatabase(null, "ivfadc", dbConf); // same db name as IVFPQ.java:203
+		if (loadIndexInMemory) {
+			loadIndexInMemory();
+		}
+	}
+
+	public GpuIVFPQ(int vectorLength, int maxNumVectors, boolean readOnly, String BDBEnvHome, int numSubVectors,
+			int numProductCentroids, TransformationType transformation, int numCoarseCentroids, long cacheSize)
+			throws Exception {
+		this(vectorLength, maxNumVectors, readOnly, BDBEnvHome, numSubVectors, numProductCentroids, transformation,
+				numCoarseCentroids, true, 0, true, cacheSize);
+	}
+
+	public void setW(int w) throws Exception { // IVFPQ.java:95-97
+		MmidxNative.setW(handle, w);
+	}
+
+	public void loadCoarseQuantizer(String filename) throws Exception { // IVFPQ.java:297-300
+		double[][] cq = AbstractFeatureAggregator.readQuantizer(filename, numCoarseCentroids, vectorLength);
+		double[] flat = new double[numCoarseCentroids * vectorLength];
+		for (int i = 0; i < numCoarseCentroids; i++)
+			System.arraycopy(cq[i], 0, flat, i * vectorLength, vectorLength);
+		MmidxNative.setCoarse(handle, flat);
+	}
+
+	public void loadProductQuantizer(String filename) throws Exception { // IVFPQ.java:275-288
+		int dsub = vectorLength / numSubVectors;
+		double[] flat = new double[numSubVectors * numProductCentroids * dsub];
+		BufferedReader in = new BufferedReader(new FileReader(new File(filename)));
+		for (int i = 0; i < numSubVectors * numProductCentroids; i++) {
+			String[] s = in.readLine().split(",");
+			for (int k = 0; k < dsub; k++)
+				flat[i * dsub + k] = Double.parseDouble(s[k]);
+		}
+		in.close();
+		MmidxNative.setPq(handle, flat);
+	}
+
+	/** hook 1 (ASS:267): encode on the GPU, append there, persist the same record as IVFPQ.java:760-772 */
+	protected void indexVectorInternal(double[] vector) throws Exception {
+		if (vector.length != vectorLength) {
+			throw new Exception("The dimensionality of the vector is wrong!");
+		}
+		int[] cell = new int[1];
+		byte[] code = new byte[numSubVectors];
+		MmidxNative.addVector(handle, loadCounter, vector, cell, code);
+		appendPersistentIndex(cell[0], code);
+	}
+
+	public synchronized boolean indexPQCode(String id, int listId, byte[] code) throws Exception { // IVFPQ.java:357-386
+		if (numProductCentroids > 256) {
+			throw new Exception("Byte is not sufficient to enumerate the centroids of the product quantizer!");
+		}
+		if (loadCounter >= maxNumVectors) {
+			System.out.println("Maximum index capacity reached, no more vectors can be indexed!");
+			return false;
+		}
+		if (isIndexed(id)) {
+			System.out.println("Vector '" + id + "' already indexed!");
+			return false;
+		}
+		createMapping(id);
+		MmidxNative.addCodes(handle, 1, new int[] { loadCounter }, new int[] { listId }, code);
+		appendPersistentIndex(listId, code);
+		loadCounter++;
+		return true;
+	}
+
+	/** hook 2 (ASS:305): one native call; the queue is rebuilt only to satisfy the hook's type */
+	protected BoundedPriorityQueue<Result> computeNearestNeighborsInternal(int k, double[] query) throws Exception {
+		int[] iids = new int[k];
+		double[] dists = new double[k];
+		int[] count = new int[1];
+		MmidxNative.search(handle, k, 1, query, iids, dists, count);
+		BoundedPriorityQueue<Result> nn = new BoundedPriorityQueue<Result>(new Result(), k);
+		for (int i = count[0] - 1; i >= 0; i--) // worst first: keeps the queue's tie order
+			nn.offer(new Result(iids[i], dists[i]));
+		return nn;
+	}
+
+	/** hook 3 (ASS:342): IVFPQ.computeKnnIVFSDC returns null in the reference (IVFPQ.java:509-511) */
+	protected BoundedPriorityQueue<Result> computeNearestNeighborsInternal(int k, int iid) throws Exception {
+		return null;
+	}
+
+	/** loadIndexInMemory IVFPQ.java:680-728: stream the BDB records to the native bulk add */
+	private void loadIndexInMemory() throws Exception {
+		final int B = 1 << 16;
+		int[] iids = new int[B], cells = new int[B];
+		byte[] codes = new byte[B * numSubVectors];
+		int n = 0;
+		DatabaseEntry key = new DatabaseEntry(), data = new DatabaseEntry();
+		Cursor cursor = iidToIvfpqDB.openCursor(null, null);
+		while (cursor.getNext(key, data, LockMode.DEFAULT) == OperationStatus.SUCCESS) {
+			TupleInput input = TupleBinding.entryToInput(data);
+			cells[n] = input.readInt();
+			iids[n] = IntegerBinding.entryToInt(key);
+			for (int i = 0; i < numSubVectors; i++)
+				codes[n * numSubVectors + i] = input.readByte();
+			if (++n == B) {
+				MmidxNative.addCodes(handle, n, iids, cells, codes);
+				n = 0;
+			}
+		}
+		cursor.close();
+		if (n > 0)
+			MmidxNative.addCodes(handle, n, java.util.Arrays.copyOf(iids, n), java.util.Arrays.copyOf(cells, n),
+					java.util.Arrays.copyOf(codes, n * numSubVectors));
+	}
+
+	private void appendPersistentIndex(int listId, byte[] code) { // IVFPQ.java:760-772, unchanged
+		TupleOutput output = new TupleOutput();
+		output.writeInt(listId);
+		for (int i = 0; i < numSubVectors; i++)
+			output.writeByte(code[i]);
+		DatabaseEntry data = new DatabaseEntry();
+		TupleBinding.outputToEntry(output, data);
+		DatabaseEntry key = new DatabaseEntry();
+		IntegerBinding.intToEntry(loadCounter, key);
+		iidToIvfpqDB.put(null, key, data);
+	}
+
+	public void outputItemsPerList() throws Exception { // IVFPQ.java:654-673
+		int[] sizes = new int[numCoarseCentroids];
+		MmidxNative.listSizes(handle, sizes);
+		int max = 0, min = Integer.MAX_VALUE;
+		double sum = 0;
+		for (int s : sizes) {
+			max = Math.max(max, s);
+			min = Math.min(min, s);
+			sum += s;
+		}
+		System.out.println("Maximum number of vectors: " + max);
+		System.out.println("Minimum number of vectors: " + min);
+		System.out.println("Average number of vectors: " + (sum / numCoarseCentroids));
+	}
+
+	@Override
+	public void outputIndexingTimesInternal() { // hook 4 (ASS:729)
+	}
+
+	@Override
+	public void closeInternal() { // hook 5 (ASS:755)
+		iidToIvfpqDB.close();
+		MmidxNative.destroy(handle);
+	}
+}

@@ -277,3 +277,41 @@ def test_large_batch_properties(mi):
     recall1 = np.mean(i1[:, 0] == qi)
     assert recall1 > 0.8, recall1
     ix.close()
+
+
+def _coarse_cells(mi, ix, Q):
+    """computeNearestCoarseIndices through the device entry point (torch only holds the buffers)."""
+    import torch
+
+    nat = importlib.import_module("multimedia-indexing_amd._native")
+    dQ = torch.tensor(np.ascontiguousarray(Q), dtype=torch.float64, device="cuda")
+    w = ix.getW()
+    cells = torch.empty(dQ.shape[0], w, dtype=torch.int32, device="cuda")
+    nat.check(mi.lib().mmidx_coarse_device(ix._h, dQ.shape[0], dQ.data_ptr(), cells.data_ptr(), None))
+    torch.cuda.synchronize()
+    return cells.cpu().numpy()
+
+
+@pytest.mark.parametrize("C", [12, 300, 2500])
+def test_coarse_topw_with_duplicate_centroids(mi, oracle, C):
+    """FLAGGED tie fixture for the coarse stage: duplicated centroids give exactly equal
+    distances; the probe order / choice must follow the bounded queue (IVFPQ.java:576-600)."""
+    D, m, ks = 8, 2, 16
+    rng = np.random.default_rng(C)
+    coarse = rng.standard_normal((C, D))
+    dup = rng.integers(0, C // 3, size=C // 2)          # half of the rows duplicate an earlier row
+    coarse[C // 2:C // 2 + len(dup)] = coarse[dup]
+    pq = rng.standard_normal((m, ks, D // m))
+    ix = mi.IVFPQ(D, 10, False, "", m, ks, 0, C, 512)
+    ix.loadCoarseQuantizer(coarse)
+    ix.loadProductQuantizer(pq)
+    ref = oracle.OracleIndex(oracle.KIND_IVFPQ, D, m, ks, C)
+    ref.set_coarse(coarse)
+    ref.set_pq(pq)
+    Q = np.concatenate([rng.standard_normal((24, D)), coarse[dup[:8]] + 1e-3])
+    for w in (1, 2, 3, 5, C // 2, C - 1, C):
+        ix.setW(w)
+        got = _coarse_cells(mi, ix, Q)
+        exp = np.stack([ref.nearest_coarse(q, w) for q in Q])
+        assert np.array_equal(got, exp), w
+    ix.close()
