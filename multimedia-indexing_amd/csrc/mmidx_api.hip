@@ -96,6 +96,7 @@ struct mmidx_index {
     int nlists = 1;
     size_t code_bytes = 1;  // per sub-quantizer
     bool coarse_set = false, pq_set = false;
+    bool no_filter = false;  // MMIDX_NO_FILTER=1: exact scan only (A/B switch for measurements)
     hipStream_t stream = nullptr;
     std::mutex mu;
 
@@ -314,6 +315,9 @@ int launch_scan(const mmidx_index *h, const ScanParams &P, dim3 grid, size_t lds
     }
 }
 
+struct SearchPlan;
+int launch_scan_filtered(const mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 grid, hipStream_t st);
+
 struct SearchPlan {
     int K1, cap, chunk, nchunks, nitems, poolq;
     size_t lds;
@@ -346,6 +350,31 @@ int make_plan(mmidx_index *h, int k, int64_t nq, SearchPlan &pl) {
     if (ivf) qb = std::min<int64_t>(qb, std::max<int64_t>(1, (1ll << 30) / ((int64_t)h->C * 8)));
     pl.qb = qb;
     return MMIDX_OK;
+}
+
+template <int M>
+int launch_filt_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t st) {
+    HIPCK(hipFuncSetAttribute((const void *)k_scan_filt<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_scan_filt<M>), grid, dim3(MMIDX_BLOCK), lds, st, P);
+    HIPCK(hipGetLastError());
+    return MMIDX_OK;
+}
+
+// pass B: lower-bound filtered scan where it applies (byte codes, templated m), else the exact scan
+int launch_scan_filtered(const mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 grid, hipStream_t st) {
+    const bool ok = h->code_bytes == 1 && h->ks <= 256 && (h->m == 8 || h->m == 16 || h->m == 32) && !h->no_filter;
+    if (!ok) return launch_scan(h, P, grid, pl.lds, st);
+    int cap = 1;
+    while (cap < pl.K1 + MMIDX_VROUND) cap <<= 1;
+    P.cap = cap;
+    const size_t lds = (size_t)h->m * h->ks * 8 + 2 * (size_t)h->D * 8 + (size_t)cap * 12 + 4 * (size_t)h->m * 8 +
+                       (size_t)MMIDX_SURV_CAP * 4 + 16 + (size_t)h->m * 256;
+    if (lds > 160 * 1024) return launch_scan(h, P, grid, pl.lds, st);
+    switch (h->m) {
+        case 8: return launch_filt_t<8>(P, grid, lds, st);
+        case 16: return launch_filt_t<16>(P, grid, lds, st);
+        default: return launch_filt_t<32>(P, grid, lds, st);
+    }
 }
 
 int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, hipStream_t st) {
@@ -462,7 +491,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
             P.n_items = (int)(nq * (P.w - 1));
             P.xcd_remap = 1;
             const unsigned gx = (unsigned)(((P.n_items + 7) / 8) * 8);
-            rc = launch_scan(h, P, dim3(gx, (unsigned)pl.nchunks), pl.lds, st);
+            rc = launch_scan_filtered(h, P, pl, dim3(gx, (unsigned)pl.nchunks), st);
             if (rc) return rc;
         }
         if (prof) HIPCK(hipEventRecord(ev[3], st));
@@ -625,6 +654,10 @@ int mmidx_create(int kind, int D, int m, int ks, int C, int transform, const int
         HIPCK(hipMemcpy(h->d_rot, rot, (size_t)D * D * sizeof(double), hipMemcpyHostToDevice));
     }
     h->h_off.assign((size_t)h->nlists + 1, 0);
+    {
+        const char *nf = getenv("MMIDX_NO_FILTER");
+        h->no_filter = nf && nf[0] == '1';
+    }
     *out = h;
     return MMIDX_OK;
 }

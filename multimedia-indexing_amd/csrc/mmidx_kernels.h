@@ -591,6 +591,274 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan(const ScanParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// K3f: filtered scan (pass B, byte codes).  The fp64 gather of K3 is LDS-bank-conflict bound
+// (random 8-byte reads over 2 KiB rows: ~3x serialisation, measured).  K3f first runs a
+// conflict-free LOWER-BOUND filter and evaluates the exact fp64 sum only for the survivors:
+//
+//   with T the query's current threshold, min_s = min_j LUT[s][j], Smin = sum_s min_s and
+//   delta = (T - Smin) / 254:      q8[s][j] = min(255, floor((LUT[s][j] - min_s) / delta))
+//   sum_s q8[s][code[s]] * delta + Smin <= d(code), so a code with sum_s q8 >= 256 has d > T and
+//   can be dropped; Smin >= T drops the whole list before a single code is read.
+//
+// A q8 row is 256 bytes = exactly one pass over the 64 LDS banks, and ds_read_b64 serves 8-byte
+// slots: two lanes either hit the same slot (broadcast) or different bank pairs -> no conflicts.
+// The wanted byte is picked from the 8-byte slot with v_perm_b32.  Survivors (typically < 1 % of
+// the codes) are queued in LDS and verified 256 at a time with the exact sequential fp64 sum from
+// the fp64 LUT, so results stay bit-identical to K3.  All roundings of the filter are directed so
+// that it can only under-estimate (never drops a candidate with d <= T).
+// ------------------------------------------------------------------------------------------------
+#define MMIDX_SURV_CAP 1024
+#define MMIDX_VROUND MMIDX_BLOCK
+
+template <int DSUB>
+__device__ __forceinline__ double lut_entry(const double *tr, const double *__restrict__ pqT, int s, int j, int ks,
+                                            int dsub_rt) {
+    double acc = 0.0;
+    if constexpr (DSUB > 0) {
+        const double *pp = pqT + (size_t)s * DSUB * ks + j;
+        double pv[DSUB];
+#pragma unroll
+        for (int t = 0; t < DSUB; t++) pv[t] = pp[(size_t)t * ks];
+        const double *tv = tr + s * DSUB;
+#pragma unroll
+        for (int t = 0; t < DSUB; t++) {
+            const double df = tv[t] - pv[t];
+            acc += df * df;
+        }
+    } else {
+        const double *pp = pqT + (size_t)s * dsub_rt * ks + j;
+        const double *tv = tr + s * dsub_rt;
+        for (int t = 0; t < dsub_rt; t++) {
+            const double df = tv[t] - pp[(size_t)t * ks];
+            acc += df * df;
+        }
+    }
+    return acc;
+}
+
+template <int M>
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_filt(const ScanParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int ks = P.ks, D = P.D;
+    double *lut = (double *)smem;                        // [M*ks]   exact fp64 table
+    double *vec = lut + (size_t)M * ks;                  // [2*D]
+    u64 *bkey = (u64 *)(vec + 2 * (size_t)D);            // [cap]    candidates: distance bits
+    u64 *s_min = bkey + P.cap;                           // [4][M]
+    u32 *bval = (u32 *)(s_min + 4 * M);                  // [cap]    candidates: list position
+    u32 *surv = bval + P.cap;                            // [SURV_CAP] filter survivors: list position
+    u32 *s_cnt = surv + MMIDX_SURV_CAP;                  // [4]: 0 candidates, 1 survivors
+    unsigned char *lut8 = (unsigned char *)(s_cnt + 4);  // [M][256] quantised lower-bound table
+
+    int item = blockIdx.x;
+    if (P.xcd_remap) {
+        const int per = (P.n_items + 7) >> 3;
+        item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    }
+    if (item >= P.n_items) return;
+    int q, pr;
+    if (P.order) {
+        if (item >= *P.n_order) return;
+        const int e = P.order[item];
+        q = e / P.w;
+        pr = e - q * P.w;
+    } else {
+        q = item / P.nrank;
+        pr = P.rank_lo + (item - q * P.nrank);
+    }
+    const int ch = blockIdx.y;
+    int cell = 0;
+    if (P.ivf) {
+        cell = P.cells[(size_t)q * P.w + pr];
+        if (cell < 0) return;
+    }
+    const int64_t beg = P.list_off[cell];
+    const int64_t len = P.list_off[cell + 1] - beg;
+    const int64_t c0 = (int64_t)ch * P.chunk;
+    if (c0 >= len) return;
+    const int64_t c1 = (c0 + P.chunk < len) ? c0 + P.chunk : len;
+    const int tid = threadIdx.x;
+    const unsigned char *codes = (const unsigned char *)P.codes + (size_t)beg * M;
+
+    CodeVec<M, unsigned char> cur[MMIDX_SEGU], nxt[MMIDX_SEGU];
+#pragma unroll
+    for (int u = 0; u < MMIDX_SEGU; u++) {
+        const int64_t i = c0 + u * MMIDX_BLOCK + tid;
+        cur[u].load(codes + (size_t)(i < c1 ? i : c1 - 1) * M);
+    }
+    if (tid < 2) s_cnt[tid] = 0;
+    const double *tr = query_vector(P, q, cell, vec);
+
+    // ---- exact LUT column j = tid, per-sub-quantizer minima ---------------------------------------
+    double e[M];
+    u64 mk[M];
+    const bool has = tid < ks;
+#pragma unroll
+    for (int s = 0; s < M; s++) {
+        double v = 0.0;
+        if (has) {
+            switch (P.dsub) {
+                case 4: v = lut_entry<4>(tr, P.pqT, s, tid, ks, 4); break;
+                case 8: v = lut_entry<8>(tr, P.pqT, s, tid, ks, 8); break;
+                case 16: v = lut_entry<16>(tr, P.pqT, s, tid, ks, 16); break;
+                default: v = lut_entry<0>(tr, P.pqT, s, tid, ks, P.dsub); break;
+            }
+            lut[s * ks + tid] = v;
+        }
+        e[s] = v;
+        mk[s] = has ? dkey(v) : MMIDX_KEY_MAX;
+    }
+#pragma unroll
+    for (int s = 0; s < M; s++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const u64 o = __shfl_xor(mk[s], off);
+            mk[s] = o < mk[s] ? o : mk[s];
+        }
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int s = 0; s < M; s++) s_min[(tid >> 6) * M + s] = mk[s];
+    }
+    u64 *Tq = P.T + q;
+    u64 T = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    double smin = 0.0;
+#pragma unroll
+    for (int s = 0; s < M; s++) {
+        u64 a = s_min[s];
+#pragma unroll
+        for (int wv = 1; wv < MMIDX_BLOCK / 64; wv++) {
+            const u64 b = s_min[wv * M + s];
+            a = b < a ? b : a;
+        }
+        mk[s] = a;
+        smin += keyd(a);
+    }
+    // directed roundings: smin_lo <= the real sum of minima; inv slightly small -> q8 under-estimates
+    const double smin_lo = smin * (1.0 - 0x1p-40);
+    const double Td = keyd(T);
+    const bool finiteT = T < 0x7FF0000000000000ull;
+    if (finiteT && !(smin_lo < Td)) return;  // no code of this list can reach the threshold
+    const bool nofilter = !finiteT || !((Td - smin_lo) > Td * 0x1p-30);
+    if (has) {
+        const double inv = nofilter ? 0.0 : (254.0 / (Td - smin_lo)) * (1.0 - 0x1p-40);
+#pragma unroll
+        for (int s = 0; s < M; s++) {
+            const double x = (e[s] - keyd(mk[s])) * inv;
+            const u32 qv = (x >= 255.0) ? 255u : (u32)x;  // x >= 0; NaN cannot occur for finite inputs
+            lut8[s * 256 + tid] = (unsigned char)(nofilter ? 0u : qv);
+        }
+    }
+    __syncthreads();
+
+    // ---- filter scan ------------------------------------------------------------------------------
+    const u64 lane_lt = (1ull << (tid & 63)) - 1ull;
+    for (int64_t seg = c0; seg < c1; seg += MMIDX_SEG) {
+        const bool more = seg + MMIDX_SEG < c1;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < MMIDX_SEGU; u++) {
+                const int64_t i = seg + MMIDX_SEG + u * MMIDX_BLOCK + tid;
+                nxt[u].load(codes + (size_t)(i < c1 ? i : c1 - 1) * M);
+            }
+        }
+        u32 acc[MMIDX_SEGU];
+#pragma unroll
+        for (int u = 0; u < MMIDX_SEGU; u++) acc[u] = 0;
+#pragma unroll
+        for (int s = 0; s < M; s++) {
+#pragma unroll
+            for (int u = 0; u < MMIDX_SEGU; u++) {
+                const u32 b = (u32)cur[u].get(s);
+                const uint2 v = *(const uint2 *)(lut8 + s * 256 + (b & 0xF8u));
+                acc[u] += __builtin_amdgcn_perm(v.y, v.x, (b & 7u) | 0x0C0C0C00u);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < MMIDX_SEGU; u++) {
+            const int64_t i = seg + u * MMIDX_BLOCK + tid;
+            const bool pass = (i < c1) && acc[u] <= 255u;
+            const u64 mask = __ballot(pass);
+            if (mask) {
+                u32 base = 0;
+                const int leader = __ffsll((long long)mask) - 1;
+                if ((tid & 63) == leader) base = atomicAdd(s_cnt + 1, (u32)__popcll(mask));
+                base = __shfl(base, leader);
+                if (pass) surv[base + (u32)__popcll(mask & lane_lt)] = (u32)i;
+            }
+        }
+        __syncthreads();
+        int ns = (int)s_cnt[1];  // uniform: no writer until the barrier below
+        __syncthreads();
+        // ---- exact verification of the queued survivors, MMIDX_VROUND at a time ------------------
+        while (ns >= MMIDX_VROUND || (!more && ns > 0)) {
+            if ((int)s_cnt[0] > P.cap - MMIDX_VROUND) {  // uniform (s_cnt[0] stable here)
+                scan_prune(bkey, bval, s_cnt, P.K1, Tq);
+                T = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const int take = ns < MMIDX_VROUND ? ns : MMIDX_VROUND;
+            const int base_s = ns - take;
+            bool pass = false;
+            u64 key = 0;
+            u32 pos = 0;
+            if (tid < take) {
+                pos = surv[base_s + tid];
+                CodeVec<M, unsigned char> cv;
+                cv.load(codes + (size_t)pos * M);
+                double d = 0.0;
+#pragma unroll
+                for (int s = 0; s < M; s++) d += lut[s * ks + cv.get(s)];
+                key = dkey(d);
+                pass = key <= T;
+            }
+            const u64 mask = __ballot(pass);
+            if (mask) {
+                u32 base = 0;
+                const int leader = __ffsll((long long)mask) - 1;
+                if ((tid & 63) == leader) base = atomicAdd(s_cnt, (u32)__popcll(mask));
+                base = __shfl(base, leader);
+                if (pass) {
+                    const u32 slot = base + (u32)__popcll(mask & lane_lt);
+                    bkey[slot] = key;
+                    bval[slot] = pos;
+                }
+            }
+            ns = base_s;
+            __syncthreads();
+            if (tid == 0) s_cnt[1] = (u32)ns;
+            __syncthreads();
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < MMIDX_SEGU; u++) cur[u] = nxt[u];
+        }
+    }
+    // ---- hand the survivors to the query's pool ------------------------------------------------
+    __syncthreads();
+    if ((int)*s_cnt > P.K1) scan_prune(bkey, bval, s_cnt, P.K1, Tq);
+    T = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int n = (int)*s_cnt;
+    for (int base0 = 0; base0 < n; base0 += MMIDX_BLOCK) {
+        const int i = base0 + tid;
+        const bool pass = (i < n) && bkey[i] <= T;
+        const u64 mask = __ballot(pass);
+        if (mask) {
+            u32 base = 0;
+            const int leader = __ffsll((long long)mask) - 1;
+            if ((tid & 63) == leader) base = atomicAdd(P.pool_cnt + q, (u32)__popcll(mask));
+            base = __shfl(base, leader);
+            if (pass) {
+                const u32 slot = base + (u32)__popcll(mask & lane_lt);
+                if (slot < (u32)P.poolq) {
+                    P.pool_key[(size_t)q * P.poolq + slot] = bkey[i];
+                    P.pool_val[(size_t)q * P.poolq + slot] = ((u64)pr << 32) | (u64)bval[i];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // per-batch ordering of the (query, probe rank >= rank_lo) pairs by cell: counting sort with
 // atomics.  The order inside a cell is arbitrary -- it only decides which block runs when.
 // ------------------------------------------------------------------------------------------------

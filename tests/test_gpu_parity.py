@@ -18,6 +18,14 @@ TOL = 1e-5  # stated tolerance (north star); asserted bit-equal below, TOL is th
 
 @pytest.fixture(scope="module")
 def mi():
+    # torch (used by one test only to hold device buffers) bundles its own HIP runtime; when it is
+    # going to be used in this process it has to initialise before libmmidx_hip.so does
+    try:
+        import torch
+
+        torch.cuda.init()
+    except Exception:
+        pass
     m = importlib.import_module("multimedia-indexing_amd")
     if m.lib().mmidx_device_count() < 1:
         pytest.fail("libmmidx_hip.so found no HIP device: GPU tests must run the native path")
