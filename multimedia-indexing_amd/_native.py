@@ -81,6 +81,25 @@ SIGNATURES = {
 }
 
 
+def _preload_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 (same soname as /opt/rocm's).  One
+    process can only drive the GPU through one HIP runtime, so when torch is installed -- the
+    bench and the multi-GPU host use it for device buffers and RCCL -- bind to ITS copy, whatever
+    the import order.  torch itself is not imported here.  Without torch (e.g. under the JNI shim)
+    the library resolves to /opt/rocm/lib through its RUNPATH."""
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     """Load libmmidx_hip.so; raises loudly when it has not been built."""
     global _lib
@@ -90,6 +109,7 @@ def lib():
         raise ImportError(
             f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    _preload_hip_runtime()
     L = C.CDLL(SO_PATH)
     for name, (res, args) in SIGNATURES.items():
         f = getattr(L, name)  # AttributeError if the symbol is not exported
