@@ -1,0 +1,136 @@
+"""Multi-GPU search: one process per GPU, inverted lists partitioned across ranks.
+
+Partitioning: whole inverted lists, list c lives on rank `c % world` (`owner_of_cell`).  Every
+(query, probe) work item therefore runs on exactly one rank (its residual LUT is built once), and
+the reference's offer order (probe rank, position in list) stays well defined.  Codebooks are
+replicated (8.25 MiB).  Per batch:
+
+  1. coarse top-w for a 1/world slice of the queries            (mmidx_coarse_device)
+  2. all-gather of the probe cells                               (RCCL, nq*w*4 bytes)
+  3. scan of the locally owned probed lists -> sorted top-(k+1)  (mmidx_search_partial_device)
+  4. all-gather of (distance, key, count) partial lists          (RCCL, nq*(k+1)*16 bytes/rank)
+  5. merge of the `world` sorted lists per query                 (mmidx_merge_partials_device)
+
+The collectives go through torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in the CPU
+tests).  The per-rank engine is pluggable so that the orchestration (this file) is exercised on
+CPU with world_size 2 by tests/test_sharded_gloo.py; on a GPU box the engine is `HipShardEngine`.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+def owner_of_cell(cells, world):
+    """rank that stores inverted list `cell`"""
+    return cells % world
+
+
+def merge_partials_host(k, pdist, pkey, pcount):
+    """Host mirror of kernel K5 (k_merge_partials): numpy arrays [S][nq][k+1], [S][nq][k+1], [S][nq].
+    Returns (iid [nq][k], dist [nq][k], count [nq]).  Order: ascending distance; equal distances
+    later-offered first, offer order = key ascending (probe_rank << 32 | iid)."""
+    S, nq, K1 = pdist.shape
+    iid = np.full((nq, k), -1, np.int32)
+    dist = np.full((nq, k), np.inf, np.float64)
+    cnt = np.zeros(nq, np.int32)
+    for q in range(nq):
+        d = np.concatenate([pdist[s, q, :min(int(pcount[s, q]), K1)] for s in range(S)])
+        ky = np.concatenate([pkey[s, q, :min(int(pcount[s, q]), K1)] for s in range(S)])
+        if d.size == 0:
+            continue
+        order = np.lexsort((ky, d))[:K1]
+        d, ky = d[order], ky[order]
+        n = min(k, d.size)
+        d, ky = d[:n], ky[:n]
+        # reverse runs of equal distance
+        out = np.arange(n)
+        a = 0
+        while a < n:
+            b = a
+            while b + 1 < n and d[b + 1] == d[a]:
+                b += 1
+            out[a:b + 1] = np.arange(b, a - 1, -1)
+            a = b + 1
+        iid[q, :n] = (ky[out] & 0xFFFFFFFF).astype(np.int64).astype(np.int32)
+        dist[q, :n] = d[out]
+        cnt[q] = n
+    return iid, dist, cnt
+
+
+class HipShardEngine:
+    """Per-rank engine over the C ABI; all buffers are torch CUDA tensors (plumbing only)."""
+
+    def __init__(self, handle, D, w, device_index):
+        import torch
+
+        self.torch = torch
+        self.h, self.D, self.w, self.dev = handle, D, w, device_index
+        self.L = N.lib()
+
+    def _stream(self):
+        return self.torch.cuda.current_stream().cuda_stream
+
+    def coarse(self, Qs):
+        t = self.torch
+        cells = t.empty(Qs.shape[0], self.w, dtype=t.int32, device=Qs.device)
+        if Qs.shape[0]:
+            N.check(self.L.mmidx_coarse_device(self.h, Qs.shape[0], Qs.data_ptr(), cells.data_ptr(), self._stream()))
+        return cells
+
+    def search_partial(self, k, Q, cells):
+        t = self.torch
+        nq, K1 = Q.shape[0], k + 1
+        pd = t.empty(nq, K1, dtype=t.float64, device=Q.device)
+        pk = t.empty(nq, K1, dtype=t.int64, device=Q.device)
+        pc = t.empty(nq, dtype=t.int32, device=Q.device)
+        N.check(self.L.mmidx_search_partial_device(self.h, k, nq, Q.data_ptr(), cells.data_ptr(), pd.data_ptr(),
+                                                   pk.data_ptr(), pc.data_ptr(), self._stream()))
+        return pd, pk, pc
+
+    def merge(self, k, pd_all, pk_all, pc_all):
+        t = self.torch
+        S, nq = pd_all.shape[0], pd_all.shape[1]
+        iid = t.empty(nq, k, dtype=t.int32, device=pd_all.device)
+        dist = t.empty(nq, k, dtype=t.float64, device=pd_all.device)
+        cnt = t.empty(nq, dtype=t.int32, device=pd_all.device)
+        N.check(self.L.mmidx_merge_partials_device(self.dev, k, nq, S, pd_all.data_ptr(), pk_all.data_ptr(),
+                                                   pc_all.data_ptr(), iid.data_ptr(), dist.data_ptr(),
+                                                   cnt.data_ptr(), self._stream()))
+        return iid, dist, cnt
+
+
+class ShardedIVFPQ:
+    """computeNearestNeighbors over `world` shards (IVFPQ.computeKnnIVFADC, IVFPQ.java:408-450)."""
+
+    def __init__(self, engine, rank, world, dist=None, group=None):
+        self.engine, self.rank, self.world, self.dist, self.group = engine, rank, world, dist, group
+
+    def _all_gather(self, x):
+        """stack of every rank's `x` along a new leading axis (same shape on all ranks)"""
+        torch = __import__("torch")
+        if self.world == 1:
+            return x.unsqueeze(0)
+        out = torch.empty((self.world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        if x.is_cuda:
+            self.dist.all_gather_into_tensor(out, x.contiguous(), group=self.group)
+        else:  # gloo: list form
+            parts = [out[i] for i in range(self.world)]
+            self.dist.all_gather(parts, x.contiguous(), group=self.group)
+        return out
+
+    def search(self, k, Q):
+        """Q: [nq][D] float64 tensor, identical on every rank.  Returns (iid, dist, count) on every rank."""
+        nq = Q.shape[0]
+        per = (nq + self.world - 1) // self.world
+        q0 = min(self.rank * per, nq)
+        q1 = min(q0 + per, nq)
+        cells_sl = self.engine.coarse(Q[q0:q1])
+        if q1 - q0 < per:  # pad the slice so that every rank contributes the same shape
+            torch = __import__("torch")
+            pad = torch.full((per - (q1 - q0), cells_sl.shape[1]), -1, dtype=cells_sl.dtype, device=cells_sl.device)
+            cells_sl = torch.cat([cells_sl, pad], 0)
+        cells = self._all_gather(cells_sl).reshape(self.world * per, -1)[:nq].contiguous()
+        pd, pk, pc = self.engine.search_partial(k, Q, cells)
+        return self.engine.merge(k, self._all_gather(pd), self._all_gather(pk), self._all_gather(pc))

@@ -323,3 +323,46 @@ def test_coarse_topw_with_duplicate_centroids(mi, oracle, C):
         exp = np.stack([ref.nearest_coarse(q, w) for q in Q])
         assert np.array_equal(got, exp), w
     ix.close()
+
+
+@pytest.mark.parametrize("S", [2, 3])
+def test_virtual_shards_on_one_device(mi, oracle, S):
+    """Multi-GPU path without a cluster: S shards (whole lists, cell mod S) on one device, the
+    same partial-search and merge kernels the RCCL path uses (kernel K5)."""
+    import torch
+
+    sh = importlib.import_module("multimedia-indexing_amd.sharded")
+    D, C, m, ks, n, w = 32, 24, 8, 256, 9000, 6
+    p = synth.make_ivfpq_problem(n=n, D=D, C=C, m=m, ks=ks, nq=40, seed=5 + S)
+    ref = oracle_ivfpq(oracle, p, D, m, ks, C, w)
+    ref.add_vectors(p["base"])
+    full = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    full.loadCoarseQuantizer(p["coarse"])
+    full.loadProductQuantizer(p["pq"])
+    full.setW(w)
+    cells, codes = full.encode(p["base"])
+    shards = []
+    for r in range(S):
+        ix = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+        ix.loadCoarseQuantizer(p["coarse"])
+        ix.loadProductQuantizer(p["pq"])
+        ix.setW(w)
+        own = np.nonzero(sh.owner_of_cell(cells, S) == r)[0]
+        ix.loadIndex(own.astype(np.int32), cells[own], codes[own])
+        shards.append(ix)
+    Q = torch.tensor(p["queries"], dtype=torch.float64, device="cuda")
+    engines = [sh.HipShardEngine(ix._h, D, w, 0) for ix in shards]
+    probe = engines[0].coarse(Q)
+    for k in (1, 10, 100):
+        parts = [e.search_partial(k, Q, probe) for e in engines]
+        iid, dd, cnt = engines[0].merge(k, torch.stack([x[0] for x in parts]), torch.stack([x[1] for x in parts]),
+                                        torch.stack([x[2] for x in parts]))
+        torch.cuda.synchronize()
+        # same merge on the host mirror
+        hi, hd, hc = sh.merge_partials_host(k, torch.stack([x[0] for x in parts]).cpu().numpy(),
+                                            torch.stack([x[1] for x in parts]).cpu().numpy(),
+                                            torch.stack([x[2] for x in parts]).cpu().numpy())
+        assert np.array_equal(iid.cpu().numpy(), hi) and np.array_equal(dd.cpu().numpy(), hd)
+        assert_same((iid.cpu().numpy(), dd.cpu().numpy(), cnt.cpu().numpy()), ref.search_batch(p["queries"], k))
+    for ix in shards + [full]:
+        ix.close()
