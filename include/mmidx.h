@@ -20,8 +20,9 @@
  *     (PQ.transformToShort, PQ.java:544-550).
  *   - internal ids (iid) are int32, as in the reference (loadCounter, ASS:65).
  *   - "_device" variants take pointers into the HBM of the handle's GPU and run asynchronously on
- *     the given hipStream_t (passed as void*; NULL = the handle's own stream).  Host variants
- *     stage through HBM and are synchronous.
+ *     the given hipStream_t (passed as void*; NULL = the HIP default stream, which is also what
+ *     PyTorch's default stream is).  Host variants stage through HBM on a private stream and
+ *     are synchronous.
  *   - threading: adds are serialised per handle (indexVector / indexPQCode are `synchronized`,
  *     ASS:229, IVFPQ.java:357); searches may run concurrently with each other but not with adds
  *     (the reference offers no reader/writer exclusion either).

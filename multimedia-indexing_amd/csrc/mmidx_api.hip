@@ -771,7 +771,7 @@ int mmidx_encode_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_
     if (n < 0 || (n > 0 && (!dX || !d_cell_out || !d_code_out))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
     rc = set_device(h);
     if (rc) return rc;
-    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t st = (hipStream_t)stream;
     if (n == 0) return MMIDX_OK;
     if (h->code_bytes == 1) {
         // kernels produce centroid indices; the boundary carries the stored form idx - 128
@@ -820,7 +820,7 @@ int mmidx_add_codes_device(mmidx_index *h, int64_t n, const int32_t *d_iids, con
     if (total_size(h) + n > 2147483647LL) return fail(MMIDX_ERR_CAPACITY, "Maximum index capacity reached, no more vectors can be indexed!");
     int rc = set_device(h);
     if (rc) return rc;
-    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t st = (hipStream_t)stream;
     std::lock_guard<std::mutex> lk(h->mu);
     if (st != h->stream) HIPCK(hipStreamSynchronize(st));
     rc = ensure_pending(h, n);
@@ -878,7 +878,7 @@ int mmidx_add_vectors_device(mmidx_index *h, int64_t n, const double *dX, const 
     if (total_size(h) + n > 2147483647LL) return fail(MMIDX_ERR_CAPACITY, "Maximum index capacity reached, no more vectors can be indexed!");
     rc = set_device(h);
     if (rc) return rc;
-    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t st = (hipStream_t)stream;
     std::lock_guard<std::mutex> lk(h->mu);
     if (st != h->stream) HIPCK(hipStreamSynchronize(st));
     rc = ensure_pending(h, n);
@@ -940,7 +940,7 @@ int mmidx_search_device(mmidx_index *h, int k, int64_t nq, const double *dQ, int
                         int32_t *d_count_out, void *stream) {
     if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
     if (nq > 0 && (!dQ || !d_iid_out || !d_dist_out || !d_count_out)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
-    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t st = (hipStream_t)stream;
     return search_common(h, k, nq, dQ, nullptr, 0, d_iid_out, d_dist_out, d_count_out, nullptr, nullptr, st);
 }
 
@@ -975,7 +975,7 @@ int mmidx_coarse_device(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d
     if (nq > 0 && (!dQ || !d_cells_out)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
     rc = set_device(h);
     if (rc) return rc;
-    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t st = (hipStream_t)stream;
     const int64_t qb = std::max<int64_t>(1, (1ll << 30) / ((int64_t)h->C * 8));
     for (int64_t q0 = 0; q0 < nq; q0 += qb) {
         const int64_t nb = std::min(qb, nq - q0);
@@ -990,7 +990,7 @@ int mmidx_search_partial_device(mmidx_index *h, int k, int64_t nq, const double 
     if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
     if (nq > 0 && (!dQ || !d_pdist || !d_pkey || !d_pcount)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
     if (h->kind == MMIDX_KIND_IVFPQ && nq > 0 && !d_cells) return fail(MMIDX_ERR_INVALID_ARG, "IVFPQ partial search needs the probe cells");
-    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t st = (hipStream_t)stream;
     return search_common(h, k, nq, dQ, h->kind == MMIDX_KIND_IVFPQ ? d_cells : nullptr, 1, nullptr, nullptr, d_pcount, d_pdist,
                          (long long *)d_pkey, st);
 }
