@@ -97,6 +97,9 @@ struct mmidx_index {
     size_t code_bytes = 1;  // per sub-quantizer
     bool coarse_set = false, pq_set = false;
     bool no_filter = false;  // MMIDX_NO_FILTER=1: exact scan only (A/B switch for measurements)
+    bool no_bound = false;   // MMIDX_NO_BOUND=1: no coarse-bound pruning of probes
+    bool debug_sync = false; // MMIDX_DEBUG_SYNC=1
+    double rmax = 0.0;       // sqrt(sum_s max_j ||pq[s][j]||^2) * (1 + 1e-12)
     hipStream_t stream = nullptr;
     std::mutex mu;
 
@@ -121,7 +124,7 @@ struct mmidx_index {
     DevBuf<int32_t> ws_cells, ws_oiid, ws_ocnt, ws_flag, ws_ecell, ws_pcount, ws_pstart, ws_pcursor, ws_order;
     DevBuf<u64> ws_T, ws_pkey, ws_pval;
     DevBuf<u32> ws_pcnt;
-    DevBuf<unsigned char> ws_ecode, ws_tmp;
+    DevBuf<unsigned char> ws_ecode, ws_tmp, ws_keep;
     DevBuf<long long> ws_dest;
 
     // profiling: HIP events recorded on the launch stream, resolved lazily by mmidx_get_stats
@@ -396,6 +399,16 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
     return MMIDX_OK;
 }
 
+// MMIDX_DEBUG_SYNC=1: synchronise after every stage and report the first failing one
+#define DBG_SYNC(name)                                                                        \
+    do {                                                                                      \
+        if (h->debug_sync) {                                                                  \
+            hipError_t e__ = hipStreamSynchronize(st);                                        \
+            fprintf(stderr, "[mmidx] %s: %s\n", name, hipGetErrorString(e__));               \
+            if (e__ != hipSuccess) return fail(MMIDX_ERR_HIP, "%s failed: %s", name, hipGetErrorString(e__)); \
+        }                                                                                     \
+    } while (0)
+
 // one sub-batch (nq <= plan.qb) entirely on device
 int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq, const double *dQ, const int32_t *d_cells_in,
                         int mode, int32_t *d_iid, double *d_dist, int32_t *d_cnt, double *d_pdist, long long *d_pkey,
@@ -458,22 +471,8 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
     P.cap = pl.cap;
     P.poolq = pl.poolq;
     if (h->n_csr > 0) {
-        // pass B order: pairs with probe rank >= 1 sorted by cell (device counting sort)
         const long long npairs = (long long)nq * P.w;
         const bool two_pass = ivf && P.w > 1;
-        if (two_pass) {
-            HIPCK(h->ws_pcount.reserve((size_t)h->C));
-            HIPCK(h->ws_pstart.reserve((size_t)h->C + 1));
-            HIPCK(h->ws_pcursor.reserve((size_t)h->C));
-            HIPCK(h->ws_order.reserve((size_t)npairs));
-            HIPCK(hipMemsetAsync(h->ws_pcount.p, 0, (size_t)h->C * sizeof(int32_t), st));
-            const unsigned g = (unsigned)((npairs + 255) / 256);
-            hipLaunchKernelGGL(k_pair_hist, dim3(g), dim3(256), 0, st, d_cells, P.w, 1, npairs, h->ws_pcount.p);
-            hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, h->C, h->ws_pstart.p, h->ws_pcursor.p);
-            hipLaunchKernelGGL(k_pair_scatter, dim3(g), dim3(256), 0, st, d_cells, P.w, 1, npairs, h->ws_pstart.p, h->ws_pcursor.p,
-                               h->ws_order.p);
-            HIPCK(hipGetLastError());
-        }
         if (prof) HIPCK(hipEventRecord(ev[2], st));
         // pass A: probe rank 0 of every query (all of them for PQ) -- fixes a tight threshold
         P.order = nullptr;
@@ -483,9 +482,46 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
         P.xcd_remap = 0;
         int rc = launch_scan(h, P, dim3((unsigned)P.n_items, (unsigned)pl.nchunks), pl.lds, st);
         if (rc) return rc;
+        DBG_SYNC("pass A scan");
         if (two_pass) {
-            // pass B: the other pairs, list-major.  Empty probe slots (cell < 0) are not in the
-            // order array; the tail items read stale ids only past n_items -> bounded by count.
+            // pass B order: pairs with probe rank >= 1 that survive the coarse bound, sorted by cell
+            // (device counting sort; needs the thresholds pass A just produced)
+            HIPCK(h->ws_pcount.reserve((size_t)h->C));
+            HIPCK(h->ws_pstart.reserve((size_t)h->C + 1));
+            HIPCK(h->ws_pcursor.reserve((size_t)h->C));
+            HIPCK(h->ws_order.reserve((size_t)npairs));
+            HIPCK(h->ws_keep.reserve((size_t)npairs));
+            HIPCK(hipMemsetAsync(h->ws_pcount.p, 0, (size_t)h->C * sizeof(int32_t), st));
+            PairBound PB{};
+            PB.Q = dQ;
+            PB.coarse = h->d_coarse;
+            PB.T = h->ws_T.p;
+            PB.rmax = h->rmax;
+            PB.D = h->D;
+            PB.enabled = (h->transform != MMIDX_TR_ROTATION && !h->no_bound) ? 1 : 0;
+            const unsigned g = (unsigned)((npairs + 255) / 256);
+            DBG_SYNC("pair memset");
+            if (h->debug_sync) {
+                std::vector<u64> ht((size_t)nq);
+                std::vector<int32_t> hc((size_t)npairs);
+                (void)hipMemcpy(ht.data(), h->ws_T.p, (size_t)nq * 8, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(hc.data(), d_cells, (size_t)npairs * 4, hipMemcpyDeviceToHost);
+                int ninf = 0, cmin = 1 << 30, cmax = -(1 << 30);
+                for (u64 t : ht) ninf += t >= 0x7FF0000000000000ull;
+                for (int32_t c : hc) { cmin = std::min(cmin, c); cmax = std::max(cmax, c); }
+                fprintf(stderr, "[mmidx] nq=%lld npairs=%lld T inf=%d cells min=%d max=%d rmax=%g D=%d w=%d keep=%p cnt=%p Q=%p coarse=%p T=%p\n", (long long)nq, npairs, ninf, cmin, cmax,
+                        h->rmax, h->D, P.w, (void*)h->ws_keep.p, (void*)h->ws_pcount.p, (void*)dQ, (void*)h->d_coarse, (void*)h->ws_T.p);
+            }
+            hipLaunchKernelGGL(k_pair_hist, dim3(g), dim3(256), 0, st, d_cells, P.w, 1, npairs, h->ws_pcount.p, h->ws_keep.p, PB);
+            DBG_SYNC("pair hist");
+            hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, h->C, h->ws_pstart.p, h->ws_pcursor.p);
+            DBG_SYNC("pair scan");
+            hipLaunchKernelGGL(k_pair_scatter, dim3(g), dim3(256), 0, st, d_cells, P.w, 1, npairs, h->ws_pstart.p, h->ws_pcursor.p,
+                               h->ws_order.p, h->ws_keep.p);
+            HIPCK(hipGetLastError());
+            DBG_SYNC("pair sort");
+            // pass B: the surviving pairs, list-major; the grid covers the worst case, blocks past
+            // the device-side count exit at once
             P.order = h->ws_order.p;
             P.n_order = h->ws_pstart.p + h->C;
             P.n_items = (int)(nq * (P.w - 1));
@@ -493,6 +529,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
             const unsigned gx = (unsigned)(((P.n_items + 7) / 8) * 8);
             rc = launch_scan_filtered(h, P, pl, dim3(gx, (unsigned)pl.nchunks), st);
             if (rc) return rc;
+            DBG_SYNC("pass B scan");
         }
         if (prof) HIPCK(hipEventRecord(ev[3], st));
         if (prof) h->launches += two_pass ? 2 : 1;
@@ -521,6 +558,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
     HIPCK(hipFuncSetAttribute((const void *)k_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
     hipLaunchKernelGGL(k_merge, dim3((unsigned)nq), dim3(MMIDX_BLOCK), mlds, st, M);
     HIPCK(hipGetLastError());
+    DBG_SYNC("merge");
     if (mode == 0 && h->n_csr > 0) {
         // exact replay for queries whose k-th / (k+1)-th distances tie (rare)
         TieParams TP{};
@@ -657,6 +695,10 @@ int mmidx_create(int kind, int D, int m, int ks, int C, int transform, const int
     {
         const char *nf = getenv("MMIDX_NO_FILTER");
         h->no_filter = nf && nf[0] == '1';
+        const char *nb = getenv("MMIDX_NO_BOUND");
+        h->no_bound = (nb && nb[0] == '1') || h->no_filter;
+        const char *ds = getenv("MMIDX_DEBUG_SYNC");
+        h->debug_sync = ds && ds[0] == '1';
     }
     *out = h;
     return MMIDX_OK;
@@ -689,6 +731,7 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_pcnt.release();
     h->ws_ecode.release();
     h->ws_tmp.release();
+    h->ws_keep.release();
     h->ws_dest.release();
     for (auto &ev : h->evpool)
         if (ev) (void)hipEventDestroy(ev);
@@ -729,6 +772,20 @@ int mmidx_set_pq(mmidx_index *h, const double *pq) {
     if (!h->d_pqT) HIPCK(hipMalloc((void **)&h->d_pqT, n * sizeof(double)));
     HIPCK(hipMemcpy(h->d_pq, pq, n * sizeof(double), hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(h->d_pqT, T.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    double r2 = 0.0;
+    for (int s = 0; s < h->m; s++) {
+        double mx = 0.0;
+        for (int j = 0; j < h->ks; j++) {
+            double nn = 0.0;
+            for (int t = 0; t < h->dsub; t++) {
+                const double v = pq[((size_t)s * h->ks + j) * h->dsub + t];
+                nn += v * v;
+            }
+            mx = std::max(mx, nn);
+        }
+        r2 += mx;
+    }
+    h->rmax = std::sqrt(r2) * (1.0 + 1e-12);
     h->pq_set = true;
     return MMIDX_OK;
 }

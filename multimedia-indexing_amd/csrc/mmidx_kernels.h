@@ -456,14 +456,15 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan(const ScanParams P) {
 
     // ---- block -> work item ---------------------------------------------------------------------
     int item = blockIdx.x;
+    const int n_items = P.order ? *P.n_order : P.n_items;  // pass B: count left by the coarse bound
     if (P.xcd_remap) {
-        const int per = (P.n_items + 7) >> 3;
+        const int per = (n_items + 7) >> 3;
+        if ((int)(blockIdx.x >> 3) >= per) return;
         item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     }
-    if (item >= P.n_items) return;
+    if (item >= n_items) return;
     int q, pr;
     if (P.order) {
-        if (item >= *P.n_order) return;
         const int e = P.order[item];
         q = e / P.w;
         pr = e - q * P.w;
@@ -650,14 +651,15 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_filt(const ScanParams P) {
     unsigned char *lut8 = (unsigned char *)(s_cnt + 4);  // [M][256] quantised lower-bound table
 
     int item = blockIdx.x;
+    const int n_items = P.order ? *P.n_order : P.n_items;  // pass B: count left by the coarse bound
     if (P.xcd_remap) {
-        const int per = (P.n_items + 7) >> 3;
+        const int per = (n_items + 7) >> 3;
+        if ((int)(blockIdx.x >> 3) >= per) return;
         item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     }
-    if (item >= P.n_items) return;
+    if (item >= n_items) return;
     int q, pr;
     if (P.order) {
-        if (item >= *P.n_order) return;
         const int e = P.order[item];
         q = e / P.w;
         pr = e - q * P.w;
@@ -862,13 +864,50 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_filt(const ScanParams P) {
 // per-batch ordering of the (query, probe rank >= rank_lo) pairs by cell: counting sort with
 // atomics.  The order inside a cell is arbitrary -- it only decides which block runs when.
 // ------------------------------------------------------------------------------------------------
+// Coarse bound (exact pruning of whole probes before any LUT is built).  The ADC distance of a
+// code in cell c is ||(c - q) - p||^2 with p the concatenation of the chosen sub-centroids, so by
+// the reverse triangle inequality d >= (||c - q|| - Rmax)^2 whenever ||c - q|| > Rmax, where
+// Rmax^2 = sum_s max_j ||pq[s][j]||^2 bounds ||p|| (a permutation keeps norms; the bound is not
+// used with a rotation matrix, which is an input and need not be exactly orthogonal).  A pair whose
+// bound exceeds the query's threshold T (valid after pass A) cannot contribute and is left out of
+// pass B.  Margins make the test conservative against fp64 rounding.
+struct PairBound {
+    const double *Q;       // [nq][D]
+    const double *coarse;  // [C][D]
+    const u64 *T;          // [nq]
+    double rmax;           // sqrt(sum_s max_j ||pq[s][j]||^2) * (1 + 1e-12)
+    int D;
+    int enabled;
+};
+// Written branch-free on purpose: with early returns hipcc (ROCm 7.2) sank the zero-extension of
+// the cell index into a divergent region and the later atomicAdd(cnt + c) used a garbage high
+// dword on the lanes that had returned early (memory aperture violation).
+__device__ __forceinline__ bool pair_keep(const PairBound &B, int q, int c) {
+    const u64 T = B.T[q];
+    double cd = 0.0;
+    const double *cc = B.coarse + (size_t)c * B.D, *qq = B.Q + (size_t)q * B.D;
+    for (int j = 0; j < B.D; j++) {
+        const double df = cc[j] - qq[j];
+        cd += df * df;
+    }
+    const double r = sqrt(cd) * (1.0 - 1e-12);
+    const double gap = r - B.rmax;
+    const double lb = gap * gap * (1.0 - 1e-9);
+    const bool prune = (B.enabled != 0) & (T < 0x7FF0000000000000ull) & (gap > 0.0) & (lb > keyd(T));
+    return !prune;
+}
+
 __global__ void k_pair_hist(const int32_t *__restrict__ cells, int w, int rank_lo, long long npairs,
-                            int32_t *__restrict__ cnt) {
+                            int32_t *__restrict__ cnt, unsigned char *__restrict__ keep, const PairBound B) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= npairs) return;
-    if ((int)(e % w) < rank_lo) return;
+    const int q = (int)(e / w);
+    if ((int)(e - (long long)q * w) < rank_lo) return;
     const int c = cells[e];
-    if (c >= 0) atomicAdd(cnt + c, 1);
+    const unsigned cu = c >= 0 ? (unsigned)c : 0u;
+    const bool k = (c >= 0) & pair_keep(B, q, (int)cu);
+    keep[e] = k ? 1 : 0;
+    if (k) atomicAdd(cnt + (size_t)cu, 1);
 }
 // single block: exclusive scan of cnt[C] -> start[C]; start[C] = total; cursor zeroed
 __global__ __launch_bounds__(1024) void k_pair_scan(const int32_t *__restrict__ cnt, int C, int32_t *__restrict__ start,
@@ -897,12 +936,12 @@ __global__ __launch_bounds__(1024) void k_pair_scan(const int32_t *__restrict__ 
 }
 __global__ void k_pair_scatter(const int32_t *__restrict__ cells, int w, int rank_lo, long long npairs,
                                const int32_t *__restrict__ start, int32_t *__restrict__ cursor,
-                               int32_t *__restrict__ order) {
+                               int32_t *__restrict__ order, const unsigned char *__restrict__ keep) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= npairs) return;
     if ((int)(e % w) < rank_lo) return;
+    if (!keep[e]) return;
     const int c = cells[e];
-    if (c < 0) return;
     const int pos = start[c] + atomicAdd(cursor + c, 1);
     order[pos] = (int32_t)e;
 }
