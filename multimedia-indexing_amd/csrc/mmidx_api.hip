@@ -387,7 +387,15 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
     hipLaunchKernelGGL(k_coarse_dist<QT>, g1, dim3(MMIDX_BLOCK), 0, st, h->d_coarseT, dQ, h->ws_cdist.p, h->C, h->D, (int)nq);
     const size_t lds = (size_t)(h->w + 1) * 12 + 16;
     if (lds > 64 * 1024) return fail(MMIDX_ERR_UNSUPPORTED, "w = %d too large", h->w);
-    if (h->C <= 8 * MMIDX_BLOCK)
+    const bool fast = h->C >= MMIDX_BLOCK && h->w + 1 <= MMIDX_BLOCK && h->C <= 64 * MMIDX_BLOCK;
+    const size_t flds = (size_t)MMIDX_CSEL_CAP * 12 + (size_t)(h->w + 1) * 12 + 16;
+    if (fast && h->C <= 8 * MMIDX_BLOCK)
+        hipLaunchKernelGGL(k_coarse_select_fast<8>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), flds, st, h->ws_cdist.p, h->C, h->w, d_cells);
+    else if (fast && h->C <= 32 * MMIDX_BLOCK)
+        hipLaunchKernelGGL(k_coarse_select_fast<32>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), flds, st, h->ws_cdist.p, h->C, h->w, d_cells);
+    else if (fast)
+        hipLaunchKernelGGL(k_coarse_select_fast<64>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), flds, st, h->ws_cdist.p, h->C, h->w, d_cells);
+    else if (h->C <= 8 * MMIDX_BLOCK)
         hipLaunchKernelGGL(k_coarse_select_reg<8>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), lds, st, h->ws_cdist.p, h->C, h->w, d_cells);
     else if (h->C <= 32 * MMIDX_BLOCK)
         hipLaunchKernelGGL(k_coarse_select_reg<32>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), lds, st, h->ws_cdist.p, h->C, h->w, d_cells);

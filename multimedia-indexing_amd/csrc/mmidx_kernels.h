@@ -245,6 +245,101 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_reg(const double 
     if (tid == 0) coarse_emit(row, C, w, rounds, sel_k, sel_i, cells + (size_t)q * w);
 }
 
+// Fast variant of K1b (C >= 256, w + 1 <= 256): instead of w+1 block-wide argmin rounds, bound the
+// (w+1)-th smallest distance from above by the (w+1)-th smallest of the 256 per-thread minima
+// (those are w+1 distinct elements, so at least w+1 elements are <= tau), gather every element
+// <= tau (a few dozen for w = 32, C = 8192) and sort just those.  Same output as the round-based
+// kernels -- the sorted head by (distance, index) -- so the tie rule in coarse_emit is unchanged.
+// If the gather overflows (massive ties) the round-based selection runs on the registers instead.
+#define MMIDX_CSEL_CAP 1024
+template <int PER>
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_fast(const double *__restrict__ dist, int C, int w,
+                                                                    int32_t *__restrict__ cells) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *ckey = (u64 *)smem;                       // [CSEL_CAP] candidates / thread minima
+    u32 *cidx = (u32 *)(ckey + MMIDX_CSEL_CAP);    // [CSEL_CAP]
+    u64 *sel_k = (u64 *)(cidx + MMIDX_CSEL_CAP);   // [w+1]
+    int *sel_i = (int *)(sel_k + (w + 1));         // [w+1]
+    __shared__ u64 s_k[MMIDX_BLOCK / 64];
+    __shared__ int s_i[MMIDX_BLOCK / 64];
+    __shared__ u32 s_n4[4];  // statics total 64 B: keeps the dynamic LDS base 16-byte aligned
+    u32 &s_n = s_n4[0];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const double *row = dist + (size_t)q * C;
+    u64 key[PER];
+    u64 lk = MMIDX_KEY_MAX;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int c = tid + i * MMIDX_BLOCK;
+        key[i] = (c < C) ? dkey(row[c]) : MMIDX_KEY_MAX;
+        lk = key[i] < lk ? key[i] : lk;
+    }
+    const int R = w + 1;  // host guarantees R <= 256 <= C
+    ckey[tid] = lk;
+    cidx[tid] = (u32)tid;
+    if (tid == 0) s_n = 0;
+    block_bitonic_sort<u32>(ckey, cidx, MMIDX_BLOCK);
+    const u64 tau = ckey[R - 1];
+    __syncthreads();
+    // gather all elements <= tau
+    const u64 lane_lt = (1ull << (tid & 63)) - 1ull;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const bool pass = key[i] <= tau && (tid + i * MMIDX_BLOCK) < C;
+        const u64 mask = __ballot(pass);
+        if (mask) {
+            u32 base = 0;
+            const int leader = __ffsll((long long)mask) - 1;
+            if ((tid & 63) == leader) base = atomicAdd(&s_n, (u32)__popcll(mask));
+            base = __shfl(base, leader);
+            if (pass) {
+                const u32 slot = base + (u32)__popcll(mask & lane_lt);
+                if (slot < MMIDX_CSEL_CAP) {
+                    ckey[slot] = key[i];
+                    cidx[slot] = (u32)(tid + i * MMIDX_BLOCK);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int n = (int)s_n;
+    if (n <= MMIDX_CSEL_CAP) {
+        const int Pn = pow2ceil(n < 2 ? 2 : n);
+        for (int i = n + tid; i < Pn; i += MMIDX_BLOCK) {
+            ckey[i] = MMIDX_KEY_MAX;
+            cidx[i] = 0xFFFFFFFFu;
+        }
+        block_bitonic_sort<u32>(ckey, cidx, Pn);
+        for (int i = tid; i < R; i += MMIDX_BLOCK) {
+            sel_k[i] = ckey[i];
+            sel_i[i] = (int)cidx[i];
+        }
+    } else {
+        for (int r = 0; r < R; r++) {  // overflow: round-based selection (as k_coarse_select_reg)
+            u64 bk = MMIDX_KEY_MAX;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                const int c = tid + i * MMIDX_BLOCK;
+                if (c < C && key[i] < bk) {
+                    bk = key[i];
+                    bi = c;
+                }
+            }
+            block_min_pair(bk, bi, s_k, s_i);
+#pragma unroll
+            for (int i = 0; i < PER; i++)
+                if (tid + i * MMIDX_BLOCK == bi) key[i] = MMIDX_KEY_MAX;
+            if (tid == 0) {
+                sel_k[r] = bk;
+                sel_i[r] = bi;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) coarse_emit(row, C, w, R, sel_k, sel_i, cells + (size_t)q * w);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2 + K3: per (query, probe, chunk) work item: residual -> transform -> ADC lookup table in LDS
 // -> coalesced scan of the list's PQ codes -> threshold-filtered candidate buffer.

@@ -366,3 +366,28 @@ def test_virtual_shards_on_one_device(mi, oracle, S):
         assert_same((iid.cpu().numpy(), dd.cpu().numpy(), cnt.cpu().numpy()), ref.search_batch(p["queries"], k))
     for ix in shards + [full]:
         ix.close()
+
+
+def test_coarse_topw_massive_ties(mi, oracle):
+    """FLAGGED tie fixture: almost all coarse centroids identical -> > 1024 exactly equal distances;
+    exercises the overflow path of the fast top-w kernel and the queue's tie rule."""
+    D, m, ks, C = 8, 2, 16, 1300
+    rng = np.random.default_rng(3)
+    coarse = np.tile(rng.standard_normal((1, D)), (C, 1))
+    special = rng.choice(C, size=9, replace=False)
+    coarse[special] += 0.05 * rng.standard_normal((9, D))
+    pq = rng.standard_normal((m, ks, D // m))
+    ix = mi.IVFPQ(D, 10, False, "", m, ks, 0, C, 512)
+    ix.loadCoarseQuantizer(coarse)
+    ix.loadProductQuantizer(pq)
+    ref = oracle.OracleIndex(oracle.KIND_IVFPQ, D, m, ks, C)
+    ref.set_coarse(coarse)
+    ref.set_pq(pq)
+    Q = coarse[special[:4]] + 1e-4 * rng.standard_normal((4, D))
+    Q = np.concatenate([Q, rng.standard_normal((4, D))])
+    for w in (1, 5, 12, 200):
+        ix.setW(w)
+        got = _coarse_cells(mi, ix, Q)
+        exp = np.stack([ref.nearest_coarse(q, w) for q in Q])
+        assert np.array_equal(got, exp), w
+    ix.close()
