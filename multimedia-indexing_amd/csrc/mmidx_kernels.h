@@ -739,8 +739,9 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_filt(const ScanParams P) {
     double *lut = (double *)smem;                        // [M*ks]   exact fp64 table
     double *vec = lut + (size_t)M * ks;                  // [2*D]
     u64 *bkey = (u64 *)(vec + 2 * (size_t)D);            // [cap]    candidates: distance bits
-    u64 *s_min = bkey + P.cap;                           // [4][M]
-    u32 *bval = (u32 *)(s_min + 4 * M);                  // [cap]    candidates: list position
+    u64 *s_min = bkey + P.cap;                           // [4][M]   per-wave minima, then [0..M) final
+    u64 *s_T = s_min + 4 * M;                            // [2]      block-uniform copy of the threshold
+    u32 *bval = (u32 *)(s_T + 2);                        // [cap]    candidates: list position
     u32 *surv = bval + P.cap;                            // [SURV_CAP] filter survivors: list position
     u32 *s_cnt = surv + MMIDX_SURV_CAP;                  // [4]: 0 candidates, 1 survivors
     unsigned char *lut8 = (unsigned char *)(s_cnt + 4);  // [M][256] quantised lower-bound table
@@ -775,6 +776,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_filt(const ScanParams P) {
     const int64_t c1 = (c0 + P.chunk < len) ? c0 + P.chunk : len;
     const int tid = threadIdx.x;
     const unsigned char *codes = (const unsigned char *)P.codes + (size_t)beg * M;
+    u64 *Tq = P.T + q;
 
     CodeVec<M, unsigned char> cur[MMIDX_SEGU], nxt[MMIDX_SEGU];
 #pragma unroll
@@ -783,74 +785,87 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_filt(const ScanParams P) {
         cur[u].load(codes + (size_t)(i < c1 ? i : c1 - 1) * M);
     }
     if (tid < 2) s_cnt[tid] = 0;
+    // every decision that steers control flow uses ONE copy of T (another block may publish a new
+    // value at any time): thread 0 reads it, the block reads the LDS copy after a barrier
+    if (tid == 0) s_T[0] = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const double *tr = query_vector(P, q, cell, vec);
 
     // ---- exact LUT column j = tid, per-sub-quantizer minima ---------------------------------------
-    double e[M];
-    u64 mk[M];
-    const bool has = tid < ks;
+    {
+        u64 mk[M];
+        const bool hasj = tid < ks;
 #pragma unroll
-    for (int s = 0; s < M; s++) {
-        double v = 0.0;
-        if (has) {
-            switch (P.dsub) {
-                case 4: v = lut_entry<4>(tr, P.pqT, s, tid, ks, 4); break;
-                case 8: v = lut_entry<8>(tr, P.pqT, s, tid, ks, 8); break;
-                case 16: v = lut_entry<16>(tr, P.pqT, s, tid, ks, 16); break;
-                default: v = lut_entry<0>(tr, P.pqT, s, tid, ks, P.dsub); break;
+        for (int s = 0; s < M; s++) {
+            double v = 0.0;
+            if (hasj) {
+                switch (P.dsub) {
+                    case 4: v = lut_entry<4>(tr, P.pqT, s, tid, ks, 4); break;
+                    case 8: v = lut_entry<8>(tr, P.pqT, s, tid, ks, 8); break;
+                    case 16: v = lut_entry<16>(tr, P.pqT, s, tid, ks, 16); break;
+                    default: v = lut_entry<0>(tr, P.pqT, s, tid, ks, P.dsub); break;
+                }
+                lut[s * ks + tid] = v;
             }
-            lut[s * ks + tid] = v;
+            mk[s] = hasj ? dkey(v) : MMIDX_KEY_MAX;
         }
-        e[s] = v;
-        mk[s] = has ? dkey(v) : MMIDX_KEY_MAX;
-    }
 #pragma unroll
-    for (int s = 0; s < M; s++) {
+        for (int s = 0; s < M; s++) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const u64 o = __shfl_xor(mk[s], off);
-            mk[s] = o < mk[s] ? o : mk[s];
+            for (int off = 32; off > 0; off >>= 1) {
+                const u64 o = __shfl_xor(mk[s], off);
+                mk[s] = o < mk[s] ? o : mk[s];
+            }
+        }
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int s = 0; s < M; s++) s_min[(tid >> 6) * M + s] = mk[s];
         }
     }
-    if ((tid & 63) == 0) {
-#pragma unroll
-        for (int s = 0; s < M; s++) s_min[(tid >> 6) * M + s] = mk[s];
+    __syncthreads();
+    if (tid < M) {  // final minimum of sub-quantizer tid -> s_min[tid] (read partials first)
+        u64 a = s_min[tid];
+        for (int wv = 1; wv < MMIDX_BLOCK / 64; wv++) {
+            const u64 b = s_min[wv * M + tid];
+            a = b < a ? b : a;
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        s_min[tid] = a;  // row 0 of the partials; rows 1..3 are dead now
     }
-    u64 *Tq = P.T + q;
-    u64 T = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     double smin = 0.0;
 #pragma unroll
-    for (int s = 0; s < M; s++) {
-        u64 a = s_min[s];
-#pragma unroll
-        for (int wv = 1; wv < MMIDX_BLOCK / 64; wv++) {
-            const u64 b = s_min[wv * M + s];
-            a = b < a ? b : a;
-        }
-        mk[s] = a;
-        smin += keyd(a);
-    }
-    // directed roundings: smin_lo <= the real sum of minima; inv slightly small -> q8 under-estimates
+    for (int s = 0; s < M; s++) smin += keyd(s_min[s]);
+    // directed roundings: smin_lo <= the real sum of minima; 1/delta slightly small -> q8 under-estimates
     const double smin_lo = smin * (1.0 - 0x1p-40);
-    const double Td = keyd(T);
-    const bool finiteT = T < 0x7FF0000000000000ull;
-    if (finiteT && !(smin_lo < Td)) return;  // no code of this list can reach the threshold
-    const bool nofilter = !finiteT || !((Td - smin_lo) > Td * 0x1p-30);
-    if (has) {
-        const double inv = nofilter ? 0.0 : (254.0 / (Td - smin_lo)) * (1.0 - 0x1p-40);
+    u64 T = s_T[0];
+    u64 T_built = MMIDX_KEY_MAX;  // threshold the current lut8 was built for
+    bool exhausted = false;       // no remaining code of this list can reach the threshold
+
+    // (re)build the quantised table for threshold Tn; block-uniform. Returns false when the list is
+    // exhausted (Smin >= T).
+    auto rebuild = [&](u64 Tn) -> bool {
+        const bool finiteT = Tn < 0x7FF0000000000000ull;
+        const double Td = keyd(Tn);
+        if (finiteT && !(smin_lo < Td)) return false;
+        const bool nofilter = !finiteT || !((Td - smin_lo) > Td * 0x1p-30);
+        if (tid < ks) {
+            const double inv = nofilter ? 0.0 : (254.0 / (Td - smin_lo)) * (1.0 - 0x1p-40);
 #pragma unroll
-        for (int s = 0; s < M; s++) {
-            const double x = (e[s] - keyd(mk[s])) * inv;
-            const u32 qv = (x >= 255.0) ? 255u : (u32)x;  // x >= 0; NaN cannot occur for finite inputs
-            lut8[s * 256 + tid] = (unsigned char)(nofilter ? 0u : qv);
+            for (int s = 0; s < M; s++) {
+                const double x = (lut[s * ks + tid] - keyd(s_min[s])) * inv;
+                const u32 qv = (x >= 255.0) ? 255u : (u32)x;  // x >= 0, finite
+                lut8[s * 256 + tid] = (unsigned char)(nofilter ? 0u : qv);
+            }
         }
-    }
-    __syncthreads();
+        __syncthreads();
+        return true;
+    };
+    if (!rebuild(T)) return;
+    T_built = T;
 
     // ---- filter scan ------------------------------------------------------------------------------
     const u64 lane_lt = (1ull << (tid & 63)) - 1ull;
-    for (int64_t seg = c0; seg < c1; seg += MMIDX_SEG) {
+    for (int64_t seg = c0; seg < c1 && !exhausted; seg += MMIDX_SEG) {
         const bool more = seg + MMIDX_SEG < c1;
         if (more) {
 #pragma unroll
@@ -891,7 +906,15 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_filt(const ScanParams P) {
         while (ns >= MMIDX_VROUND || (!more && ns > 0)) {
             if ((int)s_cnt[0] > P.cap - MMIDX_VROUND) {  // uniform (s_cnt[0] stable here)
                 scan_prune(bkey, bval, s_cnt, P.K1, Tq);
-                T = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid == 0) s_T[0] = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                T = s_T[0];
+                if (T < T_built) {  // tighter threshold: sharper filter for the rest of the list
+                    if (!rebuild(T)) {
+                        exhausted = true;  // queued survivors still need their exact check below
+                    }
+                    T_built = T;
+                }
             }
             const int take = ns < MMIDX_VROUND ? ns : MMIDX_VROUND;
             const int base_s = ns - take;
@@ -924,6 +947,44 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_filt(const ScanParams P) {
             __syncthreads();
             if (tid == 0) s_cnt[1] = (u32)ns;
             __syncthreads();
+            if (exhausted && ns > 0) continue;  // drain the queue, then leave the segment loop
+        }
+        if (exhausted) {
+            // survivors below one verification round are still queued: verify them too
+            while (ns > 0) {
+                const int take = ns < MMIDX_VROUND ? ns : MMIDX_VROUND;
+                const int base_s = ns - take;
+                if ((int)s_cnt[0] > P.cap - MMIDX_VROUND) scan_prune(bkey, bval, s_cnt, P.K1, Tq);
+                bool pass = false;
+                u64 key = 0;
+                u32 pos = 0;
+                if (tid < take) {
+                    pos = surv[base_s + tid];
+                    CodeVec<M, unsigned char> cv;
+                    cv.load(codes + (size_t)pos * M);
+                    double d = 0.0;
+#pragma unroll
+                    for (int s = 0; s < M; s++) d += lut[s * ks + cv.get(s)];
+                    key = dkey(d);
+                    pass = key <= T;
+                }
+                const u64 mask = __ballot(pass);
+                if (mask) {
+                    u32 base = 0;
+                    const int leader = __ffsll((long long)mask) - 1;
+                    if ((tid & 63) == leader) base = atomicAdd(s_cnt, (u32)__popcll(mask));
+                    base = __shfl(base, leader);
+                    if (pass) {
+                        const u32 slot = base + (u32)__popcll(mask & lane_lt);
+                        bkey[slot] = key;
+                        bval[slot] = pos;
+                    }
+                }
+                ns = base_s;
+                __syncthreads();
+                if (tid == 0) s_cnt[1] = (u32)ns;
+                __syncthreads();
+            }
         }
         if (more) {
 #pragma unroll
@@ -933,11 +994,11 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_filt(const ScanParams P) {
     // ---- hand the survivors to the query's pool ------------------------------------------------
     __syncthreads();
     if ((int)*s_cnt > P.K1) scan_prune(bkey, bval, s_cnt, P.K1, Tq);
-    T = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64 Tfin = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // per-lane use only
     const int n = (int)*s_cnt;
     for (int base0 = 0; base0 < n; base0 += MMIDX_BLOCK) {
         const int i = base0 + tid;
-        const bool pass = (i < n) && bkey[i] <= T;
+        const bool pass = (i < n) && bkey[i] <= Tfin;
         const u64 mask = __ballot(pass);
         if (mask) {
             u32 base = 0;
@@ -970,8 +1031,9 @@ struct PairBound {
     const double *Q;       // [nq][D]
     const double *coarse;  // [C][D]
     const u64 *T;          // [nq]
+    const double *cdist;   // [nq][C] coarse distances when this process computed them, else null
     double rmax;           // sqrt(sum_s max_j ||pq[s][j]||^2) * (1 + 1e-12)
-    int D;
+    int D, C;
     int enabled;
 };
 // Written branch-free on purpose: with early returns hipcc (ROCm 7.2) sank the zero-extension of
@@ -980,10 +1042,14 @@ struct PairBound {
 __device__ __forceinline__ bool pair_keep(const PairBound &B, int q, int c) {
     const u64 T = B.T[q];
     double cd = 0.0;
-    const double *cc = B.coarse + (size_t)c * B.D, *qq = B.Q + (size_t)q * B.D;
-    for (int j = 0; j < B.D; j++) {
-        const double df = cc[j] - qq[j];
-        cd += df * df;
+    if (B.cdist) {  // K1a already computed ||c - q||^2 for every (q, c)
+        cd = B.cdist[(size_t)q * B.C + c];
+    } else {
+        const double *cc = B.coarse + (size_t)c * B.D, *qq = B.Q + (size_t)q * B.D;
+        for (int j = 0; j < B.D; j++) {
+            const double df = cc[j] - qq[j];
+            cd += df * df;
+        }
     }
     const double r = sqrt(cd) * (1.0 - 1e-12);
     const double gap = r - B.rmax;
@@ -1565,11 +1631,10 @@ __global__ void k_unbias_codes(const signed char *in, unsigned char *out, long l
 // ------------------------------------------------------------------------------------------------
 __global__ void k_count_codes(const int32_t *__restrict__ cells, const int64_t *__restrict__ list_off,
                               long long n, u64 *__restrict__ total) {
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    u64 v = 0;
-    if (e < n) {
+    u64 v = 0;  // grid-stride: a few hundred blocks, one atomic per wave
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
         const int c = cells[e];
-        if (c >= 0) v = (u64)(list_off[c + 1] - list_off[c]);
+        if (c >= 0) v += (u64)(list_off[c + 1] - list_off[c]);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
