@@ -166,6 +166,36 @@ typedef struct mmidx_stats {
 int mmidx_set_profiling(mmidx_index *h, int enabled);
 int mmidx_get_stats(mmidx_index *h, mmidx_stats *out);
 
+/* ---- front end of BASELINE config 5 ----------------------------------------------------------
+ * PCA projection: PCA.loadPCAFromFile (J/dimreduction/PCA.java:257-318) + sampleToEigenSpace
+ * (:188-208).  means[ss] = line 1 of the PCA file, eig[nc] = line 2 (used iff whitening: the
+ * library folds W = diag(eig^-0.5) into V_t exactly as :283-313 does), Vt[nc][ss] = the component
+ * lines.  project: Y[n][nc] = V_t (X[n] - means), L2-normalised iff whitening (:203-204).  This is
+ * the one dense contraction of the path and runs on the f64 matrix cores; results agree with the
+ * reference to 1e-12 (relative to the row norm), not bit-for-bit (EJML summation order, A2). */
+typedef struct mmidx_pca mmidx_pca;
+int mmidx_pca_create(int nc, int ss, int whitening, const double *means, const double *eig,
+                     const double *Vt, int device, mmidx_pca **out);
+int mmidx_pca_destroy(mmidx_pca *p);
+int mmidx_pca_project(mmidx_pca *p, int64_t n, const double *X, double *Y);
+int mmidx_pca_project_device(mmidx_pca *p, int64_t n, const double *dX, double *dY, void *stream);
+
+/* VLAD aggregation: VladAggregator.aggregateInternal (J/aggregation/VladAggregator.java:56-70) with
+ * computeNearestCentroid (AbstractFeatureAggregator.java:136-155), and the multi-vocabulary wrapper
+ * with power + L2 normalisation (VladAggregatorMultipleVocabularies.java:84-101).  codebooks =
+ * the nvocab codebooks concatenated, ncent[i] centroids of dl doubles each.  desc_off[nimg+1]
+ * delimits each image's descriptors in descs[total][dl].  out[nimg][sum ncent*dl].  Without
+ * normalisation the output is bit-exact (accumulation in descriptor order); with it, 1e-12. */
+typedef struct mmidx_vlad mmidx_vlad;
+int mmidx_vlad_create(int nvocab, const int32_t *ncent, int dl, const double *codebooks,
+                      int normalizations_on, int device, mmidx_vlad **out);
+int mmidx_vlad_destroy(mmidx_vlad *v);
+int mmidx_vlad_vector_length(const mmidx_vlad *v, int *len_out);
+int mmidx_vlad_aggregate(mmidx_vlad *v, int64_t nimg, const int64_t *desc_off, const double *descs,
+                         double *out);
+int mmidx_vlad_aggregate_device(mmidx_vlad *v, int64_t nimg, const int64_t *d_desc_off,
+                                const double *d_descs, int max_desc, double *d_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,7 +40,7 @@ class Stats(C.Structure):
 
 def build(force=False):
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("mmidx_api.hip", "mmidx_kernels.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("mmidx_api.hip", "mmidx_kernels.h", "mmidx_frontend.h")]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "mmidx.h"))
     stale = not os.path.exists(SO_PATH) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
     if force or stale:
@@ -76,6 +76,15 @@ SIGNATURES = {
     "mmidx_coarse_device": (C.c_int, [_vp, C.c_int64, _dp, _i32p, _vp]),
     "mmidx_search_partial_device": (C.c_int, [_vp, C.c_int, C.c_int64, _dp, _i32p, _dp, _vp, _i32p, _vp]),
     "mmidx_merge_partials_device": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, _dp, _vp, _i32p, _i32p, _dp, _i32p, _vp]),
+    "mmidx_pca_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.POINTER(C.c_void_p)]),
+    "mmidx_pca_destroy": (C.c_int, [_vp]),
+    "mmidx_pca_project": (C.c_int, [_vp, C.c_int64, _dp, _dp]),
+    "mmidx_pca_project_device": (C.c_int, [_vp, C.c_int64, _dp, _dp, _vp]),
+    "mmidx_vlad_create": (C.c_int, [C.c_int, _i32p, C.c_int, _dp, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "mmidx_vlad_destroy": (C.c_int, [_vp]),
+    "mmidx_vlad_vector_length": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "mmidx_vlad_aggregate": (C.c_int, [_vp, C.c_int64, _vp, _dp, _dp]),
+    "mmidx_vlad_aggregate_device": (C.c_int, [_vp, C.c_int64, _vp, _dp, C.c_int, _dp, _vp]),
     "mmidx_set_profiling": (C.c_int, [_vp, C.c_int]),
     "mmidx_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
 }

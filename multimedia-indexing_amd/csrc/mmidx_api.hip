@@ -12,6 +12,7 @@
 //   pending  (cells, ids, codes) of records added since the last CSR build
 #include "../../include/mmidx.h"
 #include "mmidx_kernels.h"
+#include "mmidx_frontend.h"
 
 #include <algorithm>
 #include <cmath>
@@ -1150,6 +1151,208 @@ int mmidx_export(mmidx_index *h, int64_t *list_off_out, int32_t *iids_out, void 
             for (size_t t = 0; t < bytes; t++) c[t] = (unsigned char)(c[t] ^ 0x80);
         }
     }
+    return MMIDX_OK;
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// Front end of BASELINE config 5: PCA projection (K7) and VLAD aggregation (K8)
+// =================================================================================================
+struct mmidx_pca {
+    int nc = 0, ss = 0, whitening = 0, device = 0;
+    double *d_mu = nullptr, *d_Vt = nullptr;
+    hipStream_t stream = nullptr;
+    DevBuf<double> ws_X, ws_Y;
+};
+struct mmidx_vlad {
+    int nvocab = 0, dl = 0, norms = 0, device = 0, veclen = 0;
+    std::vector<int> nc;
+    std::vector<size_t> cb_off;  // element offset of each codebook
+    double *d_cb = nullptr;
+    hipStream_t stream = nullptr;
+    DevBuf<double> ws_desc, ws_out;
+    DevBuf<long long> ws_off;
+};
+
+extern "C" {
+
+int mmidx_pca_create(int nc, int ss, int whitening, const double *means, const double *eig, const double *Vt, int device,
+                     mmidx_pca **out) {
+    if (!out) return fail(MMIDX_ERR_INVALID_ARG, "null out pointer");
+    *out = nullptr;
+    if (nc < 1 || ss < 1 || !means || !Vt) return fail(MMIDX_ERR_INVALID_ARG, "bad PCA shape or null matrix");
+    if (whitening && !eig) return fail(MMIDX_ERR_INVALID_ARG, "whitening needs the eigenvalues line of the PCA file");
+    const int ndev = mmidx_device_count();
+    if (ndev < 1) return fail(MMIDX_ERR_NO_DEVICE, "no HIP device: libmmidx_hip has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(MMIDX_ERR_NO_DEVICE, "device %d outside 0..%d", device, ndev - 1);
+    HIPCK(hipSetDevice(device));
+    mmidx_pca *p = new mmidx_pca();
+    p->nc = nc;
+    p->ss = ss;
+    p->whitening = whitening ? 1 : 0;
+    p->device = device;
+    std::vector<double> V((size_t)nc * ss);
+    for (int i = 0; i < nc; i++) {
+        // W(i,i) = pow(eig_i, -0.5); V_t <- W * V_t  (PCA.java:283-285, :311): row i scaled by w_ii
+        const double wv = whitening ? std::pow(eig[i], -0.5) : 1.0;
+        for (int j = 0; j < ss; j++) V[(size_t)i * ss + j] = whitening ? wv * Vt[(size_t)i * ss + j] : Vt[(size_t)i * ss + j];
+    }
+    HIPCK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    HIPCK(hipMalloc((void **)&p->d_mu, (size_t)ss * 8));
+    HIPCK(hipMalloc((void **)&p->d_Vt, (size_t)nc * ss * 8));
+    HIPCK(hipMemcpy(p->d_mu, means, (size_t)ss * 8, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(p->d_Vt, V.data(), (size_t)nc * ss * 8, hipMemcpyHostToDevice));
+    *out = p;
+    return MMIDX_OK;
+}
+
+int mmidx_pca_destroy(mmidx_pca *p) {
+    if (!p) return MMIDX_OK;
+    (void)hipSetDevice(p->device);
+    if (p->d_mu) (void)hipFree(p->d_mu);
+    if (p->d_Vt) (void)hipFree(p->d_Vt);
+    p->ws_X.release();
+    p->ws_Y.release();
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+    return MMIDX_OK;
+}
+
+int mmidx_pca_project_device(mmidx_pca *p, int64_t n, const double *dX, double *dY, void *stream) {
+    if (!p) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    if (n < 0 || (n > 0 && (!dX || !dY))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (n == 0) return MMIDX_OK;
+    HIPCK(hipSetDevice(p->device));
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((n + PCA_BM - 1) / PCA_BM), (unsigned)((p->nc + PCA_BN - 1) / PCA_BN));
+    hipLaunchKernelGGL(k_pca_project, grid, dim3(256), 0, st, dX, p->d_mu, p->d_Vt, dY, (long long)n, p->nc, p->ss);
+    if (p->whitening)
+        hipLaunchKernelGGL(k_rows_normalize_l2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dY, (long long)n, p->nc);
+    HIPCK(hipGetLastError());
+    return MMIDX_OK;
+}
+
+int mmidx_pca_project(mmidx_pca *p, int64_t n, const double *X, double *Y) {
+    if (!p) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    if (n < 0 || (n > 0 && (!X || !Y))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    HIPCK(hipSetDevice(p->device));
+    const int64_t B = std::max<int64_t>(1, (int64_t)(1ll << 28) / p->ss);  // <= 2 GiB of samples per round
+    for (int64_t i0 = 0; i0 < n; i0 += B) {
+        const int64_t nb = std::min(B, n - i0);
+        HIPCK(p->ws_X.reserve((size_t)nb * p->ss));
+        HIPCK(p->ws_Y.reserve((size_t)nb * p->nc));
+        HIPCK(hipMemcpyAsync(p->ws_X.p, X + (size_t)i0 * p->ss, (size_t)nb * p->ss * 8, hipMemcpyHostToDevice, p->stream));
+        int rc = mmidx_pca_project_device(p, nb, p->ws_X.p, p->ws_Y.p, p->stream);
+        if (rc) return rc;
+        HIPCK(hipMemcpyAsync(Y + (size_t)i0 * p->nc, p->ws_Y.p, (size_t)nb * p->nc * 8, hipMemcpyDeviceToHost, p->stream));
+        HIPCK(hipStreamSynchronize(p->stream));
+    }
+    return MMIDX_OK;
+}
+
+int mmidx_vlad_create(int nvocab, const int32_t *ncent, int dl, const double *codebooks, int normalizations_on, int device,
+                      mmidx_vlad **out) {
+    if (!out) return fail(MMIDX_ERR_INVALID_ARG, "null out pointer");
+    *out = nullptr;
+    if (nvocab < 1 || !ncent || dl < 1 || !codebooks) return fail(MMIDX_ERR_INVALID_ARG, "bad codebook description");
+    const int ndev = mmidx_device_count();
+    if (ndev < 1) return fail(MMIDX_ERR_NO_DEVICE, "no HIP device: libmmidx_hip has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(MMIDX_ERR_NO_DEVICE, "device %d outside 0..%d", device, ndev - 1);
+    HIPCK(hipSetDevice(device));
+    mmidx_vlad *v = new mmidx_vlad();
+    v->nvocab = nvocab;
+    v->dl = dl;
+    v->norms = normalizations_on ? 1 : 0;
+    v->device = device;
+    size_t tot = 0;
+    for (int i = 0; i < nvocab; i++) {
+        if (ncent[i] < 1) {
+            delete v;
+            return fail(MMIDX_ERR_INVALID_ARG, "empty codebook");
+        }
+        v->nc.push_back(ncent[i]);
+        v->cb_off.push_back(tot);
+        tot += (size_t)ncent[i] * dl;
+    }
+    v->veclen = (int)tot;
+    HIPCK(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
+    HIPCK(hipMalloc((void **)&v->d_cb, tot * 8));
+    HIPCK(hipMemcpy(v->d_cb, codebooks, tot * 8, hipMemcpyHostToDevice));
+    *out = v;
+    return MMIDX_OK;
+}
+
+int mmidx_vlad_destroy(mmidx_vlad *v) {
+    if (!v) return MMIDX_OK;
+    (void)hipSetDevice(v->device);
+    if (v->d_cb) (void)hipFree(v->d_cb);
+    v->ws_desc.release();
+    v->ws_out.release();
+    v->ws_off.release();
+    if (v->stream) (void)hipStreamDestroy(v->stream);
+    delete v;
+    return MMIDX_OK;
+}
+
+int mmidx_vlad_vector_length(const mmidx_vlad *v, int *len_out) {
+    if (!v || !len_out) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    *len_out = v->veclen;
+    return MMIDX_OK;
+}
+
+// max_desc: largest descriptor count of any image in the batch (sizes the LDS work lists)
+int mmidx_vlad_aggregate_device(mmidx_vlad *v, int64_t nimg, const int64_t *d_desc_off, const double *d_descs, int max_desc,
+                                double *d_out, void *stream) {
+    if (!v) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    if (nimg < 0 || (nimg > 0 && (!d_desc_off || !d_out))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (nimg == 0) return MMIDX_OK;
+    HIPCK(hipSetDevice(v->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int maxnd = (std::max(max_desc, 2) + 1) & ~1;
+    for (int i = 0; i < v->nvocab; i++) {
+        const int nc = v->nc[(size_t)i];
+        const size_t lds = (size_t)nc * v->dl * 8 + 2 * (size_t)maxnd * 4 + (size_t)((nc + 2) & ~1) * 4 + 32;
+        if (lds > 160 * 1024)
+            return fail(MMIDX_ERR_UNSUPPORTED, "codebook %d x %d plus %d descriptors per image exceed the 160 KiB LDS", nc, v->dl, max_desc);
+        const int norms = v->norms;
+        if (v->dl == 64) {
+            HIPCK(hipFuncSetAttribute((const void *)k_vlad<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_vlad<64>, dim3((unsigned)nimg), dim3(256), lds, st, v->d_cb + v->cb_off[(size_t)i], nc, v->dl, maxnd,
+                               (const long long *)d_desc_off, d_descs, d_out, v->veclen, (int)v->cb_off[(size_t)i], norms);
+        } else {
+            HIPCK(hipFuncSetAttribute((const void *)k_vlad<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_vlad<0>, dim3((unsigned)nimg), dim3(256), lds, st, v->d_cb + v->cb_off[(size_t)i], nc, v->dl, maxnd,
+                               (const long long *)d_desc_off, d_descs, d_out, v->veclen, (int)v->cb_off[(size_t)i], norms);
+        }
+    }
+    if (v->nvocab > 1 && v->norms)
+        hipLaunchKernelGGL(k_rows_normalize_l2_block, dim3((unsigned)nimg), dim3(256), 0, st, d_out, v->veclen);
+    HIPCK(hipGetLastError());
+    return MMIDX_OK;
+}
+
+int mmidx_vlad_aggregate(mmidx_vlad *v, int64_t nimg, const int64_t *desc_off, const double *descs, double *out) {
+    if (!v) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    if (nimg < 0 || (nimg > 0 && (!desc_off || !out))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (nimg == 0) return MMIDX_OK;
+    HIPCK(hipSetDevice(v->device));
+    const int64_t total = desc_off[nimg] - desc_off[0];
+    if (total > 0 && !descs) return fail(MMIDX_ERR_INVALID_ARG, "null descriptors");
+    int max_desc = 0;
+    std::vector<long long> off((size_t)nimg + 1);
+    for (int64_t i = 0; i <= nimg; i++) off[(size_t)i] = desc_off[i] - desc_off[0];
+    for (int64_t i = 0; i < nimg; i++) max_desc = std::max<int>(max_desc, (int)(off[(size_t)i + 1] - off[(size_t)i]));
+    HIPCK(v->ws_off.reserve((size_t)nimg + 1));
+    HIPCK(v->ws_desc.reserve((size_t)std::max<int64_t>(total, 1) * v->dl));
+    HIPCK(v->ws_out.reserve((size_t)nimg * v->veclen));
+    HIPCK(hipMemcpyAsync(v->ws_off.p, off.data(), ((size_t)nimg + 1) * 8, hipMemcpyHostToDevice, v->stream));
+    if (total > 0)
+        HIPCK(hipMemcpyAsync(v->ws_desc.p, descs + (size_t)desc_off[0] * v->dl, (size_t)total * v->dl * 8, hipMemcpyHostToDevice, v->stream));
+    int rc = mmidx_vlad_aggregate_device(v, nimg, (const int64_t *)v->ws_off.p, v->ws_desc.p, max_desc, v->ws_out.p, v->stream);
+    if (rc) return rc;
+    HIPCK(hipMemcpyAsync(out, v->ws_out.p, (size_t)nimg * v->veclen * 8, hipMemcpyDeviceToHost, v->stream));
+    HIPCK(hipStreamSynchronize(v->stream));
     return MMIDX_OK;
 }
 

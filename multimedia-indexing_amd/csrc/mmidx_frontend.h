@@ -1,0 +1,265 @@
+// mmidx_frontend.h -- kernels of the two steps that feed the index (BASELINE config 5):
+//   K7  batched PCA projection  (J/dimreduction/PCA.java:188-208)   -> f64 MFMA GEMM
+//   K8  batched VLAD aggregation (J/aggregation/VladAggregator.java:56-70,
+//       AbstractFeatureAggregator.java:136-155, VladAggregatorMultipleVocabularies.java:84-101)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(4))) double f64x4;
+
+// ------------------------------------------------------------------------------------------------
+// K7: Y[n][nc] = (X[n][ss] - mu[ss]) * Vt[nc][ss]^T          (sampleToEigenSpace PCA.java:196-201)
+//
+// The one dense contraction of the path: v_mfma_f64_16x16x4_f64.  Block = 4 waves, tile 64 rows x
+// 128 components x 16 k; wave w owns rows 16w..16w+15 and all 8 column tiles (8 accumulators of 4
+// f64 per lane).  The mean is subtracted while the X tile is staged (sample - means, :199).  Tiles
+// go through LDS with a row stride of 17 doubles, which spreads the fragment reads
+// (row = lane & 15, k = lane >> 4) over distinct bank pairs; the next tile's global loads are in
+// flight while the current one is multiplied.  A/B operand: one f64 per lane,
+// A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15]; C/D: col = lane & 15,
+// row = (lane >> 4) + 4 * reg (the f64 layout, which differs from the f32 maps).
+// EJML's matrix-vector product accumulates each output sequentially with separate multiply and add
+// (assumption A2); the MFMA chain is fused and k-blocked, so parity for this kernel is a
+// tolerance (1e-12 relative to the row norm), never bit-equality.
+// ------------------------------------------------------------------------------------------------
+#define PCA_BM 64
+#define PCA_BN 128
+#define PCA_BK 16
+#define PCA_LD 17  // padded row stride in doubles
+
+__global__ __launch_bounds__(256) void k_pca_project(const double *__restrict__ X, const double *__restrict__ mu,
+                                                     const double *__restrict__ Vt, double *__restrict__ Y,
+                                                     long long n, int nc, int ss) {
+    __shared__ double As[PCA_BM * PCA_LD];
+    __shared__ double Bs[PCA_BN * PCA_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long row0 = (long long)blockIdx.x * PCA_BM;
+    const int col0 = blockIdx.y * PCA_BN;
+    f64x4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+    // staging: A 64 rows x 16 k = 512 pairs of doubles -> 2 per thread; B 128 x 16 = 1024 pairs -> 4 per thread
+    double2 ra[2], rb[4];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int p = tid + u * 256, r = p >> 3, c = (p & 7) * 2;
+            const long long gr = row0 + r;
+            double2 v = make_double2(0.0, 0.0);
+            if (gr < n) {
+                const double *src = X + (size_t)gr * ss + k0 + c;
+                if (k0 + c + 1 < ss) {
+                    v.x = src[0] - mu[k0 + c];
+                    v.y = src[1] - mu[k0 + c + 1];
+                } else if (k0 + c < ss) {
+                    v.x = src[0] - mu[k0 + c];
+                }
+            }
+            ra[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int p = tid + u * 256, r = p >> 3, c = (p & 7) * 2;
+            const int gc = col0 + r;
+            double2 v = make_double2(0.0, 0.0);
+            if (gc < nc) {
+                const double *src = Vt + (size_t)gc * ss + k0 + c;
+                if (k0 + c + 1 < ss) {
+                    v.x = src[0];
+                    v.y = src[1];
+                } else if (k0 + c < ss) {
+                    v.x = src[0];
+                }
+            }
+            rb[u] = v;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int p = tid + u * 256, r = p >> 3, c = (p & 7) * 2;
+            As[r * PCA_LD + c] = ra[u].x;
+            As[r * PCA_LD + c + 1] = ra[u].y;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int p = tid + u * 256, r = p >> 3, c = (p & 7) * 2;
+            Bs[r * PCA_LD + c] = rb[u].x;
+            Bs[r * PCA_LD + c + 1] = rb[u].y;
+        }
+    };
+    load_tiles(0);
+    for (int k0 = 0; k0 < ss; k0 += PCA_BK) {
+        __syncthreads();
+        store_tiles();
+        __syncthreads();
+        if (k0 + PCA_BK < ss) load_tiles(k0 + PCA_BK);
+        const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+        for (int kk = 0; kk < PCA_BK / 4; kk++) {
+            const double a = As[(wave * 16 + fr) * PCA_LD + kk * 4 + fk];
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const double b = Bs[(t * 16 + fr) * PCA_LD + kk * 4 + fk];
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // C/D (f64): col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const int gc = col0 + t * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const long long gr = row0 + wave * 16 + (lane >> 4) + 4 * r;
+            if (gr < n && gc < nc) Y[(size_t)gr * nc + gc] = acc[t][r];
+        }
+    }
+}
+
+// whitening: y <- y / ||y||_2, zero vector -> all ones (Normalization.normalizeL2, Normalization.java:21-37).
+// One thread per row, sequential sum in index order: the same arithmetic as the reference given y.
+__global__ void k_rows_normalize_l2(double *__restrict__ Y, long long n, int nc) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    double *y = Y + (size_t)r * nc;
+    double norm2 = 0.0;
+    for (int i = 0; i < nc; i++) norm2 += y[i] * y[i];
+    norm2 = sqrt(norm2);
+    if (norm2 == 0.0) {
+        for (int i = 0; i < nc; i++) y[i] = 1.0;
+    } else {
+        for (int i = 0; i < nc; i++) y[i] = y[i] / norm2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8: VLAD.  One block per image, one vocabulary per call segment.
+//   phase 1  thread <-> descriptor: nearest centroid, first minimum wins, sequential j
+//            (computeNearestCentroid AFA:136-155; the early break cannot change the argmin).
+//            The codebook sits in LDS ([c][dl]); every lane reads the same address (broadcast).
+//   phase 2  per centroid, the ordered list of its descriptors (stable: descriptor order).
+//   phase 3  thread <-> (centroid, dim): vlad[c*dl+i] += desc[i] - cb[c][i] in DESCRIPTOR ORDER
+//            (VladAggregator.java:63-68) -- the accumulation order is the reference's, so the raw
+//            VLAD vector is bit-exact.
+//   phase 4  optional power (signed sqrt) + L2 normalisation of the sub-vector
+//            (VladAggregatorMultipleVocabularies.java:90-91): the squared norm is a block tree
+//            reduction, so normalised outputs carry a 1e-12 tolerance (Math.pow itself is only
+//            specified to 1 ulp).
+// ------------------------------------------------------------------------------------------------
+template <int DL>
+__global__ __launch_bounds__(256) void k_vlad(const double *__restrict__ codebook, int nc, int dl_rt, int maxnd,
+                                              const long long *__restrict__ desc_off, const double *__restrict__ descs,
+                                              double *__restrict__ out, int out_stride, int out_shift, int norms_on) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int dl = DL > 0 ? DL : dl_rt;
+    double *cb = (double *)smem;                 // [nc][dl]
+    int *nn = (int *)(cb + (size_t)nc * dl);     // [maxnd] (maxnd even)
+    int *lst = nn + maxnd;                       // [maxnd] descriptors grouped by centroid
+    int *cstart = lst + maxnd;                   // [nc + 1]
+    double *red = (double *)(cstart + ((nc + 2) & ~1));  // [4]
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const long long d0 = desc_off[img];
+    const int nd = (int)(desc_off[img + 1] - d0);
+    const double *D = descs + (size_t)d0 * dl;
+    double *vout = out + (size_t)img * out_stride + out_shift;
+    const int veclen = nc * dl;
+    for (int i = tid; i < veclen; i += 256) cb[i] = codebook[i];
+    __syncthreads();
+    // phase 1 (the descriptor stays in registers when its length is a template constant)
+    for (int d = tid; d < nd; d += 256) {
+        const double *x = D + (size_t)d * dl;
+        int best = -1;
+        double mind = 1.7976931348623157e308;
+        if constexpr (DL > 0) {
+            double xr[DL];
+#pragma unroll
+            for (int j = 0; j < DL; j++) xr[j] = x[j];
+            for (int c = 0; c < nc; c++) {
+                const double *cc = cb + (size_t)c * DL;
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < DL; j++) {
+                    const double df = cc[j] - xr[j];
+                    acc += df * df;
+                }
+                if (acc < mind) {
+                    mind = acc;
+                    best = c;
+                }
+            }
+        } else {
+            for (int c = 0; c < nc; c++) {
+                const double *cc = cb + (size_t)c * dl;
+                double acc = 0.0;
+                for (int j = 0; j < dl; j++) {
+                    const double df = cc[j] - x[j];
+                    acc += df * df;
+                }
+                if (acc < mind) {
+                    mind = acc;
+                    best = c;
+                }
+            }
+        }
+        nn[d] = best < 0 ? 0 : best;
+    }
+    __syncthreads();
+    // phase 2: counts -> starts -> stable fill
+    for (int c = tid; c < nc; c += 256) {
+        int cnt = 0;
+        for (int d = 0; d < nd; d++) cnt += (nn[d] == c);
+        cstart[c + 1] = cnt;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        cstart[0] = 0;
+        for (int c = 0; c < nc; c++) cstart[c + 1] += cstart[c];
+    }
+    __syncthreads();
+    for (int c = tid; c < nc; c += 256) {
+        int p = cstart[c];
+        for (int d = 0; d < nd; d++)
+            if (nn[d] == c) lst[p++] = d;
+    }
+    __syncthreads();
+    // phase 3
+    double ss = 0.0;
+    for (int e = tid; e < veclen; e += 256) {
+        const int c = e / dl, i = e - c * dl;
+        const double cv = cb[e];
+        double v = 0.0;
+        for (int p = cstart[c]; p < cstart[c + 1]; p++) v += D[(size_t)lst[p] * dl + i] - cv;
+        if (norms_on) {
+            // normalizePower(0.5): signum(v) * pow(|v|, 0.5)   (Normalization.java:74-79)
+            const double a = sqrt(fabs(v));
+            v = (v > 0.0) ? a : ((v < 0.0) ? -a : v);
+            ss += v * v;
+        }
+        vout[e] = v;
+    }
+    if (!norms_on) return;
+    // phase 4: L2 over the sub-vector (zero norm -> ones)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const double norm = sqrt(red[0] + red[1] + red[2] + red[3]);
+    __syncthreads();
+    for (int e = tid; e < veclen; e += 256) vout[e] = (norm == 0.0) ? 1.0 : vout[e] / norm;
+}
+
+// L2 over the concatenation when more than one vocabulary (VladAggregatorMultipleVocabularies.java:97-99)
+__global__ __launch_bounds__(256) void k_rows_normalize_l2_block(double *__restrict__ Y, int len) {
+    __shared__ double red[4];
+    double *y = Y + (size_t)blockIdx.x * len;
+    double ss = 0.0;
+    for (int i = threadIdx.x; i < len; i += 256) ss += y[i] * y[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const double norm = sqrt(red[0] + red[1] + red[2] + red[3]);
+    for (int i = threadIdx.x; i < len; i += 256) y[i] = (norm == 0.0) ? 1.0 : y[i] / norm;
+}

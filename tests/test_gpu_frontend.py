@@ -1,0 +1,103 @@
+"""GPU parity of the config-5 front end: batched VLAD (K8) and the f64-MFMA PCA projection (K7)
+against the CPU oracle.  VLAD without normalisation is bit-exact (accumulation in descriptor
+order); normalised VLAD and PCA carry the stated 1e-12 tolerance (Math.pow / EJML order, A2)."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def mi():
+    try:
+        import torch
+
+        torch.cuda.init()
+    except Exception:
+        pass
+    m = importlib.import_module("multimedia-indexing_amd")
+    if m.lib().mmidx_device_count() < 1:
+        pytest.fail("libmmidx_hip.so found no HIP device: GPU tests must run the native path")
+    return m
+
+
+@pytest.mark.parametrize("nc,dl", [(128, 64), (32, 64), (20, 12)])
+def test_vlad_raw_bit_exact(mi, oracle, nc, dl):
+    rng = np.random.default_rng(nc + dl)
+    cb = rng.standard_normal((nc, dl))
+    sets = [rng.standard_normal((n, dl)) for n in (0, 1, 7, 300, 777, 256, 513)]
+    for s in sets:  # SURF-like: L2-normalised descriptors
+        if len(s):
+            s /= np.linalg.norm(s, axis=1, keepdims=True)
+    agg = mi.VladAggregator(cb)
+    out = agg.aggregate_batch(sets)
+    assert out.shape == (len(sets), nc * dl)
+    for i, s in enumerate(sets):
+        ref = oracle.vlad_aggregate(cb, s)
+        assert np.array_equal(out[i], ref), i
+    assert np.array_equal(agg.aggregate(sets[3]), oracle.vlad_aggregate(cb, sets[3]))
+    agg.close()
+
+
+def test_vlad_multi_vocab_normalised(mi, oracle):
+    rng = np.random.default_rng(5)
+    dl = 64
+    cbs = [rng.standard_normal((128, dl)), rng.standard_normal((64, dl)), rng.standard_normal((16, dl))]
+    sets = [rng.standard_normal((n, dl)) for n in (0, 5, 400)]
+    agg = mi.VladAggregatorMultipleVocabularies(cbs)
+    assert agg.getVectorLength() == (128 + 64 + 16) * dl
+    out = agg.aggregate_batch(sets)
+    for i, s in enumerate(sets):
+        ref = oracle.vlad_aggregate_multi(cbs, s, True)
+        assert np.max(np.abs(out[i] - ref)) <= TOL, i
+    # single vocabulary with normalisation: no second L2 (VladAggregatorMultipleVocabularies.java:97)
+    one = mi.VladAggregatorMultipleVocabularies([cbs[0]])
+    o1 = one.aggregate_batch(sets)
+    for i, s in enumerate(sets):
+        assert np.max(np.abs(o1[i] - oracle.vlad_aggregate_multi([cbs[0]], s, True))) <= TOL
+    # zero descriptors + normalisation -> all ones / sqrt... (zero norm -> ones, Normalization.java:29-30)
+    assert np.all(o1[0] == 1.0)
+    agg.close()
+    one.close()
+
+
+@pytest.mark.parametrize("nc,ss,n,whiten", [(128, 8192, 300, True), (128, 8192, 65, False), (40, 1000, 130, True), (7, 33, 5, False)])
+def test_pca_projection_mfma(mi, oracle, nc, ss, n, whiten):
+    rng = np.random.default_rng(nc + ss)
+    Vt = np.linalg.qr(rng.standard_normal((ss, nc)))[0].T.copy()          # orthonormal rows
+    mu = 0.01 * rng.standard_normal(ss)
+    eig = np.sort(rng.uniform(0.5, 4.0, nc))[::-1].copy()
+    X = rng.standard_normal((n, ss)) / np.sqrt(ss)
+    X[1] = mu  # projects to the zero vector: whitening then yields all ones (Normalization.java:29-30)
+    pca = mi.PCA(nc, 0, ss, whiten)
+    pca.load(mu, eig if whiten else None, Vt)
+    Y = pca.project(X)
+    Vw = oracle.pca_whiten(Vt, eig) if whiten else Vt
+    for i in range(n):
+        ref = oracle.pca_project(Vw, mu, X[i], whiten)
+        scale = max(1.0, float(np.linalg.norm(ref)))
+        assert np.max(np.abs(Y[i] - ref)) <= TOL * scale, (i, np.max(np.abs(Y[i] - ref)))
+    if whiten:
+        assert np.all(Y[1] == 1.0)
+    # A = I check with an asymmetric B (catches a transposed C/D layout)
+    y1 = pca.sampleToEigenSpace(X[0])
+    assert np.array_equal(y1, Y[0])
+    with pytest.raises(mi.MmidxError):
+        pca.project(np.zeros((2, ss + 1)))
+    pca.close()
+
+
+def test_pca_layout_identity(mi):
+    """Transpose-detecting check of the MFMA fragment maps: X = I-like rows against an asymmetric V_t."""
+    nc, ss = 32, 48
+    Vt = np.arange(nc * ss, dtype=np.float64).reshape(nc, ss) / 7.0
+    pca = mi.PCA(nc, 0, ss, False)
+    pca.load(np.zeros(ss), None, Vt)
+    X = np.zeros((ss, ss))
+    X[np.arange(ss), np.arange(ss)] = 1.0
+    Y = pca.project(X)            # Y[i][c] = Vt[c][i]
+    assert np.array_equal(Y, Vt.T)
+    pca.close()
