@@ -146,6 +146,17 @@ int mmidx_coarse_device(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d
 int mmidx_search_partial_device(mmidx_index *h, int k, int64_t nq, const double *dQ,
                                 const int32_t *d_cells, double *d_pdist, int64_t *d_pkey,
                                 int32_t *d_pcount, void *stream);
+/* Two-phase form of the partial search, so that shards can share their thresholds:
+ *   pass A scans probe rank 0 of every query on this shard and exports the shard's threshold per
+ *   query (the (k+1)-th best distance so far as a double, +inf when there are fewer candidates);
+ *   the host MIN-all-reduces that array over ranks; pass B imports it, drops every probe whose
+ *   coarse bound exceeds it, scans the rest and writes the sorted partial lists.  pass B must follow
+ *   pass A on the same handle with the same (k, nq, dQ, d_cells). */
+int mmidx_shard_pass_a_device(mmidx_index *h, int k, int64_t nq, const double *dQ,
+                              const int32_t *d_cells, double *d_T_out, void *stream);
+int mmidx_shard_pass_b_device(mmidx_index *h, int k, int64_t nq, const double *dQ,
+                              const int32_t *d_cells, const double *d_T_in, double *d_pdist,
+                              int64_t *d_pkey, int32_t *d_pcount, void *stream);
 int mmidx_merge_partials_device(int device, int k, int64_t nq, int nshards, const double *d_pdist,
                                 const int64_t *d_pkey, const int32_t *d_pcount,
                                 int32_t *d_iid_out, double *d_dist_out, int32_t *d_count_out,

@@ -422,7 +422,9 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
 // one sub-batch (nq <= plan.qb) entirely on device
 int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq, const double *dQ, const int32_t *d_cells_in,
                         int mode, int32_t *d_iid, double *d_dist, int32_t *d_cnt, double *d_pdist, long long *d_pkey,
-                        hipStream_t st) {
+                        int phase, double *d_T_io, hipStream_t st) {
+    // phase 0: whole search.  Sharded search splits it so that the thresholds can be MIN-reduced
+    // across ranks in between: phase 1 = setup + pass A + export T, phase 2 = import T + pass B + merge.
     const int ivf = h->kind == MMIDX_KIND_IVFPQ;
     bool prof = h->profiling;
     hipEvent_t *ev = nullptr;
@@ -453,8 +455,10 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
     HIPCK(h->ws_pkey.reserve((size_t)nq * pl.poolq));
     HIPCK(h->ws_pval.reserve((size_t)nq * pl.poolq));
     HIPCK(h->ws_flag.reserve((size_t)nq));
-    HIPCK(hipMemsetAsync(h->ws_T.p, 0xFF, (size_t)nq * sizeof(u64), st));
-    HIPCK(hipMemsetAsync(h->ws_pcnt.p, 0, (size_t)nq * sizeof(u32), st));
+    if (phase != 2) {
+        HIPCK(hipMemsetAsync(h->ws_T.p, 0xFF, (size_t)nq * sizeof(u64), st));
+        HIPCK(hipMemsetAsync(h->ws_pcnt.p, 0, (size_t)nq * sizeof(u32), st));
+    }
 
     ScanParams P{};
     P.Q = dQ;
@@ -492,10 +496,27 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
         P.xcd_remap = 0;
         // (the adaptive filter also works from T = +inf, but for one list per query the exact scan
         //  measured faster: 1.23 vs ~1.4 ms per 8192 queries; MMIDX_PASSA_FILTER=1 switches)
-        int rc = h->passa_filter ? launch_scan_filtered(h, P, pl, dim3((unsigned)P.n_items, (unsigned)pl.nchunks), st)
+        int rc = MMIDX_OK;
+        if (phase != 2) {
+            rc = h->passa_filter ? launch_scan_filtered(h, P, pl, dim3((unsigned)P.n_items, (unsigned)pl.nchunks), st)
                                  : launch_scan(h, P, dim3((unsigned)P.n_items, (unsigned)pl.nchunks), pl.lds, st);
-        if (rc) return rc;
-        DBG_SYNC("pass A scan");
+            if (rc) return rc;
+            DBG_SYNC("pass A scan");
+        }
+        if (phase == 1) {
+            hipLaunchKernelGGL(k_T_export, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, h->ws_T.p, d_T_io, (long long)nq);
+            HIPCK(hipGetLastError());
+            if (prof) {
+                HIPCK(hipEventRecord(ev[3], st));
+                HIPCK(hipEventRecord(ev[4], st));
+                h->launches += 1;
+            }
+            return MMIDX_OK;
+        }
+        if (phase == 2) {
+            hipLaunchKernelGGL(k_T_import, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, d_T_io, h->ws_T.p, (long long)nq);
+            HIPCK(hipGetLastError());
+        }
         if (two_pass) {
             // pass B order: pairs with probe rank >= 1 that survive the coarse bound, sorted by cell
             // (device counting sort; needs the thresholds pass A just produced)
@@ -547,10 +568,18 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
             DBG_SYNC("pass B scan");
         }
         if (prof) HIPCK(hipEventRecord(ev[3], st));
-        if (prof) h->launches += two_pass ? 2 : 1;
-    } else if (prof) {
-        HIPCK(hipEventRecord(ev[2], st));
-        HIPCK(hipEventRecord(ev[3], st));
+        if (prof) h->launches += (two_pass ? 1 : 0) + (phase != 2 ? 1 : 0);
+    } else {
+        if (prof) {
+            HIPCK(hipEventRecord(ev[2], st));
+            HIPCK(hipEventRecord(ev[3], st));
+        }
+        if (phase == 1) {
+            hipLaunchKernelGGL(k_T_export, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, h->ws_T.p, d_T_io, (long long)nq);
+            HIPCK(hipGetLastError());
+            if (prof) HIPCK(hipEventRecord(ev[4], st));
+            return MMIDX_OK;
+        }
     }
     MergeParams M{};
     M.pool_cnt = h->ws_pcnt.p;
@@ -631,7 +660,7 @@ int search_common(mmidx_index *h, int k, int64_t nq, const double *dQ, const int
         rc = search_batch_device(h, pl, k, nb, dQ + (size_t)q0 * h->D, d_cells ? d_cells + (size_t)q0 * h->w : nullptr, mode,
                                  d_iid ? d_iid + (size_t)q0 * k : nullptr, d_dist ? d_dist + (size_t)q0 * k : nullptr,
                                  d_cnt + q0, d_pdist ? d_pdist + (size_t)q0 * pl.K1 : nullptr,
-                                 d_pkey ? d_pkey + (size_t)q0 * pl.K1 : nullptr, st);
+                                 d_pkey ? d_pkey + (size_t)q0 * pl.K1 : nullptr, 0, nullptr, st);
         if (rc) return rc;
     }
     return MMIDX_OK;
@@ -1067,6 +1096,42 @@ int mmidx_search_partial_device(mmidx_index *h, int k, int64_t nq, const double 
     hipStream_t st = (hipStream_t)stream;
     return search_common(h, k, nq, dQ, h->kind == MMIDX_KIND_IVFPQ ? d_cells : nullptr, 1, nullptr, nullptr, d_pcount, d_pdist,
                          (long long *)d_pkey, st);
+}
+
+// two-phase sharded search: thresholds are exchanged between the phases (MIN all-reduce)
+static int shard_phase(mmidx_index *h, int k, int64_t nq, const double *dQ, const int32_t *d_cells, int phase, double *d_T,
+                       double *d_pdist, int64_t *d_pkey, int32_t *d_pcount, void *stream) {
+    if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    if (nq > 0 && (!dQ || !d_T)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (phase == 2 && nq > 0 && (!d_pdist || !d_pkey || !d_pcount)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    int rc = check_ready(h);
+    if (rc) return rc;
+    const int ivf = h->kind == MMIDX_KIND_IVFPQ;
+    if (ivf && nq > 0 && !d_cells) return fail(MMIDX_ERR_INVALID_ARG, "IVFPQ shard search needs the probe cells");
+    if (ivf && (h->w < 1 || h->w > h->C)) return fail(MMIDX_ERR_INVALID_ARG, "w = %d outside 1..%d (setW)", h->w, h->C);
+    if (nq == 0) return MMIDX_OK;
+    rc = set_device(h);
+    if (rc) return rc;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        rc = build_csr(h);
+        if (rc) return rc;
+    }
+    SearchPlan pl;
+    rc = make_plan(h, k, nq, pl);
+    if (rc) return rc;
+    if (nq > pl.qb) return fail(MMIDX_ERR_UNSUPPORTED, "shard phases take at most %lld queries per call for this index", (long long)pl.qb);
+    return search_batch_device(h, pl, k, nq, dQ, ivf ? d_cells : nullptr, 1, nullptr, nullptr, d_pcount, d_pdist, (long long *)d_pkey, phase,
+                               d_T, (hipStream_t)stream);
+}
+
+int mmidx_shard_pass_a_device(mmidx_index *h, int k, int64_t nq, const double *dQ, const int32_t *d_cells, double *d_T_out, void *stream) {
+    return shard_phase(h, k, nq, dQ, d_cells, 1, d_T_out, nullptr, nullptr, nullptr, stream);
+}
+
+int mmidx_shard_pass_b_device(mmidx_index *h, int k, int64_t nq, const double *dQ, const int32_t *d_cells, const double *d_T_in,
+                              double *d_pdist, int64_t *d_pkey, int32_t *d_pcount, void *stream) {
+    return shard_phase(h, k, nq, dQ, d_cells, 2, (double *)d_T_in, d_pdist, d_pkey, d_pcount, stream);
 }
 
 int mmidx_merge_partials_device(int device, int k, int64_t nq, int nshards, const double *d_pdist, const int64_t *d_pkey,

@@ -1647,3 +1647,19 @@ __global__ void k_count_flags(const int32_t *__restrict__ flag, long long n, u64
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(total, v);
 }
+
+// thresholds cross the process boundary as doubles (+inf = "fewer than k+1 candidates so far") so
+// that a MIN all-reduce over ranks is meaningful
+__global__ void k_T_export(const u64 *__restrict__ T, double *__restrict__ out, long long n) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) out[e] = (T[e] >= 0x7FF0000000000000ull) ? __longlong_as_double(0x7FF0000000000000ll) : keyd(T[e]);
+}
+__global__ void k_T_import(const double *__restrict__ in, u64 *__restrict__ T, long long n) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const double v = in[e];
+    if (v >= 0.0 && v < __longlong_as_double(0x7FF0000000000000ll)) {
+        const u64 k = dkey(v);
+        if (k < T[e]) T[e] = k;
+    }
+}

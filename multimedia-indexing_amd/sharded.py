@@ -7,9 +7,11 @@ replicated (8.25 MiB).  Per batch:
 
   1. coarse top-w for a 1/world slice of the queries            (mmidx_coarse_device)
   2. all-gather of the probe cells                               (RCCL, nq*w*4 bytes)
-  3. scan of the locally owned probed lists -> sorted top-(k+1)  (mmidx_search_partial_device)
-  4. all-gather of (distance, key, count) partial lists          (RCCL, nq*(k+1)*16 bytes/rank)
-  5. merge of the `world` sorted lists per query                 (mmidx_merge_partials_device)
+  3. pass A: scan of probe rank 0 where it is local -> thresholds  (mmidx_shard_pass_a_device)
+  4. MIN all-reduce of the thresholds                             (RCCL, nq*8 bytes)
+  5. pass B: remaining local probes under the global thresholds   (mmidx_shard_pass_b_device)
+  6. all-to-all of the sorted partial lists to the query's owner  (RCCL, nq*(k+1)*16 bytes/rank)
+  7. merge of the `world` lists per owned query, all-gather results (mmidx_merge_partials_device)
 
 The collectives go through torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in the CPU
 tests).  The per-rank engine is pluggable so that the orchestration (this file) is exercised on
@@ -79,7 +81,27 @@ class HipShardEngine:
             N.check(self.L.mmidx_coarse_device(self.h, Qs.shape[0], Qs.data_ptr(), cells.data_ptr(), self._stream()))
         return cells
 
+    def pass_a(self, k, Q, cells):
+        """scan probe rank 0 on this shard; returns the shard's thresholds [nq] float64 (+inf = none)"""
+        t = self.torch
+        T = t.empty(Q.shape[0], dtype=t.float64, device=Q.device)
+        N.check(self.L.mmidx_shard_pass_a_device(self.h, k, Q.shape[0], Q.data_ptr(), cells.data_ptr(), T.data_ptr(),
+                                                 self._stream()))
+        return T
+
+    def pass_b(self, k, Q, cells, T):
+        """remaining probes with the cross-shard thresholds; returns sorted partial lists"""
+        t = self.torch
+        nq, K1 = Q.shape[0], k + 1
+        pd = t.empty(nq, K1, dtype=t.float64, device=Q.device)
+        pk = t.empty(nq, K1, dtype=t.int64, device=Q.device)
+        pc = t.empty(nq, dtype=t.int32, device=Q.device)
+        N.check(self.L.mmidx_shard_pass_b_device(self.h, k, nq, Q.data_ptr(), cells.data_ptr(), T.data_ptr(), pd.data_ptr(),
+                                                 pk.data_ptr(), pc.data_ptr(), self._stream()))
+        return pd, pk, pc
+
     def search_partial(self, k, Q, cells):
+        """single-call form (no threshold exchange)"""
         t = self.torch
         nq, K1 = Q.shape[0], k + 1
         pd = t.empty(nq, K1, dtype=t.float64, device=Q.device)
@@ -95,14 +117,22 @@ class HipShardEngine:
         iid = t.empty(nq, k, dtype=t.int32, device=pd_all.device)
         dist = t.empty(nq, k, dtype=t.float64, device=pd_all.device)
         cnt = t.empty(nq, dtype=t.int32, device=pd_all.device)
-        N.check(self.L.mmidx_merge_partials_device(self.dev, k, nq, S, pd_all.data_ptr(), pk_all.data_ptr(),
-                                                   pc_all.data_ptr(), iid.data_ptr(), dist.data_ptr(),
-                                                   cnt.data_ptr(), self._stream()))
+        if nq:
+            N.check(self.L.mmidx_merge_partials_device(self.dev, k, nq, S, pd_all.data_ptr(), pk_all.data_ptr(),
+                                                       pc_all.data_ptr(), iid.data_ptr(), dist.data_ptr(),
+                                                       cnt.data_ptr(), self._stream()))
         return iid, dist, cnt
 
 
 class ShardedIVFPQ:
-    """computeNearestNeighbors over `world` shards (IVFPQ.computeKnnIVFADC, IVFPQ.java:408-450)."""
+    """computeNearestNeighbors over `world` shards (IVFPQ.computeKnnIVFADC, IVFPQ.java:408-450).
+
+    Collectives per batch (B queries, K1 = k + 1):
+      all-gather  probe cells        B*w*4 bytes
+      all-reduce  thresholds (MIN)   B*8 bytes            -- lets every shard prune with the global bound
+      all-to-all  partial lists      B*K1*16 bytes/rank   -- query q is merged on rank q // per
+      all-gather  results            B*k*12 bytes
+    """
 
     def __init__(self, engine, rank, world, dist=None, group=None):
         self.engine, self.rank, self.world, self.dist, self.group = engine, rank, world, dist, group
@@ -120,17 +150,45 @@ class ShardedIVFPQ:
             self.dist.all_gather(parts, x.contiguous(), group=self.group)
         return out
 
+    def _all_to_all(self, x):
+        """x [world][...]: slice r goes to rank r; returns [world][...] = what every rank sent to me"""
+        torch = __import__("torch")
+        if self.world == 1:
+            return x
+        out = torch.empty_like(x)
+        self.dist.all_to_all_single(out, x.contiguous(), group=self.group)
+        return out
+
     def search(self, k, Q):
         """Q: [nq][D] float64 tensor, identical on every rank.  Returns (iid, dist, count) on every rank."""
-        nq = Q.shape[0]
-        per = (nq + self.world - 1) // self.world
+        torch = __import__("torch")
+        nq, W = Q.shape[0], self.world
+        per = (nq + W - 1) // W
         q0 = min(self.rank * per, nq)
         q1 = min(q0 + per, nq)
         cells_sl = self.engine.coarse(Q[q0:q1])
         if q1 - q0 < per:  # pad the slice so that every rank contributes the same shape
-            torch = __import__("torch")
             pad = torch.full((per - (q1 - q0), cells_sl.shape[1]), -1, dtype=cells_sl.dtype, device=cells_sl.device)
             cells_sl = torch.cat([cells_sl, pad], 0)
-        cells = self._all_gather(cells_sl).reshape(self.world * per, -1)[:nq].contiguous()
-        pd, pk, pc = self.engine.search_partial(k, Q, cells)
-        return self.engine.merge(k, self._all_gather(pd), self._all_gather(pk), self._all_gather(pc))
+        cells = self._all_gather(cells_sl).reshape(W * per, -1)[:nq].contiguous()
+        T = self.engine.pass_a(k, Q, cells)
+        if W > 1:
+            self.dist.all_reduce(T, op=self.dist.ReduceOp.MIN, group=self.group)
+        pd, pk, pc = self.engine.pass_b(k, Q, cells, T)
+        if W == 1:
+            return self.engine.merge(k, pd.unsqueeze(0), pk.unsqueeze(0), pc.unsqueeze(0))
+        # owner merge: pad the query axis to W*per, view as [W][per][...], exchange, merge my slice
+        K1 = k + 1
+        if W * per > nq:
+            padn = W * per - nq
+            pd = torch.cat([pd, torch.full((padn, K1), float("inf"), dtype=pd.dtype, device=pd.device)], 0)
+            pk = torch.cat([pk, torch.full((padn, K1), -1, dtype=pk.dtype, device=pk.device)], 0)
+            pc = torch.cat([pc, torch.zeros(padn, dtype=pc.dtype, device=pc.device)], 0)
+        rd = self._all_to_all(pd.reshape(W, per, K1))
+        rk = self._all_to_all(pk.reshape(W, per, K1))
+        rc = self._all_to_all(pc.reshape(W, per))
+        iid, dist_, cnt = self.engine.merge(k, rd, rk, rc)  # [per][k]
+        iid = self._all_gather(iid).reshape(W * per, k)[:nq]
+        dist_ = self._all_gather(dist_).reshape(W * per, k)[:nq]
+        cnt = self._all_gather(cnt).reshape(W * per)[:nq]
+        return iid, dist_, cnt

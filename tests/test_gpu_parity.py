@@ -354,6 +354,14 @@ def test_virtual_shards_on_one_device(mi, oracle, S):
     engines = [sh.HipShardEngine(ix._h, D, w, 0) for ix in shards]
     probe = engines[0].coarse(Q)
     for k in (1, 10, 100):
+        # two-phase form with the threshold exchange the RCCL path does (MIN over shards)
+        Ts = [e.pass_a(k, Q, probe) for e in engines]
+        Tmin = torch.stack(Ts).min(0).values.contiguous()
+        parts2 = [e.pass_b(k, Q, probe, Tmin) for e in engines]
+        i2, d2, c2 = engines[0].merge(k, torch.stack([x[0] for x in parts2]), torch.stack([x[1] for x in parts2]),
+                                      torch.stack([x[2] for x in parts2]))
+        torch.cuda.synchronize()
+        assert_same((i2.cpu().numpy(), d2.cpu().numpy(), c2.cpu().numpy()), ref.search_batch(p["queries"], k))
         parts = [e.search_partial(k, Q, probe) for e in engines]
         iid, dd, cnt = engines[0].merge(k, torch.stack([x[0] for x in parts]), torch.stack([x[1] for x in parts]),
                                         torch.stack([x[2] for x in parts]))

@@ -39,6 +39,14 @@ class OracleShardEngine:
         out = np.stack([self.full.nearest_coarse(q, self.w) for q in Qs.numpy()]) if Qs.shape[0] else np.zeros((0, self.w), np.int32)
         return torch.from_numpy(out.astype(np.int32))
 
+    def pass_a(self, k, Q, cells):
+        # the oracle has no thresholds to share: +inf everywhere (pruning is a GPU-side optimisation)
+        return torch.full((Q.shape[0],), float("inf"), dtype=torch.float64)
+
+    def pass_b(self, k, Q, cells, T):
+        assert torch.all(torch.isinf(T))  # MIN over ranks of +inf
+        return self.search_partial(k, Q, cells)
+
     def search_partial(self, k, Q, cells):
         nq, K1 = Q.shape[0], k + 1
         pd = np.full((nq, K1), np.inf)
