@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--w", type=int, default=32)
     ap.add_argument("--m", type=int, default=16)
     ap.add_argument("--k", type=int, default=100)
-    ap.add_argument("--batch", type=int, default=8192)
+    ap.add_argument("--batch", type=int, default=16384)
     ap.add_argument("--nbatches", type=int, default=4)
     ap.add_argument("--chunk", type=int, default=2_000_000)
     ap.add_argument("--gt", type=int, default=1024, help="queries with exact ground truth (recall@1)")

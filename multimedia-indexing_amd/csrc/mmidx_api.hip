@@ -348,11 +348,11 @@ int make_plan(mmidx_index *h, int k, int64_t nq, SearchPlan &pl) {
     // a work item emits at most K1 survivors, but no query can emit more than its candidates
     int64_t poolq = (int64_t)pl.nitems * pl.K1;
     pl.poolq = (int)std::min<int64_t>(poolq, std::max<int64_t>(h->n_csr, pl.K1));
-    // sub-batch so that the pool stays <= 2 GiB and the coarse matrix <= 1 GiB
+    // sub-batch so that the pool and the coarse distance matrix stay <= 2 GiB each
     int64_t qb = std::min<int64_t>(nq, (int64_t)(1 << 30) / std::max(nprobe, 1));
     const int64_t pool_bytes_q = (int64_t)pl.poolq * 16;
     qb = std::min<int64_t>(qb, std::max<int64_t>(1, (2ll << 30) / std::max<int64_t>(pool_bytes_q, 1)));
-    if (ivf) qb = std::min<int64_t>(qb, std::max<int64_t>(1, (1ll << 30) / ((int64_t)h->C * 8)));
+    if (ivf) qb = std::min<int64_t>(qb, std::max<int64_t>(1, (2ll << 30) / ((int64_t)h->C * 8)));
     pl.qb = qb;
     return MMIDX_OK;
 }
@@ -1079,7 +1079,7 @@ int mmidx_coarse_device(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d
     rc = set_device(h);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const int64_t qb = std::max<int64_t>(1, (1ll << 30) / ((int64_t)h->C * 8));
+    const int64_t qb = std::max<int64_t>(1, (2ll << 30) / ((int64_t)h->C * 8));
     for (int64_t q0 = 0; q0 < nq; q0 += qb) {
         const int64_t nb = std::min(qb, nq - q0);
         rc = run_coarse(h, nb, dQ + (size_t)q0 * h->D, d_cells_out + (size_t)q0 * h->w, st);
