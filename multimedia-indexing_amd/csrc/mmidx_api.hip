@@ -106,7 +106,11 @@ struct mmidx_index {
     std::mutex mu;
 
     double *d_coarse = nullptr, *d_coarseT = nullptr, *d_pq = nullptr, *d_pqT = nullptr,
-           *d_rot = nullptr;
+           *d_rot = nullptr, *d_cn = nullptr, *d_cnorm = nullptr;
+    float *d_coarseT32 = nullptr;
+    double cn_max = 0.0, cnorm_max = 0.0;
+    bool exact_coarse = false;  // MMIDX_EXACT_COARSE=1: fp64 distances to every centroid (K1a/K1b)
+    bool cdsel_valid = false;   // ws_cdsel holds the selected cells' exact distances for the current batch
     int32_t *d_perm = nullptr;
 
     // CSR
@@ -122,7 +126,8 @@ struct mmidx_index {
     void *d_pcodes = nullptr;
 
     // workspaces
-    DevBuf<double> ws_Q, ws_cdist, ws_odist, ws_X;
+    DevBuf<double> ws_Q, ws_cdist, ws_odist, ws_X, ws_qn, ws_cdsel;
+    DevBuf<float> ws_Q32, ws_S;
     DevBuf<int32_t> ws_cells, ws_oiid, ws_ocnt, ws_flag, ws_ecell, ws_pcount, ws_pstart, ws_pcursor, ws_order;
     DevBuf<u64> ws_T, ws_pkey, ws_pval;
     DevBuf<u32> ws_pcnt;
@@ -385,6 +390,44 @@ int launch_scan_filtered(const mmidx_index *h, ScanParams P, const SearchPlan &p
 int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, hipStream_t st) {
     constexpr int QT = 8;
     HIPCK(h->ws_cdist.reserve((size_t)nq * h->C));
+    h->cdsel_valid = false;
+    const size_t alds = (size_t)MMIDX_CSEL_CAP * 12 + (size_t)(h->w + 1) * 8 + (size_t)((h->w + 2) & ~1) * 4 +
+                        (size_t)MMIDX_CAND_CHUNK * h->D * 8 + 16;
+    const bool approx = !h->exact_coarse && h->C >= MMIDX_BLOCK && h->w + 1 <= MMIDX_BLOCK && h->C <= 64 * MMIDX_BLOCK &&
+                        h->w >= 1 && alds <= 64 * 1024;
+    if (approx) {
+        // K1c + K1d: fp32 dot products for all centroids, fp64 only for the certified candidates
+        HIPCK(h->ws_Q32.reserve((size_t)nq * h->D));
+        HIPCK(h->ws_qn.reserve((size_t)nq));
+        HIPCK(h->ws_S.reserve((size_t)nq * h->C));
+        HIPCK(h->ws_cdsel.reserve((size_t)nq * h->w));
+        hipLaunchKernelGGL(k_query_prep, dim3((unsigned)((nq + 3) / 4)), dim3(MMIDX_BLOCK), 0, st, dQ, h->ws_Q32.p, h->ws_qn.p, h->D, (long long)nq);
+        dim3 g1((unsigned)((h->C + DOT_BN - 1) / DOT_BN), (unsigned)((nq + DOT_BM - 1) / DOT_BM));
+        hipLaunchKernelGGL(k_coarse_dot32, g1, dim3(MMIDX_BLOCK), 0, st, h->d_coarseT32, h->ws_Q32.p, h->d_cn, h->ws_qn.p, h->ws_S.p, h->C, h->D, (int)nq);
+        ApproxSel A{};
+        A.S = h->ws_S.p;
+        A.qn = h->ws_qn.p;
+        A.cnorm_max = h->cnorm_max;
+        A.cn_max = h->cn_max;
+        A.Q = dQ;
+        A.coarse = h->d_coarse;
+        A.coarseT = h->d_coarseT;
+        A.row_scratch = h->ws_cdist.p;
+        A.cells = d_cells;
+        A.cdsel = h->ws_cdsel.p;
+        A.C = h->C;
+        A.D = h->D;
+        A.w = h->w;
+        if (h->C <= 8 * MMIDX_BLOCK)
+            hipLaunchKernelGGL(k_coarse_select_approx<8>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), alds, st, A);
+        else if (h->C <= 32 * MMIDX_BLOCK)
+            hipLaunchKernelGGL(k_coarse_select_approx<32>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), alds, st, A);
+        else
+            hipLaunchKernelGGL(k_coarse_select_approx<64>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), alds, st, A);
+        HIPCK(hipGetLastError());
+        h->cdsel_valid = true;
+        return MMIDX_OK;
+    }
     dim3 g1((unsigned)((h->C + MMIDX_BLOCK - 1) / MMIDX_BLOCK), (unsigned)((nq + QT - 1) / QT));
     hipLaunchKernelGGL(k_coarse_dist<QT>, g1, dim3(MMIDX_BLOCK), 0, st, h->d_coarseT, dQ, h->ws_cdist.p, h->C, h->D, (int)nq);
     const size_t lds = (size_t)(h->w + 1) * 12 + 16;
@@ -530,7 +573,8 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
             PB.Q = dQ;
             PB.coarse = h->d_coarse;
             PB.T = h->ws_T.p;
-            PB.cdist = (ivf && !d_cells_in) ? h->ws_cdist.p : nullptr;
+            PB.cdsel = (ivf && !d_cells_in && h->cdsel_valid) ? h->ws_cdsel.p : nullptr;
+            PB.cdist = (ivf && !d_cells_in && !h->cdsel_valid) ? h->ws_cdist.p : nullptr;
             PB.rmax = h->rmax;
             PB.D = h->D;
             PB.C = h->C;
@@ -743,6 +787,8 @@ int mmidx_create(int kind, int D, int m, int ks, int C, int transform, const int
         h->no_bound = (nb && nb[0] == '1') || h->no_filter;
         const char *ds = getenv("MMIDX_DEBUG_SYNC");
         h->debug_sync = ds && ds[0] == '1';
+        const char *ec = getenv("MMIDX_EXACT_COARSE");
+        h->exact_coarse = ec && ec[0] == '1';
         const char *pf = getenv("MMIDX_PASSA_FILTER");
         h->passa_filter = pf && pf[0] == '1';
     }
@@ -754,7 +800,7 @@ int mmidx_destroy(mmidx_index *h) {
     if (!h) return MMIDX_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *ptrs[] = {h->d_coarse, h->d_coarseT, h->d_pq, h->d_pqT, h->d_rot, h->d_perm, h->d_off, h->d_codes,
+    void *ptrs[] = {h->d_cn, h->d_cnorm, h->d_coarseT32, h->d_coarse, h->d_coarseT, h->d_pq, h->d_pqT, h->d_rot, h->d_perm, h->d_off, h->d_codes,
                     h->d_ids,    h->d_pcell,   h->d_pid, h->d_pcodes};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -762,6 +808,10 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_cdist.release();
     h->ws_odist.release();
     h->ws_X.release();
+    h->ws_qn.release();
+    h->ws_cdsel.release();
+    h->ws_Q32.release();
+    h->ws_S.release();
     h->ws_cells.release();
     h->ws_oiid.release();
     h->ws_ocnt.release();
@@ -800,6 +850,29 @@ int mmidx_set_coarse(mmidx_index *h, const double *coarse) {
     if (!h->d_coarseT) HIPCK(hipMalloc((void **)&h->d_coarseT, n * sizeof(double)));
     HIPCK(hipMemcpy(h->d_coarse, coarse, n * sizeof(double), hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(h->d_coarseT, T.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    // certified approximate coarse stage: |c|^2, |c| (fp64) and an fp32 transposed copy
+    h->cn_max = 0.0;
+    h->cnorm_max = 0.0;
+    std::vector<double> cn((size_t)h->C), cnorm((size_t)h->C);
+    std::vector<float> T32(n);
+    for (int c = 0; c < h->C; c++) {
+        double s2 = 0.0;
+        for (int j = 0; j < h->D; j++) {
+            const double v = coarse[(size_t)c * h->D + j];
+            s2 += v * v;
+            T32[(size_t)j * h->C + c] = (float)v;
+        }
+        cn[(size_t)c] = s2;
+        cnorm[(size_t)c] = std::sqrt(s2) * (1.0 + 1e-12);
+        h->cn_max = std::max(h->cn_max, s2 * (1.0 + 1e-12));
+        h->cnorm_max = std::max(h->cnorm_max, cnorm[(size_t)c]);
+    }
+    if (!h->d_cn) HIPCK(hipMalloc((void **)&h->d_cn, (size_t)h->C * 8));
+    if (!h->d_cnorm) HIPCK(hipMalloc((void **)&h->d_cnorm, (size_t)h->C * 8));
+    if (!h->d_coarseT32) HIPCK(hipMalloc((void **)&h->d_coarseT32, n * sizeof(float)));
+    HIPCK(hipMemcpy(h->d_cn, cn.data(), (size_t)h->C * 8, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(h->d_cnorm, cnorm.data(), (size_t)h->C * 8, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(h->d_coarseT32, T32.data(), n * sizeof(float), hipMemcpyHostToDevice));
     h->coarse_set = true;
     return MMIDX_OK;
 }

@@ -252,6 +252,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_reg(const double 
 // kernels -- the sorted head by (distance, index) -- so the tie rule in coarse_emit is unchanged.
 // If the gather overflows (massive ties) the round-based selection runs on the registers instead.
 #define MMIDX_CSEL_CAP 1024
+#define MMIDX_CAND_CHUNK 16
 template <int PER>
 __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_fast(const double *__restrict__ dist, int C, int w,
                                                                     int32_t *__restrict__ cells) {
@@ -338,6 +339,381 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_fast(const double
     }
     __syncthreads();
     if (tid == 0) coarse_emit(row, C, w, R, sel_k, sel_i, cells + (size_t)q * w);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 (certified approximate path): the exact coarse stage costs C*D fp64 (sub, mul, add) triples
+// per query although only w+1 of the C distances matter.  Here the C*D work is one fp32 FMA each
+// (K1c, dot products q.c), and fp64 is spent only on the few centroids that can still be among the
+// w+1 nearest given a rigorous error bound (K1d):
+//
+//   d~(c) = |c|^2 + |q|^2 - 2 S(c),  S = fp32 FMA chain over fl32(q), fl32(c)
+//   |d~ - d| <= eps(c) = 2 (D + 3) 2^-24 (1.01) |q| |c| + 1e-12 (|c|^2 + |q|^2)
+//       (input rounding 2^-24 each, D fused multiply-adds; Cauchy-Schwarz on sum |q_j c_j|)
+//   tau = some upper bound on the (w+1)-th smallest of d~ + eps  (thread-minima trick of K1b-fast)
+//   candidates = { c : d~(c) - eps(c) <= tau }: every centroid outside has d > tau >= the (w+1)-th
+//   smallest exact distance, so it is neither selected nor tied with a selected one.
+//   The candidates get the exact sequential fp64 distance (the reference's arithmetic), are sorted
+//   by (distance, index), and the bounded-queue rule is applied to them.
+// If the candidate buffer overflows, the block computes the exact row and runs the round-based
+// selection (same code as K1b).
+// ------------------------------------------------------------------------------------------------
+// K1c: S[q][c] = sum_j Q32[q][j] * CT32[j][c] on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: an
+// exact k-ordered fp32 FMA chain, so the error bound above applies as written).  Block = 4 waves,
+// tile 64 queries x 256 centroids, K in steps of 32 through LDS; wave w owns 16 query rows and all
+// 16 column tiles.  A fragment: A[i = lane & 15][k = lane >> 4], B fragment: B[k = lane >> 4][j = lane & 15];
+// C/D (f32): col = lane & 15, row = 4 * (lane >> 4) + reg.
+#define DOT_BM 64
+#define DOT_BN 256
+#define DOT_BK 32
+#define DOT_LDA 34  // padded A row stride (floats): (2*row + k) mod 32 is conflict-free for the fragment read
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_dot32(const float *__restrict__ CT32, const float *__restrict__ Q32,
+                                                              const double *__restrict__ cn, const double *__restrict__ qn,
+                                                              float *__restrict__ S, int C, int D, int nq) {
+    __shared__ float As[DOT_BM * DOT_LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[DOT_BK * DOT_BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = blockIdx.x * DOT_BN, q0 = blockIdx.y * DOT_BM;
+    f32x4 acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 ra[2], rb[8];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {  // A: 64 rows x 32 k = 512 float4
+            const int p = tid + u * 256, r = p >> 3, c4 = (p & 7) * 4;
+            const int q = q0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < nq) {
+                const float *src = Q32 + (size_t)q * D + k0 + c4;
+                if (k0 + c4 + 3 < D) {
+                    v = *(const float4 *)src;
+                } else {
+                    float tmp[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int e = 0; e < 4; e++)
+                        if (k0 + c4 + e < D) tmp[e] = src[e];
+                    v = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
+                }
+            }
+            ra[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {  // B: 32 k x 256 c = 2048 float4
+            const int p = tid + u * 256, r = p >> 6, c4 = (p & 63) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k0 + r < D) {
+                const float *src = CT32 + (size_t)(k0 + r) * C + c0 + c4;
+                if (c0 + c4 + 3 < C) {
+                    v = *(const float4 *)src;
+                } else {
+                    float tmp[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int e = 0; e < 4; e++)
+                        if (c0 + c4 + e < C) tmp[e] = src[e];
+                    v = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
+                }
+            }
+            rb[u] = v;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int p = tid + u * 256, r = p >> 3, c4 = (p & 7) * 4;
+            float *dst = As + r * DOT_LDA + c4;
+            dst[0] = ra[u].x;
+            dst[1] = ra[u].y;
+            dst[2] = ra[u].z;
+            dst[3] = ra[u].w;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int p = tid + u * 256, r = p >> 6, c4 = (p & 63) * 4;
+            *(float4 *)(Bs + r * DOT_BN + c4) = rb[u];
+        }
+    };
+    load_tiles(0);
+    for (int k0 = 0; k0 < D; k0 += DOT_BK) {
+        __syncthreads();
+        store_tiles();
+        __syncthreads();
+        if (k0 + DOT_BK < D) load_tiles(k0 + DOT_BK);
+        const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+        for (int kk = 0; kk < DOT_BK / 4; kk++) {
+            const float a = As[(wave * 16 + fr) * DOT_LDA + kk * 4 + fk];
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const float b = Bs[(kk * 4 + fk) * DOT_BN + t * 16 + fr];
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const int c = c0 + t * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int q = q0 + wave * 16 + 4 * (lane >> 4) + r;
+            // epilogue: d~ = |c|^2 + |q|^2 - 2 S, stored as fp32 (its rounding is part of the bound)
+            if (q < nq && c < C) S[(size_t)q * C + c] = (float)((cn[c] + qn[q]) - 2.0 * (double)acc[t][r]);
+        }
+    }
+}
+
+// fl32 copy of the queries and their fp64 squared norms
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_query_prep(const double *__restrict__ Q, float *__restrict__ Q32,
+                                                            double *__restrict__ qn, int D, long long nq) {
+    const long long q = (long long)blockIdx.x * (MMIDX_BLOCK / 64) + (threadIdx.x >> 6);  // one wave per query
+    if (q >= nq) return;
+    const int lane = threadIdx.x & 63;
+    double s = 0.0;
+    for (int j = lane; j < D; j += 64) {
+        const double v = Q[(size_t)q * D + j];
+        Q32[(size_t)q * D + j] = (float)v;
+        s += v * v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) qn[q] = s * (1.0 + 1e-12);  // only ever used inside the error bound: round up
+}
+
+struct ApproxSel {
+    const float *S;          // [nq][C] d~ = |c|^2 + |q|^2 - 2 <q, c>  (fp32, from K1c)
+    const double *qn;        // [nq] |q|^2 (rounded up)
+    const double *Q;         // [nq][D]
+    const double *coarse;    // [C][D]
+    const double *coarseT;   // [D][C]
+    double *row_scratch;     // [nq][C] exact rows, written only by the overflow fallback
+    int32_t *cells;          // [nq][w]
+    double *cdsel;           // [nq][w] exact distance of every selected cell (probe-bound input)
+    double cnorm_max, cn_max;  // max |c| and max |c|^2 (rounded up): one error bound per query
+    int C, D, w;
+};
+
+template <int PER>
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_approx(const ApproxSel A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *ckey = (u64 *)smem;                       // [CSEL_CAP] thread minima, then exact candidate keys
+    u32 *cidx = (u32 *)(ckey + MMIDX_CSEL_CAP);    // [CSEL_CAP]
+    u64 *sel_k = (u64 *)(cidx + MMIDX_CSEL_CAP);   // [w+1]
+    int *sel_i = (int *)(sel_k + (A.w + 1));       // [w+1]
+    __shared__ u64 s_k[MMIDX_BLOCK / 64];
+    __shared__ int s_i[MMIDX_BLOCK / 64];
+    __shared__ u32 s_n4[4];  // statics total 64 B: keeps the dynamic LDS base 16-byte aligned
+    u32 &s_n = s_n4[0];
+    const int q = blockIdx.x, tid = threadIdx.x, C = A.C, D = A.D, w = A.w;
+    const int R = w + 1;  // host guarantees R <= 256 <= C
+    const float *srow = A.S + (size_t)q * C;
+    const double qn = A.qn[q];
+    // |d~ - d| <= eps for every centroid of this query:
+    //   dot product: 2 (D + 3) 2^-24 (1.01) |q| |c|     (input rounding + D fused multiply-adds)
+    //   fp64 epilogue and exact-sum rounding: 1e-12 (|c|^2 + |q|^2)
+    //   fp32 store of d~: 2^-23 |d~| <= 2^-23 (|c| + |q|)^2
+    const double qnorm = sqrt(qn);
+    const double sumn = A.cnorm_max + qnorm;
+    const double eps = (2.0 * (double)(D + 3) * 0x1p-24 * 1.01 * qnorm * A.cnorm_max + 1e-12 * (A.cn_max + qn) +
+                        0x1p-23 * sumn * sumn) * (1.0 + 1e-9);
+    float dt[PER];  // d~
+    float lmin = __int_as_float(0x7f800000);
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int c = tid + i * MMIDX_BLOCK;
+        const float v = (c < C) ? srow[c] : __int_as_float(0x7f800000);
+        dt[i] = v;
+        lmin = v < lmin ? v : lmin;
+    }
+    // tau: (R-th smallest per-thread minimum of d~) + eps >= the R-th smallest upper bound d~ + eps
+    // R-th smallest of the 256 minima by rank counting (one barrier instead of a 36-stage sort)
+    float *fmin = (float *)ckey;
+    fmin[tid] = lmin < 0.0f ? 0.0f : lmin;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    {
+        const float mine = fmin[tid];
+        int rank = 0;
+#pragma unroll 32
+        for (int t = 0; t < MMIDX_BLOCK; t++) {
+            const float o = fmin[t];
+            rank += (o < mine) || (o == mine && t < tid);
+        }
+        if (rank == R - 1) sel_k[0] = dkey((double)mine);
+    }
+    __syncthreads();
+    const double tau = keyd(sel_k[0]) + eps;
+    __syncthreads();
+    const u64 lane_lt = (1ull << (tid & 63)) - 1ull;
+    const double cut = tau + eps;  // candidate iff d~ - eps <= tau
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int c = tid + i * MMIDX_BLOCK;
+        const bool pass = (c < C) && ((double)dt[i] <= cut);
+        const u64 mask = __ballot(pass);
+        if (mask) {
+            u32 base = 0;
+            const int leader = __ffsll((long long)mask) - 1;
+            if ((tid & 63) == leader) base = atomicAdd(&s_n, (u32)__popcll(mask));
+            base = __shfl(base, leader);
+            if (pass) {
+                const u32 slot = base + (u32)__popcll(mask & lane_lt);
+                if (slot < MMIDX_CSEL_CAP) cidx[slot] = (u32)c;
+            }
+        }
+    }
+    __syncthreads();
+    const int n = (int)s_n;
+    const double *qv = A.Q + (size_t)q * D;
+    if (n <= MMIDX_CSEL_CAP) {
+        // exact fp64 distance of every candidate in the reference's order (IVFPQ.java:583).  The
+        // per-dimension terms (c_j - q_j)^2 are independent and are computed by all threads with
+        // coalesced loads; only their summation is order-sensitive and runs sequentially, one lane
+        // per candidate, over the terms staged in LDS.
+        double *terms = (double *)(sel_i + ((A.w + 2) & ~1));  // [CAND_CHUNK][D]
+        for (int base = 0; base < n; base += MMIDX_CAND_CHUNK) {
+            const int nc_ = (n - base < MMIDX_CAND_CHUNK) ? n - base : MMIDX_CAND_CHUNK;
+            for (int e0 = 0; e0 < nc_ * D; e0 += MMIDX_BLOCK * 8) {  // 8 independent loads in flight per thread
+                double cv[8], qq[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int e = e0 + u * MMIDX_BLOCK + tid;
+                    cv[u] = 0.0;
+                    qq[u] = 0.0;
+                    if (e < nc_ * D) {
+                        const int ci = e / D, j = e - ci * D;
+                        cv[u] = A.coarse[(size_t)cidx[base + ci] * D + j];
+                        qq[u] = qv[j];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int e = e0 + u * MMIDX_BLOCK + tid;
+                    if (e < nc_ * D) {
+                        const double df = cv[u] - qq[u];
+                        terms[e] = df * df;
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < nc_) {
+                const double *tt = terms + (size_t)tid * D;
+                double acc = 0.0;
+                int j = 0;
+                for (; j + 16 <= D; j += 16) {  // 16 LDS reads in flight, then the ordered adds
+                    double b[16];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) b[u] = tt[j + u];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) acc += b[u];
+                }
+                for (; j < D; j++) acc += tt[j];
+                ckey[base + tid] = dkey(acc);
+            }
+            __syncthreads();
+        }
+        const int Pn = pow2ceil(n < 2 ? 2 : n);
+        for (int i = n + tid; i < Pn; i += MMIDX_BLOCK) {
+            ckey[i] = MMIDX_KEY_MAX;
+            cidx[i] = 0xFFFFFFFFu;
+        }
+        block_bitonic_sort<u32>(ckey, cidx, Pn);
+        for (int i = tid; i < R; i += MMIDX_BLOCK) {
+            sel_k[i] = ckey[i];
+            sel_i[i] = (int)cidx[i];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int32_t *out = A.cells + (size_t)q * w;
+            double *dout = A.cdsel + (size_t)q * w;
+            if (sel_k[w - 1] == sel_k[w]) {
+                // tie straddles the boundary: the bounded queue's closed form over the candidates in
+                // arrival (= index) order; non-candidates are > tau and never count
+                const u64 tk = sel_k[w - 1];
+                int b = 0;
+                while (b < w && sel_k[b] < tk) b++;
+                // ties (== tk) and better (< tk) candidates are all inside the sorted prefix up to the
+                // last entry equal to tk
+                int last = w;
+                while (last + 1 < n && ckey[last + 1] == tk) last++;
+                // p = ties among the first w arrivals with key <= tk: walk indices ascending
+                int p = 0, nonjunk = 0, prev = -1;
+                while (nonjunk < w) {
+                    int best = 0x7fffffff, bpos = -1;
+                    for (int t = 0; t <= last; t++) {
+                        const int ci = (int)cidx[t];
+                        if (ci > prev && ci < best) {
+                            best = ci;
+                            bpos = t;
+                        }
+                    }
+                    if (bpos < 0) break;
+                    prev = best;
+                    nonjunk++;
+                    if (ckey[bpos] == tk) p++;
+                }
+                const int e = b - (w - p);
+                // kept ties: tie ranks e..p-1 in index order; ties sit at sorted positions b..last with
+                // ascending index (sort key = (distance, index))
+                for (int r = 0; r < w - b; r++) sel_i[b + r] = (int)cidx[b + e + r];
+            }
+            int a = 0;
+            while (a < w) {
+                int bnd = a;
+                while (bnd + 1 < w && sel_k[bnd + 1] == sel_k[a]) bnd++;
+                for (int t = a; t <= bnd; t++) {
+                    out[t] = sel_i[bnd - (t - a)];
+                    dout[t] = keyd(sel_k[a]);
+                }
+                a = bnd + 1;
+            }
+        }
+        return;
+    }
+    // ---- overflow: exact row + round-based selection (massive ties / degenerate bounds) ----------
+    double *row = A.row_scratch + (size_t)q * C;
+    u64 key[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int c = tid + i * MMIDX_BLOCK;
+        u64 k = MMIDX_KEY_MAX;
+        if (c < C) {
+            double acc = 0.0;
+            for (int j = 0; j < D; j++) {
+                const double df = A.coarseT[(size_t)j * C + c] - qv[j];
+                acc += df * df;
+            }
+            row[c] = acc;
+            k = dkey(acc);
+        }
+        key[i] = k;
+    }
+    __syncthreads();
+    for (int r = 0; r < R; r++) {
+        u64 bk = MMIDX_KEY_MAX;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int c = tid + i * MMIDX_BLOCK;
+            if (c < C && key[i] < bk) {
+                bk = key[i];
+                bi = c;
+            }
+        }
+        block_min_pair(bk, bi, s_k, s_i);
+#pragma unroll
+        for (int i = 0; i < PER; i++)
+            if (tid + i * MMIDX_BLOCK == bi) key[i] = MMIDX_KEY_MAX;
+        if (tid == 0) {
+            sel_k[r] = bk;
+            sel_i[r] = bi;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) {
+        coarse_emit(row, C, w, R, sel_k, sel_i, A.cells + (size_t)q * w);
+        for (int t = 0; t < w; t++) A.cdsel[(size_t)q * w + t] = row[A.cells[(size_t)q * w + t]];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1032,6 +1408,7 @@ struct PairBound {
     const double *coarse;  // [C][D]
     const u64 *T;          // [nq]
     const double *cdist;   // [nq][C] coarse distances when this process computed them, else null
+    const double *cdsel;   // [nq][w] exact distances of the selected cells (approximate coarse path), else null
     double rmax;           // sqrt(sum_s max_j ||pq[s][j]||^2) * (1 + 1e-12)
     int D, C;
     int enabled;
@@ -1039,10 +1416,12 @@ struct PairBound {
 // Written branch-free on purpose: with early returns hipcc (ROCm 7.2) sank the zero-extension of
 // the cell index into a divergent region and the later atomicAdd(cnt + c) used a garbage high
 // dword on the lanes that had returned early (memory aperture violation).
-__device__ __forceinline__ bool pair_keep(const PairBound &B, int q, int c) {
+__device__ __forceinline__ bool pair_keep(const PairBound &B, long long e, int q, int c) {
     const u64 T = B.T[q];
     double cd = 0.0;
-    if (B.cdist) {  // K1a already computed ||c - q||^2 for every (q, c)
+    if (B.cdsel) {  // K1d left the exact distance of every selected cell, in probe order
+        cd = B.cdsel[e];
+    } else if (B.cdist) {  // K1a computed ||c - q||^2 for every (q, c)
         cd = B.cdist[(size_t)q * B.C + c];
     } else {
         const double *cc = B.coarse + (size_t)c * B.D, *qq = B.Q + (size_t)q * B.D;
@@ -1066,7 +1445,7 @@ __global__ void k_pair_hist(const int32_t *__restrict__ cells, int w, int rank_l
     if ((int)(e - (long long)q * w) < rank_lo) return;
     const int c = cells[e];
     const unsigned cu = c >= 0 ? (unsigned)c : 0u;
-    const bool k = (c >= 0) & pair_keep(B, q, (int)cu);
+    const bool k = (c >= 0) & pair_keep(B, e, q, (int)cu);
     keep[e] = k ? 1 : 0;
     if (k) atomicAdd(cnt + (size_t)cu, 1);
 }

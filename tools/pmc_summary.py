@@ -4,6 +4,7 @@ usage: tools/pmc_summary.py 'gpurun_out/pmc_r01c_*' k_scan > profiles/r01c_pmc_k
 import collections
 import csv
 import glob
+import re
 import sys
 
 
@@ -20,7 +21,7 @@ def main(pattern, kpat):
             continue
         agg = collections.defaultdict(list)
         for r in rows:
-            if kpat in r["Kernel_Name"]:
+            if re.search(kpat, r["Kernel_Name"]) and "rocprim" not in r["Kernel_Name"]:
                 kn = r["Kernel_Name"].split("(")[0].replace("void ", "")
                 agg[(r["Counter_Name"], kn, r["Grid_Size"])].append(float(r["Counter_Value"]))
         print(f"## {d}")

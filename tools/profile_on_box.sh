@@ -20,5 +20,5 @@ for P in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_
   mkdir -p $d
   timeout 700 rocprofv3 --pmc $P --kernel-include-regex "$KRE" --output-format csv -d $d -o pmc -- python bench.py --steps 3 --warmup 1 --no-cpu --gt 0 > $d/bench.log 2>&1
 done
-python tools/pmc_summary.py "/tmp/prof_$TAG/pmc_*" "$KRE" > "$OUT/pmc_$KRE.txt" 2>&1
+python tools/pmc_summary.py "/tmp/prof_$TAG/pmc_*" "$KRE" > "$OUT/pmc_kernels.txt" 2>&1
 ls -la "$OUT"
