@@ -101,6 +101,8 @@ struct mmidx_index {
     bool no_bound = false;   // MMIDX_NO_BOUND=1: no coarse-bound pruning of probes
     bool debug_sync = false; // MMIDX_DEBUG_SYNC=1
     bool passa_filter = false;  // MMIDX_PASSA_FILTER=1
+    bool no_seed = true;        // MMIDX_SEED=1: pass A with the seeded scan K3s (measured slower than K3: 1.45 vs 1.22 ms
+                                // per 8192 queries -- one block per query is latency-bound, not LDS-bound; kept for study)
     double rmax = 0.0;       // sqrt(sum_s max_j ||pq[s][j]||^2) * (1 + 1e-12)
     hipStream_t stream = nullptr;
     std::mutex mu;
@@ -326,6 +328,7 @@ int launch_scan(const mmidx_index *h, const ScanParams &P, dim3 grid, size_t lds
 }
 
 struct SearchPlan;
+int launch_scan_seeded(const mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 grid, hipStream_t st);
 int launch_scan_filtered(const mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 grid, hipStream_t st);
 
 struct SearchPlan {
@@ -384,6 +387,32 @@ int launch_scan_filtered(const mmidx_index *h, ScanParams P, const SearchPlan &p
         case 8: return launch_filt_t<8>(P, grid, lds, st);
         case 16: return launch_filt_t<16>(P, grid, lds, st);
         default: return launch_filt_t<32>(P, grid, lds, st);
+    }
+}
+
+template <int M>
+int launch_seed_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t st) {
+    HIPCK(hipFuncSetAttribute((const void *)k_scan_seed<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_scan_seed<M>), grid, dim3(MMIDX_BLOCK), lds, st, P);
+    HIPCK(hipGetLastError());
+    return MMIDX_OK;
+}
+
+// pass A: seeded scan (exact sample -> histogram of u8 lower bounds -> exact verify) where it applies
+int launch_scan_seeded(const mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 grid, hipStream_t st) {
+    const bool ok = h->code_bytes == 1 && h->ks <= 256 && (h->m == 8 || h->m == 16 || h->m == 32) && !h->no_filter &&
+                    !h->no_seed;
+    if (!ok) return launch_scan(h, P, grid, pl.lds, st);
+    int cap = 1;
+    while (cap < pl.K1 + MMIDX_SEED_N0) cap <<= 1;
+    P.cap = cap;
+    const size_t lds = (size_t)h->m * h->ks * 8 + 2 * (size_t)h->D * 8 + (size_t)cap * 12 + 4 * (size_t)h->m * 8 + 16 +
+                       (size_t)MMIDX_SURV_CAP * 4 + 256 * 4 + 16 + (size_t)h->m * 256 + (size_t)((pl.chunk + 15) & ~15);
+    if (lds > 160 * 1024) return launch_scan(h, P, grid, pl.lds, st);
+    switch (h->m) {
+        case 8: return launch_seed_t<8>(P, grid, lds, st);
+        case 16: return launch_seed_t<16>(P, grid, lds, st);
+        default: return launch_seed_t<32>(P, grid, lds, st);
     }
 }
 
@@ -542,7 +571,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
         int rc = MMIDX_OK;
         if (phase != 2) {
             rc = h->passa_filter ? launch_scan_filtered(h, P, pl, dim3((unsigned)P.n_items, (unsigned)pl.nchunks), st)
-                                 : launch_scan(h, P, dim3((unsigned)P.n_items, (unsigned)pl.nchunks), pl.lds, st);
+                                 : launch_scan_seeded(h, P, pl, dim3((unsigned)P.n_items, (unsigned)pl.nchunks), st);
             if (rc) return rc;
             DBG_SYNC("pass A scan");
         }
@@ -791,6 +820,8 @@ int mmidx_create(int kind, int D, int m, int ks, int C, int transform, const int
         h->exact_coarse = ec && ec[0] == '1';
         const char *pf = getenv("MMIDX_PASSA_FILTER");
         h->passa_filter = pf && pf[0] == '1';
+        const char *nsd = getenv("MMIDX_SEED");
+        h->no_seed = !(nsd && nsd[0] == '1');
     }
     *out = h;
     return MMIDX_OK;

@@ -1393,6 +1393,302 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_filt(const ScanParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// K3s: seeded scan for pass A (probe rank 0: no threshold exists yet).  Same exact results as K3,
+// but only ~0.5 K codes pay the fp64 gather:
+//   stage 0  exact distances of the first 512 codes of the chunk -> T0 = their (k+1)-th smallest
+//            (a valid threshold, but loose: a ~20 % quantile of the list)
+//   stage 1  conflict-free u8 sums (table built for T0) for ALL codes of the chunk, kept in LDS
+//            (1 byte per code), plus a 256-bin histogram of the sums <= 254
+//   stage 2  the histogram gives b* = smallest sum with at least k+1 codes at or below it; every such
+//            code has d <= Smin + (b* + m) * delta (each of the m truncations loses < 1), so
+//            T1 = that bound is a valid and far tighter threshold (within m * delta of the true one)
+//   stage 3  codes whose stored sum can still reach min(T0, T1) -- a few hundred -- get the exact
+//            fp64 sum; the rest of the block is K3's prune / pool hand-off.
+// ------------------------------------------------------------------------------------------------
+#define MMIDX_SEED_N0 512
+#define MMIDX_SEGU_S 8  // codes per thread per streaming segment of stage 1: pass A streams cold lists from HBM,
+                       // so two segments (32 KiB per block) are kept in flight
+#define MMIDX_SEG_S (MMIDX_BLOCK * MMIDX_SEGU_S)
+template <int M>
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_seed(const ScanParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int ks = P.ks, D = P.D;
+    double *lut = (double *)smem;                        // [M*ks]
+    double *vec = lut + (size_t)M * ks;                  // [2*D]
+    u64 *bkey = (u64 *)(vec + 2 * (size_t)D);            // [cap] cap >= K1 + 512
+    u64 *s_min = bkey + P.cap;                           // [4][M]
+    u64 *s_T = s_min + 4 * M;                            // [2]
+    u32 *bval = (u32 *)(s_T + 2);                        // [cap]
+    u32 *surv = bval + P.cap;                            // [SURV_CAP]
+    u32 *hist = surv + MMIDX_SURV_CAP;                   // [256]
+    u32 *s_cnt = hist + 256;                             // [4]: 0 candidates, 1 survivors, 2 b*
+    unsigned char *lut8 = (unsigned char *)(s_cnt + 4);  // [M][256]
+    unsigned char *sums = lut8 + M * 256;                // [chunk] u8 lower-bound sums
+
+    const int item = blockIdx.x;
+    if (item >= P.n_items) return;
+    const int q = item / P.nrank;
+    const int pr = P.rank_lo + (item - q * P.nrank);
+    const int ch = blockIdx.y;
+    int cell = 0;
+    if (P.ivf) {
+        cell = P.cells[(size_t)q * P.w + pr];
+        if (cell < 0) return;
+    }
+    const int64_t beg = P.list_off[cell];
+    const int64_t len = P.list_off[cell + 1] - beg;
+    const int64_t c0 = (int64_t)ch * P.chunk;
+    if (c0 >= len) return;
+    const int64_t c1 = (c0 + P.chunk < len) ? c0 + P.chunk : len;
+    const int clen = (int)(c1 - c0);
+    const int tid = threadIdx.x;
+    const unsigned char *codes = (const unsigned char *)P.codes + (size_t)(beg + c0) * M;  // chunk-relative
+    u64 *Tq = P.T + q;
+    const u64 lane_lt = (1ull << (tid & 63)) - 1ull;
+
+    CodeVec<M, unsigned char> cur[MMIDX_SEGU_S], nxt[MMIDX_SEGU_S];
+#pragma unroll
+    for (int u = 0; u < MMIDX_SEGU_S; u++) {
+        const int i = u * MMIDX_BLOCK + tid;
+        cur[u].load(codes + (size_t)(i < clen ? i : clen - 1) * M);
+    }
+    if (tid < 4) s_cnt[tid] = 0;
+    hist[tid] = 0;
+    const double *tr = query_vector(P, q, cell, vec);
+    {
+        u64 mk[M];
+        const bool hasj = tid < ks;
+#pragma unroll
+        for (int s = 0; s < M; s++) {
+            double v = 0.0;
+            if (hasj) {
+                switch (P.dsub) {
+                    case 4: v = lut_entry<4>(tr, P.pqT, s, tid, ks, 4); break;
+                    case 8: v = lut_entry<8>(tr, P.pqT, s, tid, ks, 8); break;
+                    case 16: v = lut_entry<16>(tr, P.pqT, s, tid, ks, 16); break;
+                    default: v = lut_entry<0>(tr, P.pqT, s, tid, ks, P.dsub); break;
+                }
+                lut[s * ks + tid] = v;
+            }
+            mk[s] = hasj ? dkey(v) : MMIDX_KEY_MAX;
+        }
+#pragma unroll
+        for (int s = 0; s < M; s++) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const u64 o = __shfl_xor(mk[s], off);
+                mk[s] = o < mk[s] ? o : mk[s];
+            }
+        }
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int s = 0; s < M; s++) s_min[(tid >> 6) * M + s] = mk[s];
+        }
+    }
+    __syncthreads();
+    if (tid < M) {
+        u64 a = s_min[tid];
+        for (int wv = 1; wv < MMIDX_BLOCK / 64; wv++) {
+            const u64 b = s_min[wv * M + tid];
+            a = b < a ? b : a;
+        }
+        s_min[tid] = a;
+    }
+    __syncthreads();
+    double smin = 0.0;
+#pragma unroll
+    for (int s = 0; s < M; s++) smin += keyd(s_min[s]);
+    const double smin_lo = smin * (1.0 - 0x1p-40), smin_hi = smin * (1.0 + 0x1p-40);
+
+    // ---- stage 0: exact distances of the first n0 codes -> candidates -> T0 ---------------------
+    const int n0 = clen < MMIDX_SEED_N0 ? clen : MMIDX_SEED_N0;
+#pragma unroll
+    for (int u = 0; u < MMIDX_SEGU; u++) {
+        const int i = u * MMIDX_BLOCK + tid;
+        if (i < n0) {
+            double d = 0.0;
+#pragma unroll
+            for (int s = 0; s < M; s++) d += lut[s * ks + cur[u].get(s)];
+            bkey[i] = dkey(d);
+            bval[i] = (u32)(c0 + i);
+        }
+    }
+    if (tid == 0) s_cnt[0] = (u32)n0;
+    __syncthreads();
+    if (n0 > P.K1) scan_prune(bkey, bval, s_cnt, P.K1, Tq);  // publishes T0 when n0 >= K1
+    if (tid == 0) s_T[0] = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    u64 T = s_T[0];
+    const bool finiteT = T < 0x7FF0000000000000ull;
+    bool run_filter = clen > n0;
+    // (if the whole chunk was covered, or no threshold exists and none can be built, skip ahead)
+    double inv = 0.0, Td = keyd(T);
+    bool usable = finiteT && (smin_lo < Td) && ((Td - smin_lo) > Td * 0x1p-30);
+    if (run_filter && finiteT && !(smin_lo < Td)) run_filter = false;  // nothing else can qualify
+    if (run_filter) {
+        inv = usable ? (254.0 / (Td - smin_lo)) * (1.0 - 0x1p-40) : 0.0;
+        if (tid < ks) {
+#pragma unroll
+            for (int s = 0; s < M; s++) {
+                const double x = (lut[s * ks + tid] - keyd(s_min[s])) * inv;
+                const u32 qv = (x >= 255.0) ? 255u : (u32)x;
+                lut8[s * 256 + tid] = (unsigned char)(usable ? qv : 0u);
+            }
+        }
+        __syncthreads();
+        // ---- stage 1: u8 sums of every code of the chunk + histogram -------------------------------
+        for (int seg = 0; seg < clen; seg += MMIDX_SEG_S) {
+            const bool more = seg + MMIDX_SEG_S < clen;
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < MMIDX_SEGU_S; u++) {
+                    const int i = seg + MMIDX_SEG_S + u * MMIDX_BLOCK + tid;
+                    nxt[u].load(codes + (size_t)(i < clen ? i : clen - 1) * M);
+                }
+            }
+#pragma unroll
+            for (int h2 = 0; h2 < MMIDX_SEGU_S; h2 += 2) {  // two codes at a time: ILP without 8 live accumulators
+                u32 acc0 = 0, acc1 = 0;
+#pragma unroll
+                for (int s = 0; s < M; s++) {
+                    const u32 b0 = (u32)cur[h2].get(s), b1 = (u32)cur[h2 + 1].get(s);
+                    const uint2 v0 = *(const uint2 *)(lut8 + s * 256 + (b0 & 0xF8u));
+                    const uint2 v1 = *(const uint2 *)(lut8 + s * 256 + (b1 & 0xF8u));
+                    acc0 += __builtin_amdgcn_perm(v0.y, v0.x, (b0 & 7u) | 0x0C0C0C00u);
+                    acc1 += __builtin_amdgcn_perm(v1.y, v1.x, (b1 & 7u) | 0x0C0C0C00u);
+                }
+                const int i0 = seg + h2 * MMIDX_BLOCK + tid, i1 = i0 + MMIDX_BLOCK;
+                if (i0 < clen) {
+                    sums[i0] = (unsigned char)(acc0 > 255u ? 255u : acc0);
+                    if (usable && i0 >= n0 && acc0 <= 254u) atomicAdd(hist + acc0, 1u);
+                }
+                if (i1 < clen) {
+                    sums[i1] = (unsigned char)(acc1 > 255u ? 255u : acc1);
+                    if (usable && i1 >= n0 && acc1 <= 254u) atomicAdd(hist + acc1, 1u);
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < MMIDX_SEGU_S; u++) cur[u] = nxt[u];
+            }
+        }
+        __syncthreads();
+        // ---- stage 2: b* and the tighter threshold ---------------------------------------------------
+        u32 thr = 255u;  // codes with sum <= thr survive; 255 = everything (no usable filter)
+        if (usable) {
+            if (tid == 0) {
+                u32 cum = 0;
+                int bstar = -1;
+                for (int b = 0; b < 255; b++) {
+                    cum += hist[b];
+                    if ((int)cum >= P.K1) {
+                        bstar = b;
+                        break;
+                    }
+                }
+                u64 Tn = T;
+                if (bstar >= 0) {
+                    const double delta_hi = ((Td - smin_lo) / 254.0) * (1.0 + 0x1p-38);  // >= 1 / inv
+                    const double t1 = (smin_hi + (double)(bstar + M) * delta_hi) * (1.0 + 0x1p-40);
+                    const u64 k1 = dkey(t1);
+                    if (k1 < Tn) Tn = k1;
+                }
+                atomicMin(Tq, Tn);
+                s_T[0] = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            T = s_T[0];
+            // d <= T needs  sum <= (T - smin_lo) * inv  (the sum times 1/inv plus smin_lo is a lower bound)
+            const double lim = (keyd(T) - smin_lo) * inv;
+            thr = lim >= 254.0 ? 254u : (lim < 0.0 ? 0u : (u32)lim + 1u);
+            if (thr > 254u) thr = 254u;
+        }
+        // ---- stage 3: exact verification of the codes that can still qualify -------------------------
+        for (int seg = n0; seg < clen; seg += MMIDX_SEG) {
+            const bool more = seg + MMIDX_SEG < clen;
+#pragma unroll
+            for (int u = 0; u < MMIDX_SEGU; u++) {
+                const int i = seg + u * MMIDX_BLOCK + tid;
+                const bool pass = (i < clen) && (u32)sums[i] <= thr;
+                const u64 mask = __ballot(pass);
+                if (mask) {
+                    u32 base = 0;
+                    const int leader = __ffsll((long long)mask) - 1;
+                    if ((tid & 63) == leader) base = atomicAdd(s_cnt + 1, (u32)__popcll(mask));
+                    base = __shfl(base, leader);
+                    if (pass) surv[base + (u32)__popcll(mask & lane_lt)] = (u32)i;
+                }
+            }
+            __syncthreads();
+            int ns = (int)s_cnt[1];
+            __syncthreads();
+            while (ns >= MMIDX_VROUND || (!more && ns > 0)) {
+                if ((int)s_cnt[0] > P.cap - MMIDX_VROUND) {
+                    scan_prune(bkey, bval, s_cnt, P.K1, Tq);
+                    if (tid == 0) s_T[0] = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __syncthreads();
+                    T = s_T[0];
+                }
+                const int take = ns < MMIDX_VROUND ? ns : MMIDX_VROUND;
+                const int base_s = ns - take;
+                bool pass = false;
+                u64 key = 0;
+                u32 pos = 0;
+                if (tid < take) {
+                    pos = surv[base_s + tid];
+                    CodeVec<M, unsigned char> cv;
+                    cv.load(codes + (size_t)pos * M);
+                    double d = 0.0;
+#pragma unroll
+                    for (int s = 0; s < M; s++) d += lut[s * ks + cv.get(s)];
+                    key = dkey(d);
+                    pass = key <= T;
+                }
+                const u64 mask = __ballot(pass);
+                if (mask) {
+                    u32 base = 0;
+                    const int leader = __ffsll((long long)mask) - 1;
+                    if ((tid & 63) == leader) base = atomicAdd(s_cnt, (u32)__popcll(mask));
+                    base = __shfl(base, leader);
+                    if (pass) {
+                        const u32 slot = base + (u32)__popcll(mask & lane_lt);
+                        bkey[slot] = key;
+                        bval[slot] = (u32)(c0 + pos);
+                    }
+                }
+                ns = base_s;
+                __syncthreads();
+                if (tid == 0) s_cnt[1] = (u32)ns;
+                __syncthreads();
+            }
+        }
+    }
+    // ---- hand the survivors to the query's pool ------------------------------------------------
+    __syncthreads();
+    if ((int)*s_cnt > P.K1) scan_prune(bkey, bval, s_cnt, P.K1, Tq);
+    const u64 Tfin = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // per-lane use only
+    const int n = (int)*s_cnt;
+    for (int base0 = 0; base0 < n; base0 += MMIDX_BLOCK) {
+        const int i = base0 + tid;
+        const bool pass = (i < n) && bkey[i] <= Tfin;
+        const u64 mask = __ballot(pass);
+        if (mask) {
+            u32 base = 0;
+            const int leader = __ffsll((long long)mask) - 1;
+            if ((tid & 63) == leader) base = atomicAdd(P.pool_cnt + q, (u32)__popcll(mask));
+            base = __shfl(base, leader);
+            if (pass) {
+                const u32 slot = base + (u32)__popcll(mask & lane_lt);
+                if (slot < (u32)P.poolq) {
+                    P.pool_key[(size_t)q * P.poolq + slot] = bkey[i];
+                    P.pool_val[(size_t)q * P.poolq + slot] = ((u64)pr << 32) | (u64)bval[i];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // per-batch ordering of the (query, probe rank >= rank_lo) pairs by cell: counting sort with
 // atomics.  The order inside a cell is arbitrary -- it only decides which block runs when.
 // ------------------------------------------------------------------------------------------------
