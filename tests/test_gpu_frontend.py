@@ -101,3 +101,24 @@ def test_pca_layout_identity(mi):
     Y = pca.project(X)            # Y[i][c] = Vt[c][i]
     assert np.array_equal(Y, Vt.T)
     pca.close()
+
+
+def test_config5_pipeline_end_to_end(mi, oracle):
+    """descriptors -> VLAD -> PCA -> IVFPQ through the C ABI (BASELINE config 5, scaled down); the
+    index/search half is checked bit-exactly against the oracle fed with the same projected vectors."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import config5_pipeline as c5
+
+    out, (X, Q, iids, dists, counts, coarse, pq, cells, w, k) = c5.run(n_images=3000, n_queries=64, k=10, cells=64, w=8, verbose=False)
+    assert X.shape == (3000, 128) and np.allclose(np.linalg.norm(X, axis=1), 1.0, atol=1e-12)  # whitening -> unit rows
+    ref = oracle.OracleIndex(oracle.KIND_IVFPQ, 128, 16, 256, cells)
+    ref.set_coarse(coarse)
+    ref.set_pq(pq)
+    ref.set_w(w)
+    ref.add_vectors(X)
+    rid, rd, rc = ref.search_batch(Q, k)
+    assert np.array_equal(iids, rid) and np.array_equal(dists, rd) and np.array_equal(counts, rc)
+    assert out["recall_at_1_vs_exact"] >= 0.9 and out["self_hit_rate"] >= 0.9, out
