@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--gt", type=int, default=1024, help="queries with exact ground truth (recall@1)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the multi-GPU code path (encode -> owner filter -> add_codes, two-phase shard search, "
+                         "merge) even with one rank: exercises it on a single GPU")
     args = ap.parse_args()
 
     import torch
@@ -164,7 +167,7 @@ def main():
             Qsrc[sel] = X[qsrc[sel] - c0]
         torch.cuda.synchronize()
         te = time.time()
-        if world == 1:
+        if world == 1 and not args.force_sharded:
             chk(L.mmidx_add_vectors_device(h, n, X.data_ptr(), None, c0, stream))
         else:
             cells = torch.empty(n, dtype=torch.int32, device=dev)
@@ -211,7 +214,7 @@ def main():
     dist_out = torch.empty(B, k, dtype=f64, device=dev)
     cnt_out = torch.empty(B, dtype=torch.int32, device=dev)
     sharded = None
-    if world > 1:
+    if world > 1 or args.force_sharded:
         sh = importlib.import_module("multimedia-indexing_amd.sharded")
         sharded = sh.ShardedIVFPQ(sh.HipShardEngine(h, D, w, local), rank, world, dist=dist)
 

@@ -348,7 +348,14 @@ int make_plan(mmidx_index *h, int k, int64_t nq, SearchPlan &pl) {
         return fail(MMIDX_ERR_UNSUPPORTED, "lookup table of %d x %d doubles does not fit the 160 KiB LDS", h->m, h->ks);
     const int ivf = h->kind == MMIDX_KIND_IVFPQ;
     const int nprobe = ivf ? h->w : 1;
-    int64_t chunk = ivf ? 16384 : 32768;
+    int64_t chunk = 16384;
+    if (!ivf) {
+        // flat PQ: every chunk of a query rebuilds the same lookup table, so chunks grow with the
+        // batch (fewer, longer work items) while a single query still spreads over the whole chip
+        const int64_t want = (h->n_csr / 32768 + 1) * std::max<int64_t>(nq, 1) / 32768;
+        chunk = 32768;
+        while (chunk < (1 << 20) && chunk < want * 32768) chunk <<= 1;
+    }
     const int64_t maxlen = std::max<int64_t>(h->max_list_len, 1);
     pl.chunk = (int)chunk;
     pl.nchunks = (int)((maxlen + chunk - 1) / chunk);
@@ -557,8 +564,13 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
     P.cap = pl.cap;
     P.poolq = pl.poolq;
     if (h->n_csr > 0) {
+        // flat PQ: the chunks of the single list play the role of probes (P.w = number of chunks,
+        // item rank = chunk index, cell = 0), so the same two passes apply: chunk 0 fixes the
+        // threshold, the other chunks run through the filtered scan
+        const int grid_chunks = ivf ? pl.nchunks : 1;
+        if (!ivf) P.w = pl.nchunks;
         const long long npairs = (long long)nq * P.w;
-        const bool two_pass = ivf && P.w > 1;
+        const bool two_pass = P.w > 1;
         if (prof) HIPCK(hipEventRecord(ev[2], st));
         // pass A: probe rank 0 of every query (all of them for PQ) -- fixes a tight threshold
         P.order = nullptr;
@@ -570,8 +582,8 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
         //  measured faster: 1.23 vs ~1.4 ms per 8192 queries; MMIDX_PASSA_FILTER=1 switches)
         int rc = MMIDX_OK;
         if (phase != 2) {
-            rc = h->passa_filter ? launch_scan_filtered(h, P, pl, dim3((unsigned)P.n_items, (unsigned)pl.nchunks), st)
-                                 : launch_scan_seeded(h, P, pl, dim3((unsigned)P.n_items, (unsigned)pl.nchunks), st);
+            rc = h->passa_filter ? launch_scan_filtered(h, P, pl, dim3((unsigned)P.n_items, (unsigned)grid_chunks), st)
+                                 : launch_scan_seeded(h, P, pl, dim3((unsigned)P.n_items, (unsigned)grid_chunks), st);
             if (rc) return rc;
             DBG_SYNC("pass A scan");
         }
@@ -589,7 +601,18 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
             hipLaunchKernelGGL(k_T_import, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, d_T_io, h->ws_T.p, (long long)nq);
             HIPCK(hipGetLastError());
         }
-        if (two_pass) {
+        if (two_pass && !ivf) {
+            // flat PQ pass B: chunks 1.. of every query in natural order
+            P.order = nullptr;
+            P.rank_lo = 1;
+            P.nrank = P.w - 1;
+            P.n_items = (int)(nq * P.nrank);
+            P.xcd_remap = 0;
+            rc = launch_scan_filtered(h, P, pl, dim3((unsigned)P.n_items, 1), st);
+            if (rc) return rc;
+            DBG_SYNC("pass B scan (flat)");
+        }
+        if (two_pass && ivf) {
             // pass B order: pairs with probe rank >= 1 that survive the coarse bound, sorted by cell
             // (device counting sort; needs the thresholds pass A just produced)
             HIPCK(h->ws_pcount.reserve((size_t)h->C));

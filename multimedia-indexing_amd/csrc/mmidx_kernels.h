@@ -943,7 +943,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan(const ScanParams P) {
         q = item / P.nrank;
         pr = P.rank_lo + (item - q * P.nrank);
     }
-    const int ch = blockIdx.y;
+    const int ch = P.ivf ? (int)blockIdx.y : pr;  // flat PQ: the item rank is the chunk of the single list
     int cell = 0;
     if (P.ivf) {
         cell = P.cells[(size_t)q * P.w + pr];
@@ -1079,7 +1079,10 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan(const ScanParams P) {
 // the fp64 LUT, so results stay bit-identical to K3.  All roundings of the filter are directed so
 // that it can only under-estimate (never drops a candidate with d <= T).
 // ------------------------------------------------------------------------------------------------
-#define MMIDX_SURV_CAP 1024
+#define MMIDX_FSEGU 2  // codes per thread per segment in the filtered scan (4 measured no faster: the per-item
+                       // fixed cost -- LUT build, minima, q8 table -- dominates, not the lookup loop)
+#define MMIDX_FSEG (MMIDX_BLOCK * MMIDX_FSEGU)
+#define MMIDX_SURV_CAP 1024  // >= FSEG + VROUND
 #define MMIDX_VROUND MMIDX_BLOCK
 
 template <int DSUB>
@@ -1139,7 +1142,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_filt(const ScanParams P) {
         q = item / P.nrank;
         pr = P.rank_lo + (item - q * P.nrank);
     }
-    const int ch = blockIdx.y;
+    const int ch = P.ivf ? (int)blockIdx.y : pr;  // flat PQ: the item rank is the chunk of the single list
     int cell = 0;
     if (P.ivf) {
         cell = P.cells[(size_t)q * P.w + pr];
@@ -1154,9 +1157,9 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_filt(const ScanParams P) {
     const unsigned char *codes = (const unsigned char *)P.codes + (size_t)beg * M;
     u64 *Tq = P.T + q;
 
-    CodeVec<M, unsigned char> cur[MMIDX_SEGU], nxt[MMIDX_SEGU];
+    CodeVec<M, unsigned char> cur[MMIDX_FSEGU], nxt[MMIDX_FSEGU];
 #pragma unroll
-    for (int u = 0; u < MMIDX_SEGU; u++) {
+    for (int u = 0; u < MMIDX_FSEGU; u++) {
         const int64_t i = c0 + u * MMIDX_BLOCK + tid;
         cur[u].load(codes + (size_t)(i < c1 ? i : c1 - 1) * M);
     }
@@ -1241,29 +1244,40 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_filt(const ScanParams P) {
 
     // ---- filter scan ------------------------------------------------------------------------------
     const u64 lane_lt = (1ull << (tid & 63)) - 1ull;
-    for (int64_t seg = c0; seg < c1 && !exhausted; seg += MMIDX_SEG) {
-        const bool more = seg + MMIDX_SEG < c1;
+    for (int64_t seg = c0; seg < c1 && !exhausted; seg += MMIDX_FSEG) {
+        const bool more = seg + MMIDX_FSEG < c1;
         if (more) {
 #pragma unroll
-            for (int u = 0; u < MMIDX_SEGU; u++) {
-                const int64_t i = seg + MMIDX_SEG + u * MMIDX_BLOCK + tid;
+            for (int u = 0; u < MMIDX_FSEGU; u++) {
+                const int64_t i = seg + MMIDX_FSEG + u * MMIDX_BLOCK + tid;
                 nxt[u].load(codes + (size_t)(i < c1 ? i : c1 - 1) * M);
             }
         }
-        u32 acc[MMIDX_SEGU];
+        u32 acc[MMIDX_FSEGU];
+        uint2 va[MMIDX_FSEGU], vb[MMIDX_FSEGU];
+        // software pipeline over the sub-quantizers: the slots of s+1 are requested before the bytes
+        // of s are extracted, so every v_perm waits on reads issued a full row earlier (counted
+        // lgkmcnt instead of a drain)
 #pragma unroll
-        for (int u = 0; u < MMIDX_SEGU; u++) acc[u] = 0;
-#pragma unroll
-        for (int s = 0; s < M; s++) {
-#pragma unroll
-            for (int u = 0; u < MMIDX_SEGU; u++) {
-                const u32 b = (u32)cur[u].get(s);
-                const uint2 v = *(const uint2 *)(lut8 + s * 256 + (b & 0xF8u));
-                acc[u] += __builtin_amdgcn_perm(v.y, v.x, (b & 7u) | 0x0C0C0C00u);
-            }
+        for (int u = 0; u < MMIDX_FSEGU; u++) {
+            acc[u] = 0;
+            va[u] = *(const uint2 *)(lut8 + ((u32)cur[u].get(0) & 0xF8u));
         }
 #pragma unroll
-        for (int u = 0; u < MMIDX_SEGU; u++) {
+        for (int s = 0; s < M; s++) {
+            if (s + 1 < M) {
+#pragma unroll
+                for (int u = 0; u < MMIDX_FSEGU; u++)
+                    vb[u] = *(const uint2 *)(lut8 + (s + 1) * 256 + ((u32)cur[u].get(s + 1) & 0xF8u));
+            }
+#pragma unroll
+            for (int u = 0; u < MMIDX_FSEGU; u++)
+                acc[u] += __builtin_amdgcn_perm(va[u].y, va[u].x, ((u32)cur[u].get(s) & 7u) | 0x0C0C0C00u);
+#pragma unroll
+            for (int u = 0; u < MMIDX_FSEGU; u++) va[u] = vb[u];
+        }
+#pragma unroll
+        for (int u = 0; u < MMIDX_FSEGU; u++) {
             const int64_t i = seg + u * MMIDX_BLOCK + tid;
             const bool pass = (i < c1) && acc[u] <= 255u;
             const u64 mask = __ballot(pass);
@@ -1364,7 +1378,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_filt(const ScanParams P) {
         }
         if (more) {
 #pragma unroll
-            for (int u = 0; u < MMIDX_SEGU; u++) cur[u] = nxt[u];
+            for (int u = 0; u < MMIDX_FSEGU; u++) cur[u] = nxt[u];
         }
     }
     // ---- hand the survivors to the query's pool ------------------------------------------------
@@ -1429,7 +1443,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_seed(const ScanParams P) {
     if (item >= P.n_items) return;
     const int q = item / P.nrank;
     const int pr = P.rank_lo + (item - q * P.nrank);
-    const int ch = blockIdx.y;
+    const int ch = P.ivf ? (int)blockIdx.y : pr;  // flat PQ: the item rank is the chunk of the single list
     int cell = 0;
     if (P.ivf) {
         cell = P.cells[(size_t)q * P.w + pr];

@@ -104,9 +104,12 @@ class BPQ:
             raise ValueError("max size must be >= 1")
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().mmo_bpq_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None) and _lib is not None:
+                _lib.mmo_bpq_free(self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
 
     def offer(self, id_, dist):
         return bool(lib().mmo_bpq_offer(self._h, int(id_), float(dist)))
@@ -212,9 +215,12 @@ class OracleIndex:
             raise ValueError("The given number of subvectors is not valid!")
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().mmo_index_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None) and _lib is not None:
+                _lib.mmo_index_free(self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
 
     def set_coarse(self, coarse):
         a, p = _d(coarse)

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""BASELINE configs 2 and 3 on one MI355X (parity cases, not the headline bench line):
+   cfg2  PQ ADC      1M x 128, m = 8 x 256,  k = 100
+   cfg3  IVFPQ       1M x 128, C = 1024, w = 8, m = 16 x 256, k = 100
+Queries resident in HBM; every result compared with the CPU oracle on a query sample."""
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import synth  # noqa: E402
+from oracle import oracle as o  # noqa: E402  (checker only)
+
+mi = importlib.import_module("multimedia-indexing_amd")
+nat = importlib.import_module("multimedia-indexing_amd._native")
+L = mi.lib()
+dev = torch.device("cuda", 0)
+
+
+def timed_search(ix, Q, k, reps=5):
+    B = Q.shape[0]
+    dQ = torch.tensor(Q, dtype=torch.float64, device=dev)
+    iid = torch.empty(B, k, dtype=torch.int32, device=dev)
+    dd = torch.empty(B, k, dtype=torch.float64, device=dev)
+    cc = torch.empty(B, dtype=torch.int32, device=dev)
+    for _ in range(2):
+        nat.check(L.mmidx_search_device(ix._h, k, B, dQ.data_ptr(), iid.data_ptr(), dd.data_ptr(), cc.data_ptr(), None))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        nat.check(L.mmidx_search_device(ix._h, k, B, dQ.data_ptr(), iid.data_ptr(), dd.data_ptr(), cc.data_ptr(), None))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return B / dt, iid.cpu().numpy(), dd.cpu().numpy(), cc.cpu().numpy()
+
+
+out = {}
+rng = np.random.default_rng(0)
+N, D, k = 1_000_000, 128, 100
+
+# ---- cfg2: flat PQ, iid N(0, I) base (a tight mixture would tie thousands of codes)
+m, ks = 8, 256
+base = rng.standard_normal((N, D))
+pq = np.stack([synth.kmeans(base[:30000, s * 16:(s + 1) * 16], ks, iters=5, seed=s) for s in range(m)])
+ix = mi.PQ(D, N, False, "", m, ks, 0, 512)
+ix.loadProductQuantizer(pq)
+t0 = time.time()
+ix.indexVectors(list(range(N)), base)
+t_index = time.time() - t0
+Q = rng.standard_normal((4096, D))
+qps, iid, dd, cc = timed_search(ix, Q, k)
+ref = o.OracleIndex(o.KIND_PQ, D, m, ks)
+ref.set_pq(pq)
+off, ids_e, codes_e = ix.export()
+ref.load_lists(off, ids_e, codes_e)
+ns = 256
+t0 = time.perf_counter()
+rid, rd, rc = ref.search_batch(Q[:ns], k, nthreads=os.cpu_count())
+cpu_qps = ns / (time.perf_counter() - t0)
+out["cfg2_pq_adc_1M"] = {"qps_gpu": round(qps, 1), "index_s": round(t_index, 2), "ids_match": bool(np.array_equal(iid[:ns], rid)),
+                         "max_abs_ddist": float(np.max(np.abs(dd[:ns] - rd))), "cpu_qps": round(cpu_qps, 1), "cpu_threads": os.cpu_count(),
+                         "algorithmic_GBps": round(qps * N * m / 1e9, 1)}
+ix.close()
+del ref
+
+# ---- cfg3: IVFPQ 1M, C = 1024, w = 8
+C_, w, m = 1024, 8, 16
+base, mu = synth.mixture(N, D, C_, sigma=0.15, seed=1234)
+coarse = mu
+ix = mi.IVFPQ(D, N, False, "", m, ks, 0, C_, 512)
+ix.loadCoarseQuantizer(coarse)
+cell = ((base[:40000] * base[:40000]).sum(1)[:, None] - 2 * base[:40000] @ coarse.T + (coarse * coarse).sum(1)[None]).argmin(1)
+resid = coarse[cell] - base[:40000]
+pq = np.stack([synth.kmeans(resid[:, s * 8:(s + 1) * 8], ks, iters=5, seed=s) for s in range(m)])
+ix.loadProductQuantizer(pq)
+ix.setW(w)
+t0 = time.time()
+ix.indexVectors(list(range(N)), base)
+t_index = time.time() - t0
+qi = rng.choice(N, 8192, replace=False)
+Q = base[qi] + 0.01 * rng.standard_normal((8192, D))
+qps, iid, dd, cc = timed_search(ix, Q, k)
+ref = o.OracleIndex(o.KIND_IVFPQ, D, m, ks, C_)
+ref.set_coarse(coarse)
+ref.set_pq(pq)
+ref.set_w(w)
+off, ids_e, codes_e = ix.export()
+ref.load_lists(off, ids_e, codes_e)
+ns = 2048
+t0 = time.perf_counter()
+rid, rd, rc = ref.search_batch(Q[:ns], k, nthreads=os.cpu_count())
+cpu_qps = ns / (time.perf_counter() - t0)
+out["cfg3_ivfpq_1M"] = {"qps_gpu": round(qps, 1), "index_s": round(t_index, 2), "recall_at_1": float(np.mean(iid[:, 0] == qi)),
+                        "ids_match": bool(np.array_equal(iid[:ns], rid)), "max_abs_ddist": float(np.max(np.abs(dd[:ns] - rd))),
+                        "cpu_qps": round(cpu_qps, 1), "cpu_threads": os.cpu_count()}
+ix.close()
+print(json.dumps(out))
