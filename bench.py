@@ -266,8 +266,20 @@ def main():
     scan_ms = st.scan_ms / launches
     alg_bytes = float(m) * st.scan_codes / launches
     achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    # physical HBM bytes per launch: PMC FETCH_SIZE (x2 on gfx950) from the committed profile of this
+    # exact workload; PMC collection cannot run inside the timed region, so the figure is per query
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        wl = tj["workload"]
+        if world == 1 and (wl["n"], wl["dim"], wl["cells"], wl["nprobe"], wl["m"], wl["k"]) == (N, D, Cc, w, m, k):
+            traffic = tj["hbm_bytes_per_query"] * B / max(1, launches / max(1, args.steps))
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "kernel": "k_scan", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 4), "traffic": None,
+                "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                "note": "achieved = algorithmic bytes (m x probed codes) / scan-kernel time; exact pruning (coarse bound, "
+                        "Smin >= T) and L2 reuse make it exceed the physical HBM rate: see traffic and DESIGN.md section 7",
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(scan_ms, 4),
                 "bytes_per_query": alg_bytes / B, "scan_launches": int(st.scan_launches),
                 "coarse_ms_per_step": round(st.coarse_ms / launches, 4), "merge_ms_per_step": round(st.merge_ms / launches, 4)}
