@@ -128,12 +128,14 @@ struct mmidx_index {
     void *d_pcodes = nullptr;
 
     // workspaces
-    DevBuf<double> ws_Q, ws_cdist, ws_odist, ws_X, ws_qn, ws_cdsel;
+    DevBuf<double> ws_Q, ws_cdist, ws_odist, ws_X, ws_Xa, ws_qn, ws_cdsel;
     DevBuf<float> ws_Q32, ws_S;
     DevBuf<int32_t> ws_cells, ws_oiid, ws_ocnt, ws_flag, ws_ecell, ws_pcount, ws_pstart, ws_pcursor, ws_order;
     DevBuf<u64> ws_T, ws_pkey, ws_pval;
     DevBuf<u32> ws_pcnt;
-    DevBuf<unsigned char> ws_ecode, ws_tmp, ws_keep;
+    DevBuf<unsigned char> ws_ecode, ws_tmp, ws_keep, ws_amb;
+    DevBuf<int32_t> ws_aidx, ws_acell;
+    int64_t last_ambiguous = 0;  // vectors of the last encode call that needed the exact redo
     DevBuf<long long> ws_dest;
 
     // profiling: HIP events recorded on the launch stream, resolved lazily by mmidx_get_stats
@@ -277,7 +279,40 @@ size_t scan_lds_bytes(const mmidx_index *h, int cap) {
 int encode_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_cell, void *d_code, hipStream_t st) {
     if (n == 0) return MMIDX_OK;
     const int ivf = h->kind == MMIDX_KIND_IVFPQ;
-    if (ivf) {
+    const size_t asg_lds = (size_t)((ASG_BM * (h->D + 2) + 3) & ~3) * 4 + (size_t)ASG_BK * ASG_BN * 4;
+    if (ivf && !h->exact_coarse && asg_lds <= 160 * 1024 && h->C >= 2) {
+        // certified approximate assignment (fp32 MFMA) + exact redo of the flagged vectors
+        constexpr int QT = 16;
+        HIPCK(h->ws_Q32.reserve((size_t)n * h->D));
+        HIPCK(h->ws_qn.reserve((size_t)n));
+        HIPCK(h->ws_amb.reserve((size_t)n));
+        hipLaunchKernelGGL(k_query_prep, dim3((unsigned)((n + 3) / 4)), dim3(MMIDX_BLOCK), 0, st, dX, h->ws_Q32.p, h->ws_qn.p, h->D, (long long)n);
+        HIPCK(hipFuncSetAttribute((const void *)k_assign_approx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)asg_lds));
+        hipLaunchKernelGGL(k_assign_approx, dim3((unsigned)((n + ASG_BM - 1) / ASG_BM)), dim3(MMIDX_BLOCK), asg_lds, st, h->d_coarseT32,
+                           h->ws_Q32.p, h->d_cn, h->ws_qn.p, d_cell, h->ws_amb.p, h->cnorm_max, h->cn_max, h->C, h->D, (long long)n);
+        HIPCK(hipGetLastError());
+        std::vector<unsigned char> amb((size_t)n);
+        HIPCK(hipMemcpyAsync(amb.data(), h->ws_amb.p, (size_t)n, hipMemcpyDeviceToHost, st));
+        HIPCK(hipStreamSynchronize(st));
+        std::vector<int32_t> idx;
+        for (int64_t i = 0; i < n; i++)
+            if (amb[(size_t)i]) idx.push_back((int32_t)i);
+        h->last_ambiguous = (int64_t)idx.size();
+        if (!idx.empty()) {
+            const int64_t na = (int64_t)idx.size();
+            HIPCK(h->ws_aidx.reserve((size_t)na));
+            HIPCK(h->ws_acell.reserve((size_t)na));
+            HIPCK(h->ws_Xa.reserve((size_t)na * h->D));
+            HIPCK(hipMemcpyAsync(h->ws_aidx.p, idx.data(), (size_t)na * 4, hipMemcpyHostToDevice, st));
+            const long long tot = (long long)na * h->D;
+            hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dX, h->ws_aidx.p, h->ws_Xa.p, h->D, (long long)na);
+            hipLaunchKernelGGL(k_assign_coarse<QT>, dim3((unsigned)((na + QT - 1) / QT)), dim3(MMIDX_BLOCK), 0, st, h->d_coarseT, h->ws_Xa.p,
+                               h->ws_acell.p, h->C, h->D, (long long)na);
+            hipLaunchKernelGGL(k_scatter_cells, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, st, h->ws_aidx.p, h->ws_acell.p, d_cell, (long long)na);
+            HIPCK(hipGetLastError());
+            HIPCK(hipStreamSynchronize(st));  // idx (host) must outlive the copy
+        }
+    } else if (ivf) {
         constexpr int QT = 16;
         const unsigned grid = (unsigned)((n + QT - 1) / QT);
         hipLaunchKernelGGL(k_assign_coarse<QT>, dim3(grid), dim3(MMIDX_BLOCK), 0, st, h->d_coarseT, dX, d_cell, h->C, h->D, (long long)n);
@@ -863,6 +898,7 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_odist.release();
     h->ws_X.release();
     h->ws_qn.release();
+    h->ws_Xa.release();
     h->ws_cdsel.release();
     h->ws_Q32.release();
     h->ws_S.release();
@@ -882,6 +918,9 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_ecode.release();
     h->ws_tmp.release();
     h->ws_keep.release();
+    h->ws_amb.release();
+    h->ws_aidx.release();
+    h->ws_acell.release();
     h->ws_dest.release();
     for (auto &ev : h->evpool)
         if (ev) (void)hipEventDestroy(ev);

@@ -2149,6 +2149,145 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_assign_coarse(const double *__r
 }
 
 // ------------------------------------------------------------------------------------------------
+// K6a (certified approximate path): nearest coarse centroid of every vector to encode.
+// One block = 64 vectors against ALL centroids: the vectors' fp32 copy stays in LDS, centroid tiles
+// of 256 stream through, dot products on the fp32 matrix cores (as K1c), and every lane keeps the
+// two smallest d~ = |c|^2 + |x|^2 - 2<x,c> of its rows.  With eps the error bound of K1d:
+//   second - best > 2 eps  =>  every other centroid has d >= d~ - eps > best + eps >= d(best):
+//   the argmin is certified (and unique, so the reference's first-wins tie rule is moot);
+// otherwise the vector is flagged and re-done by the exact kernel k_assign_coarse (a ~1e-4 fraction).
+// ------------------------------------------------------------------------------------------------
+#define ASG_BM 64
+#define ASG_BN 256
+#define ASG_BK 32
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_assign_approx(const float *__restrict__ CT32, const float *__restrict__ X32,
+                                                               const double *__restrict__ cn, const double *__restrict__ xn,
+                                                               int32_t *__restrict__ cell_out, unsigned char *__restrict__ amb,
+                                                               double cnorm_max, double cn_max, int C, int D, long long n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lda = D + 2;                               // (2*row + k) mod 32 spreads the fragment reads
+    float *As = (float *)smem;                           // [64][D+2]
+    float *Bs = As + ((ASG_BM * lda + 3) & ~3);          // [32][256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long v0 = (long long)blockIdx.x * ASG_BM;
+    for (int e = tid; e < ASG_BM * D; e += MMIDX_BLOCK) {
+        const int r = e / D, j = e - r * D;
+        const long long v = v0 + r;
+        As[r * lda + j] = (v < n) ? X32[(size_t)v * D + j] : 0.f;
+    }
+    float m1[4], m2[4];
+    int i1[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        m1[r] = __int_as_float(0x7f800000);
+        m2[r] = __int_as_float(0x7f800000);
+        i1[r] = 0x7fffffff;
+    }
+    double xnr[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const long long v = v0 + wave * 16 + 4 * (lane >> 4) + r;
+        xnr[r] = (v < n) ? xn[v] : 0.0;
+    }
+    const int fr = lane & 15, fk = lane >> 4;
+    for (int c0 = 0; c0 < C; c0 += ASG_BN) {
+        f32x4 acc[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < D; k0 += ASG_BK) {
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 8; u++) {  // B: 32 k x 256 c = 2048 float4
+                const int p = tid + u * 256, r = p >> 6, c4 = (p & 63) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k0 + r < D) {
+                    const float *src = CT32 + (size_t)(k0 + r) * C + c0 + c4;
+                    if (c0 + c4 + 3 < C) {
+                        v = *(const float4 *)src;
+                    } else {
+                        float tmp[4] = {0.f, 0.f, 0.f, 0.f};
+                        for (int e = 0; e < 4; e++)
+                            if (c0 + c4 + e < C) tmp[e] = src[e];
+                        v = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
+                    }
+                }
+                *(float4 *)(Bs + r * ASG_BN + c4) = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < ASG_BK / 4; kk++) {
+                const int kidx = k0 + kk * 4 + fk;
+                const float a = (kidx < D) ? As[(wave * 16 + fr) * lda + kidx] : 0.f;
+#pragma unroll
+                for (int t = 0; t < 16; t++) {
+                    const float b = Bs[(kk * 4 + fk) * ASG_BN + t * 16 + fr];
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        // epilogue of this centroid tile: running two smallest d~ per row (C/D: col = lane & 15, row = 4*(lane>>4)+reg)
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int c = c0 + t * 16 + (lane & 15);
+            if (c < C) {
+                const double cnc = cn[c];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float d = (float)((cnc + xnr[r]) - 2.0 * (double)acc[t][r]);
+                    if (d < m1[r] || (d == m1[r] && c < i1[r])) {
+                        m2[r] = m1[r];
+                        m1[r] = d;
+                        i1[r] = c;
+                    } else if (d < m2[r]) {
+                        m2[r] = d;
+                    }
+                }
+            }
+        }
+    }
+    // merge across the 16 lanes that share a row
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const float om1 = __shfl_xor(m1[r], off), om2 = __shfl_xor(m2[r], off);
+            const int oi1 = __shfl_xor(i1[r], off);
+            if (om1 < m1[r] || (om1 == m1[r] && oi1 < i1[r])) {
+                m2[r] = (m1[r] < om2) ? m1[r] : om2;
+                m1[r] = om1;
+                i1[r] = oi1;
+            } else {
+                m2[r] = (om1 < m2[r]) ? om1 : m2[r];
+            }
+        }
+        const long long v = v0 + wave * 16 + 4 * (lane >> 4) + r;
+        if ((lane & 15) == 0 && v < n) {
+            const double xnorm = sqrt(xnr[r]);
+            const double sumn = cnorm_max + xnorm;
+            const double eps = (2.0 * (double)(D + 3) * 0x1p-24 * 1.01 * xnorm * cnorm_max + 1e-12 * (cn_max + xnr[r]) +
+                                0x1p-23 * sumn * sumn) * (1.0 + 1e-9);
+            const bool ok = ((double)m2[r] - (double)m1[r]) > 2.0 * eps;  // inf - x = inf > ... when C == 1
+            cell_out[v] = i1[r];
+            amb[v] = ok ? 0 : 1;
+        }
+    }
+}
+
+// compaction of the flagged vectors and write-back of their exact cells
+__global__ void k_gather_rows(const double *__restrict__ X, const int32_t *__restrict__ idx, double *__restrict__ out, int D,
+                              long long n) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * D) return;
+    const long long r = e / D;
+    out[e] = X[(size_t)idx[r] * D + (e - r * D)];
+}
+__global__ void k_scatter_cells(const int32_t *__restrict__ idx, const int32_t *__restrict__ cells, int32_t *__restrict__ out,
+                                long long n) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) out[idx[e]] = cells[e];
+}
+
+// ------------------------------------------------------------------------------------------------
 // K6b: product quantisation.  Per vector: residual (centroid - x) -> transform -> for every
 // sub-quantizer the first-minimum centroid (IVFPQ.java:316-335, :613-631; PQ.java:237-252).
 // VT vectors per block; thread j owns centroid j of every sub-quantizer.
