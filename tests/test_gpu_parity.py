@@ -399,3 +399,24 @@ def test_coarse_topw_massive_ties(mi, oracle):
         exp = np.stack([ref.nearest_coarse(q, w) for q in Q])
         assert np.array_equal(got, exp), w
     ix.close()
+
+
+def test_yfcc_shape_d1024_m64(mi, oracle):
+    """The reference's own headline shape (YFCC100MExample.java:85-90: d = 1024, m = 64 x 256),
+    scaled down in n: exercises the largest LUT (128 KiB of LDS) and the exact coarse fallbacks."""
+    D, C, m, ks, n, w, k = 1024, 32, 64, 256, 2500, 4, 10
+    rng = np.random.default_rng(7)
+    mu = rng.standard_normal((C, D))
+    base = mu[rng.integers(0, C, n)] + 0.15 * rng.standard_normal((n, D))
+    pq = 0.15 * rng.standard_normal((m, ks, D // m))
+    ix = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    ix.loadCoarseQuantizer(mu)
+    ix.loadProductQuantizer(pq)
+    ix.setW(w)
+    ref = oracle_ivfpq(oracle, {"coarse": mu, "pq": pq}, D, m, ks, C, w)
+    ix.indexVectors(list(range(n)), base)
+    ref.add_vectors(base)
+    assert np.array_equal(ix.listSizes(), ref.list_sizes())
+    Q = base[:24] + 0.01 * rng.standard_normal((24, D))
+    assert_same(ix.search_batch(k, Q), ref.search_batch(Q, k))
+    ix.close()
