@@ -100,6 +100,8 @@ struct mmidx_index {
     bool no_filter = false;  // MMIDX_NO_FILTER=1: exact scan only (A/B switch for measurements)
     bool no_bound = false;   // MMIDX_NO_BOUND=1: no coarse-bound pruning of probes
     bool debug_sync = false; // MMIDX_DEBUG_SYNC=1
+    bool passa_512 = false;  // MMIDX_PASSA_512=1: pass A with 512-thread blocks
+    bool passa_su2 = false;  // MMIDX_PASSA_SU2=1: pass A with 2 codes per thread per segment (A/B switch)
     bool passa_filter = false;  // MMIDX_PASSA_FILTER=1
     bool no_seed = true;        // MMIDX_SEED=1: pass A with the seeded scan K3s (measured slower than K3: 1.45 vs 1.22 ms
                                 // per 8192 queries -- one block per query is latency-bound, not LDS-bound; kept for study)
@@ -272,7 +274,7 @@ int check_ready(const mmidx_index *h) {
 }
 
 size_t scan_lds_bytes(const mmidx_index *h, int cap) {
-    return (size_t)h->m * h->ks * 8 + 2 * (size_t)h->D * 8 + (size_t)cap * 12 + 16;
+    return (size_t)h->m * h->ks * 8 + (h->transform ? 2 : 1) * (size_t)h->D * 8 + (size_t)cap * 12 + 16;
 }
 
 // encode n device-resident vectors into (cell, code); code_out holds centroid indices (CodeT)
@@ -336,29 +338,46 @@ int encode_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_cell, 
     return MMIDX_OK;
 }
 
-template <int M, typename CodeT>
+template <int M, typename CodeT, int SU, int NT = MMIDX_BLOCK>
 int launch_scan_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t st) {
-    HIPCK(hipFuncSetAttribute((const void *)k_scan<M, CodeT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_scan<M, CodeT>), grid, dim3(MMIDX_BLOCK), lds, st, P);
+    HIPCK(hipFuncSetAttribute((const void *)k_scan<M, CodeT, SU, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_scan<M, CodeT, SU, NT>), grid, dim3(NT), lds, st, P);
     HIPCK(hipGetLastError());
     return MMIDX_OK;
 }
 
-int launch_scan(const mmidx_index *h, const ScanParams &P, dim3 grid, size_t lds, hipStream_t st) {
+// su = codes per thread per segment (1 or 2); P.cap and lds must have been sized for it
+int launch_scan(const mmidx_index *h, const ScanParams &P, dim3 grid, size_t lds, hipStream_t st, int su = 2) {
     if (h->code_bytes == 1) {
+        if (su == 11) {  // one code per thread, 512-thread blocks
+            switch (h->m) {
+                case 8: return launch_scan_t<8, unsigned char, 1, 512>(P, grid, lds, st);
+                case 16: return launch_scan_t<16, unsigned char, 1, 512>(P, grid, lds, st);
+                case 32: return launch_scan_t<32, unsigned char, 1, 512>(P, grid, lds, st);
+                default: break;
+            }
+        }
+        if (su == 1) {
+            switch (h->m) {
+                case 8: return launch_scan_t<8, unsigned char, 1>(P, grid, lds, st);
+                case 16: return launch_scan_t<16, unsigned char, 1>(P, grid, lds, st);
+                case 32: return launch_scan_t<32, unsigned char, 1>(P, grid, lds, st);
+                default: break;
+            }
+        }
         switch (h->m) {
-            case 4: return launch_scan_t<4, unsigned char>(P, grid, lds, st);
-            case 8: return launch_scan_t<8, unsigned char>(P, grid, lds, st);
-            case 16: return launch_scan_t<16, unsigned char>(P, grid, lds, st);
-            case 32: return launch_scan_t<32, unsigned char>(P, grid, lds, st);
-            case 64: return launch_scan_t<64, unsigned char>(P, grid, lds, st);
-            default: return launch_scan_t<0, unsigned char>(P, grid, lds, st);
+            case 4: return launch_scan_t<4, unsigned char, 2>(P, grid, lds, st);
+            case 8: return launch_scan_t<8, unsigned char, 2>(P, grid, lds, st);
+            case 16: return launch_scan_t<16, unsigned char, 2>(P, grid, lds, st);
+            case 32: return launch_scan_t<32, unsigned char, 2>(P, grid, lds, st);
+            case 64: return launch_scan_t<64, unsigned char, 2>(P, grid, lds, st);
+            default: return launch_scan_t<0, unsigned char, 2>(P, grid, lds, st);
         }
     }
     switch (h->m) {
-        case 8: return launch_scan_t<8, unsigned short>(P, grid, lds, st);
-        case 16: return launch_scan_t<16, unsigned short>(P, grid, lds, st);
-        default: return launch_scan_t<0, unsigned short>(P, grid, lds, st);
+        case 8: return launch_scan_t<8, unsigned short, 2>(P, grid, lds, st);
+        case 16: return launch_scan_t<16, unsigned short, 2>(P, grid, lds, st);
+        default: return launch_scan_t<0, unsigned short, 2>(P, grid, lds, st);
     }
 }
 
@@ -617,8 +636,25 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
         //  measured faster: 1.23 vs ~1.4 ms per 8192 queries; MMIDX_PASSA_FILTER=1 switches)
         int rc = MMIDX_OK;
         if (phase != 2) {
-            rc = h->passa_filter ? launch_scan_filtered(h, P, pl, dim3((unsigned)P.n_items, (unsigned)grid_chunks), st)
-                                 : launch_scan_seeded(h, P, pl, dim3((unsigned)P.n_items, (unsigned)grid_chunks), st);
+            if (h->passa_filter) {
+                rc = launch_scan_filtered(h, P, pl, dim3((unsigned)P.n_items, (unsigned)grid_chunks), st);
+            } else if (!h->no_seed) {
+                rc = launch_scan_seeded(h, P, pl, dim3((unsigned)P.n_items, (unsigned)grid_chunks), st);
+            } else {
+                // one code per thread per segment: smaller candidate buffer -> a fourth block per CU
+                ScanParams PA = P;
+                int su = 2;
+                size_t lds_a = pl.lds;
+                if (two_pass && ivf && !h->passa_su2 && h->code_bytes == 1 && (h->m == 8 || h->m == 16 || h->m == 32)) {
+                    const int nt = h->passa_512 ? 512 : MMIDX_BLOCK;
+                    int cap1 = 1;
+                    while (cap1 < pl.K1 + nt) cap1 <<= 1;
+                    PA.cap = cap1;
+                    lds_a = scan_lds_bytes(h, cap1);
+                    su = h->passa_512 ? 11 : 1;
+                }
+                rc = launch_scan(h, PA, dim3((unsigned)P.n_items, (unsigned)grid_chunks), lds_a, st, su);
+            }
             if (rc) return rc;
             DBG_SYNC("pass A scan");
         }
@@ -876,6 +912,10 @@ int mmidx_create(int kind, int D, int m, int ks, int C, int transform, const int
         h->debug_sync = ds && ds[0] == '1';
         const char *ec = getenv("MMIDX_EXACT_COARSE");
         h->exact_coarse = ec && ec[0] == '1';
+        const char *p5 = getenv("MMIDX_PASSA_512");
+        h->passa_512 = p5 && p5[0] == '1';
+        const char *p2 = getenv("MMIDX_PASSA_SU2");
+        h->passa_su2 = p2 && p2[0] == '1';
         const char *pf = getenv("MMIDX_PASSA_FILTER");
         h->passa_filter = pf && pf[0] == '1';
         const char *nsd = getenv("MMIDX_SEED");

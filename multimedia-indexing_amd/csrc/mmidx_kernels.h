@@ -835,7 +835,7 @@ __device__ __forceinline__ void build_lut(double *lut, const double *tr, const d
     const int total = m * ks;
     if constexpr (DSUB > 0) {
 #pragma unroll 2
-        for (int idx = threadIdx.x; idx < total; idx += MMIDX_BLOCK) {
+        for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
             const int s = idx / ks, j = idx - s * ks;
             const double *pp = pqT + (size_t)s * DSUB * ks + j;
             double pv[DSUB];
@@ -851,7 +851,7 @@ __device__ __forceinline__ void build_lut(double *lut, const double *tr, const d
             lut[idx] = acc;
         }
     } else {
-        for (int idx = threadIdx.x; idx < total; idx += MMIDX_BLOCK) {
+        for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
             const int s = idx / ks, j = idx - s * ks;
             const double *pp = pqT + (size_t)s * dsub_rt * ks + j;
             const double *tv = tr + s * dsub_rt;
@@ -892,18 +892,18 @@ __device__ __forceinline__ void build_lut_any(double *lut, const double *tr, con
 __device__ __forceinline__ double *query_vector(const ScanParams &P, int q, int cell, double *vec) {
     const int D = P.D, tid = threadIdx.x;
     double *r = vec, *tr = vec + D;
-    for (int i = tid; i < D; i += MMIDX_BLOCK) {
+    for (int i = tid; i < D; i += blockDim.x) {
         const double qv = P.Q[(size_t)q * D + i];
         r[i] = P.ivf ? (P.coarse[(size_t)cell * D + i] - qv) : qv;
     }
     __syncthreads();
     if (P.transform == 2) {
-        for (int i = tid; i < D; i += MMIDX_BLOCK) tr[i] = r[P.perm[i]];
+        for (int i = tid; i < D; i += blockDim.x) tr[i] = r[P.perm[i]];
         __syncthreads();
         return tr;
     }
     if (P.transform == 1) {
-        for (int j = tid; j < D; j += MMIDX_BLOCK) {
+        for (int j = tid; j < D; j += blockDim.x) {
             double total = 0.0;
             for (int i = 0; i < D; i++) total += r[i] * P.rot[(size_t)i * D + j];
             tr[j] = total;
@@ -914,14 +914,17 @@ __device__ __forceinline__ double *query_vector(const ScanParams &P, int q, int 
     return r;
 }
 
-template <int M, typename CodeT>
-__global__ __launch_bounds__(MMIDX_BLOCK) void k_scan(const ScanParams P) {
+// SU = codes per thread per segment: 2 by default; 1 for pass A (one cold list per query: the block is a
+// long dependent chain, so LDS is traded for a fourth resident block per CU)
+// NT = threads per block (256, or 512 for pass A: twice the waves over the same LDS footprint)
+template <int M, typename CodeT, int SU, int NT>
+__global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int m = (M > 0) ? M : P.m;
     const int ks = P.ks, D = P.D;
     double *lut = (double *)smem;                 // [m*ks]
     double *vec = lut + (size_t)m * ks;           // [2*D]
-    u64 *bkey = (u64 *)(vec + 2 * (size_t)D);     // [cap]
+    u64 *bkey = (u64 *)(vec + (P.transform ? 2 : 1) * (size_t)D);  // [cap] (the transform needs a second vector)
     u32 *bval = (u32 *)(bkey + P.cap);            // [cap]
     u32 *s_cnt = bval + P.cap;                    // [4]
 
@@ -958,11 +961,11 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan(const ScanParams P) {
     const CodeT *codes = (const CodeT *)P.codes + (size_t)beg * m;
 
     // first segment's codes: issued before the LUT build so that HBM latency hides under it
-    CodeVec<(M > 0 ? M : 4), CodeT> cur[MMIDX_SEGU], nxt[MMIDX_SEGU];
+    CodeVec<(M > 0 ? M : 4), CodeT> cur[SU], nxt[SU];
     if constexpr (M > 0) {
 #pragma unroll
-        for (int u = 0; u < MMIDX_SEGU; u++) {
-            const int64_t i = c0 + u * MMIDX_BLOCK + tid;
+        for (int u = 0; u < SU; u++) {
+            const int64_t i = c0 + u * NT + tid;
             cur[u].load(codes + (size_t)(i < c1 ? i : c1 - 1) * M);
         }
     }
@@ -975,30 +978,30 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan(const ScanParams P) {
     __syncthreads();
 
     // ---- scan -----------------------------------------------------------------------------------
-    const int limit = P.cap - MMIDX_SEG;
+    const int limit = P.cap - NT * SU;
     const u64 lane_lt = (1ull << (tid & 63)) - 1ull;
-    for (int64_t seg = c0; seg < c1; seg += MMIDX_SEG) {
-        double d[MMIDX_SEGU];
-        const bool more = seg + MMIDX_SEG < c1;
+    for (int64_t seg = c0; seg < c1; seg += (NT * SU)) {
+        double d[SU];
+        const bool more = seg + NT * SU < c1;
         if constexpr (M > 0) {
             if (more) {
 #pragma unroll
-                for (int u = 0; u < MMIDX_SEGU; u++) {
-                    const int64_t i = seg + MMIDX_SEG + u * MMIDX_BLOCK + tid;
+                for (int u = 0; u < SU; u++) {
+                    const int64_t i = seg + NT * SU + u * NT + tid;
                     nxt[u].load(codes + (size_t)(i < c1 ? i : c1 - 1) * M);
                 }
             }
 #pragma unroll
-            for (int u = 0; u < MMIDX_SEGU; u++) d[u] = 0.0;
+            for (int u = 0; u < SU; u++) d[u] = 0.0;
 #pragma unroll
             for (int s = 0; s < M; s++) {
 #pragma unroll
-                for (int u = 0; u < MMIDX_SEGU; u++) d[u] += lut[s * ks + cur[u].get(s)];
+                for (int u = 0; u < SU; u++) d[u] += lut[s * ks + cur[u].get(s)];
             }
         } else {
 #pragma unroll
-            for (int u = 0; u < MMIDX_SEGU; u++) {
-                const int64_t i = seg + u * MMIDX_BLOCK + tid;
+            for (int u = 0; u < SU; u++) {
+                const int64_t i = seg + u * NT + tid;
                 const CodeT *cp = codes + (size_t)(i < c1 ? i : c1 - 1) * m;
                 double a = 0.0;
                 for (int s = 0; s < m; s++) a += lut[s * ks + (int)cp[s]];
@@ -1006,8 +1009,8 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan(const ScanParams P) {
             }
         }
 #pragma unroll
-        for (int u = 0; u < MMIDX_SEGU; u++) {
-            const int64_t i = seg + u * MMIDX_BLOCK + tid;
+        for (int u = 0; u < SU; u++) {
+            const int64_t i = seg + u * NT + tid;
             const u64 key = dkey(d[u]);
             const bool pass = (i < c1) && key <= T;
             const u64 mask = __ballot(pass);
@@ -1033,7 +1036,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan(const ScanParams P) {
         if constexpr (M > 0) {
             if (more) {
 #pragma unroll
-                for (int u = 0; u < MMIDX_SEGU; u++) cur[u] = nxt[u];
+                for (int u = 0; u < SU; u++) cur[u] = nxt[u];
             }
         }
     }
@@ -1042,7 +1045,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan(const ScanParams P) {
     if ((int)*s_cnt > P.K1) scan_prune(bkey, bval, s_cnt, P.K1, Tq);
     T = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int n = (int)*s_cnt;
-    for (int base0 = 0; base0 < n; base0 += MMIDX_BLOCK) {
+    for (int base0 = 0; base0 < n; base0 += NT) {
         const int i = base0 + tid;
         const bool pass = (i < n) && bkey[i] <= T;
         const u64 mask = __ballot(pass);
