@@ -263,6 +263,31 @@ class _PQBase(AbstractSearchStructure):
         N.check(N.lib().mmidx_export(self._h, off.ctypes.data, iids.ctypes.data, codes.ctypes.data))
         return off, iids, codes
 
+    def saveSnapshot(self, filename):
+        """Flat snapshot of the in-memory index for fast restart: the list-major
+        arrays loadIndexInMemory builds (IVFPQ.java:680-728) plus the id map; the BDB environment stays
+        the system of record on the Java side."""
+        off, iids, codes = self.export()
+        ids = np.array([str(self._iid_to_id.get(int(i), int(i))) for i in iids], dtype=object)
+        np.savez(filename, list_off=off, iids=iids, codes=codes, ids=ids, load_counter=np.int64(self.loadCounter),
+                 allow_pickle=True)
+
+    def loadSnapshot(self, filename):
+        """Inverse of saveSnapshot on an empty index of the same shape (quantizers loaded separately,
+        as after the reference's constructor)."""
+        z = np.load(filename, allow_pickle=True)
+        off, iids, codes, ids = z["list_off"], z["iids"], z["codes"], z["ids"]
+        nl = len(off) - 1
+        cells = np.repeat(np.arange(nl, dtype=np.int32), np.diff(off).astype(np.int64))
+        iids = np.ascontiguousarray(iids, np.int32)
+        codes = np.ascontiguousarray(codes, self._code_dtype)
+        N.check(N.lib().mmidx_add_codes(self._h, len(iids), iids.ctypes.data,
+                                        cells.ctypes.data if self._kind == N.KIND_IVFPQ else None, codes.ctypes.data))
+        for i, name in zip(iids, ids):
+            self._iid_to_id[int(i)] = str(name)
+            self._id_to_iid[str(name)] = int(i)
+        self.loadCounter = int(z["load_counter"])
+
     def size(self):
         n = C.c_int64()
         N.check(N.lib().mmidx_size(self._h, C.byref(n)))

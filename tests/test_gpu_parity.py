@@ -420,3 +420,26 @@ def test_yfcc_shape_d1024_m64(mi, oracle):
     Q = base[:24] + 0.01 * rng.standard_normal((24, D))
     assert_same(ix.search_batch(k, Q), ref.search_batch(Q, k))
     ix.close()
+
+
+def test_snapshot_roundtrip(mi, oracle, tmp_path):
+    """saveSnapshot / loadSnapshot (flat restart path): identical answers, ids preserved."""
+    D, C, m, ks, n, w, k = 32, 16, 8, 256, 3000, 4, 10
+    p = synth.make_ivfpq_problem(n=n, D=D, C=C, m=m, ks=ks, nq=16, seed=41)
+    a = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    b = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    for ix in (a, b):
+        ix.loadCoarseQuantizer(p["coarse"])
+        ix.loadProductQuantizer(p["pq"])
+        ix.setW(w)
+    a.indexVectors([f"im{i}" for i in range(n)], p["base"])
+    f = str(tmp_path / "snap.npz")
+    a.saveSnapshot(f)
+    b.loadSnapshot(f)
+    assert b.size() == n and b.getLoadCounter() == n and np.array_equal(a.listSizes(), b.listSizes())
+    ra, rb = a.search_batch(k, p["queries"]), b.search_batch(k, p["queries"])
+    assert_same(rb, ra)
+    assert b.computeNearestNeighbors(k, p["queries"][0]).getIds() == a.computeNearestNeighbors(k, p["queries"][0]).getIds()
+    assert b.indexVector("im5", p["base"][5]) is False  # duplicate id known after the reload
+    a.close()
+    b.close()
