@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--gt", type=int, default=1024, help="queries with exact ground truth (recall@1)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--exhaustive-steps", type=int, default=3,
+                    help="extra untimed-for-value steps with pruning off, reported as roofline_exhaustive (0 = skip)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path (encode -> owner filter -> add_codes, two-phase shard search, "
                          "merge) even with one rank: exercises it on a single GPU")
@@ -253,6 +255,29 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     qps = B * args.steps / elapsed
 
+    # the same steps with every exact shortcut switched off (each probed code read and summed in fp64):
+    # the configuration on which the scan kernel's HBM roofline fraction is a meaningful figure
+    exhaustive = None
+    if sharded is None and args.exhaustive_steps > 0:
+        chk(L.mmidx_set_option(h, b"exhaustive", 1))
+        step(Qb[0])
+        barrier()
+        chk(L.mmidx_set_profiling(h, 1))
+        t0 = time.perf_counter()
+        for i in range(args.exhaustive_steps):
+            step(Qb[i % args.nbatches])
+        barrier()
+        ex_t = time.perf_counter() - t0
+        ex = nat.Stats()
+        chk(L.mmidx_get_stats(h, C.byref(ex)))
+        chk(L.mmidx_set_profiling(h, 0))
+        chk(L.mmidx_set_option(h, b"exhaustive", 0))
+        ex_bytes = float(m) * ex.scan_codes
+        ex_ach = ex_bytes / (ex.scan_ms * 1e-3) / 1e9 if ex.scan_ms > 0 else 0.0
+        exhaustive = {"steps": args.exhaustive_steps, "queries_per_s": round(B * args.exhaustive_steps / ex_t, 1),
+                      "scan_ms_per_step": round(ex.scan_ms / args.exhaustive_steps, 4), "achieved": round(ex_ach, 1), "peak": 8000.0,
+                      "unit": "GB/s", "frac": round(ex_ach / 8000.0, 4), "bound": "lds (bank conflicts of the fp64 gather), see DESIGN.md 5.1"}
+
     # recall@1 and results of batch 0 (for the parity gate)
     step(Qb[0])
     torch.cuda.synchronize()
@@ -330,7 +355,7 @@ def main():
                        "n": N, "dim": D, "cells": Cc, "nprobe": w, "m": m, "ks": ks, "k": k, "batch": B,
                        "sharding": "single GPU" if world == 1 else f"whole inverted lists, cell mod {world}; RCCL all-gather top-k merge"},
             "recall_at_1": recall1, "recall_queries": ngt,
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
+            "roofline": roofline, "roofline_exhaustive": exhaustive, "cpu_baseline": cpu_baseline, "parity": parity,
         }
         print(json.dumps(out), flush=True)
     chk(L.mmidx_destroy(h))

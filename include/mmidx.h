@@ -175,6 +175,11 @@ typedef struct mmidx_stats {
     int32_t tie_fallbacks;
 } mmidx_stats;
 int mmidx_set_profiling(mmidx_index *h, int enabled);
+/* measurement switches; results are identical in every setting.  "exhaustive" = 1: every probed
+ * code is read and summed in fp64 (no lower-bound filter, no coarse-bound probe pruning) -- the
+ * configuration the HBM roofline of the scan kernel is quoted on; "no_filter", "no_bound",
+ * "exact_coarse" switch the individual devices (DESIGN.md sections 5.2, 5.4, 5.5). */
+int mmidx_set_option(mmidx_index *h, const char *name, int value);
 int mmidx_get_stats(mmidx_index *h, mmidx_stats *out);
 
 /* ---- front end of BASELINE config 5 ----------------------------------------------------------

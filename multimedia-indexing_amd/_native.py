@@ -88,6 +88,7 @@ SIGNATURES = {
     "mmidx_vlad_aggregate": (C.c_int, [_vp, C.c_int64, _vp, _dp, _dp]),
     "mmidx_vlad_aggregate_device": (C.c_int, [_vp, C.c_int64, _vp, _dp, C.c_int, _dp, _vp]),
     "mmidx_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "mmidx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "mmidx_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
 }
 

@@ -1357,6 +1357,25 @@ int mmidx_merge_partials_device(int device, int k, int64_t nq, int nshards, cons
     return MMIDX_OK;
 }
 
+// runtime switches for measurements (same meaning as the MMIDX_* environment variables read at create)
+int mmidx_set_option(mmidx_index *h, const char *name, int value) {
+    if (!h || !name) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    const std::string n(name);
+    if (n == "exhaustive") {  // every probed code is read and summed in fp64: no filter, no coarse bound
+        h->no_filter = value != 0;
+        h->no_bound = value != 0;
+    } else if (n == "no_filter") {
+        h->no_filter = value != 0;
+    } else if (n == "no_bound") {
+        h->no_bound = value != 0;
+    } else if (n == "exact_coarse") {
+        h->exact_coarse = value != 0;
+    } else {
+        return fail(MMIDX_ERR_INVALID_ARG, "unknown option '%s'", name);
+    }
+    return MMIDX_OK;
+}
+
 int mmidx_set_profiling(mmidx_index *h, int enabled) {
     if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
     int rc = set_device(h);
