@@ -132,6 +132,12 @@ int mmidx_search(mmidx_index *h, int k, int64_t nq, const double *Q, int32_t *ii
                  double *dist_out, int32_t *count_out);
 int mmidx_search_device(mmidx_index *h, int k, int64_t nq, const double *dQ, int32_t *d_iid_out,
                         double *d_dist_out, int32_t *d_count_out, void *stream);
+/* computeNearestNeighborsInternal(k, int iid) of PQ: computeKnnSDC, PQ.java:334-374 -- the query is
+ * the stored code of the vector with internal id iids[i]; distances are code-to-code (one sequential
+ * chain over all D dimensions).  PQ with byte codes only: IVFPQ.computeKnnIVFSDC returns null in the
+ * reference (IVFPQ.java:509-511) -> MMIDX_ERR_UNSUPPORTED. */
+int mmidx_search_sdc(mmidx_index *h, int k, int64_t nq, const int32_t *iids, int32_t *iid_out,
+                     double *dist_out, int32_t *count_out);
 
 /* ---- sharded search (one process per GPU; lists partitioned across ranks) ---------------------
  * mmidx_coarse_device: computeNearestCoarseIndices IVFPQ.java:575-601 for nq queries ->

@@ -72,6 +72,7 @@ SIGNATURES = {
     "mmidx_sync_index": (C.c_int, [_vp]),
     "mmidx_export": (C.c_int, [_vp, _vp, _i32p, _vp]),
     "mmidx_search": (C.c_int, [_vp, C.c_int, C.c_int64, _dp, _i32p, _dp, _i32p]),
+    "mmidx_search_sdc": (C.c_int, [_vp, C.c_int, C.c_int64, _i32p, _i32p, _dp, _i32p]),
     "mmidx_search_device": (C.c_int, [_vp, C.c_int, C.c_int64, _dp, _i32p, _dp, _i32p, _vp]),
     "mmidx_coarse_device": (C.c_int, [_vp, C.c_int64, _dp, _i32p, _vp]),
     "mmidx_search_partial_device": (C.c_int, [_vp, C.c_int, C.c_int64, _dp, _i32p, _dp, _vp, _i32p, _vp]),

@@ -130,7 +130,7 @@ struct mmidx_index {
     void *d_pcodes = nullptr;
 
     // workspaces
-    DevBuf<double> ws_Q, ws_cdist, ws_odist, ws_X, ws_Xa, ws_qn, ws_cdsel;
+    DevBuf<double> ws_Q, ws_cdist, ws_odist, ws_X, ws_Xa, ws_qn, ws_cdsel, ws_sdc;
     DevBuf<float> ws_Q32, ws_S;
     DevBuf<int32_t> ws_cells, ws_oiid, ws_ocnt, ws_flag, ws_ecell, ws_pcount, ws_pstart, ws_pcursor, ws_order;
     DevBuf<u64> ws_T, ws_pkey, ws_pval;
@@ -338,16 +338,23 @@ int encode_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_cell, 
     return MMIDX_OK;
 }
 
-template <int M, typename CodeT, int SU, int NT = MMIDX_BLOCK>
+template <int M, typename CodeT, int SU, int NT = MMIDX_BLOCK, bool SDC = false>
 int launch_scan_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t st) {
-    HIPCK(hipFuncSetAttribute((const void *)k_scan<M, CodeT, SU, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_scan<M, CodeT, SU, NT>), grid, dim3(NT), lds, st, P);
+    HIPCK(hipFuncSetAttribute((const void *)k_scan<M, CodeT, SU, NT, SDC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_scan<M, CodeT, SU, NT, SDC>), grid, dim3(NT), lds, st, P);
     HIPCK(hipGetLastError());
     return MMIDX_OK;
 }
 
-// su = codes per thread per segment (1 or 2); P.cap and lds must have been sized for it
+// su = codes per thread per segment (1 or 2; 11 = 1 with 512-thread blocks); P.cap and lds sized for it
 int launch_scan(const mmidx_index *h, const ScanParams &P, dim3 grid, size_t lds, hipStream_t st, int su = 2) {
+    if (P.sdc_tt) {  // symmetric distances: byte codes only (the reference NPEs on short codes, PQ.java:350)
+        switch (h->m) {
+            case 8: return launch_scan_t<8, unsigned char, 2, MMIDX_BLOCK, true>(P, grid, lds, st);
+            case 16: return launch_scan_t<16, unsigned char, 2, MMIDX_BLOCK, true>(P, grid, lds, st);
+            default: return launch_scan_t<0, unsigned char, 2, MMIDX_BLOCK, true>(P, grid, lds, st);
+        }
+    }
     if (h->code_bytes == 1) {
         if (su == 11) {  // one code per thread, 512-thread blocks
             switch (h->m) {
@@ -436,7 +443,7 @@ int launch_filt_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t st) {
 
 // pass B: lower-bound filtered scan where it applies (byte codes, templated m), else the exact scan
 int launch_scan_filtered(const mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 grid, hipStream_t st) {
-    const bool ok = h->code_bytes == 1 && h->ks <= 256 && (h->m == 8 || h->m == 16 || h->m == 32) && !h->no_filter;
+    const bool ok = h->code_bytes == 1 && h->ks <= 256 && (h->m == 8 || h->m == 16 || h->m == 32) && !h->no_filter && !P.sdc_tt;
     if (!ok) return launch_scan(h, P, grid, pl.lds, st);
     int cap = 1;
     while (cap < pl.K1 + MMIDX_VROUND) cap <<= 1;
@@ -462,7 +469,7 @@ int launch_seed_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t st) {
 // pass A: seeded scan (exact sample -> histogram of u8 lower bounds -> exact verify) where it applies
 int launch_scan_seeded(const mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 grid, hipStream_t st) {
     const bool ok = h->code_bytes == 1 && h->ks <= 256 && (h->m == 8 || h->m == 16 || h->m == 32) && !h->no_filter &&
-                    !h->no_seed;
+                    !h->no_seed && !P.sdc_tt;
     if (!ok) return launch_scan(h, P, grid, pl.lds, st);
     int cap = 1;
     while (cap < pl.K1 + MMIDX_SEED_N0) cap <<= 1;
@@ -555,7 +562,7 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
 // one sub-batch (nq <= plan.qb) entirely on device
 int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq, const double *dQ, const int32_t *d_cells_in,
                         int mode, int32_t *d_iid, double *d_dist, int32_t *d_cnt, double *d_pdist, long long *d_pkey,
-                        int phase, double *d_T_io, hipStream_t st) {
+                        int phase, double *d_T_io, hipStream_t st, const double *sdc_tt = nullptr) {
     // phase 0: whole search.  Sharded search splits it so that the thresholds can be MIN-reduced
     // across ranks in between: phase 1 = setup + pass A + export T, phase 2 = import T + pass B + merge.
     const int ivf = h->kind == MMIDX_KIND_IVFPQ;
@@ -597,6 +604,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
     P.Q = dQ;
     P.coarse = h->d_coarse;
     P.pqT = h->d_pqT;
+    P.sdc_tt = sdc_tt;
     P.perm = h->d_perm;
     P.rot = h->d_rot;
     P.cells = ivf ? d_cells : nullptr;
@@ -780,12 +788,15 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
         TP.dist_out = d_dist;
         TP.k = k;
         const size_t tlds = (size_t)h->m * h->ks * 8 + 2 * (size_t)h->D * 8;
-        if (h->code_bytes == 1) {
-            HIPCK(hipFuncSetAttribute((const void *)k_tie_resolve<unsigned char>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
-            hipLaunchKernelGGL(k_tie_resolve<unsigned char>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), tlds, st, TP);
+        if (sdc_tt) {
+            HIPCK(hipFuncSetAttribute((const void *)k_tie_resolve<unsigned char, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+            hipLaunchKernelGGL((k_tie_resolve<unsigned char, true>), dim3((unsigned)nq), dim3(MMIDX_BLOCK), tlds, st, TP);
+        } else if (h->code_bytes == 1) {
+            HIPCK(hipFuncSetAttribute((const void *)k_tie_resolve<unsigned char, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+            hipLaunchKernelGGL((k_tie_resolve<unsigned char, false>), dim3((unsigned)nq), dim3(MMIDX_BLOCK), tlds, st, TP);
         } else {
-            HIPCK(hipFuncSetAttribute((const void *)k_tie_resolve<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
-            hipLaunchKernelGGL(k_tie_resolve<unsigned short>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), tlds, st, TP);
+            HIPCK(hipFuncSetAttribute((const void *)k_tie_resolve<unsigned short, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+            hipLaunchKernelGGL((k_tie_resolve<unsigned short, false>), dim3((unsigned)nq), dim3(MMIDX_BLOCK), tlds, st, TP);
         }
         HIPCK(hipGetLastError());
     }
@@ -805,7 +816,8 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
 }
 
 int search_common(mmidx_index *h, int k, int64_t nq, const double *dQ, const int32_t *d_cells, int mode, int32_t *d_iid,
-                  double *d_dist, int32_t *d_cnt, double *d_pdist, long long *d_pkey, hipStream_t st) {
+                  double *d_dist, int32_t *d_cnt, double *d_pdist, long long *d_pkey, hipStream_t st,
+                  const double *sdc_tt = nullptr) {
     int rc = check_ready(h);
     if (rc) return rc;
     if (nq < 0) return fail(MMIDX_ERR_INVALID_ARG, "nq < 0");
@@ -827,7 +839,8 @@ int search_common(mmidx_index *h, int k, int64_t nq, const double *dQ, const int
         rc = search_batch_device(h, pl, k, nb, dQ + (size_t)q0 * h->D, d_cells ? d_cells + (size_t)q0 * h->w : nullptr, mode,
                                  d_iid ? d_iid + (size_t)q0 * k : nullptr, d_dist ? d_dist + (size_t)q0 * k : nullptr,
                                  d_cnt + q0, d_pdist ? d_pdist + (size_t)q0 * pl.K1 : nullptr,
-                                 d_pkey ? d_pkey + (size_t)q0 * pl.K1 : nullptr, 0, nullptr, st);
+                                 d_pkey ? d_pkey + (size_t)q0 * pl.K1 : nullptr, 0, nullptr, st,
+                                 sdc_tt ? sdc_tt + (size_t)q0 * h->m * h->ks * h->dsub : nullptr);
         if (rc) return rc;
     }
     return MMIDX_OK;
@@ -939,6 +952,7 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_X.release();
     h->ws_qn.release();
     h->ws_Xa.release();
+    h->ws_sdc.release();
     h->ws_cdsel.release();
     h->ws_Q32.release();
     h->ws_S.release();
@@ -1273,6 +1287,50 @@ int mmidx_search(mmidx_index *h, int k, int64_t nq, const double *Q, int32_t *ii
     HIPCK(hipMemcpyAsync(dist_out, h->ws_odist.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCK(hipMemcpyAsync(count_out, h->ws_ocnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));
+    return MMIDX_OK;
+}
+
+// computeNearestNeighborsInternal(k, iid) for PQ: computeKnnSDC, PQ.java:334-374
+int mmidx_search_sdc(mmidx_index *h, int k, int64_t nq, const int32_t *iids, int32_t *iid_out, double *dist_out, int32_t *count_out) {
+    if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    if (nq > 0 && (!iids || !iid_out || !dist_out || !count_out)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (h->kind != MMIDX_KIND_PQ) return fail(MMIDX_ERR_UNSUPPORTED, "id queries: IVFPQ.computeKnnIVFSDC is unimplemented in the reference (IVFPQ.java:509-511)");
+    if (h->code_bytes != 1) return fail(MMIDX_ERR_UNSUPPORTED, "SDC needs byte codes (the reference dereferences pqByteCodes unconditionally, PQ.java:350)");
+    if (k < 1 || k > 1023) return fail(MMIDX_ERR_INVALID_ARG, "k must be in 1..1023 (got %d)", k);
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (nq == 0) return MMIDX_OK;
+    rc = set_device(h);
+    if (rc) return rc;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        rc = build_csr(h);
+        if (rc) return rc;
+    }
+    for (int64_t i = 0; i < nq; i++)
+        if (iids[i] < 0 || iids[i] >= h->n_csr) return fail(MMIDX_ERR_INVALID_ARG, "internal id %d outside 0..%lld", iids[i], (long long)h->n_csr - 1);
+    const size_t per = (size_t)h->m * h->ks * h->dsub;
+    const int64_t QB = std::max<int64_t>(1, (int64_t)((1ull << 30) / (per * 8)));  // <= 1 GiB of term tables per round
+    for (int64_t q0 = 0; q0 < nq; q0 += QB) {
+        const int64_t nb = std::min(QB, nq - q0);
+        HIPCK(h->ws_sdc.reserve((size_t)nb * per));
+        HIPCK(h->ws_aidx.reserve((size_t)nb));
+        HIPCK(h->ws_Q.reserve((size_t)nb * h->D));  // unused by the SDC kernels, but the scan parameters want a valid pointer
+        HIPCK(h->ws_oiid.reserve((size_t)nb * k));
+        HIPCK(h->ws_odist.reserve((size_t)nb * k));
+        HIPCK(h->ws_ocnt.reserve((size_t)nb));
+        HIPCK(hipMemcpyAsync(h->ws_aidx.p, iids + q0, (size_t)nb * 4, hipMemcpyHostToDevice, h->stream));
+        const long long tot = (long long)nb * (long long)per;
+        hipLaunchKernelGGL(k_sdc_terms<unsigned char>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->d_pq,
+                           (const unsigned char *)h->d_codes, h->ws_aidx.p, h->ws_sdc.p, h->m, h->ks, h->dsub, tot);
+        HIPCK(hipGetLastError());
+        rc = search_common(h, k, nb, h->ws_Q.p, nullptr, 0, h->ws_oiid.p, h->ws_odist.p, h->ws_ocnt.p, nullptr, nullptr, h->stream, h->ws_sdc.p);
+        if (rc) return rc;
+        HIPCK(hipMemcpyAsync(iid_out + (size_t)q0 * k, h->ws_oiid.p, (size_t)nb * k * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(hipMemcpyAsync(dist_out + (size_t)q0 * k, h->ws_odist.p, (size_t)nb * k * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(hipMemcpyAsync(count_out + q0, h->ws_ocnt.p, (size_t)nb * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(hipStreamSynchronize(h->stream));
+    }
     return MMIDX_OK;
 }
 

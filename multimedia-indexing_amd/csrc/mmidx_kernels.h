@@ -747,6 +747,7 @@ struct ScanParams {
     const int32_t *cells;    // [nq][w] (IVFPQ) or null (PQ)
     const int64_t *list_off; // [nlists+1]
     const void *codes;       // [n][m] CodeT
+    const double *sdc_tt;    // SDC mode (PQ.computeKnnSDC): [nq][m][ks][dsub] squared-difference terms, else null
     const int32_t *order;    // sorted pair ids (q*w + rank) or null = natural order
     const int32_t *n_order;  // device count of valid entries in order[]
     u64 *T;                  // [nq]
@@ -917,7 +918,10 @@ __device__ __forceinline__ double *query_vector(const ScanParams &P, int q, int 
 // SU = codes per thread per segment: 2 by default; 1 for pass A (one cold list per query: the block is a
 // long dependent chain, so LDS is traded for a fourth resident block per CU)
 // NT = threads per block (256, or 512 for pass A: twice the waves over the same LDS footprint)
-template <int M, typename CodeT, int SU, int NT>
+// SDC = symmetric distances (PQ.computeKnnSDC PQ.java:334-374): instead of the LUT sum, the distance is ONE chain
+// over all D dimensions of (pq[s][code_s][t] - pq[s][querycode_s][t])^2, s outer, t inner (PQ.java:349-363); the
+// squared terms come from a per-query table in global memory (L2-resident, 256 KiB at m*ks*dsub = 32768).
+template <int M, typename CodeT, int SU, int NT, bool SDC>
 __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int m = (M > 0) ? M : P.m;
@@ -971,8 +975,13 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
     }
 
     if (tid == 0) s_cnt[0] = 0;
-    const double *tr = query_vector(P, q, cell, vec);
-    build_lut_any(lut, tr, P.pqT, m, ks, P.dsub);
+    const double *TT = nullptr;
+    if constexpr (SDC) {
+        TT = P.sdc_tt + (size_t)q * m * ks * P.dsub;
+    } else {
+        const double *tr = query_vector(P, q, cell, vec);
+        build_lut_any(lut, tr, P.pqT, m, ks, P.dsub);
+    }
     u64 *Tq = P.T + q;
     u64 T = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
@@ -993,10 +1002,20 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
             }
 #pragma unroll
             for (int u = 0; u < SU; u++) d[u] = 0.0;
+            if constexpr (SDC) {
 #pragma unroll
-            for (int s = 0; s < M; s++) {
+                for (int u = 0; u < SU; u++) {
+                    for (int s = 0; s < M; s++) {
+                        const double *tt = TT + ((size_t)s * ks + cur[u].get(s)) * P.dsub;
+                        for (int t = 0; t < P.dsub; t++) d[u] += tt[t];
+                    }
+                }
+            } else {
 #pragma unroll
-                for (int u = 0; u < SU; u++) d[u] += lut[s * ks + cur[u].get(s)];
+                for (int s = 0; s < M; s++) {
+#pragma unroll
+                    for (int u = 0; u < SU; u++) d[u] += lut[s * ks + cur[u].get(s)];
+                }
             }
         } else {
 #pragma unroll
@@ -1004,7 +1023,14 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
                 const int64_t i = seg + u * NT + tid;
                 const CodeT *cp = codes + (size_t)(i < c1 ? i : c1 - 1) * m;
                 double a = 0.0;
-                for (int s = 0; s < m; s++) a += lut[s * ks + (int)cp[s]];
+                if constexpr (SDC) {
+                    for (int s = 0; s < m; s++) {
+                        const double *tt = TT + ((size_t)s * ks + (int)cp[s]) * P.dsub;
+                        for (int t = 0; t < P.dsub; t++) a += tt[t];
+                    }
+                } else {
+                    for (int s = 0; s < m; s++) a += lut[s * ks + (int)cp[s]];
+                }
                 d[u] = a;
             }
         }
@@ -1973,7 +1999,7 @@ struct TieParams {
     int k;
 };
 
-template <typename CodeT>
+template <typename CodeT, bool SDC>
 __global__ __launch_bounds__(MMIDX_BLOCK) void k_tie_resolve(const TieParams TP) {
     const ScanParams &P = TP.S;
     const int q = blockIdx.x, tid = threadIdx.x, k = TP.k;
@@ -2009,8 +2035,13 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_tie_resolve(const TieParams TP)
             const int64_t len = P.list_off[cell + 1] - beg;
             if (len == 0) continue;
             __syncthreads();
-            const double *tr = query_vector(P, q, cell, vec);
-            build_lut_any(lut, tr, P.pqT, m, ks, P.dsub);
+            const double *TT = nullptr;
+            if constexpr (SDC) {
+                TT = P.sdc_tt + (size_t)q * m * ks * P.dsub;
+            } else {
+                const double *tr = query_vector(P, q, cell, vec);
+                build_lut_any(lut, tr, P.pqT, m, ks, P.dsub);
+            }
             __syncthreads();
             const CodeT *codes = (const CodeT *)P.codes + (size_t)beg * m;
             for (int64_t base = 0; base < len && !done; base += MMIDX_BLOCK) {
@@ -2019,7 +2050,14 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_tie_resolve(const TieParams TP)
                 if (i < len) {
                     const CodeT *cp = codes + (size_t)i * m;
                     double a = 0.0;
-                    for (int s = 0; s < m; s++) a += lut[s * ks + (int)cp[s]];
+                    if constexpr (SDC) {
+                        for (int s = 0; s < m; s++) {
+                            const double *tt = TT + ((size_t)s * ks + (int)cp[s]) * P.dsub;
+                            for (int t = 0; t < P.dsub; t++) a += tt[t];
+                        }
+                    } else {
+                        for (int s = 0; s < m; s++) a += lut[s * ks + (int)cp[s]];
+                    }
                     const u64 key = dkey(a);
                     nonjunk = key <= tau;
                     tie = key == tau;
@@ -2493,4 +2531,21 @@ __global__ void k_T_import(const double *__restrict__ in, u64 *__restrict__ T, l
         const u64 k = dkey(v);
         if (k < T[e]) T[e] = k;
     }
+}
+
+// SDC term table of one query code: TT[q][s][a][t] = (pq[s][a][t] - pq[s][b_s][t])^2, b = stored code of the
+// vector with internal id iid (PQ.java:337-344; iid == position in the flat PQ index, PQ.java:303,318)
+template <typename CodeT>
+__global__ void k_sdc_terms(const double *__restrict__ pq, const CodeT *__restrict__ codes, const int32_t *__restrict__ qpos,
+                            double *__restrict__ TT, int m, int ks, int dsub, long long total) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const long long per = (long long)m * ks * dsub;
+    const int q = (int)(e / per);
+    const long long r = e - (long long)q * per;
+    const int s = (int)(r / ((long long)ks * dsub));
+    const int t = (int)(r % dsub);
+    const int b = (int)codes[(size_t)qpos[q] * m + s];
+    const double df = pq[r] - pq[((size_t)s * ks + b) * dsub + t];
+    TT[e] = df * df;
 }

@@ -247,10 +247,24 @@ class _PQBase(AbstractSearchStructure):
         n = int(counts[0])
         return iids[0, :n].copy(), dists[0, :n].copy()
 
+    def search_sdc_batch(self, k, iids):
+        """Batch form of computeNearestNeighborsInternal(k, int iid): PQ.computeKnnSDC, PQ.java:334-374."""
+        iids = np.ascontiguousarray(iids, np.int32)
+        nq = iids.shape[0]
+        out_i = np.full((nq, max(k, 1)), -1, np.int32)
+        out_d = np.full((nq, max(k, 1)), np.inf, np.float64)
+        cnt = np.zeros(nq, np.int32)
+        N.check(N.lib().mmidx_search_sdc(self._h, k, nq, iids.ctypes.data, out_i.ctypes.data, out_d.ctypes.data, cnt.ctypes.data))
+        return out_i, out_d, cnt
+
     def computeNearestNeighborsInternalById(self, k, iid):
-        # PQ.computeKnnSDC PQ.java:334-374 is a "next" row; IVFPQ's
-        # computeKnnIVFSDC returns null in the reference (IVFPQ.java:509-511).
-        raise MmidxError(N.ERR_UNSUPPORTED, "id queries (SDC) are not implemented on the GPU path yet")
+        # PQ: computeKnnSDC (PQ.java:334-374).  IVFPQ: computeKnnIVFSDC returns null in the reference
+        # (IVFPQ.java:509-511) -> the native call reports UNSUPPORTED.
+        if iid < 0:
+            raise MmidxError(N.ERR_INVALID_ARG, "Id does not exist!")
+        i, d, c = self.search_sdc_batch(k, np.array([iid], np.int32))
+        n = int(c[0])
+        return i[0, :n].copy(), d[0, :n].copy()
 
     def export(self):
         """List-major snapshot (list_off [nlists+1], iids [n], codes [n][m] stored form)."""

@@ -101,7 +101,15 @@ public class GpuPQ extends AbstractSearchStructure {
 	}
 
 	protected BoundedPriorityQueue<Result> computeNearestNeighborsInternal(int k, int iid) throws Exception {
-		throw new Exception("SDC search (PQ.java:334-374) is not offloaded yet"); // SURVEY section 8f
+		// PQ.computeKnnSDC, PQ.java:334-374
+		int[] iids = new int[k];
+		double[] dists = new double[k];
+		int[] count = new int[1];
+		MmidxNative.searchSdc(handle, k, 1, new int[] { iid }, iids, dists, count);
+		BoundedPriorityQueue<Result> nn = new BoundedPriorityQueue<Result>(new Result(), k);
+		for (int i = count[0] - 1; i >= 0; i--)
+			nn.offer(new Result(iids[i], dists[i]));
+		return nn;
 	}
 
 	private void loadIndexInMemory() throws Exception { // PQ.java:436-483

@@ -28,6 +28,10 @@ final class MmidxNative {
 	static native void search(long handle, int k, int nq, double[] queries, int[] iidOut, double[] distOut,
 			int[] countOut) throws Exception;
 
+	/** mmidx_search_sdc: queries are internal ids (PQ.computeKnnSDC, PQ.java:334-374) */
+	static native void searchSdc(long handle, int k, int nq, int[] queryIids, int[] iidOut, double[] distOut,
+			int[] countOut) throws Exception;
+
 	static native void listSizes(long handle, int[] out) throws Exception;
 
 	private MmidxNative() {

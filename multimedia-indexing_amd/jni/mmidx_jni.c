@@ -124,6 +124,22 @@ done:
     (*env)->ReleaseIntArrayElements(env, countOut, cc, 0);
 }
 
+JNIEXPORT void JNICALL Java_gr_iti_mklab_visual_datastructures_MmidxNative_searchSdc(
+    JNIEnv *env, jclass c, jlong h, jint k, jint nq, jintArray queryIids, jintArray iidOut, jdoubleArray distOut,
+    jintArray countOut) {
+    jint *q = (*env)->GetIntArrayElements(env, queryIids, NULL);
+    jint *ii = (*env)->GetIntArrayElements(env, iidOut, NULL);
+    jdouble *dd = (*env)->GetDoubleArrayElements(env, distOut, NULL);
+    jint *cc = (*env)->GetIntArrayElements(env, countOut, NULL);
+    (void)c;
+    CHECK(mmidx_search_sdc(H(h), k, nq, (const int32_t *)q, (int32_t *)ii, dd, (int32_t *)cc));
+done:
+    (*env)->ReleaseIntArrayElements(env, queryIids, q, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, iidOut, ii, 0);
+    (*env)->ReleaseDoubleArrayElements(env, distOut, dd, 0);
+    (*env)->ReleaseIntArrayElements(env, countOut, cc, 0);
+}
+
 JNIEXPORT void JNICALL Java_gr_iti_mklab_visual_datastructures_MmidxNative_listSizes(JNIEnv *env, jclass c, jlong h,
                                                                                       jintArray out) {
     jint *o = (*env)->GetIntArrayElements(env, out, NULL);

@@ -443,3 +443,45 @@ def test_snapshot_roundtrip(mi, oracle, tmp_path):
     assert b.indexVector("im5", p["base"][5]) is False  # duplicate id known after the reload
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("D,m,ks,n,k", [(32, 8, 256, 9000, 10), (128, 16, 256, 3000, 100), (24, 6, 64, 2000, 5), (16, 4, 16, 3000, 7)])
+def test_pq_sdc_by_internal_id(mi, oracle, D, m, ks, n, k):
+    """computeNearestNeighbors(k, internalId) on PQ = computeKnnSDC (PQ.java:334-374): code-to-code
+    distances as ONE sequential fp64 chain over all D dimensions.  The last case has few distinct
+    codes -> heavy exact ties (the query's own duplicates at distance 0 included)."""
+    p = synth.make_pq_problem(n=2000, D=D, m=m, ks=ks, nq=4, seed=n)
+    if ks == 16:
+        base, _ = synth.mixture(n, D, 6, sigma=0.01, seed=3)
+    else:
+        base = np.random.default_rng(5).standard_normal((n, D))
+    ix = mi.PQ(D, n, False, "", m, ks, 0, 512)
+    ix.loadProductQuantizer(p["pq"])
+    ref = oracle.OracleIndex(oracle.KIND_PQ, D, m, ks)
+    ref.set_pq(p["pq"])
+    ix.indexVectors([str(i) for i in range(n)], base)
+    ref.add_vectors(base)
+    qi = np.array([0, 1, n // 2, n - 1, 17, 17, 3], np.int32)
+    iids, dists, cnt = ix.search_sdc_batch(k, qi)
+    for j, iid in enumerate(qi):
+        rid, rd = ref.search_sdc(int(iid), k)
+        assert cnt[j] == len(rid)
+        assert np.array_equal(iids[j, :cnt[j]], rid)
+        assert np.array_equal(dists[j, :cnt[j]], rd)
+    a_i, a_d = ix.computeNearestNeighborsInternalById(k, 17)
+    assert np.array_equal(a_i, iids[4, :cnt[4]]) and np.array_equal(a_d, dists[4, :cnt[4]])
+    ans = ix.computeNearestNeighbors(k, "17")  # ASS:320-333: id -> iid -> SDC
+    assert len(ans.getIds()) == cnt[4] and ans.getIds()[0] in [str(i) for i in iids[4, :cnt[4]]]
+    with pytest.raises(mi.MmidxError):
+        ix.search_sdc_batch(k, np.array([n], np.int32))
+    ix.close()
+    # IVFPQ: computeKnnIVFSDC is a stub returning null in the reference (IVFPQ.java:509-511)
+    pi = synth.make_ivfpq_problem(n=500, D=16, C=4, m=4, ks=16, nq=2, seed=1)
+    iv = mi.IVFPQ(16, 500, False, "", 4, 16, 0, 4, 512)
+    iv.loadCoarseQuantizer(pi["coarse"])
+    iv.loadProductQuantizer(pi["pq"])
+    iv.indexVectors([str(i) for i in range(500)], pi["base"])
+    with pytest.raises(mi.MmidxError) as ei:
+        iv.search_sdc_batch(3, np.array([0], np.int32))
+    assert ei.value.status == 10
+    iv.close()
