@@ -11,8 +11,10 @@ list scan -> top-k merge) over one batch of queries already resident in HBM.
 
 N > 1: one process per GPU; inverted lists are partitioned whole-list across ranks (cell mod N),
 queries are replicated, the coarse assignment is split across ranks and all-gathered, the
-per-shard top-(k+1) lists are all-gathered (RCCL over xGMI) and merged.  The index and the batch
-are the same for every N, so the scaling reported is "strong".
+per-shard top-(k+1) lists are sent to the query's owner rank (RCCL all-to-all over xGMI) and merged
+there.  The index is the same 100M vectors for every N; the query batch per step is `--batch` x N
+(each rank scans its 1/N of the lists for N x as many queries), so the work per GPU per step is
+fixed and the scaling reported is "weak"; `--global-batch B` pins the batch instead ("strong").
 
 The JSON line carries `roofline` (dominant kernel = k_scan, algorithmic bytes = m x scanned codes,
 timed with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle -- a C restatement
@@ -67,6 +69,8 @@ def main():
     ap.add_argument("--m", type=int, default=16)
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--batch", type=int, default=16384)
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="queries per step over all ranks (default: --batch x n_gpus = fixed work per GPU)")
     ap.add_argument("--nbatches", type=int, default=4)
     ap.add_argument("--chunk", type=int, default=2_000_000)
     ap.add_argument("--gt", type=int, default=1024, help="queries with exact ground truth (recall@1)")
@@ -74,10 +78,18 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--exhaustive-steps", type=int, default=3,
                     help="extra untimed-for-value steps with pruning off, reported as roofline_exhaustive (0 = skip)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
+                    help="mmidx_set_option(NAME, INT) on the index before the timed steps (kernel A/B switches)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path (encode -> owner filter -> add_codes, two-phase shard search, "
                          "merge) even with one rank: exercises it on a single GPU")
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line: everything else that writes to fd 1 (RCCL prints its
+    # version banner there) is routed to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch
 
@@ -95,12 +107,15 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or (args.force_sharded and "MASTER_ADDR" in os.environ):
+        # (--force-sharded under torch.distributed.run with one rank: the RCCL calls run on a 1-rank group)
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=dev)
 
-    N, D, Cc, w, m, k, B = args.n, args.dim, args.cells, args.w, args.m, args.k, args.batch
+    N, D, Cc, w, m, k = args.n, args.dim, args.cells, args.w, args.m, args.k
+    B = args.global_batch if args.global_batch > 0 else args.batch * world
+    scaling = "strong" if args.global_batch > 0 else "weak"
     ks, dsub, K1 = 256, D // m, args.k + 1
     f64 = torch.float64
     stream = torch.cuda.current_stream().cuda_stream
@@ -144,6 +159,9 @@ def main():
     chk(L.mmidx_set_coarse(h, coarse_h.ctypes.data))
     chk(L.mmidx_set_pq(h, pq_h.ctypes.data))
     chk(L.mmidx_set_w(h, w))
+    for o_ in args.opt:
+        name_, val_ = o_.split("=")
+        chk(L.mmidx_set_option(h, name_.encode(), int(val_)))
 
     sh_owner = importlib.import_module("multimedia-indexing_amd.sharded").owner_of_cell
     nq_total = B * args.nbatches
@@ -218,16 +236,17 @@ def main():
     sharded = None
     if world > 1 or args.force_sharded:
         sh = importlib.import_module("multimedia-indexing_amd.sharded")
-        sharded = sh.ShardedIVFPQ(sh.HipShardEngine(h, D, w, local), rank, world, dist=dist)
+        sharded = sh.ShardedIVFPQ(sh.HipShardEngine(h, D, w, local), rank, world, dist=dist, force_collectives=args.force_sharded)
 
     def step(Qx):
         if sharded is None:
             chk(L.mmidx_search_device(h, k, B, Qx.data_ptr(), iid_out.data_ptr(), dist_out.data_ptr(), cnt_out.data_ptr(), stream))
             return
-        i_, d_, c_ = sharded.search(k, Qx)
-        iid_out.copy_(i_)
-        dist_out.copy_(d_)
-        cnt_out.copy_(c_)
+        # results stay on the rank that owns the query slice (rank r: queries [r*B/N, (r+1)*B/N))
+        i_, d_, c_ = sharded.search(k, Qx, gather=False)
+        iid_out[:i_.shape[0]].copy_(i_)
+        dist_out[:i_.shape[0]].copy_(d_)
+        cnt_out[:i_.shape[0]].copy_(c_)
 
     def barrier():
         torch.cuda.synchronize()
@@ -307,7 +326,8 @@ def main():
                         "Smin >= T) and L2 reuse make it exceed the physical HBM rate: see traffic and DESIGN.md section 7",
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(scan_ms, 4),
                 "bytes_per_query": alg_bytes / B, "scan_launches": int(st.scan_launches),
-                "coarse_ms_per_step": round(st.coarse_ms / launches, 4), "merge_ms_per_step": round(st.merge_ms / launches, 4)}
+                "coarse_ms_per_step": round(st.coarse_ms / max(1, args.steps), 4),
+                "merge_ms_per_step": round(st.merge_ms / max(1, args.steps), 4)}
 
     # ---------------------------------------------------------------- CPU baseline + parity gate
     cpu_baseline, parity = None, None
@@ -349,15 +369,16 @@ def main():
         out = {
             "metric": "queries/sec @ recall@1, IVFPQ 100Mx128-d nprobe=32",
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"IVFPQ {N}x{D}-d, {Cc} coarse cells, nprobe w={w}, m={m}x{ks}, k={k}, batch {B} queries/step",
-                       "n": N, "dim": D, "cells": Cc, "nprobe": w, "m": m, "ks": ks, "k": k, "batch": B,
-                       "sharding": "single GPU" if world == 1 else f"whole inverted lists, cell mod {world}; RCCL all-gather top-k merge"},
+                       "n": N, "dim": D, "cells": Cc, "nprobe": w, "m": m, "ks": ks, "k": k, "batch": B, "batch_per_gpu": B // world,
+                       "sharding": "single GPU" if world == 1 else f"whole inverted lists, cell mod {world}; RCCL: all-gather probe cells, MIN all-reduce thresholds, "
+                                                                      f"all-to-all partial top-k to the query's owner rank, merge there"},
             "recall_at_1": recall1, "recall_queries": ngt,
             "roofline": roofline, "roofline_exhaustive": exhaustive, "cpu_baseline": cpu_baseline, "parity": parity,
         }
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     chk(L.mmidx_destroy(h))
     if dist is not None:
         dist.barrier()

@@ -10,7 +10,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libmmidx_hip.so")
+# MMIDX_LIB selects another build of the same library (kernel A/B experiments on the GPU box)
+SO_PATH = os.environ.get("MMIDX_LIB") or os.path.join(CSRC, "libmmidx_hip.so")
 
 OK = 0
 STATUS_NAMES = {

@@ -101,6 +101,8 @@ struct mmidx_index {
     bool no_bound = false;   // MMIDX_NO_BOUND=1: no coarse-bound pruning of probes
     bool debug_sync = false; // MMIDX_DEBUG_SYNC=1
     bool passa_512 = false;  // MMIDX_PASSA_512=1: pass A with 512-thread blocks
+    int passa_hist = -1;     // MMIDX_PASSA_HIST: 1 = always use K3h in pass A, 0 = never, -1 = lists of >= 4096 codes on average
+    int passa_prefix = 0;    // MMIDX_PASSA_PREFIX=n: pass A scans n codes exactly, the rest of the list filtered
     bool passa_su2 = false;  // MMIDX_PASSA_SU2=1: pass A with 2 codes per thread per segment (A/B switch)
     bool passa_filter = false;  // MMIDX_PASSA_FILTER=1
     bool no_seed = true;        // MMIDX_SEED=1: pass A with the seeded scan K3s (measured slower than K3: 1.45 vs 1.22 ms
@@ -130,6 +132,7 @@ struct mmidx_index {
     void *d_pcodes = nullptr;
 
     // workspaces
+    DevBuf<int32_t> ws_fb;
     DevBuf<double> ws_Q, ws_cdist, ws_odist, ws_X, ws_Xa, ws_qn, ws_cdsel, ws_sdc;
     DevBuf<float> ws_Q32, ws_S;
     DevBuf<int32_t> ws_cells, ws_oiid, ws_ocnt, ws_flag, ws_ecell, ws_pcount, ws_pstart, ws_pcursor, ws_order;
@@ -422,7 +425,8 @@ int make_plan(mmidx_index *h, int k, int64_t nq, SearchPlan &pl) {
     pl.nchunks = (int)((maxlen + chunk - 1) / chunk);
     pl.nitems = nprobe * pl.nchunks;
     // a work item emits at most K1 survivors, but no query can emit more than its candidates
-    int64_t poolq = (int64_t)pl.nitems * pl.K1;
+    // (+ MMIDX_HKEEP: a K3h pass-A item may emit up to MMIDX_HKEEP entries instead of K1)
+    int64_t poolq = (int64_t)pl.nitems * pl.K1 + MMIDX_HKEEP;
     pl.poolq = (int)std::min<int64_t>(poolq, std::max<int64_t>(h->n_csr, pl.K1));
     // sub-batch so that the pool and the coarse distance matrix stay <= 2 GiB each
     int64_t qb = std::min<int64_t>(nq, (int64_t)(1 << 30) / std::max(nprobe, 1));
@@ -466,6 +470,57 @@ int launch_seed_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t st) {
     return MMIDX_OK;
 }
 
+template <int M>
+int launch_hist_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t st) {
+    HIPCK(hipFuncSetAttribute((const void *)k_scan_hist<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_scan_hist<M>), grid, dim3(MMIDX_BLOCK), lds, st, P);
+    HIPCK(hipGetLastError());
+    return MMIDX_OK;
+}
+
+// pass A over long lists: histogram-thresholded exact scan (K3h) + a K3 launch over the items it hands back.
+// Returns 1 when K3h does not apply (the caller uses K3).
+int launch_scan_hist(mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 grid, hipStream_t st) {
+    const bool ok = h->code_bytes == 1 && (h->m == 8 || h->m == 16 || h->m == 32) && !P.sdc_tt && pl.K1 <= MMIDX_HKEEP &&
+                    !P.order && !P.xcd_remap;
+    if (!ok) return 1;
+    const size_t fixed = (size_t)h->m * h->ks * 8 + (h->transform ? 2 : 1) * (size_t)h->D * 8 + 64 + 16 + MMIDX_HB * 4 + 16;
+    // position buffer: what is left of a quarter of the CU's LDS (4 blocks per CU), within [768, 1536] entries
+    int64_t room = (int64_t)(160 * 1024 / 4) - 256 - (int64_t)fixed;
+    int cap = (int)std::min<int64_t>(4096, std::max<int64_t>(768, room / 4));
+    const size_t lds = fixed + (size_t)cap * 4;
+    if (lds > 64 * 1024) return 1;
+    const size_t nfb = (size_t)grid.x * grid.y;
+    HIPCK(h->ws_fb.reserve(2 * nfb + 4));
+    HIPCK(hipMemsetAsync(h->ws_fb.p, 0, 4 * sizeof(int32_t), st));
+    P.cap = cap;
+    P.fb_count = (u32 *)h->ws_fb.p;
+    P.fb_items = h->ws_fb.p + 4;
+    P.fb_ch = h->ws_fb.p + 4 + nfb;
+    int rc;
+    switch (h->m) {
+        case 8: rc = launch_hist_t<8>(P, grid, lds, st); break;
+        case 16: rc = launch_hist_t<16>(P, grid, lds, st); break;
+        default: rc = launch_hist_t<32>(P, grid, lds, st); break;
+    }
+    if (rc) return rc;
+    if (h->debug_sync) {
+        int32_t c4[4];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(c4, h->ws_fb.p, sizeof(c4), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[mmidx] K3h: %d of %zu items handed back to K3 (> %d entries under the final bucket; cap %d, lds %zu)\n", c4[0], nfb,
+                MMIDX_HKEEP, cap, lds);
+    }
+    // the handed-back items (device-side count; normally none: the blocks exit at once)
+    ScanParams F = P;
+    F.cap = pl.cap;
+    F.order = P.fb_items;
+    F.n_order = (const int32_t *)P.fb_count;
+    F.order_ch = P.ivf ? P.fb_ch : nullptr;
+    F.n_items = (int)nfb;
+    return launch_scan(h, F, dim3((unsigned)nfb, 1), pl.lds, st);
+}
+
 // pass A: seeded scan (exact sample -> histogram of u8 lower bounds -> exact verify) where it applies
 int launch_scan_seeded(const mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 grid, hipStream_t st) {
     const bool ok = h->code_bytes == 1 && h->ks <= 256 && (h->m == 8 || h->m == 16 || h->m == 32) && !h->no_filter &&
@@ -489,7 +544,7 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
     HIPCK(h->ws_cdist.reserve((size_t)nq * h->C));
     h->cdsel_valid = false;
     const size_t alds = (size_t)MMIDX_CSEL_CAP * 12 + (size_t)(h->w + 1) * 8 + (size_t)((h->w + 2) & ~1) * 4 +
-                        (size_t)MMIDX_CAND_CHUNK * h->D * 8 + 16;
+                        (size_t)MMIDX_CAND_CHUNK * (h->D + MMIDX_TERM_PAD) * 8 + 16;
     const bool approx = !h->exact_coarse && h->C >= MMIDX_BLOCK && h->w + 1 <= MMIDX_BLOCK && h->C <= 64 * MMIDX_BLOCK &&
                         h->w >= 1 && alds <= 64 * 1024;
     if (approx) {
@@ -622,6 +677,8 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
     P.transform = h->transform;
     P.ivf = ivf;
     P.chunk = pl.chunk;
+    P.code_lo = 0;
+    P.code_hi = 0x7fffffff;
     P.K1 = pl.K1;
     P.cap = pl.cap;
     P.poolq = pl.poolq;
@@ -648,7 +705,12 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
                 rc = launch_scan_filtered(h, P, pl, dim3((unsigned)P.n_items, (unsigned)grid_chunks), st);
             } else if (!h->no_seed) {
                 rc = launch_scan_seeded(h, P, pl, dim3((unsigned)P.n_items, (unsigned)grid_chunks), st);
+            } else if (two_pass && !sdc_tt && h->passa_hist != 0 &&
+                       (h->passa_hist > 0 || h->n_csr / std::max<int64_t>(1, ivf ? h->C : 1) >= 4096) &&
+                       (rc = launch_scan_hist(h, P, pl, dim3((unsigned)P.n_items, (unsigned)grid_chunks), st)) != 1) {
+                // (K3h ran -- its empty fallback launch is not counted as a scan launch -- or failed with rc > 1)
             } else {
+                rc = MMIDX_OK;
                 // one code per thread per segment: smaller candidate buffer -> a fourth block per CU
                 ScanParams PA = P;
                 int su = 2;
@@ -661,7 +723,19 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
                     lds_a = scan_lds_bytes(h, cap1);
                     su = h->passa_512 ? 11 : 1;
                 }
+                // prefix mode: the exact scan (LDS-bound fp64 gather) covers only the first passa_prefix
+                // codes of the nearest list -- enough for a useful threshold -- and the rest of that
+                // list goes through the filtered scan under it
+                const bool prefix = two_pass && ivf && h->passa_prefix > 0 && !sdc_tt;
+                if (prefix) PA.code_hi = h->passa_prefix;
                 rc = launch_scan(h, PA, dim3((unsigned)P.n_items, (unsigned)grid_chunks), lds_a, st, su);
+                if (rc) return rc;
+                if (prefix) {
+                    ScanParams PR = P;
+                    PR.code_lo = h->passa_prefix;
+                    rc = launch_scan_filtered(h, PR, pl, dim3((unsigned)P.n_items, (unsigned)grid_chunks), st);
+                    if (prof) h->launches += 1;
+                }
             }
             if (rc) return rc;
             DBG_SYNC("pass A scan");
@@ -706,6 +780,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
             PB.T = h->ws_T.p;
             PB.cdsel = (ivf && !d_cells_in && h->cdsel_valid) ? h->ws_cdsel.p : nullptr;
             PB.cdist = (ivf && !d_cells_in && !h->cdsel_valid) ? h->ws_cdist.p : nullptr;
+            PB.list_off = h->d_off;
             PB.rmax = h->rmax;
             PB.D = h->D;
             PB.C = h->C;
@@ -929,6 +1004,10 @@ int mmidx_create(int kind, int D, int m, int ks, int C, int transform, const int
         h->passa_512 = p5 && p5[0] == '1';
         const char *p2 = getenv("MMIDX_PASSA_SU2");
         h->passa_su2 = p2 && p2[0] == '1';
+        const char *ph = getenv("MMIDX_PASSA_HIST");
+        if (ph) h->passa_hist = atoi(ph);
+        const char *pp = getenv("MMIDX_PASSA_PREFIX");
+        if (pp) h->passa_prefix = atoi(pp);
         const char *pf = getenv("MMIDX_PASSA_FILTER");
         h->passa_filter = pf && pf[0] == '1';
         const char *nsd = getenv("MMIDX_SEED");
@@ -953,6 +1032,7 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_qn.release();
     h->ws_Xa.release();
     h->ws_sdc.release();
+    h->ws_fb.release();
     h->ws_cdsel.release();
     h->ws_Q32.release();
     h->ws_S.release();
@@ -1428,6 +1508,10 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->no_bound = value != 0;
     } else if (n == "exact_coarse") {
         h->exact_coarse = value != 0;
+    } else if (n == "passa_hist") {
+        h->passa_hist = value;
+    } else if (n == "passa_prefix") {
+        h->passa_prefix = value > 0 ? value : 0;
     } else {
         return fail(MMIDX_ERR_INVALID_ARG, "unknown option '%s'", name);
     }

@@ -252,7 +252,21 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_reg(const double 
 // kernels -- the sorted head by (distance, index) -- so the tie rule in coarse_emit is unchanged.
 // If the gather overflows (massive ties) the round-based selection runs on the registers instead.
 #define MMIDX_CSEL_CAP 1024
+#ifndef MMIDX_CAND_CHUNK
 #define MMIDX_CAND_CHUNK 16
+#endif
+#ifndef MMIDX_HIST_STOP
+#define MMIDX_HIST_STOP 0  // debug: truncate k_scan_hist (1 = after the scan loop, 2 = before the final sort)
+#endif
+#ifndef MMIDX_SCAN_STOP
+#define MMIDX_SCAN_STOP 0  // debug: truncate k_scan (1 = after the LUT build, 2 = no candidate handling)
+#endif
+#ifndef MMIDX_SEL_STOP
+#define MMIDX_SEL_STOP 0  // debug: truncate k_coarse_select_approx after phase n (timing breakdown)
+#endif
+#ifndef MMIDX_TERM_PAD
+#define MMIDX_TERM_PAD 1  // row stride D + 1 doubles: the per-candidate sequential sums read LDS conflict-free
+#endif
 template <int PER>
 __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_fast(const double *__restrict__ dist, int C, int w,
                                                                     int32_t *__restrict__ cells) {
@@ -524,6 +538,10 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_approx(const Appr
         dt[i] = v;
         lmin = v < lmin ? v : lmin;
     }
+#if MMIDX_SEL_STOP == 1
+    if (lmin < -1.0f) A.cells[(size_t)q * w] = tid;
+    return;
+#endif
     // tau: (R-th smallest per-thread minimum of d~) + eps >= the R-th smallest upper bound d~ + eps
     // R-th smallest of the 256 minima by rank counting (one barrier instead of a 36-stage sort)
     float *fmin = (float *)ckey;
@@ -543,6 +561,10 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_approx(const Appr
     __syncthreads();
     const double tau = keyd(sel_k[0]) + eps;
     __syncthreads();
+#if MMIDX_SEL_STOP == 2
+    if (tau < -1.0) A.cells[(size_t)q * w] = tid;
+    return;
+#endif
     const u64 lane_lt = (1ull << (tid & 63)) - 1ull;
     const double cut = tau + eps;  // candidate iff d~ - eps <= tau
 #pragma unroll
@@ -564,6 +586,10 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_approx(const Appr
     __syncthreads();
     const int n = (int)s_n;
     const double *qv = A.Q + (size_t)q * D;
+#if MMIDX_SEL_STOP == 3
+    if (tid == 0) A.cells[(size_t)q * w] = n + (int)cidx[0];
+    return;
+#endif
     if (n <= MMIDX_CSEL_CAP) {
         // exact fp64 distance of every candidate in the reference's order (IVFPQ.java:583).  The
         // per-dimension terms (c_j - q_j)^2 are independent and are computed by all threads with
@@ -590,13 +616,14 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_approx(const Appr
                     const int e = e0 + u * MMIDX_BLOCK + tid;
                     if (e < nc_ * D) {
                         const double df = cv[u] - qq[u];
-                        terms[e] = df * df;
+                        const int ci = e / D;
+                        terms[e + ci * MMIDX_TERM_PAD] = df * df;
                     }
                 }
             }
             __syncthreads();
             if (tid < nc_) {
-                const double *tt = terms + (size_t)tid * D;
+                const double *tt = terms + (size_t)tid * (D + MMIDX_TERM_PAD);
                 double acc = 0.0;
                 int j = 0;
                 for (; j + 16 <= D; j += 16) {  // 16 LDS reads in flight, then the ordered adds
@@ -611,6 +638,10 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_approx(const Appr
             }
             __syncthreads();
         }
+#if MMIDX_SEL_STOP == 4
+        if (tid == 0) A.cdsel[(size_t)q * w] = keyd(ckey[0]);
+        return;
+#endif
         const int Pn = pow2ceil(n < 2 ? 2 : n);
         for (int i = n + tid; i < Pn; i += MMIDX_BLOCK) {
             ckey[i] = MMIDX_KEY_MAX;
@@ -622,6 +653,10 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_approx(const Appr
             sel_i[i] = (int)cidx[i];
         }
         __syncthreads();
+#if MMIDX_SEL_STOP == 5
+        if (tid == 0) A.cdsel[(size_t)q * w] = keyd(sel_k[0]);
+        return;
+#endif
         if (tid == 0) {
             int32_t *out = A.cells + (size_t)q * w;
             double *dout = A.cdsel + (size_t)q * w;
@@ -759,6 +794,10 @@ struct ScanParams {
     int rank_lo, nrank;      // natural order: item -> (q = item / nrank, rank = rank_lo + item % nrank)
     int xcd_remap;           // 1: consecutive items -> same XCD
     int chunk;               // codes per work item
+    const int32_t *order_ch; // with `order`: chunk of each item (fallback launches), else null = blockIdx.y
+    u32 *fb_count;           // K3h: items handed back to K3
+    int32_t *fb_items, *fb_ch;
+    int code_lo, code_hi;    // only list positions [code_lo, code_hi) are scanned by this launch (pass A prefix / remainder)
     int K1;                  // k + 1
     int cap;                 // LDS candidate capacity (>= K1 + SEG, power of two)
     int poolq;
@@ -950,7 +989,7 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
         q = item / P.nrank;
         pr = P.rank_lo + (item - q * P.nrank);
     }
-    const int ch = P.ivf ? (int)blockIdx.y : pr;  // flat PQ: the item rank is the chunk of the single list
+    const int ch = P.order_ch ? P.order_ch[item] : (P.ivf ? (int)blockIdx.y : pr);  // flat PQ: the item rank is the chunk of the single list
     int cell = 0;
     if (P.ivf) {
         cell = P.cells[(size_t)q * P.w + pr];
@@ -958,9 +997,12 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
     }
     const int64_t beg = P.list_off[cell];
     const int64_t len = P.list_off[cell + 1] - beg;
-    const int64_t c0 = (int64_t)ch * P.chunk;
+    int64_t c0 = (int64_t)ch * P.chunk;
     if (c0 >= len) return;
-    const int64_t c1 = (c0 + P.chunk < len) ? c0 + P.chunk : len;
+    int64_t c1 = (c0 + P.chunk < len) ? c0 + P.chunk : len;
+    c0 = c0 < (int64_t)P.code_lo ? (int64_t)P.code_lo : c0;
+    c1 = c1 > (int64_t)P.code_hi ? (int64_t)P.code_hi : c1;
+    if (c0 >= c1) return;
     const int tid = threadIdx.x;
     const CodeT *codes = (const CodeT *)P.codes + (size_t)beg * m;
 
@@ -985,6 +1027,10 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
     u64 *Tq = P.T + q;
     u64 T = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+#if MMIDX_SCAN_STOP == 1
+    if (lut[tid] < -1.0) P.pool_cnt[q] = cur[0].get(0);
+    return;
+#endif
 
     // ---- scan -----------------------------------------------------------------------------------
     const int limit = P.cap - NT * SU;
@@ -1034,6 +1080,16 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
                 d[u] = a;
             }
         }
+#if MMIDX_SCAN_STOP == 2
+        if (d[0] < -1.0) P.pool_cnt[q] = 1;
+        if constexpr (M > 0) {
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < SU; u++) cur[u] = nxt[u];
+            }
+        }
+        continue;
+#endif
 #pragma unroll
         for (int u = 0; u < SU; u++) {
             const int64_t i = seg + u * NT + tid;
@@ -1088,6 +1144,319 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
                 }
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3h: pass A without a sorted candidate buffer (byte codes, long lists).
+//
+// In K3 the bookkeeping around the gather -- two block barriers per 256-code segment to agree on
+// "buffer full?", and a 45-stage bitonic sort of the 512-slot buffer every ~150 accepted candidates
+// -- costs more than the gather itself (measured on cfg4: 1.97 ms per 16384 lists, of which the
+// table build is 0.25 ms and the lookups 0.52 ms).  K3h keeps the same exact fp64 sums but decides
+// "could this code still be among the K1 best of the list?" with a histogram instead of a sort:
+//
+//   * segment 0 fixes a monotone map d -> bucket (MMIDX_HB uniform buckets over
+//     [min0 - 0.4 (q40 - min0), q40 + 0.1 (q40 - min0)), clamped; min0 / q40 = minimum and ~40 %
+//     quantile of the first 256 distances) -- the region where the K1 smallest of a long list end up;
+//   * a code is a candidate iff bucket(d) <= Tb, the wave's current threshold bucket; candidates
+//     bump hist[bucket] and append their list position (4 bytes) to a shared buffer;
+//   * every few segments each wave recomputes Tb = the first bucket whose cumulative count reaches
+//     K1 (a 256-entry prefix sum inside the wave).  Tb only decreases, so every code whose bucket is
+//     <= the final Tb was appended, whatever the interleaving of the waves: NO barrier in the loop;
+//   * at the end (one barrier) the final Tb is read off the complete histogram, the appended
+//     positions are re-evaluated (exact sum again, same order -> same bits) and the entries with
+//     bucket <= Tb -- at least K1, at most MMIDX_HKEEP, typically K1 + 2 -- go to the query's pool;
+//     the largest of them is the published threshold.  No sort anywhere.
+//
+// A position buffer overflow costs a second pass over the list inside the block (the histogram is
+// complete regardless).  Degenerate lists (more than 256 entries under the final Tb: massive
+// ties, or a segment 0 that is not representative) are not handled here: the item is appended to a
+// fallback list and a K3 launch over that list redoes it, so results never depend on the heuristics.
+// ------------------------------------------------------------------------------------------------
+#define MMIDX_HB 256
+#define MMIDX_HKEEP 256  // most entries one item may emit (>= K1 required: the host checks; the pool has room for them)
+#define MMIDX_HPOS 4     // appended positions re-evaluated per thread per round at the end
+
+template <int M>
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NT = MMIDX_BLOCK;
+    const int ks = P.ks, D = P.D;
+    double *lut = (double *)smem;                                        // [M*ks]
+    double *vec = lut + (size_t)M * ks;                                  // [D] or [2D]
+    double *s_red = vec + (P.transform ? 2 : 1) * (size_t)D;             // [8] wave minima / maxima of segment 0
+    u32 *hist = (u32 *)(((uintptr_t)(s_red + 8) + 15) & ~(uintptr_t)15);  // [HB] (16-byte aligned: read as uint4)
+    u32 *s_cnt = hist + MMIDX_HB;                                        // [4]: 0 appended, 1 overflow, 2-3 largest kept key (u64)
+    u32 *posbuf = s_cnt + 4;                                             // [cap] list positions
+
+    int item = blockIdx.x;
+    if (item >= P.n_items) return;
+    const int q = item / P.nrank;
+    const int pr = P.rank_lo + (item - q * P.nrank);
+    const int ch = P.ivf ? (int)blockIdx.y : pr;
+    int cell = 0;
+    if (P.ivf) {
+        cell = P.cells[(size_t)q * P.w + pr];
+        if (cell < 0) return;
+    }
+    const int64_t beg = P.list_off[cell];
+    const int64_t len = P.list_off[cell + 1] - beg;
+    int64_t c0 = (int64_t)ch * P.chunk;
+    if (c0 >= len) return;
+    int64_t c1 = (c0 + P.chunk < len) ? c0 + P.chunk : len;
+    c0 = c0 < (int64_t)P.code_lo ? (int64_t)P.code_lo : c0;
+    c1 = c1 > (int64_t)P.code_hi ? (int64_t)P.code_hi : c1;
+    if (c0 >= c1) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned char *codes = (const unsigned char *)P.codes + (size_t)beg * M;
+
+    CodeVec<M, unsigned char> cur, nxt;
+    {
+        const int64_t i = c0 + tid;
+        cur.load(codes + (size_t)(i < c1 ? i : c1 - 1) * M);
+    }
+    for (int i = tid; i < MMIDX_HB + 4; i += NT) hist[i] = 0;  // histogram and the three counters
+    const double *tr = query_vector(P, q, cell, vec);
+    build_lut_any(lut, tr, P.pqT, M, ks, P.dsub);
+    __syncthreads();
+
+    auto exact = [&](const CodeVec<M, unsigned char> &cv) -> double {
+        double d = 0.0;
+#pragma unroll
+        for (int s = 0; s < M; s++) d += lut[s * ks + cv.get(s)];
+        return d;
+    };
+
+    // ---- segment 0: the bucket map -------------------------------------------------------------
+    // Robust to far outliers in the list (members of other clusters that were assigned to this cell):
+    // the scale is (q40 - min) of the first 256 distances, not their range.  q40 ~ the K1-th smallest
+    // of segment 0 for K1 ~ 100; each wave sorts its 64 values in registers and reports its 26th.
+    double d = exact(cur);
+    {
+        const double inf = __longlong_as_double(0x7FF0000000000000ll);
+        double v = (c0 + tid < c1) ? d : inf;
+#pragma unroll
+        for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                const double o = __shfl_xor(v, stride);
+                const bool up = (lane & size) == 0, low = (lane & stride) == 0;
+                const double mn_ = o < v ? o : v, mx_ = o < v ? v : o;
+                v = (up == low) ? mn_ : mx_;
+            }
+        }
+        const double wmin = __shfl(v, 0), wq = __shfl(v, 25);
+        if (lane == 0) {
+            s_red[wv] = wmin;
+            s_red[4 + wv] = wq;
+        }
+    }
+    __syncthreads();
+    double lo, inv;
+    {
+        const double inf = __longlong_as_double(0x7FF0000000000000ll);
+        double mn = s_red[0], q40 = s_red[4];
+#pragma unroll
+        for (int i = 1; i < NT / 64; i++) {
+            mn = s_red[i] < mn ? s_red[i] : mn;
+            q40 = s_red[4 + i] < q40 ? s_red[4 + i] : q40;  // the smallest finite estimate (short lists: some waves are empty)
+        }
+        if (!(q40 < inf)) q40 = mn;
+        const double span = q40 - mn;  // >= 0
+        lo = mn - 0.4 * span;
+        const double width = 1.5 * span;  // buckets cover [lo, q40 + 0.1 span); everything above clamps into the last
+        inv = (width > 0.0 && width < 1e300) ? (double)MMIDX_HB / width : 0.0;
+        if (!(inv < 1e300)) inv = 0.0;
+    }
+    // monotone in d: (d - lo) and the product by inv >= 0 are monotone, so is the truncation
+    auto bucket = [&](double dd) -> int {
+        const double x = (dd - lo) * inv;
+        return x >= (double)(MMIDX_HB - 1) ? MMIDX_HB - 1 : (x > 0.0 ? (int)x : 0);
+    };
+
+    // ---- scan: no block barrier ----------------------------------------------------------------
+    const u64 lane_lt = (1ull << lane) - 1ull;
+    int Tb = MMIDX_HB - 1;
+    int g = 0;
+    for (int64_t seg = c0; seg < c1; seg += NT, g++) {
+        const bool more = seg + NT < c1;
+        if (more) {
+            const int64_t i = seg + NT + tid;
+            nxt.load(codes + (size_t)(i < c1 ? i : c1 - 1) * M);
+        }
+        if (g > 0) d = exact(cur);
+        const int64_t i = seg + tid;
+        const int b = bucket(d);
+        const bool pass = (i < c1) && b <= Tb;
+        const u64 mask = __ballot(pass);
+        if (mask) {
+            u32 base = 0;
+            const int leader = __ffsll((long long)mask) - 1;
+            if (lane == leader) base = atomicAdd(s_cnt, (u32)__popcll(mask));
+            base = __shfl(base, leader);
+            if (pass) {
+                atomicAdd(hist + b, 1u);
+                const u32 slot = base + (u32)__popcll(mask & lane_lt);
+                if (slot < (u32)P.cap) posbuf[slot] = (u32)i;
+                else s_cnt[1] = 1;
+            }
+        }
+        // refresh the threshold bucket after segments 1, 2, 4, 8 and then every 8th
+        const int gn = g + 1;
+        if ((gn & g) == 0 || (gn & 7) == 0) {
+            const uint4 hv = ((const uint4 *)hist)[lane];  // buckets 4*lane .. 4*lane+3 (own atomics are ordered before this read)
+            const u32 own = hv.x + hv.y + hv.z + hv.w;
+            u32 incl = own;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const u32 o = __shfl_up(incl, off);
+                if (lane >= off) incl += o;
+            }
+            const u32 excl = incl - own;
+            int cand = MMIDX_HB - 1;
+            if (excl < (u32)P.K1 && incl >= (u32)P.K1) {
+                u32 c = excl + hv.x;
+                cand = 4 * lane;
+                if (c < (u32)P.K1) { c += hv.y; cand++; }
+                if (c < (u32)P.K1) { c += hv.z; cand++; }
+                if (c < (u32)P.K1) { cand++; }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const int o = __shfl_xor(cand, off);
+                cand = o < cand ? o : cand;
+            }
+            Tb = cand < Tb ? cand : Tb;
+        }
+        if (more) cur = nxt;
+    }
+    __syncthreads();
+
+#if MMIDX_HIST_STOP == 1
+    if (Tb < -1) P.pool_cnt[q] = 1;
+    return;
+#endif
+    // ---- final threshold bucket from the complete histogram (identical in every wave) ------------
+    u32 kept_total;
+    {
+        const uint4 hv = ((const uint4 *)hist)[lane];
+        const u32 own = hv.x + hv.y + hv.z + hv.w;
+        u32 incl = own;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        const u32 excl = incl - own;
+        int cand = MMIDX_HB - 1;
+        u32 upto = 0xFFFFFFFFu;  // cumulative count including bucket cand
+        if (excl < (u32)P.K1 && incl >= (u32)P.K1) {
+            u32 c = excl + hv.x;
+            cand = 4 * lane;
+            if (c < (u32)P.K1) { c += hv.y; cand++; }
+            if (c < (u32)P.K1) { c += hv.z; cand++; }
+            if (c < (u32)P.K1) { c += hv.w; cand++; }
+            upto = c;
+        }
+        const u32 total = __shfl(incl, 63);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const int o = __shfl_xor(cand, off);
+            const u32 ou = __shfl_xor(upto, off);
+            cand = o < cand ? o : cand;
+            upto = ou < upto ? ou : upto;
+        }
+        Tb = cand;  // fewer than K1 candidates in all: every bucket counts
+        kept_total = (upto == 0xFFFFFFFFu) ? total : upto;
+    }
+    const u32 n_app = s_cnt[0];
+    const bool overflow = s_cnt[1] != 0 || n_app > (u32)P.cap;  // block-uniform (read after the barrier)
+    if (kept_total > (u32)MMIDX_HKEEP) {  // block-uniform: redo this item with K3
+        if (tid == 0) {
+            const u32 slot = atomicAdd(P.fb_count, 1u);
+            P.fb_items[slot] = q * P.w + pr;
+            P.fb_ch[slot] = ch;
+        }
+        return;
+    }
+    // Every entry under the final bucket goes to the query's pool (unordered; K4 sorts it) and the
+    // largest of them is published as the threshold: at least K1 list entries are <= it.  kept_total
+    // exceeds K1 by about half a bucket's population (~2 on cfg4), so the bound is as good as the exact
+    // K1-th smallest, without any sort.
+    u64 *Tq = P.T + q;
+    const u64 Tg = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // other chunks / shards may have published one
+    u64 kmax = 0;
+    auto keep_entry = [&](bool keep, double dd, u32 p) {
+        const u64 key = dkey(dd);
+        if (keep) kmax = key > kmax ? key : kmax;
+        const bool emit = keep && key <= Tg;
+        const u64 mask = __ballot(emit);
+        if (mask) {
+            u32 base = 0;
+            const int leader = __ffsll((long long)mask) - 1;
+            if (lane == leader) base = atomicAdd(P.pool_cnt + q, (u32)__popcll(mask));
+            base = __shfl(base, leader);
+            if (emit) {
+                const u32 slot = base + (u32)__popcll(mask & lane_lt);
+                if (slot < (u32)P.poolq) {
+                    P.pool_key[(size_t)q * P.poolq + slot] = key;
+                    P.pool_val[(size_t)q * P.poolq + slot] = ((u64)pr << 32) | (u64)p;
+                }
+            }
+        }
+    };
+    if (!overflow) {
+        // ---- re-evaluate the appended positions, keep those under the final bucket ----------------
+        for (u32 e0 = 0; e0 < n_app; e0 += MMIDX_HPOS * NT) {
+            u32 pos[MMIDX_HPOS];
+            CodeVec<M, unsigned char> cv[MMIDX_HPOS];
+#pragma unroll
+            for (int j = 0; j < MMIDX_HPOS; j++) {
+                const u32 e = e0 + (u32)(j * NT + tid);
+                pos[j] = e < n_app ? posbuf[e] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int j = 0; j < MMIDX_HPOS; j++)
+                if (e0 + (u32)(j * NT) < n_app) cv[j].load(codes + (size_t)(pos[j] != 0xFFFFFFFFu ? pos[j] : (u32)c0) * M);
+#pragma unroll
+            for (int j = 0; j < MMIDX_HPOS; j++) {
+                if (e0 + (u32)(j * NT) < n_app) {  // block-uniform
+                    const double dd = exact(cv[j]);
+                    keep_entry(pos[j] != 0xFFFFFFFFu && bucket(dd) <= Tb, dd, pos[j]);
+                }
+            }
+        }
+    } else {
+        // ---- the position buffer overflowed (the histogram is still complete): second pass over the
+        //      list with the final threshold bucket ------------------------------------------------
+        {
+            const int64_t i = c0 + tid;
+            cur.load(codes + (size_t)(i < c1 ? i : c1 - 1) * M);
+        }
+        for (int64_t seg = c0; seg < c1; seg += NT) {
+            const bool more = seg + NT < c1;
+            if (more) {
+                const int64_t i = seg + NT + tid;
+                nxt.load(codes + (size_t)(i < c1 ? i : c1 - 1) * M);
+            }
+            const double dd = exact(cur);
+            const int64_t i = seg + tid;
+            keep_entry((i < c1) && bucket(dd) <= Tb, dd, (u32)i);
+            if (more) cur = nxt;
+        }
+    }
+    // ---- threshold: the largest kept key, if the list had K1 entries at all ----------------------
+    if (kept_total >= (u32)P.K1) {  // block-uniform
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const u64 o = __shfl_xor(kmax, off);
+            kmax = o > kmax ? o : kmax;
+        }
+        u64 *s_max = (u64 *)(s_cnt + 2);  // zeroed with the histogram, 8-byte aligned
+        if (lane == 0) atomicMax(s_max, kmax);
+        __syncthreads();
+        if (tid == 0) atomicMin(Tq, *s_max);
     }
 }
 
@@ -1179,9 +1548,12 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_filt(const ScanParams P) {
     }
     const int64_t beg = P.list_off[cell];
     const int64_t len = P.list_off[cell + 1] - beg;
-    const int64_t c0 = (int64_t)ch * P.chunk;
+    int64_t c0 = (int64_t)ch * P.chunk;
     if (c0 >= len) return;
-    const int64_t c1 = (c0 + P.chunk < len) ? c0 + P.chunk : len;
+    int64_t c1 = (c0 + P.chunk < len) ? c0 + P.chunk : len;
+    c0 = c0 < (int64_t)P.code_lo ? (int64_t)P.code_lo : c0;
+    c1 = c1 > (int64_t)P.code_hi ? (int64_t)P.code_hi : c1;
+    if (c0 >= c1) return;
     const int tid = threadIdx.x;
     const unsigned char *codes = (const unsigned char *)P.codes + (size_t)beg * M;
     u64 *Tq = P.T + q;
@@ -1480,9 +1852,12 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_seed(const ScanParams P) {
     }
     const int64_t beg = P.list_off[cell];
     const int64_t len = P.list_off[cell + 1] - beg;
-    const int64_t c0 = (int64_t)ch * P.chunk;
+    int64_t c0 = (int64_t)ch * P.chunk;
     if (c0 >= len) return;
-    const int64_t c1 = (c0 + P.chunk < len) ? c0 + P.chunk : len;
+    int64_t c1 = (c0 + P.chunk < len) ? c0 + P.chunk : len;
+    c0 = c0 < (int64_t)P.code_lo ? (int64_t)P.code_lo : c0;
+    c1 = c1 > (int64_t)P.code_hi ? (int64_t)P.code_hi : c1;
+    if (c0 >= c1) return;
     const int clen = (int)(c1 - c0);
     const int tid = threadIdx.x;
     const unsigned char *codes = (const unsigned char *)P.codes + (size_t)(beg + c0) * M;  // chunk-relative
@@ -1748,6 +2123,7 @@ struct PairBound {
     const u64 *T;          // [nq]
     const double *cdist;   // [nq][C] coarse distances when this process computed them, else null
     const double *cdsel;   // [nq][w] exact distances of the selected cells (approximate coarse path), else null
+    const int64_t *list_off;  // [C+1] pairs whose list is empty here (other shards' lists) are dropped
     double rmax;           // sqrt(sum_s max_j ||pq[s][j]||^2) * (1 + 1e-12)
     int D, C;
     int enabled;
@@ -1757,6 +2133,7 @@ struct PairBound {
 // dword on the lanes that had returned early (memory aperture violation).
 __device__ __forceinline__ bool pair_keep(const PairBound &B, long long e, int q, int c) {
     const u64 T = B.T[q];
+    const bool nonempty = B.list_off[c + 1] > B.list_off[c];
     double cd = 0.0;
     if (B.cdsel) {  // K1d left the exact distance of every selected cell, in probe order
         cd = B.cdsel[e];
@@ -1764,7 +2141,8 @@ __device__ __forceinline__ bool pair_keep(const PairBound &B, long long e, int q
         cd = B.cdist[(size_t)q * B.C + c];
     } else {
         const double *cc = B.coarse + (size_t)c * B.D, *qq = B.Q + (size_t)q * B.D;
-        for (int j = 0; j < B.D; j++) {
+        const int Dn = nonempty ? B.D : 0;  // (a trip count, not an early return: see above)
+        for (int j = 0; j < Dn; j++) {
             const double df = cc[j] - qq[j];
             cd += df * df;
         }
@@ -1773,7 +2151,7 @@ __device__ __forceinline__ bool pair_keep(const PairBound &B, long long e, int q
     const double gap = r - B.rmax;
     const double lb = gap * gap * (1.0 - 1e-9);
     const bool prune = (B.enabled != 0) & (T < 0x7FF0000000000000ull) & (gap > 0.0) & (lb > keyd(T));
-    return !prune;
+    return nonempty & !prune;
 }
 
 __global__ void k_pair_hist(const int32_t *__restrict__ cells, int w, int rank_lo, long long npairs,

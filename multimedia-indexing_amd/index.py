@@ -310,6 +310,10 @@ class _PQBase(AbstractSearchStructure):
     def set_profiling(self, on=True):
         N.check(N.lib().mmidx_set_profiling(self._h, int(on)))
 
+    def set_option(self, name, value):
+        """measurement / A-B switches of the native library (mmidx_set_option)"""
+        N.check(N.lib().mmidx_set_option(self._h, name.encode(), int(value)))
+
     def get_stats(self):
         s = N.Stats()
         N.check(N.lib().mmidx_get_stats(self._h, C.byref(s)))

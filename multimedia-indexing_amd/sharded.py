@@ -134,13 +134,16 @@ class ShardedIVFPQ:
       all-gather  results            B*k*12 bytes
     """
 
-    def __init__(self, engine, rank, world, dist=None, group=None):
+    def __init__(self, engine, rank, world, dist=None, group=None, force_collectives=False):
         self.engine, self.rank, self.world, self.dist, self.group = engine, rank, world, dist, group
+        # world == 1 normally short-circuits every collective; force_collectives issues them anyway
+        # (a 1-rank process group) so that the RCCL calls can be exercised on a single-GPU box
+        self.force = bool(force_collectives and dist is not None)
 
     def _all_gather(self, x):
         """stack of every rank's `x` along a new leading axis (same shape on all ranks)"""
         torch = __import__("torch")
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return x.unsqueeze(0)
         out = torch.empty((self.world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
         if x.is_cuda:
@@ -153,14 +156,17 @@ class ShardedIVFPQ:
     def _all_to_all(self, x):
         """x [world][...]: slice r goes to rank r; returns [world][...] = what every rank sent to me"""
         torch = __import__("torch")
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return x
         out = torch.empty_like(x)
         self.dist.all_to_all_single(out, x.contiguous(), group=self.group)
         return out
 
-    def search(self, k, Q):
-        """Q: [nq][D] float64 tensor, identical on every rank.  Returns (iid, dist, count) on every rank."""
+    def search(self, k, Q, gather=True):
+        """Q: [nq][D] float64 tensor, identical on every rank.  Returns (iid, dist, count) for all
+        queries on every rank, or with gather=False only this rank's slice (queries
+        [rank*per, (rank+1)*per), per = ceil(nq / world)) -- what a serving front-end needs when
+        each rank answers the clients whose queries it owns."""
         torch = __import__("torch")
         nq, W = Q.shape[0], self.world
         per = (nq + W - 1) // W
@@ -172,10 +178,10 @@ class ShardedIVFPQ:
             cells_sl = torch.cat([cells_sl, pad], 0)
         cells = self._all_gather(cells_sl).reshape(W * per, -1)[:nq].contiguous()
         T = self.engine.pass_a(k, Q, cells)
-        if W > 1:
+        if W > 1 or self.force:
             self.dist.all_reduce(T, op=self.dist.ReduceOp.MIN, group=self.group)
         pd, pk, pc = self.engine.pass_b(k, Q, cells, T)
-        if W == 1:
+        if W == 1 and not self.force:  # (gather is moot: the one rank owns every query)
             return self.engine.merge(k, pd.unsqueeze(0), pk.unsqueeze(0), pc.unsqueeze(0))
         # owner merge: pad the query axis to W*per, view as [W][per][...], exchange, merge my slice
         K1 = k + 1
@@ -188,6 +194,8 @@ class ShardedIVFPQ:
         rk = self._all_to_all(pk.reshape(W, per, K1))
         rc = self._all_to_all(pc.reshape(W, per))
         iid, dist_, cnt = self.engine.merge(k, rd, rk, rc)  # [per][k]
+        if not gather:
+            return iid[:q1 - q0], dist_[:q1 - q0], cnt[:q1 - q0]
         iid = self._all_gather(iid).reshape(W * per, k)[:nq]
         dist_ = self._all_gather(dist_).reshape(W * per, k)[:nq]
         cnt = self._all_gather(cnt).reshape(W * per)[:nq]

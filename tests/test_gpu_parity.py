@@ -485,3 +485,49 @@ def test_pq_sdc_by_internal_id(mi, oracle, D, m, ks, n, k):
         iv.search_sdc_batch(3, np.array([0], np.int32))
     assert ei.value.status == 10
     iv.close()
+
+
+@pytest.mark.parametrize("case", ["long_lists", "ties", "short_lists", "flat_pq", "k1023_falls_back"])
+def test_pass_a_histogram_kernel(mi, oracle, case):
+    """K3h (histogram-thresholded pass A) forced on: same answers as the oracle on long lists, on
+    tie-heavy lists (handed back to K3 through the fallback list), on lists shorter than a segment,
+    and on the flat PQ chunk-as-probe path."""
+    rng = np.random.default_rng(9)
+    if case == "flat_pq":
+        D, m, ks, n, k = 32, 8, 256, 150000, 20
+        p = synth.make_pq_problem(n=4000, D=D, m=m, ks=ks, nq=12, seed=21)
+        base = rng.standard_normal((n, D))
+        ix = mi.PQ(D, n, False, "", m, ks, 0, 512)
+        ix.loadProductQuantizer(p["pq"])
+        ref = oracle.OracleIndex(oracle.KIND_PQ, D, m, ks)
+        ref.set_pq(p["pq"])
+        ix.set_option("passa_hist", 1)
+        ix.indexVectors([str(i) for i in range(n)], base)
+        ref.add_vectors(base)
+        assert_same(ix.search_batch(k, p["queries"]), ref.search_batch(p["queries"], k))
+        ix.close()
+        return
+    D, m, ks = 32, 8, 256
+    if case == "long_lists":
+        C, w, n, ks_ = 4, 3, 60000, 256
+    elif case == "ties":
+        C, w, n, ks_ = 4, 4, 30000, 4  # 4 centroids per sub-quantizer: few distinct codes, thousands of exact ties
+    elif case == "short_lists":
+        C, w, n, ks_ = 64, 8, 6000, 256
+    else:
+        C, w, n, ks_ = 4, 2, 20000, 256
+    p = synth.make_ivfpq_problem(n=min(n, 8000), D=D, C=C, m=m, ks=ks_, nq=10, seed=17)
+    base, _ = synth.mixture(n, D, C, sigma=0.3, seed=23)
+    ix = mi.IVFPQ(D, n, False, "", m, ks_, 0, C, 512)
+    ix.loadCoarseQuantizer(p["coarse"])
+    ix.loadProductQuantizer(p["pq"])
+    ix.setW(w)
+    ix.set_option("passa_hist", 1)
+    ref = oracle_ivfpq(oracle, p, D, m, ks_, C, w)
+    ix.indexVectors([str(i) for i in range(n)], base)
+    ref.add_vectors(base)
+    q = base[rng.choice(n, 12, replace=False)] + 0.01 * rng.standard_normal((12, D))
+    ks_list = (1023,) if case == "k1023_falls_back" else (1, 10, 100, 255)
+    for k in ks_list:
+        assert_same(ix.search_batch(k, q), ref.search_batch(q, k))
+    ix.close()

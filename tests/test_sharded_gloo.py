@@ -94,6 +94,11 @@ def _worker(rank, world, port, ret):
     ok, compared = True, 0
     for k in (1, 10, 64):
         iid, dd, cnt = srch.search(k, Q)
+        # owner-kept form: this rank's slice of the same answer, no final all-gather
+        per = (Q.shape[0] + world - 1) // world
+        si, sd, sc = srch.search(k, Q, gather=False)
+        lo, hi = min(rank * per, Q.shape[0]), min(rank * per + per, Q.shape[0])
+        ok &= bool(torch.equal(si, iid[lo:hi]) and torch.equal(sd, dd[lo:hi]) and torch.equal(sc, cnt[lo:hi]))
         rid, rd, rc = ref.search_batch(p["queries"], k)
         _, rd1, rc1 = ref.search_batch(p["queries"], k + 1)
         for qi in range(Q.shape[0]):

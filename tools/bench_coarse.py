@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Microbenchmark of the coarse stage alone (K1c + K1d through mmidx_coarse_device):
+    python tools/bench_coarse.py [nq] [C] [D] [w]
+MMIDX_LIB=<path to another libmmidx_hip.so build> selects a kernel variant."""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+nat = importlib.import_module("multimedia-indexing_amd._native")
+nq = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+Cc = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+D = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+w = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+torch.cuda.init()
+L = nat.lib()
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev)
+g.manual_seed(1234)
+mu = torch.randn(Cc, D, generator=g, device=dev, dtype=torch.float64)
+pq = torch.randn(16, 256, D // 16, generator=g, device=dev, dtype=torch.float64) * 0.15
+Q = mu[torch.randint(0, Cc, (nq,), generator=g, device=dev)] + 0.15 * torch.randn(nq, D, generator=g, device=dev, dtype=torch.float64)
+h = C.c_void_p()
+nat.check(L.mmidx_create(nat.KIND_IVFPQ, D, 16, 256, Cc, 0, None, None, 0, C.byref(h)))
+mu_h, pq_h = mu.cpu().numpy(), pq.cpu().numpy()
+nat.check(L.mmidx_set_coarse(h, mu_h.ctypes.data))
+nat.check(L.mmidx_set_pq(h, pq_h.ctypes.data))
+nat.check(L.mmidx_set_w(h, w))
+cells = torch.empty(nq, w, dtype=torch.int32, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+for _ in range(3):
+    nat.check(L.mmidx_coarse_device(h, nq, Q.data_ptr(), cells.data_ptr(), st))
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+R = 20
+for _ in range(R):
+    nat.check(L.mmidx_coarse_device(h, nq, Q.data_ptr(), cells.data_ptr(), st))
+e1.record()
+torch.cuda.synchronize()
+print(f"lib={os.path.basename(nat.SO_PATH)} nq={nq} C={Cc} D={D} w={w}: {e0.elapsed_time(e1) / R * 1e3:.1f} us per call, "
+      f"checksum {int(cells.long().sum().item())}")
+nat.check(L.mmidx_destroy(h))

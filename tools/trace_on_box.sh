@@ -13,7 +13,7 @@ db = sqlite3.connect("/tmp/prof_$TAG/kt/kt_results.db")
 cur = db.cursor()
 cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
 print(cols)
-rows = list(cur.execute("select * from kernels order by start desc limit 40"))
+rows = list(cur.execute("select * from kernels order by start desc limit ${TL_ROWS:-40}"))
 ni = cols.index("name") if "name" in cols else None
 si, ei = cols.index("start"), cols.index("end")
 rows = rows[::-1]
