@@ -484,10 +484,10 @@ int launch_scan_hist(mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 gr
     const bool ok = h->code_bytes == 1 && (h->m == 8 || h->m == 16 || h->m == 32) && !P.sdc_tt && pl.K1 <= MMIDX_HKEEP &&
                     !P.order && !P.xcd_remap;
     if (!ok) return 1;
-    const size_t fixed = (size_t)h->m * h->ks * 8 + (h->transform ? 2 : 1) * (size_t)h->D * 8 + 64 + 16 + MMIDX_HB * 4 + 16;
+    const size_t fixed = (size_t)h->m * h->ks * 8 + (h->transform ? 2 : 1) * (size_t)h->D * 8 + 64 + 16 + MMIDX_HB * 4 + 32;
     // position buffer: what is left of a quarter of the CU's LDS (4 blocks per CU), within [768, 1536] entries
     int64_t room = (int64_t)(160 * 1024 / 4) - 256 - (int64_t)fixed;
-    int cap = (int)std::min<int64_t>(4096, std::max<int64_t>(768, room / 4));
+    int cap = (int)std::min<int64_t>(4096, std::max<int64_t>(768, room / 4)) & ~3;  // a quarter per wave
     const size_t lds = fixed + (size_t)cap * 4;
     if (lds > 64 * 1024) return 1;
     const size_t nfb = (size_t)grid.x * grid.y;
@@ -508,8 +508,9 @@ int launch_scan_hist(mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 gr
         int32_t c4[4];
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(c4, h->ws_fb.p, sizeof(c4), hipMemcpyDeviceToHost);
-        fprintf(stderr, "[mmidx] K3h: %d of %zu items handed back to K3 (> %d entries under the final bucket; cap %d, lds %zu)\n", c4[0], nfb,
-                MMIDX_HKEEP, cap, lds);
+        fprintf(stderr, "[mmidx] K3h: %d of %zu items handed back to K3 (> %d entries under the final bucket; cap %d, lds %zu); "
+                "debug build only: %d second passes, %.1f appended and %.1f kept per item\n", c4[0], nfb, MMIDX_HKEEP, cap, lds,
+                c4[1], (double)(unsigned)c4[2] / (double)nfb, (double)(unsigned)c4[3] / (double)nfb);
     }
     // the handed-back items (device-side count; normally none: the blocks exit at once)
     ScanParams F = P;

@@ -255,6 +255,9 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_reg(const double 
 #ifndef MMIDX_CAND_CHUNK
 #define MMIDX_CAND_CHUNK 16
 #endif
+#ifndef MMIDX_HIST_DEBUG
+#define MMIDX_HIST_DEBUG 0  // debug: K3h adds overflow / appended / kept totals to the fallback header
+#endif
 #ifndef MMIDX_HIST_STOP
 #define MMIDX_HIST_STOP 0  // debug: truncate k_scan_hist (1 = after the scan loop, 2 = before the final sort)
 #endif
@@ -1160,10 +1163,12 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
 //     [min0 - 0.4 (q40 - min0), q40 + 0.1 (q40 - min0)), clamped; min0 / q40 = minimum and ~40 %
 //     quantile of the first 256 distances) -- the region where the K1 smallest of a long list end up;
 //   * a code is a candidate iff bucket(d) <= Tb, the wave's current threshold bucket; candidates
-//     bump hist[bucket] and append their list position (4 bytes) to a shared buffer;
-//   * every few segments each wave recomputes Tb = the first bucket whose cumulative count reaches
-//     K1 (a 256-entry prefix sum inside the wave).  Tb only decreases, so every code whose bucket is
-//     <= the final Tb was appended, whatever the interleaving of the waves: NO barrier in the loop;
+//     bump hist[bucket] and append their list position (4 bytes) to the wave's own quarter of a
+//     position buffer (count in a register: no atomic with a return value);
+//   * every segment at first, then every fourth, each wave recomputes Tb = the first bucket whose
+//     cumulative count reaches K1 (a 256-entry prefix sum inside the wave).  Tb only decreases, so
+//     every code whose bucket is <= the final Tb was appended, whatever the interleaving of the
+//     waves: NO barrier in the loop;
 //   * at the end (one barrier) the final Tb is read off the complete histogram, the appended
 //     positions are re-evaluated (exact sum again, same order -> same bits) and the entries with
 //     bucket <= Tb -- at least K1, at most MMIDX_HKEEP, typically K1 + 2 -- go to the query's pool;
@@ -1174,6 +1179,25 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
 // ties, or a segment 0 that is not representative) are not handled here: the item is appended to a
 // fallback list and a K3 launch over that list redoes it, so results never depend on the heuristics.
 // ------------------------------------------------------------------------------------------------
+// wave64 helpers that stay in the VALU (DPP / readlane): inside K3h's scan loop the LDS pipe is saturated
+// by the table gather, and every ds_bpermute-based __shfl would queue behind it
+__device__ __forceinline__ u32 wave_incl_scan_u32(u32 x) {
+    u32 v = x;  // Hillis-Steele inside each row of 16 lanes, then the row totals (gfx9 row broadcasts)
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+__device__ __forceinline__ u32 wave_read_u32(u32 x, int l) { return (u32)__builtin_amdgcn_readlane((int)x, l); }
+__device__ __forceinline__ double wave_read_f64(double x, int l) {
+    const u64 b = (u64)__double_as_longlong(x);
+    const u32 lo_ = wave_read_u32((u32)b, l), hi_ = wave_read_u32((u32)(b >> 32), l);
+    return __longlong_as_double((long long)(((u64)hi_ << 32) | lo_));
+}
+
 #define MMIDX_HB 256
 #define MMIDX_HKEEP 256  // most entries one item may emit (>= K1 required: the host checks; the pool has room for them)
 #define MMIDX_HPOS 4     // appended positions re-evaluated per thread per round at the end
@@ -1187,8 +1211,8 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
     double *vec = lut + (size_t)M * ks;                                  // [D] or [2D]
     double *s_red = vec + (P.transform ? 2 : 1) * (size_t)D;             // [8] wave minima / maxima of segment 0
     u32 *hist = (u32 *)(((uintptr_t)(s_red + 8) + 15) & ~(uintptr_t)15);  // [HB] (16-byte aligned: read as uint4)
-    u32 *s_cnt = hist + MMIDX_HB;                                        // [4]: 0 appended, 1 overflow, 2-3 largest kept key (u64)
-    u32 *posbuf = s_cnt + 4;                                             // [cap] list positions
+    u32 *s_cnt = hist + MMIDX_HB;                                        // [8]: 0-3 appended per wave, 4-5 largest kept key (u64)
+    u32 *posbuf = s_cnt + 8;                                             // [cap] list positions, one quarter per wave
 
     int item = blockIdx.x;
     if (item >= P.n_items) return;
@@ -1216,7 +1240,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
         const int64_t i = c0 + tid;
         cur.load(codes + (size_t)(i < c1 ? i : c1 - 1) * M);
     }
-    for (int i = tid; i < MMIDX_HB + 4; i += NT) hist[i] = 0;  // histogram and the three counters
+    for (int i = tid; i < MMIDX_HB + 8; i += NT) hist[i] = 0;  // histogram and the counters
     const double *tr = query_vector(P, q, cell, vec);
     build_lut_any(lut, tr, P.pqT, M, ks, P.dsub);
     __syncthreads();
@@ -1228,44 +1252,54 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
         return d;
     };
 
-    // ---- segment 0: the bucket map -------------------------------------------------------------
-    // Robust to far outliers in the list (members of other clusters that were assigned to this cell):
-    // the scale is (q40 - min) of the first 256 distances, not their range.  q40 ~ the K1-th smallest
-    // of segment 0 for K1 ~ 100; each wave sorts its 64 values in registers and reports its 26th.
+    // ---- segment 0: the bucket map and the first threshold bucket ---------------------------------
+    // Each wave sorts its 64 distances in registers and reports its minimum and its r-th smallest,
+    // r = ceil(K1 / 4).  qr = the largest of the four r-th values has at least 4 r >= K1 entries of
+    // segment 0 at or below it, so bucket(qr) is a valid first threshold; and (qr - min) is a scale that
+    // far outliers in the list (members of other clusters assigned to this cell) cannot stretch.
     double d = exact(cur);
+    const int r_sel = (P.K1 + NT / 64 - 1) / (NT / 64);  // <= 64: the host launches K3h for K1 <= 256 only
     {
         const double inf = __longlong_as_double(0x7FF0000000000000ll);
-        double v = (c0 + tid < c1) ? d : inf;
-#pragma unroll
-        for (int size = 2; size <= 64; size <<= 1) {
-#pragma unroll
-            for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                const double o = __shfl_xor(v, stride);
-                const bool up = (lane & size) == 0, low = (lane & stride) == 0;
-                const double mn_ = o < v ? o : v, mx_ = o < v ? v : o;
-                v = (up == low) ? mn_ : mx_;
-            }
+        const double v = (c0 + tid < c1) ? d : inf;
+        int rank = 0;  // position of this lane's value in the wave's ascending order (ties by lane)
+#pragma unroll 16
+        for (int j = 0; j < 64; j++) {
+            const double o = wave_read_f64(v, j);
+            rank += (o < v) || (o == v && j < lane);
         }
-        const double wmin = __shfl(v, 0), wq = __shfl(v, 25);
+        const double wmin = wave_read_f64(v, __ffsll((long long)__ballot(rank == 0)) - 1);
+        const double wq = wave_read_f64(v, __ffsll((long long)__ballot(rank == r_sel - 1)) - 1);
         if (lane == 0) {
             s_red[wv] = wmin;
             s_red[4 + wv] = wq;
         }
     }
     __syncthreads();
-    double lo, inv;
+    double lo, inv, qr;
+    bool qr_valid = true;
     {
         const double inf = __longlong_as_double(0x7FF0000000000000ll);
-        double mn = s_red[0], q40 = s_red[4];
+        double mn = s_red[0];
+        qr = s_red[4];
 #pragma unroll
         for (int i = 1; i < NT / 64; i++) {
             mn = s_red[i] < mn ? s_red[i] : mn;
-            q40 = s_red[4 + i] < q40 ? s_red[4 + i] : q40;  // the smallest finite estimate (short lists: some waves are empty)
+            qr = s_red[4 + i] > qr ? s_red[4 + i] : qr;
         }
-        if (!(q40 < inf)) q40 = mn;
-        const double span = q40 - mn;  // >= 0
+        if (!(qr < inf)) {  // a wave with fewer than r entries (short list): no first threshold, scale from what there is
+            qr_valid = false;
+            qr = -inf;
+#pragma unroll
+            for (int i = 0; i < NT / 64; i++) {
+                const double a = s_red[4 + i];
+                qr = (a < inf && a > qr) ? a : qr;
+            }
+            if (!(qr > -inf)) qr = mn;
+        }
+        const double span = qr - mn;  // >= 0
         lo = mn - 0.4 * span;
-        const double width = 1.5 * span;  // buckets cover [lo, q40 + 0.1 span); everything above clamps into the last
+        const double width = 1.5 * span;  // buckets cover [lo, qr + 0.1 span); everything above clamps into the last
         inv = (width > 0.0 && width < 1e300) ? (double)MMIDX_HB / width : 0.0;
         if (!(inv < 1e300)) inv = 0.0;
     }
@@ -1274,10 +1308,38 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
         const double x = (dd - lo) * inv;
         return x >= (double)(MMIDX_HB - 1) ? MMIDX_HB - 1 : (x > 0.0 ? (int)x : 0);
     };
+    // first bucket whose cumulative count reaches K1, from this lane's four buckets hv (HB - 1 if none)
+    auto threshold_bucket = [&](const uint4 hv, u32 &upto, u32 &total) -> int {
+        const u32 own = hv.x + hv.y + hv.z + hv.w;
+        const u32 incl = wave_incl_scan_u32(own);
+        total = wave_read_u32(incl, 63);
+        upto = 0xFFFFFFFFu;  // cumulative count including the returned bucket
+        const u64 reached = __ballot(incl >= (u32)P.K1);
+        if (!reached) return MMIDX_HB - 1;
+        const int L = __ffsll((long long)reached) - 1;  // the lane whose four buckets cross K1 (wave-uniform)
+        const u32 hx = wave_read_u32(hv.x, L), hy = wave_read_u32(hv.y, L), hz = wave_read_u32(hv.z, L),
+                  hw = wave_read_u32(hv.w, L);
+        u32 c = wave_read_u32(incl, L) - (hx + hy + hz + hw) + hx;
+        int cand = 4 * L;
+        if (c < (u32)P.K1) { c += hy; cand++; }
+        if (c < (u32)P.K1) { c += hz; cand++; }
+        if (c < (u32)P.K1) { c += hw; cand++; }
+        upto = c;
+        return cand;
+    };
 
-    // ---- scan: no block barrier ----------------------------------------------------------------
+    // ---- scan: no block barrier, no LDS round trip besides the gather itself -------------------------
+    // Each wave appends to its own quarter of the position buffer (count in a register, no atomic) and
+    // reads its four histogram buckets TOGETHER with the segment's table lookups; the threshold bucket
+    // derived from them applies from the next segment on (a stale histogram only errs on the safe side).
     const u64 lane_lt = (1ull << lane) - 1ull;
-    int Tb = MMIDX_HB - 1;
+    const u32 capw = (u32)P.cap / (NT / 64);
+    u32 *mybuf = posbuf + (size_t)wv * capw;
+    u32 wcnt = 0;  // wave-uniform
+    int Tb = qr_valid ? bucket(qr) : MMIDX_HB - 1;
+#if MMIDX_HIST_STOP == 3
+    Tb = -1;
+#endif
     int g = 0;
     for (int64_t seg = c0; seg < c1; seg += NT, g++) {
         const bool more = seg + NT < c1;
@@ -1285,93 +1347,57 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
             const int64_t i = seg + NT + tid;
             nxt.load(codes + (size_t)(i < c1 ? i : c1 - 1) * M);
         }
+        const bool refresh = MMIDX_HIST_STOP != 3 && g > 0 && (g < 16 || (g & 3) == 0);
+        uint4 hv = make_uint4(0, 0, 0, 0);
+        if (refresh) hv = ((const uint4 *)hist)[lane];  // buckets 4*lane .. 4*lane+3
         if (g > 0) d = exact(cur);
         const int64_t i = seg + tid;
         const int b = bucket(d);
         const bool pass = (i < c1) && b <= Tb;
         const u64 mask = __ballot(pass);
-        if (mask) {
-            u32 base = 0;
-            const int leader = __ffsll((long long)mask) - 1;
-            if (lane == leader) base = atomicAdd(s_cnt, (u32)__popcll(mask));
-            base = __shfl(base, leader);
-            if (pass) {
-                atomicAdd(hist + b, 1u);
-                const u32 slot = base + (u32)__popcll(mask & lane_lt);
-                if (slot < (u32)P.cap) posbuf[slot] = (u32)i;
-                else s_cnt[1] = 1;
-            }
+        if (pass) {
+            atomicAdd(hist + b, 1u);
+            const u32 slot = wcnt + (u32)__popcll(mask & lane_lt);
+            if (slot < capw) mybuf[slot] = (u32)i;
         }
-        // refresh the threshold bucket after segments 1, 2, 4, 8 and then every 8th
-        const int gn = g + 1;
-        if ((gn & g) == 0 || (gn & 7) == 0) {
-            const uint4 hv = ((const uint4 *)hist)[lane];  // buckets 4*lane .. 4*lane+3 (own atomics are ordered before this read)
-            const u32 own = hv.x + hv.y + hv.z + hv.w;
-            u32 incl = own;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const u32 o = __shfl_up(incl, off);
-                if (lane >= off) incl += o;
-            }
-            const u32 excl = incl - own;
-            int cand = MMIDX_HB - 1;
-            if (excl < (u32)P.K1 && incl >= (u32)P.K1) {
-                u32 c = excl + hv.x;
-                cand = 4 * lane;
-                if (c < (u32)P.K1) { c += hv.y; cand++; }
-                if (c < (u32)P.K1) { c += hv.z; cand++; }
-                if (c < (u32)P.K1) { cand++; }
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const int o = __shfl_xor(cand, off);
-                cand = o < cand ? o : cand;
-            }
+        wcnt += (u32)__popcll(mask);  // > capw: overflow, seen at the end
+        if (refresh) {
+            u32 upto, total;
+            const int cand = threshold_bucket(hv, upto, total);
             Tb = cand < Tb ? cand : Tb;
         }
         if (more) cur = nxt;
     }
+    if (lane == 0) s_cnt[wv] = wcnt;
     __syncthreads();
-
-#if MMIDX_HIST_STOP == 1
+#if MMIDX_HIST_STOP == 1 || MMIDX_HIST_STOP == 3
     if (Tb < -1) P.pool_cnt[q] = 1;
     return;
 #endif
     // ---- final threshold bucket from the complete histogram (identical in every wave) ------------
     u32 kept_total;
     {
-        const uint4 hv = ((const uint4 *)hist)[lane];
-        const u32 own = hv.x + hv.y + hv.z + hv.w;
-        u32 incl = own;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const u32 o = __shfl_up(incl, off);
-            if (lane >= off) incl += o;
-        }
-        const u32 excl = incl - own;
-        int cand = MMIDX_HB - 1;
-        u32 upto = 0xFFFFFFFFu;  // cumulative count including bucket cand
-        if (excl < (u32)P.K1 && incl >= (u32)P.K1) {
-            u32 c = excl + hv.x;
-            cand = 4 * lane;
-            if (c < (u32)P.K1) { c += hv.y; cand++; }
-            if (c < (u32)P.K1) { c += hv.z; cand++; }
-            if (c < (u32)P.K1) { c += hv.w; cand++; }
-            upto = c;
-        }
-        const u32 total = __shfl(incl, 63);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const int o = __shfl_xor(cand, off);
-            const u32 ou = __shfl_xor(upto, off);
-            cand = o < cand ? o : cand;
-            upto = ou < upto ? ou : upto;
-        }
-        Tb = cand;  // fewer than K1 candidates in all: every bucket counts
+        u32 upto, total;
+        Tb = threshold_bucket(((const uint4 *)hist)[lane], upto, total);  // fewer than K1 candidates in all: every bucket counts
         kept_total = (upto == 0xFFFFFFFFu) ? total : upto;
     }
-    const u32 n_app = s_cnt[0];
-    const bool overflow = s_cnt[1] != 0 || n_app > (u32)P.cap;  // block-uniform (read after the barrier)
+    u32 woff[NT / 64 + 1];
+    bool overflow = false;  // block-uniform (read after the barrier)
+    woff[0] = 0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; i++) {
+        const u32 c = s_cnt[i];
+        overflow |= c > capw;
+        woff[i + 1] = woff[i] + (c > capw ? capw : c);
+    }
+    const u32 n_app = woff[NT / 64];
+#if MMIDX_HIST_DEBUG
+    if (tid == 0) {
+        atomicAdd(P.fb_count + 1, overflow ? 1u : 0u);
+        atomicAdd(P.fb_count + 2, n_app);
+        atomicAdd(P.fb_count + 3, kept_total);
+    }
+#endif
     if (kept_total > (u32)MMIDX_HKEEP) {  // block-uniform: redo this item with K3
         if (tid == 0) {
             const u32 slot = atomicAdd(P.fb_count, 1u);
@@ -1414,7 +1440,13 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
 #pragma unroll
             for (int j = 0; j < MMIDX_HPOS; j++) {
                 const u32 e = e0 + (u32)(j * NT + tid);
-                pos[j] = e < n_app ? posbuf[e] : 0xFFFFFFFFu;
+                u32 pv = 0xFFFFFFFFu;
+                if (e < n_app) {
+                    const int w_ = (e >= woff[1]) + (e >= woff[2]) + (e >= woff[3]);
+                    const u32 o_ = w_ == 0 ? woff[0] : (w_ == 1 ? woff[1] : (w_ == 2 ? woff[2] : woff[3]));
+                    pv = posbuf[(size_t)w_ * capw + (e - o_)];
+                }
+                pos[j] = pv;
             }
 #pragma unroll
             for (int j = 0; j < MMIDX_HPOS; j++)
@@ -1453,7 +1485,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
             const u64 o = __shfl_xor(kmax, off);
             kmax = o > kmax ? o : kmax;
         }
-        u64 *s_max = (u64 *)(s_cnt + 2);  // zeroed with the histogram, 8-byte aligned
+        u64 *s_max = (u64 *)(s_cnt + 4);  // zeroed with the histogram, 8-byte aligned
         if (lane == 0) atomicMax(s_max, kmax);
         __syncthreads();
         if (tid == 0) atomicMin(Tq, *s_max);
