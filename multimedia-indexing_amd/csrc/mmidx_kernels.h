@@ -1451,11 +1451,39 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
 #pragma unroll
             for (int j = 0; j < MMIDX_HPOS; j++)
                 if (e0 + (u32)(j * NT) < n_app) cv[j].load(codes + (size_t)(pos[j] != 0xFFFFFFFFu ? pos[j] : (u32)c0) * M);
+            // one pool reservation per wave per round: the kept entries wait in registers
+            u64 kk[MMIDX_HPOS];
+            u32 nk = 0, emit_bits = 0;
 #pragma unroll
             for (int j = 0; j < MMIDX_HPOS; j++) {
+                kk[j] = 0;
                 if (e0 + (u32)(j * NT) < n_app) {  // block-uniform
                     const double dd = exact(cv[j]);
-                    keep_entry(pos[j] != 0xFFFFFFFFu && bucket(dd) <= Tb, dd, pos[j]);
+                    const bool keep = pos[j] != 0xFFFFFFFFu && bucket(dd) <= Tb;
+                    const u64 key = dkey(dd);
+                    if (keep) kmax = key > kmax ? key : kmax;
+                    kk[j] = key;
+                    if (keep && key <= Tg) {
+                        emit_bits |= 1u << j;
+                        nk++;
+                    }
+                }
+            }
+            const u32 incl = wave_incl_scan_u32(nk);
+            const u32 wtot = wave_read_u32(incl, 63);
+            if (wtot) {  // wave-uniform
+                u32 base = 0;
+                if (lane == 0) base = atomicAdd(P.pool_cnt + q, wtot);
+                u32 slot = wave_read_u32(base, 0) + incl - nk;
+#pragma unroll
+                for (int j = 0; j < MMIDX_HPOS; j++) {
+                    if (emit_bits & (1u << j)) {
+                        if (slot < (u32)P.poolq) {
+                            P.pool_key[(size_t)q * P.poolq + slot] = kk[j];
+                            P.pool_val[(size_t)q * P.poolq + slot] = ((u64)pr << 32) | (u64)pos[j];
+                        }
+                        slot++;
+                    }
                 }
             }
         }
