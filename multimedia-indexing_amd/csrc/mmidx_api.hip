@@ -21,6 +21,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <limits>
 #include <vector>
 
 namespace {
@@ -114,6 +115,11 @@ struct mmidx_index {
     double *d_coarse = nullptr, *d_coarseT = nullptr, *d_pq = nullptr, *d_pqT = nullptr,
            *d_rot = nullptr, *d_cn = nullptr, *d_cnorm = nullptr;
     float *d_coarseT32 = nullptr;
+    // K1e/K1f (bf16-split coarse dot products + group minima): padded bf16 head/tail copies of the centroids
+    unsigned short *d_Ch = nullptr, *d_Cl = nullptr;
+    double *d_cn_pad = nullptr;  // [Cp] |c|^2, +inf on the padding rows
+    int Cp = 0, Dp = 0;          // C rounded up to 128, D rounded up to 32
+    bool coarse_v1 = false;      // MMIDX_COARSE_V1=1: K1c/K1d (fp32 MFMA, full d~ matrix) instead
     double cn_max = 0.0, cnorm_max = 0.0;
     bool exact_coarse = false;  // MMIDX_EXACT_COARSE=1: fp64 distances to every centroid (K1a/K1b)
     bool cdsel_valid = false;   // ws_cdsel holds the selected cells' exact distances for the current batch
@@ -133,6 +139,8 @@ struct mmidx_index {
 
     // workspaces
     DevBuf<int32_t> ws_fb;
+    DevBuf<unsigned short> ws_Qh, ws_Ql;
+    DevBuf<float> ws_gmin;
     DevBuf<double> ws_Q, ws_cdist, ws_odist, ws_X, ws_Xa, ws_qn, ws_cdsel, ws_sdc;
     DevBuf<float> ws_Q32, ws_S;
     DevBuf<int32_t> ws_cells, ws_oiid, ws_ocnt, ws_flag, ws_ecell, ws_pcount, ws_pstart, ws_pcursor, ws_order;
@@ -548,6 +556,53 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
                         (size_t)MMIDX_CAND_CHUNK * (h->D + MMIDX_TERM_PAD) * 8 + 16;
     const bool approx = !h->exact_coarse && h->C >= MMIDX_BLOCK && h->w + 1 <= MMIDX_BLOCK && h->C <= 64 * MMIDX_BLOCK &&
                         h->w >= 1 && alds <= 64 * 1024;
+    const size_t glds = (size_t)MMIDX_CSEL_CAP * 12 + (size_t)(h->w + 1) * 8 + (size_t)((h->w + 2) & ~1) * 4 +
+                        std::max<size_t>((size_t)MMIDX_CAND_CHUNK * (h->D + MMIDX_TERM_PAD) * 8, (size_t)MMIDX_BLOCK * 4) + 16;
+    const int G = h->Cp / 8;
+    if (approx && !h->coarse_v1 && h->d_Ch && G >= 4 * (h->w + 1) && glds <= 64 * 1024) {
+        // K1e + K1f: bf16-split dot products on the matrix cores, group minima only, certified candidates in fp64
+        HIPCK(h->ws_qn.reserve((size_t)nq));
+        HIPCK(h->ws_Qh.reserve((size_t)nq * h->Dp));
+        HIPCK(h->ws_Ql.reserve((size_t)nq * h->Dp));
+        HIPCK(h->ws_gmin.reserve((size_t)nq * G * 2));
+        HIPCK(h->ws_cdsel.reserve((size_t)nq * h->w));
+        hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)((nq + 3) / 4)), dim3(MMIDX_BLOCK), 0, st, dQ, (__bf16 *)h->ws_Qh.p, (__bf16 *)h->ws_Ql.p,
+                           (float *)nullptr, h->ws_qn.p, h->D, h->Dp, (long long)nq);
+        const int ntiles = h->Cp / G16_BC;
+        const int qblocks = (int)((nq + G16_BQ - 1) / G16_BQ);
+        const int csplit = std::max(1, std::min(ntiles, (512 + qblocks - 1) / qblocks));
+        const size_t l16 = 2 * (size_t)G16_BC * G16_STRIDE;
+        HIPCK(hipFuncSetAttribute((const void *)k_coarse_gmin16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l16));
+        hipLaunchKernelGGL(k_coarse_gmin16, dim3((unsigned)qblocks, (unsigned)csplit), dim3(MMIDX_BLOCK), l16, st, (const __bf16 *)h->ws_Qh.p,
+                           (const __bf16 *)h->ws_Ql.p, (const __bf16 *)h->d_Ch, (const __bf16 *)h->d_Cl, h->d_cn_pad, h->ws_qn.p,
+                           (float2 *)h->ws_gmin.p, h->Cp, h->Dp, (int)nq, G);
+        HIPCK(hipGetLastError());
+        ApproxSel A{};
+        A.qn = h->ws_qn.p;
+        A.cnorm_max = h->cnorm_max;
+        A.cn_max = h->cn_max;
+        A.Q = dQ;
+        A.coarse = h->d_coarse;
+        A.coarseT = h->d_coarseT;
+        A.row_scratch = h->ws_cdist.p;
+        A.cells = d_cells;
+        A.cdsel = h->ws_cdsel.p;
+        A.C = h->C;
+        A.D = h->D;
+        A.w = h->w;
+        A.gpair = (const float2 *)h->ws_gmin.p;
+        A.G = G;
+        A.Dp = h->Dp;
+        if (h->C <= 8 * MMIDX_BLOCK)
+            hipLaunchKernelGGL(k_coarse_select_grp<8>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), glds, st, A);
+        else if (h->C <= 32 * MMIDX_BLOCK)
+            hipLaunchKernelGGL(k_coarse_select_grp<32>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), glds, st, A);
+        else
+            hipLaunchKernelGGL(k_coarse_select_grp<64>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), glds, st, A);
+        HIPCK(hipGetLastError());
+        h->cdsel_valid = true;
+        return MMIDX_OK;
+    }
     if (approx) {
         // K1c + K1d: fp32 dot products for all centroids, fp64 only for the certified candidates
         HIPCK(h->ws_Q32.reserve((size_t)nq * h->D));
@@ -1005,6 +1060,8 @@ int mmidx_create(int kind, int D, int m, int ks, int C, int transform, const int
         h->passa_512 = p5 && p5[0] == '1';
         const char *p2 = getenv("MMIDX_PASSA_SU2");
         h->passa_su2 = p2 && p2[0] == '1';
+        const char *cv1 = getenv("MMIDX_COARSE_V1");
+        h->coarse_v1 = cv1 && cv1[0] == '1';
         const char *ph = getenv("MMIDX_PASSA_HIST");
         if (ph) h->passa_hist = atoi(ph);
         const char *pp = getenv("MMIDX_PASSA_PREFIX");
@@ -1022,7 +1079,7 @@ int mmidx_destroy(mmidx_index *h) {
     if (!h) return MMIDX_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *ptrs[] = {h->d_cn, h->d_cnorm, h->d_coarseT32, h->d_coarse, h->d_coarseT, h->d_pq, h->d_pqT, h->d_rot, h->d_perm, h->d_off, h->d_codes,
+    void *ptrs[] = {h->d_Ch, h->d_Cl, h->d_cn_pad, h->d_cn, h->d_cnorm, h->d_coarseT32, h->d_coarse, h->d_coarseT, h->d_pq, h->d_pqT, h->d_rot, h->d_perm, h->d_off, h->d_codes,
                     h->d_ids,    h->d_pcell,   h->d_pid, h->d_pcodes};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1034,6 +1091,9 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_Xa.release();
     h->ws_sdc.release();
     h->ws_fb.release();
+    h->ws_Qh.release();
+    h->ws_Ql.release();
+    h->ws_gmin.release();
     h->ws_cdsel.release();
     h->ws_Q32.release();
     h->ws_S.release();
@@ -1101,6 +1161,29 @@ int mmidx_set_coarse(mmidx_index *h, const double *coarse) {
     HIPCK(hipMemcpy(h->d_cn, cn.data(), (size_t)h->C * 8, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(h->d_cnorm, cnorm.data(), (size_t)h->C * 8, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(h->d_coarseT32, T32.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    // bf16 head / tail copies, rows padded to a multiple of 128 (zero rows, |c|^2 = +inf), k to a multiple of 32
+    h->Cp = (h->C + 127) / 128 * 128;
+    h->Dp = (h->D + 31) / 32 * 32;
+    if (h->d_Ch) (void)hipFree(h->d_Ch);
+    if (h->d_Cl) (void)hipFree(h->d_Cl);
+    if (h->d_cn_pad) (void)hipFree(h->d_cn_pad);
+    h->d_Ch = h->d_Cl = nullptr;
+    h->d_cn_pad = nullptr;
+    const size_t nb = (size_t)h->Cp * h->Dp;
+    HIPCK(hipMalloc((void **)&h->d_Ch, nb * 2));
+    HIPCK(hipMalloc((void **)&h->d_Cl, nb * 2));
+    HIPCK(hipMalloc((void **)&h->d_cn_pad, (size_t)h->Cp * 8));
+    HIPCK(hipMemset(h->d_Ch, 0, nb * 2));
+    HIPCK(hipMemset(h->d_Cl, 0, nb * 2));
+    {
+        std::vector<double> cnp((size_t)h->Cp, std::numeric_limits<double>::infinity());
+        for (int c = 0; c < h->C; c++) cnp[(size_t)c] = cn[(size_t)c];
+        HIPCK(hipMemcpy(h->d_cn_pad, cnp.data(), (size_t)h->Cp * 8, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)((h->C + 3) / 4)), dim3(MMIDX_BLOCK), 0, h->stream, h->d_coarse, (__bf16 *)h->d_Ch,
+                       (__bf16 *)h->d_Cl, (float *)nullptr, (double *)nullptr, h->D, h->Dp, (long long)h->C);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(h->stream));
     h->coarse_set = true;
     return MMIDX_OK;
 }
@@ -1509,6 +1592,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->no_bound = value != 0;
     } else if (n == "exact_coarse") {
         h->exact_coarse = value != 0;
+    } else if (n == "coarse_v1") {
+        h->coarse_v1 = value != 0;
     } else if (n == "passa_hist") {
         h->passa_hist = value;
     } else if (n == "passa_prefix") {

@@ -47,6 +47,25 @@ __device__ __forceinline__ void block_bitonic_sort(u64 *key, V *val, int n) {
     __syncthreads();
 }
 
+// wave64 helpers that stay in the VALU (DPP / readlane): inside K3h's scan loop the LDS pipe is saturated
+// by the table gather, and every ds_bpermute-based __shfl would queue behind it
+__device__ __forceinline__ u32 wave_incl_scan_u32(u32 x) {
+    u32 v = x;  // Hillis-Steele inside each row of 16 lanes, then the row totals (gfx9 row broadcasts)
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+__device__ __forceinline__ u32 wave_read_u32(u32 x, int l) { return (u32)__builtin_amdgcn_readlane((int)x, l); }
+__device__ __forceinline__ double wave_read_f64(double x, int l) {
+    const u64 b = (u64)__double_as_longlong(x);
+    const u32 lo_ = wave_read_u32((u32)b, l), hi_ = wave_read_u32((u32)(b >> 32), l);
+    return __longlong_as_double((long long)(((u64)hi_ << 32) | lo_));
+}
+
 __device__ __forceinline__ int pow2ceil(int n) {
     int p = 1;
     while (p < n) p <<= 1;
@@ -253,7 +272,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_reg(const double 
 // If the gather overflows (massive ties) the round-based selection runs on the registers instead.
 #define MMIDX_CSEL_CAP 1024
 #ifndef MMIDX_CAND_CHUNK
-#define MMIDX_CAND_CHUNK 16
+#define MMIDX_CAND_CHUNK 24
 #endif
 #ifndef MMIDX_HIST_DEBUG
 #define MMIDX_HIST_DEBUG 0  // debug: K3h adds overflow / appended / kept totals to the fallback header
@@ -507,92 +526,21 @@ struct ApproxSel {
     double *cdsel;           // [nq][w] exact distance of every selected cell (probe-bound input)
     double cnorm_max, cn_max;  // max |c| and max |c|^2 (rounded up): one error bound per query
     int C, D, w;
+    // K1f (group minima front end)
+    const float2 *gpair;     // [nq][G] (smallest, runner-up | position) of d~ over each group of 8 centroids (K1e)
+    int G, Dp;               // groups per query (Cp / 8), k padded to a multiple of 32
 };
 
+// Second half of the certified coarse selection, shared by the two front ends (K1d over the full d~ row,
+// K1f over group minima): the n candidates in cidx[] get the exact sequential fp64 distance, are ordered
+// by (distance, index), and the bounded-queue rule picks the w cells.  Every thread of the block calls it
+// after a barrier that made cidx[0..n) and n visible.
 template <int PER>
-__global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_approx(const ApproxSel A) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64 *ckey = (u64 *)smem;                       // [CSEL_CAP] thread minima, then exact candidate keys
-    u32 *cidx = (u32 *)(ckey + MMIDX_CSEL_CAP);    // [CSEL_CAP]
-    u64 *sel_k = (u64 *)(cidx + MMIDX_CSEL_CAP);   // [w+1]
-    int *sel_i = (int *)(sel_k + (A.w + 1));       // [w+1]
-    __shared__ u64 s_k[MMIDX_BLOCK / 64];
-    __shared__ int s_i[MMIDX_BLOCK / 64];
-    __shared__ u32 s_n4[4];  // statics total 64 B: keeps the dynamic LDS base 16-byte aligned
-    u32 &s_n = s_n4[0];
-    const int q = blockIdx.x, tid = threadIdx.x, C = A.C, D = A.D, w = A.w;
-    const int R = w + 1;  // host guarantees R <= 256 <= C
-    const float *srow = A.S + (size_t)q * C;
-    const double qn = A.qn[q];
-    // |d~ - d| <= eps for every centroid of this query:
-    //   dot product: 2 (D + 3) 2^-24 (1.01) |q| |c|     (input rounding + D fused multiply-adds)
-    //   fp64 epilogue and exact-sum rounding: 1e-12 (|c|^2 + |q|^2)
-    //   fp32 store of d~: 2^-23 |d~| <= 2^-23 (|c| + |q|)^2
-    const double qnorm = sqrt(qn);
-    const double sumn = A.cnorm_max + qnorm;
-    const double eps = (2.0 * (double)(D + 3) * 0x1p-24 * 1.01 * qnorm * A.cnorm_max + 1e-12 * (A.cn_max + qn) +
-                        0x1p-23 * sumn * sumn) * (1.0 + 1e-9);
-    float dt[PER];  // d~
-    float lmin = __int_as_float(0x7f800000);
-#pragma unroll
-    for (int i = 0; i < PER; i++) {
-        const int c = tid + i * MMIDX_BLOCK;
-        const float v = (c < C) ? srow[c] : __int_as_float(0x7f800000);
-        dt[i] = v;
-        lmin = v < lmin ? v : lmin;
-    }
-#if MMIDX_SEL_STOP == 1
-    if (lmin < -1.0f) A.cells[(size_t)q * w] = tid;
-    return;
-#endif
-    // tau: (R-th smallest per-thread minimum of d~) + eps >= the R-th smallest upper bound d~ + eps
-    // R-th smallest of the 256 minima by rank counting (one barrier instead of a 36-stage sort)
-    float *fmin = (float *)ckey;
-    fmin[tid] = lmin < 0.0f ? 0.0f : lmin;
-    if (tid == 0) s_n = 0;
-    __syncthreads();
-    {
-        const float mine = fmin[tid];
-        int rank = 0;
-#pragma unroll 32
-        for (int t = 0; t < MMIDX_BLOCK; t++) {
-            const float o = fmin[t];
-            rank += (o < mine) || (o == mine && t < tid);
-        }
-        if (rank == R - 1) sel_k[0] = dkey((double)mine);
-    }
-    __syncthreads();
-    const double tau = keyd(sel_k[0]) + eps;
-    __syncthreads();
-#if MMIDX_SEL_STOP == 2
-    if (tau < -1.0) A.cells[(size_t)q * w] = tid;
-    return;
-#endif
-    const u64 lane_lt = (1ull << (tid & 63)) - 1ull;
-    const double cut = tau + eps;  // candidate iff d~ - eps <= tau
-#pragma unroll
-    for (int i = 0; i < PER; i++) {
-        const int c = tid + i * MMIDX_BLOCK;
-        const bool pass = (c < C) && ((double)dt[i] <= cut);
-        const u64 mask = __ballot(pass);
-        if (mask) {
-            u32 base = 0;
-            const int leader = __ffsll((long long)mask) - 1;
-            if ((tid & 63) == leader) base = atomicAdd(&s_n, (u32)__popcll(mask));
-            base = __shfl(base, leader);
-            if (pass) {
-                const u32 slot = base + (u32)__popcll(mask & lane_lt);
-                if (slot < MMIDX_CSEL_CAP) cidx[slot] = (u32)c;
-            }
-        }
-    }
-    __syncthreads();
-    const int n = (int)s_n;
+__device__ __forceinline__ void coarse_select_finish(const ApproxSel &A, const int q, const int n, u64 *ckey, u32 *cidx,
+                                                     u64 *sel_k, int *sel_i, u64 *s_k, int *s_i) {
+    const int tid = threadIdx.x, C = A.C, D = A.D, w = A.w;
+    const int R = w + 1;
     const double *qv = A.Q + (size_t)q * D;
-#if MMIDX_SEL_STOP == 3
-    if (tid == 0) A.cells[(size_t)q * w] = n + (int)cidx[0];
-    return;
-#endif
     if (n <= MMIDX_CSEL_CAP) {
         // exact fp64 distance of every candidate in the reference's order (IVFPQ.java:583).  The
         // per-dimension terms (c_j - q_j)^2 are independent and are computed by all threads with
@@ -645,22 +593,56 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_approx(const Appr
         if (tid == 0) A.cdsel[(size_t)q * w] = keyd(ckey[0]);
         return;
 #endif
-        const int Pn = pow2ceil(n < 2 ? 2 : n);
-        for (int i = n + tid; i < Pn; i += MMIDX_BLOCK) {
-            ckey[i] = MMIDX_KEY_MAX;
-            cidx[i] = 0xFFFFFFFFu;
-        }
-        block_bitonic_sort<u32>(ckey, cidx, Pn);
-        for (int i = tid; i < R; i += MMIDX_BLOCK) {
-            sel_k[i] = ckey[i];
-            sel_i[i] = (int)cidx[i];
+        if (n <= 64) {
+            // the usual case: one wave ranks the candidates by (distance, index) in registers (readlane,
+            // no LDS round trips, no barriers) and writes them back in order
+            if (tid < 64) {
+                const bool have = tid < n;
+                const u64 mk = have ? ckey[tid] : MMIDX_KEY_MAX;
+                const u32 mv = have ? cidx[tid] : 0xFFFFFFFFu;
+                int rank = 0;
+#pragma unroll 8
+                for (int j = 0; j < 64; j++) {
+                    const u32 olo = wave_read_u32((u32)mk, j), ohi = wave_read_u32((u32)(mk >> 32), j), ov = wave_read_u32(mv, j);
+                    const u64 ok = ((u64)ohi << 32) | olo;
+                    rank += (ok < mk) || (ok == mk && (ov < mv || (ov == mv && j < tid)));
+                }
+                // (every lane has read its entry before any lane writes: one wave, program order)
+                ckey[rank] = mk;
+                cidx[rank] = mv;
+                if (rank < R) {
+                    sel_k[rank] = mk;
+                    sel_i[rank] = (int)mv;
+                }
+            }
+        } else {
+            const int Pn = pow2ceil(n < 2 ? 2 : n);
+            for (int i = n + tid; i < Pn; i += MMIDX_BLOCK) {
+                ckey[i] = MMIDX_KEY_MAX;
+                cidx[i] = 0xFFFFFFFFu;
+            }
+            block_bitonic_sort<u32>(ckey, cidx, Pn);
+            for (int i = tid; i < R; i += MMIDX_BLOCK) {
+                sel_k[i] = ckey[i];
+                sel_i[i] = (int)cidx[i];
+            }
         }
         __syncthreads();
 #if MMIDX_SEL_STOP == 5
         if (tid == 0) A.cdsel[(size_t)q * w] = keyd(sel_k[0]);
         return;
 #endif
-        if (tid == 0) {
+        // no two equal keys among the w+1 best (the usual case): the answer is the sorted prefix
+        bool plain = false;
+        if (w < 64 && tid < 64) {
+            const bool eq = tid < w && sel_k[tid] == sel_k[tid + 1];
+            plain = __ballot(eq) == 0;
+            if (plain && tid < w) {
+                A.cells[(size_t)q * w + tid] = sel_i[tid];
+                A.cdsel[(size_t)q * w + tid] = keyd(sel_k[tid]);
+            }
+        }
+        if (tid == 0 && !plain) {
             int32_t *out = A.cells + (size_t)q * w;
             double *dout = A.cdsel + (size_t)q * w;
             if (sel_k[w - 1] == sel_k[w]) {
@@ -752,6 +734,367 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_approx(const Appr
         coarse_emit(row, C, w, R, sel_k, sel_i, A.cells + (size_t)q * w);
         for (int t = 0; t < w; t++) A.cdsel[(size_t)q * w + t] = row[A.cells[(size_t)q * w + t]];
     }
+}
+
+template <int PER>
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_approx(const ApproxSel A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *ckey = (u64 *)smem;                       // [CSEL_CAP] thread minima, then exact candidate keys
+    u32 *cidx = (u32 *)(ckey + MMIDX_CSEL_CAP);    // [CSEL_CAP]
+    u64 *sel_k = (u64 *)(cidx + MMIDX_CSEL_CAP);   // [w+1]
+    int *sel_i = (int *)(sel_k + (A.w + 1));       // [w+1]
+    __shared__ u64 s_k[MMIDX_BLOCK / 64];
+    __shared__ int s_i[MMIDX_BLOCK / 64];
+    __shared__ u32 s_n4[4];  // statics total 64 B: keeps the dynamic LDS base 16-byte aligned
+    u32 &s_n = s_n4[0];
+    const int q = blockIdx.x, tid = threadIdx.x, C = A.C, D = A.D, w = A.w;
+    const int R = w + 1;  // host guarantees R <= 256 <= C
+    const float *srow = A.S + (size_t)q * C;
+    const double qn = A.qn[q];
+    // |d~ - d| <= eps for every centroid of this query:
+    //   dot product: 2 (D + 3) 2^-24 (1.01) |q| |c|     (input rounding + D fused multiply-adds)
+    //   fp64 epilogue and exact-sum rounding: 1e-12 (|c|^2 + |q|^2)
+    //   fp32 store of d~: 2^-23 |d~| <= 2^-23 (|c| + |q|)^2
+    const double qnorm = sqrt(qn);
+    const double sumn = A.cnorm_max + qnorm;
+    const double eps = (2.0 * (double)(D + 3) * 0x1p-24 * 1.01 * qnorm * A.cnorm_max + 1e-12 * (A.cn_max + qn) +
+                        0x1p-23 * sumn * sumn) * (1.0 + 1e-9);
+    float dt[PER];  // d~
+    float lmin = __int_as_float(0x7f800000);
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int c = tid + i * MMIDX_BLOCK;
+        const float v = (c < C) ? srow[c] : __int_as_float(0x7f800000);
+        dt[i] = v;
+        lmin = v < lmin ? v : lmin;
+    }
+#if MMIDX_SEL_STOP == 1
+    if (lmin < -1.0f) A.cells[(size_t)q * w] = tid;
+    return;
+#endif
+    // tau: (R-th smallest per-thread minimum of d~) + eps >= the R-th smallest upper bound d~ + eps
+    // R-th smallest of the 256 minima by rank counting (one barrier instead of a 36-stage sort)
+    float *fmin = (float *)ckey;
+    fmin[tid] = lmin < 0.0f ? 0.0f : lmin;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    {
+        const float mine = fmin[tid];
+        int rank = 0;
+#pragma unroll 32
+        for (int t = 0; t < MMIDX_BLOCK; t++) {
+            const float o = fmin[t];
+            rank += (o < mine) || (o == mine && t < tid);
+        }
+        if (rank == R - 1) sel_k[0] = dkey((double)mine);
+    }
+    __syncthreads();
+    const double tau = keyd(sel_k[0]) + eps;
+    __syncthreads();
+#if MMIDX_SEL_STOP == 2
+    if (tau < -1.0) A.cells[(size_t)q * w] = tid;
+    return;
+#endif
+    const u64 lane_lt = (1ull << (tid & 63)) - 1ull;
+    const double cut = tau + eps;  // candidate iff d~ - eps <= tau
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int c = tid + i * MMIDX_BLOCK;
+        const bool pass = (c < C) && ((double)dt[i] <= cut);
+        const u64 mask = __ballot(pass);
+        if (mask) {
+            u32 base = 0;
+            const int leader = __ffsll((long long)mask) - 1;
+            if ((tid & 63) == leader) base = atomicAdd(&s_n, (u32)__popcll(mask));
+            base = __shfl(base, leader);
+            if (pass) {
+                const u32 slot = base + (u32)__popcll(mask & lane_lt);
+                if (slot < MMIDX_CSEL_CAP) cidx[slot] = (u32)c;
+            }
+        }
+    }
+    __syncthreads();
+    coarse_select_finish<PER>(A, q, (int)s_n, ckey, cidx, sel_k, sel_i, s_k, s_i);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// K1e + K1f: the same certified selection without materialising the [nq][C] matrix of d~.
+//
+// K1c writes 4 bytes per (query, centroid) and K1d reads them back -- 1 GiB of HBM traffic per 16384
+// queries at C = 8192 -- although only ~w+3 entries per row matter.  Here the dot products run on the
+// bf16 matrix cores with a two-term split (x = xh + xl + O(2^-16 x); q.c ~ qh.ch + qh.cl + ql.ch, each
+// product exact in fp32), 16x the fp32 MFMA rate, and the epilogue keeps, per group of 8 centroids (the 8
+// columns one lane holds for a row: no cross-lane work), the smallest d~, its position and the runner-up
+// (K1e: [nq][C/8] float2, a quarter of the traffic).  K1f then
+//   * takes tau = (w+1)-th smallest of its 256 per-thread minima + eps16: w+1 distinct centroids have an
+//     exact distance <= their d~ + eps16, so tau bounds the (w+1)-th smallest exact distance;
+//   * nominates the minimum of every group with d~ <= tau + eps16 (any centroid with exact distance <= tau
+//     satisfies that), and all 8 members of a group whose runner-up passes too (rare: 8 (w+1) / C);
+//   * hands the nominees to the shared exact second half.
+// Error bound of the split dot product (|x - xh - xl| <= 2^-16 |x| elementwise, |xl| <= 2^-8 |x|):
+//   |q.c - (qh.ch + qh.cl + ql.ch)| <= 3.1 * 2^-16 |q||c|   (dropped terms, Cauchy-Schwarz)
+//   accumulation of 3D exact products in fp32, any order, at most 2^-22 relative per step (twice the IEEE
+//   unit roundoff: the MFMA's internal summation order and rounding are not documented)
+//                                   <= (3D + 16) 2^-22 |q||c|
+//   d~ = |c|^2 + |q|^2 - 2 S evaluated in fp64 and stored as fp32: 2^-23 (|c| + |q|)^2
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+#define G16_BQ 128     // queries per block (32 per wave)
+#define G16_BC 128     // centroids per tile
+#define G16_KC 128     // k per LDS tile
+#define G16_STRIDE 272 // bytes per LDS row: 256 + 16 (conflict-free 16-byte fragment reads)
+
+// one wave per row: X (fp64) -> bf16 head / tail (zero padded to Dp), optional fp32 copy and squared norm
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_split_bf16(const double *__restrict__ X, __bf16 *__restrict__ H,
+                                                            __bf16 *__restrict__ L, float *__restrict__ X32,
+                                                            double *__restrict__ nrm2, int D, int Dp, long long n) {
+    const long long r = (long long)blockIdx.x * (MMIDX_BLOCK / 64) + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int lane = threadIdx.x & 63;
+    double s = 0.0;
+    for (int j = lane; j < Dp; j += 64) {
+        const double v = j < D ? X[(size_t)r * D + j] : 0.0;
+        const float f = (float)v;
+        const __bf16 h = (__bf16)f;
+        const __bf16 l = (__bf16)(f - (float)h);  // f - h is exact in fp32
+        H[(size_t)r * Dp + j] = h;
+        L[(size_t)r * Dp + j] = l;
+        if (X32 && j < D) X32[(size_t)r * D + j] = f;
+        s += v * v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (nrm2 && lane == 0) nrm2[r] = s * (1.0 + 1e-12);  // only ever used inside error bounds: round up
+}
+
+// row-wise minimum over the 16 lanes that share lane >> 4 (all of them receive it); VALU only
+__device__ __forceinline__ float row16_min(float v) {
+    float o;
+    o = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v = o < v ? o : v;
+    o = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    v = o < v ? o : v;
+    o = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    v = o < v ? o : v;
+    o = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xf, 0xf, true));  // row_mirror
+    v = o < v ? o : v;
+    return v;
+}
+
+// K1e.  grid = (ceil(nq / 128), csplit); block = 4 waves, wave w owns query rows [32 w, 32 w + 32).
+// Output: gpair[q][G = Cp / 8] = (smallest, second smallest | position of the smallest) of d~ over group
+// g = 16 t + fr = centroids { 128 t + fr + 16 ct : ct = 0..7 }.
+__global__ __launch_bounds__(MMIDX_BLOCK, 2) void k_coarse_gmin16(const __bf16 *__restrict__ Qh, const __bf16 *__restrict__ Ql,
+                                                               const __bf16 *__restrict__ Ch, const __bf16 *__restrict__ Cl,
+                                                               const double *__restrict__ cn, const double *__restrict__ qn,
+                                                               float2 *__restrict__ gpair, int Cp, int Dp, int nq, int G) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *Bh = smem, *Bl = smem + G16_BC * G16_STRIDE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int q0 = blockIdx.x * G16_BQ + wave * 32;
+    const int ntiles = Cp / G16_BC;
+    const int t_per = (ntiles + gridDim.y - 1) / gridDim.y;
+    const int t_lo = blockIdx.y * t_per, t_hi = (t_lo + t_per < ntiles) ? t_lo + t_per : ntiles;
+    const int nkc = (Dp + G16_KC - 1) / G16_KC;
+    double qn_r[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int q = q0 + rt * 16 + 4 * fg + r;
+            qn_r[rt][r] = q < nq ? qn[q] : 0.0;
+        }
+    bf16x8 ah[2][4], al[2][4];  // A fragments of one k chunk: [row tile][k step of 32]
+    auto load_a = [&](int kc) {
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++) {
+            int q = q0 + rt * 16 + fr;
+            q = q < nq ? q : nq - 1;
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const int k = kc * G16_KC + ks * 32 + fg * 8;
+                if (k < Dp) {
+                    ah[rt][ks] = *(const bf16x8 *)(Qh + (size_t)q * Dp + k);
+                    al[rt][ks] = *(const bf16x8 *)(Ql + (size_t)q * Dp + k);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        ah[rt][ks][e] = (__bf16)0.0f;
+                        al[rt][ks][e] = (__bf16)0.0f;
+                    }
+                }
+            }
+        }
+    };
+    if (nkc == 1) load_a(0);
+    for (int t = t_lo; t < t_hi; t++) {
+        const int c0 = t * G16_BC;
+        f32x4 acc[2][8];
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int ct = 0; ct < 8; ct++) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kc = 0; kc < nkc; kc++) {
+            const int kbase = kc * G16_KC;
+            const int kw = (Dp - kbase < G16_KC) ? Dp - kbase : G16_KC;  // multiple of 32
+            const int upr = kw >> 3;                                      // 16-byte units per row
+            __syncthreads();  // the previous tile's fragment reads are done
+            for (int u = tid; u < G16_BC * upr; u += MMIDX_BLOCK) {
+                const int row = u / upr, cu = u - row * upr;
+                const size_t src = (size_t)(c0 + row) * Dp + kbase + cu * 8;
+                *(uint4 *)(Bh + row * G16_STRIDE + cu * 16) = *(const uint4 *)(Ch + src);
+                *(uint4 *)(Bl + row * G16_STRIDE + cu * 16) = *(const uint4 *)(Cl + src);
+            }
+            if (nkc > 1) load_a(kc);
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                if (ks * 32 < kw) {  // block-uniform
+#pragma unroll
+                    for (int ct = 0; ct < 8; ct++) {
+                        const int off = (ct * 16 + fr) * G16_STRIDE + (ks * 32 + fg * 8) * 2;
+                        const bf16x8 bh = *(const bf16x8 *)(Bh + off);
+                        const bf16x8 bl = *(const bf16x8 *)(Bl + off);
+#pragma unroll
+                        for (int rt = 0; rt < 2; rt++) {
+                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bh, acc[rt][ct], 0, 0, 0);
+                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bl, acc[rt][ct], 0, 0, 0);
+                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt][ks], bh, acc[rt][ct], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        // epilogue: d~ = |c|^2 + |q|^2 - 2 S.  A group = the 8 columns one lane holds for a row
+        // (c0 + fr + 16 ct, ct = 0..7): its two smallest d~ and the position of the smallest, no cross-lane work
+        double cn_c[8];
+#pragma unroll
+        for (int ct = 0; ct < 8; ct++) cn_c[ct] = cn[c0 + ct * 16 + fr];
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float m1 = __int_as_float(0x7f800000), m2 = m1;
+                int a1 = 0;
+#pragma unroll
+                for (int ct = 0; ct < 8; ct++) {
+                    const float dv = (float)(cn_c[ct] + qn_r[rt][r] - 2.0 * (double)acc[rt][ct][r]);
+                    const bool lt1 = dv < m1;
+                    m2 = lt1 ? m1 : (dv < m2 ? dv : m2);
+                    a1 = lt1 ? ct : a1;
+                    m1 = lt1 ? dv : m1;
+                }
+                m2 = m2 < 0.0f ? 0.0f : m2;
+                // the position of the minimum rides in the 3 low mantissa bits of the runner-up (masked off by the reader)
+                const float m2p = __int_as_float((__float_as_int(m2) & ~7) | a1);
+                const int q = q0 + rt * 16 + 4 * fg + r;
+                if (q < nq) gpair[(size_t)q * G + (size_t)t * 16 + fr] = make_float2(m1, m2p);
+            }
+        }
+    }
+}
+
+// K1f: front end of the selection over group minima (see above); one block per query
+template <int PER>
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_grp(const ApproxSel A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *ckey = (u64 *)smem;                       // [CSEL_CAP] exact candidate keys (second half)
+    u32 *cidx = (u32 *)(ckey + MMIDX_CSEL_CAP);    // [CSEL_CAP]
+    u64 *sel_k = (u64 *)(cidx + MMIDX_CSEL_CAP);   // [w+1]
+    int *sel_i = (int *)(sel_k + (A.w + 1));       // [w+1]
+    __shared__ u64 s_k[MMIDX_BLOCK / 64];
+    __shared__ int s_i[MMIDX_BLOCK / 64];
+    __shared__ u32 s_n4[4];  // 0: candidates (statics total 64 B + 16 B: the dynamic LDS base stays 16-byte aligned)
+    __shared__ float s_tau4[4];
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int C = A.C, w = A.w, G = A.G;
+    const int R = w + 1;  // host guarantees R <= min(G, 256)
+    constexpr int PERG = (PER + 7) / 8;  // groups per thread
+    // the second half stages its difference terms after sel_i; this front end uses that space first
+    float *gsort = (float *)(sel_i + ((A.w + 2) & ~1));  // [256] wave-sorted thread minima
+    const double qn = A.qn[q];
+    const double qnorm = sqrt(qn);
+    const double sumn = A.cnorm_max + qnorm;
+    // (+ 2^-20 (|c| + |q|)^2: the three mantissa bits borrowed from the runner-up)
+    const double eps16 = (2.0 * 3.1 * 0x1p-16 * qnorm * A.cnorm_max + 2.0 * (3.0 * (double)A.Dp + 16.0) * 0x1p-22 * qnorm * A.cnorm_max +
+                          1e-12 * (A.cn_max + qn) + (0x1p-22 + 0x1p-20) * sumn * sumn) * (1.0 + 1e-9);
+    const float inf = __int_as_float(0x7f800000);
+    float m1[PERG], m2[PERG];
+    int a1[PERG];
+    float gm = inf;
+#pragma unroll
+    for (int i = 0; i < PERG; i++) {
+        const int g = tid + i * MMIDX_BLOCK;
+        float2 v = make_float2(inf, inf);
+        if (g < G) v = A.gpair[(size_t)q * G + g];
+        m1[i] = v.x < 0.0f ? 0.0f : v.x;  // exact distances are >= 0
+        a1[i] = __float_as_int(v.y) & 7;
+        m2[i] = __int_as_float(__float_as_int(v.y) & ~7);  // rounded towards zero: never above the true runner-up
+        gm = m1[i] < gm ? m1[i] : gm;
+    }
+    if (tid == 0) s_n4[0] = 0;
+    // ---- tau: the R-th smallest of the 256 thread minima (R distinct centroids lie at or below it) ----
+    int rk = 0;  // rank inside the wave (ties by lane), VALU only
+#pragma unroll 16
+    for (int j = 0; j < 64; j++) {
+        const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gm), j));
+        rk += (o < gm) || (o == gm && j < lane);
+    }
+    gsort[wv * 64 + rk] = gm;
+    __syncthreads();
+    {
+        int grank = rk;
+#pragma unroll
+        for (int ow = 0; ow < MMIDX_BLOCK / 64; ow++) {
+            if (ow == wv) continue;
+            // elements of wave ow that precede mine: value <, or == and ow < wv
+            const float *lst = gsort + ow * 64;
+            int lo_ = 0, hi_ = 64;  // first index whose element does NOT precede mine
+            while (lo_ < hi_) {
+                const int mid = (lo_ + hi_) >> 1;
+                const float o = lst[mid];
+                const bool prec = (o < gm) || (o == gm && ow < wv);
+                if (prec) lo_ = mid + 1;
+                else hi_ = mid;
+            }
+            grank += lo_;
+        }
+        if (grank == R - 1) s_tau4[0] = gm;
+    }
+    __syncthreads();
+    // any centroid with exact distance <= tau has d~ <= tau + eps16
+    const double cut = ((double)s_tau4[0] + eps16) + eps16;
+    // ---- candidates: the minimum of every group at or under the cut; the whole group when its runner-up is too
+    const u64 lane_lt = (1ull << lane) - 1ull;
+    auto push = [&](bool pass, int c) {
+        const u64 mask = __ballot(pass);
+        if (mask) {
+            u32 base = 0;
+            const int leader = __ffsll((long long)mask) - 1;
+            if (lane == leader) base = atomicAdd(&s_n4[0], (u32)__popcll(mask));
+            base = __shfl(base, leader);
+            if (pass) {
+                const u32 slot = base + (u32)__popcll(mask & lane_lt);
+                if (slot < MMIDX_CSEL_CAP) cidx[slot] = (u32)c;
+            }
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < PERG; i++) {
+        const int g = tid + i * MMIDX_BLOCK;
+        const int cb = (g >> 4) * G16_BC + (g & 15);  // column ct of the group is centroid cb + 16 ct
+        const bool hot = (double)m1[i] <= cut;
+        push(hot && cb + 16 * a1[i] < C, cb + 16 * a1[i]);
+        const bool all = hot && (double)m2[i] <= cut;
+        if (__ballot(all)) {  // rare: two of the w+1 nearest in one group of 8
+#pragma unroll
+            for (int ct = 0; ct < 8; ct++) push(all && ct != a1[i] && cb + 16 * ct < C, cb + 16 * ct);
+        }
+    }
+    __syncthreads();
+    coarse_select_finish<PER>(A, q, (int)s_n4[0], ckey, cidx, sel_k, sel_i, s_k, s_i);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1179,25 +1522,6 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
 // ties, or a segment 0 that is not representative) are not handled here: the item is appended to a
 // fallback list and a K3 launch over that list redoes it, so results never depend on the heuristics.
 // ------------------------------------------------------------------------------------------------
-// wave64 helpers that stay in the VALU (DPP / readlane): inside K3h's scan loop the LDS pipe is saturated
-// by the table gather, and every ds_bpermute-based __shfl would queue behind it
-__device__ __forceinline__ u32 wave_incl_scan_u32(u32 x) {
-    u32 v = x;  // Hillis-Steele inside each row of 16 lanes, then the row totals (gfx9 row broadcasts)
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
-    return v;
-}
-__device__ __forceinline__ u32 wave_read_u32(u32 x, int l) { return (u32)__builtin_amdgcn_readlane((int)x, l); }
-__device__ __forceinline__ double wave_read_f64(double x, int l) {
-    const u64 b = (u64)__double_as_longlong(x);
-    const u32 lo_ = wave_read_u32((u32)b, l), hi_ = wave_read_u32((u32)(b >> 32), l);
-    return __longlong_as_double((long long)(((u64)hi_ << 32) | lo_));
-}
-
 #define MMIDX_HB 256
 #define MMIDX_HKEEP 256  // most entries one item may emit (>= K1 required: the host checks; the pool has room for them)
 #define MMIDX_HPOS 4     // appended positions re-evaluated per thread per round at the end
