@@ -490,7 +490,7 @@ int launch_hist_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t st) {
 // Returns 1 when K3h does not apply (the caller uses K3).
 int launch_scan_hist(mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 grid, hipStream_t st) {
     const bool ok = h->code_bytes == 1 && (h->m == 8 || h->m == 16 || h->m == 32) && !P.sdc_tt && pl.K1 <= MMIDX_HKEEP &&
-                    !P.order && !P.xcd_remap;
+                    !P.order && !P.xcd_remap && pl.chunk <= (1 << 24);
     if (!ok) return 1;
     const size_t fixed = (size_t)h->m * h->ks * 8 + (h->transform ? 2 : 1) * (size_t)h->D * 8 + 64 + 16 + MMIDX_HB * 4 + 32;
     // position buffer: what is left of a quarter of the CU's LDS (4 blocks per CU), within [768, 1536] entries
@@ -888,6 +888,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
         }
     }
     MergeParams M{};
+    M.T = h->ws_T.p;
     M.pool_cnt = h->ws_pcnt.p;
     M.pool_key = h->ws_pkey.p;
     M.pool_val = h->ws_pval.p;
@@ -904,7 +905,10 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
     M.flag_out = h->ws_flag.p;
     M.pdist = d_pdist;
     M.pkey = d_pkey;
-    const size_t mlds = (size_t)MMIDX_MCAP * 16;
+    int mcap = 512;
+    while (mcap < 2 * pl.K1) mcap <<= 1;  // <= 2048
+    M.cap = mcap;
+    const size_t mlds = (size_t)mcap * 16 + ((ivf && P.w <= 1024) ? (size_t)P.w * 8 : 0);
     HIPCK(hipFuncSetAttribute((const void *)k_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
     hipLaunchKernelGGL(k_merge, dim3((unsigned)nq), dim3(MMIDX_BLOCK), mlds, st, M);
     HIPCK(hipGetLastError());

@@ -601,8 +601,7 @@ __device__ __forceinline__ void coarse_select_finish(const ApproxSel &A, const i
                 const u64 mk = have ? ckey[tid] : MMIDX_KEY_MAX;
                 const u32 mv = have ? cidx[tid] : 0xFFFFFFFFu;
                 int rank = 0;
-#pragma unroll 8
-                for (int j = 0; j < 64; j++) {
+                for (int j = 0; j < n; j++) {  // (entries past n would never precede a real one)
                     const u32 olo = wave_read_u32((u32)mk, j), ohi = wave_read_u32((u32)(mk >> 32), j), ov = wave_read_u32(mv, j);
                     const u64 ok = ((u64)ohi << 32) | olo;
                     rank += (ok < mk) || (ok == mk && (ov < mv || (ov == mv && j < tid)));
@@ -1094,6 +1093,10 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_grp(const ApproxS
         }
     }
     __syncthreads();
+#if MMIDX_SEL_STOP == 3
+    if (tid == 0) A.cells[(size_t)q * w] = (int)s_n4[0] + (int)cidx[0];
+    return;
+#endif
     coarse_select_finish<PER>(A, q, (int)s_n4[0], ckey, cidx, sel_k, sel_i, s_k, s_i);
 }
 
@@ -1682,7 +1685,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
         if (pass) {
             atomicAdd(hist + b, 1u);
             const u32 slot = wcnt + (u32)__popcll(mask & lane_lt);
-            if (slot < capw) mybuf[slot] = (u32)i;
+            if (slot < capw) mybuf[slot] = ((u32)b << 24) | (u32)(i - c0);  // chunk <= 2^24 codes: the host checks
         }
         wcnt += (u32)__popcll(mask);  // > capw: overflow, seen at the end
         if (refresh) {
@@ -1714,8 +1717,8 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
         overflow |= c > capw;
         woff[i + 1] = woff[i] + (c > capw ? capw : c);
     }
-    const u32 n_app = woff[NT / 64];
 #if MMIDX_HIST_DEBUG
+    const u32 n_app = woff[NT / 64];
     if (tid == 0) {
         atomicAdd(P.fb_count + 1, overflow ? 1u : 0u);
         atomicAdd(P.fb_count + 2, n_app);
@@ -1757,58 +1760,42 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
         }
     };
     if (!overflow) {
-        // ---- re-evaluate the appended positions, keep those under the final bucket ----------------
-        for (u32 e0 = 0; e0 < n_app; e0 += MMIDX_HPOS * NT) {
-            u32 pos[MMIDX_HPOS];
-            CodeVec<M, unsigned char> cv[MMIDX_HPOS];
-#pragma unroll
-            for (int j = 0; j < MMIDX_HPOS; j++) {
-                const u32 e = e0 + (u32)(j * NT + tid);
-                u32 pv = 0xFFFFFFFFu;
-                if (e < n_app) {
-                    const int w_ = (e >= woff[1]) + (e >= woff[2]) + (e >= woff[3]);
-                    const u32 o_ = w_ == 0 ? woff[0] : (w_ == 1 ? woff[1] : (w_ == 2 ? woff[2] : woff[3]));
-                    pv = posbuf[(size_t)w_ * capw + (e - o_)];
-                }
-                pos[j] = pv;
-            }
-#pragma unroll
-            for (int j = 0; j < MMIDX_HPOS; j++)
-                if (e0 + (u32)(j * NT) < n_app) cv[j].load(codes + (size_t)(pos[j] != 0xFFFFFFFFu ? pos[j] : (u32)c0) * M);
-            // one pool reservation per wave per round: the kept entries wait in registers
-            u64 kk[MMIDX_HPOS];
-            u32 nk = 0, emit_bits = 0;
-#pragma unroll
-            for (int j = 0; j < MMIDX_HPOS; j++) {
-                kk[j] = 0;
-                if (e0 + (u32)(j * NT) < n_app) {  // block-uniform
-                    const double dd = exact(cv[j]);
-                    const bool keep = pos[j] != 0xFFFFFFFFu && bucket(dd) <= Tb;
-                    const u64 key = dkey(dd);
-                    if (keep) kmax = key > kmax ? key : kmax;
-                    kk[j] = key;
-                    if (keep && key <= Tg) {
-                        emit_bits |= 1u << j;
-                        nk++;
-                    }
-                }
-            }
-            const u32 incl = wave_incl_scan_u32(nk);
-            const u32 wtot = wave_read_u32(incl, 63);
-            if (wtot) {  // wave-uniform
+        // ---- the appended entries carry their bucket: pick those under the final one (each wave its own
+        //      region), then evaluate only them -- kept_total <= HKEEP = one per thread -------------------
+        u32 *keptpos = hist;  // the histogram is dead (every wave has derived the final bucket): barrier first
+        __syncthreads();
+        const u32 mine = s_cnt[wv];  // <= capw here
+        for (u32 e0 = 0; e0 < mine; e0 += 64) {
+            const u32 e = e0 + (u32)lane;
+            const u32 v = e < mine ? mybuf[e] : 0xFFFFFFFFu;
+            const bool keep = e < mine && (int)(v >> 24) <= Tb;
+            const u64 mask = __ballot(keep);
+            if (mask) {
                 u32 base = 0;
-                if (lane == 0) base = atomicAdd(P.pool_cnt + q, wtot);
-                u32 slot = wave_read_u32(base, 0) + incl - nk;
-#pragma unroll
-                for (int j = 0; j < MMIDX_HPOS; j++) {
-                    if (emit_bits & (1u << j)) {
-                        if (slot < (u32)P.poolq) {
-                            P.pool_key[(size_t)q * P.poolq + slot] = kk[j];
-                            P.pool_val[(size_t)q * P.poolq + slot] = ((u64)pr << 32) | (u64)pos[j];
-                        }
-                        slot++;
-                    }
-                }
+                const int leader = __ffsll((long long)mask) - 1;
+                if (lane == leader) base = atomicAdd(s_cnt + 6, (u32)__popcll(mask));
+                base = wave_read_u32(base, leader);
+                if (keep) keptpos[base + (u32)__popcll(mask & lane_lt)] = v & 0xFFFFFFu;
+            }
+        }
+        __syncthreads();
+        const bool have = (u32)tid < kept_total;  // == s_cnt[6]
+        const u32 p = have ? (u32)c0 + keptpos[tid] : (u32)c0;
+        CodeVec<M, unsigned char> cv;
+        cv.load(codes + (size_t)p * M);
+        const double dd = exact(cv);
+        const u64 key = dkey(dd);
+        if (have) kmax = key;
+        const u32 nk = (have && key <= Tg) ? 1u : 0u;
+        const u32 incl = wave_incl_scan_u32(nk);
+        const u32 wtot = wave_read_u32(incl, 63);
+        if (wtot) {  // wave-uniform: one pool reservation per wave
+            u32 base = 0;
+            if (lane == 0) base = atomicAdd(P.pool_cnt + q, wtot);
+            const u32 slot = wave_read_u32(base, 0) + incl - nk;
+            if (nk && slot < (u32)P.poolq) {
+                P.pool_key[(size_t)q * P.poolq + slot] = key;
+                P.pool_val[(size_t)q * P.poolq + slot] = ((u64)pr << 32) | (u64)p;
             }
         }
     } else {
@@ -2593,8 +2580,9 @@ __global__ void k_pair_scatter(const int32_t *__restrict__ cells, int w, int ran
 // mode 0: final results (iid / dist / count / tie flag); mode 1: sorted partial list for the
 // cross-shard merge (pdist, pkey = probe_rank << 32 | iid, pcount).
 // ------------------------------------------------------------------------------------------------
-#define MMIDX_MCAP 4096
+#define MMIDX_MCAP 2048  // > K1 (k <= 1023): the chunked fallback needs room beyond the kept prefix
 struct MergeParams {
+    const u64 *T;            // [nq] final thresholds (null: no filtering)
     const u32 *pool_cnt;
     const u64 *pool_key;
     const u64 *pool_val;
@@ -2603,6 +2591,7 @@ struct MergeParams {
     const int64_t *list_off;
     const int32_t *ids;
     int w, k, mode;
+    int cap;                 // LDS entries (power of two, > k + 1)
     int32_t *iid_out;        // [nq][k]
     double *dist_out;        // [nq][k]
     int32_t *count_out;      // [nq]
@@ -2613,32 +2602,104 @@ struct MergeParams {
 
 __global__ __launch_bounds__(MMIDX_BLOCK) void k_merge(const MergeParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64 *key = (u64 *)smem;          // [MCAP]
-    u64 *val = key + MMIDX_MCAP;     // [MCAP]
+    const int CAP = P.cap;           // power of two, > K1
+    u64 *key = (u64 *)smem;          // [CAP]
+    u64 *val = key + CAP;            // [CAP]
+    int64_t *s_off = (int64_t *)(val + CAP);  // [w] start of every probed list (the id lookups at the end)
     const int q = blockIdx.x, tid = threadIdx.x;
     const int K1 = P.k + 1;
+    __shared__ u32 s_m;
     int n = (int)P.pool_cnt[q];
     if (n > P.poolq) n = P.poolq;
     const u64 *pk = P.pool_key + (size_t)q * P.poolq;
     const u64 *pv = P.pool_val + (size_t)q * P.poolq;
-    int kept = 0, consumed = 0;
-    do {
-        int take = n - consumed;
-        if (take > MMIDX_MCAP - kept) take = MMIDX_MCAP - kept;
-        for (int i = tid; i < take; i += MMIDX_BLOCK) {
-            key[kept + i] = pk[consumed + i];
-            val[kept + i] = pv[consumed + i];
+    // Entries above the query's final threshold cannot be among the K1 best (at least K1 candidates are at or
+    // below it): drop them while loading.  What is left is K1 plus a few entries, small enough to be ordered
+    // by counting ranks -- one pass of broadcast LDS reads, no 36-stage sorting network.
+    const u64 T = P.T ? __hip_atomic_load(P.T + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : MMIDX_KEY_MAX;
+    if (tid == 0) s_m = 0;
+    const bool offs_in_lds = P.cells && P.w <= 1024;  // (the host sized the LDS accordingly)
+    if (offs_in_lds)
+        for (int t = tid; t < P.w; t += MMIDX_BLOCK) s_off[t] = P.list_off[P.cells[(size_t)q * P.w + t]];
+    auto list_start = [&](int rank) -> int64_t {
+        if (offs_in_lds) return s_off[rank];
+        return P.list_off[P.cells ? P.cells[(size_t)q * P.w + rank] : 0];
+    };
+    __syncthreads();
+    {
+        const u64 lane_lt = (1ull << (tid & 63)) - 1ull;
+        for (int base0 = 0; base0 < n; base0 += MMIDX_BLOCK) {
+            const int e = base0 + tid;
+            u64 kk = MMIDX_KEY_MAX, vv = 0;
+            if (e < n) {  // both loads in flight together
+                kk = pk[e];
+                vv = pv[e];
+            }
+            const bool pass = e < n && kk <= T;
+            const u64 mask = __ballot(pass);
+            if (mask) {
+                u32 base = 0;
+                const int leader = __ffsll((long long)mask) - 1;
+                if ((tid & 63) == leader) base = atomicAdd(&s_m, (u32)__popcll(mask));
+                base = __shfl(base, leader);
+                if (pass) {
+                    const u32 slot = base + (u32)__popcll(mask & lane_lt);
+                    if (slot < (u32)CAP) {
+                        key[slot] = kk;
+                        val[slot] = vv;
+                    }
+                }
+            }
         }
-        const int filled = kept + take;
-        const int Pn = pow2ceil(filled < 2 ? 2 : filled);
-        for (int i = filled + tid; i < Pn; i += MMIDX_BLOCK) {
+    }
+    __syncthreads();
+    const int m = (int)s_m;
+    int kept = 0;
+    if (m <= MMIDX_BLOCK) {
+        const bool have = tid < m;
+        const u64 mk = have ? key[tid] : MMIDX_KEY_MAX, mv = have ? val[tid] : MMIDX_KEY_MAX;
+        int rank = 0;
+        for (int j = 0; j < m; j++) {
+            const u64 ok = key[j], ov = val[j];
+            rank += (ok < mk) || (ok == mk && ov < mv);
+        }
+        __syncthreads();  // every entry has been read
+        if (have) {
+            key[rank] = mk;
+            val[rank] = mv;
+        }
+        __syncthreads();
+        kept = m < K1 ? m : K1;
+    } else if (m <= CAP) {
+        const int Pn = pow2ceil(m);
+        for (int i = m + tid; i < Pn; i += MMIDX_BLOCK) {
             key[i] = MMIDX_KEY_MAX;
             val[i] = MMIDX_KEY_MAX;
         }
         block_bitonic_sort<u64>(key, val, Pn);
-        consumed += take;
-        kept = filled < K1 ? filled : K1;
-    } while (consumed < n);
+        kept = m < K1 ? m : K1;
+    } else {
+        // more survivors than the buffer holds: chunked selection over the whole pool
+        int consumed = 0;
+        do {
+            int take = n - consumed;
+            if (take > CAP - kept) take = CAP - kept;
+            __syncthreads();
+            for (int i = tid; i < take; i += MMIDX_BLOCK) {
+                key[kept + i] = pk[consumed + i];
+                val[kept + i] = pv[consumed + i];
+            }
+            const int filled = kept + take;
+            const int Pn = pow2ceil(filled < 2 ? 2 : filled);
+            for (int i = filled + tid; i < Pn; i += MMIDX_BLOCK) {
+                key[i] = MMIDX_KEY_MAX;
+                val[i] = MMIDX_KEY_MAX;
+            }
+            block_bitonic_sort<u64>(key, val, Pn);
+            consumed += take;
+            kept = filled < K1 ? filled : K1;
+        } while (consumed < n);
+    }
     const int total = kept;  // min(n, K1), sorted by (key, offer order)
     const int cnt = total < P.k ? total : P.k;
     if (P.mode == 1) {
@@ -2649,8 +2710,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_merge(const MergeParams P) {
                 const u64 v = val[i];
                 const int rank = (int)(v >> 32);
                 const u32 pos = (u32)v;
-                const int cell = P.cells ? P.cells[(size_t)q * P.w + rank] : 0;
-                const int iid = P.ids[P.list_off[cell] + pos];
+                const int iid = P.ids[list_start(rank) + pos];
                 dd = keyd(key[i]);
                 kk = (long long)(((u64)rank << 32) | (u32)iid);
             }
@@ -2673,8 +2733,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_merge(const MergeParams P) {
             const u64 v = val[src];
             const int rank = (int)(v >> 32);
             const u32 pos = (u32)v;
-            const int cell = P.cells ? P.cells[(size_t)q * P.w + rank] : 0;
-            iid = P.ids[P.list_off[cell] + pos];
+            iid = P.ids[list_start(rank) + pos];
             dd = keyd(ki);
         }
         P.iid_out[(size_t)q * P.k + i] = iid;
