@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MMIDX_ABI_VERSION 1
+#define MMIDX_ABI_VERSION 2
 
 typedef struct mmidx_index mmidx_index; /* opaque handle: one index on one GPU */
 
@@ -141,14 +141,16 @@ int mmidx_search_sdc(mmidx_index *h, int k, int64_t nq, const int32_t *iids, int
 
 /* ---- sharded search (one process per GPU; lists partitioned across ranks) ---------------------
  * mmidx_coarse_device: computeNearestCoarseIndices IVFPQ.java:575-601 for nq queries ->
- *   d_cells_out[nq][w] (nearest first).
+ *   d_cells_out[nq][w] (nearest first) and, when d_cdist_out is not NULL, the exact squared distance
+ *   of every selected cell, d_cdist_out[nq][w] (what pass B's coarse bound needs: ranks that did not
+ *   run the coarse stage for a query receive it with the all-gather of the cells).
  * mmidx_search_partial_device: scan of this shard's lists for the given probe cells; writes the
  *   shard's best k+1 candidates per query, sorted: d_pdist[nq][k+1] (fp64), d_pkey[nq][k+1]
  *   (int64 = probe_rank << 32 | iid -- the reference's offer order), d_pcount[nq].
  * mmidx_merge_partials_device: merges nshards partial lists laid out [nshards][nq][k+1] (as an
  *   all-gather delivers them) into final results; no index handle needed. */
 int mmidx_coarse_device(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells_out,
-                        void *stream);
+                        double *d_cdist_out, void *stream);
 int mmidx_search_partial_device(mmidx_index *h, int k, int64_t nq, const double *dQ,
                                 const int32_t *d_cells, double *d_pdist, int64_t *d_pkey,
                                 int32_t *d_pcount, void *stream);
@@ -157,12 +159,13 @@ int mmidx_search_partial_device(mmidx_index *h, int k, int64_t nq, const double 
  *   query (the (k+1)-th best distance so far as a double, +inf when there are fewer candidates);
  *   the host MIN-all-reduces that array over ranks; pass B imports it, drops every probe whose
  *   coarse bound exceeds it, scans the rest and writes the sorted partial lists.  pass B must follow
- *   pass A on the same handle with the same (k, nq, dQ, d_cells). */
+ *   pass A on the same handle with the same (k, nq, dQ, d_cells).  d_cdist (may be NULL: the bound
+ *   is then evaluated from the centroids) = the distances mmidx_coarse_device delivered. */
 int mmidx_shard_pass_a_device(mmidx_index *h, int k, int64_t nq, const double *dQ,
                               const int32_t *d_cells, double *d_T_out, void *stream);
 int mmidx_shard_pass_b_device(mmidx_index *h, int k, int64_t nq, const double *dQ,
-                              const int32_t *d_cells, const double *d_T_in, double *d_pdist,
-                              int64_t *d_pkey, int32_t *d_pcount, void *stream);
+                              const int32_t *d_cells, const double *d_cdist, const double *d_T_in,
+                              double *d_pdist, int64_t *d_pkey, int32_t *d_pcount, void *stream);
 int mmidx_merge_partials_device(int device, int k, int64_t nq, int nshards, const double *d_pdist,
                                 const int64_t *d_pkey, const int32_t *d_pcount,
                                 int32_t *d_iid_out, double *d_dist_out, int32_t *d_count_out,

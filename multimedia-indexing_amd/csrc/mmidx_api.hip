@@ -673,7 +673,7 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
 // one sub-batch (nq <= plan.qb) entirely on device
 int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq, const double *dQ, const int32_t *d_cells_in,
                         int mode, int32_t *d_iid, double *d_dist, int32_t *d_cnt, double *d_pdist, long long *d_pkey,
-                        int phase, double *d_T_io, hipStream_t st, const double *sdc_tt = nullptr) {
+                        int phase, double *d_T_io, hipStream_t st, const double *sdc_tt = nullptr, const double *d_cdsel_in = nullptr) {
     // phase 0: whole search.  Sharded search splits it so that the thresholds can be MIN-reduced
     // across ranks in between: phase 1 = setup + pass A + export T, phase 2 = import T + pass B + merge.
     const int ivf = h->kind == MMIDX_KIND_IVFPQ;
@@ -834,7 +834,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
             PB.Q = dQ;
             PB.coarse = h->d_coarse;
             PB.T = h->ws_T.p;
-            PB.cdsel = (ivf && !d_cells_in && h->cdsel_valid) ? h->ws_cdsel.p : nullptr;
+            PB.cdsel = (ivf && !d_cells_in && h->cdsel_valid) ? h->ws_cdsel.p : ((ivf && d_cells_in) ? d_cdsel_in : nullptr);
             PB.cdist = (ivf && !d_cells_in && !h->cdsel_valid) ? h->ws_cdist.p : nullptr;
             PB.list_off = h->d_off;
             PB.rmax = h->rmax;
@@ -1502,7 +1502,7 @@ int mmidx_search_sdc(mmidx_index *h, int k, int64_t nq, const int32_t *iids, int
     return MMIDX_OK;
 }
 
-int mmidx_coarse_device(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells_out, void *stream) {
+int mmidx_coarse_device(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells_out, double *d_cdist_out, void *stream) {
     int rc = check_ready(h);
     if (rc) return rc;
     if (h->kind != MMIDX_KIND_IVFPQ) return fail(MMIDX_ERR_INVALID_ARG, "PQ index has no coarse quantizer");
@@ -1516,6 +1516,17 @@ int mmidx_coarse_device(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d
         const int64_t nb = std::min(qb, nq - q0);
         rc = run_coarse(h, nb, dQ + (size_t)q0 * h->D, d_cells_out + (size_t)q0 * h->w, st);
         if (rc) return rc;
+        if (d_cdist_out) {
+            double *dst = d_cdist_out + (size_t)q0 * h->w;
+            if (h->cdsel_valid) {
+                HIPCK(hipMemcpyAsync(dst, h->ws_cdsel.p, (size_t)nb * h->w * 8, hipMemcpyDeviceToDevice, st));
+            } else {
+                const long long tot = (long long)nb * h->w;
+                hipLaunchKernelGGL(k_gather_cdist, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->ws_cdist.p,
+                                   d_cells_out + (size_t)q0 * h->w, dst, h->C, h->w, tot);
+                HIPCK(hipGetLastError());
+            }
+        }
     }
     return MMIDX_OK;
 }
@@ -1531,8 +1542,8 @@ int mmidx_search_partial_device(mmidx_index *h, int k, int64_t nq, const double 
 }
 
 // two-phase sharded search: thresholds are exchanged between the phases (MIN all-reduce)
-static int shard_phase(mmidx_index *h, int k, int64_t nq, const double *dQ, const int32_t *d_cells, int phase, double *d_T,
-                       double *d_pdist, int64_t *d_pkey, int32_t *d_pcount, void *stream) {
+static int shard_phase(mmidx_index *h, int k, int64_t nq, const double *dQ, const int32_t *d_cells, const double *d_cdist, int phase,
+                       double *d_T, double *d_pdist, int64_t *d_pkey, int32_t *d_pcount, void *stream) {
     if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
     if (nq > 0 && (!dQ || !d_T)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
     if (phase == 2 && nq > 0 && (!d_pdist || !d_pkey || !d_pcount)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
@@ -1554,16 +1565,16 @@ static int shard_phase(mmidx_index *h, int k, int64_t nq, const double *dQ, cons
     if (rc) return rc;
     if (nq > pl.qb) return fail(MMIDX_ERR_UNSUPPORTED, "shard phases take at most %lld queries per call for this index", (long long)pl.qb);
     return search_batch_device(h, pl, k, nq, dQ, ivf ? d_cells : nullptr, 1, nullptr, nullptr, d_pcount, d_pdist, (long long *)d_pkey, phase,
-                               d_T, (hipStream_t)stream);
+                               d_T, (hipStream_t)stream, nullptr, ivf ? d_cdist : nullptr);
 }
 
 int mmidx_shard_pass_a_device(mmidx_index *h, int k, int64_t nq, const double *dQ, const int32_t *d_cells, double *d_T_out, void *stream) {
-    return shard_phase(h, k, nq, dQ, d_cells, 1, d_T_out, nullptr, nullptr, nullptr, stream);
+    return shard_phase(h, k, nq, dQ, d_cells, nullptr, 1, d_T_out, nullptr, nullptr, nullptr, stream);
 }
 
-int mmidx_shard_pass_b_device(mmidx_index *h, int k, int64_t nq, const double *dQ, const int32_t *d_cells, const double *d_T_in,
-                              double *d_pdist, int64_t *d_pkey, int32_t *d_pcount, void *stream) {
-    return shard_phase(h, k, nq, dQ, d_cells, 2, (double *)d_T_in, d_pdist, d_pkey, d_pcount, stream);
+int mmidx_shard_pass_b_device(mmidx_index *h, int k, int64_t nq, const double *dQ, const int32_t *d_cells, const double *d_cdist,
+                              const double *d_T_in, double *d_pdist, int64_t *d_pkey, int32_t *d_pcount, void *stream) {
+    return shard_phase(h, k, nq, dQ, d_cells, d_cdist, 2, (double *)d_T_in, d_pdist, d_pkey, d_pcount, stream);
 }
 
 int mmidx_merge_partials_device(int device, int k, int64_t nq, int nshards, const double *d_pdist, const int64_t *d_pkey,

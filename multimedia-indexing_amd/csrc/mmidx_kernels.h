@@ -2525,6 +2525,14 @@ __device__ __forceinline__ bool pair_keep(const PairBound &B, long long e, int q
     return nonempty & !prune;
 }
 
+// cdist_out[q][r] = dist[q][cells[q][r]] (exact coarse path: the selected cells' distances for other ranks)
+__global__ void k_gather_cdist(const double *__restrict__ dist, const int32_t *__restrict__ cells, double *__restrict__ out, int C, int w,
+                               long long total) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int c = cells[e];
+    out[e] = c >= 0 ? dist[(size_t)(e / w) * C + c] : 0.0;
+}
 __global__ void k_pair_hist(const int32_t *__restrict__ cells, int w, int rank_lo, long long npairs,
                             int32_t *__restrict__ cnt, unsigned char *__restrict__ keep, const PairBound B) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;

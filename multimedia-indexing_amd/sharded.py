@@ -6,7 +6,7 @@ the reference's offer order (probe rank, position in list) stays well defined.  
 replicated (8.25 MiB).  Per batch:
 
   1. coarse top-w for a 1/world slice of the queries            (mmidx_coarse_device)
-  2. all-gather of the probe cells                               (RCCL, nq*w*4 bytes)
+  2. all-gather of the probe cells and their coarse distances    (RCCL, nq*w*12 bytes)
   3. pass A: scan of probe rank 0 where it is local -> thresholds  (mmidx_shard_pass_a_device)
   4. MIN all-reduce of the thresholds                             (RCCL, nq*8 bytes)
   5. pass B: remaining local probes under the global thresholds   (mmidx_shard_pass_b_device)
@@ -75,11 +75,13 @@ class HipShardEngine:
         return self.torch.cuda.current_stream().cuda_stream
 
     def coarse(self, Qs):
+        """probe cells [n][w] (nearest first) and the exact squared distance of each [n][w]"""
         t = self.torch
         cells = t.empty(Qs.shape[0], self.w, dtype=t.int32, device=Qs.device)
+        cdist = t.empty(Qs.shape[0], self.w, dtype=t.float64, device=Qs.device)
         if Qs.shape[0]:
-            N.check(self.L.mmidx_coarse_device(self.h, Qs.shape[0], Qs.data_ptr(), cells.data_ptr(), self._stream()))
-        return cells
+            N.check(self.L.mmidx_coarse_device(self.h, Qs.shape[0], Qs.data_ptr(), cells.data_ptr(), cdist.data_ptr(), self._stream()))
+        return cells, cdist
 
     def pass_a(self, k, Q, cells):
         """scan probe rank 0 on this shard; returns the shard's thresholds [nq] float64 (+inf = none)"""
@@ -89,14 +91,15 @@ class HipShardEngine:
                                                  self._stream()))
         return T
 
-    def pass_b(self, k, Q, cells, T):
+    def pass_b(self, k, Q, cells, cdist, T):
         """remaining probes with the cross-shard thresholds; returns sorted partial lists"""
         t = self.torch
         nq, K1 = Q.shape[0], k + 1
         pd = t.empty(nq, K1, dtype=t.float64, device=Q.device)
         pk = t.empty(nq, K1, dtype=t.int64, device=Q.device)
         pc = t.empty(nq, dtype=t.int32, device=Q.device)
-        N.check(self.L.mmidx_shard_pass_b_device(self.h, k, nq, Q.data_ptr(), cells.data_ptr(), T.data_ptr(), pd.data_ptr(),
+        N.check(self.L.mmidx_shard_pass_b_device(self.h, k, nq, Q.data_ptr(), cells.data_ptr(),
+                                                 cdist.data_ptr() if cdist is not None else None, T.data_ptr(), pd.data_ptr(),
                                                  pk.data_ptr(), pc.data_ptr(), self._stream()))
         return pd, pk, pc
 
@@ -128,7 +131,7 @@ class ShardedIVFPQ:
     """computeNearestNeighbors over `world` shards (IVFPQ.computeKnnIVFADC, IVFPQ.java:408-450).
 
     Collectives per batch (B queries, K1 = k + 1):
-      all-gather  probe cells        B*w*4 bytes
+      all-gather  probe cells        B*w*4 bytes  (+ their exact coarse distances, B*w*8: pass B's coarse bound)
       all-reduce  thresholds (MIN)   B*8 bytes            -- lets every shard prune with the global bound
       all-to-all  partial lists      B*K1*16 bytes/rank   -- query q is merged on rank q // per
       all-gather  results            B*k*12 bytes
@@ -172,15 +175,17 @@ class ShardedIVFPQ:
         per = (nq + W - 1) // W
         q0 = min(self.rank * per, nq)
         q1 = min(q0 + per, nq)
-        cells_sl = self.engine.coarse(Q[q0:q1])
+        cells_sl, cdist_sl = self.engine.coarse(Q[q0:q1])
         if q1 - q0 < per:  # pad the slice so that every rank contributes the same shape
             pad = torch.full((per - (q1 - q0), cells_sl.shape[1]), -1, dtype=cells_sl.dtype, device=cells_sl.device)
             cells_sl = torch.cat([cells_sl, pad], 0)
+            cdist_sl = torch.cat([cdist_sl, torch.zeros(pad.shape, dtype=cdist_sl.dtype, device=cdist_sl.device)], 0)
         cells = self._all_gather(cells_sl).reshape(W * per, -1)[:nq].contiguous()
+        cdist = self._all_gather(cdist_sl).reshape(W * per, -1)[:nq].contiguous()
         T = self.engine.pass_a(k, Q, cells)
         if W > 1 or self.force:
             self.dist.all_reduce(T, op=self.dist.ReduceOp.MIN, group=self.group)
-        pd, pk, pc = self.engine.pass_b(k, Q, cells, T)
+        pd, pk, pc = self.engine.pass_b(k, Q, cells, cdist, T)
         if W == 1 and not self.force:  # (gather is moot: the one rank owns every query)
             return self.engine.merge(k, pd.unsqueeze(0), pk.unsqueeze(0), pc.unsqueeze(0))
         # owner merge: pad the query axis to W*per, view as [W][per][...], exchange, merge my slice

@@ -295,7 +295,7 @@ def _coarse_cells(mi, ix, Q):
     dQ = torch.tensor(np.ascontiguousarray(Q), dtype=torch.float64, device="cuda")
     w = ix.getW()
     cells = torch.empty(dQ.shape[0], w, dtype=torch.int32, device="cuda")
-    nat.check(mi.lib().mmidx_coarse_device(ix._h, dQ.shape[0], dQ.data_ptr(), cells.data_ptr(), None))
+    nat.check(mi.lib().mmidx_coarse_device(ix._h, dQ.shape[0], dQ.data_ptr(), cells.data_ptr(), None, None))
     torch.cuda.synchronize()
     return cells.cpu().numpy()
 
@@ -352,12 +352,12 @@ def test_virtual_shards_on_one_device(mi, oracle, S):
         shards.append(ix)
     Q = torch.tensor(p["queries"], dtype=torch.float64, device="cuda")
     engines = [sh.HipShardEngine(ix._h, D, w, 0) for ix in shards]
-    probe = engines[0].coarse(Q)
+    probe, pdist = engines[0].coarse(Q)
     for k in (1, 10, 100):
         # two-phase form with the threshold exchange the RCCL path does (MIN over shards)
         Ts = [e.pass_a(k, Q, probe) for e in engines]
         Tmin = torch.stack(Ts).min(0).values.contiguous()
-        parts2 = [e.pass_b(k, Q, probe, Tmin) for e in engines]
+        parts2 = [e.pass_b(k, Q, probe, pdist if k != 10 else None, Tmin) for e in engines]  # (k = 10: bound from the centroids)
         i2, d2, c2 = engines[0].merge(k, torch.stack([x[0] for x in parts2]), torch.stack([x[1] for x in parts2]),
                                       torch.stack([x[2] for x in parts2]))
         torch.cuda.synchronize()

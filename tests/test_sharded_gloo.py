@@ -31,20 +31,26 @@ class OracleShardEngine:
         self.shard.set_pq(p["pq"])
         self.shard.set_w(w)
         self.cell_of = cells_of
+        self.coarse_np = np.asarray(p["coarse"], np.float64)
         own = np.nonzero(cells_of % world == rank)[0]
         for i in own:
             self.shard.add_code(int(i), int(cells_of[i]), codes[i])
 
     def coarse(self, Qs):
         out = np.stack([self.full.nearest_coarse(q, self.w) for q in Qs.numpy()]) if Qs.shape[0] else np.zeros((0, self.w), np.int32)
-        return torch.from_numpy(out.astype(np.int32))
+        cells = out.astype(np.int32)
+        cd = np.zeros(cells.shape, np.float64)
+        for i, q in enumerate(Qs.numpy()):
+            cd[i] = ((self.coarse_np[cells[i]] - q[None, :]) ** 2).sum(1)  # (pass-through payload for pass B's bound)
+        return torch.from_numpy(cells), torch.from_numpy(cd)
 
     def pass_a(self, k, Q, cells):
         # the oracle has no thresholds to share: +inf everywhere (pruning is a GPU-side optimisation)
         return torch.full((Q.shape[0],), float("inf"), dtype=torch.float64)
 
-    def pass_b(self, k, Q, cells, T):
+    def pass_b(self, k, Q, cells, cdist, T):
         assert torch.all(torch.isinf(T))  # MIN over ranks of +inf
+        assert cdist.shape == cells.shape
         return self.search_partial(k, Q, cells)
 
     def search_partial(self, k, Q, cells):
