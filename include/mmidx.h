@@ -147,8 +147,10 @@ int mmidx_search_sdc(mmidx_index *h, int k, int64_t nq, const int32_t *iids, int
  * mmidx_search_partial_device: scan of this shard's lists for the given probe cells; writes the
  *   shard's best k+1 candidates per query, sorted: d_pdist[nq][k+1] (fp64), d_pkey[nq][k+1]
  *   (int64 = probe_rank << 32 | iid -- the reference's offer order), d_pcount[nq].
- * mmidx_merge_partials_device: merges nshards partial lists laid out [nshards][nq][k+1] (as an
- *   all-gather delivers them) into final results; no index handle needed. */
+ * mmidx_merge_partials_device: merges nshards partial lists into final results; no index handle
+ *   needed.  Layout: dense [nshards][nq][k+1] (d_poff NULL), or ragged -- only the d_pcount[s][q] valid
+ *   entries of every list, concatenated, list (s, q) starting at element d_poff[s * nq + q] (what a
+ *   variable-size all-to-all delivers). */
 int mmidx_coarse_device(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells_out,
                         double *d_cdist_out, void *stream);
 int mmidx_search_partial_device(mmidx_index *h, int k, int64_t nq, const double *dQ,
@@ -166,8 +168,13 @@ int mmidx_shard_pass_a_device(mmidx_index *h, int k, int64_t nq, const double *d
 int mmidx_shard_pass_b_device(mmidx_index *h, int k, int64_t nq, const double *dQ,
                               const int32_t *d_cells, const double *d_cdist, const double *d_T_in,
                               double *d_pdist, int64_t *d_pkey, int32_t *d_pcount, void *stream);
+/* dense partial lists [nq][k+1] -> ragged (list q = its d_pcount[q] valid entries at element d_poff[q]):
+ * what a rank sends through the variable-size all-to-all */
+int mmidx_compact_partials_device(int device, int k, int64_t nq, const double *d_pdist,
+                                  const int64_t *d_pkey, const int32_t *d_pcount, const int64_t *d_poff,
+                                  double *d_out_dist, int64_t *d_out_key, void *stream);
 int mmidx_merge_partials_device(int device, int k, int64_t nq, int nshards, const double *d_pdist,
-                                const int64_t *d_pkey, const int32_t *d_pcount,
+                                const int64_t *d_pkey, const int32_t *d_pcount, const int64_t *d_poff,
                                 int32_t *d_iid_out, double *d_dist_out, int32_t *d_count_out,
                                 void *stream);
 

@@ -409,7 +409,7 @@ struct SearchPlan {
     int64_t qb;  // queries per sub-batch
 };
 
-int make_plan(mmidx_index *h, int k, int64_t nq, SearchPlan &pl) {
+int make_plan(mmidx_index *h, int k, int64_t nq, SearchPlan &pl, bool need_coarse = true) {
     if (k < 1 || k > 1023) return fail(MMIDX_ERR_INVALID_ARG, "k must be in 1..1023 (got %d)", k);
     pl.K1 = k + 1;
     int cap = 1;
@@ -436,11 +436,12 @@ int make_plan(mmidx_index *h, int k, int64_t nq, SearchPlan &pl) {
     // (+ MMIDX_HKEEP: a K3h pass-A item may emit up to MMIDX_HKEEP entries instead of K1)
     int64_t poolq = (int64_t)pl.nitems * pl.K1 + MMIDX_HKEEP;
     pl.poolq = (int)std::min<int64_t>(poolq, std::max<int64_t>(h->n_csr, pl.K1));
-    // sub-batch so that the pool and the coarse distance matrix stay <= 2 GiB each
+    // sub-batch so that the pool stays <= 16 GiB (sized for 288 GB of HBM: a sharded search hands a rank the
+    // whole node's batch at once) and, when the coarse stage runs inside the call, its scratch matrix <= 2 GiB
     int64_t qb = std::min<int64_t>(nq, (int64_t)(1 << 30) / std::max(nprobe, 1));
     const int64_t pool_bytes_q = (int64_t)pl.poolq * 16;
-    qb = std::min<int64_t>(qb, std::max<int64_t>(1, (2ll << 30) / std::max<int64_t>(pool_bytes_q, 1)));
-    if (ivf) qb = std::min<int64_t>(qb, std::max<int64_t>(1, (2ll << 30) / ((int64_t)h->C * 8)));
+    qb = std::min<int64_t>(qb, std::max<int64_t>(1, (16ll << 30) / std::max<int64_t>(pool_bytes_q, 1)));
+    if (ivf && need_coarse) qb = std::min<int64_t>(qb, std::max<int64_t>(1, (2ll << 30) / ((int64_t)h->C * 8)));
     pl.qb = qb;
     return MMIDX_OK;
 }
@@ -967,7 +968,7 @@ int search_common(mmidx_index *h, int k, int64_t nq, const double *dQ, const int
         if (rc) return rc;
     }
     SearchPlan pl;
-    rc = make_plan(h, k, nq, pl);
+    rc = make_plan(h, k, nq, pl, d_cells == nullptr);
     if (rc) return rc;
     for (int64_t q0 = 0; q0 < nq; q0 += pl.qb) {
         const int64_t nb = std::min<int64_t>(pl.qb, nq - q0);
@@ -1561,7 +1562,7 @@ static int shard_phase(mmidx_index *h, int k, int64_t nq, const double *dQ, cons
         if (rc) return rc;
     }
     SearchPlan pl;
-    rc = make_plan(h, k, nq, pl);
+    rc = make_plan(h, k, nq, pl, false);
     if (rc) return rc;
     if (nq > pl.qb) return fail(MMIDX_ERR_UNSUPPORTED, "shard phases take at most %lld queries per call for this index", (long long)pl.qb);
     return search_batch_device(h, pl, k, nq, dQ, ivf ? d_cells : nullptr, 1, nullptr, nullptr, d_pcount, d_pdist, (long long *)d_pkey, phase,
@@ -1578,7 +1579,8 @@ int mmidx_shard_pass_b_device(mmidx_index *h, int k, int64_t nq, const double *d
 }
 
 int mmidx_merge_partials_device(int device, int k, int64_t nq, int nshards, const double *d_pdist, const int64_t *d_pkey,
-                                const int32_t *d_pcount, int32_t *d_iid_out, double *d_dist_out, int32_t *d_count_out, void *stream) {
+                                const int32_t *d_pcount, const int64_t *d_poff, int32_t *d_iid_out, double *d_dist_out,
+                                int32_t *d_count_out, void *stream) {
     if (k < 1 || k > 1023) return fail(MMIDX_ERR_INVALID_ARG, "k must be in 1..1023 (got %d)", k);
     if (nshards < 1 || nq < 0) return fail(MMIDX_ERR_INVALID_ARG, "bad shard / query count");
     if (nq > 0 && (!d_pdist || !d_pkey || !d_pcount || !d_iid_out || !d_dist_out || !d_count_out))
@@ -1589,7 +1591,21 @@ int mmidx_merge_partials_device(int device, int k, int64_t nq, int nshards, cons
     const size_t mlds = (size_t)MMIDX_MCAP * 16;
     HIPCK(hipFuncSetAttribute((const void *)k_merge_partials, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
     hipLaunchKernelGGL(k_merge_partials, dim3((unsigned)nq), dim3(MMIDX_BLOCK), mlds, (hipStream_t)stream, k, (int)nq, nshards, d_pdist,
-                       (const long long *)d_pkey, d_pcount, d_iid_out, d_dist_out, d_count_out);
+                       (const long long *)d_pkey, d_pcount, (const long long *)d_poff, d_iid_out, d_dist_out, d_count_out);
+    HIPCK(hipGetLastError());
+    return MMIDX_OK;
+}
+
+int mmidx_compact_partials_device(int device, int k, int64_t nq, const double *d_pdist, const int64_t *d_pkey, const int32_t *d_pcount,
+                                  const int64_t *d_poff, double *d_out_dist, int64_t *d_out_key, void *stream) {
+    if (k < 1 || k > 1023 || nq < 0) return fail(MMIDX_ERR_INVALID_ARG, "bad k / query count");
+    if (nq > 0 && (!d_pdist || !d_pkey || !d_pcount || !d_poff)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (mmidx_device_count() < 1) return fail(MMIDX_ERR_NO_DEVICE, "no HIP device: libmmidx_hip has no CPU fallback");
+    if (nq == 0) return MMIDX_OK;
+    HIPCK(hipSetDevice(device));
+    hipLaunchKernelGGL(k_compact_partials, dim3((unsigned)((nq + 3) / 4)), dim3(MMIDX_BLOCK), 0, (hipStream_t)stream, d_pdist,
+                       (const long long *)d_pkey, d_pcount, (const long long *)d_poff, d_out_dist, (long long *)d_out_key, k + 1,
+                       (long long)nq);
     HIPCK(hipGetLastError());
     return MMIDX_OK;
 }

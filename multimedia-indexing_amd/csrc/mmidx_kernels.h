@@ -2624,6 +2624,10 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_merge(const MergeParams P) {
     // Entries above the query's final threshold cannot be among the K1 best (at least K1 candidates are at or
     // below it): drop them while loading.  What is left is K1 plus a few entries, small enough to be ordered
     // by counting ranks -- one pass of broadcast LDS reads, no 36-stage sorting network.
+    if (n == 0 && P.mode == 1) {  // nothing on this shard for this query (the usual case for most queries of a rank):
+        if (tid == 0) P.count_out[q] = 0;  // the merge reads count entries, the list itself stays unwritten
+        return;
+    }
     const u64 T = P.T ? __hip_atomic_load(P.T + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : MMIDX_KEY_MAX;
     if (tid == 0) s_m = 0;
     const bool offs_in_lds = P.cells && P.w <= 1024;  // (the host sized the LDS accordingly)
@@ -2762,6 +2766,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_merge_partials(int k, int nq, i
                                                                 const double *__restrict__ pdist,
                                                                 const long long *__restrict__ pkey,
                                                                 const int32_t *__restrict__ pcount,
+                                                                const long long *__restrict__ poff,
                                                                 int32_t *iid_out, double *dist_out,
                                                                 int32_t *count_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2777,7 +2782,8 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_merge_partials(int k, int nq, i
             int c = pcount[(size_t)s * nq + q];
             if (c > K1) c = K1;
             if (filled + c > MMIDX_MCAP) break;
-            const size_t base = ((size_t)s * nq + q) * K1;
+            // dense [nshards][nq][K1] or, with poff, ragged: list (s, q) starts at poff[s * nq + q]
+            const size_t base = poff ? (size_t)poff[(size_t)s * nq + q] : ((size_t)s * nq + q) * K1;
             for (int i = tid; i < c; i += MMIDX_BLOCK) {
                 key[filled + i] = dkey(pdist[base + i]);
                 val[filled + i] = (u64)pkey[base + i];
@@ -2809,6 +2815,21 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_merge_partials(int k, int nq, i
         dist_out[(size_t)q * k + i] = dd;
     }
     if (tid == 0) count_out[q] = cnt;
+}
+
+// dense partial lists [nq][K1] -> ragged: the pcount[q] valid entries of list q at out[poff[q] ...] (one wave per query)
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_compact_partials(const double *__restrict__ pdist, const long long *__restrict__ pkey,
+                                                                  const int32_t *__restrict__ pcount, const long long *__restrict__ poff,
+                                                                  double *__restrict__ out_d, long long *__restrict__ out_k, int K1,
+                                                                  long long nq) {
+    const long long q = (long long)blockIdx.x * (MMIDX_BLOCK / 64) + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const int c = pcount[q] < K1 ? pcount[q] : K1;
+    const long long o = poff[q];
+    for (int i = threadIdx.x & 63; i < c; i += 64) {
+        out_d[o + i] = pdist[(size_t)q * K1 + i];
+        out_k[o + i] = pkey[(size_t)q * K1 + i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -10,7 +10,7 @@ replicated (8.25 MiB).  Per batch:
   3. pass A: scan of probe rank 0 where it is local -> thresholds  (mmidx_shard_pass_a_device)
   4. MIN all-reduce of the thresholds                             (RCCL, nq*8 bytes)
   5. pass B: remaining local probes under the global thresholds   (mmidx_shard_pass_b_device)
-  6. all-to-all of the sorted partial lists to the query's owner  (RCCL, nq*(k+1)*16 bytes/rank)
+  6. all-to-all of the sorted partial lists to the query's owner  (RCCL: counts, then the valid entries only)
   7. merge of the `world` lists per owned query, all-gather results (mmidx_merge_partials_device)
 
 The collectives go through torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in the CPU
@@ -114,16 +114,29 @@ class HipShardEngine:
                                                    pk.data_ptr(), pc.data_ptr(), self._stream()))
         return pd, pk, pc
 
-    def merge(self, k, pd_all, pk_all, pc_all):
+    def compact(self, k, pd, pk, pc, total):
+        """the pc[q] valid entries of every list, concatenated in query order (total = their number)"""
         t = self.torch
-        S, nq = pd_all.shape[0], pd_all.shape[1]
-        iid = t.empty(nq, k, dtype=t.int32, device=pd_all.device)
-        dist = t.empty(nq, k, dtype=t.float64, device=pd_all.device)
-        cnt = t.empty(nq, dtype=t.int32, device=pd_all.device)
+        pc64 = pc.to(t.int64)
+        poff = (t.cumsum(pc64, 0) - pc64).contiguous()
+        od = t.empty(total, dtype=pd.dtype, device=pd.device)
+        ok = t.empty(total, dtype=pk.dtype, device=pk.device)
+        if pd.shape[0]:
+            N.check(self.L.mmidx_compact_partials_device(self.dev, k, pd.shape[0], pd.data_ptr(), pk.data_ptr(), pc.data_ptr(),
+                                                         poff.data_ptr(), od.data_ptr(), ok.data_ptr(), self._stream()))
+        return od, ok
+
+    def merge(self, k, pd_all, pk_all, pc_all, poff=None):
+        """dense: pd_all / pk_all [S][nq][k+1]; ragged (poff [S][nq] int64 element offsets): flat arrays"""
+        t = self.torch
+        S, nq = pc_all.shape[0], pc_all.shape[1]
+        iid = t.empty(nq, k, dtype=t.int32, device=pc_all.device)
+        dist = t.empty(nq, k, dtype=t.float64, device=pc_all.device)
+        cnt = t.empty(nq, dtype=t.int32, device=pc_all.device)
         if nq:
             N.check(self.L.mmidx_merge_partials_device(self.dev, k, nq, S, pd_all.data_ptr(), pk_all.data_ptr(),
-                                                       pc_all.data_ptr(), iid.data_ptr(), dist.data_ptr(),
-                                                       cnt.data_ptr(), self._stream()))
+                                                       pc_all.data_ptr(), poff.data_ptr() if poff is not None else None,
+                                                       iid.data_ptr(), dist.data_ptr(), cnt.data_ptr(), self._stream()))
         return iid, dist, cnt
 
 
@@ -133,7 +146,8 @@ class ShardedIVFPQ:
     Collectives per batch (B queries, K1 = k + 1):
       all-gather  probe cells        B*w*4 bytes  (+ their exact coarse distances, B*w*8: pass B's coarse bound)
       all-reduce  thresholds (MIN)   B*8 bytes            -- lets every shard prune with the global bound
-      all-to-all  partial lists      B*K1*16 bytes/rank   -- query q is merged on rank q // per
+      all-to-all  partial lists      counts (B*4 bytes/rank), then only the valid entries, 16 bytes each
+                                     (about B*(k+few)*16 bytes over all ranks) -- query q is merged on rank q // per
       all-gather  results            B*k*12 bytes
     """
 
@@ -195,10 +209,24 @@ class ShardedIVFPQ:
             pd = torch.cat([pd, torch.full((padn, K1), float("inf"), dtype=pd.dtype, device=pd.device)], 0)
             pk = torch.cat([pk, torch.full((padn, K1), -1, dtype=pk.dtype, device=pk.device)], 0)
             pc = torch.cat([pc, torch.zeros(padn, dtype=pc.dtype, device=pc.device)], 0)
-        rd = self._all_to_all(pd.reshape(W, per, K1))
-        rk = self._all_to_all(pk.reshape(W, per, K1))
-        rc = self._all_to_all(pc.reshape(W, per))
-        iid, dist_, cnt = self.engine.merge(k, rd, rk, rc)  # [per][k]
+        # Most (rank, query) lists are empty or short (a query's candidates live on the few ranks that own its
+        # nearest cells), so only the valid entries travel: counts first (fixed size), then a variable-size
+        # all-to-all of the compacted lists; the merge kernel reads them ragged.
+        pcw = pc.reshape(W, per)
+        rc = self._all_to_all(pcw)                                   # [W][per]: what every rank holds for my queries
+        sizes = torch.stack([pcw.sum(1), rc.sum(1)]).cpu().tolist()  # one host sync: the split sizes
+        send_sz, recv_sz = [int(x) for x in sizes[0]], [int(x) for x in sizes[1]]
+        sd, sk = self.engine.compact(k, pd, pk, pc, sum(send_sz))    # (query, position) order = destination-major
+        rd = torch.empty(sum(recv_sz), dtype=pd.dtype, device=pd.device)
+        rk = torch.empty(sum(recv_sz), dtype=pk.dtype, device=pk.device)
+        if W == 1 and not self.force:
+            rd, rk = sd, sk
+        else:
+            self.dist.all_to_all_single(rd, sd, recv_sz, send_sz, group=self.group)
+            self.dist.all_to_all_single(rk, sk, recv_sz, send_sz, group=self.group)
+        flat = rc.reshape(-1).to(torch.int64)
+        poff = (torch.cumsum(flat, 0) - flat).reshape(W, per).contiguous()
+        iid, dist_, cnt = self.engine.merge(k, rd, rk, rc.contiguous(), poff)  # [per][k]
         if not gather:
             return iid[:q1 - q0], dist_[:q1 - q0], cnt[:q1 - q0]
         iid = self._all_gather(iid).reshape(W * per, k)[:nq]

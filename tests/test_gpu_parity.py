@@ -366,6 +366,14 @@ def test_virtual_shards_on_one_device(mi, oracle, S):
         iid, dd, cnt = engines[0].merge(k, torch.stack([x[0] for x in parts]), torch.stack([x[1] for x in parts]),
                                         torch.stack([x[2] for x in parts]))
         torch.cuda.synchronize()
+        # ragged form (what the variable-size all-to-all delivers): compact every shard's lists, concatenate
+        pcs = torch.stack([x[2] for x in parts])
+        comp = [engines[0].compact(k, x[0], x[1], x[2], int(x[2].sum())) for x in parts]
+        flat = pcs.reshape(-1).to(torch.int64)
+        poff = (torch.cumsum(flat, 0) - flat).reshape(pcs.shape).contiguous()
+        ri, rd_, rcnt = engines[0].merge(k, torch.cat([c[0] for c in comp]), torch.cat([c[1] for c in comp]), pcs.contiguous(), poff)
+        torch.cuda.synchronize()
+        assert torch.equal(ri, iid) and torch.equal(rd_, dd) and torch.equal(rcnt, cnt)
         # same merge on the host mirror
         hi, hd, hc = sh.merge_partials_host(k, torch.stack([x[0] for x in parts]).cpu().numpy(),
                                             torch.stack([x[1] for x in parts]).cpu().numpy(),

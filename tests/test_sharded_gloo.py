@@ -70,8 +70,24 @@ class OracleShardEngine:
             pd[qi, :n], pk[qi, :n], pc[qi] = ds[order], keys[order], n
         return torch.from_numpy(pd), torch.from_numpy(pk), torch.from_numpy(pc)
 
-    def merge(self, k, pd_all, pk_all, pc_all):
+    def compact(self, k, pd, pk, pc, total):
+        mask = torch.arange(k + 1)[None, :] < pc[:, None]
+        assert int(mask.sum()) == total
+        return pd[mask], pk[mask]
+
+    def merge(self, k, pd_all, pk_all, pc_all, poff=None):
         sh = importlib.import_module("multimedia-indexing_amd.sharded")
+        if poff is not None:  # ragged lists (what the variable-size all-to-all delivers) -> dense for the host mirror
+            S, nq, K1 = pc_all.shape[0], pc_all.shape[1], k + 1
+            dd = np.full((S, nq, K1), np.inf)
+            kk = np.full((S, nq, K1), -1, np.int64)
+            fd, fk, off, cnt = pd_all.numpy(), pk_all.numpy(), poff.numpy(), pc_all.numpy()
+            for s_ in range(S):
+                for q_ in range(nq):
+                    c_ = int(cnt[s_, q_])
+                    dd[s_, q_, :c_] = fd[off[s_, q_]:off[s_, q_] + c_]
+                    kk[s_, q_, :c_] = fk[off[s_, q_]:off[s_, q_] + c_]
+            pd_all, pk_all = torch.from_numpy(dd), torch.from_numpy(kk)
         i, d, c = sh.merge_partials_host(k, pd_all.numpy(), pk_all.numpy(), pc_all.numpy())
         return torch.from_numpy(i), torch.from_numpy(d), torch.from_numpy(c)
 
