@@ -41,20 +41,18 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def torch_kmeans(X, k, iters, gen):
-    """Lloyd in torch fp32 (codebook learning is offline in the reference, J/quantization/*)."""
-    import torch
-
-    n = X.shape[0]
-    cent = X[torch.randperm(n, device=X.device, generator=gen)[:k]].clone()
-    for _ in range(iters):
-        d = (X * X).sum(1, keepdim=True) - 2.0 * X @ cent.T + (cent * cent).sum(1)[None, :]
-        a = d.argmin(1)
-        sums = torch.zeros_like(cent).index_add_(0, a, X)
-        cnt = torch.zeros(k, device=X.device, dtype=X.dtype).index_add_(0, a, torch.ones(n, device=X.device, dtype=X.dtype))
-        nz = cnt > 0
-        cent[nz] = sums[nz] / cnt[nz, None]
-    return cent
+def gpu_kmeans(nat, L, dev_index, X, k, iters, seed=1, init=None, plus_plus=False):
+    """codebook learning with the library's own k-means (csrc/mmidx_learn.hip; the reference uses Weka offline,
+    J/quantization/*): X = fp64 CUDA tensor [n][d]; returns a [k][d] numpy array (empty clusters -> all-1000 rows,
+    ProductQuantizationLearning.java:285-302)"""
+    n, d = X.shape
+    out = np.full((k, d), 1000.0)
+    kout, it = C.c_int32(0), C.c_int32(0)
+    ini = None if init is None else np.ascontiguousarray(init, np.float64)
+    nat.check(L.mmidx_kmeans_device(dev_index, n, d, k, iters, seed, 1 if plus_plus else 0, X.data_ptr(),
+                                    ini.ctypes.data if ini is not None else None, out.ctypes.data, None, None, C.addressof(it),
+                                    C.addressof(kout), None))
+    return out
 
 
 def main():
@@ -130,31 +128,33 @@ def main():
     mu = torch.randn(Cc, D, generator=g0, device=dev, dtype=f64)
     ns = min(N, 1 << 20)
     gs = torch.randint(0, Cc, (ns,), generator=g0, device=dev)
-    Xs = (mu[gs] + 0.15 * torch.randn(ns, D, generator=g0, device=dev, dtype=f64)).float()
-    # one Lloyd refinement of the mixture means = the coarse quantizer
-    cent = mu.float().clone()
-    dmat_arg = torch.empty(ns, dtype=torch.long, device=dev)
-    for i0 in range(0, ns, 1 << 17):
-        xs = Xs[i0:i0 + (1 << 17)]
-        dmat_arg[i0:i0 + (1 << 17)] = ((xs * xs).sum(1, keepdim=True) - 2.0 * xs @ cent.T + (cent * cent).sum(1)[None]).argmin(1)
-    sums = torch.zeros_like(cent).index_add_(0, dmat_arg, Xs)
-    cnt = torch.zeros(Cc, device=dev).index_add_(0, dmat_arg, torch.ones(ns, device=dev))
-    nz = cnt > 0
-    cent[nz] = sums[nz] / cnt[nz, None]
-    coarse = cent.double().contiguous()
-    # residual PQ codebooks: k-means per sub-space on centroid - vector (ResidualVectorComputation.java:34)
+    Xs = mu[gs] + 0.15 * torch.randn(ns, D, generator=g0, device=dev, dtype=f64)
+    torch.cuda.synchronize()
+    # coarse quantizer: Lloyd from the mixture means (2 iterations); residual PQ codebooks: k-means++ per sub-space on
+    # centroid - vector (ResidualVectorComputation.java:34)
+    coarse_h0 = gpu_kmeans(nat, L, local, Xs, Cc, 2, init=mu.cpu().numpy())
+    coarse = torch.from_numpy(coarse_h0).to(dev)
+    hq = C.c_void_p()
+    chk(L.mmidx_create(nat.KIND_IVFPQ, D, 1, 2, Cc, 0, None, None, local, C.byref(hq)))
+    chk(L.mmidx_set_coarse(hq, coarse_h0.ctypes.data))
     nr = min(ns, 1 << 18)
-    resid = (cent[dmat_arg[:nr]] - Xs[:nr])
+    cell_s = torch.empty(nr, dtype=torch.int32, device=dev)
+    chk(L.mmidx_assign_device(hq, nr, Xs.data_ptr(), cell_s.data_ptr(), stream))
+    torch.cuda.synchronize()
+    chk(L.mmidx_destroy(hq))
+    resid = coarse[cell_s.long()] - Xs[:nr]
     pq = torch.empty(m, ks, dsub, device=dev, dtype=f64)
     for s in range(m):
-        pq[s] = torch_kmeans(resid[:, s * dsub:(s + 1) * dsub].contiguous(), ks, 8, g0).double()
-    del Xs, resid, sums
+        sub = resid[:, s * dsub:(s + 1) * dsub].contiguous()
+        torch.cuda.synchronize()
+        pq[s] = torch.from_numpy(gpu_kmeans(nat, L, local, sub, ks, 8, seed=s + 1, plus_plus=True)).to(dev)
+    del Xs, resid
     log(f"codebooks learned in {time.time() - t0:.1f}s")
 
     # ---------------------------------------------------------------- index
     h = C.c_void_p()
     chk(L.mmidx_create(nat.KIND_IVFPQ, D, m, ks, Cc, 0, None, None, local, C.byref(h)))
-    coarse_h = coarse.cpu().numpy()
+    coarse_h = coarse.cpu().numpy().copy()
     pq_h = pq.cpu().numpy()
     chk(L.mmidx_set_coarse(h, coarse_h.ctypes.data))
     chk(L.mmidx_set_pq(h, pq_h.ctypes.data))

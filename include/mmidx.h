@@ -139,6 +139,10 @@ int mmidx_search_device(mmidx_index *h, int k, int64_t nq, const double *dQ, int
 int mmidx_search_sdc(mmidx_index *h, int k, int64_t nq, const int32_t *iids, int32_t *iid_out,
                      double *dist_out, int32_t *count_out);
 
+/* computeNearestCoarseIndex (IVFPQ.java:547-564) for n device-resident vectors: d_cell_out[i] = the exact
+ * fp64 argmin cell, first index wins ties.  Needs only the coarse quantizer (used by the codebook learner). */
+int mmidx_assign_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_cell_out, void *stream);
+
 /* ---- sharded search (one process per GPU; lists partitioned across ranks) ---------------------
  * mmidx_coarse_device: computeNearestCoarseIndices IVFPQ.java:575-601 for nq queries ->
  *   d_cells_out[nq][w] (nearest first) and, when d_cdist_out is not NULL, the exact squared distance
@@ -177,6 +181,24 @@ int mmidx_merge_partials_device(int device, int k, int64_t nq, int nshards, cons
                                 const int64_t *d_pkey, const int32_t *d_pcount, const int64_t *d_poff,
                                 int32_t *d_iid_out, double *d_dist_out, int32_t *d_count_out,
                                 void *stream);
+
+/* ---- codebook learning (J/visual/quantization/AbstractQuantizerLearning.java:39-81) ------
+ * k-means on the GPU in place of Weka's SimpleKMeans, which the reference calls with setSeed(seed),
+ * setNumClusters(k), setMaxIterations(max_iter) and, optionally, k-means++ seeding.  flags:
+ *   MMIDX_KMEANS_PLUS_PLUS  k-means++ seeding (else SimpleKMeans' default random seeding),
+ *   MMIDX_KMEANS_NORMALIZE  min-max attribute normalisation inside the distance (Weka's default).
+ * init_centroids (host, [k][d], may be NULL) overrides the seeding.  Empty clusters are dropped as Weka does:
+ * *k_out <= k centroids are written to centroids_out (host, room for [k][d]); assign_out[i] indexes them.
+ * sse = squared error in the space the clustering ran in.  Weka is an absent third-party dependency: the
+ * algorithm is restated, its random stream and summation order are not reproduced (parity unpinned). */
+enum mmidx_kmeans_flags { MMIDX_KMEANS_PLUS_PLUS = 1, MMIDX_KMEANS_NORMALIZE = 2 };
+int mmidx_kmeans_device(int device, int64_t n, int d, int k, int max_iter, int64_t seed, int flags,
+                        const double *dX, const double *init_centroids, double *centroids_out,
+                        int32_t *d_assign_out, double *sse_out, int32_t *iters_out, int32_t *k_out,
+                        void *stream);
+int mmidx_kmeans(int device, int64_t n, int d, int k, int max_iter, int64_t seed, int flags,
+                 const double *X, const double *init_centroids, double *centroids_out,
+                 int32_t *assign_out, double *sse_out, int32_t *iters_out, int32_t *k_out);
 
 /* ---- instrumentation -------------------------------------------------------------------------
  * Per-handle statistics accumulated over the search calls since the last mmidx_get_stats, measured

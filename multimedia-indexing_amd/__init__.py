@@ -8,3 +8,4 @@ from . import _native  # noqa: F401
 from ._native import MmidxError, build, lib  # noqa: F401
 from .index import IVFPQ, PQ, AbstractSearchStructure, Answer, TransformationType, read_quantizer  # noqa: F401
 from .frontend import PCA, VladAggregator, VladAggregatorMultipleVocabularies  # noqa: F401
+from . import quantization  # noqa: F401

@@ -41,7 +41,7 @@ class Stats(C.Structure):
 
 def build(force=False):
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("mmidx_api.hip", "mmidx_kernels.h", "mmidx_frontend.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("mmidx_api.hip", "mmidx_learn.hip", "mmidx_kernels.h", "mmidx_frontend.h")]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "mmidx.h"))
     stale = not os.path.exists(SO_PATH) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
     if force or stale:
@@ -70,6 +70,7 @@ SIGNATURES = {
     "mmidx_add_vectors_device": (C.c_int, [_vp, C.c_int64, _dp, _i32p, C.c_int32, _vp]),
     "mmidx_add_codes_device": (C.c_int, [_vp, C.c_int64, _i32p, _i32p, _vp, _vp]),
     "mmidx_encode_device": (C.c_int, [_vp, C.c_int64, _dp, _i32p, _vp, _vp]),
+    "mmidx_assign_device": (C.c_int, [_vp, C.c_int64, _dp, _i32p, _vp]),
     "mmidx_sync_index": (C.c_int, [_vp]),
     "mmidx_export": (C.c_int, [_vp, _vp, _i32p, _vp]),
     "mmidx_search": (C.c_int, [_vp, C.c_int, C.c_int64, _dp, _i32p, _dp, _i32p]),
@@ -90,6 +91,10 @@ SIGNATURES = {
     "mmidx_vlad_vector_length": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "mmidx_vlad_aggregate": (C.c_int, [_vp, C.c_int64, _vp, _dp, _dp]),
     "mmidx_vlad_aggregate_device": (C.c_int, [_vp, C.c_int64, _vp, _dp, C.c_int, _dp, _vp]),
+    "mmidx_kmeans_device": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, _dp, _dp, _dp, _i32p, _dp,
+                                      _i32p, _i32p, _vp]),
+    "mmidx_kmeans": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, _dp, _dp, _dp, _i32p, _dp, _i32p,
+                               _i32p]),
     "mmidx_set_profiling": (C.c_int, [_vp, C.c_int]),
     "mmidx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "mmidx_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),

@@ -289,7 +289,9 @@ size_t scan_lds_bytes(const mmidx_index *h, int cap) {
 }
 
 // encode n device-resident vectors into (cell, code); code_out holds centroid indices (CodeT)
-int encode_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_cell, void *d_code, hipStream_t st) {
+// nearest coarse centroid of n device-resident vectors (computeNearestCoarseIndex, IVFPQ.java:547-564): exact fp64 argmin,
+// first index wins ties; -1 for a PQ index
+int assign_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_cell, hipStream_t st) {
     if (n == 0) return MMIDX_OK;
     const int ivf = h->kind == MMIDX_KIND_IVFPQ;
     const size_t asg_lds = (size_t)((ASG_BM * (h->D + 2) + 3) & ~3) * 4 + (size_t)ASG_BK * ASG_BN * 4;
@@ -332,6 +334,14 @@ int encode_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_cell, 
     } else {
         HIPCK(hipMemsetAsync(d_cell, 0xFF, (size_t)n * sizeof(int32_t), st));  // -1
     }
+    return MMIDX_OK;
+}
+
+int encode_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_cell, void *d_code, hipStream_t st) {
+    if (n == 0) return MMIDX_OK;
+    const int ivf = h->kind == MMIDX_KIND_IVFPQ;
+    int rc0 = assign_device(h, n, dX, d_cell, st);
+    if (rc0) return rc0;
     constexpr int VT = 8;
     const size_t lds = 2 * (size_t)VT * h->D * 8 + (size_t)h->m * VT * 4 * 12;
     if (lds > 160 * 1024) return fail(MMIDX_ERR_UNSUPPORTED, "vector length %d too large for the encode kernel", h->D);
@@ -1593,6 +1603,23 @@ int mmidx_merge_partials_device(int device, int k, int64_t nq, int nshards, cons
     hipLaunchKernelGGL(k_merge_partials, dim3((unsigned)nq), dim3(MMIDX_BLOCK), mlds, (hipStream_t)stream, k, (int)nq, nshards, d_pdist,
                        (const long long *)d_pkey, d_pcount, (const long long *)d_poff, d_iid_out, d_dist_out, d_count_out);
     HIPCK(hipGetLastError());
+    return MMIDX_OK;
+}
+
+int mmidx_assign_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_cell_out, void *stream) {
+    if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    if (h->kind != MMIDX_KIND_IVFPQ) return fail(MMIDX_ERR_INVALID_ARG, "PQ index has no coarse quantizer");
+    if (!h->coarse_set) return fail(MMIDX_ERR_NOT_READY, "coarse quantizer not loaded (loadCoarseQuantizer)");
+    if (n < 0 || (n > 0 && (!dX || !d_cell_out))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    int rc = set_device(h);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t step = 1 << 22;  // bounded scratch for the certified approximate path
+    for (int64_t i0 = 0; i0 < n; i0 += step) {
+        const int64_t nb = std::min(step, n - i0);
+        rc = assign_device(h, nb, dX + (size_t)i0 * h->D, d_cell_out + i0, st);
+        if (rc) return rc;
+    }
     return MMIDX_OK;
 }
 
