@@ -55,13 +55,16 @@ def run(n_images=20000, n_queries=256, k=10, seed=0, cells=256, w=8, verbose=Tru
     t0 = time.time()
     X = pca.project(V)
     t_pca = time.time() - t0
-    # IVFPQ over the projected vectors
+    # IVFPQ over the projected vectors; quantizers learned on the GPU (quantization.py = the reference's
+    # CoarseQuantizerLearning / ProductQuantizationLearning with Weka's k-means restated in HIP)
     D, m, ks = nc_out, 16, 256
-    coarse = synth.kmeans(X[: min(n_images, 20000)], cells, iters=6, seed=1)
-    cell = ((X[:, None, :] - coarse[None]) ** 2).sum(-1).argmin(1) if n_images * cells * D < 3e8 else \
-        ((X * X).sum(1)[:, None] - 2 * X @ coarse.T + (coarse * coarse).sum(1)[None]).argmin(1)
-    resid = coarse[cell] - X
-    pq = np.stack([synth.kmeans(resid[:20000, s * 8:(s + 1) * 8], ks, iters=5, seed=10 + s) for s in range(m)])
+    t0 = time.time()
+    learn = X[: min(n_images, 20000)]
+    coarse = mi.quantization.CoarseQuantizerLearning.learn(learn, cells, maxIterations=10, seed=1, kMeansPlusPlus=True)
+    if coarse.shape[0] < cells:  # dropped clusters: pad like the product-quantizer learner does
+        coarse = np.concatenate([coarse, np.full((cells - coarse.shape[0], D), 1000.0)])
+    pq = mi.quantization.ProductQuantizationLearning.learn(learn, m, ks, maxIterations=8, numKmeansRepeats=1, coarseQuantizer=coarse)
+    t_learn = time.time() - t0
     ix = mi.IVFPQ(D, n_images, False, "", m, ks, mi.TransformationType.None_, cells, 512)
     ix.loadCoarseQuantizer(coarse)
     ix.loadProductQuantizer(pq)
@@ -72,7 +75,7 @@ def run(n_images=20000, n_queries=256, k=10, seed=0, cells=256, w=8, verbose=Tru
     # queries: re-rendered copies of indexed images (same topic words, fresh noise) through the same front end
     qi = rng.choice(n_images, n_queries, replace=False)
     qimgs = [images[i] + 0.02 * rng.standard_normal(images[i].shape) for i in qi]
-    Q = pca.project(vlad.aggregate_batch(qimgs))
+    Q = mi.frontend.ImageVectorizer(vlad, pca).transform_batch(qimgs)  # descriptors -> 128-d in one native call
     t0 = time.time()
     iids, dists, counts = ix.search_batch(k, Q)
     t_search = time.time() - t0
@@ -81,7 +84,7 @@ def run(n_images=20000, n_queries=256, k=10, seed=0, cells=256, w=8, verbose=Tru
     out = {"images": n_images, "queries": n_queries, "k": k,
            "recall_at_1_vs_exact": float(np.mean(iids[:, 0] == exact)),
            "self_hit_rate": float(np.mean(iids[:, 0] == qi)),
-           "seconds": {"descriptor_synthesis_cpu": round(t_gen, 2), "vlad": round(t_vlad, 3), "pca": round(t_pca, 3),
+           "seconds": {"descriptor_synthesis_cpu": round(t_gen, 2), "vlad": round(t_vlad, 3), "pca": round(t_pca, 3), "learn_quantizers": round(t_learn, 3),
                        "index": round(t_index, 3), "search": round(t_search, 4)},
            "answer0": ix.computeNearestNeighbors(k, Q[0]).getIds()[:3]}
     for o in (vlad, pca, ix):

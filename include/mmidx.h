@@ -250,6 +250,13 @@ int mmidx_vlad_aggregate(mmidx_vlad *v, int64_t nimg, const int64_t *desc_off, c
 int mmidx_vlad_aggregate_device(mmidx_vlad *v, int64_t nimg, const int64_t *d_desc_off,
                                 const double *d_descs, int max_desc, double *d_out, void *stream);
 
+/* ImageVectorization.transformToVector (J/vectorization/ImageVectorization.java:169-208) for a batch of images:
+ * aggregate (VLAD) then PCA.sampleToEigenSpace in one call; the VLAD vectors stay on the device.  out[nimg][nc]. */
+int mmidx_vectorize(mmidx_vlad *v, mmidx_pca *p, int64_t nimg, const int64_t *desc_off, const double *descs,
+                    double *out);
+int mmidx_vectorize_device(mmidx_vlad *v, mmidx_pca *p, int64_t nimg, const int64_t *d_desc_off,
+                           const double *d_descs, int max_desc, double *d_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1932,4 +1932,52 @@ int mmidx_vlad_aggregate(mmidx_vlad *v, int64_t nimg, const int64_t *desc_off, c
     return MMIDX_OK;
 }
 
+// ImageVectorization.transformToVector (J/vectorization/ImageVectorization.java:169-208) for a batch: aggregate, then
+// PCA.sampleToEigenSpace -- descriptors in, projected vectors out, the VLAD vectors never leave the device
+int mmidx_vectorize_device(mmidx_vlad *v, mmidx_pca *p, int64_t nimg, const int64_t *d_desc_off, const double *d_descs, int max_desc,
+                           double *d_out, void *stream) {
+    if (!v || !p) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    if (v->veclen != p->ss)
+        return fail(MMIDX_ERR_WRONG_DIM, "VLAD vector length %d does not match the PCA sample size %d", v->veclen, p->ss);
+    if (v->device != p->device) return fail(MMIDX_ERR_INVALID_ARG, "aggregator and PCA live on different devices");
+    if (nimg < 0 || (nimg > 0 && (!d_desc_off || !d_out))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (nimg == 0) return MMIDX_OK;
+    HIPCK(hipSetDevice(v->device));
+    const int64_t B = std::max<int64_t>(1, (int64_t)(1ll << 28) / v->veclen);  // <= 2 GiB of VLAD vectors per round
+    for (int64_t i0 = 0; i0 < nimg; i0 += B) {
+        const int64_t nb = std::min(B, nimg - i0);
+        HIPCK(v->ws_out.reserve((size_t)nb * v->veclen));
+        // (the offsets are absolute into d_descs: a sub-range of images needs no rebasing)
+        int rc = mmidx_vlad_aggregate_device(v, nb, d_desc_off + i0, d_descs, max_desc, v->ws_out.p, stream);
+        if (rc) return rc;
+        rc = mmidx_pca_project_device(p, nb, v->ws_out.p, d_out + (size_t)i0 * p->nc, stream);
+        if (rc) return rc;
+    }
+    return MMIDX_OK;
+}
+
+int mmidx_vectorize(mmidx_vlad *v, mmidx_pca *p, int64_t nimg, const int64_t *desc_off, const double *descs, double *out) {
+    if (!v || !p) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    if (nimg < 0 || (nimg > 0 && (!desc_off || !out))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (nimg == 0) return MMIDX_OK;
+    HIPCK(hipSetDevice(v->device));
+    const int64_t total = desc_off[nimg] - desc_off[0];
+    if (total > 0 && !descs) return fail(MMIDX_ERR_INVALID_ARG, "null descriptors");
+    int max_desc = 0;
+    std::vector<long long> off((size_t)nimg + 1);
+    for (int64_t i = 0; i <= nimg; i++) off[(size_t)i] = desc_off[i] - desc_off[0];
+    for (int64_t i = 0; i < nimg; i++) max_desc = std::max<int>(max_desc, (int)(off[(size_t)i + 1] - off[(size_t)i]));
+    HIPCK(v->ws_off.reserve((size_t)nimg + 1));
+    HIPCK(v->ws_desc.reserve((size_t)std::max<int64_t>(total, 1) * v->dl));
+    HIPCK(p->ws_Y.reserve((size_t)nimg * p->nc));
+    HIPCK(hipMemcpyAsync(v->ws_off.p, off.data(), ((size_t)nimg + 1) * 8, hipMemcpyHostToDevice, v->stream));
+    if (total > 0)
+        HIPCK(hipMemcpyAsync(v->ws_desc.p, descs + (size_t)desc_off[0] * v->dl, (size_t)total * v->dl * 8, hipMemcpyHostToDevice, v->stream));
+    int rc = mmidx_vectorize_device(v, p, nimg, (const int64_t *)v->ws_off.p, v->ws_desc.p, max_desc, p->ws_Y.p, v->stream);
+    if (rc) return rc;
+    HIPCK(hipMemcpyAsync(out, p->ws_Y.p, (size_t)nimg * p->nc * 8, hipMemcpyDeviceToHost, v->stream));
+    HIPCK(hipStreamSynchronize(v->stream));
+    return MMIDX_OK;
+}
+
 }  // extern "C"

@@ -142,3 +142,33 @@ class VladAggregator(VladAggregatorMultipleVocabularies):
 
     def __init__(self, codebook, device=0):
         super().__init__([codebook], normalizationsOn=False, device=device)
+
+
+class ImageVectorizer:
+    """Batch form of ImageVectorization.transformToVector (J/vectorization/ImageVectorization.java:169-208):
+    descriptors -> VLAD -> PCA projection in one native call (`mmidx_vectorize`), replacing the reference's
+    per-image thread pool (ImageVectorizer.java:123-126); the 8192-d VLAD vectors never leave the GPU."""
+
+    def __init__(self, aggregator, pca):
+        if aggregator.getVectorLength() != pca.sampleSize:
+            raise MmidxError(N.ERR_WRONG_DIM, "aggregator vector length does not match the PCA sample size")
+        self.aggregator, self.pca = aggregator, pca
+
+    def transform_batch(self, descriptor_sets):
+        """descriptor_sets: list of [n_i][descriptorLength] arrays -> [nimg][numComponents]"""
+        ag = self.aggregator
+        nimg = len(descriptor_sets)
+        off = np.zeros(nimg + 1, np.int64)
+        for i, d in enumerate(descriptor_sets):
+            off[i + 1] = off[i] + (0 if d is None else len(d))
+        total = int(off[-1])
+        descs = np.zeros((max(total, 1), ag.descriptorLength))
+        for i, d in enumerate(descriptor_sets):
+            if off[i + 1] > off[i]:
+                descs[off[i]:off[i + 1]] = _f64(d).reshape(-1, ag.descriptorLength)
+        out = np.zeros((nimg, self.pca.numComponents))
+        N.check(N.lib().mmidx_vectorize(ag._h, self.pca._h, nimg, off.ctypes.data, descs.ctypes.data, out.ctypes.data))
+        return out
+
+    def transformToVector(self, descriptors):
+        return self.transform_batch([descriptors])[0]

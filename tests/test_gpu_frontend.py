@@ -122,3 +122,24 @@ def test_config5_pipeline_end_to_end(mi, oracle):
     rid, rd, rc = ref.search_batch(Q, k)
     assert np.array_equal(iids, rid) and np.array_equal(dists, rd) and np.array_equal(counts, rc)
     assert out["recall_at_1_vs_exact"] >= 0.9 and out["self_hit_rate"] >= 0.9, out
+
+
+def test_fused_vectorize_equals_the_two_stages(mi):
+    """mmidx_vectorize (descriptors -> VLAD -> PCA, VLAD vectors kept on the device) = aggregate_batch + project,
+    bit for bit: the same two kernels run on the same data (ImageVectorization.java:169-208)."""
+    rng = np.random.default_rng(42)
+    nc, dl, ncomp = 32, 16, 24
+    cb = rng.standard_normal((nc, dl)) / 4.0
+    sets = [rng.standard_normal((n, dl)) for n in (5, 0, 300, 41, 1, 800)]
+    agg = mi.VladAggregatorMultipleVocabularies([cb], normalizationsOn=True)
+    ss = nc * dl
+    pca = mi.PCA(ncomp, 0, ss, True)
+    pca.load(rng.standard_normal(ss) * 0.01, np.linspace(3.0, 0.4, ncomp), np.linalg.qr(rng.standard_normal((ss, ncomp)))[0].T.copy())
+    two = pca.project(agg.aggregate_batch(sets))
+    vec = mi.frontend.ImageVectorizer(agg, pca)
+    one = vec.transform_batch(sets)
+    assert one.shape == (len(sets), ncomp) and np.array_equal(one, two)
+    assert np.array_equal(vec.transformToVector(sets[2]), two[2])
+    bad = mi.PCA(ncomp, 0, ss + 1, False)
+    with pytest.raises(mi.MmidxError):
+        mi.frontend.ImageVectorizer(agg, bad)
