@@ -16,7 +16,7 @@ there.  The index is the same 100M vectors for every N; the query batch per step
 (each rank scans its 1/N of the lists for N x as many queries), so the work per GPU per step is
 fixed and the scaling reported is "weak"; `--global-batch B` pins the batch instead ("strong").
 
-The JSON line carries `roofline` (dominant kernel = k_scan, algorithmic bytes = m x scanned codes,
+The JSON line carries `roofline` (dominant kernels = the list scans, algorithmic bytes = m x scanned codes,
 timed with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle -- a C restatement
 of the Java reference, kind "port" -- timed on this host's cores on a bounded query sample).
 """
@@ -320,7 +320,7 @@ def main():
             traffic = tj["hbm_bytes_per_query"] * B / max(1, launches / max(1, args.steps))
     except Exception:
         traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_scan", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": "scan launches: k_scan_hist (pass A) + k_scan_filt (pass B)", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "note": "achieved = algorithmic bytes (m x probed codes) / scan-kernel time; exact pruning (coarse bound, "
                         "Smin >= T) and L2 reuse make it exceed the physical HBM rate: see traffic and DESIGN.md section 7",

@@ -539,3 +539,70 @@ def test_pass_a_histogram_kernel(mi, oracle, case):
     for k in ks_list:
         assert_same(ix.search_batch(k, q), ref.search_batch(q, k))
     ix.close()
+
+
+@pytest.mark.parametrize("D,C,w", [(24, 1000, 7), (130, 700, 12), (128, 2049, 31), (260, 1536, 5), (64, 4100, 40), (16, 16390, 9)])
+def test_coarse_stage_group_minima_shapes(mi, oracle, D, C, w):
+    """K1e/K1f (bf16-split MFMA dot products + group minima) on shapes that exercise its padding: D not a multiple
+    of 32, more than one 128-wide k chunk (D > 128), C not a multiple of 128, C / 8 groups per thread > 1; clustered
+    centroids (realistic) plus exact duplicates (ties).  Selected cells AND the exact distances that travel to the
+    other ranks must equal the oracle's / the exact fp64 path's."""
+    import torch
+
+    nat = importlib.import_module("multimedia-indexing_amd._native")
+    rng = np.random.default_rng(D * 7 + C)
+    centers = 4.0 * rng.standard_normal((C // 40 + 2, D))
+    coarse = centers[rng.integers(0, len(centers), C)] + 0.7 * rng.standard_normal((C, D))
+    coarse[C // 2:C // 2 + 20] = coarse[:20]  # duplicates -> equal distances
+    m = 2 if D % 2 == 0 else 1
+    pq = rng.standard_normal((m, 16, D // m))
+    ix = mi.IVFPQ(D, 10, False, "", m, 16, 0, C, 512)
+    ix.loadCoarseQuantizer(coarse)
+    ix.loadProductQuantizer(pq)
+    ix.setW(w)
+    ref = oracle.OracleIndex(oracle.KIND_IVFPQ, D, m, 16, C)
+    ref.set_coarse(coarse)
+    ref.set_pq(pq)
+    Q = np.concatenate([coarse[rng.integers(0, C, 40)] + 0.05 * rng.standard_normal((40, D)), coarse[:6] + 1e-9,
+                        5.0 * rng.standard_normal((10, D))])
+    dQ = torch.tensor(Q, dtype=torch.float64, device="cuda")
+    res = {}
+    for v1 in (0, 1):
+        ix.set_option("coarse_v1", v1)
+        cells = torch.empty(len(Q), w, dtype=torch.int32, device="cuda")
+        cd = torch.empty(len(Q), w, dtype=torch.float64, device="cuda")
+        nat.check(mi.lib().mmidx_coarse_device(ix._h, len(Q), dQ.data_ptr(), cells.data_ptr(), cd.data_ptr(), None))
+        torch.cuda.synchronize()
+        res[v1] = (cells.cpu().numpy(), cd.cpu().numpy())
+    exp = np.stack([ref.nearest_coarse(q, w) for q in Q])
+    assert np.array_equal(res[0][0], exp) and np.array_equal(res[1][0], exp)
+    assert np.array_equal(res[0][1], res[1][1])
+    # exact distances: sequential fp64 sums of the selected cells
+    for qi in (0, 17, len(Q) - 1):
+        for r in (0, w - 1):
+            acc = 0.0
+            for a, b in zip(coarse[exp[qi, r]], Q[qi]):
+                df = a - b
+                acc += df * df
+            assert res[0][1][qi, r] == acc
+    ix.close()
+
+
+@pytest.mark.parametrize("m,D,k", [(16, 64, 50), (32, 64, 100), (8, 128, 200)])
+def test_pass_a_histogram_kernel_other_widths(mi, oracle, m, D, k):
+    """K3h template instances m = 16 / 32 and a larger k, long lists (forced on)."""
+    ks, C, w, n = 256, 3, 3, 36000
+    p = synth.make_ivfpq_problem(n=6000, D=D, C=C, m=m, ks=ks, nq=8, seed=m + k)
+    base, _ = synth.mixture(n, D, C, sigma=0.3, seed=m)
+    ix = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    ix.loadCoarseQuantizer(p["coarse"])
+    ix.loadProductQuantizer(p["pq"])
+    ix.setW(w)
+    ix.set_option("passa_hist", 1)
+    ref = oracle_ivfpq(oracle, p, D, m, ks, C, w)
+    ix.indexVectors([str(i) for i in range(n)], base)
+    ref.add_vectors(base)
+    rng = np.random.default_rng(1)
+    q = base[rng.choice(n, 10, replace=False)] + 0.01 * rng.standard_normal((10, D))
+    assert_same(ix.search_batch(k, q), ref.search_batch(q, k))
+    ix.close()
