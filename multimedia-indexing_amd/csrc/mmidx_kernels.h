@@ -836,7 +836,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_approx(const Appr
 //   accumulation of 3D exact products in fp32, any order, at most 2^-22 relative per step (twice the IEEE
 //   unit roundoff: the MFMA's internal summation order and rounding are not documented)
 //                                   <= (3D + 16) 2^-22 |q||c|
-//   d~ = |c|^2 + |q|^2 - 2 S evaluated in fp64 and stored as fp32: 2^-23 (|c| + |q|)^2
+//   d~ = |c|^2 + |q|^2 - 2 S evaluated in fp32 from fp32 copies of the norms: 2^-21 (|c| + |q|)^2
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 #define G16_BQ 128     // queries per block (32 per wave)
@@ -897,13 +897,13 @@ __global__ __launch_bounds__(MMIDX_BLOCK, 2) void k_coarse_gmin16(const __bf16 *
     const int t_per = (ntiles + gridDim.y - 1) / gridDim.y;
     const int t_lo = blockIdx.y * t_per, t_hi = (t_lo + t_per < ntiles) ? t_lo + t_per : ntiles;
     const int nkc = (Dp + G16_KC - 1) / G16_KC;
-    double qn_r[2][4];
+    float qn_r[2][4];
 #pragma unroll
     for (int rt = 0; rt < 2; rt++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int q = q0 + rt * 16 + 4 * fg + r;
-            qn_r[rt][r] = q < nq ? qn[q] : 0.0;
+            qn_r[rt][r] = q < nq ? (float)qn[q] : 0.0f;
         }
     bf16x8 ah[2][4], al[2][4];  // A fragments of one k chunk: [row tile][k step of 32]
     auto load_a = [&](int kc) {
@@ -940,37 +940,68 @@ __global__ __launch_bounds__(MMIDX_BLOCK, 2) void k_coarse_gmin16(const __bf16 *
             const int kw = (Dp - kbase < G16_KC) ? Dp - kbase : G16_KC;  // multiple of 32
             const int upr = kw >> 3;                                      // 16-byte units per row
             __syncthreads();  // the previous tile's fragment reads are done
-            for (int u = tid; u < G16_BC * upr; u += MMIDX_BLOCK) {
-                const int row = u / upr, cu = u - row * upr;
-                const size_t src = (size_t)(c0 + row) * Dp + kbase + cu * 8;
-                *(uint4 *)(Bh + row * G16_STRIDE + cu * 16) = *(const uint4 *)(Ch + src);
-                *(uint4 *)(Bl + row * G16_STRIDE + cu * 16) = *(const uint4 *)(Cl + src);
+            if (upr == 16) {  // full-width chunk: all 16 loads of the thread in flight, then the LDS stores
+                uint4 vh[8], vl[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int u = tid + i * MMIDX_BLOCK, row = u >> 4, cu = u & 15;
+                    const size_t src = (size_t)(c0 + row) * Dp + kbase + cu * 8;
+                    vh[i] = *(const uint4 *)(Ch + src);
+                    vl[i] = *(const uint4 *)(Cl + src);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int u = tid + i * MMIDX_BLOCK, row = u >> 4, cu = u & 15;
+                    *(uint4 *)(Bh + row * G16_STRIDE + cu * 16) = vh[i];
+                    *(uint4 *)(Bl + row * G16_STRIDE + cu * 16) = vl[i];
+                }
+            } else {
+                for (int u = tid; u < G16_BC * upr; u += MMIDX_BLOCK) {
+                    const int row = u / upr, cu = u - row * upr;
+                    const size_t src = (size_t)(c0 + row) * Dp + kbase + cu * 8;
+                    *(uint4 *)(Bh + row * G16_STRIDE + cu * 16) = *(const uint4 *)(Ch + src);
+                    *(uint4 *)(Bl + row * G16_STRIDE + cu * 16) = *(const uint4 *)(Cl + src);
+                }
             }
             if (nkc > 1) load_a(kc);
             __syncthreads();
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
                 if (ks * 32 < kw) {  // block-uniform
+                    // two column tiles at a time: four independent accumulators between dependent MFMAs
 #pragma unroll
-                    for (int ct = 0; ct < 8; ct++) {
-                        const int off = (ct * 16 + fr) * G16_STRIDE + (ks * 32 + fg * 8) * 2;
-                        const bf16x8 bh = *(const bf16x8 *)(Bh + off);
-                        const bf16x8 bl = *(const bf16x8 *)(Bl + off);
+                    for (int ct = 0; ct < 8; ct += 2) {
+                        bf16x8 bh[2], bl[2];
 #pragma unroll
-                        for (int rt = 0; rt < 2; rt++) {
-                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bh, acc[rt][ct], 0, 0, 0);
-                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bl, acc[rt][ct], 0, 0, 0);
-                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt][ks], bh, acc[rt][ct], 0, 0, 0);
+                        for (int u = 0; u < 2; u++) {
+                            const int off = ((ct + u) * 16 + fr) * G16_STRIDE + (ks * 32 + fg * 8) * 2;
+                            bh[u] = *(const bf16x8 *)(Bh + off);
+                            bl[u] = *(const bf16x8 *)(Bl + off);
                         }
+#pragma unroll
+                        for (int u = 0; u < 2; u++)
+#pragma unroll
+                            for (int rt = 0; rt < 2; rt++)
+                                acc[rt][ct + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bh[u], acc[rt][ct + u], 0, 0, 0);
+#pragma unroll
+                        for (int u = 0; u < 2; u++)
+#pragma unroll
+                            for (int rt = 0; rt < 2; rt++)
+                                acc[rt][ct + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bl[u], acc[rt][ct + u], 0, 0, 0);
+#pragma unroll
+                        for (int u = 0; u < 2; u++)
+#pragma unroll
+                            for (int rt = 0; rt < 2; rt++)
+                                acc[rt][ct + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt][ks], bh[u], acc[rt][ct + u], 0, 0, 0);
                     }
                 }
             }
         }
         // epilogue: d~ = |c|^2 + |q|^2 - 2 S.  A group = the 8 columns one lane holds for a row
         // (c0 + fr + 16 ct, ct = 0..7): its two smallest d~ and the position of the smallest, no cross-lane work
-        double cn_c[8];
+        float cn_c[8];  // (fp32 epilogue: three roundings of at most 2^-24 (|c| + |q|)^2 each, inside eps16's last term)
 #pragma unroll
-        for (int ct = 0; ct < 8; ct++) cn_c[ct] = cn[c0 + ct * 16 + fr];
+        for (int ct = 0; ct < 8; ct++) cn_c[ct] = (float)cn[c0 + ct * 16 + fr];
 #pragma unroll
         for (int rt = 0; rt < 2; rt++) {
 #pragma unroll
@@ -979,7 +1010,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK, 2) void k_coarse_gmin16(const __bf16 *
                 int a1 = 0;
 #pragma unroll
                 for (int ct = 0; ct < 8; ct++) {
-                    const float dv = (float)(cn_c[ct] + qn_r[rt][r] - 2.0 * (double)acc[rt][ct][r]);
+                    const float dv = (cn_c[ct] + qn_r[rt][r]) - 2.0f * acc[rt][ct][r];
                     const bool lt1 = dv < m1;
                     m2 = lt1 ? m1 : (dv < m2 ? dv : m2);
                     a1 = lt1 ? ct : a1;
@@ -1016,9 +1047,10 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_grp(const ApproxS
     const double qn = A.qn[q];
     const double qnorm = sqrt(qn);
     const double sumn = A.cnorm_max + qnorm;
-    // (+ 2^-20 (|c| + |q|)^2: the three mantissa bits borrowed from the runner-up)
+    // (2^-21 (|c| + |q|)^2: fp32 copies of |c|^2, |q|^2 and the three fp32 operations of the epilogue, five roundings of at
+    //  most 2^-24 each; + 2^-20: the three mantissa bits borrowed from the runner-up)
     const double eps16 = (2.0 * 3.1 * 0x1p-16 * qnorm * A.cnorm_max + 2.0 * (3.0 * (double)A.Dp + 16.0) * 0x1p-22 * qnorm * A.cnorm_max +
-                          1e-12 * (A.cn_max + qn) + (0x1p-22 + 0x1p-20) * sumn * sumn) * (1.0 + 1e-9);
+                          1e-12 * (A.cn_max + qn) + (0x1p-21 + 0x1p-20) * sumn * sumn) * (1.0 + 1e-9);
     const float inf = __int_as_float(0x7f800000);
     float m1[PERG], m2[PERG];
     int a1[PERG];

@@ -32,13 +32,13 @@ nat.check(L.mmidx_set_w(h, w))
 cells = torch.empty(nq, w, dtype=torch.int32, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 for _ in range(3):
-    nat.check(L.mmidx_coarse_device(h, nq, Q.data_ptr(), cells.data_ptr(), st))
+    nat.check(L.mmidx_coarse_device(h, nq, Q.data_ptr(), cells.data_ptr(), None, st))
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 R = 20
 for _ in range(R):
-    nat.check(L.mmidx_coarse_device(h, nq, Q.data_ptr(), cells.data_ptr(), st))
+    nat.check(L.mmidx_coarse_device(h, nq, Q.data_ptr(), cells.data_ptr(), None, st))
 e1.record()
 torch.cuda.synchronize()
 print(f"lib={os.path.basename(nat.SO_PATH)} nq={nq} C={Cc} D={D} w={w}: {e0.elapsed_time(e1) / R * 1e3:.1f} us per call, "
