@@ -606,3 +606,31 @@ def test_pass_a_histogram_kernel_other_widths(mi, oracle, m, D, k):
     q = base[rng.choice(n, 10, replace=False)] + 0.01 * rng.standard_normal((10, D))
     assert_same(ix.search_batch(k, q), ref.search_batch(q, k))
     ix.close()
+
+
+@pytest.mark.parametrize("name", ["ivfpq_small.npz", "ivfpq_perm.npz", "ivfpq_ties.npz", "pq_small.npz"])
+def test_golden_fixtures_gpu(mi, name):
+    """HIP path against the COMMITTED answers of tests/golden/ (no live oracle in the loop): encode output, neighbour
+    ids and distance bits.  ivfpq_ties is the flagged tie fixture (every vector three times, ties straddle k)."""
+    import os
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
+    D, m, ks, k = int(z["D"]), int(z["m"]), int(z["ks"]), int(z["k"])
+    n = len(z["base"])
+    if "coarse" in z.files:
+        tr = {0: mi.TransformationType.None_, 2: mi.TransformationType.RandomPermutation}[int(z["transform"])]
+        ix = mi.IVFPQ(D, n, False, "", m, ks, tr, int(z["C"]), 512)
+        ix.loadCoarseQuantizer(z["coarse"])
+        ix.loadProductQuantizer(z["pq"])
+        ix.setW(int(z["w"]))
+        cells, codes = ix.encode(z["base"])
+        assert np.array_equal(cells, z["cells"])
+    else:
+        ix = mi.PQ(D, n, False, "", m, ks, 0, 512)
+        ix.loadProductQuantizer(z["pq"])
+        cells, codes = ix.encode(z["base"])
+    assert np.array_equal(codes.astype(np.int32) + (128 if ks <= 256 else 0), z["codes"])
+    ix.indexVectors([str(i) for i in range(n)], z["base"])
+    iids, dists, counts = ix.search_batch(k, z["queries"])
+    assert np.array_equal(counts, z["counts"]) and np.array_equal(iids, z["ids"]) and np.array_equal(dists, z["dists"])
+    ix.close()
