@@ -102,6 +102,8 @@ struct mmidx_index {
     bool no_bound = false;   // MMIDX_NO_BOUND=1: no coarse-bound pruning of probes
     bool debug_sync = false; // MMIDX_DEBUG_SYNC=1
     bool passa_512 = false;  // MMIDX_PASSA_512=1: pass A with 512-thread blocks
+    int32_t *pin_hint = nullptr;  // pinned host word: pass B's item count of the previous call (launch sizing hint)
+    int passb_main_grid = 0;      // > 0: fixed size of pass B's main launch (tests: force the looping tail kernel)
     int passa_hist = -1;     // MMIDX_PASSA_HIST: 1 = always use K3h in pass A, 0 = never, -1 = lists of >= 4096 codes on average
     int passa_prefix = 0;    // MMIDX_PASSA_PREFIX=n: pass A scans n codes exactly, the rest of the list filtered
     bool passa_su2 = false;  // MMIDX_PASSA_SU2=1: pass A with 2 codes per thread per segment (A/B switch)
@@ -457,9 +459,29 @@ int make_plan(mmidx_index *h, int k, int64_t nq, SearchPlan &pl, bool need_coars
 }
 
 template <int M>
-int launch_filt_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t st) {
+int launch_filt_t(const mmidx_index *h, ScanParams P, dim3 grid, size_t lds, hipStream_t st) {
     HIPCK(hipFuncSetAttribute((const void *)k_scan_filt<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned worst = grid.x;
+    P.vgrid = worst;
+    P.vb_base = 0;
+    unsigned g1 = worst;
+    if (P.order) {
+        // device-side item count: size the main launch from the count seen last time (read back asynchronously into
+        // pinned memory: a hint, possibly stale), let a small grid of looping blocks cover the rest
+        const int32_t seen = h->pin_hint ? *(volatile int32_t *)h->pin_hint : -1;
+        const unsigned hint = seen >= 0 ? (unsigned)seen : worst;
+        const unsigned want = h->passb_main_grid > 0 ? (unsigned)h->passb_main_grid : 2u * hint + 2048u;
+        g1 = std::min(worst, (want + 7u) & ~7u);
+    }
+    grid.x = g1;
     hipLaunchKernelGGL((k_scan_filt<M>), grid, dim3(MMIDX_BLOCK), lds, st, P);
+    if (g1 < worst) {
+        HIPCK(hipFuncSetAttribute((const void *)k_scan_filt_tail<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        P.vb_base = g1;
+        grid.x = (std::min(worst - g1, 2048u) + 7u) & ~7u;
+        hipLaunchKernelGGL((k_scan_filt_tail<M>), grid, dim3(MMIDX_BLOCK), lds, st, P);
+    }
+    if (P.order && h->pin_hint) HIPCK(hipMemcpyAsync(h->pin_hint, P.n_order, 4, hipMemcpyDeviceToHost, st));
     HIPCK(hipGetLastError());
     return MMIDX_OK;
 }
@@ -475,9 +497,9 @@ int launch_scan_filtered(const mmidx_index *h, ScanParams P, const SearchPlan &p
                        (size_t)MMIDX_SURV_CAP * 4 + 16 + (size_t)h->m * 256;
     if (lds > 160 * 1024) return launch_scan(h, P, grid, pl.lds, st);
     switch (h->m) {
-        case 8: return launch_filt_t<8>(P, grid, lds, st);
-        case 16: return launch_filt_t<16>(P, grid, lds, st);
-        default: return launch_filt_t<32>(P, grid, lds, st);
+        case 8: return launch_filt_t<8>(h, P, grid, lds, st);
+        case 16: return launch_filt_t<16>(h, P, grid, lds, st);
+        default: return launch_filt_t<32>(h, P, grid, lds, st);
     }
 }
 
@@ -873,6 +895,12 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
                                h->ws_order.p, h->ws_keep.p);
             HIPCK(hipGetLastError());
             DBG_SYNC("pair sort");
+            if (h->debug_sync) {
+                int32_t nsurv = 0;
+                (void)hipMemcpy(&nsurv, h->ws_pstart.p + h->C, 4, hipMemcpyDeviceToHost);
+                fprintf(stderr, "[mmidx] pass B: %d of %lld (query, probe) pairs survive the coarse bound (rmax %.4f)\n", nsurv,
+                        (long long)nq * (P.w - 1), h->rmax);
+            }
             // pass B: the surviving pairs, list-major; the grid covers the worst case, blocks past
             // the device-side count exit at once
             P.order = h->ws_order.p;
@@ -1033,6 +1061,12 @@ int mmidx_create(int kind, int D, int m, int ks, int C, int transform, const int
     h->device = device;
     h->nlists = kind == MMIDX_KIND_IVFPQ ? C : 1;
     h->code_bytes = ks <= 256 ? 1 : 2;
+    if (hipHostMalloc((void **)&h->pin_hint, 64) == hipSuccess) {
+        *h->pin_hint = 0;
+    } else {
+        h->pin_hint = nullptr;  // (launches are then sized for the worst case)
+        (void)hipGetLastError();
+    }
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete h;
@@ -1094,6 +1128,11 @@ int mmidx_destroy(mmidx_index *h) {
     if (!h) return MMIDX_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->pin_hint) {
+        (void)hipDeviceSynchronize();  // a read-back of the hint may still be queued on the caller's stream
+        (void)hipHostFree(h->pin_hint);
+        h->pin_hint = nullptr;
+    }
     void *ptrs[] = {h->d_Ch, h->d_Cl, h->d_cn_pad, h->d_cn, h->d_cnorm, h->d_coarseT32, h->d_coarse, h->d_coarseT, h->d_pq, h->d_pqT, h->d_rot, h->d_perm, h->d_off, h->d_codes,
                     h->d_ids,    h->d_pcell,   h->d_pid, h->d_pcodes};
     for (void *p : ptrs)
@@ -1650,6 +1689,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->no_bound = value != 0;
     } else if (n == "exact_coarse") {
         h->exact_coarse = value != 0;
+    } else if (n == "passb_main_grid") {
+        h->passb_main_grid = value;
     } else if (n == "coarse_v1") {
         h->coarse_v1 = value != 0;
     } else if (n == "passa_hist") {

@@ -1175,6 +1175,7 @@ struct ScanParams {
     int rank_lo, nrank;      // natural order: item -> (q = item / nrank, rank = rank_lo + item % nrank)
     int xcd_remap;           // 1: consecutive items -> same XCD
     int chunk;               // codes per work item
+    unsigned vb_base, vgrid; // K3f: first virtual block of this launch / total number of virtual blocks
     const int32_t *order_ch; // with `order`: chunk of each item (fallback launches), else null = blockIdx.y
     u32 *fb_count;           // K3h: items handed back to K3
     int32_t *fb_items, *fb_ch;
@@ -1912,8 +1913,9 @@ __device__ __forceinline__ double lut_entry(const double *tr, const double *__re
     return acc;
 }
 
+// one work item of K3f; vb = virtual block index
 template <int M>
-__global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_filt(const ScanParams P) {
+__device__ __forceinline__ void scan_filt_body(const ScanParams &P, const unsigned vb, const int n_items) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int ks = P.ks, D = P.D;
     double *lut = (double *)smem;                        // [M*ks]   exact fp64 table
@@ -1926,12 +1928,11 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_filt(const ScanParams P) {
     u32 *s_cnt = surv + MMIDX_SURV_CAP;                  // [4]: 0 candidates, 1 survivors
     unsigned char *lut8 = (unsigned char *)(s_cnt + 4);  // [M][256] quantised lower-bound table
 
-    int item = blockIdx.x;
-    const int n_items = P.order ? *P.n_order : P.n_items;  // pass B: count left by the coarse bound
+    int item = (int)vb;
     if (P.xcd_remap) {
         const int per = (n_items + 7) >> 3;
-        if ((int)(blockIdx.x >> 3) >= per) return;
-        item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if ((int)(vb >> 3) >= per) return;
+        item = (int)(vb & 7) * per + (int)(vb >> 3);
     }
     if (item >= n_items) return;
     int q, pr;
@@ -2207,6 +2208,27 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_filt(const ScanParams P) {
                 }
             }
         }
+    }
+}
+
+// K3f launches.  Pass B's item count is only known on the device (what the coarse bound left), and a grid sized
+// for the worst case costs 0.1 ms of pure block dispatch when -- as on the benchmark -- nothing is left.  So the
+// host sizes the main launch from the count it saw last time (a hint, read back asynchronously), and a small grid
+// of looping blocks covers whatever lies beyond it.  Virtual block vb -> item is the same map in both.
+template <int M>
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_filt(const ScanParams P) {
+    const int n_items = P.order ? *P.n_order : P.n_items;  // pass B: count left by the coarse bound
+    scan_filt_body<M>(P, P.vb_base + blockIdx.x, n_items);
+}
+// (the loop costs registers -- the optimiser keeps far more live across it -- which is why it is not the main kernel)
+template <int M>
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_filt_tail(const ScanParams P) {
+    const int n_items = P.order ? *P.n_order : P.n_items;
+    const unsigned vlim = P.xcd_remap ? (unsigned)(((n_items + 7) >> 3) << 3) : (unsigned)n_items;
+    const unsigned vend = vlim < P.vgrid ? vlim : P.vgrid;
+    for (unsigned vb = P.vb_base + blockIdx.x; vb < vend; vb += gridDim.x) {
+        scan_filt_body<M>(P, vb, n_items);
+        __syncthreads();  // LDS is reused by the next item
     }
 }
 

@@ -634,3 +634,26 @@ def test_golden_fixtures_gpu(mi, name):
     iids, dists, counts = ix.search_batch(k, z["queries"])
     assert np.array_equal(counts, z["counts"]) and np.array_equal(iids, z["ids"]) and np.array_equal(dists, z["dists"])
     ix.close()
+
+
+def test_pass_b_tail_kernel(mi, oracle):
+    """Pass B's launch is sized from the item count of the previous call; what lies beyond it is handled by a small
+    grid of looping blocks (k_scan_filt_tail).  Force almost everything through that tail: same answers."""
+    D, C, m, ks, n, w = 32, 64, 8, 256, 30000, 32
+    p = synth.make_ivfpq_problem(n=8000, D=D, C=C, m=m, ks=ks, nq=40, seed=77)
+    base, _ = synth.mixture(n, D, C, sigma=0.5, seed=78)
+    ix = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    ix.loadCoarseQuantizer(p["coarse"])
+    ix.loadProductQuantizer(p["pq"])
+    ix.setW(w)
+    ref = oracle_ivfpq(oracle, p, D, m, ks, C, w)
+    ix.indexVectors([str(i) for i in range(n)], base)
+    ref.add_vectors(base)
+    rng = np.random.default_rng(2)
+    q = base[rng.choice(n, 40, replace=False)] + 0.2 * rng.standard_normal((40, D))
+    ix.set_option("no_bound", 1)  # keep every probe: plenty of pass-B items
+    want = ref.search_batch(q, 20)
+    for g in (8, 64, 0, 0):  # 0 = sized from the hint of the previous call (first large, then fitted)
+        ix.set_option("passb_main_grid", g)
+        assert_same(ix.search_batch(20, q), want)
+    ix.close()
