@@ -182,6 +182,20 @@ int mmidx_merge_partials_device(int device, int k, int64_t nq, int nshards, cons
                                 int32_t *d_iid_out, double *d_dist_out, int32_t *d_count_out,
                                 void *stream);
 
+/* ---- Linear: exhaustive exact search (J/datastructures/Linear.java; BASELINE config 1) ------------------------
+ * add = indexVectorInternal (:111-122), search = computeNearestNeighborsInternal(k, double[]) (:138-163): exact
+ * sequential fp64 squared distances, bounded-queue order and ties, ids = insertion order; get_vector = getVector
+ * (:253-263).  The vectors go through the coarse-stage kernels as if they were centroids (same arithmetic, same
+ * queue rule). */
+typedef struct mmidx_linear mmidx_linear;
+int mmidx_linear_create(int D, int64_t capacity, int device, mmidx_linear **out);
+int mmidx_linear_destroy(mmidx_linear *l);
+int mmidx_linear_add(mmidx_linear *l, int64_t n, const double *X);
+int mmidx_linear_size(const mmidx_linear *l, int64_t *n_out);
+int mmidx_linear_get_vector(const mmidx_linear *l, int64_t iid, double *out);
+int mmidx_linear_search(mmidx_linear *l, int k, int64_t nq, const double *Q, int32_t *iid_out, double *dist_out,
+                        int32_t *count_out);
+
 /* ---- codebook learning (J/visual/quantization/AbstractQuantizerLearning.java:39-81) ------
  * k-means on the GPU in place of Weka's SimpleKMeans, which the reference calls with setSeed(seed),
  * setNumClusters(k), setMaxIterations(max_iter) and, optionally, k-means++ seeding.  flags:

@@ -6,6 +6,6 @@ The directory name carries a hyphen (it follows the upstream project name), so i
 """
 from . import _native  # noqa: F401
 from ._native import MmidxError, build, lib  # noqa: F401
-from .index import IVFPQ, PQ, AbstractSearchStructure, Answer, TransformationType, read_quantizer  # noqa: F401
+from .index import IVFPQ, PQ, Linear, AbstractSearchStructure, Answer, TransformationType, read_quantizer  # noqa: F401
 from .frontend import PCA, VladAggregator, VladAggregatorMultipleVocabularies  # noqa: F401
 from . import quantization  # noqa: F401

@@ -91,6 +91,12 @@ SIGNATURES = {
     "mmidx_vlad_vector_length": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "mmidx_vlad_aggregate": (C.c_int, [_vp, C.c_int64, _vp, _dp, _dp]),
     "mmidx_vlad_aggregate_device": (C.c_int, [_vp, C.c_int64, _vp, _dp, C.c_int, _dp, _vp]),
+    "mmidx_linear_create": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
+    "mmidx_linear_destroy": (C.c_int, [_vp]),
+    "mmidx_linear_add": (C.c_int, [_vp, C.c_int64, _dp]),
+    "mmidx_linear_size": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    "mmidx_linear_get_vector": (C.c_int, [_vp, C.c_int64, _dp]),
+    "mmidx_linear_search": (C.c_int, [_vp, C.c_int, C.c_int64, _dp, _i32p, _dp, _i32p]),
     "mmidx_vectorize": (C.c_int, [_vp, _vp, C.c_int64, _vp, _dp, _dp]),
     "mmidx_vectorize_device": (C.c_int, [_vp, _vp, C.c_int64, _vp, _dp, C.c_int, _dp, _vp]),
     "mmidx_kmeans_device": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, _dp, _dp, _dp, _i32p, _dp,

@@ -2021,4 +2021,127 @@ int mmidx_vectorize(mmidx_vlad *v, mmidx_pca *p, int64_t nimg, const int64_t *de
     return MMIDX_OK;
 }
 
+// ---- Linear (exhaustive exact search, J/datastructures/Linear.java) -----------------------------------------------
+// computeNearestNeighborsInternal (Linear.java:138-163) offers (i, sum_j (q_j - x_ij)^2) for every vector in index order
+// to a bounded queue of size k: exactly what computeNearestCoarseIndices does with the coarse centroids and w, so the
+// indexed vectors are handed to the coarse stage as "centroids" (certified bf16 / fp32 matrix-core filter + exact fp64 for
+// the few candidates while n <= 16384, the plain exact kernels beyond that); (q - x)^2 and (x - q)^2 are the same bits.
+struct mmidx_linear {
+    int D = 0, device = 0;
+    int64_t capacity = 0;
+    std::vector<double> X;  // [n][D]; Linear keeps its vectors in memory too (TDoubleArrayList, Linear.java:45)
+    mmidx_index *inner = nullptr;
+    int64_t inner_n = -1;   // number of vectors the inner handle was built for
+    DevBuf<double> ws_Q, ws_d;
+    DevBuf<int32_t> ws_i;
+};
+
+int mmidx_linear_create(int D, int64_t capacity, int device, mmidx_linear **out) {
+    if (!out) return fail(MMIDX_ERR_INVALID_ARG, "null out pointer");
+    *out = nullptr;
+    if (D < 1 || capacity < 0) return fail(MMIDX_ERR_INVALID_ARG, "bad vector length / capacity");
+    const int ndev = mmidx_device_count();
+    if (ndev < 1) return fail(MMIDX_ERR_NO_DEVICE, "no HIP device: libmmidx_hip has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(MMIDX_ERR_NO_DEVICE, "device %d outside 0..%d", device, ndev - 1);
+    mmidx_linear *l = new mmidx_linear();
+    l->D = D;
+    l->device = device;
+    l->capacity = capacity;
+    *out = l;
+    return MMIDX_OK;
+}
+
+int mmidx_linear_destroy(mmidx_linear *l) {
+    if (!l) return MMIDX_OK;
+    (void)hipSetDevice(l->device);
+    if (l->inner) mmidx_destroy(l->inner);
+    l->ws_Q.release();
+    l->ws_d.release();
+    l->ws_i.release();
+    delete l;
+    return MMIDX_OK;
+}
+
+int mmidx_linear_add(mmidx_linear *l, int64_t n, const double *X) {  // indexVectorInternal, Linear.java:111-122
+    if (!l || n < 0 || (n > 0 && !X)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    const int64_t have = (int64_t)(l->X.size() / (size_t)l->D);
+    if (l->capacity > 0 && have + n > l->capacity) return fail(MMIDX_ERR_CAPACITY, "Maximum index capacity reached, no more vectors can be indexed!");
+    l->X.insert(l->X.end(), X, X + (size_t)n * l->D);
+    return MMIDX_OK;
+}
+
+int mmidx_linear_size(const mmidx_linear *l, int64_t *n_out) {
+    if (!l || !n_out) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    *n_out = (int64_t)(l->X.size() / (size_t)l->D);
+    return MMIDX_OK;
+}
+
+int mmidx_linear_get_vector(const mmidx_linear *l, int64_t iid, double *out) {  // Linear.getVector, Linear.java:253-263
+    if (!l || !out) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    const int64_t have = (int64_t)(l->X.size() / (size_t)l->D);
+    if (iid < 0 || iid >= have) return fail(MMIDX_ERR_INVALID_ARG, "Internal id %lld is out of range!", (long long)iid);
+    memcpy(out, l->X.data() + (size_t)iid * l->D, (size_t)l->D * 8);
+    return MMIDX_OK;
+}
+
+int mmidx_linear_search(mmidx_linear *l, int k, int64_t nq, const double *Q, int32_t *iid_out, double *dist_out, int32_t *count_out) {
+    if (!l) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    if (k < 1) return fail(MMIDX_ERR_INVALID_ARG, "k must be positive (got %d)", k);
+    if (nq < 0 || (nq > 0 && (!Q || !iid_out || !dist_out || !count_out))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    const int64_t n = (int64_t)(l->X.size() / (size_t)l->D);
+    if (n > 0x7fffffff) return fail(MMIDX_ERR_CAPACITY, "internal ids are 32-bit, as in the reference");
+    for (int64_t i = 0; i < nq * k; i++) {
+        iid_out[i] = -1;
+        dist_out[i] = std::numeric_limits<double>::infinity();
+    }
+    for (int64_t q = 0; q < nq; q++) count_out[q] = 0;
+    if (nq == 0 || n == 0) return MMIDX_OK;
+    HIPCK(hipSetDevice(l->device));
+    if (l->inner_n != n) {
+        if (l->inner) mmidx_destroy(l->inner);
+        l->inner = nullptr;
+        l->inner_n = -1;
+        int rc = mmidx_create(MMIDX_KIND_IVFPQ, l->D, 1, 2, (int)n, MMIDX_TR_NONE, nullptr, nullptr, l->device, &l->inner);
+        if (rc) return rc;
+        rc = mmidx_set_coarse(l->inner, l->X.data());
+        if (rc) return rc;
+        l->inner_n = n;
+    }
+    mmidx_index *h = l->inner;
+    const int w = (int)std::min<int64_t>(k, n);
+    h->w = w;
+    hipStream_t st = h->stream;
+    const int64_t qb = std::max<int64_t>(1, std::min<int64_t>(nq, (2ll << 30) / ((int64_t)n * 8)));
+    HIPCK(l->ws_Q.reserve((size_t)qb * l->D));
+    HIPCK(l->ws_i.reserve((size_t)qb * w));
+    HIPCK(l->ws_d.reserve((size_t)qb * w));
+    std::vector<int32_t> hi((size_t)qb * w);
+    std::vector<double> hd((size_t)qb * w);
+    for (int64_t q0 = 0; q0 < nq; q0 += qb) {
+        const int64_t nb = std::min(qb, nq - q0);
+        HIPCK(hipMemcpyAsync(l->ws_Q.p, Q + (size_t)q0 * l->D, (size_t)nb * l->D * 8, hipMemcpyHostToDevice, st));
+        int rc = run_coarse(h, nb, l->ws_Q.p, l->ws_i.p, st);
+        if (rc) return rc;
+        if (h->cdsel_valid) {
+            HIPCK(hipMemcpyAsync(l->ws_d.p, h->ws_cdsel.p, (size_t)nb * w * 8, hipMemcpyDeviceToDevice, st));
+        } else {
+            const long long tot = (long long)nb * w;
+            hipLaunchKernelGGL(k_gather_cdist, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->ws_cdist.p, l->ws_i.p, l->ws_d.p,
+                               h->C, w, tot);
+            HIPCK(hipGetLastError());
+        }
+        HIPCK(hipMemcpyAsync(hi.data(), l->ws_i.p, (size_t)nb * w * 4, hipMemcpyDeviceToHost, st));
+        HIPCK(hipMemcpyAsync(hd.data(), l->ws_d.p, (size_t)nb * w * 8, hipMemcpyDeviceToHost, st));
+        HIPCK(hipStreamSynchronize(st));
+        for (int64_t q = 0; q < nb; q++) {
+            for (int t = 0; t < w; t++) {
+                iid_out[(size_t)(q0 + q) * k + t] = hi[(size_t)q * w + t];
+                dist_out[(size_t)(q0 + q) * k + t] = hd[(size_t)q * w + t];
+            }
+            count_out[q0 + q] = w;
+        }
+    }
+    return MMIDX_OK;
+}
+
 }  // extern "C"

@@ -437,3 +437,61 @@ class IVFPQ(_PQBase):
         print(f"Maximum number of vectors: {int(s.max())}")
         print(f"Minimum number of vectors: {int(s.min())}")
         print(f"Average number of vectors: {float(s.sum()) / self.numCoarseCentroids}")
+
+
+class Linear(AbstractSearchStructure):
+    """Linear(vectorLength, maxNumVectors, readOnly, BDBEnvHome, ...), J/datastructures/Linear.java:67-100: exhaustive
+    exact search (BASELINE config 1).  indexVector / computeNearestNeighbors as everywhere; the arithmetic is the
+    reference's (sequential fp64 squared distance per vector, bounded queue in index order, Linear.java:138-163)."""
+
+    def __init__(self, vectorLength, maxNumVectors, readOnly=False, BDBEnvHome="", loadIndexInMemory=True, countSizeOnLoad=True,
+                 loadCounter=0, device=0):
+        super().__init__(vectorLength, maxNumVectors, readOnly, countSizeOnLoad, loadCounter, loadIndexInMemory)
+        h = C.c_void_p()
+        N.check(N.lib().mmidx_linear_create(vectorLength, maxNumVectors, device, C.byref(h)))
+        self._h = h
+
+    def _add_vectors(self, X, iids):
+        X = _f64(X)
+        N.check(N.lib().mmidx_linear_add(self._h, X.shape[0], X.ctypes.data))
+
+    def indexVectorInternal(self, vector):
+        if len(vector) != self.vectorLength:
+            raise MmidxError(N.ERR_WRONG_DIM, "The dimensionality of the vector is wrong!")
+        self._add_vectors(_f64(vector).reshape(1, -1), None)
+
+    def search_batch(self, k, Q):
+        Q = _f64(Q)
+        if Q.ndim != 2 or Q.shape[1] != self.vectorLength:
+            raise MmidxError(N.ERR_WRONG_DIM, "The dimensionality of the vector is wrong!")
+        nq = Q.shape[0]
+        iids = np.full((nq, max(k, 1)), -1, np.int32)
+        dists = np.full((nq, max(k, 1)), np.inf, np.float64)
+        counts = np.zeros(nq, np.int32)
+        N.check(N.lib().mmidx_linear_search(self._h, k, nq, Q.ctypes.data, iids.ctypes.data, dists.ctypes.data, counts.ctypes.data))
+        return iids, dists, counts
+
+    def computeNearestNeighborsInternal(self, k, query):
+        iids, dists, counts = self.search_batch(k, _f64(query).reshape(1, -1))
+        n = int(counts[0])
+        return iids[0, :n].copy(), dists[0, :n].copy()
+
+    def computeNearestNeighborsInternalById(self, k, iid):
+        # Linear.java:181-186: the stored vector of iid is the query
+        return self.computeNearestNeighborsInternal(k, self.getVector(iid))
+
+    def getVector(self, iid):
+        """Linear.getVector, Linear.java:253-263"""
+        out = np.zeros(self.vectorLength, np.float64)
+        N.check(N.lib().mmidx_linear_get_vector(self._h, int(iid), out.ctypes.data))
+        return out
+
+    def size(self):
+        n = C.c_int64(0)
+        N.check(N.lib().mmidx_linear_size(self._h, C.byref(n)))
+        return n.value
+
+    def close(self):
+        if self._h:
+            N.lib().mmidx_linear_destroy(self._h)
+            self._h = None

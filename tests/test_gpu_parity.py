@@ -657,3 +657,28 @@ def test_pass_b_tail_kernel(mi, oracle):
         ix.set_option("passb_main_grid", g)
         assert_same(ix.search_batch(20, q), want)
     ix.close()
+
+
+@pytest.mark.parametrize("n,D,k", [(10000, 128, 10), (40000, 32, 5), (300, 16, 400), (17000, 24, 100)])
+def test_linear_exact_search(mi, oracle, n, D, k):
+    """BASELINE config 1 (Linear, 10k x 128, k = 10) through the native path: ids and distance bits equal the oracle's
+    Linear restatement (Linear.java:138-163); n <= 16384 runs the certified matrix-core filter, larger n the plain exact
+    kernels; k > n returns n results; duplicated vectors exercise the queue's tie order."""
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((n, D))
+    X[n // 2:n // 2 + 30] = X[:30]  # exact duplicates
+    ix = mi.Linear(D, n + 5)
+    ix.indexVectors([f"v{i}" for i in range(n)], X)
+    assert ix.size() == n and np.array_equal(ix.getVector(7), X[7])
+    Q = np.concatenate([X[rng.choice(n, 20, replace=False)] + 0.05 * rng.standard_normal((20, D)), X[:4], rng.standard_normal((8, D))])
+    iids, dists, counts = ix.search_batch(k, Q)
+    for qi, q in enumerate(Q):
+        rid, rd = oracle.linear_search(X, q, k)
+        assert counts[qi] == len(rid) == min(k, n)
+        assert np.array_equal(iids[qi, :counts[qi]], rid), qi
+        assert np.array_equal(dists[qi, :counts[qi]], rd), qi
+    ans = ix.computeNearestNeighbors(3, "v11")  # by id: the stored vector is the query (Linear.java:181-186)
+    assert ans.getIds()[0] in ("v11", f"v{n // 2 + 11}") and ans.getDistances()[0] == 0.0
+    with pytest.raises(mi.MmidxError):
+        ix.indexVector("bad", np.zeros(D + 1))
+    ix.close()

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""BASELINE configs 2 and 3 on one MI355X (parity cases, not the headline bench line):
+"""BASELINE configs 1, 2 and 3 on one MI355X (parity cases, not the headline bench line):
+   cfg1  Linear      10k x 128, k = 10 (exact search through the coarse-stage kernels)
    cfg2  PQ ADC      1M x 128, m = 8 x 256,  k = 100
    cfg3  IVFPQ       1M x 128, C = 1024, w = 8, m = 16 x 256, k = 100
 Queries resident in HBM; every result compared with the CPU oracle on a query sample."""
@@ -102,4 +103,22 @@ out["cfg3_ivfpq_1M"] = {"qps_gpu": round(qps, 1), "index_s": round(t_index, 2), 
                         "ids_match": bool(np.array_equal(iid[:ns], rid)), "max_abs_ddist": float(np.max(np.abs(dd[:ns] - rd))),
                         "cpu_qps": round(cpu_qps, 1), "cpu_threads": os.cpu_count()}
 ix.close()
+
+# ---- cfg1: Linear 10k x 128, k = 10 (host pointers in and out: PCIe-inclusive)
+n1, k1 = 10000, 10
+X1 = rng.standard_normal((n1, D))
+lin = mi.Linear(D, n1)
+lin.indexVectors(list(range(n1)), X1)
+Q1 = X1[rng.choice(n1, 1000, replace=False)] + 0.05 * rng.standard_normal((1000, D))
+lin.search_batch(k1, Q1[:16])
+t0 = time.perf_counter()
+for _ in range(5):
+    li, ld, lc = lin.search_batch(k1, Q1)
+qps1 = 5 * len(Q1) / (time.perf_counter() - t0)
+t0 = time.perf_counter()
+bi, bd, bc = o.linear_search_batch(X1, Q1, k1, nthreads=os.cpu_count())
+cpu1 = len(Q1) / (time.perf_counter() - t0)
+out["cfg1_linear_10k"] = {"qps_gpu_host_buffers": round(qps1, 1), "ids_match": bool(np.array_equal(li, bi)),
+                          "max_abs_ddist": float(np.max(np.abs(ld - bd))), "cpu_qps": round(cpu1, 1), "cpu_threads": os.cpu_count()}
+lin.close()
 print(json.dumps(out))
