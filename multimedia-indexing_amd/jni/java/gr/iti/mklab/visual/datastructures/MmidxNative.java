@@ -34,6 +34,16 @@ final class MmidxNative {
 
 	static native void listSizes(long handle, int[] out) throws Exception;
 
+	/* ---- Linear (mmidx_linear_*) ---- */
+	static native long linearCreate(int vectorLength, long maxNumVectors, int device) throws Exception;
+
+	static native void linearDestroy(long handle);
+
+	static native void linearAdd(long handle, int n, double[] flatVectors) throws Exception;
+
+	static native void linearSearch(long handle, int k, int nq, double[] queries, int[] iidOut, double[] distOut,
+			int[] countOut) throws Exception;
+
 	private MmidxNative() {
 	}
 }

@@ -6,7 +6,7 @@
  * NOT compiled in the build container (no JDK, no jni.h).  On a box with a JDK:
  *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../include \
  *       mmidx_jni.c -o libmmidx_jni.so -L../csrc -lmmidx_hip
- * Java side: java/gr/iti/mklab/visual/datastructures/{MmidxNative,GpuIVFPQ,GpuPQ}.java
+ * Java side: java/gr/iti/mklab/visual/datastructures/{MmidxNative,GpuIVFPQ,GpuPQ,GpuLinear}.java
  */
 #include <jni.h>
 #include <stdint.h>
@@ -147,4 +147,47 @@ JNIEXPORT void JNICALL Java_gr_iti_mklab_visual_datastructures_MmidxNative_listS
     CHECK(mmidx_list_sizes(H(h), (int32_t *)o));
 done:
     (*env)->ReleaseIntArrayElements(env, out, o, 0);
+}
+
+/* ---- Linear ---------------------------------------------------------------------------------- */
+#define HL(handle) ((mmidx_linear *)(intptr_t)(handle))
+
+JNIEXPORT jlong JNICALL Java_gr_iti_mklab_visual_datastructures_MmidxNative_linearCreate(JNIEnv *env, jclass c, jint D,
+                                                                                          jlong cap, jint device) {
+    mmidx_linear *l = NULL;
+    (void)c;
+    CHECK(mmidx_linear_create(D, cap, device, &l));
+done:
+    return (jlong)(intptr_t)l;
+}
+
+JNIEXPORT void JNICALL Java_gr_iti_mklab_visual_datastructures_MmidxNative_linearDestroy(JNIEnv *env, jclass c, jlong h) {
+    (void)env;
+    (void)c;
+    mmidx_linear_destroy(HL(h));
+}
+
+JNIEXPORT void JNICALL Java_gr_iti_mklab_visual_datastructures_MmidxNative_linearAdd(JNIEnv *env, jclass c, jlong h, jint n,
+                                                                                      jdoubleArray flat) {
+    jdouble *a = (*env)->GetDoubleArrayElements(env, flat, NULL);
+    (void)c;
+    CHECK(mmidx_linear_add(HL(h), n, a));
+done:
+    (*env)->ReleaseDoubleArrayElements(env, flat, a, JNI_ABORT);
+}
+
+JNIEXPORT void JNICALL Java_gr_iti_mklab_visual_datastructures_MmidxNative_linearSearch(
+    JNIEnv *env, jclass c, jlong h, jint k, jint nq, jdoubleArray queries, jintArray iidOut, jdoubleArray distOut,
+    jintArray countOut) {
+    jdouble *q = (*env)->GetDoubleArrayElements(env, queries, NULL);
+    jint *ii = (*env)->GetIntArrayElements(env, iidOut, NULL);
+    jdouble *dd = (*env)->GetDoubleArrayElements(env, distOut, NULL);
+    jint *cc = (*env)->GetIntArrayElements(env, countOut, NULL);
+    (void)c;
+    CHECK(mmidx_linear_search(HL(h), k, nq, q, (int32_t *)ii, dd, (int32_t *)cc));
+done:
+    (*env)->ReleaseDoubleArrayElements(env, queries, q, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, iidOut, ii, 0);
+    (*env)->ReleaseDoubleArrayElements(env, distOut, dd, 0);
+    (*env)->ReleaseIntArrayElements(env, countOut, cc, 0);
 }
