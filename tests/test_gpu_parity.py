@@ -495,7 +495,7 @@ def test_pq_sdc_by_internal_id(mi, oracle, D, m, ks, n, k):
     iv.close()
 
 
-@pytest.mark.parametrize("case", ["long_lists", "ties", "short_lists", "flat_pq", "k1023_falls_back"])
+@pytest.mark.parametrize("case", ["long_lists", "ties", "short_lists", "flat_pq", "k1023_falls_back", "two_chunks", "two_chunks_ties"])
 def test_pass_a_histogram_kernel(mi, oracle, case):
     """K3h (histogram-thresholded pass A) forced on: same answers as the oracle on long lists, on
     tie-heavy lists (handed back to K3 through the fallback list), on lists shorter than a segment,
@@ -520,6 +520,10 @@ def test_pass_a_histogram_kernel(mi, oracle, case):
         C, w, n, ks_ = 4, 3, 60000, 256
     elif case == "ties":
         C, w, n, ks_ = 4, 4, 30000, 4  # 4 centroids per sub-quantizer: few distinct codes, thousands of exact ties
+    elif case == "two_chunks":  # lists longer than one 16384-code chunk: two K3h blocks per (query, list)
+        C, w, n, ks_ = 3, 3, 75000, 256
+    elif case == "two_chunks_ties":  # ... and handed back to K3 per (item, chunk) through the fallback list
+        C, w, n, ks_ = 3, 2, 70000, 4
     elif case == "short_lists":
         C, w, n, ks_ = 64, 8, 6000, 256
     else:
