@@ -113,6 +113,7 @@ struct mmidx_index {
     double rmax = 0.0;       // sqrt(sum_s max_j ||pq[s][j]||^2) * (1 + 1e-12)
     hipStream_t stream = nullptr;
     std::mutex mu;
+    std::mutex search_mu;  // host-pointer searches share the handle's workspaces and stream: one at a time
 
     double *d_coarse = nullptr, *d_coarseT = nullptr, *d_pq = nullptr, *d_pqT = nullptr,
            *d_rot = nullptr, *d_cn = nullptr, *d_cnorm = nullptr;
@@ -1492,6 +1493,7 @@ int mmidx_search(mmidx_index *h, int k, int64_t nq, const double *Q, int32_t *ii
     int rc = check_ready(h);
     if (rc) return rc;
     if (nq == 0) return MMIDX_OK;
+    std::lock_guard<std::mutex> slk(h->search_mu);  // concurrent readers are legal in the reference: they queue up here
     rc = set_device(h);
     if (rc) return rc;
     HIPCK(h->ws_Q.reserve((size_t)nq * h->D));
@@ -1518,6 +1520,7 @@ int mmidx_search_sdc(mmidx_index *h, int k, int64_t nq, const int32_t *iids, int
     int rc = check_ready(h);
     if (rc) return rc;
     if (nq == 0) return MMIDX_OK;
+    std::lock_guard<std::mutex> slk(h->search_mu);
     rc = set_device(h);
     if (rc) return rc;
     {

@@ -686,3 +686,40 @@ def test_linear_exact_search(mi, oracle, n, D, k):
     with pytest.raises(mi.MmidxError):
         ix.indexVector("bad", np.zeros(D + 1))
     ix.close()
+
+
+def test_concurrent_reader_threads(mi, oracle):
+    """computeNearestNeighbors is not synchronized in the reference (ASS:281-291): several threads may query one index.
+    The native host-pointer search queues them on a per-handle lock; every thread must get its own right answer."""
+    import threading
+
+    D, C, m, ks, n, w, k = 32, 16, 8, 256, 8000, 5, 10
+    p = synth.make_ivfpq_problem(n=n, D=D, C=C, m=m, ks=ks, nq=64, seed=91)
+    ix = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    ix.loadCoarseQuantizer(p["coarse"])
+    ix.loadProductQuantizer(p["pq"])
+    ix.setW(w)
+    ref = oracle_ivfpq(oracle, p, D, m, ks, C, w)
+    ix.indexVectors([str(i) for i in range(n)], p["base"])
+    ref.add_vectors(p["base"])
+    want = ref.search_batch(p["queries"], k)
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(6):
+                sl = slice((t * 7 + rep * 5) % 48, (t * 7 + rep * 5) % 48 + 16)
+                got = ix.search_batch(k, p["queries"][sl])
+                for a, b in zip(got, want):
+                    if not np.array_equal(a, b[sl]):
+                        errors.append((t, rep))
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
+    ix.close()
