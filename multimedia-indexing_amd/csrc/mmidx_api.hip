@@ -1780,12 +1780,14 @@ int mmidx_export(mmidx_index *h, int64_t *list_off_out, int32_t *iids_out, void 
 // Front end of BASELINE config 5: PCA projection (K7) and VLAD aggregation (K8)
 // =================================================================================================
 struct mmidx_pca {
+    std::mutex mu;  // host-pointer calls share the workspaces
     int nc = 0, ss = 0, whitening = 0, device = 0;
     double *d_mu = nullptr, *d_Vt = nullptr;
     hipStream_t stream = nullptr;
     DevBuf<double> ws_X, ws_Y;
 };
 struct mmidx_vlad {
+    std::mutex mu;  // host-pointer calls share the workspaces
     int nvocab = 0, dl = 0, norms = 0, device = 0, veclen = 0;
     std::vector<int> nc;
     std::vector<size_t> cb_off;  // element offset of each codebook
@@ -1856,6 +1858,7 @@ int mmidx_pca_project_device(mmidx_pca *p, int64_t n, const double *dX, double *
 int mmidx_pca_project(mmidx_pca *p, int64_t n, const double *X, double *Y) {
     if (!p) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
     if (n < 0 || (n > 0 && (!X || !Y))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(p->mu);
     HIPCK(hipSetDevice(p->device));
     const int64_t B = std::max<int64_t>(1, (int64_t)(1ll << 28) / p->ss);  // <= 2 GiB of samples per round
     for (int64_t i0 = 0; i0 < n; i0 += B) {
@@ -1956,6 +1959,7 @@ int mmidx_vlad_aggregate(mmidx_vlad *v, int64_t nimg, const int64_t *desc_off, c
     if (!v) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
     if (nimg < 0 || (nimg > 0 && (!desc_off || !out))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
     if (nimg == 0) return MMIDX_OK;
+    std::lock_guard<std::mutex> lk(v->mu);
     HIPCK(hipSetDevice(v->device));
     const int64_t total = desc_off[nimg] - desc_off[0];
     if (total > 0 && !descs) return fail(MMIDX_ERR_INVALID_ARG, "null descriptors");
@@ -2004,6 +2008,8 @@ int mmidx_vectorize(mmidx_vlad *v, mmidx_pca *p, int64_t nimg, const int64_t *de
     if (!v || !p) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
     if (nimg < 0 || (nimg > 0 && (!desc_off || !out))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
     if (nimg == 0) return MMIDX_OK;
+    std::lock_guard<std::mutex> lk(v->mu);
+    std::lock_guard<std::mutex> lk2(p->mu);
     HIPCK(hipSetDevice(v->device));
     const int64_t total = desc_off[nimg] - desc_off[0];
     if (total > 0 && !descs) return fail(MMIDX_ERR_INVALID_ARG, "null descriptors");
@@ -2030,6 +2036,7 @@ int mmidx_vectorize(mmidx_vlad *v, mmidx_pca *p, int64_t nimg, const int64_t *de
 // indexed vectors are handed to the coarse stage as "centroids" (certified bf16 / fp32 matrix-core filter + exact fp64 for
 // the few candidates while n <= 16384, the plain exact kernels beyond that); (q - x)^2 and (x - q)^2 are the same bits.
 struct mmidx_linear {
+    std::mutex mu;
     int D = 0, device = 0;
     int64_t capacity = 0;
     std::vector<double> X;  // [n][D]; Linear keeps its vectors in memory too (TDoubleArrayList, Linear.java:45)
@@ -2067,6 +2074,7 @@ int mmidx_linear_destroy(mmidx_linear *l) {
 
 int mmidx_linear_add(mmidx_linear *l, int64_t n, const double *X) {  // indexVectorInternal, Linear.java:111-122
     if (!l || n < 0 || (n > 0 && !X)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(l->mu);
     const int64_t have = (int64_t)(l->X.size() / (size_t)l->D);
     if (l->capacity > 0 && have + n > l->capacity) return fail(MMIDX_ERR_CAPACITY, "Maximum index capacity reached, no more vectors can be indexed!");
     l->X.insert(l->X.end(), X, X + (size_t)n * l->D);
@@ -2091,6 +2099,7 @@ int mmidx_linear_search(mmidx_linear *l, int k, int64_t nq, const double *Q, int
     if (!l) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
     if (k < 1) return fail(MMIDX_ERR_INVALID_ARG, "k must be positive (got %d)", k);
     if (nq < 0 || (nq > 0 && (!Q || !iid_out || !dist_out || !count_out))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(l->mu);
     const int64_t n = (int64_t)(l->X.size() / (size_t)l->D);
     if (n > 0x7fffffff) return fail(MMIDX_ERR_CAPACITY, "internal ids are 32-bit, as in the reference");
     for (int64_t i = 0; i < nq * k; i++) {
