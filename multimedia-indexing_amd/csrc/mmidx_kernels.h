@@ -274,6 +274,9 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_reg(const double 
 #ifndef MMIDX_CAND_CHUNK
 #define MMIDX_CAND_CHUNK 24
 #endif
+#ifndef MMIDX_LUT_PAIRS
+#define MMIDX_LUT_PAIRS 1  // table build: two adjacent entries per thread (16-byte loads)
+#endif
 #ifndef MMIDX_HIST_DEBUG
 #define MMIDX_HIST_DEBUG 0  // debug: K3h adds overflow / appended / kept totals to the fallback header
 #endif
@@ -1256,6 +1259,29 @@ __device__ __forceinline__ void build_lut(double *lut, const double *tr, const d
                                           int ks, int dsub_rt) {
     const int total = m * ks;
     if constexpr (DSUB > 0) {
+#if MMIDX_LUT_PAIRS
+        if ((ks & 1) == 0) {  // two adjacent entries per thread: 16-byte loads, half as many load instructions
+            const int hk = ks >> 1;
+#pragma unroll 2
+            for (int pi = threadIdx.x; pi < (total >> 1); pi += blockDim.x) {
+                const int s = pi / hk, j = (pi - s * hk) * 2;
+                const double *pp = pqT + (size_t)s * DSUB * ks + j;
+                double2 pv[DSUB];
+#pragma unroll
+                for (int t = 0; t < DSUB; t++) pv[t] = *(const double2 *)(pp + (size_t)t * ks);
+                const double *tv = tr + s * DSUB;
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int t = 0; t < DSUB; t++) {
+                    const double d0 = tv[t] - pv[t].x, d1 = tv[t] - pv[t].y;
+                    a0 += d0 * d0;
+                    a1 += d1 * d1;
+                }
+                *(double2 *)(lut + s * ks + j) = make_double2(a0, a1);
+            }
+            return;
+        }
+#endif
 #pragma unroll 2
         for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
             const int s = idx / ks, j = idx - s * ks;
