@@ -552,7 +552,36 @@ __device__ __forceinline__ void coarse_select_finish(const ApproxSel &A, const i
         double *terms = (double *)(sel_i + ((A.w + 2) & ~1));  // [CAND_CHUNK][D]
         for (int base = 0; base < n; base += MMIDX_CAND_CHUNK) {
             const int nc_ = (n - base < MMIDX_CAND_CHUNK) ? n - base : MMIDX_CAND_CHUNK;
-            for (int e0 = 0; e0 < nc_ * D; e0 += MMIDX_BLOCK * 8) {  // 8 independent loads in flight per thread
+            if ((D & 1) == 0) {
+                // 16-byte loads: element pairs (j, j + 1) of a candidate row; 8 pairs in flight per thread
+                const int hD = D >> 1;
+                for (int e0 = 0; e0 < nc_ * hD; e0 += MMIDX_BLOCK * 8) {
+                    double2 cv[8], qq[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int e = e0 + u * MMIDX_BLOCK + tid;
+                        cv[u] = make_double2(0.0, 0.0);
+                        qq[u] = cv[u];
+                        if (e < nc_ * hD) {
+                            const int ci = e / hD, j = (e - ci * hD) * 2;
+                            cv[u] = *(const double2 *)(A.coarse + (size_t)cidx[base + ci] * D + j);
+                            qq[u] = *(const double2 *)(qv + j);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int e = e0 + u * MMIDX_BLOCK + tid;
+                        if (e < nc_ * hD) {
+                            const int ci = e / hD, j = (e - ci * hD) * 2;
+                            const double d0 = cv[u].x - qq[u].x, d1 = cv[u].y - qq[u].y;
+                            double *tt = terms + (size_t)ci * (D + MMIDX_TERM_PAD) + j;
+                            tt[0] = d0 * d0;
+                            tt[1] = d1 * d1;
+                        }
+                    }
+                }
+            } else
+                for (int e0 = 0; e0 < nc_ * D; e0 += MMIDX_BLOCK * 8) {  // 8 independent loads in flight per thread
                 double cv[8], qq[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
