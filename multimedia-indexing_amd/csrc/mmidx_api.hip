@@ -132,6 +132,7 @@ struct mmidx_index {
     int64_t n_csr = 0;
     std::vector<int64_t> h_off;  // [nlists+1]
     int64_t max_list_len = 0;
+    int64_t nonempty_lists = 0;  // (a shard holds only its share of the lists: averages are taken over these)
     int64_t *d_off = nullptr;
     void *d_codes = nullptr;
     int32_t *d_ids = nullptr;
@@ -275,7 +276,12 @@ int build_csr(mmidx_index *h) {
         h->ws_dest.release();
     }
     h->max_list_len = 0;
-    for (int c = 0; c < nl; c++) h->max_list_len = std::max(h->max_list_len, off_new[(size_t)c + 1] - off_new[(size_t)c]);
+    h->nonempty_lists = 0;
+    for (int c = 0; c < nl; c++) {
+        const int64_t len = off_new[(size_t)c + 1] - off_new[(size_t)c];
+        h->max_list_len = std::max(h->max_list_len, len);
+        h->nonempty_lists += len > 0;
+    }
     return MMIDX_OK;
 }
 
@@ -796,7 +802,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
             } else if (!h->no_seed) {
                 rc = launch_scan_seeded(h, P, pl, dim3((unsigned)P.n_items, (unsigned)grid_chunks), st);
             } else if (two_pass && !sdc_tt && h->passa_hist != 0 &&
-                       (h->passa_hist > 0 || h->n_csr / std::max<int64_t>(1, ivf ? h->C : 1) >= 4096) &&
+                       (h->passa_hist > 0 || h->n_csr / std::max<int64_t>(1, ivf ? h->nonempty_lists : 1) >= 4096) &&
                        (rc = launch_scan_hist(h, P, pl, dim3((unsigned)P.n_items, (unsigned)grid_chunks), st)) != 1) {
                 // (K3h ran -- its empty fallback launch is not counted as a scan launch -- or failed with rc > 1)
             } else {
