@@ -955,8 +955,13 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
     while (mcap < 2 * pl.K1) mcap <<= 1;  // <= 2048
     M.cap = mcap;
     const size_t mlds = (size_t)mcap * 16 + ((ivf && P.w <= 1024) ? (size_t)P.w * 8 : 0);
-    HIPCK(hipFuncSetAttribute((const void *)k_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
-    hipLaunchKernelGGL(k_merge, dim3((unsigned)nq), dim3(MMIDX_BLOCK), mlds, st, M);
+    if (pl.K1 <= 128) {
+        HIPCK(hipFuncSetAttribute((const void *)k_merge<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+        hipLaunchKernelGGL(k_merge<128>, dim3((unsigned)nq), dim3(128), mlds, st, M);
+    } else {
+        HIPCK(hipFuncSetAttribute((const void *)k_merge<MMIDX_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+        hipLaunchKernelGGL(k_merge<MMIDX_BLOCK>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), mlds, st, M);
+    }
     HIPCK(hipGetLastError());
     DBG_SYNC("merge");
     if (mode == 0 && h->n_csr > 0) {

@@ -2717,7 +2717,10 @@ struct MergeParams {
     long long *pkey;         // [nq][k+1]
 };
 
-__global__ __launch_bounds__(MMIDX_BLOCK) void k_merge(const MergeParams P) {
+// NT = threads per block: 128 when k + 1 <= 128 (the survivors fit one per thread and twice as many queries are in
+// flight per CU: the kernel is a chain of dependent memory round trips), else 256
+template <int NT>
+__global__ __launch_bounds__(NT) void k_merge(const MergeParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int CAP = P.cap;           // power of two, > K1
     u64 *key = (u64 *)smem;          // [CAP]
@@ -2741,7 +2744,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_merge(const MergeParams P) {
     if (tid == 0) s_m = 0;
     const bool offs_in_lds = P.cells && P.w <= 1024;  // (the host sized the LDS accordingly)
     if (offs_in_lds)
-        for (int t = tid; t < P.w; t += MMIDX_BLOCK) s_off[t] = P.list_off[P.cells[(size_t)q * P.w + t]];
+        for (int t = tid; t < P.w; t += NT) s_off[t] = P.list_off[P.cells[(size_t)q * P.w + t]];
     auto list_start = [&](int rank) -> int64_t {
         if (offs_in_lds) return s_off[rank];
         return P.list_off[P.cells ? P.cells[(size_t)q * P.w + rank] : 0];
@@ -2749,7 +2752,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_merge(const MergeParams P) {
     __syncthreads();
     {
         const u64 lane_lt = (1ull << (tid & 63)) - 1ull;
-        for (int base0 = 0; base0 < n; base0 += MMIDX_BLOCK) {
+        for (int base0 = 0; base0 < n; base0 += NT) {
             const int e = base0 + tid;
             u64 kk = MMIDX_KEY_MAX, vv = 0;
             if (e < n) {  // both loads in flight together
@@ -2776,7 +2779,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_merge(const MergeParams P) {
     __syncthreads();
     const int m = (int)s_m;
     int kept = 0;
-    if (m <= MMIDX_BLOCK) {
+    if (m <= NT) {
         const bool have = tid < m;
         const u64 mk = have ? key[tid] : MMIDX_KEY_MAX, mv = have ? val[tid] : MMIDX_KEY_MAX;
         int rank = 0;
@@ -2793,7 +2796,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_merge(const MergeParams P) {
         kept = m < K1 ? m : K1;
     } else if (m <= CAP) {
         const int Pn = pow2ceil(m);
-        for (int i = m + tid; i < Pn; i += MMIDX_BLOCK) {
+        for (int i = m + tid; i < Pn; i += NT) {
             key[i] = MMIDX_KEY_MAX;
             val[i] = MMIDX_KEY_MAX;
         }
@@ -2806,13 +2809,13 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_merge(const MergeParams P) {
             int take = n - consumed;
             if (take > CAP - kept) take = CAP - kept;
             __syncthreads();
-            for (int i = tid; i < take; i += MMIDX_BLOCK) {
+            for (int i = tid; i < take; i += NT) {
                 key[kept + i] = pk[consumed + i];
                 val[kept + i] = pv[consumed + i];
             }
             const int filled = kept + take;
             const int Pn = pow2ceil(filled < 2 ? 2 : filled);
-            for (int i = filled + tid; i < Pn; i += MMIDX_BLOCK) {
+            for (int i = filled + tid; i < Pn; i += NT) {
                 key[i] = MMIDX_KEY_MAX;
                 val[i] = MMIDX_KEY_MAX;
             }
@@ -2824,7 +2827,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_merge(const MergeParams P) {
     const int total = kept;  // min(n, K1), sorted by (key, offer order)
     const int cnt = total < P.k ? total : P.k;
     if (P.mode == 1) {
-        for (int i = tid; i < K1; i += MMIDX_BLOCK) {
+        for (int i = tid; i < K1; i += NT) {
             double dd = __longlong_as_double(0x7FF0000000000000ll);
             long long kk = -1;
             if (i < total) {
@@ -2841,7 +2844,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_merge(const MergeParams P) {
         if (tid == 0) P.count_out[q] = total;
         return;
     }
-    for (int i = tid; i < P.k; i += MMIDX_BLOCK) {
+    for (int i = tid; i < P.k; i += NT) {
         int iid = -1;
         double dd = __longlong_as_double(0x7FF0000000000000ll);
         if (i < cnt) {
