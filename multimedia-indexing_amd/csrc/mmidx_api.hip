@@ -539,8 +539,10 @@ int launch_scan_hist(mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 gr
     const size_t lds = fixed + (size_t)cap * 4;
     if (lds > 64 * 1024) return 1;
     const size_t nfb = (size_t)grid.x * grid.y;
-    HIPCK(h->ws_fb.reserve(2 * nfb + 4));
-    HIPCK(hipMemsetAsync(h->ws_fb.p, 0, 4 * sizeof(int32_t), st));
+    if (h->ws_fb.cap < 2 * nfb + 4) {  // (search_batch_device reserves and zeroes the header; a direct caller would land here)
+        HIPCK(h->ws_fb.reserve(2 * nfb + 4));
+        HIPCK(hipMemsetAsync(h->ws_fb.p, 0, 4 * sizeof(int32_t), st));
+    }
     P.cap = cap;
     P.fb_count = (u32 *)h->ws_fb.p;
     P.fb_items = h->ws_fb.p + 4;
@@ -746,9 +748,20 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
     HIPCK(h->ws_pkey.reserve((size_t)nq * pl.poolq));
     HIPCK(h->ws_pval.reserve((size_t)nq * pl.poolq));
     HIPCK(h->ws_flag.reserve((size_t)nq));
+    bool pcount_zeroed = false;
     if (phase != 2) {
-        HIPCK(hipMemsetAsync(h->ws_T.p, 0xFF, (size_t)nq * sizeof(u64), st));
-        HIPCK(hipMemsetAsync(h->ws_pcnt.p, 0, (size_t)nq * sizeof(u32), st));
+        // thresholds, pool counters, per-cell pair counters and the K3h fallback header in one launch
+        int32_t *pc = nullptr;
+        if (ivf) {
+            HIPCK(h->ws_pcount.reserve((size_t)h->C));
+            pc = h->ws_pcount.p;
+            pcount_zeroed = phase == 0;  // (phase 1 ends before the pair sort; phase 2 zeroes them itself)
+        }
+        HIPCK(h->ws_fb.reserve(2 * (size_t)nq * (size_t)std::max(1, pl.nchunks) + 4));
+        const long long span = std::max<long long>((long long)nq, ivf ? (long long)h->C : 0);
+        hipLaunchKernelGGL(k_step_init, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, st, h->ws_T.p, h->ws_pcnt.p, (long long)nq, pc,
+                           h->C, h->ws_fb.p);
+        HIPCK(hipGetLastError());
     }
 
     ScanParams P{};
@@ -869,7 +882,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
             HIPCK(h->ws_pcursor.reserve((size_t)h->C));
             HIPCK(h->ws_order.reserve((size_t)npairs));
             HIPCK(h->ws_keep.reserve((size_t)npairs));
-            HIPCK(hipMemsetAsync(h->ws_pcount.p, 0, (size_t)h->C * sizeof(int32_t), st));
+            if (!pcount_zeroed) HIPCK(hipMemsetAsync(h->ws_pcount.p, 0, (size_t)h->C * sizeof(int32_t), st));
             PairBound PB{};
             PB.Q = dQ;
             PB.coarse = h->d_coarse;

@@ -2634,6 +2634,18 @@ __device__ __forceinline__ bool pair_keep(const PairBound &B, long long e, int q
     return nonempty & !prune;
 }
 
+// one launch instead of four memsets at the start of a search step: thresholds = +inf (all ones), pool counters,
+// per-cell pair counters and the K3h fallback header = 0
+__global__ void k_step_init(u64 *__restrict__ T, u32 *__restrict__ pool_cnt, long long nq, int32_t *__restrict__ pcount, int C,
+                            int32_t *__restrict__ fb_header) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nq) {
+        T[i] = MMIDX_KEY_MAX;
+        pool_cnt[i] = 0;
+    }
+    if (pcount && i < C) pcount[i] = 0;
+    if (fb_header && i < 4) fb_header[i] = 0;
+}
 // cdist_out[q][r] = dist[q][cells[q][r]] (exact coarse path: the selected cells' distances for other ranks)
 __global__ void k_gather_cdist(const double *__restrict__ dist, const int32_t *__restrict__ cells, double *__restrict__ out, int C, int w,
                                long long total) {
@@ -2657,27 +2669,25 @@ __global__ void k_pair_hist(const int32_t *__restrict__ cells, int w, int rank_l
 // single block: exclusive scan of cnt[C] -> start[C]; start[C] = total; cursor zeroed
 __global__ __launch_bounds__(1024) void k_pair_scan(const int32_t *__restrict__ cnt, int C, int32_t *__restrict__ start,
                                                     int32_t *__restrict__ cursor) {
-    __shared__ int s_part[1024];
-    const int tid = threadIdx.x;
+    __shared__ u32 s_wave[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int per = (C + 1023) / 1024;
     const int lo = tid * per, hi = (lo + per < C) ? lo + per : C;
-    int sum = 0;
-    for (int c = lo; c < hi; c++) sum += cnt[c];
-    s_part[tid] = sum;
+    u32 sum = 0;
+    for (int c = lo; c < hi; c++) sum += (u32)cnt[c];
+    const u32 incl = wave_incl_scan_u32(sum);  // inside the wave: DPP, no barrier
+    if (lane == 63) s_wave[wv] = incl;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        int v = (tid >= off) ? s_part[tid - off] : 0;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
-    }
-    int run = s_part[tid] - sum;  // exclusive prefix of this thread's range
+    u32 base = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) base += (i < wv) ? s_wave[i] : 0u;
+    u32 run = base + incl - sum;  // exclusive prefix of this thread's range
     for (int c = lo; c < hi; c++) {
-        start[c] = run;
+        start[c] = (int32_t)run;
         cursor[c] = 0;
-        run += cnt[c];
+        run += (u32)cnt[c];
     }
-    if (tid == 1023) start[C] = s_part[1023];
+    if (tid == 1023) start[C] = (int32_t)(base + incl);
 }
 __global__ void k_pair_scatter(const int32_t *__restrict__ cells, int w, int rank_lo, long long npairs,
                                const int32_t *__restrict__ start, int32_t *__restrict__ cursor,
