@@ -1852,6 +1852,9 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
         //      region), then evaluate only them -- kept_total <= HKEEP = one per thread -------------------
         u32 *keptpos = hist;  // the histogram is dead (every wave has derived the final bucket): barrier first
         __syncthreads();
+        // the pool space of all kept_total entries is reserved now, so that the reservation's round trip overlaps the
+        // compaction and the code loads (entries above another chunk's threshold are written too: harmless)
+        if (tid == 0) s_cnt[7] = atomicAdd(P.pool_cnt + q, kept_total);
         const u32 mine = s_cnt[wv];  // <= capw here
         for (u32 e0 = 0; e0 < mine; e0 += 64) {
             const u32 e = e0 + (u32)lane;
@@ -1873,15 +1876,10 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
         cv.load(codes + (size_t)p * M);
         const double dd = exact(cv);
         const u64 key = dkey(dd);
-        if (have) kmax = key;
-        const u32 nk = (have && key <= Tg) ? 1u : 0u;
-        const u32 incl = wave_incl_scan_u32(nk);
-        const u32 wtot = wave_read_u32(incl, 63);
-        if (wtot) {  // wave-uniform: one pool reservation per wave
-            u32 base = 0;
-            if (lane == 0) base = atomicAdd(P.pool_cnt + q, wtot);
-            const u32 slot = wave_read_u32(base, 0) + incl - nk;
-            if (nk && slot < (u32)P.poolq) {
+        if (have) {
+            kmax = key;
+            const u32 slot = s_cnt[7] + (u32)tid;  // (written before the barrier above)
+            if (slot < (u32)P.poolq) {
                 P.pool_key[(size_t)q * P.poolq + slot] = key;
                 P.pool_val[(size_t)q * P.poolq + slot] = ((u64)pr << 32) | (u64)p;
             }
