@@ -1001,14 +1001,12 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
     }
     if (prof) {
         HIPCK(hipEventRecord(ev[4], st));
-        if (ivf) {
+        if (!ivf) h->host_codes += nq * h->n_csr;
+        if (ivf || mode == 0) {
             const long long tot = (long long)nq * h->w;
-            hipLaunchKernelGGL(k_count_codes, dim3((unsigned)std::min<long long>((tot + 255) / 256, 256)), dim3(256), 0, st, d_cells, h->d_off, tot, h->d_counters);
-        } else {
-            h->host_codes += nq * h->n_csr;
+            hipLaunchKernelGGL(k_count_stats, dim3(256), dim3(256), 0, st, ivf ? d_cells : nullptr, h->d_off, tot,
+                               mode == 0 ? h->ws_flag.p : nullptr, (long long)nq, h->d_counters);
         }
-        if (mode == 0)
-            hipLaunchKernelGGL(k_count_flags, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, h->ws_flag.p, (long long)nq, h->d_counters + 1);
         HIPCK(hipGetLastError());
     }
     return MMIDX_OK;

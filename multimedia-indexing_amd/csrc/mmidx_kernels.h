@@ -3468,23 +3468,42 @@ __global__ void k_unbias_codes(const signed char *in, unsigned char *out, long l
 // instrumentation (profiling mode only): algorithmic work of a launch = sum over (query, probe) of
 // the probed list lengths; number of queries that needed the tie replay.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_count_codes(const int32_t *__restrict__ cells, const int64_t *__restrict__ list_off,
-                              long long n, u64 *__restrict__ total) {
-    u64 v = 0;  // grid-stride: a few hundred blocks, one atomic per wave
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
-        const int c = cells[e];
-        if (c >= 0) v += (u64)(list_off[c + 1] - list_off[c]);
+// profiling counters in one launch: total[0] += sum of the probed lists' lengths (cells may be null: flat PQ counts on the
+// host), total[1] += number of flagged queries (flag may be null).  Eight independent loads per thread are in flight
+// before their dependent list_off loads: the kernel sits inside the timed region of bench.py.
+__global__ void k_count_stats(const int32_t *__restrict__ cells, const int64_t *__restrict__ list_off, long long n,
+                              const int32_t *__restrict__ flag, long long nq, u64 *__restrict__ total) {
+    const long long stride = (long long)gridDim.x * blockDim.x, t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 v = 0, f = 0;
+    if (cells) {
+        for (long long e0 = t0; e0 < n; e0 += 8 * stride) {
+            int c[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const long long e = e0 + u * stride;
+                c[u] = e < n ? cells[e] : -1;
+            }
+            int64_t a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                a[u] = c[u] >= 0 ? list_off[c[u]] : 0;
+                b[u] = c[u] >= 0 ? list_off[c[u] + 1] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) v += (u64)(b[u] - a[u]);
+        }
     }
+    if (flag)
+        for (long long e = t0; e < nq; e += stride) f += flag[e] ? 1 : 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(total, v);
-}
-__global__ void k_count_flags(const int32_t *__restrict__ flag, long long n, u64 *__restrict__ total) {
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    u64 v = (e < n && flag[e]) ? 1 : 0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(total, v);
+    for (int off = 32; off > 0; off >>= 1) {
+        v += __shfl_xor(v, off);
+        f += __shfl_xor(f, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (v) atomicAdd(total, v);
+        if (f) atomicAdd(total + 1, f);
+    }
 }
 
 // thresholds cross the process boundary as doubles (+inf = "fewer than k+1 candidates so far") so
