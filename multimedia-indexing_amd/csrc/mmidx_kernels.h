@@ -3500,7 +3500,18 @@ __global__ void k_count_stats(const int32_t *__restrict__ cells, const int64_t *
         v += __shfl_xor(v, off);
         f += __shfl_xor(f, off);
     }
+    __shared__ u64 s_v[16], s_f[16];  // one pair of atomics per block, not per wave (they all hit the same two words)
+    const int wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     if ((threadIdx.x & 63) == 0) {
+        s_v[wv] = v;
+        s_f[wv] = f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < nw; i++) {
+            v += s_v[i];
+            f += s_f[i];
+        }
         if (v) atomicAdd(total, v);
         if (f) atomicAdd(total + 1, f);
     }
