@@ -1058,6 +1058,195 @@ __global__ __launch_bounds__(MMIDX_BLOCK, 2) void k_coarse_gmin16(const __bf16 *
     }
 }
 
+// K6a': certified nearest-centroid assignment with the bf16-split dot products of K1e (the encoder's and the learner's
+// argmin).  Each block keeps 128 vectors' fragments in registers and walks ALL centroid tiles; every lane tracks the
+// smallest and second smallest d~ (and the index of the smallest) over the columns it holds for each of its rows, the 16
+// lanes of a row are merged at the end (DPP), and the vector is certified when second - best > 2 eps16 -- otherwise
+// (exact ties included) it is flagged and the exact fp64 kernel redoes it, exactly as with K6a.
+__global__ __launch_bounds__(MMIDX_BLOCK, 2) void k_assign_gmin16(const __bf16 *__restrict__ Xh, const __bf16 *__restrict__ Xl,
+                                                               const __bf16 *__restrict__ Ch, const __bf16 *__restrict__ Cl,
+                                                               const double *__restrict__ cn, const double *__restrict__ xn,
+                                                               int32_t *__restrict__ cell_out, unsigned char *__restrict__ amb,
+                                                               double cnorm_max, double cn_max, int Cp, int Dp, long long n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *Bh = smem, *Bl = smem + G16_BC * G16_STRIDE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const long long q0 = (long long)blockIdx.x * G16_BQ + wave * 32;
+    const int ntiles = Cp / G16_BC;
+    const int nkc = (Dp + G16_KC - 1) / G16_KC;
+    float xn_r[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const long long q = q0 + rt * 16 + 4 * fg + r;
+            xn_r[rt][r] = q < n ? (float)xn[q] : 0.0f;
+        }
+    bf16x8 ah[2][4], al[2][4];
+    auto load_a = [&](int kc) {
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++) {
+            long long q = q0 + rt * 16 + fr;
+            q = q < n ? q : n - 1;
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const int k = kc * G16_KC + ks * 32 + fg * 8;
+                if (k < Dp) {
+                    ah[rt][ks] = *(const bf16x8 *)(Xh + (size_t)q * Dp + k);
+                    al[rt][ks] = *(const bf16x8 *)(Xl + (size_t)q * Dp + k);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        ah[rt][ks][e] = (__bf16)0.0f;
+                        al[rt][ks][e] = (__bf16)0.0f;
+                    }
+                }
+            }
+        }
+    };
+    if (nkc == 1) load_a(0);
+    const float inf = __int_as_float(0x7f800000);
+    float b1[2][4], b2[2][4];
+    int i1[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            b1[rt][r] = inf;
+            b2[rt][r] = inf;
+            i1[rt][r] = 0;
+        }
+    for (int t = 0; t < ntiles; t++) {
+        const int c0 = t * G16_BC;
+        f32x4 acc[2][8];
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int ct = 0; ct < 8; ct++) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kc = 0; kc < nkc; kc++) {
+            const int kbase = kc * G16_KC;
+            const int kw = (Dp - kbase < G16_KC) ? Dp - kbase : G16_KC;
+            const int upr = kw >> 3;
+            __syncthreads();
+            if (upr == 16) {
+                uint4 vh[8], vl[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int u = tid + i * MMIDX_BLOCK, row = u >> 4, cu = u & 15;
+                    const size_t src = (size_t)(c0 + row) * Dp + kbase + cu * 8;
+                    vh[i] = *(const uint4 *)(Ch + src);
+                    vl[i] = *(const uint4 *)(Cl + src);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int u = tid + i * MMIDX_BLOCK, row = u >> 4, cu = u & 15;
+                    *(uint4 *)(Bh + row * G16_STRIDE + cu * 16) = vh[i];
+                    *(uint4 *)(Bl + row * G16_STRIDE + cu * 16) = vl[i];
+                }
+            } else {
+                for (int u = tid; u < G16_BC * upr; u += MMIDX_BLOCK) {
+                    const int row = u / upr, cu = u - row * upr;
+                    const size_t src = (size_t)(c0 + row) * Dp + kbase + cu * 8;
+                    *(uint4 *)(Bh + row * G16_STRIDE + cu * 16) = *(const uint4 *)(Ch + src);
+                    *(uint4 *)(Bl + row * G16_STRIDE + cu * 16) = *(const uint4 *)(Cl + src);
+                }
+            }
+            if (nkc > 1) load_a(kc);
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                if (ks * 32 < kw) {
+#pragma unroll
+                    for (int ct = 0; ct < 8; ct += 2) {
+                        bf16x8 bh[2], bl[2];
+#pragma unroll
+                        for (int u = 0; u < 2; u++) {
+                            const int off = ((ct + u) * 16 + fr) * G16_STRIDE + (ks * 32 + fg * 8) * 2;
+                            bh[u] = *(const bf16x8 *)(Bh + off);
+                            bl[u] = *(const bf16x8 *)(Bl + off);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 2; u++)
+#pragma unroll
+                            for (int rt = 0; rt < 2; rt++)
+                                acc[rt][ct + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bh[u], acc[rt][ct + u], 0, 0, 0);
+#pragma unroll
+                        for (int u = 0; u < 2; u++)
+#pragma unroll
+                            for (int rt = 0; rt < 2; rt++)
+                                acc[rt][ct + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bl[u], acc[rt][ct + u], 0, 0, 0);
+#pragma unroll
+                        for (int u = 0; u < 2; u++)
+#pragma unroll
+                            for (int rt = 0; rt < 2; rt++)
+                                acc[rt][ct + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt][ks], bh[u], acc[rt][ct + u], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        float cn_c[8];
+#pragma unroll
+        for (int ct = 0; ct < 8; ct++) cn_c[ct] = (float)cn[c0 + ct * 16 + fr];
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int ct = 0; ct < 8; ct++) {
+                    const float dv = (cn_c[ct] + xn_r[rt][r]) - 2.0f * acc[rt][ct][r];
+                    const bool lt1 = dv < b1[rt][r];
+                    b2[rt][r] = lt1 ? b1[rt][r] : (dv < b2[rt][r] ? dv : b2[rt][r]);
+                    i1[rt][r] = lt1 ? c0 + ct * 16 + fr : i1[rt][r];
+                    b1[rt][r] = lt1 ? dv : b1[rt][r];
+                }
+    }
+    // merge the 16 lanes of every row: (best, its index, second best)
+    auto dppf = [](float v, int ctrl) -> float {
+        switch (ctrl) {
+            case 0: return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));
+            case 1: return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));
+            case 2: return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, true));
+            default: return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xf, 0xf, true));
+        }
+    };
+    auto dppi = [](int v, int ctrl) -> int {
+        switch (ctrl) {
+            case 0: return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);
+            case 1: return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);
+            case 2: return __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true);
+            default: return __builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true);
+        }
+    };
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float m1 = b1[rt][r], m2 = b2[rt][r];
+            int ix = i1[rt][r];
+#pragma unroll
+            for (int step = 0; step < 4; step++) {
+                const float o1 = dppf(m1, step), o2 = dppf(m2, step);
+                const int oi = dppi(ix, step);
+                const bool take = o1 < m1 || (o1 == m1 && oi < ix);
+                const float hi1 = take ? m1 : o1;  // the larger of the two bests
+                const float lo2 = o2 < m2 ? o2 : m2;
+                m2 = hi1 < lo2 ? hi1 : lo2;
+                ix = take ? oi : ix;
+                m1 = take ? o1 : m1;
+            }
+            const long long q = q0 + rt * 16 + 4 * fg + r;
+            if (fr == 0 && q < n) {
+                const double xnd = xn[q];
+                const double xnorm = sqrt(xnd), sumn = cnorm_max + xnorm;
+                const double eps = (2.0 * 3.1 * 0x1p-16 * xnorm * cnorm_max + 2.0 * (3.0 * (double)Dp + 16.0) * 0x1p-22 * xnorm * cnorm_max +
+                                    1e-12 * (cn_max + xnd) + 0x1p-21 * sumn * sumn) * (1.0 + 1e-9);
+                cell_out[q] = ix;
+                amb[q] = (((double)m2 - (double)m1) > 2.0 * eps) ? 0 : 1;  // inf - x = inf > ... when there is one centroid
+            }
+        }
+}
+
 // K1f: front end of the selection over group minima (see above); one block per query
 template <int PER>
 __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_grp(const ApproxSel A) {
