@@ -723,3 +723,29 @@ def test_concurrent_reader_threads(mi, oracle):
         th.join()
     assert not errors, errors[:3]
     ix.close()
+
+
+@pytest.mark.parametrize("D,C", [(32, 300), (128, 1000), (130, 260), (24, 5000)])
+def test_assignment_kernel_ties_and_padding(mi, oracle, D, C):
+    """computeNearestCoarseIndex (IVFPQ.java:547-564) through the bf16-split certified assignment: duplicated centroids
+    (exact ties: the first index must win), vectors sitting on centroids, C / D not multiples of the tile sizes; the
+    flagged vectors go through the exact kernel.  Cells must equal the oracle's for every vector."""
+    rng = np.random.default_rng(C + D)
+    coarse = rng.standard_normal((C, D))
+    coarse[C // 2:C // 2 + 25] = coarse[10:35]          # duplicates of earlier rows
+    coarse[C - 3] = coarse[C - 4] + 1e-13                # a near tie far below any fp32 / bf16 resolution
+    m = 2
+    pq = rng.standard_normal((m, 16, D // m))
+    ix = mi.IVFPQ(D, 10, False, "", m, 16, 0, C, 512)
+    ix.loadCoarseQuantizer(coarse)
+    ix.loadProductQuantizer(pq)
+    ref = oracle.OracleIndex(oracle.KIND_IVFPQ, D, m, 16, C)
+    ref.set_coarse(coarse)
+    ref.set_pq(pq)
+    X = np.concatenate([coarse[10:35], coarse[C // 2:C // 2 + 25] + 1e-12, coarse[[C - 3, C - 4]], 0.5 * (coarse[C - 3] + coarse[C - 4])[None],
+                        coarse[rng.integers(0, C, 3000)] + 0.3 * rng.standard_normal((3000, D)), 3.0 * rng.standard_normal((500, D))])
+    cells, _ = ix.encode(X)
+    rcells, _ = ref.encode_batch(X)
+    assert np.array_equal(cells, rcells)
+    assert np.all(cells[:25] == np.arange(10, 35))       # on a duplicated centroid: the lower index
+    ix.close()
