@@ -997,6 +997,14 @@ __global__ __launch_bounds__(MMIDX_BLOCK, 2) void k_coarse_gmin16(const __bf16 *
             }
             if (nkc > 1) load_a(kc);
             __syncthreads();
+            // touch the next tile (one word per 128-byte line, this k chunk): after the scan kernels the centroids are
+            // not in L2 any more, and the staging loads of the next tile would wait on HBM with nothing else to do
+            unsigned touch_h = 0, touch_l = 0;
+            if (t + 1 < t_hi && kw == G16_KC && Dp == G16_KC) {
+                const size_t nxt = (size_t)(c0 + G16_BC) * Dp + (size_t)tid * 64;  // 256 threads x 128 B = the 32 KiB of a tile
+                touch_h = *(const volatile unsigned *)(Ch + nxt);
+                touch_l = *(const volatile unsigned *)(Cl + nxt);
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
                 if (ks * 32 < kw) {  // block-uniform
@@ -1028,6 +1036,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK, 2) void k_coarse_gmin16(const __bf16 *
                     }
                 }
             }
+            asm volatile("" ::"v"(touch_h), "v"(touch_l));  // (keeps the two loads; their data is not used)
         }
         // epilogue: d~ = |c|^2 + |q|^2 - 2 S.  A group = the 8 columns one lane holds for a row
         // (c0 + fr + 16 ct, ct = 0..7): its two smallest d~ and the position of the smallest, no cross-lane work
