@@ -364,6 +364,28 @@ int encode_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_cell, 
     const int ivf = h->kind == MMIDX_KIND_IVFPQ;
     int rc0 = assign_device(h, n, dX, d_cell, st);
     if (rc0) return rc0;
+    if ((h->transform == MMIDX_TR_NONE || h->transform == MMIDX_TR_PERMUTATION) && (h->dsub == 4 || h->dsub == 8 || h->dsub == 16)) {
+        // K6b': one thread per vector, one sub-quantizer table in LDS at a time
+        const size_t rl = (size_t)h->ks * h->dsub * 8 + (size_t)MMIDX_BLOCK * h->m * h->code_bytes;
+        if (rl <= 64 * 1024) {
+            const unsigned g = (unsigned)((n + MMIDX_BLOCK - 1) / MMIDX_BLOCK);
+#define LAUNCH_ROWS(DS, CT)                                                                                                     \
+    hipLaunchKernelGGL((k_encode_pq_rows<DS, CT>), dim3(g), dim3(MMIDX_BLOCK), rl, st, dX, d_cell, h->d_coarse, h->d_pq, h->d_perm, \
+                       (CT *)d_code, h->D, h->m, h->ks, h->transform, ivf, (long long)n)
+            if (h->code_bytes == 1) {
+                if (h->dsub == 4) LAUNCH_ROWS(4, unsigned char);
+                else if (h->dsub == 8) LAUNCH_ROWS(8, unsigned char);
+                else LAUNCH_ROWS(16, unsigned char);
+            } else {
+                if (h->dsub == 4) LAUNCH_ROWS(4, unsigned short);
+                else if (h->dsub == 8) LAUNCH_ROWS(8, unsigned short);
+                else LAUNCH_ROWS(16, unsigned short);
+            }
+#undef LAUNCH_ROWS
+            HIPCK(hipGetLastError());
+            return MMIDX_OK;
+        }
+    }
     constexpr int VT = 8;
     const size_t lds = 2 * (size_t)VT * h->D * 8 + (size_t)h->m * VT * 4 * 12;
     if (lds > 160 * 1024) return fail(MMIDX_ERR_UNSUPPORTED, "vector length %d too large for the encode kernel", h->D);

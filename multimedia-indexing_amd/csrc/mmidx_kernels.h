@@ -3615,6 +3615,63 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_encode_pq(const double *__restr
     }
 }
 
+// K6b': the same arithmetic with one thread per vector (no transform or a permutation; dsub = 4, 8, 16).  K6b reads the
+// whole codebook from L2 for every 8 vectors; here a block of 256 vectors stages one sub-quantizer's table (ks x dsub
+// doubles) in LDS at a time and every thread walks it with broadcast reads, keeping its sub-vector in registers: the
+// first minimum in j order wins, as in computeNearestProductIndex (IVFPQ.java:613-631).  pq is the file-order table
+// [m][ks][dsub].
+template <int DSUB, typename CodeT>
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_encode_pq_rows(const double *__restrict__ X, const int32_t *__restrict__ cell,
+                                                                const double *__restrict__ coarse, const double *__restrict__ pq,
+                                                                const int32_t *__restrict__ perm, CodeT *__restrict__ code_out, int D,
+                                                                int m, int ks, int transform, int ivf, long long n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *tab = (double *)smem;                        // [ks][DSUB] of the current sub-quantizer
+    CodeT *cbuf = (CodeT *)(tab + (size_t)ks * DSUB);    // [256][m] the block's codes, written out coalesced at the end
+    const int tid = threadIdx.x;
+    const long long v0 = (long long)blockIdx.x * MMIDX_BLOCK, v = v0 + tid;
+    const long long vv = v < n ? v : n - 1;
+    int c = 0;
+    if (ivf) {
+        c = cell[vv];
+        c = c < 0 ? 0 : c;
+    }
+    const double *xrow = X + (size_t)vv * D, *crow = coarse + (size_t)c * D;
+    for (int s = 0; s < m; s++) {
+        __syncthreads();  // the previous table has been consumed
+        const double *src = pq + (size_t)s * ks * DSUB;
+        for (int i = tid; i < ks * DSUB; i += MMIDX_BLOCK) tab[i] = src[i];
+        double r[DSUB];
+#pragma unroll
+        for (int t = 0; t < DSUB; t++) {
+            const int idx = s * DSUB + t;
+            const int from = transform == 2 ? perm[idx] : idx;
+            const double xv = xrow[from];
+            r[t] = ivf ? crow[from] - xv : xv;
+        }
+        __syncthreads();
+        double best = __longlong_as_double(0x7FF0000000000000ll);
+        int bi = 0;
+#pragma unroll 4
+        for (int j = 0; j < ks; j++) {
+            const double *pv = tab + (size_t)j * DSUB;  // the same address in every lane: LDS broadcast
+            double acc = 0.0;
+#pragma unroll
+            for (int t = 0; t < DSUB; t++) {
+                const double df = pv[t] - r[t];
+                acc += df * df;
+            }
+            const bool lt = acc < best;  // strict: the first minimum wins (sums are >= 0 and finite)
+            best = lt ? acc : best;
+            bi = lt ? j : bi;
+        }
+        cbuf[(size_t)tid * m + s] = (CodeT)bi;
+    }
+    __syncthreads();
+    const long long nvalid = (n - v0 < MMIDX_BLOCK) ? n - v0 : MMIDX_BLOCK;
+    for (long long i = tid; i < nvalid * m; i += MMIDX_BLOCK) code_out[(size_t)v0 * m + i] = cbuf[i];
+}
+
 // ------------------------------------------------------------------------------------------------
 // inverted-list maintenance: move the existing CSR entries / place the new ones
 // ------------------------------------------------------------------------------------------------
