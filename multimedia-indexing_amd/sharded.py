@@ -151,8 +151,11 @@ class ShardedIVFPQ:
       all-gather  results            B*k*12 bytes
     """
 
-    def __init__(self, engine, rank, world, dist=None, group=None, force_collectives=False):
+    def __init__(self, engine, rank, world, dist=None, group=None, force_collectives=False, max_batch=262144):
         self.engine, self.rank, self.world, self.dist, self.group = engine, rank, world, dist, group
+        # queries per collective round: the shard phases take a bounded batch per call (pool memory); longer batches
+        # are cut into rounds of max_batch queries (a multiple of world keeps the owner slices aligned)
+        self.max_batch = max(world, max_batch - max_batch % world)
         # world == 1 normally short-circuits every collective; force_collectives issues them anyway
         # (a 1-rank process group) so that the RCCL calls can be exercised on a single-GPU box
         self.force = bool(force_collectives and dist is not None)
@@ -183,8 +186,12 @@ class ShardedIVFPQ:
         """Q: [nq][D] float64 tensor, identical on every rank.  Returns (iid, dist, count) for all
         queries on every rank, or with gather=False only this rank's slice (queries
         [rank*per, (rank+1)*per), per = ceil(nq / world)) -- what a serving front-end needs when
-        each rank answers the clients whose queries it owns."""
+        each rank answers the clients whose queries it owns.  Batches longer than max_batch run as several
+        collective rounds (with gather=False a rank then holds its slice of every round, concatenated)."""
         torch = __import__("torch")
+        if Q.shape[0] > self.max_batch:
+            parts = [self.search(k, Q[i:i + self.max_batch], gather) for i in range(0, Q.shape[0], self.max_batch)]
+            return tuple(torch.cat([p[j] for p in parts], 0) for j in range(3))
         nq, W = Q.shape[0], self.world
         per = (nq + W - 1) // W
         q0 = min(self.rank * per, nq)

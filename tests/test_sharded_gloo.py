@@ -121,6 +121,10 @@ def _worker(rank, world, port, ret):
         si, sd, sc = srch.search(k, Q, gather=False)
         lo, hi = min(rank * per, Q.shape[0]), min(rank * per + per, Q.shape[0])
         ok &= bool(torch.equal(si, iid[lo:hi]) and torch.equal(sd, dd[lo:hi]) and torch.equal(sc, cnt[lo:hi]))
+        # a batch longer than max_batch is cut into collective rounds (here 4 queries each): same answer
+        small = sh.ShardedIVFPQ(eng, rank, world, dist=dist, max_batch=4)
+        ci, cd, cc = small.search(k, Q)
+        ok &= bool(torch.equal(ci, iid) and torch.equal(cd, dd) and torch.equal(cc, cnt))
         rid, rd, rc = ref.search_batch(p["queries"], k)
         _, rd1, rc1 = ref.search_batch(p["queries"], k + 1)
         for qi in range(Q.shape[0]):
