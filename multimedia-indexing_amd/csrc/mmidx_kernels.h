@@ -1327,6 +1327,12 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_grp(const ApproxS
     __syncthreads();
     // any centroid with exact distance <= tau has d~ <= tau + eps16
     const double cut = ((double)s_tau4[0] + eps16) + eps16;
+    if (!(cut < (double)inf)) {
+        // magnitudes beyond fp32 / bf16 (inf or NaN in d~): nothing can be certified -> the exact row (overflow path)
+        __syncthreads();
+        coarse_select_finish<PER>(A, q, MMIDX_CSEL_CAP + 1, ckey, cidx, sel_k, sel_i, s_k, s_i);
+        return;
+    }
     // ---- candidates: the minimum of every group at or under the cut; the whole group when its runner-up is too
     const u64 lane_lt = (1ull << lane) - 1ull;
     auto push = [&](bool pass, int c) {

@@ -749,3 +749,30 @@ def test_assignment_kernel_ties_and_padding(mi, oracle, D, C):
     assert np.array_equal(cells, rcells)
     assert np.all(cells[:25] == np.arange(10, 35))       # on a duplicated centroid: the lower index
     ix.close()
+
+
+def test_coarse_stage_huge_magnitudes(mi, oracle):
+    """Coordinates beyond the fp32 range (1e25): the matrix-core filter overflows to inf / NaN and must hand every query to
+    the exact path instead of certifying garbage; the encoder's assignment flags such vectors for the exact kernel."""
+    import torch
+
+    nat = importlib.import_module("multimedia-indexing_amd._native")
+    rng = np.random.default_rng(4)
+    D, C, w = 32, 1200, 6
+    coarse = 1e25 * rng.standard_normal((C, D))
+    pq = rng.standard_normal((2, 16, D // 2))
+    ix = mi.IVFPQ(D, 10, False, "", 2, 16, 0, C, 512)
+    ix.loadCoarseQuantizer(coarse)
+    ix.loadProductQuantizer(pq)
+    ix.setW(w)
+    ref = oracle.OracleIndex(oracle.KIND_IVFPQ, D, 2, 16, C)
+    ref.set_coarse(coarse)
+    ref.set_pq(pq)
+    Q = coarse[rng.integers(0, C, 12)] * (1.0 + 1e-3 * rng.standard_normal((12, D)))
+    got = _coarse_cells(mi, ix, Q)
+    exp = np.stack([ref.nearest_coarse(q, w) for q in Q])
+    assert np.array_equal(got, exp)
+    cells, _ = ix.encode(Q)
+    rcells, _ = ref.encode_batch(Q)
+    assert np.array_equal(cells, rcells)
+    ix.close()
