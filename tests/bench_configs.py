@@ -14,7 +14,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (this file lives in tests/)
 for p in (ROOT, os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import synth  # noqa: E402

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Randomised differential test: random small IVFPQ / PQ configurations through the HIP path and through the CPU oracle
+(checker), ids and distance bits compared, ties included (the oracle replays the bounded queue).
+
+    python tests/fuzz_parity.py [cases] [seed]
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import synth  # noqa: E402
+from oracle import oracle as o  # noqa: E402  (checker only)
+
+try:
+    import torch
+
+    torch.cuda.init()
+except Exception:
+    pass
+mi = importlib.import_module("multimedia-indexing_amd")
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for case in range(cases):
+    kind = rng.choice(["ivfpq", "ivfpq", "pq"])
+    m = int(rng.choice([1, 2, 4, 8, 16, 32, 6]))
+    dsub = int(rng.choice([1, 2, 4, 8, 16, 3]))
+    D = m * dsub
+    ks = int(rng.choice([2, 16, 64, 256, 256, 300]))
+    if ks > 256 and m >= 32:
+        ks = 256
+    n = int(rng.integers(1, 40000))
+    k = int(rng.choice([1, 2, 10, 100, 101, 255, 256, 600]))
+    C = int(rng.choice([1, 2, 7, 40, 130, 300, 1100]))
+    w = int(rng.integers(1, C + 1))
+    tr = int(rng.choice([0, 0, 2, 1])) if D > 1 else 0
+    dup = rng.random() < 0.3
+    hist = int(rng.choice([-1, 1, 0]))
+    v1 = int(rng.random() < 0.25)
+    desc = dict(kind=kind, D=D, m=m, ks=ks, n=n, k=k, C=C, w=w, tr=tr, dup=dup, hist=hist, v1=v1)
+    try:
+        nb = min(n, 3000)
+        if kind == "ivfpq":
+            p = synth.make_ivfpq_problem(n=max(nb, ks + C + 8), D=D, C=C, m=m, ks=ks, nq=6, seed=int(rng.integers(1 << 30)))
+        else:
+            p = synth.make_pq_problem(n=max(nb, ks + 8), D=D, m=m, ks=ks, nq=6, seed=int(rng.integers(1 << 30)))
+        base = rng.standard_normal((n, D)) * 0.6 + (p["coarse"][rng.integers(0, C, n)] if kind == "ivfpq" else 0.0)
+        if dup and n > 10:
+            base[n // 2:] = base[:n - n // 2]
+        perm = o.random_permutation(1, D) if tr == 2 else None
+        rot = np.linalg.qr(rng.standard_normal((D, D)))[0] if tr == 1 else None
+        if kind == "ivfpq":
+            ix = mi.IVFPQ(D, n, False, "", m, ks, tr, C, 512, rot=rot)
+            ix.loadCoarseQuantizer(p["coarse"])
+            ref = o.OracleIndex(o.KIND_IVFPQ, D, m, ks, C, transform=tr, perm=perm, rot=rot)
+            ref.set_coarse(p["coarse"])
+            ix.setW(w)
+            ref.set_w(w)
+        else:
+            ix = mi.PQ(D, n, False, "", m, ks, tr, 512, rot=rot)
+            ref = o.OracleIndex(o.KIND_PQ, D, m, ks, transform=tr, perm=perm, rot=rot)
+        ix.loadProductQuantizer(p["pq"])
+        ref.set_pq(p["pq"])
+        ix.set_option("passa_hist", hist)
+        ix.set_option("coarse_v1", v1)
+        half = n // 2
+        ix.indexVectors([str(i) for i in range(half)], base[:half])
+        if half:
+            ix.search_batch(min(k, 3), base[:2])  # a search between the two adds: the CSR is rebuilt incrementally
+        ix.indexVectors([str(i) for i in range(half, n)], base[half:])
+        ref.add_vectors(base)
+        Q = np.concatenate([base[rng.integers(0, n, 4)] + 0.01 * rng.standard_normal((4, D)), p["queries"][:3]])
+        got = ix.search_batch(k, Q)
+        want = ref.search_batch(Q, k)
+        exact = tr != 1
+        ok = np.array_equal(got[2], want[2]) and np.array_equal(got[0], want[0])
+        if exact:
+            ok = ok and np.array_equal(got[1], want[1])
+        else:
+            fin = np.isfinite(want[1])
+            ok = ok and np.allclose(got[1][fin], want[1][fin], rtol=0, atol=1e-9)
+        ix.close()
+        if not ok:
+            bad += 1
+            print("MISMATCH", desc, flush=True)
+    except mi.MmidxError as e:
+        print("native error (acceptable if UNSUPPORTED)", e.status, desc, str(e)[:80], flush=True)
+        if e.status != 10:
+            bad += 1
+print(f"{cases} cases, {bad} bad")
+sys.exit(1 if bad else 0)

@@ -776,3 +776,16 @@ def test_coarse_stage_huge_magnitudes(mi, oracle):
     rcells, _ = ref.encode_batch(Q)
     assert np.array_equal(cells, rcells)
     ix.close()
+
+
+def test_randomised_differential_fuzz():
+    """tests/fuzz_parity.py: random small PQ / IVFPQ configurations (shapes, transforms, duplicates, k up to 600, forced
+    kernel variants, adds interleaved with a search) through the HIP path and the oracle; 300 cases over several seeds were
+    run clean when it was written, 30 run here."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "fuzz_parity.py"), "30", "11"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
