@@ -127,7 +127,10 @@ int mmidx_export(mmidx_index *h, int64_t *list_off_out, int32_t *iids_out, void 
  * computeKnnADC PQ.java:290-322, for nq queries Q[nq][D].  Row i of iid_out / dist_out holds
  * count_out[i] = min(k, #candidates) results, best first: ascending squared distance, equal
  * distances in the bounded queue's order (ASS.lookUp, ASS:345-358).  Unused tail entries are
- * iid -1 / +inf.  k must be in 1..1023. */
+ * iid -1 / +inf.  k must be in 1..1023.
+ * mmidx_search may be called from any number of threads (computeNearestNeighbors is not synchronized,
+ * ASS:281-291): callers that arrive while a batch is running are served together as one device batch
+ * (same k), each with the answer of its own call. */
 int mmidx_search(mmidx_index *h, int k, int64_t nq, const double *Q, int32_t *iid_out,
                  double *dist_out, int32_t *count_out);
 int mmidx_search_device(mmidx_index *h, int k, int64_t nq, const double *dQ, int32_t *d_iid_out,
@@ -230,7 +233,8 @@ int mmidx_set_profiling(mmidx_index *h, int enabled);
 /* measurement switches; results are identical in every setting.  "exhaustive" = 1: every probed
  * code is read and summed in fp64 (no lower-bound filter, no coarse-bound probe pruning) -- the
  * configuration the HBM roofline of the scan kernel is quoted on; "no_filter", "no_bound",
- * "exact_coarse" switch the individual devices (DESIGN.md sections 5.2, 5.4, 5.5). */
+ * "exact_coarse" switch the individual devices (DESIGN.md sections 5.2, 5.4, 5.5); "combine" = 0:
+ * concurrent mmidx_search callers are served one at a time instead of together (section 5.11). */
 int mmidx_set_option(mmidx_index *h, const char *name, int value);
 int mmidx_get_stats(mmidx_index *h, mmidx_stats *out);
 

@@ -16,9 +16,11 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <limits>
@@ -91,6 +93,20 @@ struct DevBuf {
     }
 };
 
+// one host-pointer search call waiting to be served (see mmidx_search)
+struct SearchReq {
+    int k;
+    int64_t nq;
+    const double *Q;
+    int32_t *iid;
+    double *dist;
+    int32_t *cnt;
+    int rc = MMIDX_OK;
+    bool done = false;
+    std::string err;
+    std::condition_variable cv;  // its caller sleeps here: woken when served, or when it is the oldest and nobody leads
+};
+
 }  // namespace
 
 struct mmidx_index {
@@ -114,6 +130,14 @@ struct mmidx_index {
     hipStream_t stream = nullptr;
     std::mutex mu;
     std::mutex search_mu;  // host-pointer searches share the handle's workspaces and stream: one at a time
+    // concurrent mmidx_search callers are combined into one device batch (the reference's API is one query per
+    // call, from many reader threads): requests queue here, one caller at a time leads and serves the queue
+    std::mutex comb_mu;
+    std::deque<SearchReq *> comb_q;
+    bool comb_busy = false;
+    int combine = 1;                  // option "combine": 0 = every call runs on its own
+    unsigned char *pin_stage = nullptr;  // pinned staging: queries in, (distances | ids | counts) out
+    size_t pin_stage_cap = 0;
 
     double *d_coarse = nullptr, *d_coarseT = nullptr, *d_pq = nullptr, *d_pqT = nullptr,
            *d_rot = nullptr, *d_cn = nullptr, *d_cnorm = nullptr;
@@ -150,7 +174,7 @@ struct mmidx_index {
     DevBuf<int32_t> ws_cells, ws_oiid, ws_ocnt, ws_flag, ws_ecell, ws_pcount, ws_pstart, ws_pcursor, ws_order;
     DevBuf<u64> ws_T, ws_pkey, ws_pval;
     DevBuf<u32> ws_pcnt;
-    DevBuf<unsigned char> ws_ecode, ws_tmp, ws_keep, ws_amb;
+    DevBuf<unsigned char> ws_ecode, ws_tmp, ws_keep, ws_amb, ws_out;
     DevBuf<int32_t> ws_aidx, ws_acell;
     int64_t last_ambiguous = 0;  // vectors of the last encode call that needed the exact redo
     DevBuf<long long> ws_dest;
@@ -1191,6 +1215,9 @@ int mmidx_destroy(mmidx_index *h) {
         (void)hipHostFree(h->pin_hint);
         h->pin_hint = nullptr;
     }
+    if (h->pin_stage) (void)hipHostFree(h->pin_stage);
+    h->pin_stage = nullptr;
+    h->ws_out.release();
     void *ptrs[] = {h->d_Ch, h->d_Cl, h->d_cn_pad, h->d_cn, h->d_cnorm, h->d_coarseT32, h->d_coarse, h->d_coarseT, h->d_pq, h->d_pqT, h->d_rot, h->d_perm, h->d_off, h->d_codes,
                     h->d_ids,    h->d_pcell,   h->d_pid, h->d_pcodes};
     for (void *p : ptrs)
@@ -1543,6 +1570,89 @@ int mmidx_search_device(mmidx_index *h, int k, int64_t nq, const double *dQ, int
     return search_common(h, k, nq, dQ, nullptr, 0, d_iid_out, d_dist_out, d_count_out, nullptr, nullptr, st);
 }
 
+// Queries of several concurrent callers in one device batch.  The reference's API is one query per call
+// (ASS.computeNearestNeighbors) from as many reader threads as the application likes; one call costs ~0.15 ms of
+// launches and copies whatever its size, so callers that arrive while a batch is running are queued and served
+// TOGETHER by the next leader: queries staged in pinned memory (one H2D), one search, one D2H of
+// (distances | ids | counts), results scattered to the callers' buffers.  Every query's answer is the one it
+// would get alone (queries of a batch are independent in every kernel).
+#define MMIDX_COMB_MAX_Q 4096   // queries per combined batch; larger requests run alone with direct copies
+static int search_host_direct(mmidx_index *h, const SearchReq &r) {
+    const int k = r.k;
+    const int64_t nq = r.nq;
+    HIPCK(h->ws_Q.reserve((size_t)nq * h->D));
+    HIPCK(h->ws_oiid.reserve((size_t)nq * k));
+    HIPCK(h->ws_odist.reserve((size_t)nq * k));
+    HIPCK(h->ws_ocnt.reserve((size_t)nq));
+    HIPCK(hipMemcpyAsync(h->ws_Q.p, r.Q, (size_t)nq * h->D * 8, hipMemcpyHostToDevice, h->stream));
+    int rc = search_common(h, k, nq, h->ws_Q.p, nullptr, 0, h->ws_oiid.p, h->ws_odist.p, h->ws_ocnt.p, nullptr, nullptr, h->stream);
+    if (rc) return rc;
+    HIPCK(hipMemcpyAsync(r.iid, h->ws_oiid.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipMemcpyAsync(r.dist, h->ws_odist.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipMemcpyAsync(r.cnt, h->ws_ocnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    return MMIDX_OK;
+}
+
+// serves batch[0..nb) (same k, sum of nq <= MMIDX_COMB_MAX_Q unless nb == 1); the caller holds search_mu
+static int search_host_batch(mmidx_index *h, SearchReq *const *batch, size_t nb) {
+    int rc = set_device(h);
+    if (rc) return rc;
+    const int k = batch[0]->k;
+    int64_t tot = 0;
+    for (size_t i = 0; i < nb; i++) tot += batch[i]->nq;
+    if (tot > MMIDX_COMB_MAX_Q) return search_host_direct(h, *batch[0]);  // (nb == 1)
+    const size_t in_bytes = (size_t)tot * h->D * 8;
+    const size_t od = (size_t)tot * k * 8, oi = (size_t)tot * k * 4, oc = (size_t)tot * 4;
+    const size_t need = in_bytes + od + oi + oc;
+    if (need > h->pin_stage_cap) {
+        if (h->pin_stage) (void)hipHostFree(h->pin_stage);
+        h->pin_stage = nullptr;
+        h->pin_stage_cap = 0;
+        const size_t want = need + need / 4 + 4096;
+        if (hipHostMalloc((void **)&h->pin_stage, want) == hipSuccess) {
+            h->pin_stage_cap = want;
+        } else {
+            (void)hipGetLastError();
+            h->pin_stage = nullptr;
+        }
+    }
+    if (!h->pin_stage) {  // no pinned memory: every request on its own, pageable copies
+        for (size_t i = 0; i < nb; i++) {
+            rc = search_host_direct(h, *batch[i]);
+            if (rc) return rc;
+        }
+        return MMIDX_OK;
+    }
+    unsigned char *hin = h->pin_stage, *hout = h->pin_stage + in_bytes;
+    {
+        size_t off = 0;
+        for (size_t i = 0; i < nb; i++) {
+            const size_t b = (size_t)batch[i]->nq * h->D * 8;
+            memcpy(hin + off, batch[i]->Q, b);
+            off += b;
+        }
+    }
+    HIPCK(h->ws_Q.reserve((size_t)tot * h->D));
+    HIPCK(h->ws_out.reserve(od + oi + oc));
+    double *d_dist = (double *)h->ws_out.p;
+    int32_t *d_iid = (int32_t *)(h->ws_out.p + od), *d_cnt = (int32_t *)(h->ws_out.p + od + oi);
+    HIPCK(hipMemcpyAsync(h->ws_Q.p, hin, in_bytes, hipMemcpyHostToDevice, h->stream));
+    rc = search_common(h, k, tot, h->ws_Q.p, nullptr, 0, d_iid, d_dist, d_cnt, nullptr, nullptr, h->stream);
+    if (rc) return rc;
+    HIPCK(hipMemcpyAsync(hout, h->ws_out.p, od + oi + oc, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    int64_t q0 = 0;
+    for (size_t i = 0; i < nb; i++) {
+        const int64_t nq = batch[i]->nq;
+        memcpy(batch[i]->dist, hout + (size_t)q0 * k * 8, (size_t)nq * k * 8);
+        memcpy(batch[i]->iid, hout + od + (size_t)q0 * k * 4, (size_t)nq * k * 4);
+        memcpy(batch[i]->cnt, hout + od + oi + (size_t)q0 * 4, (size_t)nq * 4);
+        q0 += nq;
+    }
+    return MMIDX_OK;
+}
+
 int mmidx_search(mmidx_index *h, int k, int64_t nq, const double *Q, int32_t *iid_out, double *dist_out, int32_t *count_out) {
     if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
     if (nq > 0 && (!Q || !iid_out || !dist_out || !count_out)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
@@ -1550,21 +1660,61 @@ int mmidx_search(mmidx_index *h, int k, int64_t nq, const double *Q, int32_t *ii
     int rc = check_ready(h);
     if (rc) return rc;
     if (nq == 0) return MMIDX_OK;
-    std::lock_guard<std::mutex> slk(h->search_mu);  // concurrent readers are legal in the reference: they queue up here
-    rc = set_device(h);
-    if (rc) return rc;
-    HIPCK(h->ws_Q.reserve((size_t)nq * h->D));
-    HIPCK(h->ws_oiid.reserve((size_t)nq * k));
-    HIPCK(h->ws_odist.reserve((size_t)nq * k));
-    HIPCK(h->ws_ocnt.reserve((size_t)nq));
-    HIPCK(hipMemcpyAsync(h->ws_Q.p, Q, (size_t)nq * h->D * 8, hipMemcpyHostToDevice, h->stream));
-    rc = search_common(h, k, nq, h->ws_Q.p, nullptr, 0, h->ws_oiid.p, h->ws_odist.p, h->ws_ocnt.p, nullptr, nullptr, h->stream);
-    if (rc) return rc;
-    HIPCK(hipMemcpyAsync(iid_out, h->ws_oiid.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCK(hipMemcpyAsync(dist_out, h->ws_odist.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCK(hipMemcpyAsync(count_out, h->ws_ocnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCK(hipStreamSynchronize(h->stream));
-    return MMIDX_OK;
+    SearchReq me;
+    me.k = k;
+    me.nq = nq;
+    me.Q = Q;
+    me.iid = iid_out;
+    me.dist = dist_out;
+    me.cnt = count_out;
+    std::unique_lock<std::mutex> lk(h->comb_mu);
+    h->comb_q.push_back(&me);
+    while (!me.done) {
+        if (h->comb_busy) {
+            me.cv.wait(lk);
+            continue;
+        }
+        // lead: the oldest request and everything behind it with the same k, up to the batch limit
+        h->comb_busy = true;
+        std::vector<SearchReq *> batch;
+        {
+            SearchReq *first = h->comb_q.front();
+            h->comb_q.pop_front();
+            batch.push_back(first);
+            int64_t tot = first->nq;
+            if (h->combine && tot <= MMIDX_COMB_MAX_Q) {
+                for (auto it = h->comb_q.begin(); it != h->comb_q.end();) {
+                    if ((*it)->k == first->k && tot + (*it)->nq <= MMIDX_COMB_MAX_Q) {
+                        tot += (*it)->nq;
+                        batch.push_back(*it);
+                        it = h->comb_q.erase(it);
+                    } else {
+                        ++it;
+                    }
+                }
+            }
+        }
+        lk.unlock();
+        int brc;
+        {
+            std::lock_guard<std::mutex> slk(h->search_mu);  // (id queries and the other host entry points use the same workspaces)
+            brc = search_host_batch(h, batch.data(), batch.size());
+        }
+        lk.lock();
+        for (SearchReq *r : batch) {
+            r->rc = brc;
+            if (brc && r != &me) r->err = g_err;  // the message lives in the leader's thread
+            r->done = true;
+            if (r != &me) r->cv.notify_one();
+        }
+        h->comb_busy = false;
+        // hand the lead to the oldest waiting caller (only that thread is woken); if this call is still unserved
+        // -- the batch was another k's -- it leads again itself
+        if (me.done && !h->comb_q.empty()) h->comb_q.front()->cv.notify_one();
+    }
+    lk.unlock();
+    if (me.rc && !me.err.empty()) g_err = me.err;
+    return me.rc;
 }
 
 // computeNearestNeighborsInternal(k, iid) for PQ: computeKnnSDC, PQ.java:334-374
@@ -1749,6 +1899,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->no_bound = value != 0;
     } else if (n == "exact_coarse") {
         h->exact_coarse = value != 0;
+    } else if (n == "combine") {
+        h->combine = value != 0;
     } else if (n == "passb_main_grid") {
         h->passb_main_grid = value;
     } else if (n == "coarse_v1") {

@@ -725,6 +725,57 @@ def test_concurrent_reader_threads(mi, oracle):
     ix.close()
 
 
+@pytest.mark.parametrize("combine", [1, 0])
+def test_single_query_callers_are_combined(mi, oracle, combine):
+    """The reference's API is one query per call from many reader threads.  mmidx_search serves the callers that arrive
+    while a batch is running TOGETHER (one staged copy in, one search, one copy out, results scattered); every caller
+    must get exactly the answer of its own query, also when calls with different k and sizes are mixed, and with
+    combining switched off."""
+    import threading
+
+    D, C, m, ks, n, w = 32, 16, 8, 256, 8000, 5
+    p = synth.make_ivfpq_problem(n=n, D=D, C=C, m=m, ks=ks, nq=96, seed=92)
+    ix = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    ix.loadCoarseQuantizer(p["coarse"])
+    ix.loadProductQuantizer(p["pq"])
+    ix.setW(w)
+    ix.set_option("combine", combine)
+    ref = oracle_ivfpq(oracle, p, D, m, ks, C, w)
+    ix.indexVectors([str(i) for i in range(n)], p["base"])
+    ref.add_vectors(p["base"])
+    want = {k: ref.search_batch(p["queries"], k) for k in (1, 10, 37)}
+    errors = []
+    start = threading.Barrier(24)
+
+    def worker(t):
+        try:
+            start.wait()
+            k = (1, 10, 10, 37)[t % 4]
+            for rep in range(40):
+                q0 = (t * 11 + rep * 7) % 90
+                nq = 1 if (t + rep) % 5 else 1 + (rep % 6)
+                got = ix.search_batch(k, p["queries"][q0:q0 + nq])
+                for a, b in zip(got, want[k]):
+                    if not np.array_equal(a, b[q0:q0 + nq]):
+                        errors.append((t, rep, k, q0, nq))
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(24)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
+    # a failing call reports its own error and does not disturb the others
+    with pytest.raises(Exception):
+        ix.search_batch(5000, p["queries"][:1])
+    got = ix.search_batch(10, p["queries"][:3])
+    for a, b in zip(got, want[10]):
+        assert np.array_equal(a, b[:3])
+    ix.close()
+
+
 @pytest.mark.parametrize("D,C", [(32, 300), (128, 1000), (130, 260), (24, 5000)])
 def test_assignment_kernel_ties_and_padding(mi, oracle, D, C):
     """computeNearestCoarseIndex (IVFPQ.java:547-564) through the bf16-split certified assignment: duplicated centroids
