@@ -295,7 +295,7 @@ def main():
         ex_ach = ex_bytes / (ex.scan_ms * 1e-3) / 1e9 if ex.scan_ms > 0 else 0.0
         exhaustive = {"steps": args.exhaustive_steps, "queries_per_s": round(B * args.exhaustive_steps / ex_t, 1),
                       "scan_ms_per_step": round(ex.scan_ms / args.exhaustive_steps, 4), "achieved": round(ex_ach, 1), "peak": 8000.0,
-                      "unit": "GB/s", "frac": round(ex_ach / 8000.0, 4), "bound": "lds (bank conflicts of the fp64 gather), see DESIGN.md 5.1"}
+                      "unit": "GB/s", "frac": round(ex_ach / 8000.0, 4), "frac_of_measured_copy_ceiling": round(ex_ach / 6290.0, 4), "bound": "lds (bank conflicts of the fp64 gather), see DESIGN.md 5.1"}
 
     # recall@1 and results of batch 0 (for the parity gate)
     step(Qb[0])
@@ -321,7 +321,7 @@ def main():
     except Exception:
         traffic = None
     roofline = {"bound": "hbm", "kernel": "scan launches: k_scan_hist (pass A) + k_scan_filt (pass B)", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                "frac": round(achieved / 8000.0, 4), "frac_of_measured_copy_ceiling": round(achieved / 6290.0, 4), "traffic": traffic,
                 "note": "achieved = algorithmic bytes (m x probed codes) / scan-kernel time; exact pruning (coarse bound, "
                         "Smin >= T) and L2 reuse make it exceed the physical HBM rate: see traffic and DESIGN.md section 7",
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(scan_ms, 4),
@@ -347,7 +347,25 @@ def main():
         ref.set_w(w)
         ref.load_lists(off, iids, codes)
         del iids, codes
-        cores = os.cpu_count() or 1
+        # threads = the CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota
+        # (a 256-thread box with a 16-CPU quota throttles 256 runnable threads to 16 CPUs' worth of time)
+        logical = os.cpu_count() or 1
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else logical
+        quota = None
+        try:
+            qv, pv = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if qv != "max":
+                quota = float(qv) / float(pv)
+        except (OSError, ValueError):
+            try:
+                qv = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+                pv = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if qv > 0:
+                    quota = qv / pv
+            except (OSError, ValueError):
+                pass
+        if quota is not None:
+            cores = max(1, min(cores, int(quota + 0.999)))
         Qh = Qb[0].cpu().numpy()
         tc = time.perf_counter()
         ref.search_batch(Qh[:cores], k, nthreads=cores)  # calibration
@@ -356,9 +374,30 @@ def main():
         tc = time.perf_counter()
         rid, rd, rc = ref.search_batch(Qh[:nsamp], k, nthreads=cores)
         cpu_t = time.perf_counter() - tc
+        # one reader thread (the reference's single call), a couple of seconds of work
+        tc = time.perf_counter()
+        ref.search_batch(Qh[:2], k, nthreads=1)
+        per_q = max((time.perf_counter() - tc) / 2, 1e-4)
+        n1 = int(min(nsamp, max(2, 2.0 / per_q)))
+        tc = time.perf_counter()
+        r1 = ref.search_batch(Qh[:n1], k, nthreads=1)
+        one_t = time.perf_counter() - tc
+        one_ok = bool(np.array_equal(r1[0], rid[:n1]))
+        cpu_model = "unknown"
+        try:
+            for ln in open("/proc/cpuinfo"):
+                if ln.startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
         cpu_baseline = {"value": round(nsamp / cpu_t, 2), "unit": "queries/s", "cores": cores, "kind": "port",
                         "sample": f"{nsamp} queries of batch 0 (same index, k={k}, w={w}), C restatement of "
-                                  f"IVFPQ.computeKnnIVFADC, {cores} concurrent reader threads, {cpu_t:.1f}s"}
+                                  f"IVFPQ.computeKnnIVFADC, {cores} concurrent reader threads "
+                                  f"({logical} logical CPUs, cgroup quota {quota if quota is not None else 'none'}), {cpu_t:.1f}s",
+                        "cpu_model": cpu_model,
+                        "one_thread": {"value": round(n1 / one_t, 2), "unit": "queries/s", "queries": n1,
+                                       "same_results_as_threaded": one_ok}}
         ids_match = bool(np.array_equal(res_iid[:nsamp], rid))
         fin = np.isfinite(rd)
         maxd = float(np.max(np.abs(res_dist[:nsamp][fin] - rd[fin]), initial=0.0))

@@ -270,7 +270,9 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_reg(const double 
 // <= tau (a few dozen for w = 32, C = 8192) and sort just those.  Same output as the round-based
 // kernels -- the sorted head by (distance, index) -- so the tie rule in coarse_emit is unchanged.
 // If the gather overflows (massive ties) the round-based selection runs on the registers instead.
+#ifndef MMIDX_CSEL_CAP
 #define MMIDX_CSEL_CAP 1024
+#endif
 #ifndef MMIDX_CAND_CHUNK
 #define MMIDX_CAND_CHUNK 24
 #endif

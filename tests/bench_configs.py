@@ -15,6 +15,36 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (this file lives in tests/)
+
+
+def usable_cpus():
+    """CPUs this process may use: affinity mask capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        qv, pv = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if qv != "max":
+            n = max(1, min(n, int(float(qv) / float(pv) + 0.999)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+NCPU = usable_cpus()
+
+
+def cpu_best(fn, nq):
+    """the oracle timed with the quota's thread count and with every logical CPU (short samples are not throttled);
+    returns (best queries/s, its thread count, its results)"""
+    best = None
+    for nt in sorted({NCPU, os.cpu_count() or 1}):
+        t0 = time.perf_counter()
+        r = fn(nt)
+        qps_ = nq / (time.perf_counter() - t0)
+        if best is None or qps_ > best[0]:
+            best = (qps_, nt, r)
+    return best
+
+
 for p in (ROOT, os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import synth  # noqa: E402
@@ -63,11 +93,9 @@ ref.set_pq(pq)
 off, ids_e, codes_e = ix.export()
 ref.load_lists(off, ids_e, codes_e)
 ns = 256
-t0 = time.perf_counter()
-rid, rd, rc = ref.search_batch(Q[:ns], k, nthreads=os.cpu_count())
-cpu_qps = ns / (time.perf_counter() - t0)
+cpu_qps, cpu_nt, (rid, rd, rc) = cpu_best(lambda nt: ref.search_batch(Q[:ns], k, nthreads=nt), ns)
 out["cfg2_pq_adc_1M"] = {"qps_gpu": round(qps, 1), "index_s": round(t_index, 2), "ids_match": bool(np.array_equal(iid[:ns], rid)),
-                         "max_abs_ddist": float(np.max(np.abs(dd[:ns] - rd))), "cpu_qps": round(cpu_qps, 1), "cpu_threads": os.cpu_count(),
+                         "max_abs_ddist": float(np.max(np.abs(dd[:ns] - rd))), "cpu_qps": round(cpu_qps, 1), "cpu_threads": cpu_nt,
                          "algorithmic_GBps": round(qps * N * m / 1e9, 1)}
 ix.close()
 del ref
@@ -96,12 +124,10 @@ ref.set_w(w)
 off, ids_e, codes_e = ix.export()
 ref.load_lists(off, ids_e, codes_e)
 ns = 2048
-t0 = time.perf_counter()
-rid, rd, rc = ref.search_batch(Q[:ns], k, nthreads=os.cpu_count())
-cpu_qps = ns / (time.perf_counter() - t0)
+cpu_qps, cpu_nt, (rid, rd, rc) = cpu_best(lambda nt: ref.search_batch(Q[:ns], k, nthreads=nt), ns)
 out["cfg3_ivfpq_1M"] = {"qps_gpu": round(qps, 1), "index_s": round(t_index, 2), "recall_at_1": float(np.mean(iid[:, 0] == qi)),
                         "ids_match": bool(np.array_equal(iid[:ns], rid)), "max_abs_ddist": float(np.max(np.abs(dd[:ns] - rd))),
-                        "cpu_qps": round(cpu_qps, 1), "cpu_threads": os.cpu_count()}
+                        "cpu_qps": round(cpu_qps, 1), "cpu_threads": cpu_nt}
 ix.close()
 
 # ---- cfg1: Linear 10k x 128, k = 10 (host pointers in and out: PCIe-inclusive)
@@ -115,10 +141,8 @@ t0 = time.perf_counter()
 for _ in range(5):
     li, ld, lc = lin.search_batch(k1, Q1)
 qps1 = 5 * len(Q1) / (time.perf_counter() - t0)
-t0 = time.perf_counter()
-bi, bd, bc = o.linear_search_batch(X1, Q1, k1, nthreads=os.cpu_count())
-cpu1 = len(Q1) / (time.perf_counter() - t0)
+cpu1, cpu_nt, (bi, bd, bc) = cpu_best(lambda nt: o.linear_search_batch(X1, Q1, k1, nthreads=nt), len(Q1))
 out["cfg1_linear_10k"] = {"qps_gpu_host_buffers": round(qps1, 1), "ids_match": bool(np.array_equal(li, bi)),
-                          "max_abs_ddist": float(np.max(np.abs(ld - bd))), "cpu_qps": round(cpu1, 1), "cpu_threads": os.cpu_count()}
+                          "max_abs_ddist": float(np.max(np.abs(ld - bd))), "cpu_qps": round(cpu1, 1), "cpu_threads": cpu_nt}
 lin.close()
 print(json.dumps(out))
