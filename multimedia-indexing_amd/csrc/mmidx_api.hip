@@ -107,6 +107,64 @@ struct SearchReq {
     std::condition_variable cv;  // its caller sleeps here: woken when served, or when it is the oldest and nobody leads
 };
 
+// Concurrent callers of a host-pointer search are combined into one device batch (the reference's API is one query
+// per call, from many reader threads): requests queue here, one caller at a time leads and serves the queue.
+struct Combiner {
+    std::mutex mu;
+    std::deque<SearchReq *> q;
+    bool busy = false;
+    int enabled = 1;  // 0 = every call runs on its own
+};
+
+// Queues `me`, leads batches (serve(requests, count) -> status) until `me` has been served, returns its status.
+template <class Serve>
+int combiner_submit(Combiner &c, SearchReq &me, int64_t max_q, Serve serve) {
+    std::unique_lock<std::mutex> lk(c.mu);
+    c.q.push_back(&me);
+    while (!me.done) {
+        if (c.busy) {
+            me.cv.wait(lk);
+            continue;
+        }
+        // lead: the oldest request and everything behind it with the same k, up to the batch limit
+        c.busy = true;
+        std::vector<SearchReq *> batch;
+        {
+            SearchReq *first = c.q.front();
+            c.q.pop_front();
+            batch.push_back(first);
+            int64_t tot = first->nq;
+            if (c.enabled && tot <= max_q) {
+                for (auto it = c.q.begin(); it != c.q.end();) {
+                    if ((*it)->k == first->k && tot + (*it)->nq <= max_q) {
+                        tot += (*it)->nq;
+                        batch.push_back(*it);
+                        it = c.q.erase(it);
+                    } else {
+                        ++it;
+                    }
+                }
+            }
+        }
+        lk.unlock();
+        const int brc = serve(batch.data(), batch.size());
+        lk.lock();
+        for (SearchReq *r : batch) {
+            r->rc = brc;
+            if (brc && r != &me) r->err = g_err;  // the message lives in the leader's thread
+            r->done = true;
+            if (r != &me) r->cv.notify_one();
+        }
+        c.busy = false;
+        // hand the lead to the oldest waiting caller (only that thread is woken); if this call is still unserved
+        // -- the batch was another k's -- it leads again itself
+        if (me.done && !c.q.empty()) c.q.front()->cv.notify_one();
+    }
+    lk.unlock();
+    if (me.rc && !me.err.empty()) g_err = me.err;
+    return me.rc;
+}
+
 }  // namespace
 
 struct mmidx_index {
@@ -130,12 +188,7 @@ struct mmidx_index {
     hipStream_t stream = nullptr;
     std::mutex mu;
     std::mutex search_mu;  // host-pointer searches share the handle's workspaces and stream: one at a time
-    // concurrent mmidx_search callers are combined into one device batch (the reference's API is one query per
-    // call, from many reader threads): requests queue here, one caller at a time leads and serves the queue
-    std::mutex comb_mu;
-    std::deque<SearchReq *> comb_q;
-    bool comb_busy = false;
-    int combine = 1;                  // option "combine": 0 = every call runs on its own
+    Combiner comb;  // concurrent mmidx_search callers are served together (see mmidx_search)
     unsigned char *pin_stage = nullptr;  // pinned staging: queries in, (distances | ids | counts) out
     size_t pin_stage_cap = 0;
 
@@ -1667,54 +1720,10 @@ int mmidx_search(mmidx_index *h, int k, int64_t nq, const double *Q, int32_t *ii
     me.iid = iid_out;
     me.dist = dist_out;
     me.cnt = count_out;
-    std::unique_lock<std::mutex> lk(h->comb_mu);
-    h->comb_q.push_back(&me);
-    while (!me.done) {
-        if (h->comb_busy) {
-            me.cv.wait(lk);
-            continue;
-        }
-        // lead: the oldest request and everything behind it with the same k, up to the batch limit
-        h->comb_busy = true;
-        std::vector<SearchReq *> batch;
-        {
-            SearchReq *first = h->comb_q.front();
-            h->comb_q.pop_front();
-            batch.push_back(first);
-            int64_t tot = first->nq;
-            if (h->combine && tot <= MMIDX_COMB_MAX_Q) {
-                for (auto it = h->comb_q.begin(); it != h->comb_q.end();) {
-                    if ((*it)->k == first->k && tot + (*it)->nq <= MMIDX_COMB_MAX_Q) {
-                        tot += (*it)->nq;
-                        batch.push_back(*it);
-                        it = h->comb_q.erase(it);
-                    } else {
-                        ++it;
-                    }
-                }
-            }
-        }
-        lk.unlock();
-        int brc;
-        {
-            std::lock_guard<std::mutex> slk(h->search_mu);  // (id queries and the other host entry points use the same workspaces)
-            brc = search_host_batch(h, batch.data(), batch.size());
-        }
-        lk.lock();
-        for (SearchReq *r : batch) {
-            r->rc = brc;
-            if (brc && r != &me) r->err = g_err;  // the message lives in the leader's thread
-            r->done = true;
-            if (r != &me) r->cv.notify_one();
-        }
-        h->comb_busy = false;
-        // hand the lead to the oldest waiting caller (only that thread is woken); if this call is still unserved
-        // -- the batch was another k's -- it leads again itself
-        if (me.done && !h->comb_q.empty()) h->comb_q.front()->cv.notify_one();
-    }
-    lk.unlock();
-    if (me.rc && !me.err.empty()) g_err = me.err;
-    return me.rc;
+    return combiner_submit(h->comb, me, MMIDX_COMB_MAX_Q, [h](SearchReq *const *batch, size_t nb) {
+        std::lock_guard<std::mutex> slk(h->search_mu);  // (id queries use the same workspaces and stream)
+        return search_host_batch(h, batch, nb);
+    });
 }
 
 // computeNearestNeighborsInternal(k, iid) for PQ: computeKnnSDC, PQ.java:334-374
@@ -1900,7 +1909,7 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
     } else if (n == "exact_coarse") {
         h->exact_coarse = value != 0;
     } else if (n == "combine") {
-        h->combine = value != 0;
+        h->comb.enabled = value != 0;
     } else if (n == "passb_main_grid") {
         h->passb_main_grid = value;
     } else if (n == "coarse_v1") {
@@ -2253,6 +2262,8 @@ struct mmidx_linear {
     int64_t inner_n = -1;   // number of vectors the inner handle was built for
     DevBuf<double> ws_Q, ws_d;
     DevBuf<int32_t> ws_i;
+    Combiner comb;              // concurrent one-query callers are served together, as in mmidx_search
+    std::vector<double> cat_Q;  // their queries, concatenated
 };
 
 int mmidx_linear_create(int D, int64_t capacity, int device, mmidx_linear **out) {
@@ -2304,19 +2315,32 @@ int mmidx_linear_get_vector(const mmidx_linear *l, int64_t iid, double *out) {  
     return MMIDX_OK;
 }
 
-int mmidx_linear_search(mmidx_linear *l, int k, int64_t nq, const double *Q, int32_t *iid_out, double *dist_out, int32_t *count_out) {
-    if (!l) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
-    if (k < 1) return fail(MMIDX_ERR_INVALID_ARG, "k must be positive (got %d)", k);
-    if (nq < 0 || (nq > 0 && (!Q || !iid_out || !dist_out || !count_out))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(l->mu);
+// serves batch[0..nb) (same k) as one search over the concatenated queries; the caller holds l->mu
+static int linear_search_batch(mmidx_linear *l, SearchReq *const *batch, size_t nb) {
+    const int k = batch[0]->k;
     const int64_t n = (int64_t)(l->X.size() / (size_t)l->D);
     if (n > 0x7fffffff) return fail(MMIDX_ERR_CAPACITY, "internal ids are 32-bit, as in the reference");
-    for (int64_t i = 0; i < nq * k; i++) {
-        iid_out[i] = -1;
-        dist_out[i] = std::numeric_limits<double>::infinity();
+    int64_t nq = 0;
+    for (size_t b = 0; b < nb; b++) {
+        SearchReq *r = batch[b];
+        for (int64_t i = 0; i < r->nq * k; i++) {
+            r->iid[i] = -1;
+            r->dist[i] = std::numeric_limits<double>::infinity();
+        }
+        for (int64_t q = 0; q < r->nq; q++) r->cnt[q] = 0;
+        nq += r->nq;
     }
-    for (int64_t q = 0; q < nq; q++) count_out[q] = 0;
     if (nq == 0 || n == 0) return MMIDX_OK;
+    const double *Q = batch[0]->Q;
+    if (nb > 1) {
+        l->cat_Q.resize((size_t)nq * l->D);
+        size_t off = 0;
+        for (size_t b = 0; b < nb; b++) {
+            memcpy(l->cat_Q.data() + off, batch[b]->Q, (size_t)batch[b]->nq * l->D * 8);
+            off += (size_t)batch[b]->nq * l->D;
+        }
+        Q = l->cat_Q.data();
+    }
     HIPCK(hipSetDevice(l->device));
     if (l->inner_n != n) {
         if (l->inner) mmidx_destroy(l->inner);
@@ -2338,31 +2362,57 @@ int mmidx_linear_search(mmidx_linear *l, int k, int64_t nq, const double *Q, int
     HIPCK(l->ws_d.reserve((size_t)qb * w));
     std::vector<int32_t> hi((size_t)qb * w);
     std::vector<double> hd((size_t)qb * w);
+    size_t cur = 0;        // request that holds query q0 + q, and that query's position in it
+    int64_t cur_q = 0;
     for (int64_t q0 = 0; q0 < nq; q0 += qb) {
-        const int64_t nb = std::min(qb, nq - q0);
-        HIPCK(hipMemcpyAsync(l->ws_Q.p, Q + (size_t)q0 * l->D, (size_t)nb * l->D * 8, hipMemcpyHostToDevice, st));
-        int rc = run_coarse(h, nb, l->ws_Q.p, l->ws_i.p, st);
+        const int64_t nbq = std::min(qb, nq - q0);
+        HIPCK(hipMemcpyAsync(l->ws_Q.p, Q + (size_t)q0 * l->D, (size_t)nbq * l->D * 8, hipMemcpyHostToDevice, st));
+        int rc = run_coarse(h, nbq, l->ws_Q.p, l->ws_i.p, st);
         if (rc) return rc;
         if (h->cdsel_valid) {
-            HIPCK(hipMemcpyAsync(l->ws_d.p, h->ws_cdsel.p, (size_t)nb * w * 8, hipMemcpyDeviceToDevice, st));
+            HIPCK(hipMemcpyAsync(l->ws_d.p, h->ws_cdsel.p, (size_t)nbq * w * 8, hipMemcpyDeviceToDevice, st));
         } else {
-            const long long tot = (long long)nb * w;
+            const long long tot = (long long)nbq * w;
             hipLaunchKernelGGL(k_gather_cdist, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->ws_cdist.p, l->ws_i.p, l->ws_d.p,
                                h->C, w, tot);
             HIPCK(hipGetLastError());
         }
-        HIPCK(hipMemcpyAsync(hi.data(), l->ws_i.p, (size_t)nb * w * 4, hipMemcpyDeviceToHost, st));
-        HIPCK(hipMemcpyAsync(hd.data(), l->ws_d.p, (size_t)nb * w * 8, hipMemcpyDeviceToHost, st));
+        HIPCK(hipMemcpyAsync(hi.data(), l->ws_i.p, (size_t)nbq * w * 4, hipMemcpyDeviceToHost, st));
+        HIPCK(hipMemcpyAsync(hd.data(), l->ws_d.p, (size_t)nbq * w * 8, hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
-        for (int64_t q = 0; q < nb; q++) {
-            for (int t = 0; t < w; t++) {
-                iid_out[(size_t)(q0 + q) * k + t] = hi[(size_t)q * w + t];
-                dist_out[(size_t)(q0 + q) * k + t] = hd[(size_t)q * w + t];
+        for (int64_t q = 0; q < nbq; q++) {
+            while (cur_q >= batch[cur]->nq) {
+                cur++;
+                cur_q = 0;
             }
-            count_out[q0 + q] = w;
+            SearchReq *r = batch[cur];
+            for (int t = 0; t < w; t++) {
+                r->iid[(size_t)cur_q * k + t] = hi[(size_t)q * w + t];
+                r->dist[(size_t)cur_q * k + t] = hd[(size_t)q * w + t];
+            }
+            r->cnt[cur_q] = w;
+            cur_q++;
         }
     }
     return MMIDX_OK;
+}
+
+int mmidx_linear_search(mmidx_linear *l, int k, int64_t nq, const double *Q, int32_t *iid_out, double *dist_out, int32_t *count_out) {
+    if (!l) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    if (k < 1) return fail(MMIDX_ERR_INVALID_ARG, "k must be positive (got %d)", k);
+    if (nq < 0 || (nq > 0 && (!Q || !iid_out || !dist_out || !count_out))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (nq == 0) return MMIDX_OK;
+    SearchReq me;
+    me.k = k;
+    me.nq = nq;
+    me.Q = Q;
+    me.iid = iid_out;
+    me.dist = dist_out;
+    me.cnt = count_out;
+    return combiner_submit(l->comb, me, MMIDX_COMB_MAX_Q, [l](SearchReq *const *batch, size_t nb) {
+        std::lock_guard<std::mutex> lk(l->mu);
+        return linear_search_batch(l, batch, nb);
+    });
 }
 
 }  // extern "C"

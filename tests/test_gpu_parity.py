@@ -688,6 +688,45 @@ def test_linear_exact_search(mi, oracle, n, D, k):
     ix.close()
 
 
+def test_linear_single_query_callers_are_combined(mi, oracle):
+    """Linear.computeNearestNeighbors from many threads, one query per call (the reference's usage): the callers are
+    served together as one device batch and every one of them gets the answer of its own query."""
+    import threading
+
+    n, D = 3000, 32
+    rng = np.random.default_rng(77)
+    X = rng.standard_normal((n, D))
+    ix = mi.Linear(D, n)
+    ix.indexVectors([f"v{i}" for i in range(n)], X)
+    Q = X[rng.choice(n, 64, replace=False)] + 0.05 * rng.standard_normal((64, D))
+    want = {k: [oracle.linear_search(X, q, k) for q in Q] for k in (1, 10)}
+    errors = []
+    start = threading.Barrier(16)
+
+    def worker(t):
+        try:
+            start.wait()
+            k = (1, 10)[t % 2]
+            for rep in range(30):
+                q0 = (t * 5 + rep * 3) % 60
+                nq = 1 if rep % 4 else 3
+                iids, dists, counts = ix.search_batch(k, Q[q0:q0 + nq])
+                for j in range(nq):
+                    rid, rd = want[k][q0 + j]
+                    if counts[j] != len(rid) or not np.array_equal(iids[j, :counts[j]], rid) or not np.array_equal(dists[j, :counts[j]], rd):
+                        errors.append((t, rep, k, q0, j))
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
+    ix.close()
+
+
 def test_concurrent_reader_threads(mi, oracle):
     """computeNearestNeighbors is not synchronized in the reference (ASS:281-291): several threads may query one index.
     The native host-pointer search queues them on a per-handle lock; every thread must get its own right answer."""

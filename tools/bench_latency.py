@@ -133,5 +133,23 @@ for combine in (1, 0):
         trows.append(r)
         print(r, file=sys.stderr, flush=True)
 nat.check(L.mmidx_set_option(h, b"combine", 1))
-print(json.dumps({"workload": f"IVFPQ {N}x{D}, C={Cc}, w={w}, m={m}x{ks}, k={k}", "latency": rows, "single_query_callers": trows}))
+# ---- the same callers on BASELINE config 1 (Linear, 10k x 128, k = 10) --------------------------------------
+lrows = []
+rng = np.random.default_rng(5)
+X1 = rng.standard_normal((10000, D))
+Q1 = np.ascontiguousarray(X1[rng.choice(10000, 1000, replace=False)] + 0.05 * rng.standard_normal((1000, D)))
+lh = C.c_void_p()
+nat.check(L.mmidx_linear_create(D, 10000, 0, C.byref(lh)))
+nat.check(L.mmidx_linear_add(lh, 10000, X1.ctypes.data))
+lfn = C.cast(L.mmidx_linear_search, C.c_void_p)
+for T in [int(t) for t in args.threads.split(",")]:
+    calls = max(20, min(1000, 40000 // T))
+    errs = C.c_int(0)
+    H.run_callers(lfn, lh, 10, D, Q1.ctypes.data, 1000, T, 20, C.byref(errs))
+    sec = H.run_callers(lfn, lh, 10, D, Q1.ctypes.data, 1000, T, calls, C.byref(errs))
+    r = {"threads": T, "calls": T * calls, "qps": round(T * calls / sec, 1), "ms_per_call": round(sec / calls * 1e3, 4), "errors": errs.value}
+    lrows.append(r)
+    print("linear", r, file=sys.stderr, flush=True)
+nat.check(L.mmidx_linear_destroy(lh))
+print(json.dumps({"workload": f"IVFPQ {N}x{D}, C={Cc}, w={w}, m={m}x{ks}, k={k}", "latency": rows, "single_query_callers": trows, "linear_10k_single_query_callers": lrows}))
 L.mmidx_destroy(h)
