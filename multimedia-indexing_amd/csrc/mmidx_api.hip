@@ -632,8 +632,13 @@ int launch_seed_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t st) {
 
 template <int M>
 int launch_hist_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t st) {
-    HIPCK(hipFuncSetAttribute((const void *)k_scan_hist<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_scan_hist<M>), grid, dim3(MMIDX_BLOCK), lds, st, P);
+    if (P.ks == 256) {
+        HIPCK(hipFuncSetAttribute((const void *)k_scan_hist<M, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_scan_hist<M, 256>), grid, dim3(MMIDX_BLOCK), lds, st, P);
+    } else {
+        HIPCK(hipFuncSetAttribute((const void *)k_scan_hist<M, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_scan_hist<M, 0>), grid, dim3(MMIDX_BLOCK), lds, st, P);
+    }
     HIPCK(hipGetLastError());
     return MMIDX_OK;
 }

@@ -1823,15 +1823,20 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
 #define MMIDX_HKEEP 256  // most entries one item may emit (>= K1 required: the host checks; the pool has room for them)
 #define MMIDX_HPOS 4     // appended positions re-evaluated per thread per round at the end
 
-template <int M>
+// KS = 256: the usual codebook size as a compile-time constant (the table row of sub-quantizer s then sits at an
+// immediate offset of the gather's ds_read instead of costing a VALU add per lookup); KS = 0: ks from the parameters.
+template <int M, int KS>
 __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = MMIDX_BLOCK;
-    const int ks = P.ks, D = P.D;
+    const int ks = KS > 0 ? KS : P.ks, D = P.D;
     double *lut = (double *)smem;                                        // [M*ks]
     double *vec = lut + (size_t)M * ks;                                  // [D] or [2D]
     double *s_red = vec + (P.transform ? 2 : 1) * (size_t)D;             // [8] wave minima / maxima of segment 0
-    u32 *hist = (u32 *)(((uintptr_t)(s_red + 8) + 15) & ~(uintptr_t)15);  // [HB] (16-byte aligned: read as uint4)
+    // [HB], 16-byte aligned (read as uint4).  The offset is computed on the index, not on the pointer value: a cast
+    // through uintptr_t loses the LDS address space and every access below becomes a FLAT instruction
+    const size_t hist_off = ((((size_t)M * ks + (P.transform ? 2 : 1) * (size_t)D + 8) * 8) + 15) & ~(size_t)15;
+    u32 *hist = (u32 *)(smem + hist_off);
     u32 *s_cnt = hist + MMIDX_HB;                                        // [8]: 0-3 appended per wave, 4-5 largest kept key (u64)
     u32 *posbuf = s_cnt + 8;                                             // [cap] list positions, one quarter per wave
 
@@ -1866,10 +1871,12 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
     build_lut_any(lut, tr, P.pqT, M, ks, P.dsub);
     __syncthreads();
 
+    // (0.0 + x == x bit for bit: the table entries are sums of squares from +0.0, never -0.0, so the reference's
+    //  `d = 0; d += LUT[0][..]` is the first entry itself)
     auto exact = [&](const CodeVec<M, unsigned char> &cv) -> double {
-        double d = 0.0;
+        double d = lut[cv.get(0)];
 #pragma unroll
-        for (int s = 0; s < M; s++) d += lut[s * ks + cv.get(s)];
+        for (int s = 1; s < M; s++) d += lut[s * ks + cv.get(s)];
         return d;
     };
 
