@@ -1968,25 +1968,41 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
 #if MMIDX_HIST_STOP == 3
     Tb = -1;
 #endif
-    int g = 0;
-    for (int64_t seg = c0; seg < c1; seg += NT, g++) {
-        const bool more = seg + NT < c1;
+    // The loop is VALU-bound as much as LDS-bound (PMC: VALU ~78 % busy, LDS ~73 %), so its bookkeeping is kept in
+    // scalar registers and 32-bit arithmetic: the list bounds are made wave-uniform explicitly (they come from vector
+    // loads), positions are relative to c0 (chunk <= 2^24 codes: the host checks), the bucket clamp is two fp64
+    // min / max, and the ballot is the compare mask itself.
+    const u32 n_seg = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(c1 - c0));
+    const unsigned char *codes0;  // (rebuilt from the kernel argument: a pointer made from integers would be FLAT-addressed)
+    {
+        const u64 e0 = (u64)(beg + c0);
+        const u32 lo32 = (u32)__builtin_amdgcn_readfirstlane((int)(u32)e0), hi32 = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(e0 >> 32));
+        codes0 = (const unsigned char *)P.codes + (size_t)(((u64)hi32 << 32) | lo32) * M;
+    }
+    auto bucket_fast = [&](double dd) -> int {  // == bucket(dd): the same monotone map, clamped in fp64 before the conversion
+        const double x = (dd - lo) * inv;
+        return (int)__builtin_fmax(__builtin_fmin(x, (double)(MMIDX_HB - 1)), 0.0);
+    };
+    u32 g = 0;
+    for (u32 seg = 0; seg < n_seg; seg += NT, g++) {
+        const bool more = seg + NT < n_seg;  // scalar
         if (more) {
-            const int64_t i = seg + NT + tid;
-            nxt.load(codes + (size_t)(i < c1 ? i : c1 - 1) * M);
+            const u32 i = seg + NT + (u32)tid;
+            const u32 ic = i < n_seg ? i : n_seg - 1u;
+            nxt.load(codes0 + ic * (u32)M);  // (32-bit offset from a uniform base)
         }
         const bool refresh = MMIDX_HIST_STOP != 3 && g > 0 && (g < 16 || (g & 3) == 0);
-        uint4 hv = make_uint4(0, 0, 0, 0);
+        uint4 hv;  // live only on refresh rounds
         if (refresh) hv = ((const uint4 *)hist)[lane];  // buckets 4*lane .. 4*lane+3
         if (g > 0) d = exact(cur);
-        const int64_t i = seg + tid;
-        const int b = bucket(d);
-        const bool pass = (i < c1) && b <= Tb;
-        const u64 mask = __ballot(pass);
+        const u32 pos = seg + (u32)tid;
+        const int b = bucket_fast(d);
+        const bool pass = (pos < n_seg) && b <= Tb;
+        const u64 mask = __builtin_amdgcn_ballot_w64(pass);
         if (pass) {
             atomicAdd(hist + b, 1u);
             const u32 slot = wcnt + (u32)__popcll(mask & lane_lt);
-            if (slot < capw) mybuf[slot] = ((u32)b << 24) | (u32)(i - c0);  // chunk <= 2^24 codes: the host checks
+            if (slot < capw) mybuf[slot] = ((u32)b << 24) | pos;
         }
         wcnt += (u32)__popcll(mask);  // > capw: overflow, seen at the end
         if (refresh) {
