@@ -1822,6 +1822,12 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
 #define MMIDX_HB 256
 #define MMIDX_HKEEP 256  // most entries one item may emit (>= K1 required: the host checks; the pool has room for them)
 #define MMIDX_HPOS 4     // appended positions re-evaluated per thread per round at the end
+#ifndef MMIDX_HREF_EARLY
+#define MMIDX_HREF_EARLY 16  // the threshold bucket is re-derived every segment at first ...
+#endif
+#ifndef MMIDX_HREF_MASK
+#define MMIDX_HREF_MASK 3    // ... then every (mask + 1)-th
+#endif
 
 // KS = 256: the usual codebook size as a compile-time constant (the table row of sub-quantizer s then sits at an
 // immediate offset of the gather's ds_read instead of costing a VALU add per lookup); KS = 0: ks from the parameters.
@@ -1991,7 +1997,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
             const u32 ic = i < n_seg ? i : n_seg - 1u;
             nxt.load(codes0 + ic * (u32)M);  // (32-bit offset from a uniform base)
         }
-        const bool refresh = MMIDX_HIST_STOP != 3 && g > 0 && (g < 16 || (g & 3) == 0);
+        const bool refresh = MMIDX_HIST_STOP != 3 && g > 0 && (g < MMIDX_HREF_EARLY || (g & MMIDX_HREF_MASK) == 0);
         uint4 hv;  // live only on refresh rounds
         if (refresh) hv = ((const uint4 *)hist)[lane];  // buckets 4*lane .. 4*lane+3
         if (g > 0) d = exact(cur);
