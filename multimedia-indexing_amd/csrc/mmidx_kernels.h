@@ -333,7 +333,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_fast(const double
             u32 base = 0;
             const int leader = __ffsll((long long)mask) - 1;
             if ((tid & 63) == leader) base = atomicAdd(&s_n, (u32)__popcll(mask));
-            base = __shfl(base, leader);
+            base = wave_read_u32(base, leader);  // (v_readlane: no trip through the LDS pipe)
             if (pass) {
                 const u32 slot = base + (u32)__popcll(mask & lane_lt);
                 if (slot < MMIDX_CSEL_CAP) {
@@ -554,9 +554,38 @@ __device__ __forceinline__ void coarse_select_finish(const ApproxSel &A, const i
         double *terms = (double *)(sel_i + ((A.w + 2) & ~1));  // [CAND_CHUNK][D]
         for (int base = 0; base < n; base += MMIDX_CAND_CHUNK) {
             const int nc_ = (n - base < MMIDX_CAND_CHUNK) ? n - base : MMIDX_CAND_CHUNK;
-            if ((D & 1) == 0) {
+            const int hD = D >> 1;
+            if ((D & 1) == 0 && (hD & (hD - 1)) == 0 && hD <= MMIDX_BLOCK) {
+                // D/2 a power of two that divides the block (the usual case, D = 128): a thread owns ONE pair of
+                // coordinates (j, j + 1) and walks the candidates -- no division per element, the query pair is
+                // loaded once, the row offset is one 32 x 32 -> 64 bit multiply.  Same operations on the same
+                // operands as the general branch below: (c_j - q_j)^2 per coordinate.
+                constexpr int PU = 6;  // candidate rows in flight per thread (24 = one chunk at D = 128)
+                const int sh = __ffs(hD) - 1;
+                const int j = (tid & (hD - 1)) * 2;
+                const int ci0 = tid >> sh, cstep = MMIDX_BLOCK >> sh;
+                const double2 qj = *(const double2 *)(qv + j);
+                for (int cb = 0; cb < nc_; cb += PU * cstep) {
+                    double2 cv[PU];
+#pragma unroll
+                    for (int u = 0; u < PU; u++) {
+                        const int ci = cb + ci0 + u * cstep;
+                        cv[u] = make_double2(0.0, 0.0);
+                        if (ci < nc_) cv[u] = *(const double2 *)(A.coarse + (size_t)cidx[base + ci] * (u32)D + j);
+                    }
+#pragma unroll
+                    for (int u = 0; u < PU; u++) {
+                        const int ci = cb + ci0 + u * cstep;
+                        if (ci < nc_) {
+                            const double d0 = cv[u].x - qj.x, d1 = cv[u].y - qj.y;
+                            double *tt = terms + (size_t)ci * (D + MMIDX_TERM_PAD) + j;
+                            tt[0] = d0 * d0;
+                            tt[1] = d1 * d1;
+                        }
+                    }
+                }
+            } else if ((D & 1) == 0) {
                 // 16-byte loads: element pairs (j, j + 1) of a candidate row; 8 pairs in flight per thread
-                const int hD = D >> 1;
                 for (int e0 = 0; e0 < nc_ * hD; e0 += MMIDX_BLOCK * 8) {
                     double2 cv[8], qq[8];
 #pragma unroll
@@ -839,7 +868,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_approx(const Appr
             u32 base = 0;
             const int leader = __ffsll((long long)mask) - 1;
             if ((tid & 63) == leader) base = atomicAdd(&s_n, (u32)__popcll(mask));
-            base = __shfl(base, leader);
+            base = wave_read_u32(base, leader);  // (v_readlane: no trip through the LDS pipe)
             if (pass) {
                 const u32 slot = base + (u32)__popcll(mask & lane_lt);
                 if (slot < MMIDX_CSEL_CAP) cidx[slot] = (u32)c;
@@ -1343,7 +1372,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_grp(const ApproxS
             u32 base = 0;
             const int leader = __ffsll((long long)mask) - 1;
             if (lane == leader) base = atomicAdd(&s_n4[0], (u32)__popcll(mask));
-            base = __shfl(base, leader);
+            base = wave_read_u32(base, leader);  // (v_readlane: no trip through the LDS pipe)
             if (pass) {
                 const u32 slot = base + (u32)__popcll(mask & lane_lt);
                 if (slot < MMIDX_CSEL_CAP) cidx[slot] = (u32)c;
@@ -1743,7 +1772,7 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
                 u32 base = 0;
                 const int leader = __ffsll((long long)mask) - 1;
                 if ((tid & 63) == leader) base = atomicAdd(s_cnt, (u32)__popcll(mask));
-                base = __shfl(base, leader);
+                base = wave_read_u32(base, leader);  // (v_readlane: no trip through the LDS pipe)
                 if (pass) {
                     const u32 slot = base + (u32)__popcll(mask & lane_lt);
                     bkey[slot] = key;
@@ -1778,7 +1807,7 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
             u32 base = 0;
             const int leader = __ffsll((long long)mask) - 1;
             if ((tid & 63) == leader) base = atomicAdd(P.pool_cnt + q, (u32)__popcll(mask));
-            base = __shfl(base, leader);
+            base = wave_read_u32(base, leader);  // (v_readlane: no trip through the LDS pipe)
             if (pass) {
                 const u32 slot = base + (u32)__popcll(mask & lane_lt);
                 if (slot < (u32)P.poolq) {
@@ -2072,7 +2101,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
             u32 base = 0;
             const int leader = __ffsll((long long)mask) - 1;
             if (lane == leader) base = atomicAdd(P.pool_cnt + q, (u32)__popcll(mask));
-            base = __shfl(base, leader);
+            base = wave_read_u32(base, leader);  // (v_readlane: no trip through the LDS pipe)
             if (emit) {
                 const u32 slot = base + (u32)__popcll(mask & lane_lt);
                 if (slot < (u32)P.poolq) {
@@ -2378,7 +2407,7 @@ __device__ __forceinline__ void scan_filt_body(const ScanParams &P, const unsign
                 u32 base = 0;
                 const int leader = __ffsll((long long)mask) - 1;
                 if ((tid & 63) == leader) base = atomicAdd(s_cnt + 1, (u32)__popcll(mask));
-                base = __shfl(base, leader);
+                base = wave_read_u32(base, leader);  // (v_readlane: no trip through the LDS pipe)
                 if (pass) surv[base + (u32)__popcll(mask & lane_lt)] = (u32)i;
             }
         }
@@ -2419,7 +2448,7 @@ __device__ __forceinline__ void scan_filt_body(const ScanParams &P, const unsign
                 u32 base = 0;
                 const int leader = __ffsll((long long)mask) - 1;
                 if ((tid & 63) == leader) base = atomicAdd(s_cnt, (u32)__popcll(mask));
-                base = __shfl(base, leader);
+                base = wave_read_u32(base, leader);  // (v_readlane: no trip through the LDS pipe)
                 if (pass) {
                     const u32 slot = base + (u32)__popcll(mask & lane_lt);
                     bkey[slot] = key;
@@ -2456,7 +2485,7 @@ __device__ __forceinline__ void scan_filt_body(const ScanParams &P, const unsign
                     u32 base = 0;
                     const int leader = __ffsll((long long)mask) - 1;
                     if ((tid & 63) == leader) base = atomicAdd(s_cnt, (u32)__popcll(mask));
-                    base = __shfl(base, leader);
+                    base = wave_read_u32(base, leader);  // (v_readlane: no trip through the LDS pipe)
                     if (pass) {
                         const u32 slot = base + (u32)__popcll(mask & lane_lt);
                         bkey[slot] = key;
@@ -2487,7 +2516,7 @@ __device__ __forceinline__ void scan_filt_body(const ScanParams &P, const unsign
             u32 base = 0;
             const int leader = __ffsll((long long)mask) - 1;
             if ((tid & 63) == leader) base = atomicAdd(P.pool_cnt + q, (u32)__popcll(mask));
-            base = __shfl(base, leader);
+            base = wave_read_u32(base, leader);  // (v_readlane: no trip through the LDS pipe)
             if (pass) {
                 const u32 slot = base + (u32)__popcll(mask & lane_lt);
                 if (slot < (u32)P.poolq) {
@@ -2746,7 +2775,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_seed(const ScanParams P) {
                     u32 base = 0;
                     const int leader = __ffsll((long long)mask) - 1;
                     if ((tid & 63) == leader) base = atomicAdd(s_cnt + 1, (u32)__popcll(mask));
-                    base = __shfl(base, leader);
+                    base = wave_read_u32(base, leader);  // (v_readlane: no trip through the LDS pipe)
                     if (pass) surv[base + (u32)__popcll(mask & lane_lt)] = (u32)i;
                 }
             }
@@ -2780,7 +2809,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_seed(const ScanParams P) {
                     u32 base = 0;
                     const int leader = __ffsll((long long)mask) - 1;
                     if ((tid & 63) == leader) base = atomicAdd(s_cnt, (u32)__popcll(mask));
-                    base = __shfl(base, leader);
+                    base = wave_read_u32(base, leader);  // (v_readlane: no trip through the LDS pipe)
                     if (pass) {
                         const u32 slot = base + (u32)__popcll(mask & lane_lt);
                         bkey[slot] = key;
@@ -2807,7 +2836,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_seed(const ScanParams P) {
             u32 base = 0;
             const int leader = __ffsll((long long)mask) - 1;
             if ((tid & 63) == leader) base = atomicAdd(P.pool_cnt + q, (u32)__popcll(mask));
-            base = __shfl(base, leader);
+            base = wave_read_u32(base, leader);  // (v_readlane: no trip through the LDS pipe)
             if (pass) {
                 const u32 slot = base + (u32)__popcll(mask & lane_lt);
                 if (slot < (u32)P.poolq) {
@@ -3008,7 +3037,7 @@ __global__ __launch_bounds__(NT) void k_merge(const MergeParams P) {
                 u32 base = 0;
                 const int leader = __ffsll((long long)mask) - 1;
                 if ((tid & 63) == leader) base = atomicAdd(&s_m, (u32)__popcll(mask));
-                base = __shfl(base, leader);
+                base = wave_read_u32(base, leader);  // (v_readlane: no trip through the LDS pipe)
                 if (pass) {
                     const u32 slot = base + (u32)__popcll(mask & lane_lt);
                     if (slot < (u32)CAP) {
