@@ -60,6 +60,20 @@ __device__ __forceinline__ u32 wave_incl_scan_u32(u32 x) {
     return v;
 }
 __device__ __forceinline__ u32 wave_read_u32(u32 x, int l) { return (u32)__builtin_amdgcn_readlane((int)x, l); }
+// minimum / maximum over the wave (same DPP ladder; lanes a step does not reach keep their own value), wave-uniform result
+__device__ __forceinline__ u32 wave_min_u32(u32 x) {
+    u32 v = x;
+#define MMIDX_DPP_MIN(ctrl, rmask)                                                              \
+    {                                                                                           \
+        const u32 o = (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xf, false); \
+        v = o < v ? o : v;                                                                      \
+    }
+    MMIDX_DPP_MIN(0x111, 0xf) MMIDX_DPP_MIN(0x112, 0xf) MMIDX_DPP_MIN(0x114, 0xf) MMIDX_DPP_MIN(0x118, 0xf)
+    MMIDX_DPP_MIN(0x142, 0xa) MMIDX_DPP_MIN(0x143, 0xc)
+#undef MMIDX_DPP_MIN
+    return wave_read_u32(v, 63);
+}
+__device__ __forceinline__ u32 wave_max_u32(u32 x) { return ~wave_min_u32(~x); }
 __device__ __forceinline__ double wave_read_f64(double x, int l) {
     const u64 b = (u64)__double_as_longlong(x);
     const u32 lo_ = wave_read_u32((u32)b, l), hi_ = wave_read_u32((u32)(b >> 32), l);
@@ -1304,7 +1318,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_grp(const ApproxS
     const int R = w + 1;  // host guarantees R <= min(G, 256)
     constexpr int PERG = (PER + 7) / 8;  // groups per thread
     // the second half stages its difference terms after sel_i; this front end uses that space first
-    float *gsort = (float *)(sel_i + ((A.w + 2) & ~1));  // [256] wave-sorted thread minima
+    float *gsort = (float *)(sel_i + ((A.w + 2) & ~1));  // [256] thread minima
     const double qn = A.qn[q];
     const double qnorm = sqrt(qn);
     const double sumn = A.cnorm_max + qnorm;
@@ -1328,32 +1342,24 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_grp(const ApproxS
     }
     if (tid == 0) s_n4[0] = 0;
     // ---- tau: the R-th smallest of the 256 thread minima (R distinct centroids lie at or below it) ----
-    int rk = 0;  // rank inside the wave (ties by lane), VALU only
-#pragma unroll 16
-    for (int j = 0; j < 64; j++) {
-        const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gm), j));
-        rk += (o < gm) || (o == gm && j < lane);
-    }
-    gsort[wv * 64 + rk] = gm;
+    // The values are >= 0 (or NaN / inf, which order above everything finite), so their bit patterns order them: one
+    // wave takes all 256 (four per lane) and bisects on the pattern -- four compares + popcounts per step, ~24 steps,
+    // scalar bookkeeping -- instead of every thread ranking its value against the other 255.
+    gsort[tid] = gm;
     __syncthreads();
-    {
-        int grank = rk;
-#pragma unroll
-        for (int ow = 0; ow < MMIDX_BLOCK / 64; ow++) {
-            if (ow == wv) continue;
-            // elements of wave ow that precede mine: value <, or == and ow < wv
-            const float *lst = gsort + ow * 64;
-            int lo_ = 0, hi_ = 64;  // first index whose element does NOT precede mine
-            while (lo_ < hi_) {
-                const int mid = (lo_ + hi_) >> 1;
-                const float o = lst[mid];
-                const bool prec = (o < gm) || (o == gm && ow < wv);
-                if (prec) lo_ = mid + 1;
-                else hi_ = mid;
-            }
-            grank += lo_;
+    if (wv == 0) {
+        const u32 k0 = (u32)__float_as_int(gsort[lane]) & 0x7fffffffu, k1 = (u32)__float_as_int(gsort[64 + lane]) & 0x7fffffffu,
+                  k2 = (u32)__float_as_int(gsort[128 + lane]) & 0x7fffffffu, k3 = (u32)__float_as_int(gsort[192 + lane]) & 0x7fffffffu;
+        const u32 mn01 = k0 < k1 ? k0 : k1, mn23 = k2 < k3 ? k2 : k3, mx01 = k0 < k1 ? k1 : k0, mx23 = k2 < k3 ? k3 : k2;
+        u32 lo_k = wave_min_u32(mn01 < mn23 ? mn01 : mn23), hi_k = wave_max_u32(mx01 < mx23 ? mx23 : mx01);
+        while (lo_k < hi_k) {  // smallest pattern with at least R values at or below it == the R-th smallest value
+            const u32 mid = lo_k + ((hi_k - lo_k) >> 1);
+            const int c = (int)__popcll(__builtin_amdgcn_ballot_w64(k0 <= mid)) + (int)__popcll(__builtin_amdgcn_ballot_w64(k1 <= mid)) +
+                          (int)__popcll(__builtin_amdgcn_ballot_w64(k2 <= mid)) + (int)__popcll(__builtin_amdgcn_ballot_w64(k3 <= mid));
+            if (c >= R) hi_k = mid;
+            else lo_k = mid + 1;
         }
-        if (grank == R - 1) s_tau4[0] = gm;
+        if (lane == 0) s_tau4[0] = __int_as_float((int)hi_k);
     }
     __syncthreads();
     // any centroid with exact distance <= tau has d~ <= tau + eps16
