@@ -1084,29 +1084,43 @@ __global__ __launch_bounds__(MMIDX_BLOCK, 2) void k_coarse_gmin16(const __bf16 *
             asm volatile("" ::"v"(touch_h), "v"(touch_l));  // (keeps the two loads; their data is not used)
         }
         // epilogue: d~ = |c|^2 + |q|^2 - 2 S.  A group = the 8 columns one lane holds for a row
-        // (c0 + fr + 16 ct, ct = 0..7): its two smallest d~ and the position of the smallest, no cross-lane work
-        float cn_c[8];  // (fp32 epilogue: three roundings of at most 2^-24 (|c| + |q|)^2 each, inside eps16's last term)
+        // (c0 + fr + 16 ct, ct = 0..7): its two smallest d~ and the position of the smallest, no cross-lane work.
+        // The epilogue's VALU work was half of this kernel's time (timing experiment: 155 us with, 48 us without), so
+        // it is four instructions per value: t = fma(-2, S, |c|^2) (|q|^2, constant along the row, is added to the two
+        // survivors only), the column index packed into t's three low mantissa bits (v_and_or_b32: the minimum then
+        // carries its own position), runner-up = med3(best, runner-up, t), best = min(best, t).
+        // Roundings: fp32 copies of the norms, the fma, the final addition (4 x 2^-24) and the three borrowed bits
+        // (2^-20, on either survivor) -- inside eps16's last term (2^-21 + 2^-20)(|c| + |q|)^2.  Nothing here can
+        // overflow or produce a NaN: K1f sends rows with (|c|max + |q|)^2 >= 1e37 to the exact path before it looks at
+        // these values, and the +inf norms of the padding centroids are clamped to a finite "far".
+        float cn_c[8];
 #pragma unroll
-        for (int ct = 0; ct < 8; ct++) cn_c[ct] = (float)cn[c0 + ct * 16 + fr];
+        for (int ct = 0; ct < 8; ct++) {
+            const float cf = (float)cn[c0 + ct * 16 + fr];
+            cn_c[ct] = cf < 3.0e38f ? cf : 3.0e38f;
+        }
 #pragma unroll
         for (int rt = 0; rt < 2; rt++) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                float m1 = __int_as_float(0x7f800000), m2 = m1;
-                int a1 = 0;
+                float m1 = __int_as_float(0x7f7ffff8), m2 = m1;  // (largest finite value with the position bits clear)
 #pragma unroll
                 for (int ct = 0; ct < 8; ct++) {
-                    const float dv = (cn_c[ct] + qn_r[rt][r]) - 2.0f * acc[rt][ct][r];
-                    const bool lt1 = dv < m1;
-                    m2 = lt1 ? m1 : (dv < m2 ? dv : m2);
-                    a1 = lt1 ? ct : a1;
-                    m1 = lt1 ? dv : m1;
+                    const float t = __builtin_fmaf(-2.0f, acc[rt][ct][r], cn_c[ct]);
+                    const float tp = __int_as_float((__float_as_int(t) & ~7) | ct);
+                    m2 = __builtin_amdgcn_fmed3f(m1, m2, tp);
+                    // min(m1, tp) as the median with a value below everything (|t| < 1e37 here): a minnum of a value
+                    // assembled from bits would be preceded by a canonicalising v_max, a fifth instruction per value
+                    m1 = __builtin_amdgcn_fmed3f(m1, tp, -3.0e38f);
                 }
-                m2 = m2 < 0.0f ? 0.0f : m2;
+                const int a1 = __float_as_int(m1) & 7;
+                const float d1 = m1 + qn_r[rt][r];
+                float d2 = m2 + qn_r[rt][r];
+                d2 = d2 < 0.0f ? 0.0f : d2;
                 // the position of the minimum rides in the 3 low mantissa bits of the runner-up (masked off by the reader)
-                const float m2p = __int_as_float((__float_as_int(m2) & ~7) | a1);
+                const float m2p = __int_as_float((__float_as_int(d2) & ~7) | a1);
                 const int q = q0 + rt * 16 + 4 * fg + r;
-                if (q < nq) gpair[(size_t)q * G + (size_t)t * 16 + fr] = make_float2(m1, m2p);
+                if (q < nq) gpair[(size_t)q * G + (size_t)t * 16 + fr] = make_float2(d1, m2p);
             }
         }
     }
@@ -1364,7 +1378,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_grp(const ApproxS
     __syncthreads();
     // any centroid with exact distance <= tau has d~ <= tau + eps16
     const double cut = ((double)s_tau4[0] + eps16) + eps16;
-    if (!(cut < (double)inf)) {
+    if (!(cut < (double)inf) || !(sumn * sumn < 1e37)) {  // (beyond 1e37 K1e's fp32 values may have overflowed: they are not looked at)
         // magnitudes beyond fp32 / bf16 (inf or NaN in d~): nothing can be certified -> the exact row (overflow path)
         __syncthreads();
         coarse_select_finish<PER>(A, q, MMIDX_CSEL_CAP + 1, ckey, cidx, sel_k, sel_i, s_k, s_i);
