@@ -1310,7 +1310,9 @@ __global__ __launch_bounds__(MMIDX_BLOCK, 2) void k_assign_gmin16(const __bf16 *
                 const double eps = (2.0 * 3.1 * 0x1p-16 * xnorm * cnorm_max + 2.0 * (3.0 * (double)Dp + 16.0) * 0x1p-22 * xnorm * cnorm_max +
                                     1e-12 * (cn_max + xnd) + 0x1p-21 * sumn * sumn) * (1.0 + 1e-9);
                 cell_out[q] = ix;
-                amb[q] = (((double)m2 - (double)m1) > 2.0 * eps) ? 0 : 1;  // inf - x = inf > ... when there is one centroid
+                // (beyond 1e37 the fp32 quantities above may have overflowed -- an infinite dot product would even make a
+                //  far centroid look nearest: such vectors go to the exact kernel)
+                amb[q] = (((double)m2 - (double)m1) > 2.0 * eps && sumn * sumn < 1e37) ? 0 : 1;  // inf - x = inf > ... when there is one centroid
             }
         }
 }

@@ -841,15 +841,15 @@ def test_assignment_kernel_ties_and_padding(mi, oracle, D, C):
     ix.close()
 
 
-def test_coarse_stage_huge_magnitudes(mi, oracle):
-    """Coordinates beyond the fp32 range (1e25): the matrix-core filter overflows to inf / NaN and must hand every query to
-    the exact path instead of certifying garbage; the encoder's assignment flags such vectors for the exact kernel."""
-    import torch
-
-    nat = importlib.import_module("multimedia-indexing_amd._native")
+@pytest.mark.parametrize("scale", [1e25, 1e17, 3e17, 1.5e18, 6e18])
+def test_coarse_stage_huge_magnitudes(mi, oracle, scale):
+    """Coordinates near and beyond the fp32 range: at 1e25 the matrix-core filter overflows to inf / NaN everywhere, around
+    1e18 only some of its fp32 quantities do (squared norms ~1e37..1e39) -- it must hand every such query to the exact path
+    instead of certifying garbage (at 1e17 everything is still finite and the certified path runs); the encoder's
+    assignment flags such vectors for the exact kernel."""
     rng = np.random.default_rng(4)
     D, C, w = 32, 1200, 6
-    coarse = 1e25 * rng.standard_normal((C, D))
+    coarse = scale * rng.standard_normal((C, D))
     pq = rng.standard_normal((2, 16, D // 2))
     ix = mi.IVFPQ(D, 10, False, "", 2, 16, 0, C, 512)
     ix.loadCoarseQuantizer(coarse)
