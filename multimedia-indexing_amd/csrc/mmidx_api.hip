@@ -200,6 +200,7 @@ struct mmidx_index {
     double *d_cn_pad = nullptr;  // [Cp] |c|^2, +inf on the padding rows
     int Cp = 0, Dp = 0;          // C rounded up to 128, D rounded up to 32
     bool coarse_v1 = false;      // MMIDX_COARSE_V1=1: K1c/K1d (fp32 MFMA, full d~ matrix) instead
+    bool coarse_nodma = false;   // option "coarse_nodma": K1e with register staging also when Dp == 128 (A/B switch)
     double cn_max = 0.0, cnorm_max = 0.0;
     bool exact_coarse = false;  // MMIDX_EXACT_COARSE=1: fp64 distances to every centroid (K1a/K1b)
     bool cdsel_valid = false;   // ws_cdsel holds the selected cells' exact distances for the current batch
@@ -730,11 +731,18 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
         const int ntiles = h->Cp / G16_BC;
         const int qblocks = (int)((nq + G16_BQ - 1) / G16_BQ);
         const int csplit = std::max(1, std::min(ntiles, (512 + qblocks - 1) / qblocks));
-        const size_t l16 = 2 * (size_t)G16_BC * G16_STRIDE;
-        HIPCK(hipFuncSetAttribute((const void *)k_coarse_gmin16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l16));
-        hipLaunchKernelGGL(k_coarse_gmin16, dim3((unsigned)qblocks, (unsigned)csplit), dim3(MMIDX_BLOCK), l16, st, (const __bf16 *)h->ws_Qh.p,
-                           (const __bf16 *)h->ws_Ql.p, (const __bf16 *)h->d_Ch, (const __bf16 *)h->d_Cl, h->d_cn_pad, h->ws_qn.p,
-                           (float2 *)h->ws_gmin.p, h->Cp, h->Dp, (int)nq, G);
+        if (h->Dp == G16_KC && !h->coarse_nodma) {
+            // one k chunk: centroid tiles by LDS-DMA into two half-tile buffers (static LDS)
+            hipLaunchKernelGGL(k_coarse_gmin16_dma, dim3((unsigned)qblocks, (unsigned)csplit), dim3(MMIDX_BLOCK), 0, st, (const __bf16 *)h->ws_Qh.p,
+                               (const __bf16 *)h->ws_Ql.p, (const __bf16 *)h->d_Ch, (const __bf16 *)h->d_Cl, h->d_cn_pad, h->ws_qn.p,
+                               (float2 *)h->ws_gmin.p, h->Cp, (int)nq, G);
+        } else {
+            const size_t l16 = 2 * (size_t)G16_BC * G16_STRIDE;
+            HIPCK(hipFuncSetAttribute((const void *)k_coarse_gmin16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l16));
+            hipLaunchKernelGGL(k_coarse_gmin16, dim3((unsigned)qblocks, (unsigned)csplit), dim3(MMIDX_BLOCK), l16, st, (const __bf16 *)h->ws_Qh.p,
+                               (const __bf16 *)h->ws_Ql.p, (const __bf16 *)h->d_Ch, (const __bf16 *)h->d_Cl, h->d_cn_pad, h->ws_qn.p,
+                               (float2 *)h->ws_gmin.p, h->Cp, h->Dp, (int)nq, G);
+        }
         HIPCK(hipGetLastError());
         ApproxSel A{};
         A.qn = h->ws_qn.p;
@@ -1919,6 +1927,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->passb_main_grid = value;
     } else if (n == "coarse_v1") {
         h->coarse_v1 = value != 0;
+    } else if (n == "coarse_nodma") {
+        h->coarse_nodma = value != 0;
     } else if (n == "passa_hist") {
         h->passa_hist = value;
     } else if (n == "passa_prefix") {

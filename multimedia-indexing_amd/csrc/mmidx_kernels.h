@@ -916,6 +916,9 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_approx(const Appr
 //   d~ = |c|^2 + |q|^2 - 2 S evaluated in fp32 from fp32 copies of the norms: 2^-21 (|c| + |q|)^2
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+#ifndef G16_DMA_TOUCH
+#define G16_DMA_TOUCH 1  // K1e': touch the next tile's lines one tile ahead
+#endif
 #define G16_BQ 128     // queries per block (32 per wave)
 #define G16_BC 128     // centroids per tile
 #define G16_KC 128     // k per LDS tile
@@ -1123,6 +1126,160 @@ __global__ __launch_bounds__(MMIDX_BLOCK, 2) void k_coarse_gmin16(const __bf16 *
                 if (q < nq) gpair[(size_t)q * G + (size_t)t * 16 + fr] = make_float2(d1, m2p);
             }
         }
+    }
+}
+
+// K1e', Dp == 128 (one k chunk: the usual D = 128): the same computation with the centroid tiles brought in by LDS-DMA
+// (global_load_lds_dwordx4) into TWO buffers of half a tile (64 centroids x 256 B x {head, tail} = 32 KiB each), so that
+// the next half tile lands while the matrix cores work on the current one -- in K1e the staging round trip
+// (global -> registers -> LDS, two barriers) cost a third of the kernel (timing experiment: 155 us with, 103 us without).
+//   * the DMA writes lane-linear (wave-uniform base + lane x 16 B), so the rows cannot be padded; the 16-byte units of a
+//     row are XOR-swizzled instead -- unit u of row r is FETCHED into slot u ^ (r & 15) by choosing the lane's global
+//     address, and read back from that slot: the 16 lanes of a fragment read (rows r .. r + 15, same u) hit 16 different
+//     slots = all 64 banks;
+//   * the two buffers are two distinct __shared__ arrays and the loop is unrolled by two halves, so that the compiler can
+//     tell the buffer being filled from the one being read (it waits for ALL outstanding LDS-DMA before a ds_read it
+//     cannot disambiguate); the barrier that ends a half drains the DMA issued at its start;
+//   * groups, epilogue and output are those of K1e (a group = the 8 columns a lane holds over the two halves of a tile).
+__global__ __launch_bounds__(MMIDX_BLOCK, 2) void k_coarse_gmin16_dma(const __bf16 *__restrict__ Qh, const __bf16 *__restrict__ Ql,
+                                                                   const __bf16 *__restrict__ Ch, const __bf16 *__restrict__ Cl,
+                                                                   const double *__restrict__ cn, const double *__restrict__ qn,
+                                                                   float2 *__restrict__ gpair, int Cp, int nq, int G) {
+    constexpr int Dp = G16_KC;               // 128 bf16 = 256 B = 16 units per row
+    constexpr int HROWS = G16_BC / 2;        // centroids per half tile
+    constexpr int HBYTES = HROWS * Dp * 2;   // 16 KiB per part (head / tail)
+    __shared__ __attribute__((aligned(1024))) unsigned char buf0[2 * HBYTES];
+    __shared__ __attribute__((aligned(1024))) unsigned char buf1[2 * HBYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int q0 = blockIdx.x * G16_BQ + wave * 32;
+    const int ntiles = Cp / G16_BC;
+    const int t_per = (ntiles + gridDim.y - 1) / gridDim.y;
+    const int t_lo = blockIdx.y * t_per, t_hi = (t_lo + t_per < ntiles) ? t_lo + t_per : ntiles;
+    if (t_lo >= t_hi) return;  // block-uniform
+    float qn_r[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int q = q0 + rt * 16 + 4 * fg + r;
+            qn_r[rt][r] = q < nq ? (float)qn[q] : 0.0f;
+        }
+    bf16x8 ah[2][4], al[2][4];  // A fragments: [row tile][k step of 32], resident for the whole block
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++) {
+        int q = q0 + rt * 16 + fr;
+        q = q < nq ? q : nq - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            ah[rt][ks] = *(const bf16x8 *)(Qh + (size_t)q * Dp + ks * 32 + fg * 8);
+            al[rt][ks] = *(const bf16x8 *)(Ql + (size_t)q * Dp + ks * 32 + fg * 8);
+        }
+    }
+    // DMA of one half tile (first centroid row0) into a buffer: 4 + 4 wave-instructions of 1 KiB (4 rows) per wave
+    auto issue = [&](unsigned char *buf, int row0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int pu = (i * 4 + wave) * 64 + lane;  // 16-byte slot of the part this lane fills
+            const int row = pu >> 4, slot = pu & 15;
+            const size_t src = ((size_t)(row0 + row) * Dp + (size_t)((slot ^ (row & 15)) * 8)) * 2;  // bytes
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const unsigned char *)Ch + src),
+                                             (__attribute__((address_space(3))) void *)(buf + (i * 4 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const unsigned char *)Cl + src),
+                                             (__attribute__((address_space(3))) void *)(buf + HBYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+        }
+    };
+    f32x4 acc[2][8];
+    // the four column tiles of one half: acc[rt][ct0 .. ct0 + 3] += A x B
+    auto half_mma = [&](const unsigned char *buf, const int ct0) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+#pragma unroll
+            for (int cp = 0; cp < 4; cp += 2) {
+                bf16x8 bh[2], bl[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int row = (cp + u) * 16 + fr;
+                    const int off = row * (Dp * 2) + (((ks * 4 + fg) ^ fr) * 16);  // (row & 15 == fr)
+                    bh[u] = *(const bf16x8 *)(buf + off);
+                    bl[u] = *(const bf16x8 *)(buf + HBYTES + off);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int rt = 0; rt < 2; rt++)
+                        acc[rt][ct0 + cp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bh[u], acc[rt][ct0 + cp + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int rt = 0; rt < 2; rt++)
+                        acc[rt][ct0 + cp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bl[u], acc[rt][ct0 + cp + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int rt = 0; rt < 2; rt++)
+                        acc[rt][ct0 + cp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt][ks], bh[u], acc[rt][ct0 + cp + u], 0, 0, 0);
+            }
+        }
+    };
+    issue(buf0, t_lo * G16_BC);
+    __syncthreads();
+    for (int t = t_lo; t < t_hi; t++) {
+        const int c0 = t * G16_BC;
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int ct = 0; ct < 8; ct++) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (the tile's squared norms are requested before the DMA: a wait for them then does not wait for the DMA)
+        float cn_c[8];
+#pragma unroll
+        for (int ct = 0; ct < 8; ct++) {
+            const float cf = (float)cn[c0 + ct * 16 + fr];
+            cn_c[ct] = cf < 3.0e38f ? cf : 3.0e38f;
+        }
+        // first half (columns c0 + fr + 16 ct, ct = 0..3) from buf0 while the second half lands in buf1
+        issue(buf1, c0 + HROWS);
+        // (the tile after this one: one word per 128-byte line, so that its DMA finds the lines in L2 -- after the scan
+        //  kernels the centroids are not there any more.  Issued as bare instructions: a volatile load would be followed
+        //  by s_waitcnt vmcnt(0), i.e. by a wait for the DMA just issued; the destination registers stay reserved until
+        //  the wait at the end of the tile)
+        unsigned touch_h = 0, touch_l = 0;
+#if G16_DMA_TOUCH
+        if (t + 1 < t_hi) {
+            const size_t nxt = (size_t)(c0 + G16_BC) * Dp + (size_t)tid * 64;  // 256 threads x 128 B = the 32 KiB of a tile
+            asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "=&v"(touch_h), "=&v"(touch_l) : "v"(Ch + nxt), "v"(Cl + nxt) : "memory");
+        }
+#endif
+        half_mma(buf0, 0);
+        __syncthreads();  // buf1 has landed (every wave waited for its own DMA), buf0 is free
+        if (t + 1 < t_hi) issue(buf0, c0 + G16_BC);
+        half_mma(buf1, 4);
+        // epilogue: as in K1e
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float m1 = __int_as_float(0x7f7ffff8), m2 = m1;
+#pragma unroll
+                for (int ct = 0; ct < 8; ct++) {
+                    const float tv = __builtin_fmaf(-2.0f, acc[rt][ct][r], cn_c[ct]);
+                    const float tp = __int_as_float((__float_as_int(tv) & ~7) | ct);
+                    m2 = __builtin_amdgcn_fmed3f(m1, m2, tp);
+                    m1 = __builtin_amdgcn_fmed3f(m1, tp, -3.0e38f);
+                }
+                const int a1 = __float_as_int(m1) & 7;
+                const float d1 = m1 + qn_r[rt][r];
+                float d2 = m2 + qn_r[rt][r];
+                d2 = d2 < 0.0f ? 0.0f : d2;
+                const float m2p = __int_as_float((__float_as_int(d2) & ~7) | a1);
+                const int q = q0 + rt * 16 + 4 * fg + r;
+                if (q < nq) gpair[(size_t)q * G + (size_t)t * 16 + fr] = make_float2(d1, m2p);
+            }
+        }
+#if G16_DMA_TOUCH
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(touch_h), "v"(touch_l) : "memory");  // (the touch loads have returned: their registers are free)
+#endif
+        __syncthreads();  // the next tile's first half has landed in buf0, buf1 is free
     }
 }
 

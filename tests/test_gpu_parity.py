@@ -545,7 +545,7 @@ def test_pass_a_histogram_kernel(mi, oracle, case):
     ix.close()
 
 
-@pytest.mark.parametrize("D,C,w", [(24, 1000, 7), (130, 700, 12), (128, 2049, 31), (260, 1536, 5), (64, 4100, 40), (16, 16390, 9)])
+@pytest.mark.parametrize("D,C,w", [(24, 1000, 7), (130, 700, 12), (128, 2049, 31), (260, 1536, 5), (64, 4100, 40), (16, 16390, 9), (100, 1000, 9), (128, 8192, 32), (128, 128, 3)])
 def test_coarse_stage_group_minima_shapes(mi, oracle, D, C, w):
     """K1e/K1f (bf16-split MFMA dot products + group minima) on shapes that exercise its padding: D not a multiple
     of 32, more than one 128-wide k chunk (D > 128), C not a multiple of 128, C / 8 groups per thread > 1; clustered
