@@ -566,6 +566,64 @@ __device__ __forceinline__ void coarse_select_finish(const ApproxSel &A, const i
         // coalesced loads; only their summation is order-sensitive and runs sequentially, one lane
         // per candidate, over the terms staged in LDS.
         double *terms = (double *)(sel_i + ((A.w + 2) & ~1));  // [CAND_CHUNK][D]
+        // the ordered sum of one chunk: lane c adds the D staged terms of candidate base + c, j ascending (between barriers)
+        auto sum_chunk = [&](const int base, const int nc_) {
+            __syncthreads();
+            if (tid < nc_) {
+                const double *tt = terms + (size_t)tid * (D + MMIDX_TERM_PAD);
+                double acc = 0.0;
+                int j = 0;
+                for (; j + 16 <= D; j += 16) {  // 16 LDS reads in flight, then the ordered adds
+                    double b[16];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) b[u] = tt[j + u];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) acc += b[u];
+                }
+                for (; j < D; j++) acc += tt[j];
+                ckey[base + tid] = dkey(acc);
+            }
+            __syncthreads();
+        };
+        const int hD0 = D >> 1;
+        constexpr int PUP = 6;  // candidate rows in flight per thread in the pipelined form
+        const bool pipelined = (D & 1) == 0 && (hD0 & (hD0 - 1)) == 0 && hD0 <= MMIDX_BLOCK && MMIDX_CAND_CHUNK <= PUP * (MMIDX_BLOCK / hD0);
+        if (pipelined) {
+            // D/2 a power of two and a whole chunk in one round of loads (D = 128: 4 candidates per 256 threads, 6 rounds):
+            // a thread owns ONE pair of coordinates (j, j + 1) -- no division per element, the query pair is loaded once --
+            // and the rows of the NEXT chunk are requested before the ordered sum of the current one, so that their
+            // latency (44 % of this kernel's L2 requests miss: 8 MB of fp64 centroids, 4 MB of L2 per XCD) runs under it.
+            const int sh = __ffs(hD0) - 1;
+            const int j = (tid & (hD0 - 1)) * 2;
+            const int ci0 = tid >> sh, cstep = MMIDX_BLOCK >> sh;
+            const double2 qj = *(const double2 *)(qv + j);
+            double2 cv[PUP];
+            auto request = [&](const int base) {
+                const int nc_ = (n - base < MMIDX_CAND_CHUNK) ? n - base : MMIDX_CAND_CHUNK;
+#pragma unroll
+                for (int u = 0; u < PUP; u++) {
+                    const int ci = ci0 + u * cstep;
+                    cv[u] = make_double2(0.0, 0.0);
+                    if (ci < nc_) cv[u] = *(const double2 *)(A.coarse + (size_t)cidx[base + ci] * (u32)D + j);
+                }
+            };
+            if (n > 0) request(0);
+            for (int base = 0; base < n; base += MMIDX_CAND_CHUNK) {
+                const int nc_ = (n - base < MMIDX_CAND_CHUNK) ? n - base : MMIDX_CAND_CHUNK;
+#pragma unroll
+                for (int u = 0; u < PUP; u++) {
+                    const int ci = ci0 + u * cstep;
+                    if (ci < nc_) {
+                        const double d0 = cv[u].x - qj.x, d1 = cv[u].y - qj.y;
+                        double *tt = terms + (size_t)ci * (D + MMIDX_TERM_PAD) + j;
+                        tt[0] = d0 * d0;
+                        tt[1] = d1 * d1;
+                    }
+                }
+                if (base + MMIDX_CAND_CHUNK < n) request(base + MMIDX_CAND_CHUNK);
+                sum_chunk(base, nc_);
+            }
+        } else
         for (int base = 0; base < n; base += MMIDX_CAND_CHUNK) {
             const int nc_ = (n - base < MMIDX_CAND_CHUNK) ? n - base : MMIDX_CAND_CHUNK;
             const int hD = D >> 1;
@@ -649,22 +707,7 @@ __device__ __forceinline__ void coarse_select_finish(const ApproxSel &A, const i
                     }
                 }
             }
-            __syncthreads();
-            if (tid < nc_) {
-                const double *tt = terms + (size_t)tid * (D + MMIDX_TERM_PAD);
-                double acc = 0.0;
-                int j = 0;
-                for (; j + 16 <= D; j += 16) {  // 16 LDS reads in flight, then the ordered adds
-                    double b[16];
-#pragma unroll
-                    for (int u = 0; u < 16; u++) b[u] = tt[j + u];
-#pragma unroll
-                    for (int u = 0; u < 16; u++) acc += b[u];
-                }
-                for (; j < D; j++) acc += tt[j];
-                ckey[base + tid] = dkey(acc);
-            }
-            __syncthreads();
+            sum_chunk(base, nc_);
         }
 #if MMIDX_SEL_STOP == 4
         if (tid == 0) A.cdsel[(size_t)q * w] = keyd(ckey[0]);
@@ -916,9 +959,6 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_approx(const Appr
 //   d~ = |c|^2 + |q|^2 - 2 S evaluated in fp32 from fp32 copies of the norms: 2^-21 (|c| + |q|)^2
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-#ifndef G16_DMA_TOUCH
-#define G16_DMA_TOUCH 1  // K1e': touch the next tile's lines one tile ahead
-#endif
 #define G16_BQ 128     // queries per block (32 per wave)
 #define G16_BC 128     // centroids per tile
 #define G16_KC 128     // k per LDS tile
@@ -1140,7 +1180,8 @@ __global__ __launch_bounds__(MMIDX_BLOCK, 2) void k_coarse_gmin16(const __bf16 *
 //   * the two buffers are two distinct __shared__ arrays and the loop is unrolled by two halves, so that the compiler can
 //     tell the buffer being filled from the one being read (it waits for ALL outstanding LDS-DMA before a ds_read it
 //     cannot disambiguate); the barrier that ends a half drains the DMA issued at its start;
-//   * groups, epilogue and output are those of K1e (a group = the 8 columns a lane holds over the two halves of a tile).
+//   * groups, epilogue and output are those of K1e (a group = the 8 columns a lane holds over the two halves of a tile);
+//   * no "touch" of the tile after next as in K1e: with the DMA half a tile ahead it measured slightly slower.
 __global__ __launch_bounds__(MMIDX_BLOCK, 2) void k_coarse_gmin16_dma(const __bf16 *__restrict__ Qh, const __bf16 *__restrict__ Ql,
                                                                    const __bf16 *__restrict__ Ch, const __bf16 *__restrict__ Cl,
                                                                    const double *__restrict__ cn, const double *__restrict__ qn,
@@ -1239,17 +1280,6 @@ __global__ __launch_bounds__(MMIDX_BLOCK, 2) void k_coarse_gmin16_dma(const __bf
         }
         // first half (columns c0 + fr + 16 ct, ct = 0..3) from buf0 while the second half lands in buf1
         issue(buf1, c0 + HROWS);
-        // (the tile after this one: one word per 128-byte line, so that its DMA finds the lines in L2 -- after the scan
-        //  kernels the centroids are not there any more.  Issued as bare instructions: a volatile load would be followed
-        //  by s_waitcnt vmcnt(0), i.e. by a wait for the DMA just issued; the destination registers stay reserved until
-        //  the wait at the end of the tile)
-        unsigned touch_h = 0, touch_l = 0;
-#if G16_DMA_TOUCH
-        if (t + 1 < t_hi) {
-            const size_t nxt = (size_t)(c0 + G16_BC) * Dp + (size_t)tid * 64;  // 256 threads x 128 B = the 32 KiB of a tile
-            asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "=&v"(touch_h), "=&v"(touch_l) : "v"(Ch + nxt), "v"(Cl + nxt) : "memory");
-        }
-#endif
         half_mma(buf0, 0);
         __syncthreads();  // buf1 has landed (every wave waited for its own DMA), buf0 is free
         if (t + 1 < t_hi) issue(buf0, c0 + G16_BC);
@@ -1276,9 +1306,6 @@ __global__ __launch_bounds__(MMIDX_BLOCK, 2) void k_coarse_gmin16_dma(const __bf
                 if (q < nq) gpair[(size_t)q * G + (size_t)t * 16 + fr] = make_float2(d1, m2p);
             }
         }
-#if G16_DMA_TOUCH
-        asm volatile("s_waitcnt vmcnt(0)" ::"v"(touch_h), "v"(touch_l) : "memory");  // (the touch loads have returned: their registers are free)
-#endif
         __syncthreads();  // the next tile's first half has landed in buf0, buf1 is free
     }
 }
