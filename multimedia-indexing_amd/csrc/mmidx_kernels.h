@@ -3260,10 +3260,21 @@ __global__ __launch_bounds__(NT) void k_merge(const MergeParams P) {
     if (m <= NT) {
         const bool have = tid < m;
         const u64 mk = have ? key[tid] : MMIDX_KEY_MAX, mv = have ? val[tid] : MMIDX_KEY_MAX;
-        int rank = 0;
+        // rank = entries that precede mine in (key, offer order).  Equal keys are rare, so the first pass reads and
+        // compares the keys only (one broadcast LDS read and half the VALU work per entry) and counts the equal ones
+        // (itself included); only a wave that saw a tie reads the offer orders as well.
+        int rank = 0, eqc = 0;
         for (int j = 0; j < m; j++) {
-            const u64 ok = key[j], ov = val[j];
-            rank += (ok < mk) || (ok == mk && ov < mv);
+            const u64 ok = key[j];
+            rank += ok < mk;
+            eqc += ok == mk;
+        }
+        if (__builtin_amdgcn_ballot_w64(have && eqc > 1)) {  // wave-uniform
+            rank = 0;
+            for (int j = 0; j < m; j++) {
+                const u64 ok = key[j], ov = val[j];
+                rank += (ok < mk) || (ok == mk && ov < mv);
+            }
         }
         __syncthreads();  // every entry has been read
         if (have) {
