@@ -720,11 +720,22 @@ __device__ __forceinline__ void coarse_select_finish(const ApproxSel &A, const i
                 const bool have = tid < n;
                 const u64 mk = have ? ckey[tid] : MMIDX_KEY_MAX;
                 const u32 mv = have ? cidx[tid] : 0xFFFFFFFFu;
-                int rank = 0;
+                // (equal distances are rare: the first pass compares the keys only and counts the equal ones, itself
+                //  included; the index / position tie-breaks are read only if some lane saw a tie)
+                int rank = 0, eqc = 0;
                 for (int j = 0; j < n; j++) {  // (entries past n would never precede a real one)
-                    const u32 olo = wave_read_u32((u32)mk, j), ohi = wave_read_u32((u32)(mk >> 32), j), ov = wave_read_u32(mv, j);
+                    const u32 olo = wave_read_u32((u32)mk, j), ohi = wave_read_u32((u32)(mk >> 32), j);
                     const u64 ok = ((u64)ohi << 32) | olo;
-                    rank += (ok < mk) || (ok == mk && (ov < mv || (ov == mv && j < tid)));
+                    rank += ok < mk;
+                    eqc += ok == mk;
+                }
+                if (__builtin_amdgcn_ballot_w64(have && eqc > 1)) {  // wave-uniform
+                    rank = 0;
+                    for (int j = 0; j < n; j++) {
+                        const u32 olo = wave_read_u32((u32)mk, j), ohi = wave_read_u32((u32)(mk >> 32), j), ov = wave_read_u32(mv, j);
+                        const u64 ok = ((u64)ohi << 32) | olo;
+                        rank += (ok < mk) || (ok == mk && (ov < mv || (ov == mv && j < tid)));
+                    }
                 }
                 // (every lane has read its entry before any lane writes: one wave, program order)
                 ckey[rank] = mk;
