@@ -201,6 +201,9 @@ struct mmidx_index {
     int Cp = 0, Dp = 0;          // C rounded up to 128, D rounded up to 32
     bool coarse_v1 = false;      // MMIDX_COARSE_V1=1: K1c/K1d (fp32 MFMA, full d~ matrix) instead
     bool coarse_nodma = false;   // option "coarse_nodma": K1e with register staging also when Dp == 128 (A/B switch)
+    bool no_item_compaction = false;  // option "no_item_compaction": a shard's pass A over every query (A/B switch)
+    int passa_item_min = 4096;        // option "passa_item_min": fewest queries per call for that compaction
+    int passa_item_margin = 1024;     // option "passa_item_margin": blocks launched beyond 1.15 x the expected count (tests: 0)
     double cn_max = 0.0, cnorm_max = 0.0;
     bool exact_coarse = false;  // MMIDX_EXACT_COARSE=1: fp64 distances to every centroid (K1a/K1b)
     bool cdsel_valid = false;   // ws_cdsel holds the selected cells' exact distances for the current batch
@@ -650,6 +653,9 @@ int launch_scan_hist(mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 gr
     const bool ok = h->code_bytes == 1 && (h->m == 8 || h->m == 16 || h->m == 32) && !P.sdc_tt && pl.K1 <= MMIDX_HKEEP &&
                     !P.order && !P.xcd_remap && pl.chunk <= (1 << 24);
     if (!ok) return 1;
+    // a shard (at most half of the lists live here): launch over the queries whose nearest list is non-empty only
+    const bool compact_items = P.ivf && P.nrank == 1 && P.rank_lo == 0 && grid.y == 1 && !h->no_item_compaction &&
+                               h->nonempty_lists * 2 <= (int64_t)h->C && (int64_t)grid.x >= (int64_t)h->passa_item_min;
     const size_t fixed = (size_t)h->m * h->ks * 8 + (h->transform ? 2 : 1) * (size_t)h->D * 8 + 64 + 16 + MMIDX_HB * 4 + 32;
     // position buffer: what is left of a quarter of the CU's LDS (4 blocks per CU), within [768, 1536] entries
     int64_t room = (int64_t)(160 * 1024 / 4) - 256 - (int64_t)fixed;
@@ -665,6 +671,21 @@ int launch_scan_hist(mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 gr
     P.fb_count = (u32 *)h->ws_fb.p;
     P.fb_items = h->ws_fb.p + 4;
     P.fb_ch = h->ws_fb.p + 4 + nfb;
+    if (compact_items) {
+        const long long nq_items = (long long)grid.x;
+        const double share = (double)h->nonempty_lists / (double)h->C;  // expected fraction of queries served here
+        long long gm = (long long)(1.15 * share * (double)nq_items) + h->passa_item_margin;
+        if (gm < 1) gm = 1;
+        if (gm > nq_items) gm = nq_items;
+        HIPCK(h->ws_order.reserve((size_t)nq_items * (size_t)P.w));  // (pass B's size: its reserve later must not reallocate under this launch)
+        int32_t *cnt = h->ws_fb.p + 1;  // (zeroed with the hand-back header)
+        hipLaunchKernelGGL(k_passa_items, dim3((unsigned)((nq_items + MMIDX_BLOCK - 1) / MMIDX_BLOCK)), dim3(MMIDX_BLOCK), 0, st, P.cells, P.w,
+                           P.list_off, nq_items, (int)gm, h->ws_order.p, cnt, P.fb_count, P.fb_items, P.fb_ch);
+        HIPCK(hipGetLastError());
+        P.order = h->ws_order.p;
+        P.n_order = cnt;
+        grid.x = (unsigned)gm;
+    }
     int rc;
     switch (h->m) {
         case 8: rc = launch_hist_t<8>(P, grid, lds, st); break;
@@ -1929,6 +1950,12 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->coarse_v1 = value != 0;
     } else if (n == "coarse_nodma") {
         h->coarse_nodma = value != 0;
+    } else if (n == "no_item_compaction") {
+        h->no_item_compaction = value != 0;
+    } else if (n == "passa_item_min") {
+        h->passa_item_min = value;
+    } else if (n == "passa_item_margin") {
+        h->passa_item_margin = value;
     } else if (n == "passa_hist") {
         h->passa_hist = value;
     } else if (n == "passa_prefix") {

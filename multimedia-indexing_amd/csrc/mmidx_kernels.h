@@ -2093,6 +2093,11 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
     u32 *posbuf = s_cnt + 8;                                             // [cap] list positions, one quarter per wave
 
     int item = blockIdx.x;
+    if (P.order) {  // (a shard's pass A: the queries whose nearest list is here, k_passa_items)
+        const int lim = *P.n_order < (int)gridDim.x ? *P.n_order : (int)gridDim.x;
+        if (item >= lim) return;
+        item = P.order[item];
+    }
     if (item >= P.n_items) return;
     const int q = item / P.nrank;
     const int pr = P.rank_lo + (item - q * P.nrank);
@@ -3125,6 +3130,38 @@ __global__ void k_step_init(u64 *__restrict__ T, u32 *__restrict__ pool_cnt, lon
     if (pcount && i < C) pcount[i] = 0;
     if (fb_header && i < 4) fb_header[i] = 0;
 }
+// Pass A on a shard: most queries' nearest cell lives on another rank, and a block per query that only finds an empty
+// list still costs its dispatch (0.1 ms per 114688 of them).  This lists the queries whose nearest list is non-empty
+// here -- order[0 .. count) -- so that K3h is launched over about nq / world blocks; the grid is sized for the expected
+// count plus a margin, and whatever does not fit is appended to K3h's hand-back list (the K3 launch behind it).
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_passa_items(const int32_t *__restrict__ cells, int w, const int64_t *__restrict__ list_off,
+                                                             long long nq, int grid_main, int32_t *__restrict__ order,
+                                                             int32_t *__restrict__ count, u32 *__restrict__ fb_count,
+                                                             int32_t *__restrict__ fb_items, int32_t *__restrict__ fb_ch) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool own = false;
+    if (q < nq) {
+        const int cell = cells[(size_t)q * w];
+        own = cell >= 0 && list_off[cell + 1] > list_off[cell];
+    }
+    const u64 mask = __builtin_amdgcn_ballot_w64(own);
+    if (!mask) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    u32 base = 0;
+    if (lane == leader) base = (u32)atomicAdd(count, (int)__popcll(mask));
+    base = wave_read_u32(base, leader);
+    if (own) {
+        const u32 slot = base + (u32)__popcll(mask & ((1ull << lane) - 1ull));
+        if (slot < (u32)grid_main) {
+            order[slot] = (int32_t)q;
+        } else {
+            const u32 f = atomicAdd(fb_count, 1u);
+            fb_items[f] = (int32_t)(q * w);  // (query, probe rank 0)
+            fb_ch[f] = 0;
+        }
+    }
+}
 // cdist_out[q][r] = dist[q][cells[q][r]] (exact coarse path: the selected cells' distances for other ranks)
 __global__ void k_gather_cdist(const double *__restrict__ dist, const int32_t *__restrict__ cells, double *__restrict__ out, int C, int w,
                                long long total) {
@@ -3403,12 +3440,39 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_merge_partials(int k, int nq, i
             filled += c;
             s++;
         }
-        const int Pn = pow2ceil(filled < 2 ? 2 : filled);
-        for (int i = filled + tid; i < Pn; i += MMIDX_BLOCK) {
-            key[i] = MMIDX_KEY_MAX;
-            val[i] = MMIDX_KEY_MAX;
+        if (kept == 0 && s == nshards && filled <= MMIDX_BLOCK) {
+            // the usual case (phase 2 drops everything above the global threshold: about k + 1 entries over all
+            // shards): one entry per thread, ordered by counting ranks as in K4 -- keys only unless a wave sees a tie
+            __syncthreads();
+            const bool have = tid < filled;
+            const u64 mk = have ? key[tid] : MMIDX_KEY_MAX, mv = have ? val[tid] : MMIDX_KEY_MAX;
+            int rank = 0, eqc = 0;
+            for (int j = 0; j < filled; j++) {
+                const u64 ok = key[j];
+                rank += ok < mk;
+                eqc += ok == mk;
+            }
+            if (__builtin_amdgcn_ballot_w64(have && eqc > 1)) {  // wave-uniform
+                rank = 0;
+                for (int j = 0; j < filled; j++) {
+                    const u64 ok = key[j], ov = val[j];
+                    rank += (ok < mk) || (ok == mk && ov < mv);
+                }
+            }
+            __syncthreads();  // every entry has been read
+            if (have) {
+                key[rank] = mk;
+                val[rank] = mv;
+            }
+            __syncthreads();
+        } else {
+            const int Pn = pow2ceil(filled < 2 ? 2 : filled);
+            for (int i = filled + tid; i < Pn; i += MMIDX_BLOCK) {
+                key[i] = MMIDX_KEY_MAX;
+                val[i] = MMIDX_KEY_MAX;
+            }
+            block_bitonic_sort<u64>(key, val, Pn);
         }
-        block_bitonic_sort<u64>(key, val, Pn);
         kept = filled < K1 ? filled : K1;
     }
     const int cnt = kept < k ? kept : k;

@@ -384,6 +384,63 @@ def test_virtual_shards_on_one_device(mi, oracle, S):
         ix.close()
 
 
+@pytest.mark.parametrize("margin", [0, 1024])
+def test_shard_pass_a_item_compaction(mi, oracle, margin):
+    """A shard's pass A runs over the queries whose nearest list it holds (k_passa_items), in a grid sized for the expected
+    share; with margin 0 and queries that crowd onto one shard most of them overflow that grid and must come back through
+    the hand-back list (the K3 launch behind K3h).  Three shards, long lists (K3h forced), results against the oracle."""
+    import torch
+
+    sh = importlib.import_module("multimedia-indexing_amd.sharded")
+    S, D, C, m, ks, n, w, k = 3, 32, 24, 16, 256, 30000, 5, 20
+    p = synth.make_ivfpq_problem(n=6000, D=D, C=C, m=m, ks=ks, nq=8, seed=77)
+    base, _ = synth.mixture(n, D, C, sigma=0.3, seed=3)
+    rng = np.random.default_rng(8)
+    ref = oracle_ivfpq(oracle, p, D, m, ks, C, w)
+    ref.add_vectors(base)
+    full = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    full.loadCoarseQuantizer(p["coarse"])
+    full.loadProductQuantizer(p["pq"])
+    full.setW(w)
+    cells, codes = full.encode(base)
+    # queries: 260 near vectors of shard 0's cells, 40 anywhere
+    own0 = np.nonzero(sh.owner_of_cell(cells, S) == 0)[0]
+    qsrc = np.concatenate([rng.choice(own0, 260), rng.choice(n, 40)])
+    Qn = base[qsrc] + 0.01 * rng.standard_normal((len(qsrc), D))
+    shards = []
+    for r in range(S):
+        ix = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+        ix.loadCoarseQuantizer(p["coarse"])
+        ix.loadProductQuantizer(p["pq"])
+        ix.setW(w)
+        own = np.nonzero(sh.owner_of_cell(cells, S) == r)[0]
+        ix.loadIndex(own.astype(np.int32), cells[own], codes[own])
+        ix.set_option("passa_hist", 1)
+        ix.set_option("passa_item_min", 1)
+        ix.set_option("passa_item_margin", margin)
+        shards.append(ix)
+    # the fixture must be tie-free (the codebook was learned on other data: equal codes -> equal distances): keep the
+    # queries whose k + 1 best distances are distinct
+    _, ed, _ = ref.search_batch(Qn, k + 1)
+    Qn = Qn[(np.diff(ed, axis=1) > 0).all(1)]
+    assert len(Qn) > 200
+    Q = torch.tensor(Qn, dtype=torch.float64, device="cuda")
+    engines = [sh.HipShardEngine(ix._h, D, w, 0) for ix in shards]
+    probe, pdist = engines[0].coarse(Q)
+    Ts = [e.pass_a(k, Q, probe) for e in engines]
+    Tmin = torch.stack(Ts).min(0).values.contiguous()
+    parts = [e.pass_b(k, Q, probe, pdist, Tmin) for e in engines]
+    iid, dd, cnt = engines[0].merge(k, torch.stack([x[0] for x in parts]), torch.stack([x[1] for x in parts]), torch.stack([x[2] for x in parts]))
+    torch.cuda.synchronize()
+    assert_same((iid.cpu().numpy(), dd.cpu().numpy(), cnt.cpu().numpy()), ref.search_batch(Qn, k))
+    # the overflow really happened with margin 0: more owned queries on shard 0 than blocks launched
+    own_q = sh.owner_of_cell(probe.cpu().numpy()[:, 0], S)
+    if margin == 0:
+        assert (own_q == 0).sum() > 1.15 * len(Qn) / 3 + 20
+    for ix in shards + [full]:
+        ix.close()
+
+
 def test_coarse_topw_massive_ties(mi, oracle):
     """FLAGGED tie fixture: almost all coarse centroids identical -> > 1024 exactly equal distances;
     exercises the overflow path of the fast top-w kernel and the queue's tie rule."""
