@@ -313,21 +313,44 @@ def main():
     # physical HBM bytes per launch: PMC FETCH_SIZE (x2 on gfx950) from the committed profile of this
     # exact workload; PMC collection cannot run inside the timed region, so the figure is per query
     traffic = None
+    traffic_passa = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
         wl = tj["workload"]
         if world == 1 and (wl["n"], wl["dim"], wl["cells"], wl["nprobe"], wl["m"], wl["k"]) == (N, D, Cc, w, m, k):
             traffic = tj["hbm_bytes_per_query"] * B / max(1, launches / max(1, args.steps))
+            traffic_passa = tj["k_scan_hist_fetch_kib_per_step"] * 1024.0 * 2.0 * B / wl["batch"]
     except Exception:
         traffic = None
-    roofline = {"bound": "hbm", "kernel": "scan launches: k_scan_hist (pass A) + k_scan_filt (pass B)", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 4), "frac_of_measured_copy_ceiling": round(achieved / 6290.0, 4), "traffic": traffic,
-                "note": "achieved = algorithmic bytes (m x probed codes) / scan-kernel time; exact pruning (coarse bound, "
-                        "Smin >= T) and L2 reuse make it exceed the physical HBM rate: see traffic and DESIGN.md section 7",
-                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(scan_ms, 4),
-                "bytes_per_query": alg_bytes / B, "scan_launches": int(st.scan_launches),
-                "coarse_ms_per_step": round(st.coarse_ms / max(1, args.steps), 4),
-                "merge_ms_per_step": round(st.merge_ms / max(1, args.steps), 4)}
+    # The dominant kernel is pass A (k_scan_hist: every query's nearest list, read and summed exactly: ~62 % of the step).
+    # Its algorithmic bytes are m x the codes of those lists -- no pruning is involved, so this is a plain HBM roofline
+    # fraction: the kernel is bound by the LDS gather and the VALU work around it, not by HBM.
+    pa_l = max(1, st.passa_launches)
+    pa_ms = st.passa_ms / pa_l
+    pa_bytes = float(m) * st.passa_codes / pa_l
+    pa_ach = pa_bytes / (pa_ms * 1e-3) / 1e9 if pa_ms > 0 else 0.0
+    if sharded is None and st.passa_launches > 0:
+        roofline = {"bound": "hbm", "kernel": "k_scan_hist (pass A: the exact scan of every query's nearest list; the launch also "
+                                               "carries its empty hand-back launch)",
+                    "achieved": round(pa_ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(pa_ach / 8000.0, 4),
+                    "frac_of_measured_copy_ceiling": round(pa_ach / 6290.0, 4), "traffic": traffic_passa,
+                    "algorithmic_bytes_per_launch": pa_bytes, "avg_launch_ms": round(pa_ms, 4), "launches": int(st.passa_launches),
+                    "note": "limited by the LDS gather (16 fp64 table entries per code, ~60 % of its LDS cycles are bank conflicts) "
+                            "and the VALU work around it (both pipes ~75 % busy, profiles/r01p_pmc_kernels.txt), not by HBM"}
+    else:
+        roofline = None
+    # the whole search in algorithmic bytes (every probed list counted, although the coarse bound and the lower-bound filter
+    # keep almost all of them from being read): how far exact pruning takes the path beyond what HBM could stream
+    whole = {"bound": "hbm", "kernel": "all scan launches: k_scan_hist (pass A) + k_scan_filt (pass B)", "achieved": round(achieved, 1),
+             "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+             "note": "achieved = algorithmic bytes (m x probed codes) / scan-kernel time; exact pruning (coarse bound, "
+                     "Smin >= T) and L2 reuse make it exceed the physical HBM rate: see traffic and DESIGN.md section 7",
+             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(scan_ms, 4),
+             "bytes_per_query": alg_bytes / B, "scan_launches": int(st.scan_launches),
+             "coarse_ms_per_step": round(st.coarse_ms / max(1, args.steps), 4),
+             "merge_ms_per_step": round(st.merge_ms / max(1, args.steps), 4)}
+    if roofline is None:
+        roofline = whole
 
     # ---------------------------------------------------------------- CPU baseline + parity gate
     cpu_baseline, parity = None, None
@@ -415,7 +438,8 @@ def main():
                        "sharding": "single GPU" if world == 1 else f"whole inverted lists, cell mod {world}; RCCL: all-gather probe cells, MIN all-reduce thresholds, "
                                                                       f"all-to-all partial top-k to the query's owner rank, merge there"},
             "recall_at_1": recall1, "recall_queries": ngt,
-            "roofline": roofline, "roofline_exhaustive": exhaustive, "cpu_baseline": cpu_baseline, "parity": parity,
+            "roofline": roofline, "roofline_whole_search": whole, "roofline_exhaustive": exhaustive,
+            "cpu_baseline": cpu_baseline, "parity": parity,
         }
         print(json.dumps(out), file=json_out, flush=True)
     chk(L.mmidx_destroy(h))

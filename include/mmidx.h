@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MMIDX_ABI_VERSION 2
+#define MMIDX_ABI_VERSION 3
 
 typedef struct mmidx_index mmidx_index; /* opaque handle: one index on one GPU */
 
@@ -228,6 +228,12 @@ typedef struct mmidx_stats {
     int64_t scan_codes;
     int32_t scan_launches;
     int32_t tie_fallbacks;
+    /* pass A alone (the dominant kernel: the exact scan of every query's nearest list): time between the events around
+     * its launches, the codes of the probe-rank-0 lists, the number of calls that ran it (ABI version 3) */
+    double passa_ms;
+    int64_t passa_codes;
+    int32_t passa_launches;
+    int32_t reserved_;
 } mmidx_stats;
 int mmidx_set_profiling(mmidx_index *h, int enabled);
 /* measurement switches; results are identical in every setting.  "exhaustive" = 1: every probed

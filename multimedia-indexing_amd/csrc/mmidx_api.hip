@@ -239,11 +239,13 @@ struct mmidx_index {
     // profiling: HIP events recorded on the launch stream, resolved lazily by mmidx_get_stats
     bool profiling = false;
     mmidx_stats stats{};
-    std::vector<hipEvent_t> evpool;  // groups of 5: start, coarse end, scan start, scan end, end
+    std::vector<hipEvent_t> evpool;  // groups of 6: start, coarse end, scan start, scan end, end, pass A end
     size_t ev_used = 0;
-    u64 *d_counters = nullptr;       // [0] scan codes, [1] tie fallbacks
+    u64 *d_counters = nullptr;       // [0] scan codes, [1] tie fallbacks, [2] codes of the probe-rank-0 lists (pass A)
     int64_t host_codes = 0;          // PQ: nq * n, known on the host
     int32_t launches = 0;
+    int32_t passa_launches = 0;
+    int64_t host_passa_codes = 0;
 };
 
 namespace {
@@ -868,16 +870,16 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
     bool prof = h->profiling;
     hipEvent_t *ev = nullptr;
     if (prof) {
-        if (h->ev_used + 5 > 5 * 4096) {
+        if (h->ev_used + 6 > 6 * 4096) {
             prof = false;  // event pool exhausted: call mmidx_get_stats to drain it
         } else {
-            while (h->evpool.size() < h->ev_used + 5) {
+            while (h->evpool.size() < h->ev_used + 6) {
                 hipEvent_t e;
                 HIPCK(hipEventCreate(&e));
                 h->evpool.push_back(e);
             }
             ev = h->evpool.data() + h->ev_used;
-            h->ev_used += 5;
+            h->ev_used += 6;
             HIPCK(hipEventRecord(ev[0], st));
         }
     }
@@ -945,7 +947,10 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
         if (!ivf) P.w = pl.nchunks;
         const long long npairs = (long long)nq * P.w;
         const bool two_pass = P.w > 1;
-        if (prof) HIPCK(hipEventRecord(ev[2], st));
+        if (prof) {
+            HIPCK(hipEventRecord(ev[2], st));
+            HIPCK(hipEventRecord(ev[5], st));  // (recorded again behind pass A when it runs)
+        }
         // pass A: probe rank 0 of every query (all of them for PQ) -- fixes a tight threshold
         P.order = nullptr;
         P.rank_lo = 0;
@@ -994,6 +999,11 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
             }
             if (rc) return rc;
             DBG_SYNC("pass A scan");
+            if (prof) {
+                HIPCK(hipEventRecord(ev[5], st));
+                h->passa_launches += 1;
+                if (!ivf) h->host_passa_codes += nq * std::min<int64_t>(h->n_csr, two_pass ? (int64_t)pl.chunk : h->n_csr);
+            }
         }
         if (phase == 1) {
             hipLaunchKernelGGL(k_T_export, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, h->ws_T.p, d_T_io, (long long)nq);
@@ -1083,6 +1093,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
     } else {
         if (prof) {
             HIPCK(hipEventRecord(ev[2], st));
+            HIPCK(hipEventRecord(ev[5], st));
             HIPCK(hipEventRecord(ev[3], st));
         }
         if (phase == 1) {
@@ -1150,7 +1161,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
         if (!ivf) h->host_codes += nq * h->n_csr;
         if (ivf || mode == 0) {
             const long long tot = (long long)nq * h->w;
-            hipLaunchKernelGGL(k_count_stats, dim3(256), dim3(256), 0, st, ivf ? d_cells : nullptr, h->d_off, tot,
+            hipLaunchKernelGGL(k_count_stats, dim3(256), dim3(256), 0, st, ivf ? d_cells : nullptr, h->d_off, tot, h->w,
                                mode == 0 ? h->ws_flag.p : nullptr, (long long)nq, h->d_counters);
         }
         HIPCK(hipGetLastError());
@@ -1241,7 +1252,7 @@ int mmidx_create(int kind, int D, int m, int ks, int C, int transform, const int
         delete h;
         return fail(MMIDX_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
     }
-    if (hipMalloc((void **)&h->d_counters, 2 * sizeof(u64)) != hipSuccess || hipMemset(h->d_counters, 0, 2 * sizeof(u64)) != hipSuccess) {
+    if (hipMalloc((void **)&h->d_counters, 4 * sizeof(u64)) != hipSuccess || hipMemset(h->d_counters, 0, 4 * sizeof(u64)) != hipSuccess) {
         delete h;
         return fail(MMIDX_ERR_HIP, "hipMalloc failed");
     }
@@ -1976,7 +1987,9 @@ int mmidx_set_profiling(mmidx_index *h, int enabled) {
     h->ev_used = 0;
     h->host_codes = 0;
     h->launches = 0;
-    HIPCK(hipMemset(h->d_counters, 0, 2 * sizeof(u64)));
+    h->passa_launches = 0;
+    h->host_passa_codes = 0;
+    HIPCK(hipMemset(h->d_counters, 0, 4 * sizeof(u64)));
     return MMIDX_OK;
 }
 
@@ -1989,28 +2002,32 @@ int mmidx_get_stats(mmidx_index *h, mmidx_stats *out) {
     mmidx_stats s{};
     if (h->ev_used) HIPCK(hipEventSynchronize(h->evpool[h->ev_used - 1]));
     HIPCK(hipDeviceSynchronize());
-    for (size_t g = 0; g + 5 <= h->ev_used; g += 5) {
+    for (size_t g = 0; g + 6 <= h->ev_used; g += 6) {
         hipEvent_t *ev = h->evpool.data() + g;
-        float a = 0, b = 0, c = 0, t = 0;
+        float a = 0, b = 0, c = 0, t = 0, pa = 0;
         HIPCK(hipEventElapsedTime(&a, ev[0], ev[1]));
         HIPCK(hipEventElapsedTime(&b, ev[2], ev[3]));
         HIPCK(hipEventElapsedTime(&c, ev[3], ev[4]));
         HIPCK(hipEventElapsedTime(&t, ev[0], ev[4]));
+        HIPCK(hipEventElapsedTime(&pa, ev[2], ev[5]));
         s.coarse_ms += a;
         s.scan_ms += b;
         s.merge_ms += c;
         s.total_ms += t;
+        s.passa_ms += pa;
     }
-    u64 cnt[2] = {0, 0};
+    u64 cnt[3] = {0, 0, 0};
     HIPCK(hipMemcpy(cnt, h->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));
     s.scan_codes = (int64_t)cnt[0] + h->host_codes;
     s.tie_fallbacks = (int32_t)cnt[1];
     s.scan_launches = h->launches;
+    s.passa_codes = (int64_t)cnt[2] + h->host_passa_codes;
+    s.passa_launches = h->passa_launches;
     *out = s;
     h->ev_used = 0;
     h->host_codes = 0;
     h->launches = 0;
-    HIPCK(hipMemset(h->d_counters, 0, 2 * sizeof(u64)));
+    HIPCK(hipMemset(h->d_counters, 0, 4 * sizeof(u64)));
     return MMIDX_OK;
 }
 

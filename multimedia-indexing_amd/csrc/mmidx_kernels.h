@@ -4084,10 +4084,10 @@ __global__ void k_unbias_codes(const signed char *in, unsigned char *out, long l
 // profiling counters in one launch: total[0] += sum of the probed lists' lengths (cells may be null: flat PQ counts on the
 // host), total[1] += number of flagged queries (flag may be null).  Eight independent loads per thread are in flight
 // before their dependent list_off loads: the kernel sits inside the timed region of bench.py.
-__global__ void k_count_stats(const int32_t *__restrict__ cells, const int64_t *__restrict__ list_off, long long n,
+__global__ void k_count_stats(const int32_t *__restrict__ cells, const int64_t *__restrict__ list_off, long long n, int w,
                               const int32_t *__restrict__ flag, long long nq, u64 *__restrict__ total) {
     const long long stride = (long long)gridDim.x * blockDim.x, t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    u64 v = 0, f = 0;
+    u64 v = 0, f = 0, v0 = 0;  // v0: the probe-rank-0 lists (what pass A scans)
     if (cells) {
         for (long long e0 = t0; e0 < n; e0 += 8 * stride) {
             int c[8];
@@ -4103,7 +4103,10 @@ __global__ void k_count_stats(const int32_t *__restrict__ cells, const int64_t *
                 b[u] = c[u] >= 0 ? list_off[c[u] + 1] : 0;
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) v += (u64)(b[u] - a[u]);
+            for (int u = 0; u < 8; u++) {
+                v += (u64)(b[u] - a[u]);
+                if ((e0 + u * stride) % w == 0) v0 += (u64)(b[u] - a[u]);
+            }
         }
     }
     if (flag)
@@ -4112,21 +4115,25 @@ __global__ void k_count_stats(const int32_t *__restrict__ cells, const int64_t *
     for (int off = 32; off > 0; off >>= 1) {
         v += __shfl_xor(v, off);
         f += __shfl_xor(f, off);
+        v0 += __shfl_xor(v0, off);
     }
-    __shared__ u64 s_v[16], s_f[16];  // one pair of atomics per block, not per wave (they all hit the same two words)
+    __shared__ u64 s_v[16], s_f[16], s_v0[16];  // one set of atomics per block, not per wave (they all hit the same words)
     const int wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     if ((threadIdx.x & 63) == 0) {
         s_v[wv] = v;
         s_f[wv] = f;
+        s_v0[wv] = v0;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int i = 1; i < nw; i++) {
             v += s_v[i];
             f += s_f[i];
+            v0 += s_v0[i];
         }
         if (v) atomicAdd(total, v);
         if (f) atomicAdd(total + 1, f);
+        if (v0) atomicAdd(total + 2, v0);
     }
 }
 
