@@ -606,7 +606,6 @@ int launch_filt_t(const mmidx_index *h, ScanParams P, dim3 grid, size_t lds, hip
         grid.x = (std::min(worst - g1, 2048u) + 7u) & ~7u;
         hipLaunchKernelGGL((k_scan_filt_tail<M>), grid, dim3(MMIDX_BLOCK), lds, st, P);
     }
-    if (P.order && h->pin_hint) HIPCK(hipMemcpyAsync(h->pin_hint, P.n_order, 4, hipMemcpyDeviceToHost, st));
     HIPCK(hipGetLastError());
     return MMIDX_OK;
 }
@@ -1065,7 +1064,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
             }
             hipLaunchKernelGGL(k_pair_hist, dim3(g), dim3(256), 0, st, d_cells, P.w, 1, npairs, h->ws_pcount.p, h->ws_keep.p, PB);
             DBG_SYNC("pair hist");
-            hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, h->C, h->ws_pstart.p, h->ws_pcursor.p);
+            hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, h->C, h->ws_pstart.p, h->ws_pcursor.p, h->pin_hint);
             DBG_SYNC("pair scan");
             hipLaunchKernelGGL(k_pair_scatter, dim3(g), dim3(256), 0, st, d_cells, P.w, 1, npairs, h->ws_pstart.p, h->ws_pcursor.p,
                                h->ws_order.p, h->ws_keep.p);

@@ -3183,8 +3183,10 @@ __global__ void k_pair_hist(const int32_t *__restrict__ cells, int w, int rank_l
     if (k) atomicAdd(cnt + (size_t)cu, 1);
 }
 // single block: exclusive scan of cnt[C] -> start[C]; start[C] = total; cursor zeroed
+// (host_hint: pinned host word that receives the total as well -- the next call sizes pass B's launch from it; written
+//  from here it needs no copy node in the stream)
 __global__ __launch_bounds__(1024) void k_pair_scan(const int32_t *__restrict__ cnt, int C, int32_t *__restrict__ start,
-                                                    int32_t *__restrict__ cursor) {
+                                                    int32_t *__restrict__ cursor, int32_t *host_hint) {
     __shared__ u32 s_wave[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int per = (C + 1023) / 1024;
@@ -3203,7 +3205,10 @@ __global__ __launch_bounds__(1024) void k_pair_scan(const int32_t *__restrict__ 
         cursor[c] = 0;
         run += (u32)cnt[c];
     }
-    if (tid == 1023) start[C] = (int32_t)(base + incl);
+    if (tid == 1023) {
+        start[C] = (int32_t)(base + incl);
+        if (host_hint) *host_hint = (int32_t)(base + incl);
+    }
 }
 __global__ void k_pair_scatter(const int32_t *__restrict__ cells, int w, int rank_lo, long long npairs,
                                const int32_t *__restrict__ start, int32_t *__restrict__ cursor,
