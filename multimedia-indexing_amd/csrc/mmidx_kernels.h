@@ -2068,6 +2068,9 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
 #define MMIDX_HB 256
 #define MMIDX_HKEEP 256  // most entries one item may emit (>= K1 required: the host checks; the pool has room for them)
 #define MMIDX_HPOS 4     // appended positions re-evaluated per thread per round at the end
+#ifndef MMIDX_K3H_PAIR
+#define MMIDX_K3H_PAIR 2  // K3h: 1 + this many segments per round of the scan loop (0 = the one-segment loop; 3 costs a block per CU)
+#endif
 #ifndef MMIDX_HREF_EARLY
 #define MMIDX_HREF_EARLY 16  // the threshold bucket is re-derived every segment at first ...
 #endif
@@ -2240,6 +2243,63 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
         const double x = (dd - lo) * inv;
         return (int)__builtin_fmax(__builtin_fmin(x, (double)(MMIDX_HB - 1)), 0.0);
     };
+#if MMIDX_K3H_PAIR
+    // U = MMIDX_K3H_PAIR + 1 segments per round: their table gathers are independent chains (U times the LDS requests in
+    // flight per wave) and the round's bookkeeping -- loop control, prefetch addresses, the threshold refresh -- is paid
+    // once.  Segment 0 (already summed into d) is candidate-tested first, on its own.
+    constexpr int U = MMIDX_K3H_PAIR + 1;
+    auto offer = [&](const double dd, const u32 pos) {
+        const int b = bucket_fast(dd);
+        const bool pass = (pos < n_seg) && b <= Tb;
+        const u64 mask = __builtin_amdgcn_ballot_w64(pass);
+        if (pass) {
+            atomicAdd(hist + b, 1u);
+            const u32 slot = wcnt + (u32)__popcll(mask & lane_lt);
+            if (slot < capw) mybuf[slot] = ((u32)b << 24) | pos;
+        }
+        wcnt += (u32)__popcll(mask);  // > capw: overflow, seen at the end
+    };
+    offer(d, (u32)tid);
+    CodeVec<M, unsigned char> cu[U], nx[U];
+    auto fetch = [&](CodeVec<M, unsigned char> &dst, const u32 i) {
+        const u32 ic = i < n_seg ? i : n_seg - 1u;
+        dst.load(codes0 + ic * (u32)M);  // (32-bit offset from a uniform base)
+    };
+    if (NT < n_seg) {
+#pragma unroll
+        for (int u = 0; u < U; u++) fetch(cu[u], (u32)(1 + u) * NT + (u32)tid);
+    }
+    u32 g = 1;
+    for (u32 seg = NT; seg < n_seg; seg += U * NT, g++) {
+        const bool more = seg + U * NT < n_seg;  // scalar
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < U; u++) fetch(nx[u], seg + (u32)(U + u) * NT + (u32)tid);
+        }
+        const bool refresh = MMIDX_HIST_STOP != 3 && (g < MMIDX_HREF_EARLY / U || (g & 1) == 0);
+        uint4 hv;  // live only on refresh rounds
+        if (refresh) hv = ((const uint4 *)hist)[lane];  // buckets 4*lane .. 4*lane+3
+        double dd[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) dd[u] = lut[cu[u].get(0)];
+#pragma unroll
+        for (int sq = 1; sq < M; sq++) {
+#pragma unroll
+            for (int u = 0; u < U; u++) dd[u] += lut[sq * ks + cu[u].get(sq)];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) offer(dd[u], seg + (u32)u * NT + (u32)tid);
+        if (refresh) {
+            u32 upto, total;
+            const int cand = threshold_bucket(hv, upto, total);
+            Tb = cand < Tb ? cand : Tb;
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < U; u++) cu[u] = nx[u];
+        }
+    }
+#else
     u32 g = 0;
     for (u32 seg = 0; seg < n_seg; seg += NT, g++) {
         const bool more = seg + NT < n_seg;  // scalar
@@ -2269,6 +2329,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
         }
         if (more) cur = nxt;
     }
+#endif
     if (lane == 0) s_cnt[wv] = wcnt;
     __syncthreads();
 #if MMIDX_HIST_STOP == 1 || MMIDX_HIST_STOP == 3
