@@ -235,6 +235,9 @@ typedef struct mmidx_stats {
     int32_t passa_launches;
     int32_t reserved_;
 } mmidx_stats;
+/* enabled: 0 off; 1 full (six events per search call and the code counters: every field below); 2 light (only the two
+ * events around pass A: passa_ms / passa_launches -- an event record is a ~5 us bubble in the stream, so a throughput
+ * run carries as few as its roofline figure needs) */
 int mmidx_set_profiling(mmidx_index *h, int enabled);
 /* measurement switches; results are identical in every setting.  "exhaustive" = 1: every probed
  * code is read and summed in fp64 (no lower-bound filter, no coarse-bound probe pruning) -- the

@@ -237,7 +237,7 @@ struct mmidx_index {
     DevBuf<long long> ws_dest;
 
     // profiling: HIP events recorded on the launch stream, resolved lazily by mmidx_get_stats
-    bool profiling = false;
+    int profiling = 0;  // 0 off, 1 full (six events per call + code counters), 2 light (the pass-A pair only)
     mmidx_stats stats{};
     std::vector<hipEvent_t> evpool;  // groups of 6: start, coarse end, scan start, scan end, end, pass A end
     size_t ev_used = 0;
@@ -866,11 +866,13 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
     // phase 0: whole search.  Sharded search splits it so that the thresholds can be MIN-reduced
     // across ranks in between: phase 1 = setup + pass A + export T, phase 2 = import T + pass B + merge.
     const int ivf = h->kind == MMIDX_KIND_IVFPQ;
-    bool prof = h->profiling;
+    // profiling 1: all six events + the code counters; 2 ("light"): only the two events around pass A -- every event
+    // record is a ~5 us bubble in the stream, and a throughput run should carry as few as the roofline figure needs
+    bool prof = h->profiling == 1, plight = h->profiling == 2;
     hipEvent_t *ev = nullptr;
-    if (prof) {
+    if (prof || plight) {
         if (h->ev_used + 6 > 6 * 4096) {
-            prof = false;  // event pool exhausted: call mmidx_get_stats to drain it
+            prof = plight = false;  // event pool exhausted: call mmidx_get_stats to drain it
         } else {
             while (h->evpool.size() < h->ev_used + 6) {
                 hipEvent_t e;
@@ -879,7 +881,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
             }
             ev = h->evpool.data() + h->ev_used;
             h->ev_used += 6;
-            HIPCK(hipEventRecord(ev[0], st));
+            if (prof) HIPCK(hipEventRecord(ev[0], st));
         }
     }
     const int32_t *d_cells = d_cells_in;
@@ -946,9 +948,9 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
         if (!ivf) P.w = pl.nchunks;
         const long long npairs = (long long)nq * P.w;
         const bool two_pass = P.w > 1;
-        if (prof) {
+        if (prof || plight) {
             HIPCK(hipEventRecord(ev[2], st));
-            HIPCK(hipEventRecord(ev[5], st));  // (recorded again behind pass A when it runs)
+            if (prof || phase == 2) HIPCK(hipEventRecord(ev[5], st));  // (recorded again behind pass A when it runs)
         }
         // pass A: probe rank 0 of every query (all of them for PQ) -- fixes a tight threshold
         P.order = nullptr;
@@ -998,7 +1000,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
             }
             if (rc) return rc;
             DBG_SYNC("pass A scan");
-            if (prof) {
+            if (prof || plight) {
                 HIPCK(hipEventRecord(ev[5], st));
                 h->passa_launches += 1;
                 if (!ivf) h->host_passa_codes += nq * std::min<int64_t>(h->n_csr, two_pass ? (int64_t)pl.chunk : h->n_csr);
@@ -1090,6 +1092,10 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
         if (prof) HIPCK(hipEventRecord(ev[3], st));
         if (prof) h->launches += (two_pass ? 1 : 0) + (phase != 2 ? 1 : 0);
     } else {
+        if (plight) {
+            HIPCK(hipEventRecord(ev[2], st));
+            HIPCK(hipEventRecord(ev[5], st));
+        }
         if (prof) {
             HIPCK(hipEventRecord(ev[2], st));
             HIPCK(hipEventRecord(ev[5], st));
@@ -1981,7 +1987,7 @@ int mmidx_set_profiling(mmidx_index *h, int enabled) {
     int rc = set_device(h);
     if (rc) return rc;
     HIPCK(hipDeviceSynchronize());
-    h->profiling = enabled != 0;
+    h->profiling = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
     h->stats = mmidx_stats{};
     h->ev_used = 0;
     h->host_codes = 0;
@@ -2004,6 +2010,11 @@ int mmidx_get_stats(mmidx_index *h, mmidx_stats *out) {
     for (size_t g = 0; g + 6 <= h->ev_used; g += 6) {
         hipEvent_t *ev = h->evpool.data() + g;
         float a = 0, b = 0, c = 0, t = 0, pa = 0;
+        if (h->profiling == 2) {  // light: only the pass-A pair was recorded
+            HIPCK(hipEventElapsedTime(&pa, ev[2], ev[5]));
+            s.passa_ms += pa;
+            continue;
+        }
         HIPCK(hipEventElapsedTime(&a, ev[0], ev[1]));
         HIPCK(hipEventElapsedTime(&b, ev[2], ev[3]));
         HIPCK(hipEventElapsedTime(&c, ev[3], ev[4]));
