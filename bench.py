@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--gt", type=int, default=1024, help="queries with exact ground truth (recall@1)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--sigma", type=float, default=0.15, help="mixture noise (0.15 = SURVEY 8d's generator)")
+    ap.add_argument("--settle", type=int, default=24)
     ap.add_argument("--exhaustive-steps", type=int, default=3,
                     help="extra untimed-for-value steps with pruning off, reported as roofline_exhaustive (0 = skip)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
@@ -128,7 +130,7 @@ def main():
     mu = torch.randn(Cc, D, generator=g0, device=dev, dtype=f64)
     ns = min(N, 1 << 20)
     gs = torch.randint(0, Cc, (ns,), generator=g0, device=dev)
-    Xs = mu[gs] + 0.15 * torch.randn(ns, D, generator=g0, device=dev, dtype=f64)
+    Xs = mu[gs] + args.sigma * torch.randn(ns, D, generator=g0, device=dev, dtype=f64)
     torch.cuda.synchronize()
     # coarse quantizer: Lloyd from the mixture means (2 iterations); residual PQ codebooks: k-means++ per sub-space on
     # centroid - vector (ResidualVectorComputation.java:34)
@@ -181,7 +183,7 @@ def main():
         gc.manual_seed(10_000 + c0 // args.chunk)
         g = torch.randint(0, Cc, (n,), generator=gc, device=dev)
         X = mu[g]
-        X += 0.15 * torch.randn(n, D, generator=gc, device=dev, dtype=f64)
+        X += args.sigma * torch.randn(n, D, generator=gc, device=dev, dtype=f64)
         sel = (qsrc >= c0) & (qsrc < c0 + n)
         if sel.any():
             Qsrc[sel] = X[qsrc[sel] - c0]
@@ -220,7 +222,7 @@ def main():
             gc.manual_seed(10_000 + c0 // args.chunk)
             g = torch.randint(0, Cc, (n,), generator=gc, device=dev)
             X = mu[g]
-            X += 0.15 * torch.randn(n, D, generator=gc, device=dev, dtype=f64)
+            X += args.sigma * torch.randn(n, D, generator=gc, device=dev, dtype=f64)
             dm = (X * X).sum(1)[None, :] - 2.0 * (Qg @ X.T) + qn[:, None]
             bv, bi = dm.min(1)
             upd = bv < gt_best
@@ -256,7 +258,7 @@ def main():
 
     # settle the device before the W warm-up steps the caller asked for (clocks, caches, the pass-B launch hint): with a
     # small W the first timed steps otherwise run ~10 % slower than the steady state
-    for i in range(24):
+    for i in range(args.settle):
         step(Qb[i % args.nbatches])
     barrier()
     for i in range(args.warmup):
@@ -452,7 +454,7 @@ def main():
                        "n": N, "dim": D, "cells": Cc, "nprobe": w, "m": m, "ks": ks, "k": k, "batch": B, "batch_per_gpu": B // world,
                        "sharding": "single GPU" if world == 1 else f"whole inverted lists, cell mod {world}; RCCL: all-gather probe cells, MIN all-reduce thresholds, "
                                                                       f"all-to-all partial top-k to the query's owner rank, merge there"},
-            "recall_at_1": recall1, "recall_queries": ngt,
+            "recall_at_1": recall1, "recall_queries": ngt, "sigma": args.sigma, "passb_items_last": int(st.passb_items_last),
             "roofline": roofline, "roofline_whole_search": whole, "roofline_exhaustive": exhaustive,
             "cpu_baseline": cpu_baseline, "parity": parity,
         }

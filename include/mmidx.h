@@ -233,7 +233,9 @@ typedef struct mmidx_stats {
     double passa_ms;
     int64_t passa_codes;
     int32_t passa_launches;
-    int32_t reserved_;
+    /* (query, probe) pairs of the most recent search call that survived the coarse bound and went through pass B
+     * (-1: unknown); read from the pinned word the device writes for the launch-size hint */
+    int32_t passb_items_last;
 } mmidx_stats;
 /* enabled: 0 off; 1 full (six events per search call and the code counters: every field below); 2 light (only the two
  * events around pass A: passa_ms / passa_launches -- an event record is a ~5 us bubble in the stream, so a throughput

@@ -12,6 +12,7 @@
 //   pending  (cells, ids, codes) of records added since the last CSR build
 #include "../../include/mmidx.h"
 #include "mmidx_kernels.h"
+#include "mmidx_scan_grp.h"
 #include "mmidx_frontend.h"
 
 #include <algorithm>
@@ -185,6 +186,13 @@ struct mmidx_index {
     bool no_seed = true;        // MMIDX_SEED=1: pass A with the seeded scan K3s (measured slower than K3: 1.45 vs 1.22 ms
                                 // per 8192 queries -- one block per query is latency-bound, not LDS-bound; kept for study)
     double rmax = 0.0;       // sqrt(sum_s max_j ||pq[s][j]||^2) * (1 + 1e-12)
+    // K3g (grouped pass B, mmidx_scan_grp.h): index-side fp32 table CPN[C][m][256] and the codebook norm maxima
+    float *d_cpn = nullptr;
+    double *d_pnmax = nullptr;
+    bool grp_valid = false;  // tables match the current quantizers
+    int no_grp = 0;          // option "no_grp" = 1: pass B through K3f only (A/B switch)
+    int grp_blocks = 0;      // option "grp_blocks": persistent blocks of K3g (0 = occupancy x CUs)
+    int num_cus = 0;
     hipStream_t stream = nullptr;
     std::mutex mu;
     std::mutex search_mu;  // host-pointer searches share the handle's workspaces and stream: one at a time
@@ -235,6 +243,9 @@ struct mmidx_index {
     DevBuf<int32_t> ws_aidx, ws_acell;
     int64_t last_ambiguous = 0;  // vectors of the last encode call that needed the exact redo
     DevBuf<long long> ws_dest;
+    DevBuf<float> ws_qp2;
+    DevBuf<int4> ws_gdesc;
+    DevBuf<int32_t> ws_gfb;
 
     // profiling: HIP events recorded on the launch stream, resolved lazily by mmidx_get_stats
     int profiling = 0;  // 0 off, 1 full (six events per call + code counters), 2 light (the pass-A pair only)
@@ -357,6 +368,11 @@ int build_csr(mmidx_index *h) {
         h->d_pcodes = nullptr;
         h->cap_pend = 0;
         h->ws_dest.release();
+    h->ws_qp2.release();
+    h->ws_gdesc.release();
+    h->ws_gfb.release();
+    if (h->d_cpn) (void)hipFree(h->d_cpn);
+    if (h->d_pnmax) (void)hipFree(h->d_pnmax);
     }
     h->max_list_len = 0;
     h->nonempty_lists = 0;
@@ -538,7 +554,7 @@ int launch_scan(const mmidx_index *h, const ScanParams &P, dim3 grid, size_t lds
 
 struct SearchPlan;
 int launch_scan_seeded(const mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 grid, hipStream_t st);
-int launch_scan_filtered(const mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 grid, hipStream_t st);
+int launch_scan_filtered(const mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 grid, hipStream_t st, int main_grid = 0);
 
 struct SearchPlan {
     int K1, cap, chunk, nchunks, nitems, poolq;
@@ -584,7 +600,7 @@ int make_plan(mmidx_index *h, int k, int64_t nq, SearchPlan &pl, bool need_coars
 }
 
 template <int M>
-int launch_filt_t(const mmidx_index *h, ScanParams P, dim3 grid, size_t lds, hipStream_t st) {
+int launch_filt_t(const mmidx_index *h, ScanParams P, dim3 grid, size_t lds, hipStream_t st, int main_grid = 0) {
     HIPCK(hipFuncSetAttribute((const void *)k_scan_filt<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned worst = grid.x;
     P.vgrid = worst;
@@ -595,7 +611,8 @@ int launch_filt_t(const mmidx_index *h, ScanParams P, dim3 grid, size_t lds, hip
         // pinned memory: a hint, possibly stale), let a small grid of looping blocks cover the rest
         const int32_t seen = h->pin_hint ? *(volatile int32_t *)h->pin_hint : -1;
         const unsigned hint = seen >= 0 ? (unsigned)seen : worst;
-        const unsigned want = h->passb_main_grid > 0 ? (unsigned)h->passb_main_grid : 2u * hint + 2048u;
+        const unsigned want = main_grid > 0 ? (unsigned)main_grid
+                                            : (h->passb_main_grid > 0 ? (unsigned)h->passb_main_grid : 2u * hint + 2048u);
         g1 = std::min(worst, (want + 7u) & ~7u);
     }
     grid.x = g1;
@@ -611,7 +628,7 @@ int launch_filt_t(const mmidx_index *h, ScanParams P, dim3 grid, size_t lds, hip
 }
 
 // pass B: lower-bound filtered scan where it applies (byte codes, templated m), else the exact scan
-int launch_scan_filtered(const mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 grid, hipStream_t st) {
+int launch_scan_filtered(const mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 grid, hipStream_t st, int main_grid) {
     const bool ok = h->code_bytes == 1 && h->ks <= 256 && (h->m == 8 || h->m == 16 || h->m == 32) && !h->no_filter && !P.sdc_tt;
     if (!ok) return launch_scan(h, P, grid, pl.lds, st);
     int cap = 1;
@@ -621,9 +638,9 @@ int launch_scan_filtered(const mmidx_index *h, ScanParams P, const SearchPlan &p
                        (size_t)MMIDX_SURV_CAP * 4 + 16 + (size_t)h->m * 256;
     if (lds > 160 * 1024) return launch_scan(h, P, grid, pl.lds, st);
     switch (h->m) {
-        case 8: return launch_filt_t<8>(h, P, grid, lds, st);
-        case 16: return launch_filt_t<16>(h, P, grid, lds, st);
-        default: return launch_filt_t<32>(h, P, grid, lds, st);
+        case 8: return launch_filt_t<8>(h, P, grid, lds, st, main_grid);
+        case 16: return launch_filt_t<16>(h, P, grid, lds, st, main_grid);
+        default: return launch_filt_t<32>(h, P, grid, lds, st, main_grid);
     }
 }
 
@@ -728,6 +745,113 @@ int launch_scan_seeded(const mmidx_index *h, ScanParams P, const SearchPlan &pl,
         case 16: return launch_seed_t<16>(P, grid, lds, st);
         default: return launch_seed_t<32>(P, grid, lds, st);
     }
+}
+
+// MMIDX_DEBUG_SYNC=1: synchronise after every stage and report the first failing one
+#define DBG_SYNC(name)                                                                        \
+    do {                                                                                      \
+        if (h->debug_sync) {                                                                  \
+            hipError_t e__ = hipStreamSynchronize(st);                                        \
+            fprintf(stderr, "[mmidx] %s: %s\n", name, hipGetErrorString(e__));               \
+            if (e__ != hipSuccess) return fail(MMIDX_ERR_HIP, "%s failed: %s", name, hipGetErrorString(e__)); \
+        }                                                                                     \
+    } while (0)
+
+// ---- K3g (mmidx_scan_grp.h): grouped, list-major pass B -------------------------------------------------------
+// index-side tables: built once per (coarse, product) quantizer pair, on the handle's stream, synchronously
+int build_grp_tables(mmidx_index *h) {
+    if (h->grp_valid) return MMIDX_OK;
+    const bool shape_ok = h->kind == MMIDX_KIND_IVFPQ && h->code_bytes == 1 && h->ks <= 256 && (h->m == 8 || h->m == 16 || h->m == 32) &&
+                          h->transform != MMIDX_TR_ROTATION && (size_t)h->C * h->m * 256 * sizeof(float) <= ((size_t)8 << 30);
+    if (!shape_ok || !h->coarse_set || !h->pq_set) return MMIDX_OK;
+    if (h->d_cpn) (void)hipFree(h->d_cpn);
+    h->d_cpn = nullptr;
+    HIPCK(hipMalloc((void **)&h->d_cpn, (size_t)h->C * h->m * 256 * sizeof(float)));
+    if (!h->d_pnmax) HIPCK(hipMalloc((void **)&h->d_pnmax, 2 * (size_t)h->m * sizeof(double)));
+    hipLaunchKernelGGL(k_cpn_table, dim3((unsigned)h->C), dim3(256), (size_t)h->D * 8, h->stream, h->d_coarse, h->d_pqT, h->d_perm, h->d_cpn,
+                       h->D, h->m, h->ks, h->dsub);
+    hipLaunchKernelGGL(k_pn_max, dim3((unsigned)h->m), dim3(256), 0, h->stream, h->d_pqT, h->d_pnmax, h->m, h->ks, h->dsub);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(h->stream));
+    h->grp_valid = true;
+    return MMIDX_OK;
+}
+
+template <int M, int G>
+int launch_grp_t(mmidx_index *h, const GrpParams &GP, size_t lds, hipStream_t st) {
+    HIPCK(hipFuncSetAttribute((const void *)k_scan_grp<M, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int blocks = h->grp_blocks;
+    if (blocks <= 0) {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_scan_grp<M, G>, GRP_NT, lds) != hipSuccess || occ < 1) {
+            (void)hipGetLastError();
+            occ = 1;
+        }
+        blocks = occ * std::max(h->num_cus, 8);
+    }
+    blocks = std::max(8, (blocks + 7) & ~7);
+    hipLaunchKernelGGL((k_scan_grp<M, G>), dim3((unsigned)blocks), dim3(GRP_NT), lds, st, GP);
+    HIPCK(hipGetLastError());
+    return MMIDX_OK;
+}
+
+// pass B over the sorted pairs (P.order / P.n_order as for K3f; per-cell counts and starts in ws_pcount / ws_pstart).
+// Returns 1 when K3g does not apply (the caller uses K3f).
+int launch_scan_grouped(mmidx_index *h, const ScanParams &P, const SearchPlan &pl, long long nq, long long npairs, hipStream_t st) {
+    if (h->no_grp || !h->grp_valid || !h->d_cpn || h->no_filter || P.sdc_tt || !P.ivf || h->max_list_len >= (1 << 24)) return 1;
+    const int G = h->m == 32 ? 4 : 8;
+    int cb = 1;
+    while (cb < pl.K1 + GRP_VR) cb <<= 1;
+    const GrpLds L(h->m, G, h->D, cb);
+    if (L.total > 160 * 1024 || pl.K1 + GRP_VR > GRP_NT) return 1;
+    const size_t nfb = (size_t)npairs * (size_t)pl.nchunks;
+    HIPCK(h->ws_qp2.reserve((size_t)nq * h->m * 256));
+    HIPCK(h->ws_gdesc.reserve((size_t)npairs / G + (size_t)h->C + 8));
+    HIPCK(h->ws_gfb.reserve(4 + 2 * nfb + 16));
+    if (h->debug_sync) HIPCK(hipMemsetAsync(h->ws_gfb.p, 0, (4 + 2 * nfb + 16) * sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_qp_table, dim3((unsigned)((nq + GRP_QT - 1) / GRP_QT)), dim3(256), (size_t)GRP_QT * h->D * 8, st, P.Q, h->d_pqT,
+                       h->d_perm, h->ws_qp2.p, h->D, h->m, h->ks, h->dsub, nq);
+    DBG_SYNC("K3g qp table");
+    hipLaunchKernelGGL(k_group_build, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, h->ws_pstart.p, h->C, G, h->ws_gdesc.p, h->ws_gfb.p,
+                       (u32 *)(h->ws_gfb.p + 1));
+    HIPCK(hipGetLastError());
+    DBG_SYNC("K3g group build");
+    GrpParams GP{};
+    GP.S = P;
+    GP.pq = h->d_pq;
+    GP.cpn = h->d_cpn;
+    GP.qp2 = h->ws_qp2.p;
+    GP.pnmax = h->d_pnmax;
+    GP.gdesc = h->ws_gdesc.p;
+    GP.n_groups = h->ws_gfb.p;
+    GP.nchunks = pl.nchunks;
+    GP.fb_count = (u32 *)(h->ws_gfb.p + 1);
+    GP.fb_items = h->ws_gfb.p + 4;
+    GP.fb_ch = h->ws_gfb.p + 4 + nfb;
+    GP.cb = cb;
+    int rc;
+    switch (h->m) {
+        case 8: rc = launch_grp_t<8, 8>(h, GP, L.total, st); break;
+        case 16: rc = launch_grp_t<16, 8>(h, GP, L.total, st); break;
+        default: rc = launch_grp_t<32, 4>(h, GP, L.total, st); break;
+    }
+    if (rc) return rc;
+    DBG_SYNC("K3g scan");
+    if (h->debug_sync) {
+        int32_t c4[2];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(c4, h->ws_gfb.p, sizeof(c4), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[mmidx] K3g: %d groups of <= %d pairs, %d (pair, chunk) items handed back to K3f (lds %zu, cb %d)\n", c4[0], G, c4[1],
+                L.total, cb);
+    }
+    // the handed-back items (device-side count; normally few): a small main grid, the looping tail covers the rest
+    ScanParams F = P;
+    F.order = GP.fb_items;
+    F.n_order = (const int32_t *)GP.fb_count;
+    F.order_ch = GP.fb_ch;
+    F.n_items = (int)std::min<size_t>(nfb, (size_t)0x7fffff00);
+    F.xcd_remap = 0;
+    return launch_scan_filtered(h, F, pl, dim3((unsigned)F.n_items, 1), st, 1024);
 }
 
 int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, hipStream_t st) {
@@ -849,15 +973,6 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
     return MMIDX_OK;
 }
 
-// MMIDX_DEBUG_SYNC=1: synchronise after every stage and report the first failing one
-#define DBG_SYNC(name)                                                                        \
-    do {                                                                                      \
-        if (h->debug_sync) {                                                                  \
-            hipError_t e__ = hipStreamSynchronize(st);                                        \
-            fprintf(stderr, "[mmidx] %s: %s\n", name, hipGetErrorString(e__));               \
-            if (e__ != hipSuccess) return fail(MMIDX_ERR_HIP, "%s failed: %s", name, hipGetErrorString(e__)); \
-        }                                                                                     \
-    } while (0)
 
 // one sub-batch (nq <= plan.qb) entirely on device
 int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq, const double *dQ, const int32_t *d_cells_in,
@@ -1084,8 +1199,11 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
             P.n_order = h->ws_pstart.p + h->C;
             P.n_items = (int)(nq * (P.w - 1));
             P.xcd_remap = 1;
-            const unsigned gx = (unsigned)(((P.n_items + 7) / 8) * 8);
-            rc = launch_scan_filtered(h, P, pl, dim3(gx, (unsigned)pl.nchunks), st);
+            rc = launch_scan_grouped(h, P, pl, (long long)nq, npairs, st);
+            if (rc == 1) {
+                const unsigned gx = (unsigned)(((P.n_items + 7) / 8) * 8);
+                rc = launch_scan_filtered(h, P, pl, dim3(gx, (unsigned)pl.nchunks), st);
+            }
             if (rc) return rc;
             DBG_SYNC("pass B scan");
         }
@@ -1189,6 +1307,8 @@ int search_common(mmidx_index *h, int k, int64_t nq, const double *dQ, const int
         std::lock_guard<std::mutex> lk(h->mu);
         rc = build_csr(h);
         if (rc) return rc;
+        rc = build_grp_tables(h);
+        if (rc) return rc;
     }
     SearchPlan pl;
     rc = make_plan(h, k, nq, pl, d_cells == nullptr);
@@ -1246,6 +1366,11 @@ int mmidx_create(int kind, int D, int m, int ks, int C, int transform, const int
     h->device = device;
     h->nlists = kind == MMIDX_KIND_IVFPQ ? C : 1;
     h->code_bytes = ks <= 256 ? 1 : 2;
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) (void)hipGetLastError();
+        h->num_cus = ncu > 0 ? ncu : 256;
+    }
     if (hipHostMalloc((void **)&h->pin_hint, 64) == hipSuccess) {
         *h->pin_hint = 0;
     } else {
@@ -1359,6 +1484,11 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_aidx.release();
     h->ws_acell.release();
     h->ws_dest.release();
+    h->ws_qp2.release();
+    h->ws_gdesc.release();
+    h->ws_gfb.release();
+    if (h->d_cpn) (void)hipFree(h->d_cpn);
+    if (h->d_pnmax) (void)hipFree(h->d_pnmax);
     for (auto &ev : h->evpool)
         if (ev) (void)hipEventDestroy(ev);
     if (h->d_counters) (void)hipFree(h->d_counters);
@@ -1427,6 +1557,7 @@ int mmidx_set_coarse(mmidx_index *h, const double *coarse) {
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(h->stream));
     h->coarse_set = true;
+    h->grp_valid = false;
     return MMIDX_OK;
 }
 
@@ -1459,6 +1590,7 @@ int mmidx_set_pq(mmidx_index *h, const double *pq) {
     }
     h->rmax = std::sqrt(r2) * (1.0 + 1e-12);
     h->pq_set = true;
+    h->grp_valid = false;
     return MMIDX_OK;
 }
 
@@ -1878,6 +2010,8 @@ static int shard_phase(mmidx_index *h, int k, int64_t nq, const double *dQ, cons
         std::lock_guard<std::mutex> lk(h->mu);
         rc = build_csr(h);
         if (rc) return rc;
+        rc = build_grp_tables(h);
+        if (rc) return rc;
     }
     SearchPlan pl;
     rc = make_plan(h, k, nq, pl, false);
@@ -1974,6 +2108,10 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->passa_item_margin = value;
     } else if (n == "passa_hist") {
         h->passa_hist = value;
+    } else if (n == "no_grp") {  // pass B through K3f (one block per (query, list)) instead of the grouped K3g
+        h->no_grp = value != 0;
+    } else if (n == "grp_blocks") {
+        h->grp_blocks = value > 0 ? value : 0;
     } else if (n == "passa_prefix") {
         h->passa_prefix = value > 0 ? value : 0;
     } else {
@@ -2033,10 +2171,13 @@ int mmidx_get_stats(mmidx_index *h, mmidx_stats *out) {
     s.scan_launches = h->launches;
     s.passa_codes = (int64_t)cnt[2] + h->host_passa_codes;
     s.passa_launches = h->passa_launches;
+    s.passb_items_last = h->pin_hint ? *(volatile int32_t *)h->pin_hint : -1;
     *out = s;
     h->ev_used = 0;
     h->host_codes = 0;
     h->launches = 0;
+    h->passa_launches = 0;
+    h->host_passa_codes = 0;
     HIPCK(hipMemset(h->d_counters, 0, 4 * sizeof(u64)));
     return MMIDX_OK;
 }

@@ -2544,7 +2544,8 @@ __device__ __forceinline__ void scan_filt_body(const ScanParams &P, const unsign
         q = item / P.nrank;
         pr = P.rank_lo + (item - q * P.nrank);
     }
-    const int ch = P.ivf ? (int)blockIdx.y : pr;  // flat PQ: the item rank is the chunk of the single list
+    // flat PQ: the item rank is the chunk of the single list; order_ch: (pair, chunk) items handed back by K3g
+    const int ch = (P.order && P.order_ch) ? P.order_ch[item] : (P.ivf ? (int)blockIdx.y : pr);
     int cell = 0;
     if (P.ivf) {
         cell = P.cells[(size_t)q * P.w + pr];

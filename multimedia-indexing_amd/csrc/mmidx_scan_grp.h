@@ -1,0 +1,595 @@
+// mmidx_scan_grp.h -- K3g: pass B of the IVFADC search as a list-major, multi-query filtered scan (gfx950).
+//
+// Reference loop: the per-probe body of computeKnnIVFADC, J/datastructures/IVFPQ.java:414-447 (residual :417,
+// lookup table :427 -> :525-538, scan :429-446).  Results are those of K3 / K3f bit for bit; what changes is who
+// shares what:
+//   * a block takes ONE inverted list (or one chunk of it) and a GROUP of up to G queries that probe it (the pairs of
+//     pass B are already sorted by cell).  A code is loaded once, its m bytes are split into (8-byte slot, byte
+//     selector) once, and every query of the group pays only one conflict-free ds_read_b64 + v_perm + v_add per
+//     sub-quantizer (K3f: one block per (query, list), 5 VALU per lookup).
+//   * the quantised lower-bound table (the q8 rows of K3f) is built from two precomputed fp32 tables
+//     instead of the exact fp64 table: with r = c - q the table entry is
+//         ||r_s - p||^2 = ||r_s||^2 + (||p||^2 - 2 c_s.p) + 2 q_s.p
+//     CPN[cell][s][j] = ||p_sj||^2 - 2 c_s.p_sj is a property of the index (built once, C x m x 256 floats),
+//     QP2[q][s][j] = 2 q_s.p_sj is built once per batch -- 32 KiB of reads and 2 flops per entry and item instead of
+//     256 KiB of codebook and 24 fp64 flops.  The fp32 evaluation is certified: a rigorous error term is subtracted
+//     from the minima, every rounding of the quantisation is directed downwards, so the filter can only
+//     under-estimate (it never drops a code with d <= T).
+//   * the EXACT distance is computed only for the filter's survivors, four lanes per survivor, each lane building the
+//     m/4 table entries it needs in the reference's order (t ascending, IVFPQ.java:531-534) and the sum passed
+//     through the quad in sub-quantizer order (s ascending, :435-438) -- same bits as a lookup in the fp64 table.
+//   * a wave stops looking a query's bytes up as soon as none of its 128 codes can still pass (checked after every
+//     four sub-quantizers): far lists die after 4-8 of the m lookups.
+// Items the kernel does not handle (no finite threshold yet, degenerate or huge magnitudes) are handed to K3f through
+// a device-side list, so results never depend on the heuristics.
+#pragma once
+#include "mmidx_kernels.h"
+
+#define GRP_NT 512     // threads per block (8 wave64: 4 per SIMD at two blocks per CU)
+#define GRP_QCAP 2048  // survivor queue entries (>= 64 lanes x 2 codes x 8 queries = one wave's worst case)
+#define GRP_VR 128     // survivors verified per round: 4 lanes each
+#define GRP_SEGU 2     // codes per thread per segment
+#define GRP_SEG (GRP_NT * GRP_SEGU)
+#ifndef GRP_WPS
+#define GRP_WPS 2  // waves per SIMD the register allocation is held to (blocks per CU x 2)
+#endif
+
+struct GrpParams {
+    ScanParams S;             // Q, coarse, perm, list_off, codes, order (sorted pairs), T, pool_*, D, m, ks, dsub, w, transform, chunk, K1, poolq
+    const double *pq;         // [m][ks][dsub] (file order)
+    const float *cpn;         // [C][m][256]   ||p||^2 - 2 c_s.p   (+inf beyond ks)
+    const float *qp2;         // [nq][m][256]  2 q_s.p              (0 beyond ks)
+    const double *pnmax;      // [2][m]: max_j ||p_sj||, max_j ||p_sj||^2
+    const int4 *gdesc;        // per group: {cell, first index into order[], number of pairs (1..G), 0}
+    const int32_t *n_groups;  // device-side count
+    int nchunks;              // chunks per list (list position < 2^24)
+    u32 *fb_count;            // items handed to K3f: (pair, chunk)
+    int32_t *fb_items, *fb_ch;
+    int cb;                   // candidate buffer entries per query: power of two >= K1 + GRP_VR
+};
+
+// LDS layout, shared by host (size) and device (offsets)
+struct GrpLds {
+    size_t lut8, tr, ctr, ckey, cpos, queue, sT, err, nrf, mn, inv, misc, total;
+    __host__ __device__ GrpLds(int M, int G, int D, int cb) {
+        size_t o = 0;
+        lut8 = o; o += (size_t)G * M * 256;
+        tr = o; o += (size_t)G * D * 8;
+        ctr = o; o += (size_t)D * 8;
+        ckey = o; o += (size_t)G * cb * 8;
+        sT = o; o += (size_t)G * 8;
+        err = o; o += (size_t)G * M * 8;
+        cpos = o; o += (size_t)G * cb * 4;
+        queue = o; o += (size_t)GRP_QCAP * 4;
+        nrf = o; o += (size_t)G * M * 4;
+        mn = o; o += (size_t)G * M * 4;
+        inv = o; o += (size_t)G * 4;
+        misc = o; o += 64 * 4;  // [0..G) q, [G..2G) rank, [2G..3G) state, [3G..4G) candidate counts, [32..35) new, [36..39) valid
+        total = (o + 15) & ~(size_t)15;
+    }
+};
+
+__device__ __forceinline__ float wave_min_f32(float x) {
+    float v = x;
+#define GRP_DPP_MIN(ctrl, rmask)                                                                                              \
+    {                                                                                                                         \
+        const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rmask, 0xf, false)); \
+        v = fminf(o, v);                                                                                                      \
+    }
+    GRP_DPP_MIN(0x111, 0xf) GRP_DPP_MIN(0x112, 0xf) GRP_DPP_MIN(0x114, 0xf) GRP_DPP_MIN(0x118, 0xf)
+    GRP_DPP_MIN(0x142, 0xa) GRP_DPP_MIN(0x143, 0xc)
+#undef GRP_DPP_MIN
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// value of the previous lane of the quad (lane 0 of a quad keeps its own) / of the quad's last lane
+__device__ __forceinline__ double quad_prev_f64(double x) {
+    const u64 b = (u64)__double_as_longlong(x);
+    const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)b, 0x90, 0xf, 0xf, false);  // quad_perm [0,0,1,2]
+    const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(b >> 32), 0x90, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+__device__ __forceinline__ double quad_last_f64(double x) {
+    const u64 b = (u64)__double_as_longlong(x);
+    const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)b, 0xFF, 0xf, 0xf, false);  // quad_perm [3,3,3,3]
+    const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(b >> 32), 0xFF, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+
+// ---- index-side table: CPN[c][s][j] = ||p_sj||^2 - 2 <c'_s, p_sj>, c' = the centroid after the permutation --------
+// (fp64 arithmetic, one rounding to fp32; entries beyond ks are +inf so that they never win a minimum)
+__global__ __launch_bounds__(256) void k_cpn_table(const double *__restrict__ coarse, const double *__restrict__ pqT,
+                                                   const int32_t *__restrict__ perm, float *__restrict__ cpn, int D, int m, int ks,
+                                                   int dsub) {
+    extern __shared__ double s_c[];  // [D]
+    const int c = blockIdx.x, j = threadIdx.x;
+    for (int i = j; i < D; i += 256) s_c[i] = coarse[(size_t)c * D + (perm ? perm[i] : i)];
+    __syncthreads();
+    for (int s = 0; s < m; s++) {
+        float out = __int_as_float(0x7F800000);
+        if (j < ks) {
+            const double *pp = pqT + (size_t)s * dsub * ks + j;
+            double pn = 0.0, cp = 0.0;
+            for (int t = 0; t < dsub; t++) {
+                const double p = pp[(size_t)t * ks];
+                pn += p * p;
+                cp += s_c[s * dsub + t] * p;
+            }
+            out = (float)(pn - 2.0 * cp);
+        }
+        cpn[((size_t)c * m + s) * 256 + j] = out;
+    }
+}
+// pnmax[s] = max_j ||p_sj|| * (1 + 1e-12), pnmax[m + s] = max_j ||p_sj||^2 * (1 + 1e-12)
+__global__ __launch_bounds__(256) void k_pn_max(const double *__restrict__ pqT, double *__restrict__ pnmax, int m, int ks, int dsub) {
+    __shared__ double s_w[4];
+    const int s = blockIdx.x, j = threadIdx.x;
+    double pn = 0.0;
+    for (int jj = j; jj < ks; jj += 256) {
+        double a = 0.0;
+        for (int t = 0; t < dsub; t++) {
+            const double p = pqT[((size_t)s * dsub + t) * ks + jj];
+            a += p * p;
+        }
+        pn = a > pn ? a : pn;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(pn, off);
+        pn = o > pn ? o : pn;
+    }
+    if ((j & 63) == 0) s_w[j >> 6] = pn;
+    __syncthreads();
+    if (j == 0) {
+        double a = s_w[0];
+        for (int i = 1; i < 4; i++) a = s_w[i] > a ? s_w[i] : a;
+        pnmax[s] = sqrt(a) * (1.0 + 1e-12);
+        pnmax[m + s] = a * (1.0 + 1e-12);
+    }
+}
+// ---- batch-side table: QP2[q][s][j] = 2 <q'_s, p_sj> (fp64, one rounding to fp32; 0 beyond ks) --------------------
+#define GRP_QT 8
+__global__ __launch_bounds__(256) void k_qp_table(const double *__restrict__ Q, const double *__restrict__ pqT,
+                                                  const int32_t *__restrict__ perm, float *__restrict__ qp2, int D, int m, int ks,
+                                                  int dsub, long long nq) {
+    extern __shared__ double s_q[];  // [GRP_QT][D]
+    const long long q0 = (long long)blockIdx.x * GRP_QT;
+    const int j = threadIdx.x;
+    for (int i = j; i < GRP_QT * D; i += 256) {
+        const int qi = i / D, d = i - qi * D;
+        s_q[i] = (q0 + qi < nq) ? Q[(size_t)(q0 + qi) * D + (perm ? perm[d] : d)] : 0.0;
+    }
+    __syncthreads();
+    for (int s = 0; s < m; s++) {
+        double acc[GRP_QT];
+#pragma unroll
+        for (int qi = 0; qi < GRP_QT; qi++) acc[qi] = 0.0;
+        if (j < ks) {
+            const double *pp = pqT + (size_t)s * dsub * ks + j;
+            for (int t = 0; t < dsub; t++) {
+                const double p = pp[(size_t)t * ks];
+#pragma unroll
+                for (int qi = 0; qi < GRP_QT; qi++) acc[qi] += s_q[qi * D + s * dsub + t] * p;
+            }
+        }
+#pragma unroll
+        for (int qi = 0; qi < GRP_QT; qi++)
+            if (q0 + qi < nq) qp2[((size_t)(q0 + qi) * m + s) * 256 + j] = (float)(2.0 * acc[qi]);
+    }
+}
+
+// ---- groups: the pairs of a cell (contiguous in order[]) in runs of G -----------------------------------------------
+// single block; also zeroes the hand-back counter of this step
+__global__ __launch_bounds__(1024) void k_group_build(const int32_t *__restrict__ cnt, const int32_t *__restrict__ start, int C, int G,
+                                                      int4 *__restrict__ gdesc, int32_t *__restrict__ n_groups, u32 *__restrict__ fb_count) {
+    __shared__ u32 s_wave[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per = (C + 1023) / 1024;
+    const int lo = tid * per, hi = (lo + per < C) ? lo + per : C;
+    u32 sum = 0;
+    for (int c = lo; c < hi; c++) sum += ((u32)cnt[c] + (u32)G - 1u) / (u32)G;
+    const u32 incl = wave_incl_scan_u32(sum);
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    u32 base = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) base += (i < wv) ? s_wave[i] : 0u;
+    u32 run = base + incl - sum;
+    for (int c = lo; c < hi; c++) {
+        const int n = cnt[c], st = start[c];
+        for (int o = 0; o < n; o += G) gdesc[run++] = make_int4(c, st + o, (n - o < G) ? n - o : G, 0);
+    }
+    if (tid == 1023) *n_groups = (int32_t)(base + incl);
+    if (tid == 0) *fb_count = 0u;
+}
+
+// prune query i's candidate buffer to the K1 smallest by (distance, list position); publishes the threshold
+__device__ __forceinline__ void grp_prune(u64 *ckey, u32 *cpos, u32 *s_cnt, u64 *s_T, int K1, u64 *Tq) {
+    scan_prune(ckey, cpos, s_cnt, K1, Tq);  // (barriers inside; every thread of the block calls it)
+    if (threadIdx.x == 0) *s_T = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+}
+
+template <int M, int G>
+__global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P) {
+    static_assert(M % 8 == 0 && G <= 8 && G * M * 256 <= 65536, "imm offsets of the table reads");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int LQ = M * 256;  // bytes of one query's u8 table
+    constexpr int SPW = M / 8;   // sub-quantizers per wave in the table build
+    constexpr int GH = G > 4 ? G / 2 : G;  // queries per round of the table build
+    constexpr int EPL = M / 4;   // exact entries per lane of a verifying quad
+    const int D = P.S.D, ks = P.S.ks, dsub = P.S.dsub, cb = P.cb, K1 = P.S.K1;
+    const GrpLds L(M, G, D, cb);
+    unsigned char *lut8 = smem + L.lut8;
+    double *s_tr = (double *)(smem + L.tr);
+    double *s_ctr = (double *)(smem + L.ctr);
+    u64 *ckey = (u64 *)(smem + L.ckey);
+    u32 *cpos = (u32 *)(smem + L.cpos);
+    u32 *s_queue = (u32 *)(smem + L.queue);
+    u64 *s_T = (u64 *)(smem + L.sT);
+    double *s_err = (double *)(smem + L.err);
+    float *s_nrf = (float *)(smem + L.nrf);
+    float *s_mn = (float *)(smem + L.mn);
+    float *s_inv = (float *)(smem + L.inv);
+    int *s_q = (int *)(smem + L.misc);
+    int *s_pr = s_q + G;
+    int *s_state = s_q + 2 * G;
+    u32 *s_ccnt = (u32 *)(s_q + 3 * G);
+    u32 *s_new = (u32 *)(s_q + 32);
+    u32 *s_qvalid = (u32 *)(s_q + 36);
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u64 lane_lt = (1ull << lane) - 1ull;
+    const int nv = *P.n_groups * P.nchunks;
+    const int per = (nv + 7) >> 3;
+    const int xcd = blockIdx.x & 7, nj = gridDim.x >> 3;
+
+    for (int it = (int)(blockIdx.x >> 3); it < per; it += nj) {
+        const int v = xcd * per + it;  // consecutive items -- the groups of one list -- run on the same XCD
+        if (v >= nv) break;
+        const int g = v / P.nchunks, ch = v - g * P.nchunks;
+        const int4 gd = P.gdesc[g];
+        const int cell = gd.x, first = gd.y, np = gd.z;
+        const int64_t beg = P.S.list_off[cell];
+        const int64_t len = P.S.list_off[cell + 1] - beg;
+        const int64_t c0 = (int64_t)ch * P.S.chunk;
+        if (c0 >= len) continue;
+        const int64_t c1 = (c0 + P.S.chunk < len) ? c0 + P.S.chunk : len;
+        const unsigned char *codes = (const unsigned char *)P.S.codes + (size_t)beg * M;
+
+        // ---- (a) the group's pairs, thresholds, counters ---------------------------------------------------------
+        if (tid < G) {
+            int q = 0, pr = 0;
+            u64 T = 0;
+            if (tid < np) {
+                const int e = P.S.order[first + tid];
+                q = e / P.S.w;
+                pr = e - q * P.S.w;
+                T = __hip_atomic_load(P.S.T + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s_q[tid] = q;
+            s_pr[tid] = pr;
+            s_T[tid] = T;
+            s_ccnt[tid] = 0;
+        }
+        if (tid < 3) {
+            s_new[tid] = 0;
+            s_qvalid[tid] = 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        // ---- (b) transformed centroid and residuals (exact: centroid - q, IVFPQ.java:645, then the permutation) ----
+        for (int idx = tid; idx < (G + 1) * D; idx += GRP_NT) {
+            const int i = idx / D, d = idx - i * D;
+            const int src = P.S.perm ? P.S.perm[d] : d;
+            const double cv = P.S.coarse[(size_t)cell * D + src];
+            if (i == G) s_ctr[d] = cv;
+            else if (i < np) s_tr[i * D + d] = cv - P.S.Q[(size_t)s_q[i] * D + src];
+        }
+        __syncthreads();
+        // ---- (c) per (query, sub-quantizer): ||r_s||^2 and the error term of the fp32 table ----------------------
+        if (tid < G * M) {
+            const int i = tid / M, s = tid - i * M;
+            double nr = 0.0, cs2 = 0.0;
+            if (i < np) {
+                for (int t = 0; t < dsub; t++) {
+                    const double r = s_tr[i * D + s * dsub + t], c = s_ctr[s * dsub + t];
+                    nr += r * r;
+                    cs2 += c * c;
+                }
+            }
+            // |fp32 table entry - exact entry| <= 3 * 2^-24 * (nr + pn + 2 (|c_s| + |q_s|) |p|), |q_s| <= |c_s| + |r_s|;
+            // 2^-22 leaves a factor for the fp64 evaluation order of the exact entry
+            const double pm = P.pnmax[s], pm2 = P.pnmax[M + s];
+            s_err[tid] = 0x1p-22 * (nr + pm2 + 2.0 * (2.0 * sqrt(cs2) + sqrt(nr)) * pm);  // (inf / nan for huge inputs: caught in (e))
+            s_nrf[tid] = (float)nr;
+        }
+        __syncthreads();
+        // ---- (d)-(f) u8 rows, GH queries per round (the fp32 entries of a round stay in registers across its barriers) ----
+        u32 alive0 = 0;
+        float4 cp4[SPW];
+#pragma unroll
+        for (int ss = 0; ss < SPW; ss++) cp4[ss] = *(const float4 *)(P.cpn + ((size_t)cell * M + wv * SPW + ss) * 256 + 4 * lane);
+#pragma unroll 1
+        for (int i0 = 0; i0 < G; i0 += GH) {
+            if (i0 >= np) break;  // (uniform)
+            // (d) fp32 table entries and per-sub-quantizer minima
+            float A[GH][SPW][4];
+            float mnv[GH][SPW];
+#pragma unroll
+            for (int ii = 0; ii < GH; ii++) {
+                const int i = i0 + ii;
+                if (i < np) {
+                    const float *qrow = P.qp2 + (size_t)s_q[i] * M * 256 + 4 * lane;
+#pragma unroll
+                    for (int ss = 0; ss < SPW; ss++) {
+                        const int s = wv * SPW + ss;
+                        const float4 qp = *(const float4 *)(qrow + s * 256);
+                        const float nrf = s_nrf[i * M + s];
+                        A[ii][ss][0] = (nrf + cp4[ss].x) + qp.x;
+                        A[ii][ss][1] = (nrf + cp4[ss].y) + qp.y;
+                        A[ii][ss][2] = (nrf + cp4[ss].z) + qp.z;
+                        A[ii][ss][3] = (nrf + cp4[ss].w) + qp.w;
+                        const float m4 = fminf(fminf(A[ii][ss][0], A[ii][ss][1]), fminf(A[ii][ss][2], A[ii][ss][3]));
+                        mnv[ii][ss] = wave_min_f32(m4);
+                        if (lane == 0) s_mn[i * M + s] = mnv[ii][ss];
+                    }
+                }
+            }
+            __syncthreads();
+            // (e) per query: lower bound of the sum of minima, state, quantisation step
+            if (tid >= i0 && tid < i0 + GH) {
+                int state = 1;  // 0 scan, 1 nothing to do (no pair / list exhausted: Smin >= T), 2 hand back to K3f
+                float inv = 0.f;
+                if (tid < np) {
+                    double smin = 0.0, es = 0.0;
+                    for (int s = 0; s < M; s++) {
+                        smin += (double)s_mn[tid * M + s] - s_err[tid * M + s];
+                        es += s_err[tid * M + s];
+                    }
+                    const double smin_lo = smin - fabs(smin) * 0x1p-40;
+                    const u64 T = s_T[tid];
+                    const double Td = keyd(T);
+                    if (!(T < 0x7FF0000000000000ull) || !(es < 1e24) || !(fabs(smin_lo) < 1e30)) {
+                        state = 2;  // no finite threshold yet, or magnitudes beyond what fp32 carries
+                    } else if (!(smin_lo < Td)) {
+                        state = 1;
+                    } else if (!((Td - smin_lo) > Td * 0x1p-20)) {
+                        state = 2;  // degenerate step
+                    } else {
+                        state = 0;
+                        inv = (float)((254.0 / (Td - smin_lo)) * (1.0 - 0x1p-18));
+                    }
+                    if (state == 2) {
+                        const u32 f = atomicAdd(P.fb_count, 1u);
+                        P.fb_items[f] = s_q[tid] * P.S.w + s_pr[tid];
+                        P.fb_ch[f] = ch;
+                    }
+                }
+                s_state[tid] = state;
+                s_inv[tid] = inv;
+            }
+            __syncthreads();
+            // (f) u8 rows: q8 = min(255, floor((A - min) * inv)), packed four per store
+#pragma unroll
+            for (int ii = 0; ii < GH; ii++) {
+                const int i = i0 + ii;
+                if (i < np && s_state[i] == 0) {
+                    alive0 |= 1u << i;
+                    const float inv = s_inv[i];
+#pragma unroll
+                    for (int ss = 0; ss < SPW; ss++) {
+                        u32 pk = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const float x = fminf((A[ii][ss][k] - mnv[ii][ss]) * inv, 255.f);  // >= 0; +inf beyond ks -> 255
+                            pk |= (u32)x << (8 * k);
+                        }
+                        *(u32 *)(lut8 + i * LQ + (wv * SPW + ss) * 256 + 4 * lane) = pk;
+                    }
+                }
+            }
+        }
+        alive0 = (u32)__builtin_amdgcn_readfirstlane((int)alive0);
+        __syncthreads();
+        if (alive0 == 0) continue;
+
+        // ---- (g) filter scan ---------------------------------------------------------------------------------------
+        CodeVec<M, unsigned char> cur[GRP_SEGU], nxt[GRP_SEGU];
+#pragma unroll
+        for (int u = 0; u < GRP_SEGU; u++) {
+            const int64_t p = c0 + u * GRP_NT + tid;
+            cur[u].load(codes + (size_t)(p < c1 ? p : c1 - 1) * M);
+        }
+        u32 carried = 0;  // queue entries carried over from earlier segments (block-uniform)
+        int par = 0;
+        for (int64_t seg = c0; seg < c1; seg += GRP_SEG) {
+            const bool more = seg + GRP_SEG < c1;
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < GRP_SEGU; u++) {
+                    const int64_t p = seg + GRP_SEG + u * GRP_NT + tid;
+                    nxt[u].load(codes + (size_t)(p < c1 ? p : c1 - 1) * M);
+                }
+            }
+            u32 acc[G][GRP_SEGU];
+            u32 posv[GRP_SEGU];
+            u32 alu[GRP_SEGU];
+#pragma unroll
+            for (int u = 0; u < GRP_SEGU; u++) {  // one code of the lane at a time: 64 codes per wave and early-out test
+                const int64_t p = seg + u * GRP_NT + tid;
+                posv[u] = (u32)p;
+                const u32 a0 = p < c1 ? 0u : 0x10000u;
+#pragma unroll
+                for (int i = 0; i < G; i++) acc[i][u] = a0;
+                u32 al = alive0;
+#pragma unroll
+                for (int sb = 0; sb < M / 4; sb++) {
+                    u32 slot[4], sel[4];
+                    const u32 wd = cur[u].wd[sb];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const u32 b = (wd >> (8 * k)) & 0xFFu;
+                        slot[k] = b & 0xF8u;
+                        sel[k] = (b & 7u) | 0x0C0C0C00u;
+                    }
+#pragma unroll
+                    for (int i = 0; i < G; i++) {
+                        if ((al >> i) & 1u) {  // wave-uniform
+                            uint2 rv[4];
+#pragma unroll
+                            for (int k = 0; k < 4; k++) rv[k] = *(const uint2 *)(lut8 + i * LQ + (sb * 4 + k) * 256 + slot[k]);
+#pragma unroll
+                            for (int k = 0; k < 4; k++) acc[i][u] += __builtin_amdgcn_perm(rv[k].y, rv[k].x, sel[k]);
+                            if (sb + 1 < M / 4) {
+                                if (__builtin_amdgcn_ballot_w64(acc[i][u] <= 254u) == 0) al &= ~(1u << i);
+                            }
+                        }
+                    }
+                }
+                alu[u] = al;
+            }
+            // survivors: sum of lower bounds <= 254 (255 already certifies d > T)
+            u32 pend = 0;
+#pragma unroll
+            for (int i = 0; i < G; i++)
+#pragma unroll
+                for (int u = 0; u < GRP_SEGU; u++)
+                    if (((alu[u] >> i) & 1u) && acc[i][u] <= 254u) pend |= 1u << (i * GRP_SEGU + u);
+            // ---- append to the queue; verify when a round is full, at the end, or when the queue overflowed ----
+            for (;;) {
+                u32 nw = 0;
+#pragma unroll
+                for (int b = 0; b < G * GRP_SEGU; b++) nw += (u32)__popcll(__builtin_amdgcn_ballot_w64((pend >> b) & 1u));
+                if (nw) {
+                    u32 base = 0;
+                    if (lane == 0) base = atomicAdd(s_new + par, nw);
+                    base = carried + (u32)__builtin_amdgcn_readfirstlane((int)base);
+                    if (base + nw <= GRP_QCAP) {
+                        u32 off = base;
+#pragma unroll
+                        for (int b = 0; b < G * GRP_SEGU; b++) {
+                            const bool mine = (pend >> b) & 1u;
+                            const u64 mk = __builtin_amdgcn_ballot_w64(mine);
+                            if (mine) s_queue[off + (u32)__popcll(mk & lane_lt)] = ((u32)(b / GRP_SEGU) << 24) | posv[b % GRP_SEGU];
+                            off += (u32)__popcll(mk);
+                        }
+                        pend = 0;
+                    } else if (lane == 0) {
+                        atomicMin(s_qvalid + par, base);  // everything from here on in this round failed
+                    }
+                }
+                __syncthreads();
+                const u32 cnt = carried + s_new[par], qv = s_qvalid[par];
+                // three sets of round words: the set of round r + 2 is cleared here, behind the barrier of round r (every
+                // thread has read it -- it was round r - 1's -- before arriving) and ahead of the barrier of round r + 1
+                const int par2 = par == 0 ? 2 : par - 1;
+                if (tid == 0) {
+                    s_new[par2] = 0;
+                    s_qvalid[par2] = 0xFFFFFFFFu;
+                }
+                par = par == 2 ? 0 : par + 1;
+                const bool failed = qv != 0xFFFFFFFFu;
+                if (!failed && more && cnt < (u32)(2 * GRP_VR)) {
+                    carried = cnt;
+                    break;
+                }
+                const u32 nvalid = failed ? (qv < cnt ? qv : cnt) : cnt;
+                // ---- exact verification, GRP_VR survivors per round, four lanes each --------------------------
+                for (u32 r0 = 0; r0 < nvalid; r0 += GRP_VR) {
+                    __syncthreads();  // candidate counts of the previous round are final
+                    u32 full = 0;     // queries whose buffer may not take another round
+#pragma unroll
+                    for (int i = 0; i < G; i++) full |= (s_ccnt[i] > (u32)(cb - GRP_VR)) ? 1u << i : 0u;
+                    __syncthreads();  // every thread has its snapshot before this round's appends start
+#pragma unroll 1
+                    for (int i = 0; i < G; i++)
+                        if ((full >> i) & 1u) grp_prune(ckey + (size_t)i * cb, cpos + (size_t)i * cb, s_ccnt + i, s_T + i, K1, P.S.T + s_q[i]);
+                    // Written without a divergent region on purpose: every quad runs the whole chain (quads past the end
+                    // redo the round's last survivor) and only the final append is predicated.  With the loads inside
+                    // `if (e < nvalid)` hipcc (ROCm 7.2) produced a kernel that died with a memory aperture violation on
+                    // valid entries -- the same family as the note at pair_keep() in mmidx_kernels.h.
+                    const u32 e_raw = r0 + (u32)(tid >> 2);
+                    const bool act = e_raw < nvalid;
+                    const u32 e = act ? e_raw : nvalid - 1u;
+                    const int ql = tid & 3;
+                    const u32 ent = s_queue[e];
+                    const int i = (int)(ent >> 24);
+                    const u32 pos = ent & 0xFFFFFFu;
+                    // the lane's EPL code bytes (sub-quantizers ql*EPL ..): one aligned load, no indexed register array
+                    const u32 coff = pos * (u32)M + (u32)(ql * EPL);  // (< 2^24 * M: list positions are below 2^24)
+                    u32 cw[(EPL + 3) / 4];
+                    if constexpr (EPL >= 4) {
+#pragma unroll
+                        for (int x = 0; x < EPL / 4; x++) cw[x] = *(const u32 *)(codes + coff + 4 * x);
+                    } else {
+                        cw[0] = (u32) * (const unsigned short *)(codes + coff);
+                    }
+                    double en[EPL];
+#pragma unroll
+                    for (int k = 0; k < EPL; k++) {
+                        const int s = ql * EPL + k;
+                        const u32 cs = (cw[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                        const double *pp = P.pq + (u32)((s * ks + (int)cs) * dsub);
+                        const double *tv = s_tr + i * D + s * dsub;
+                        double ac = 0.0;  // (t ascending from 0.0: IVFPQ.java:531-534)
+                        for (int t = 0; t < dsub; t++) {
+                            const double df = tv[t] - pp[t];
+                            ac += df * df;
+                        }
+                        en[k] = ac;
+                    }
+                    // d = ((0 + e_0) + e_1) + ... in sub-quantizer order: lane 0's partial sum moves down the quad
+                    double d = 0.0;
+#pragma unroll
+                    for (int ph = 0; ph < 4; ph++) {
+                        const double din = quad_prev_f64(d);
+                        if (ql == ph) {
+                            d = ph ? din : 0.0;
+#pragma unroll
+                            for (int k = 0; k < EPL; k++) d += en[k];
+                        }
+                    }
+                    const u64 key = dkey(d);
+                    if (act && ql == 3 && key <= s_T[i]) {
+                        const u32 slot = atomicAdd(s_ccnt + i, 1u);
+                        ckey[(size_t)i * cb + slot] = key;
+                        cpos[(size_t)i * cb + slot] = pos;
+                    }
+                }
+                __syncthreads();
+                carried = 0;
+                if (!failed) break;
+            }
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < GRP_SEGU; u++) cur[u] = nxt[u];
+            }
+        }
+        // ---- (h) hand the candidates to the queries' pools (at most K1 per item) ------------------------------------
+        __syncthreads();
+#pragma unroll 1
+        for (int i = 0; i < G; i++) {
+            if (!((alive0 >> i) & 1u)) continue;
+            if (s_ccnt[i] > (u32)K1) grp_prune(ckey + (size_t)i * cb, cpos + (size_t)i * cb, s_ccnt + i, s_T + i, K1, P.S.T + s_q[i]);
+            const int n = (int)s_ccnt[i];
+            if (n == 0) continue;
+            const int q = s_q[i];
+            const u64 Tfin = __hip_atomic_load(P.S.T + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // per-lane use only
+            const bool pass = tid < n && ckey[(size_t)i * cb + tid] <= Tfin;
+            const u64 mask = __builtin_amdgcn_ballot_w64(pass);
+            if (mask) {
+                u32 base = 0;
+                const int leader = __ffsll((long long)mask) - 1;
+                if (lane == leader) base = atomicAdd(P.S.pool_cnt + q, (u32)__popcll(mask));
+                base = wave_read_u32(base, leader);
+                if (pass) {
+                    const u32 slot = base + (u32)__popcll(mask & lane_lt);
+                    if (slot < (u32)P.S.poolq) {
+                        P.S.pool_key[(size_t)q * P.S.poolq + slot] = ckey[(size_t)i * cb + tid];
+                        P.S.pool_val[(size_t)q * P.S.poolq + slot] = ((u64)s_pr[i] << 32) | (u64)cpos[(size_t)i * cb + tid];
+                    }
+                }
+            }
+        }
+        __syncthreads();  // LDS is reused by the next item
+    }
+}
