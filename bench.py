@@ -454,7 +454,7 @@ def main():
                        "n": N, "dim": D, "cells": Cc, "nprobe": w, "m": m, "ks": ks, "k": k, "batch": B, "batch_per_gpu": B // world,
                        "sharding": "single GPU" if world == 1 else f"whole inverted lists, cell mod {world}; RCCL: all-gather probe cells, MIN all-reduce thresholds, "
                                                                       f"all-to-all partial top-k to the query's owner rank, merge there"},
-            "recall_at_1": recall1, "recall_queries": ngt, "sigma": args.sigma, "passb_items_last": int(st.passb_items_last),
+            "recall_at_1": recall1, "recall_queries": ngt, "sigma": args.sigma, "passb_items_last": int(st.passb_items_last), "verified_codes_per_step": int(st.verified_codes) // max(1, detail_steps),
             "roofline": roofline, "roofline_whole_search": whole, "roofline_exhaustive": exhaustive,
             "cpu_baseline": cpu_baseline, "parity": parity,
         }

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MMIDX_ABI_VERSION 3
+#define MMIDX_ABI_VERSION 4
 
 typedef struct mmidx_index mmidx_index; /* opaque handle: one index on one GPU */
 
@@ -236,6 +236,8 @@ typedef struct mmidx_stats {
     /* (query, probe) pairs of the most recent search call that survived the coarse bound and went through pass B
      * (-1: unknown); read from the pinned word the device writes for the launch-size hint */
     int32_t passb_items_last;
+    /* codes of pass B that survived the lower-bound filter and had their exact distance computed (ABI version 4) */
+    int64_t verified_codes;
 } mmidx_stats;
 /* enabled: 0 off; 1 full (six events per search call and the code counters: every field below); 2 light (only the two
  * events around pass A: passa_ms / passa_launches -- an event record is a ~5 us bubble in the stream, so a throughput

@@ -186,8 +186,8 @@ struct mmidx_index {
     bool no_seed = true;        // MMIDX_SEED=1: pass A with the seeded scan K3s (measured slower than K3: 1.45 vs 1.22 ms
                                 // per 8192 queries -- one block per query is latency-bound, not LDS-bound; kept for study)
     double rmax = 0.0;       // sqrt(sum_s max_j ||pq[s][j]||^2) * (1 + 1e-12)
-    // K3g (grouped pass B, mmidx_scan_grp.h): index-side fp32 table CPN[C][m][256] and the codebook norm maxima
-    float *d_cpn = nullptr;
+    // K3g (grouped pass B, mmidx_scan_grp.h): fp32 copy of the codebook (entry index innermost), ||p||^2 and their maxima
+    float *d_pq32T = nullptr, *d_pn32 = nullptr;
     double *d_pnmax = nullptr;
     bool grp_valid = false;  // tables match the current quantizers
     int no_grp = 0;          // option "no_grp" = 1: pass B through K3f only (A/B switch)
@@ -243,7 +243,6 @@ struct mmidx_index {
     DevBuf<int32_t> ws_aidx, ws_acell;
     int64_t last_ambiguous = 0;  // vectors of the last encode call that needed the exact redo
     DevBuf<long long> ws_dest;
-    DevBuf<float> ws_qp2;
     DevBuf<int4> ws_gdesc;
     DevBuf<int32_t> ws_gfb;
 
@@ -368,10 +367,10 @@ int build_csr(mmidx_index *h) {
         h->d_pcodes = nullptr;
         h->cap_pend = 0;
         h->ws_dest.release();
-    h->ws_qp2.release();
     h->ws_gdesc.release();
     h->ws_gfb.release();
-    if (h->d_cpn) (void)hipFree(h->d_cpn);
+    if (h->d_pq32T) (void)hipFree(h->d_pq32T);
+    if (h->d_pn32) (void)hipFree(h->d_pn32);
     if (h->d_pnmax) (void)hipFree(h->d_pnmax);
     }
     h->max_list_len = 0;
@@ -762,14 +761,12 @@ int launch_scan_seeded(const mmidx_index *h, ScanParams P, const SearchPlan &pl,
 int build_grp_tables(mmidx_index *h) {
     if (h->grp_valid) return MMIDX_OK;
     const bool shape_ok = h->kind == MMIDX_KIND_IVFPQ && h->code_bytes == 1 && h->ks <= 256 && (h->m == 8 || h->m == 16 || h->m == 32) &&
-                          h->transform != MMIDX_TR_ROTATION && (size_t)h->C * h->m * 256 * sizeof(float) <= ((size_t)8 << 30);
-    if (!shape_ok || !h->coarse_set || !h->pq_set) return MMIDX_OK;
-    if (h->d_cpn) (void)hipFree(h->d_cpn);
-    h->d_cpn = nullptr;
-    HIPCK(hipMalloc((void **)&h->d_cpn, (size_t)h->C * h->m * 256 * sizeof(float)));
+                          h->transform != MMIDX_TR_ROTATION;
+    if (!shape_ok || !h->pq_set) return MMIDX_OK;
+    if (!h->d_pq32T) HIPCK(hipMalloc((void **)&h->d_pq32T, (size_t)h->m * h->dsub * 256 * sizeof(float)));
+    if (!h->d_pn32) HIPCK(hipMalloc((void **)&h->d_pn32, (size_t)h->m * 256 * sizeof(float)));
     if (!h->d_pnmax) HIPCK(hipMalloc((void **)&h->d_pnmax, 2 * (size_t)h->m * sizeof(double)));
-    hipLaunchKernelGGL(k_cpn_table, dim3((unsigned)h->C), dim3(256), (size_t)h->D * 8, h->stream, h->d_coarse, h->d_pqT, h->d_perm, h->d_cpn,
-                       h->D, h->m, h->ks, h->dsub);
+    hipLaunchKernelGGL(k_pq32_table, dim3((unsigned)h->m), dim3(256), 0, h->stream, h->d_pqT, h->d_pq32T, h->d_pn32, h->m, h->ks, h->dsub);
     hipLaunchKernelGGL(k_pn_max, dim3((unsigned)h->m), dim3(256), 0, h->stream, h->d_pqT, h->d_pnmax, h->m, h->ks, h->dsub);
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(h->stream));
@@ -777,20 +774,20 @@ int build_grp_tables(mmidx_index *h) {
     return MMIDX_OK;
 }
 
-template <int M, int G>
+template <int M, int G, int DSUB>
 int launch_grp_t(mmidx_index *h, const GrpParams &GP, size_t lds, hipStream_t st) {
-    HIPCK(hipFuncSetAttribute((const void *)k_scan_grp<M, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCK(hipFuncSetAttribute((const void *)k_scan_grp<M, G, DSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int blocks = h->grp_blocks;
     if (blocks <= 0) {
         int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_scan_grp<M, G>, GRP_NT, lds) != hipSuccess || occ < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_scan_grp<M, G, DSUB>, GRP_NT, lds) != hipSuccess || occ < 1) {
             (void)hipGetLastError();
             occ = 1;
         }
         blocks = occ * std::max(h->num_cus, 8);
     }
     blocks = std::max(8, (blocks + 7) & ~7);
-    hipLaunchKernelGGL((k_scan_grp<M, G>), dim3((unsigned)blocks), dim3(GRP_NT), lds, st, GP);
+    hipLaunchKernelGGL((k_scan_grp<M, G, DSUB>), dim3((unsigned)blocks), dim3(GRP_NT), lds, st, GP);
     HIPCK(hipGetLastError());
     return MMIDX_OK;
 }
@@ -798,20 +795,16 @@ int launch_grp_t(mmidx_index *h, const GrpParams &GP, size_t lds, hipStream_t st
 // pass B over the sorted pairs (P.order / P.n_order as for K3f; per-cell counts and starts in ws_pcount / ws_pstart).
 // Returns 1 when K3g does not apply (the caller uses K3f).
 int launch_scan_grouped(mmidx_index *h, const ScanParams &P, const SearchPlan &pl, long long nq, long long npairs, hipStream_t st) {
-    if (h->no_grp || !h->grp_valid || !h->d_cpn || h->no_filter || P.sdc_tt || !P.ivf || h->max_list_len >= (1 << 24)) return 1;
+    if (h->no_grp || !h->grp_valid || !h->d_pq32T || h->no_filter || P.sdc_tt || !P.ivf || h->max_list_len >= (1 << 24)) return 1;
     const int G = h->m == 32 ? 4 : 8;
     int cb = 1;
     while (cb < pl.K1 + GRP_VR) cb <<= 1;
     const GrpLds L(h->m, G, h->D, cb);
     if (L.total > 160 * 1024 || pl.K1 + GRP_VR > GRP_NT) return 1;
     const size_t nfb = (size_t)npairs * (size_t)pl.nchunks;
-    HIPCK(h->ws_qp2.reserve((size_t)nq * h->m * 256));
     HIPCK(h->ws_gdesc.reserve((size_t)npairs / G + (size_t)h->C + 8));
     HIPCK(h->ws_gfb.reserve(4 + 2 * nfb + 16));
     if (h->debug_sync) HIPCK(hipMemsetAsync(h->ws_gfb.p, 0, (4 + 2 * nfb + 16) * sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_qp_table, dim3((unsigned)((nq + GRP_QT - 1) / GRP_QT)), dim3(256), (size_t)GRP_QT * h->D * 8, st, P.Q, h->d_pqT,
-                       h->d_perm, h->ws_qp2.p, h->D, h->m, h->ks, h->dsub, nq);
-    DBG_SYNC("K3g qp table");
     hipLaunchKernelGGL(k_group_build, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, h->ws_pstart.p, h->C, G, h->ws_gdesc.p, h->ws_gfb.p,
                        (u32 *)(h->ws_gfb.p + 1));
     HIPCK(hipGetLastError());
@@ -819,8 +812,8 @@ int launch_scan_grouped(mmidx_index *h, const ScanParams &P, const SearchPlan &p
     GrpParams GP{};
     GP.S = P;
     GP.pq = h->d_pq;
-    GP.cpn = h->d_cpn;
-    GP.qp2 = h->ws_qp2.p;
+    GP.pq32T = h->d_pq32T;
+    GP.pn32 = h->d_pn32;
     GP.pnmax = h->d_pnmax;
     GP.gdesc = h->ws_gdesc.p;
     GP.n_groups = h->ws_gfb.p;
@@ -829,11 +822,24 @@ int launch_scan_grouped(mmidx_index *h, const ScanParams &P, const SearchPlan &p
     GP.fb_items = h->ws_gfb.p + 4;
     GP.fb_ch = h->ws_gfb.p + 4 + nfb;
     GP.cb = cb;
+    GP.stat = (h->profiling == 1 || h->debug_sync) ? (unsigned long long *)(h->d_counters + 3) : nullptr;
     int rc;
+    const int ds = h->dsub;
     switch (h->m) {
-        case 8: rc = launch_grp_t<8, 8>(h, GP, L.total, st); break;
-        case 16: rc = launch_grp_t<16, 8>(h, GP, L.total, st); break;
-        default: rc = launch_grp_t<32, 4>(h, GP, L.total, st); break;
+        case 8:
+            rc = ds == 16  ? launch_grp_t<8, 8, 16>(h, GP, L.total, st)
+                 : ds == 8 ? launch_grp_t<8, 8, 8>(h, GP, L.total, st)
+                 : ds == 4 ? launch_grp_t<8, 8, 4>(h, GP, L.total, st)
+                           : launch_grp_t<8, 8, 0>(h, GP, L.total, st);
+            break;
+        case 16:
+            rc = ds == 8   ? launch_grp_t<16, 8, 8>(h, GP, L.total, st)
+                 : ds == 4 ? launch_grp_t<16, 8, 4>(h, GP, L.total, st)
+                           : launch_grp_t<16, 8, 0>(h, GP, L.total, st);
+            break;
+        default:
+            rc = ds == 4 ? launch_grp_t<32, 4, 4>(h, GP, L.total, st) : launch_grp_t<32, 4, 0>(h, GP, L.total, st);
+            break;
     }
     if (rc) return rc;
     DBG_SYNC("K3g scan");
@@ -1484,10 +1490,10 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_aidx.release();
     h->ws_acell.release();
     h->ws_dest.release();
-    h->ws_qp2.release();
     h->ws_gdesc.release();
     h->ws_gfb.release();
-    if (h->d_cpn) (void)hipFree(h->d_cpn);
+    if (h->d_pq32T) (void)hipFree(h->d_pq32T);
+    if (h->d_pn32) (void)hipFree(h->d_pn32);
     if (h->d_pnmax) (void)hipFree(h->d_pnmax);
     for (auto &ev : h->evpool)
         if (ev) (void)hipEventDestroy(ev);
@@ -1557,7 +1563,6 @@ int mmidx_set_coarse(mmidx_index *h, const double *coarse) {
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(h->stream));
     h->coarse_set = true;
-    h->grp_valid = false;
     return MMIDX_OK;
 }
 
@@ -2164,13 +2169,14 @@ int mmidx_get_stats(mmidx_index *h, mmidx_stats *out) {
         s.total_ms += t;
         s.passa_ms += pa;
     }
-    u64 cnt[3] = {0, 0, 0};
+    u64 cnt[4] = {0, 0, 0, 0};
     HIPCK(hipMemcpy(cnt, h->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));
     s.scan_codes = (int64_t)cnt[0] + h->host_codes;
     s.tie_fallbacks = (int32_t)cnt[1];
     s.scan_launches = h->launches;
     s.passa_codes = (int64_t)cnt[2] + h->host_passa_codes;
     s.passa_launches = h->passa_launches;
+    s.verified_codes = (int64_t)cnt[3];
     s.passb_items_last = h->pin_hint ? *(volatile int32_t *)h->pin_hint : -1;
     *out = s;
     h->ev_used = 0;

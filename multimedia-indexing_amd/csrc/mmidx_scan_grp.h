@@ -7,14 +7,14 @@
 //     pass B are already sorted by cell).  A code is loaded once, its m bytes are split into (8-byte slot, byte
 //     selector) once, and every query of the group pays only one conflict-free ds_read_b64 + v_perm + v_add per
 //     sub-quantizer (K3f: one block per (query, list), 5 VALU per lookup).
-//   * the quantised lower-bound table (the q8 rows of K3f) is built from two precomputed fp32 tables
-//     instead of the exact fp64 table: with r = c - q the table entry is
-//         ||r_s - p||^2 = ||r_s||^2 + (||p||^2 - 2 c_s.p) + 2 q_s.p
-//     CPN[cell][s][j] = ||p_sj||^2 - 2 c_s.p_sj is a property of the index (built once, C x m x 256 floats),
-//     QP2[q][s][j] = 2 q_s.p_sj is built once per batch -- 32 KiB of reads and 2 flops per entry and item instead of
-//     256 KiB of codebook and 24 fp64 flops.  The fp32 evaluation is certified: a rigorous error term is subtracted
-//     from the minima, every rounding of the quantisation is directed downwards, so the filter can only
-//     under-estimate (it never drops a code with d <= T).
+//   * the quantised lower-bound table (the q8 rows of K3f) is built from an fp32 evaluation of the entries
+//     instead of the exact fp64 table: with the exact residual r = c - q held in LDS,
+//         ||r_s - p||^2 = ||r_s||^2 + ||p||^2 - 2 r_s.p
+//     the dot products run on an fp32 copy of the codebook (128 KiB for 16 x 256 x 8, L2-resident, transposed so that a
+//     lane's four entries are one 16-byte load per dimension), ||p||^2 comes from a 16 KiB table, ||r_s||^2 is computed in
+//     fp64 once per (query, sub-quantizer).  The fp32 evaluation is certified: a rigorous error term is subtracted from
+//     the minima, every rounding of the quantisation is directed downwards, so the filter can only under-estimate (it
+//     never drops a code with d <= T).  Nothing is precomputed per cell or per query.
 //   * the EXACT distance is computed only for the filter's survivors, four lanes per survivor, each lane building the
 //     m/4 table entries it needs in the reference's order (t ascending, IVFPQ.java:531-534) and the sum passed
 //     through the quad in sub-quantizer order (s ascending, :435-438) -- same bits as a lookup in the fp64 table.
@@ -30,15 +30,18 @@
 #define GRP_VR 128     // survivors verified per round: 4 lanes each
 #define GRP_SEGU 2     // codes per thread per segment
 #define GRP_SEG (GRP_NT * GRP_SEGU)
+#ifndef GRP_BIS
+#define GRP_BIS 0
+#endif
 #ifndef GRP_WPS
-#define GRP_WPS 2  // waves per SIMD the register allocation is held to (blocks per CU x 2)
+#define GRP_WPS 4  // waves per SIMD the register allocation is held to (blocks per CU x 2)
 #endif
 
 struct GrpParams {
     ScanParams S;             // Q, coarse, perm, list_off, codes, order (sorted pairs), T, pool_*, D, m, ks, dsub, w, transform, chunk, K1, poolq
     const double *pq;         // [m][ks][dsub] (file order)
-    const float *cpn;         // [C][m][256]   ||p||^2 - 2 c_s.p   (+inf beyond ks)
-    const float *qp2;         // [nq][m][256]  2 q_s.p              (0 beyond ks)
+    const float *pq32T;       // [m][dsub][256] fp32 copy of the codebook, entry index innermost (0 beyond ks)
+    const float *pn32;        // [m][256]       ||p_sj||^2 (+inf beyond ks: such an entry never wins a minimum)
     const double *pnmax;      // [2][m]: max_j ||p_sj||, max_j ||p_sj||^2
     const int4 *gdesc;        // per group: {cell, first index into order[], number of pairs (1..G), 0}
     const int32_t *n_groups;  // device-side count
@@ -46,16 +49,17 @@ struct GrpParams {
     u32 *fb_count;            // items handed to K3f: (pair, chunk)
     int32_t *fb_items, *fb_ch;
     int cb;                   // candidate buffer entries per query: power of two >= K1 + GRP_VR
+    unsigned long long *stat; // null, or: [0] += filter survivors that were verified exactly
 };
 
 // LDS layout, shared by host (size) and device (offsets)
 struct GrpLds {
-    size_t lut8, tr, ctr, ckey, cpos, queue, sT, err, nrf, mn, inv, misc, total;
+    size_t lut8, tr, tr32, ckey, cpos, queue, sT, err, nrf, mn, inv, misc, total;
     __host__ __device__ GrpLds(int M, int G, int D, int cb) {
         size_t o = 0;
         lut8 = o; o += (size_t)G * M * 256;
         tr = o; o += (size_t)G * D * 8;
-        ctr = o; o += (size_t)D * 8;
+        tr32 = o; o += (size_t)G * D * 4;  // fp32 copy of the residuals (table build)
         ckey = o; o += (size_t)G * cb * 8;
         sT = o; o += (size_t)G * 8;
         err = o; o += (size_t)G * M * 8;
@@ -95,29 +99,17 @@ __device__ __forceinline__ double quad_last_f64(double x) {
     return __longlong_as_double((long long)(((u64)hi << 32) | lo));
 }
 
-// ---- index-side table: CPN[c][s][j] = ||p_sj||^2 - 2 <c'_s, p_sj>, c' = the centroid after the permutation --------
-// (fp64 arithmetic, one rounding to fp32; entries beyond ks are +inf so that they never win a minimum)
-__global__ __launch_bounds__(256) void k_cpn_table(const double *__restrict__ coarse, const double *__restrict__ pqT,
-                                                   const int32_t *__restrict__ perm, float *__restrict__ cpn, int D, int m, int ks,
-                                                   int dsub) {
-    extern __shared__ double s_c[];  // [D]
-    const int c = blockIdx.x, j = threadIdx.x;
-    for (int i = j; i < D; i += 256) s_c[i] = coarse[(size_t)c * D + (perm ? perm[i] : i)];
-    __syncthreads();
-    for (int s = 0; s < m; s++) {
-        float out = __int_as_float(0x7F800000);
-        if (j < ks) {
-            const double *pp = pqT + (size_t)s * dsub * ks + j;
-            double pn = 0.0, cp = 0.0;
-            for (int t = 0; t < dsub; t++) {
-                const double p = pp[(size_t)t * ks];
-                pn += p * p;
-                cp += s_c[s * dsub + t] * p;
-            }
-            out = (float)(pn - 2.0 * cp);
-        }
-        cpn[((size_t)c * m + s) * 256 + j] = out;
+// ---- index-side tables: fp32 codebook, entry index innermost, and ||p_sj||^2 (fp64 sum, one rounding) -------------
+__global__ __launch_bounds__(256) void k_pq32_table(const double *__restrict__ pqT, float *__restrict__ pq32T, float *__restrict__ pn32,
+                                                    int m, int ks, int dsub) {
+    const int s = blockIdx.x, j = threadIdx.x;
+    double pn = 0.0;
+    for (int t = 0; t < dsub; t++) {
+        const double p = j < ks ? pqT[((size_t)s * dsub + t) * ks + j] : 0.0;
+        pq32T[((size_t)s * dsub + t) * 256 + j] = (float)p;
+        pn += p * p;
     }
+    pn32[(size_t)s * 256 + j] = j < ks ? (float)pn : __int_as_float(0x7F800000);
 }
 // pnmax[s] = max_j ||p_sj|| * (1 + 1e-12), pnmax[m + s] = max_j ||p_sj||^2 * (1 + 1e-12)
 __global__ __launch_bounds__(256) void k_pn_max(const double *__restrict__ pqT, double *__restrict__ pnmax, int m, int ks, int dsub) {
@@ -146,37 +138,6 @@ __global__ __launch_bounds__(256) void k_pn_max(const double *__restrict__ pqT, 
         pnmax[m + s] = a * (1.0 + 1e-12);
     }
 }
-// ---- batch-side table: QP2[q][s][j] = 2 <q'_s, p_sj> (fp64, one rounding to fp32; 0 beyond ks) --------------------
-#define GRP_QT 8
-__global__ __launch_bounds__(256) void k_qp_table(const double *__restrict__ Q, const double *__restrict__ pqT,
-                                                  const int32_t *__restrict__ perm, float *__restrict__ qp2, int D, int m, int ks,
-                                                  int dsub, long long nq) {
-    extern __shared__ double s_q[];  // [GRP_QT][D]
-    const long long q0 = (long long)blockIdx.x * GRP_QT;
-    const int j = threadIdx.x;
-    for (int i = j; i < GRP_QT * D; i += 256) {
-        const int qi = i / D, d = i - qi * D;
-        s_q[i] = (q0 + qi < nq) ? Q[(size_t)(q0 + qi) * D + (perm ? perm[d] : d)] : 0.0;
-    }
-    __syncthreads();
-    for (int s = 0; s < m; s++) {
-        double acc[GRP_QT];
-#pragma unroll
-        for (int qi = 0; qi < GRP_QT; qi++) acc[qi] = 0.0;
-        if (j < ks) {
-            const double *pp = pqT + (size_t)s * dsub * ks + j;
-            for (int t = 0; t < dsub; t++) {
-                const double p = pp[(size_t)t * ks];
-#pragma unroll
-                for (int qi = 0; qi < GRP_QT; qi++) acc[qi] += s_q[qi * D + s * dsub + t] * p;
-            }
-        }
-#pragma unroll
-        for (int qi = 0; qi < GRP_QT; qi++)
-            if (q0 + qi < nq) qp2[((size_t)(q0 + qi) * m + s) * 256 + j] = (float)(2.0 * acc[qi]);
-    }
-}
-
 // ---- groups: the pairs of a cell (contiguous in order[]) in runs of G -----------------------------------------------
 // single block; also zeroes the hand-back counter of this step
 __global__ __launch_bounds__(1024) void k_group_build(const int32_t *__restrict__ cnt, const int32_t *__restrict__ start, int C, int G,
@@ -209,19 +170,79 @@ __device__ __forceinline__ void grp_prune(u64 *ckey, u32 *cpos, u32 *s_cnt, u64 
     __syncthreads();
 }
 
-template <int M, int G>
+// fp32 table entries of sub-quantizer s for the G queries of a group: Av[i][k] = ||r_s||^2 + ||p||^2 - 2 r_s.p for the
+// entries j = 4 lane + k (r from the fp32 copy of the residuals in LDS, broadcast reads)
+template <int M, int G, int DSUB>
+__device__ __forceinline__ void grp_entries(float (&Av)[G][4], const int s, const int lane, const float *__restrict__ pq32T,
+                                            const float *__restrict__ pn32, const float *s_tr32, const float *s_nrf, const int D,
+                                            const int dsub) {
+    const u32 col = (u32)s * 256u + 4u * (u32)lane;
+    const float4 pn4 = *(const float4 *)(pn32 + col);
+    float4 dot[G];
+#pragma unroll
+    for (int i = 0; i < G; i++) dot[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const u32 pbase = (u32)s * (u32)dsub * 256u + 4u * (u32)lane;
+    const float *rrow = s_tr32 + s * dsub;
+#pragma unroll 2
+    for (int t = 0; t < (DSUB > 0 ? DSUB : dsub); t++) {
+        const float4 p4 = *(const float4 *)(pq32T + (pbase + (u32)t * 256u));
+#pragma unroll
+        for (int i = 0; i < G; i++) {
+            const float r = rrow[i * D + t];  // (broadcast read)
+            dot[i].x = fmaf(r, p4.x, dot[i].x);
+            dot[i].y = fmaf(r, p4.y, dot[i].y);
+            dot[i].z = fmaf(r, p4.z, dot[i].z);
+            dot[i].w = fmaf(r, p4.w, dot[i].w);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < G; i++) {
+        const float nrf = s_nrf[i * M + s];
+        Av[i][0] = fmaf(-2.f, dot[i].x, nrf + pn4.x);
+        Av[i][1] = fmaf(-2.f, dot[i].y, nrf + pn4.y);
+        Av[i][2] = fmaf(-2.f, dot[i].z, nrf + pn4.z);
+        Av[i][3] = fmaf(-2.f, dot[i].w, nrf + pn4.w);
+    }
+}
+
+template <int DSUB>
+__device__ __forceinline__ double grp_exact_entry(const double *tv, const double *__restrict__ pp, int dsub_rt) {
+    double acc = 0.0;
+    if constexpr (DSUB > 0) {
+        double pv[DSUB];
+#pragma unroll
+        for (int t = 0; t < DSUB; t += 2) {
+            const double2 v = *(const double2 *)(pp + t);
+            pv[t] = v.x;
+            pv[t + 1] = v.y;
+        }
+#pragma unroll
+        for (int t = 0; t < DSUB; t++) {
+            const double df = tv[t] - pv[t];
+            acc += df * df;
+        }
+    } else {
+        for (int t = 0; t < dsub_rt; t++) {
+            const double df = tv[t] - pp[t];
+            acc += df * df;
+        }
+    }
+    return acc;
+}
+
+// DSUB = dimensions per sub-quantizer as a compile-time constant (4 / 8 / 16), or 0 = run-time value
+template <int M, int G, int DSUB>
 __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P) {
     static_assert(M % 8 == 0 && G <= 8 && G * M * 256 <= 65536, "imm offsets of the table reads");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LQ = M * 256;  // bytes of one query's u8 table
     constexpr int SPW = M / 8;   // sub-quantizers per wave in the table build
-    constexpr int GH = G > 4 ? G / 2 : G;  // queries per round of the table build
     constexpr int EPL = M / 4;   // exact entries per lane of a verifying quad
-    const int D = P.S.D, ks = P.S.ks, dsub = P.S.dsub, cb = P.cb, K1 = P.S.K1;
+    const int D = P.S.D, ks = P.S.ks, dsub = DSUB > 0 ? DSUB : P.S.dsub, cb = P.cb, K1 = P.S.K1;
     const GrpLds L(M, G, D, cb);
     unsigned char *lut8 = smem + L.lut8;
     double *s_tr = (double *)(smem + L.tr);
-    double *s_ctr = (double *)(smem + L.ctr);
+    float *s_tr32 = (float *)(smem + L.tr32);
     u64 *ckey = (u64 *)(smem + L.ckey);
     u32 *cpos = (u32 *)(smem + L.cpos);
     u32 *s_queue = (u32 *)(smem + L.queue);
@@ -257,130 +278,131 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
         const unsigned char *codes = (const unsigned char *)P.S.codes + (size_t)beg * M;
 
         // ---- (a) the group's pairs, thresholds, counters ---------------------------------------------------------
-        if (tid < G) {
-            int q = 0, pr = 0;
-            u64 T = 0;
-            if (tid < np) {
-                const int e = P.S.order[first + tid];
-                q = e / P.S.w;
-                pr = e - q * P.S.w;
-                T = __hip_atomic_load(P.S.T + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (Loads whose 64-bit address depends on an index are kept out of divergent regions throughout this kernel: every
+        //  thread computes a valid address -- clamped to the group's last pair -- and only the stores are predicated.  hipcc
+        //  (ROCm 7.2) otherwise produced wild addresses here, as described at pair_keep() in mmidx_kernels.h.)
+        {
+            const int tl = tid < np ? tid : np - 1;
+            const int e = P.S.order[first + tl];
+            const int q = e / P.S.w;
+            const int pr = e - q * P.S.w;
+            const u64 T = __hip_atomic_load(P.S.T + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid < G) {
+                s_q[tid] = q;  // (slots past np repeat the last pair; their state is "nothing to do")
+                s_pr[tid] = pr;
+                s_T[tid] = tid < np ? T : 0;
+                s_ccnt[tid] = 0;
             }
-            s_q[tid] = q;
-            s_pr[tid] = pr;
-            s_T[tid] = T;
-            s_ccnt[tid] = 0;
         }
         if (tid < 3) {
             s_new[tid] = 0;
             s_qvalid[tid] = 0xFFFFFFFFu;
         }
         __syncthreads();
-        // ---- (b) transformed centroid and residuals (exact: centroid - q, IVFPQ.java:645, then the permutation) ----
-        for (int idx = tid; idx < (G + 1) * D; idx += GRP_NT) {
+        // ---- (b) transformed residuals (exact: centroid - q, IVFPQ.java:645, then the permutation) + fp32 copies -------
+        for (int idx = tid; idx < G * D; idx += GRP_NT) {
             const int i = idx / D, d = idx - i * D;
             const int src = P.S.perm ? P.S.perm[d] : d;
-            const double cv = P.S.coarse[(size_t)cell * D + src];
-            if (i == G) s_ctr[d] = cv;
-            else if (i < np) s_tr[i * D + d] = cv - P.S.Q[(size_t)s_q[i] * D + src];
+            const double r = P.S.coarse[(size_t)cell * D + src] - P.S.Q[(size_t)s_q[i] * D + src];
+            s_tr[idx] = r;
+            s_tr32[idx] = (float)r;
         }
         __syncthreads();
+#if GRP_BIS == 1
+        continue;
+#endif
         // ---- (c) per (query, sub-quantizer): ||r_s||^2 and the error term of the fp32 table ----------------------
         if (tid < G * M) {
             const int i = tid / M, s = tid - i * M;
-            double nr = 0.0, cs2 = 0.0;
-            if (i < np) {
-                for (int t = 0; t < dsub; t++) {
-                    const double r = s_tr[i * D + s * dsub + t], c = s_ctr[s * dsub + t];
-                    nr += r * r;
-                    cs2 += c * c;
-                }
+            double nr = 0.0;
+            for (int t = 0; t < dsub; t++) {
+                const double r = s_tr[i * D + s * dsub + t];
+                nr += r * r;
             }
-            // |fp32 table entry - exact entry| <= 3 * 2^-24 * (nr + pn + 2 (|c_s| + |q_s|) |p|), |q_s| <= |c_s| + |r_s|;
-            // 2^-22 leaves a factor for the fp64 evaluation order of the exact entry
+            // fp32 entry = fl(fl(nrf + pn32) - 2 dot32(r32, p32)): input roundings 2^-24 each, dsub fused steps, two final
+            // roundings:  |entry - exact| <= 2^-24 [3 (nr + pn) + (2 dsub + 8.1) |r_s| |p|]; 1.01 and the absolute term cover
+            // the fp64 evaluation order of nr / of the exact entry and flushed denormals
             const double pm = P.pnmax[s], pm2 = P.pnmax[M + s];
-            s_err[tid] = 0x1p-22 * (nr + pm2 + 2.0 * (2.0 * sqrt(cs2) + sqrt(nr)) * pm);  // (inf / nan for huge inputs: caught in (e))
+            s_err[tid] = 0x1p-24 * 1.01 * (3.0 * (nr + pm2) + (2.0 * dsub + 9.0) * sqrt(nr) * pm) + 1e-30;  // (inf / nan for huge inputs: caught in (e))
             s_nrf[tid] = (float)nr;
         }
         __syncthreads();
-        // ---- (d)-(f) u8 rows, GH queries per round (the fp32 entries of a round stay in registers across its barriers) ----
+#if GRP_BIS == 2
+        continue;
+#endif
+        // ---- (d)-(f) u8 rows.  Two passes over the fp32 entries (minima, then quantisation): recomputing an entry is 2 dsub
+        //      flops and one L2-resident 16-byte load per dimension, cheaper than carrying G x M x 256 floats across the barriers
         u32 alive0 = 0;
-        float4 cp4[SPW];
+        float mnv[G][SPW];
+        // (d) per-sub-quantizer minima
 #pragma unroll
-        for (int ss = 0; ss < SPW; ss++) cp4[ss] = *(const float4 *)(P.cpn + ((size_t)cell * M + wv * SPW + ss) * 256 + 4 * lane);
-#pragma unroll 1
-        for (int i0 = 0; i0 < G; i0 += GH) {
-            if (i0 >= np) break;  // (uniform)
-            // (d) fp32 table entries and per-sub-quantizer minima
-            float A[GH][SPW][4];
-            float mnv[GH][SPW];
+        for (int ss = 0; ss < SPW; ss++) {
+            float Av[G][4];
+            grp_entries<M, G, DSUB>(Av, wv * SPW + ss, lane, P.pq32T, P.pn32, s_tr32, s_nrf, D, dsub);
 #pragma unroll
-            for (int ii = 0; ii < GH; ii++) {
-                const int i = i0 + ii;
-                if (i < np) {
-                    const float *qrow = P.qp2 + (size_t)s_q[i] * M * 256 + 4 * lane;
-#pragma unroll
-                    for (int ss = 0; ss < SPW; ss++) {
-                        const int s = wv * SPW + ss;
-                        const float4 qp = *(const float4 *)(qrow + s * 256);
-                        const float nrf = s_nrf[i * M + s];
-                        A[ii][ss][0] = (nrf + cp4[ss].x) + qp.x;
-                        A[ii][ss][1] = (nrf + cp4[ss].y) + qp.y;
-                        A[ii][ss][2] = (nrf + cp4[ss].z) + qp.z;
-                        A[ii][ss][3] = (nrf + cp4[ss].w) + qp.w;
-                        const float m4 = fminf(fminf(A[ii][ss][0], A[ii][ss][1]), fminf(A[ii][ss][2], A[ii][ss][3]));
-                        mnv[ii][ss] = wave_min_f32(m4);
-                        if (lane == 0) s_mn[i * M + s] = mnv[ii][ss];
-                    }
+            for (int i = 0; i < G; i++) {
+                const float m4 = fminf(fminf(Av[i][0], Av[i][1]), fminf(Av[i][2], Av[i][3]));
+                mnv[i][ss] = wave_min_f32(m4);
+                if (lane == 0) s_mn[i * M + wv * SPW + ss] = mnv[i][ss];
+            }
+        }
+        __syncthreads();
+#if GRP_BIS == 3
+        continue;
+#endif
+        // (e) per query: lower bound of the sum of minima, state, quantisation step
+        if (tid < G) {
+            int state = 1;  // 0 scan, 1 nothing to do (no pair / list exhausted: Smin >= T), 2 hand back to K3f
+            float inv = 0.f;
+            if (tid < np) {
+                double smin = 0.0, es = 0.0;
+                for (int s = 0; s < M; s++) {
+                    smin += (double)s_mn[tid * M + s] - s_err[tid * M + s];
+                    es += s_err[tid * M + s];
+                }
+                const double smin_lo = smin - fabs(smin) * 0x1p-40;
+                const u64 T = s_T[tid];
+                const double Td = keyd(T);
+                if (!(T < 0x7FF0000000000000ull) || !(es < 1e24) || !(fabs(smin_lo) < 1e30)) {
+                    state = 2;  // no finite threshold yet, or magnitudes beyond what fp32 carries
+                } else if (!(smin_lo < Td)) {
+                    state = 1;
+                } else if (!((Td - smin_lo) > Td * 0x1p-20)) {
+                    state = 2;  // degenerate step
+                } else {
+                    state = 0;
+                    inv = (float)((254.0 / (Td - smin_lo)) * (1.0 - 0x1p-18));
+                }
+                if (state == 2) {
+                    const u32 f = atomicAdd(P.fb_count, 1u);
+                    P.fb_items[f] = s_q[tid] * P.S.w + s_pr[tid];
+                    P.fb_ch[f] = ch;
                 }
             }
-            __syncthreads();
-            // (e) per query: lower bound of the sum of minima, state, quantisation step
-            if (tid >= i0 && tid < i0 + GH) {
-                int state = 1;  // 0 scan, 1 nothing to do (no pair / list exhausted: Smin >= T), 2 hand back to K3f
-                float inv = 0.f;
-                if (tid < np) {
-                    double smin = 0.0, es = 0.0;
-                    for (int s = 0; s < M; s++) {
-                        smin += (double)s_mn[tid * M + s] - s_err[tid * M + s];
-                        es += s_err[tid * M + s];
-                    }
-                    const double smin_lo = smin - fabs(smin) * 0x1p-40;
-                    const u64 T = s_T[tid];
-                    const double Td = keyd(T);
-                    if (!(T < 0x7FF0000000000000ull) || !(es < 1e24) || !(fabs(smin_lo) < 1e30)) {
-                        state = 2;  // no finite threshold yet, or magnitudes beyond what fp32 carries
-                    } else if (!(smin_lo < Td)) {
-                        state = 1;
-                    } else if (!((Td - smin_lo) > Td * 0x1p-20)) {
-                        state = 2;  // degenerate step
-                    } else {
-                        state = 0;
-                        inv = (float)((254.0 / (Td - smin_lo)) * (1.0 - 0x1p-18));
-                    }
-                    if (state == 2) {
-                        const u32 f = atomicAdd(P.fb_count, 1u);
-                        P.fb_items[f] = s_q[tid] * P.S.w + s_pr[tid];
-                        P.fb_ch[f] = ch;
-                    }
-                }
-                s_state[tid] = state;
-                s_inv[tid] = inv;
-            }
-            __syncthreads();
-            // (f) u8 rows: q8 = min(255, floor((A - min) * inv)), packed four per store
+            s_state[tid] = state;
+            s_inv[tid] = inv;
+        }
+        __syncthreads();
+#if GRP_BIS == 4
+        continue;
+#endif
+        // (f) u8 rows: q8 = min(255, floor((entry - min) * inv)), packed four per store
 #pragma unroll
-            for (int ii = 0; ii < GH; ii++) {
-                const int i = i0 + ii;
-                if (i < np && s_state[i] == 0) {
-                    alive0 |= 1u << i;
-                    const float inv = s_inv[i];
+        for (int i = 0; i < G; i++)
+            if (s_state[i] == 0) alive0 |= 1u << i;
+        if (alive0) {
 #pragma unroll
-                    for (int ss = 0; ss < SPW; ss++) {
+            for (int ss = 0; ss < SPW; ss++) {
+                float Av[G][4];
+                grp_entries<M, G, DSUB>(Av, wv * SPW + ss, lane, P.pq32T, P.pn32, s_tr32, s_nrf, D, dsub);
+#pragma unroll
+                for (int i = 0; i < G; i++) {
+                    if ((alive0 >> i) & 1u) {
+                        const float inv = s_inv[i];
                         u32 pk = 0;
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            const float x = fminf((A[ii][ss][k] - mnv[ii][ss]) * inv, 255.f);  // >= 0; +inf beyond ks -> 255
+                            const float x = fminf((Av[i][k] - mnv[i][ss]) * inv, 255.f);  // >= 0; +inf beyond ks -> 255
                             pk |= (u32)x << (8 * k);
                         }
                         *(u32 *)(lut8 + i * LQ + (wv * SPW + ss) * 256 + 4 * lane) = pk;
@@ -391,6 +413,9 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
         alive0 = (u32)__builtin_amdgcn_readfirstlane((int)alive0);
         __syncthreads();
         if (alive0 == 0) continue;
+#if defined(GRP_TIMING_STOP_AFTER_BUILD) || GRP_BIS == 5  // (timing experiments only: results are wrong)
+        continue;
+#endif
 
         // ---- (g) filter scan ---------------------------------------------------------------------------------------
         CodeVec<M, unsigned char> cur[GRP_SEGU], nxt[GRP_SEGU];
@@ -400,6 +425,7 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
             cur[u].load(codes + (size_t)(p < c1 ? p : c1 - 1) * M);
         }
         u32 carried = 0;  // queue entries carried over from earlier segments (block-uniform)
+        u32 n_verified = 0;
         int par = 0;
         for (int64_t seg = c0; seg < c1; seg += GRP_SEG) {
             const bool more = seg + GRP_SEG < c1;
@@ -410,16 +436,17 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
                     nxt[u].load(codes + (size_t)(p < c1 ? p : c1 - 1) * M);
                 }
             }
-            u32 acc[G][GRP_SEGU];
+            // one code of the lane at a time (64 codes per wave and early-out test); only the survivor bits outlive a code
+            u32 pend = 0;  // bit i * GRP_SEGU + u: code u of this lane survives query i's filter
             u32 posv[GRP_SEGU];
-            u32 alu[GRP_SEGU];
 #pragma unroll
-            for (int u = 0; u < GRP_SEGU; u++) {  // one code of the lane at a time: 64 codes per wave and early-out test
+            for (int u = 0; u < GRP_SEGU; u++) {
                 const int64_t p = seg + u * GRP_NT + tid;
                 posv[u] = (u32)p;
                 const u32 a0 = p < c1 ? 0u : 0x10000u;
+                u32 acc[G];
 #pragma unroll
-                for (int i = 0; i < G; i++) acc[i][u] = a0;
+                for (int i = 0; i < G; i++) acc[i] = a0;
                 u32 al = alive0;
 #pragma unroll
                 for (int sb = 0; sb < M / 4; sb++) {
@@ -433,27 +460,29 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
                     }
 #pragma unroll
                     for (int i = 0; i < G; i++) {
-                        if ((al >> i) & 1u) {  // wave-uniform
+                        if ((al >> i) & 1u) {  // wave-uniform; (one branch per query also keeps the compiler from fusing two queries'
+                                            //  rows into ds_read2st64_b64, which costs 8 LDS cycles against 2 x 2: measured 13.6 vs 11.1 ms)
                             uint2 rv[4];
 #pragma unroll
                             for (int k = 0; k < 4; k++) rv[k] = *(const uint2 *)(lut8 + i * LQ + (sb * 4 + k) * 256 + slot[k]);
 #pragma unroll
-                            for (int k = 0; k < 4; k++) acc[i][u] += __builtin_amdgcn_perm(rv[k].y, rv[k].x, sel[k]);
+                            for (int k = 0; k < 4; k++) acc[i] += __builtin_amdgcn_perm(rv[k].y, rv[k].x, sel[k]);
                             if (sb + 1 < M / 4) {
-                                if (__builtin_amdgcn_ballot_w64(acc[i][u] <= 254u) == 0) al &= ~(1u << i);
+                                if (__builtin_amdgcn_ballot_w64(acc[i] <= 254u) == 0) al &= ~(1u << i);
                             }
                         }
                     }
                 }
-                alu[u] = al;
+                // survivors: sum of lower bounds <= 254 (255 already certifies d > T)
+#pragma unroll
+                for (int i = 0; i < G; i++)
+                    if (((al >> i) & 1u) && acc[i] <= 254u) pend |= 1u << (i * GRP_SEGU + u);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            // survivors: sum of lower bounds <= 254 (255 already certifies d > T)
-            u32 pend = 0;
-#pragma unroll
-            for (int i = 0; i < G; i++)
-#pragma unroll
-                for (int u = 0; u < GRP_SEGU; u++)
-                    if (((alu[u] >> i) & 1u) && acc[i][u] <= 254u) pend |= 1u << (i * GRP_SEGU + u);
+#ifdef GRP_TIMING_NO_VERIFY
+            if (pend == 0x2345u) s_queue[1] = 1;  // (keeps the scan alive)
+            pend = 0;
+#endif
             // ---- append to the queue; verify when a round is full, at the end, or when the queue overflowed ----
             for (;;) {
                 u32 nw = 0;
@@ -493,6 +522,7 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
                     break;
                 }
                 const u32 nvalid = failed ? (qv < cnt ? qv : cnt) : cnt;
+                n_verified += nvalid;
                 // ---- exact verification, GRP_VR survivors per round, four lanes each --------------------------
                 for (u32 r0 = 0; r0 < nvalid; r0 += GRP_VR) {
                     __syncthreads();  // candidate counts of the previous round are final
@@ -530,12 +560,8 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
                         const u32 cs = (cw[k >> 2] >> (8 * (k & 3))) & 0xFFu;
                         const double *pp = P.pq + (u32)((s * ks + (int)cs) * dsub);
                         const double *tv = s_tr + i * D + s * dsub;
-                        double ac = 0.0;  // (t ascending from 0.0: IVFPQ.java:531-534)
-                        for (int t = 0; t < dsub; t++) {
-                            const double df = tv[t] - pp[t];
-                            ac += df * df;
-                        }
-                        en[k] = ac;
+                        // (t ascending from 0.0: IVFPQ.java:531-534; the loads of an entry are issued together)
+                        en[k] = grp_exact_entry<DSUB>(tv, pp, dsub);
                     }
                     // d = ((0 + e_0) + e_1) + ... in sub-quantizer order: lane 0's partial sum moves down the quad
                     double d = 0.0;
@@ -566,6 +592,7 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
         }
         // ---- (h) hand the candidates to the queries' pools (at most K1 per item) ------------------------------------
         __syncthreads();
+        if (tid == 0 && P.stat) atomicAdd(P.stat, (unsigned long long)n_verified);
 #pragma unroll 1
         for (int i = 0; i < G; i++) {
             if (!((alive0 >> i) & 1u)) continue;
