@@ -73,76 +73,83 @@ def timed_search(ix, Q, k, reps=5):
     return B / dt, iid.cpu().numpy(), dd.cpu().numpy(), cc.cpu().numpy()
 
 
-out = {}
-rng = np.random.default_rng(0)
-N, D, k = 1_000_000, 128, 100
+def run_all():
+    """cfg1-3 at their stated sizes; returns the dict bench.py publishes as `other_configs`"""
+    out = {}
+    rng = np.random.default_rng(0)
+    N, D, k = 1_000_000, 128, 100
 
-# ---- cfg2: flat PQ, iid N(0, I) base (a tight mixture would tie thousands of codes)
-m, ks = 8, 256
-base = rng.standard_normal((N, D))
-pq = np.stack([synth.kmeans(base[:30000, s * 16:(s + 1) * 16], ks, iters=5, seed=s) for s in range(m)])
-ix = mi.PQ(D, N, False, "", m, ks, 0, 512)
-ix.loadProductQuantizer(pq)
-t0 = time.time()
-ix.indexVectors(list(range(N)), base)
-t_index = time.time() - t0
-Q = rng.standard_normal((4096, D))
-qps, iid, dd, cc = timed_search(ix, Q, k)
-ref = o.OracleIndex(o.KIND_PQ, D, m, ks)
-ref.set_pq(pq)
-off, ids_e, codes_e = ix.export()
-ref.load_lists(off, ids_e, codes_e)
-ns = 256
-cpu_qps, cpu_nt, (rid, rd, rc) = cpu_best(lambda nt: ref.search_batch(Q[:ns], k, nthreads=nt), ns)
-out["cfg2_pq_adc_1M"] = {"qps_gpu": round(qps, 1), "index_s": round(t_index, 2), "ids_match": bool(np.array_equal(iid[:ns], rid)),
-                         "max_abs_ddist": float(np.max(np.abs(dd[:ns] - rd))), "cpu_qps": round(cpu_qps, 1), "cpu_threads": cpu_nt,
-                         "algorithmic_GBps": round(qps * N * m / 1e9, 1)}
-ix.close()
-del ref
+    # ---- cfg2: flat PQ, iid N(0, I) base (SURVEY 8d: a tight mixture would tie thousands of codes)
+    m, ks = 8, 256
+    base = rng.standard_normal((N, D))
+    pq = np.stack([synth.kmeans(base[:30000, s * 16:(s + 1) * 16], ks, iters=5, seed=s) for s in range(m)])
+    ix = mi.PQ(D, N, False, "", m, ks, 0, 512)
+    ix.loadProductQuantizer(pq)
+    t0 = time.time()
+    ix.indexVectors(list(range(N)), base)
+    t_index = time.time() - t0
+    Q = rng.standard_normal((4096, D))
+    qps, iid, dd, cc = timed_search(ix, Q, k)
+    ref = o.OracleIndex(o.KIND_PQ, D, m, ks)
+    ref.set_pq(pq)
+    off, ids_e, codes_e = ix.export()
+    ref.load_lists(off, ids_e, codes_e)
+    ns = 256
+    cpu_qps, cpu_nt, (rid, rd, rc) = cpu_best(lambda nt: ref.search_batch(Q[:ns], k, nthreads=nt), ns)
+    out["cfg2_pq_adc_1M"] = {"qps_gpu": round(qps, 1), "index_s": round(t_index, 2), "ids_match": bool(np.array_equal(iid[:ns], rid)),
+                             "max_abs_ddist": float(np.max(np.abs(dd[:ns] - rd))), "cpu_qps": round(cpu_qps, 1), "cpu_threads": cpu_nt,
+                             "algorithmic_GBps": round(qps * N * m / 1e9, 1)}
+    ix.close()
+    del ref
 
-# ---- cfg3: IVFPQ 1M, C = 1024, w = 8
-C_, w, m = 1024, 8, 16
-base, mu = synth.mixture(N, D, C_, sigma=0.15, seed=1234)
-coarse = mu
-ix = mi.IVFPQ(D, N, False, "", m, ks, 0, C_, 512)
-ix.loadCoarseQuantizer(coarse)
-cell = ((base[:40000] * base[:40000]).sum(1)[:, None] - 2 * base[:40000] @ coarse.T + (coarse * coarse).sum(1)[None]).argmin(1)
-resid = coarse[cell] - base[:40000]
-pq = np.stack([synth.kmeans(resid[:, s * 8:(s + 1) * 8], ks, iters=5, seed=s) for s in range(m)])
-ix.loadProductQuantizer(pq)
-ix.setW(w)
-t0 = time.time()
-ix.indexVectors(list(range(N)), base)
-t_index = time.time() - t0
-qi = rng.choice(N, 8192, replace=False)
-Q = base[qi] + 0.01 * rng.standard_normal((8192, D))
-qps, iid, dd, cc = timed_search(ix, Q, k)
-ref = o.OracleIndex(o.KIND_IVFPQ, D, m, ks, C_)
-ref.set_coarse(coarse)
-ref.set_pq(pq)
-ref.set_w(w)
-off, ids_e, codes_e = ix.export()
-ref.load_lists(off, ids_e, codes_e)
-ns = 2048
-cpu_qps, cpu_nt, (rid, rd, rc) = cpu_best(lambda nt: ref.search_batch(Q[:ns], k, nthreads=nt), ns)
-out["cfg3_ivfpq_1M"] = {"qps_gpu": round(qps, 1), "index_s": round(t_index, 2), "recall_at_1": float(np.mean(iid[:, 0] == qi)),
-                        "ids_match": bool(np.array_equal(iid[:ns], rid)), "max_abs_ddist": float(np.max(np.abs(dd[:ns] - rd))),
-                        "cpu_qps": round(cpu_qps, 1), "cpu_threads": cpu_nt}
-ix.close()
+    # ---- cfg3: IVFPQ 1M, C = 1024, w = 8
+    C_, w, m = 1024, 8, 16
+    base, mu = synth.mixture(N, D, C_, sigma=0.15, seed=1234)
+    coarse = mu
+    ix = mi.IVFPQ(D, N, False, "", m, ks, 0, C_, 512)
+    ix.loadCoarseQuantizer(coarse)
+    cell = ((base[:40000] * base[:40000]).sum(1)[:, None] - 2 * base[:40000] @ coarse.T + (coarse * coarse).sum(1)[None]).argmin(1)
+    resid = coarse[cell] - base[:40000]
+    pq = np.stack([synth.kmeans(resid[:, s * 8:(s + 1) * 8], ks, iters=5, seed=s) for s in range(m)])
+    ix.loadProductQuantizer(pq)
+    ix.setW(w)
+    t0 = time.time()
+    ix.indexVectors(list(range(N)), base)
+    t_index = time.time() - t0
+    qi = rng.choice(N, 8192, replace=False)
+    Q = base[qi] + 0.01 * rng.standard_normal((8192, D))
+    qps, iid, dd, cc = timed_search(ix, Q, k)
+    ref = o.OracleIndex(o.KIND_IVFPQ, D, m, ks, C_)
+    ref.set_coarse(coarse)
+    ref.set_pq(pq)
+    ref.set_w(w)
+    off, ids_e, codes_e = ix.export()
+    ref.load_lists(off, ids_e, codes_e)
+    ns = 2048
+    cpu_qps, cpu_nt, (rid, rd, rc) = cpu_best(lambda nt: ref.search_batch(Q[:ns], k, nthreads=nt), ns)
+    out["cfg3_ivfpq_1M"] = {"qps_gpu": round(qps, 1), "index_s": round(t_index, 2), "recall_at_1": float(np.mean(iid[:, 0] == qi)),
+                            "ids_match": bool(np.array_equal(iid[:ns], rid)), "max_abs_ddist": float(np.max(np.abs(dd[:ns] - rd))),
+                            "cpu_qps": round(cpu_qps, 1), "cpu_threads": cpu_nt}
+    ix.close()
 
-# ---- cfg1: Linear 10k x 128, k = 10 (host pointers in and out: PCIe-inclusive)
-n1, k1 = 10000, 10
-X1 = rng.standard_normal((n1, D))
-lin = mi.Linear(D, n1)
-lin.indexVectors(list(range(n1)), X1)
-Q1 = X1[rng.choice(n1, 1000, replace=False)] + 0.05 * rng.standard_normal((1000, D))
-lin.search_batch(k1, Q1[:16])
-t0 = time.perf_counter()
-for _ in range(5):
-    li, ld, lc = lin.search_batch(k1, Q1)
-qps1 = 5 * len(Q1) / (time.perf_counter() - t0)
-cpu1, cpu_nt, (bi, bd, bc) = cpu_best(lambda nt: o.linear_search_batch(X1, Q1, k1, nthreads=nt), len(Q1))
-out["cfg1_linear_10k"] = {"qps_gpu_host_buffers": round(qps1, 1), "ids_match": bool(np.array_equal(li, bi)),
-                          "max_abs_ddist": float(np.max(np.abs(ld - bd))), "cpu_qps": round(cpu1, 1), "cpu_threads": cpu_nt}
-lin.close()
-print(json.dumps(out))
+    # ---- cfg1: Linear 10k x 128, k = 10 (host pointers in and out: PCIe-inclusive)
+    n1, k1 = 10000, 10
+    X1 = rng.standard_normal((n1, D))
+    lin = mi.Linear(D, n1)
+    lin.indexVectors(list(range(n1)), X1)
+    Q1 = X1[rng.choice(n1, 1000, replace=False)] + 0.05 * rng.standard_normal((1000, D))
+    lin.search_batch(k1, Q1[:16])
+    t0 = time.perf_counter()
+    for _ in range(5):
+        li, ld, lc = lin.search_batch(k1, Q1)
+    qps1 = 5 * len(Q1) / (time.perf_counter() - t0)
+    cpu1, cpu_nt, (bi, bd, bc) = cpu_best(lambda nt: o.linear_search_batch(X1, Q1, k1, nthreads=nt), len(Q1))
+    out["cfg1_linear_10k"] = {"qps_gpu_host_buffers": round(qps1, 1), "ids_match": bool(np.array_equal(li, bi)),
+                              "max_abs_ddist": float(np.max(np.abs(ld - bd))), "cpu_qps": round(cpu1, 1), "cpu_threads": cpu_nt}
+    lin.close()
+
+    return out
+
+
+if __name__ == "__main__":
+    print(json.dumps(run_all()))
