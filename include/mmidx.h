@@ -122,6 +122,21 @@ int mmidx_sync_index(mmidx_index *h);
  * iids_out[n], codes_out[n][m] in stored form.  iids_out / codes_out may be NULL. */
 int mmidx_export(mmidx_index *h, int64_t *list_off_out, int32_t *iids_out, void *codes_out);
 
+/* ---- per-id utilities of IVFPQ / PQ ----------------------------------------------------------------
+ * mmidx_get_dims: the constructor arguments of the handle (vectorLength, numSubVectors, numProductCentroids,
+ *   numCoarseCentroids) and the bytes per stored code entry (1: byte codes, 2: short codes); any pointer may be NULL.
+ *   (Lets a binding check array lengths before it hands them over.)
+ * mmidx_get_codes: getInvertedListId (IVFPQ.java:865-880) and getPQCodeByte / getPQCodeShort (:801-855) for n internal
+ *   ids: cell_out[n] (-1 for PQ) and code_out[n][m] in stored form (int8 or int16).  An id that was never indexed fails
+ *   with MMIDX_ERR_INVALID_ARG, message "Id does not exist!" (IVFPQ.java:803-805).  Either output may be NULL.
+ * mmidx_distance: computeDistanceIVFADC(double[] qVector, String existingVecId), IVFPQ.java:464-497, for n (query, id) pairs:
+ *   residual of Q[i] w.r.t. the cell of iids[i] (:470), the handle's transformation (:473-477), then the sum over the
+ *   sub-quantizers of the lookup-table entries the stored code selects (:482-495), in the reference's order -- bit-equal to
+ *   the distance a search reports for that candidate.  For a PQ handle the query itself takes the place of the residual. */
+int mmidx_get_dims(const mmidx_index *h, int *D, int *m, int *ks, int *C, int *code_bytes);
+int mmidx_get_codes(mmidx_index *h, int64_t n, const int32_t *iids, int32_t *cell_out, void *code_out);
+int mmidx_distance(mmidx_index *h, int64_t n, const double *Q, const int32_t *iids, double *dist_out);
+
 /* ---- search ---------------------------------------------------------------------------------
  * computeNearestNeighborsInternal(k, double[]) : computeKnnIVFADC IVFPQ.java:408-450 /
  * computeKnnADC PQ.java:290-322, for nq queries Q[nq][D].  Row i of iid_out / dist_out holds

@@ -42,7 +42,7 @@ class Stats(C.Structure):
 
 def build(force=False):
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("mmidx_api.hip", "mmidx_learn.hip", "mmidx_kernels.h", "mmidx_frontend.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("mmidx_api.hip", "mmidx_learn.hip", "mmidx_kernels.h", "mmidx_scan_grp.h", "mmidx_frontend.h")]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "mmidx.h"))
     stale = not os.path.exists(SO_PATH) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
     if force or stale:
@@ -74,6 +74,9 @@ SIGNATURES = {
     "mmidx_assign_device": (C.c_int, [_vp, C.c_int64, _dp, _i32p, _vp]),
     "mmidx_sync_index": (C.c_int, [_vp]),
     "mmidx_export": (C.c_int, [_vp, _vp, _i32p, _vp]),
+    "mmidx_get_dims": (C.c_int, [_vp] + [C.POINTER(C.c_int)] * 5),
+    "mmidx_get_codes": (C.c_int, [_vp, C.c_int64, _i32p, _i32p, _vp]),
+    "mmidx_distance": (C.c_int, [_vp, C.c_int64, _dp, _i32p, _dp]),
     "mmidx_search": (C.c_int, [_vp, C.c_int, C.c_int64, _dp, _i32p, _dp, _i32p]),
     "mmidx_search_sdc": (C.c_int, [_vp, C.c_int, C.c_int64, _i32p, _i32p, _dp, _i32p]),
     "mmidx_search_device": (C.c_int, [_vp, C.c_int, C.c_int64, _dp, _i32p, _dp, _i32p, _vp]),

@@ -244,6 +244,9 @@ struct mmidx_index {
     int64_t last_ambiguous = 0;  // vectors of the last encode call that needed the exact redo
     DevBuf<long long> ws_dest;
     DevBuf<int4> ws_gdesc;
+    DevBuf<int32_t> ws_inv;   // iid -> position in the list-major arrays (-1: absent), built on demand
+    bool inv_valid = false;
+    int64_t inv_size = 0;
     DevBuf<int32_t> ws_gfb;
 
     // profiling: HIP events recorded on the launch stream, resolved lazily by mmidx_get_stats
@@ -367,12 +370,8 @@ int build_csr(mmidx_index *h) {
         h->d_pcodes = nullptr;
         h->cap_pend = 0;
         h->ws_dest.release();
-    h->ws_gdesc.release();
-    h->ws_gfb.release();
-    if (h->d_pq32T) (void)hipFree(h->d_pq32T);
-    if (h->d_pn32) (void)hipFree(h->d_pn32);
-    if (h->d_pnmax) (void)hipFree(h->d_pnmax);
     }
+    h->inv_valid = false;  // (iid -> position map of mmidx_get_codes / mmidx_distance)
     h->max_list_len = 0;
     h->nonempty_lists = 0;
     for (int c = 0; c < nl; c++) {
@@ -1492,6 +1491,7 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_dest.release();
     h->ws_gdesc.release();
     h->ws_gfb.release();
+    h->ws_inv.release();
     if (h->d_pq32T) (void)hipFree(h->d_pq32T);
     if (h->d_pn32) (void)hipFree(h->d_pn32);
     if (h->d_pnmax) (void)hipFree(h->d_pnmax);
@@ -2185,6 +2185,173 @@ int mmidx_get_stats(mmidx_index *h, mmidx_stats *out) {
     h->passa_launches = 0;
     h->host_passa_codes = 0;
     HIPCK(hipMemset(h->d_counters, 0, 4 * sizeof(u64)));
+    return MMIDX_OK;
+}
+
+/* ---- per-id utilities (IVFPQ.java:464-497, :801-880) ------------------------------------------------------------ */
+namespace {
+// iid -> position map over the list-major arrays; h->mu held by the caller
+int ensure_inverse(mmidx_index *h) {
+    if (h->inv_valid) return MMIDX_OK;
+    int32_t *d_max = nullptr;
+    HIPCK(hipMalloc((void **)&d_max, sizeof(int32_t)));
+    int32_t mx = -1;
+    HIPCK(hipMemcpy(d_max, &mx, sizeof(mx), hipMemcpyHostToDevice));
+    const long long n = h->n_csr;
+    if (n > 0) {
+        hipLaunchKernelGGL(k_iid_max, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_ids, n, d_max);
+        HIPCK(hipStreamSynchronize(h->stream));
+    }
+    hipError_t e = hipMemcpy(&mx, d_max, sizeof(mx), hipMemcpyDeviceToHost);
+    (void)hipFree(d_max);
+    if (e != hipSuccess) return fail(MMIDX_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
+    h->inv_size = (int64_t)mx + 1;
+    HIPCK(h->ws_inv.reserve((size_t)std::max<int64_t>(h->inv_size, 1)));
+    HIPCK(hipMemsetAsync(h->ws_inv.p, 0xFF, (size_t)std::max<int64_t>(h->inv_size, 1) * sizeof(int32_t), h->stream));
+    if (n > 0) hipLaunchKernelGGL(k_inv_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_ids, n, h->ws_inv.p);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(h->stream));
+    h->inv_valid = true;
+    return MMIDX_OK;
+}
+
+// device lookup of n records: d_pos[n], d_code[n][m] (stored form); host cells from the list offsets
+int lookup_records(mmidx_index *h, int64_t n, const int32_t *iids, int32_t **d_pos_out, void **d_code_out, std::vector<int32_t> &pos,
+                   std::vector<int32_t> &cells) {
+    int rc = build_csr(h);
+    if (rc) return rc;
+    rc = ensure_inverse(h);
+    if (rc) return rc;
+    int32_t *d_iids = nullptr, *d_pos = nullptr;
+    void *d_code = nullptr;
+    const size_t cbytes = (size_t)n * h->m * h->code_bytes;
+    HIPCK(hipMalloc((void **)&d_iids, std::max<size_t>((size_t)n * 4, 16)));
+    if (hipMalloc((void **)&d_pos, std::max<size_t>((size_t)n * 4, 16)) != hipSuccess || hipMalloc(&d_code, std::max<size_t>(cbytes, 16)) != hipSuccess) {
+        (void)hipFree(d_iids);
+        if (d_pos) (void)hipFree(d_pos);
+        return fail(MMIDX_ERR_HIP, "hipMalloc failed");
+    }
+    auto cleanup = [&]() {
+        (void)hipFree(d_iids);
+        (void)hipFree(d_pos);
+        (void)hipFree(d_code);
+    };
+    pos.assign((size_t)n, -1);
+    cells.assign((size_t)n, -1);
+    hipError_t e = hipMemcpyAsync(d_iids, iids, (size_t)n * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        const unsigned grid = (unsigned)((n + 255) / 256);
+        if (h->code_bytes == 1)
+            hipLaunchKernelGGL(k_lookup_codes<unsigned char>, dim3(grid), dim3(256), 0, h->stream, d_iids, (long long)n, h->ws_inv.p, (long long)h->inv_size,
+                               (const unsigned char *)h->d_codes, h->m, d_pos, (unsigned char *)d_code);
+        else
+            hipLaunchKernelGGL(k_lookup_codes<unsigned short>, dim3(grid), dim3(256), 0, h->stream, d_iids, (long long)n, h->ws_inv.p, (long long)h->inv_size,
+                               (const unsigned short *)h->d_codes, h->m, d_pos, (unsigned short *)d_code);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(pos.data(), d_pos, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+        cleanup();
+        return fail(MMIDX_ERR_HIP, "record lookup failed: %s", hipGetErrorString(e));
+    }
+    for (int64_t i = 0; i < n; i++) {
+        if (pos[(size_t)i] < 0) {
+            cleanup();
+            return fail(MMIDX_ERR_INVALID_ARG, "Id does not exist!");  // IVFPQ.java:803-805, :868-870
+        }
+        // list of a position: the last list whose start is <= pos
+        const auto it = std::upper_bound(h->h_off.begin(), h->h_off.end(), (int64_t)pos[(size_t)i]);
+        cells[(size_t)i] = (int32_t)(it - h->h_off.begin()) - 1;
+    }
+    (void)hipFree(d_iids);
+    *d_pos_out = d_pos;
+    *d_code_out = d_code;
+    return MMIDX_OK;
+}
+}  // namespace
+
+int mmidx_get_dims(const mmidx_index *h, int *D, int *m, int *ks, int *C, int *code_bytes) {
+    if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    if (D) *D = h->D;
+    if (m) *m = h->m;
+    if (ks) *ks = h->ks;
+    if (C) *C = h->C;
+    if (code_bytes) *code_bytes = (int)h->code_bytes;
+    return MMIDX_OK;
+}
+
+int mmidx_get_codes(mmidx_index *h, int64_t n, const int32_t *iids, int32_t *cell_out, void *code_out) {
+    if (!h || (n > 0 && !iids)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (n < 0) return fail(MMIDX_ERR_INVALID_ARG, "n < 0");
+    if (n == 0) return MMIDX_OK;
+    int rc = set_device(h);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    int32_t *d_pos = nullptr;
+    void *d_code = nullptr;
+    std::vector<int32_t> pos, cells;
+    rc = lookup_records(h, n, iids, &d_pos, &d_code, pos, cells);
+    if (rc) return rc;
+    hipError_t e = hipSuccess;
+    if (code_out) e = hipMemcpy(code_out, d_code, (size_t)n * h->m * h->code_bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d_pos);
+    (void)hipFree(d_code);
+    if (e != hipSuccess) return fail(MMIDX_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
+    if (cell_out)
+        for (int64_t i = 0; i < n; i++) cell_out[i] = h->kind == MMIDX_KIND_IVFPQ ? cells[(size_t)i] : -1;
+    return MMIDX_OK;
+}
+
+int mmidx_distance(mmidx_index *h, int64_t n, const double *Q, const int32_t *iids, double *dist_out) {
+    if (!h || (n > 0 && (!Q || !iids || !dist_out))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (n < 0) return fail(MMIDX_ERR_INVALID_ARG, "n < 0");
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (n == 0) return MMIDX_OK;
+    rc = set_device(h);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    int32_t *d_pos = nullptr;
+    void *d_code = nullptr;
+    std::vector<int32_t> pos, cells;
+    rc = lookup_records(h, n, iids, &d_pos, &d_code, pos, cells);
+    if (rc) return rc;
+    (void)hipFree(d_code);
+    double *dQ = nullptr, *d_out = nullptr;
+    int32_t *d_cell = nullptr;
+    hipError_t e = hipMalloc((void **)&dQ, (size_t)n * h->D * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, (size_t)n * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_cell, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(dQ, Q, (size_t)n * h->D * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_cell, cells.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        ScanParams P{};
+        P.Q = dQ;
+        P.coarse = h->d_coarse;
+        P.perm = h->d_perm;
+        P.rot = h->d_rot;
+        P.codes = h->d_codes;
+        P.D = h->D;
+        P.m = h->m;
+        P.ks = h->ks;
+        P.dsub = h->dsub;
+        P.transform = h->transform;
+        P.ivf = h->kind == MMIDX_KIND_IVFPQ;
+        const size_t lds = 2 * (size_t)h->D * 8;
+        if (h->code_bytes == 1)
+            hipLaunchKernelGGL(k_pair_distance<unsigned char>, dim3((unsigned)n), dim3(MMIDX_BLOCK), lds, h->stream, P, h->d_pq, d_pos, d_cell, d_out);
+        else
+            hipLaunchKernelGGL(k_pair_distance<unsigned short>, dim3((unsigned)n), dim3(MMIDX_BLOCK), lds, h->stream, P, h->d_pq, d_pos, d_cell, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(dist_out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_pos);
+    if (dQ) (void)hipFree(dQ);
+    if (d_out) (void)hipFree(d_out);
+    if (d_cell) (void)hipFree(d_cell);
+    if (e != hipSuccess) return fail(MMIDX_ERR_HIP, "mmidx_distance failed: %s", hipGetErrorString(e));
     return MMIDX_OK;
 }
 

@@ -4236,3 +4236,70 @@ __global__ void k_sdc_terms(const double *__restrict__ pq, const CodeT *__restri
     const double df = pq[r] - pq[((size_t)s * ks + b) * dsub + t];
     TT[e] = df * df;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// per-id utilities of IVFPQ (J/datastructures/IVFPQ.java:464-497 computeDistanceIVFADC, :801-880 getPQCodeByte /
+// getPQCodeShort / getInvertedListId): the reference reads the record {list id, code} of an internal id from BDB; here
+// the record lives in the list-major arrays, found through an iid -> position map built on demand.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_iid_max(const int32_t *__restrict__ ids, long long n, int32_t *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int v = i < n ? ids[i] : -1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(v, off);
+        v = o > v ? o : v;
+    }
+    if ((threadIdx.x & 63) == 0 && v >= 0) atomicMax(out, v);
+}
+__global__ void k_inv_scatter(const int32_t *__restrict__ ids, long long n, int32_t *__restrict__ inv) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && ids[i] >= 0) inv[ids[i]] = (int32_t)i;
+}
+// pos_out[i] = position of iids[i] (-1: not indexed); code_out[i][m] in stored form (byte: index - 128, PQ.java:552-558)
+template <typename CodeT>
+__global__ void k_lookup_codes(const int32_t *__restrict__ iids, long long n, const int32_t *__restrict__ inv, long long inv_size,
+                               const CodeT *__restrict__ codes, int m, int32_t *__restrict__ pos_out, CodeT *__restrict__ code_out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t id = iids[i];
+    const int32_t pos = (id >= 0 && id < inv_size) ? inv[id] : -1;
+    pos_out[i] = pos;
+    const long long src = pos >= 0 ? pos : 0;
+    for (int s = 0; s < m; s++) {
+        const CodeT v = pos >= 0 ? codes[src * m + s] : (CodeT)0;
+        code_out[i * m + s] = sizeof(CodeT) == 1 ? (CodeT)(v - 128) : v;
+    }
+}
+// computeDistanceIVFADC for pair i = (query Q[i], indexed vector at position pos[i] of list cell[i]): one block per pair;
+// residual / transform exactly as the search does (query_vector), then the table entries the code selects, t ascending,
+// summed in sub-quantizer order (IVFPQ.java:487-495 over :525-538).  Thread 0 runs the sequential chain.
+template <typename CodeT>
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_pair_distance(const ScanParams P, const double *__restrict__ pq, const int32_t *__restrict__ pos,
+                                                               const int32_t *__restrict__ cell, double *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *vec = (double *)smem;  // [2 * D]
+    const int i = blockIdx.x;
+    const int32_t p = pos[i];
+    const int c = P.ivf ? cell[i] : 0;
+    if (p < 0 || c < 0) {  // (uniform)
+        if (threadIdx.x == 0) out[i] = __longlong_as_double(0x7FF8000000000000ll);
+        return;
+    }
+    const double *tr = query_vector(P, i, c, vec);
+    if (threadIdx.x == 0) {
+        const CodeT *code = (const CodeT *)P.codes + (size_t)p * P.m;
+        double d = 0.0;
+        for (int s = 0; s < P.m; s++) {
+            const double *pp = pq + ((size_t)s * P.ks + code[s]) * P.dsub;
+            double acc = 0.0;
+            for (int t = 0; t < P.dsub; t++) {
+                const double df = tr[s * P.dsub + t] - pp[t];
+                acc += df * df;
+            }
+            d += acc;
+        }
+        out[i] = d;
+    }
+}

@@ -111,7 +111,14 @@ class AbstractSearchStructure:
         if vector.ndim != 1 or vector.shape[0] != self.vectorLength:
             raise MmidxError(N.ERR_WRONG_DIM, "The dimensionality of the vector is wrong!")
         self._create_mapping(id_)
-        self.indexVectorInternal(vector)
+        try:
+            self.indexVectorInternal(vector)
+        except Exception:
+            # a failed native call must not leave the id marked as indexed (the reference's createMapping precedes
+            # indexVectorInternal too, ASS:244-248, but its only failure there is the dimension check done above)
+            self._iid_to_id.pop(self.loadCounter, None)
+            self._id_to_iid.pop(id_, None)
+            raise
         self.loadCounter += 1
         return True
 
@@ -282,14 +289,14 @@ class _PQBase(AbstractSearchStructure):
         arrays loadIndexInMemory builds (IVFPQ.java:680-728) plus the id map; the BDB environment stays
         the system of record on the Java side."""
         off, iids, codes = self.export()
-        ids = np.array([str(self._iid_to_id.get(int(i), int(i))) for i in iids], dtype=object)
-        np.savez(filename, list_off=off, iids=iids, codes=codes, ids=ids, load_counter=np.int64(self.loadCounter),
-                 allow_pickle=True)
+        # ids as a fixed-width unicode array: loadable without pickle (an untrusted snapshot must not be able to run code)
+        ids = np.array([str(self._iid_to_id.get(int(i), int(i))) for i in iids], dtype=str)
+        np.savez(filename, list_off=off, iids=iids, codes=codes, ids=ids, load_counter=np.int64(self.loadCounter))
 
     def loadSnapshot(self, filename):
         """Inverse of saveSnapshot on an empty index of the same shape (quantizers loaded separately,
         as after the reference's constructor)."""
-        z = np.load(filename, allow_pickle=True)
+        z = np.load(filename, allow_pickle=False)
         off, iids, codes, ids = z["list_off"], z["iids"], z["codes"], z["ids"]
         nl = len(off) - 1
         cells = np.repeat(np.arange(nl, dtype=np.int32), np.diff(off).astype(np.int64))
@@ -301,6 +308,45 @@ class _PQBase(AbstractSearchStructure):
             self._iid_to_id[int(i)] = str(name)
             self._id_to_iid[str(name)] = int(i)
         self.loadCounter = int(z["load_counter"])
+
+    # -- per-id utilities (IVFPQ.java:464-497, :801-880; the reference reads the BDB record of the id) --
+    def _record(self, id_):
+        iid = self.getInternalId(id_)
+        if iid == -1:
+            raise MmidxError(N.ERR_INVALID_ARG, "Id does not exist!")
+        iids = np.array([iid], np.int32)
+        cell = np.zeros(1, np.int32)
+        code = np.zeros((1, self.numSubVectors), self._code_dtype)
+        N.check(N.lib().mmidx_get_codes(self._h, 1, iids.ctypes.data, cell.ctypes.data, code.ctypes.data))
+        return int(cell[0]), code[0]
+
+    def getPQCodeByte(self, id_):
+        """IVFPQ.java:801-824: the stored byte code (index - 128) of the vector with the given id"""
+        if self.getInternalId(id_) == -1:
+            raise MmidxError(N.ERR_INVALID_ARG, "Id does not exist!")
+        if self.numProductCentroids > 256:
+            raise MmidxError(N.ERR_INVALID_ARG, "Call the short variant of the method!")
+        return self._record(id_)[1]
+
+    def getPQCodeShort(self, id_):
+        """IVFPQ.java:833-856"""
+        if self.getInternalId(id_) == -1:
+            raise MmidxError(N.ERR_INVALID_ARG, "Id does not exist!")
+        if self.numProductCentroids <= 256:
+            raise MmidxError(N.ERR_INVALID_ARG, "Call the short variant of the method!")  # (sic: the reference's message)
+        return self._record(id_)[1]
+
+    def computeDistance(self, qVector, existingVecId):
+        """distance between a query vector and the code of an indexed vector: IVFPQ.computeDistanceIVFADC, IVFPQ.java:464-497
+        (for PQ: the same sum with the query in place of the residual)"""
+        iid = self.getInternalId(existingVecId)
+        if iid == -1:
+            raise MmidxError(N.ERR_INVALID_ARG, "Id does not exist!")
+        q = _f64(qVector, (1, self.vectorLength))
+        iids = np.array([iid], np.int32)
+        out = np.zeros(1, np.float64)
+        N.check(N.lib().mmidx_distance(self._h, 1, q.ctypes.data, iids.ctypes.data, out.ctypes.data))
+        return float(out[0])
 
     def size(self):
         n = C.c_int64()
@@ -425,6 +471,14 @@ class IVFPQ(_PQBase):
             self._iid_to_id[int(i)] = str(int(i))
             self._id_to_iid[str(int(i))] = int(i)
         self.loadCounter += len(iids)
+
+    def getInvertedListId(self, id_):
+        """IVFPQ.java:865-880: the inverted list (coarse cell) of the vector with the given id"""
+        return self._record(id_)[0]
+
+    def computeDistanceIVFADC(self, qVector, existingVecId):
+        """IVFPQ.java:464-497"""
+        return self.computeDistance(qVector, existingVecId)
 
     def listSizes(self):
         out = np.zeros(self.numCoarseCentroids, np.int32)

@@ -585,6 +585,60 @@ void mmo_index_list_sizes(const mmo_index *ix, int *out) {
     for (int i = 0; i < ix->nlists; i++) out[i] = ix->lists[i].len;
 }
 
+/* ---- per-id utilities: the reference reads the BDB record {listId, code} of the id (IVFPQ.java:760-772 layout);
+ * here the record is found by scanning the in-memory lists (test sizes only). ---- */
+static int find_record(const mmo_index *ix, int iid, int *cell_out, int *pos_out) {
+    for (int c = 0; c < ix->nlists; c++) {
+        const mmo_list *L = &ix->lists[c];
+        for (int j = 0; j < L->len; j++)
+            if (L->iids[j] == iid) {
+                *cell_out = c;
+                *pos_out = j;
+                return 1;
+            }
+    }
+    return 0;
+}
+/* getInvertedListId IVFPQ.java:865-880 + getPQCodeByte :801-824 / getPQCodeShort :833-856: cell (-1 for PQ) and the STORED
+ * code values (byte: idx-128, short: idx) widened to int; returns 0 when the id does not exist ("Id does not exist!") */
+int mmo_index_get_record(const mmo_index *ix, int iid, int *cell_out, int *code_out) {
+    int c, j;
+    if (!find_record(ix, iid, &c, &j)) return 0;
+    const mmo_list *L = &ix->lists[c];
+    *cell_out = ix->kind == MMO_KIND_IVFPQ ? c : -1;
+    for (int s = 0; s < ix->m; s++)
+        code_out[s] = ix->ks <= 256 ? (int)L->bcodes[(size_t)j * ix->m + s] : (int)L->scodes[(size_t)j * ix->m + s];
+    return 1;
+}
+/* computeDistanceIVFADC IVFPQ.java:464-497: residual w.r.t. the id's cell (:470), transformation (:473-477), lookup table
+ * (:480), sum over the sub-quantizers of the entries the stored code selects (:482-495).  PQ: the query itself is
+ * transformed (no residual).  Returns 0 when the id does not exist. */
+int mmo_index_distance(const mmo_index *ix, const double *q, int iid, double *dist_out) {
+    int c, j;
+    if (!find_record(ix, iid, &c, &j)) return 0;
+    const mmo_list *L = &ix->lists[c];
+    double *res = (double *)malloc(sizeof(double) * (size_t)ix->D);
+    double *tr = (double *)malloc(sizeof(double) * (size_t)ix->D);
+    double *lut = (double *)malloc(sizeof(double) * (size_t)ix->m * (size_t)ix->ks);
+    if (ix->kind == MMO_KIND_IVFPQ) {
+        residual_vector(ix, q, c, res);
+        apply_transform(ix, res, tr);
+    } else {
+        apply_transform(ix, q, tr);
+    }
+    mmo_index_lookup_adc(ix, tr, lut);
+    double distance = 0; /* :465 */
+    for (int s = 0; s < ix->m; s++) {
+        if (ix->ks <= 256) distance += lut[(size_t)s * ix->ks + (L->bcodes[(size_t)j * ix->m + s] + 128)]; /* :486 */
+        else distance += lut[(size_t)s * ix->ks + L->scodes[(size_t)j * ix->m + s]];                         /* :491 */
+    }
+    free(res);
+    free(tr);
+    free(lut);
+    *dist_out = distance;
+    return 1;
+}
+
 /* computeKnnSDC PQ.java:334-374 (byte codes; the reference dereferences pqByteCodes
  * unconditionally at :350, so short codes NPE there -- not restated). */
 int mmo_pq_search_sdc(const mmo_index *ix, int k, int iid, int *ids, double *dists) {

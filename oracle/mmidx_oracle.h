@@ -103,6 +103,9 @@ void mmo_index_nearest_coarse(const mmo_index *ix, const double *q, int w, int *
 /* computeLookupADC IVFPQ.java:525-538 / PQ.java:387-399 : lut[m][ks] */
 void mmo_index_lookup_adc(const mmo_index *ix, const double *qvec, double *lut);
 /* computeKnnSDC PQ.java:334-374 (byte codes only; the reference NPEs on short codes) */
+/* per-id utilities: IVFPQ.java:865-880 / :801-856 (record of an id) and :464-497 (computeDistanceIVFADC); 0 = unknown id */
+int mmo_index_get_record(const mmo_index *ix, int iid, int *cell_out, int *code_out);
+int mmo_index_distance(const mmo_index *ix, const double *q, int iid, double *dist_out);
 int mmo_pq_search_sdc(const mmo_index *ix, int k, int iid, int *ids, double *dists);
 
 /* batch driver used for the timed CPU baseline: nthreads concurrent readers, each issuing whole

@@ -67,6 +67,8 @@ def lib():
         "mmo_index_nearest_coarse": (None, [vp, dp, C.c_int, ip]),
         "mmo_index_lookup_adc": (None, [vp, dp, dp]),
         "mmo_pq_search_sdc": (C.c_int, [vp, C.c_int, C.c_int, ip, dp]),
+        "mmo_index_get_record": (C.c_int, [vp, C.c_int, ip, ip]),
+        "mmo_index_distance": (C.c_int, [vp, dp, C.c_int, dp]),
         "mmo_index_search_batch": (None, [vp, C.c_int, C.c_int, dp, ip, dp, ip, C.c_int]),
         "mmo_linear_search_batch": (None, [dp, C.c_int, C.c_int, C.c_int, C.c_int, dp, ip, dp, ip, C.c_int]),
         "mmo_index_probed_codes": (C.c_longlong, [vp, dp]),
@@ -318,6 +320,20 @@ class OracleIndex:
         lut = np.zeros((self.m, self.ks), np.float64)
         lib().mmo_index_lookup_adc(self._h, qp, lut.ctypes.data_as(C.POINTER(C.c_double)))
         return lut
+
+    def get_record(self, iid):
+        """(cell, stored code) of an internal id, or None when it does not exist (IVFPQ.java:801-880)"""
+        cell = C.c_int(0)
+        code = np.zeros(self.m, np.int32)
+        ok = lib().mmo_index_get_record(self._h, int(iid), C.byref(cell), code.ctypes.data_as(C.POINTER(C.c_int)))
+        return (cell.value, code) if ok else None
+
+    def distance(self, q, iid):
+        """computeDistanceIVFADC (IVFPQ.java:464-497); None when the id does not exist"""
+        q, qp = _d(q)
+        out = C.c_double(0.0)
+        ok = lib().mmo_index_distance(self._h, qp, int(iid), C.byref(out))
+        return out.value if ok else None
 
     def search_sdc(self, iid, k):
         ids = np.zeros(k, np.int32)

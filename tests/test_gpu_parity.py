@@ -6,6 +6,8 @@ the explicitly flagged tie fixtures, which pin the bounded-queue rule (assumptio
 """
 import importlib
 
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -143,6 +145,66 @@ def test_short_codes(mi, oracle):
     with pytest.raises(mi.MmidxError) as ei:
         ix.indexPQCode("x", 0, np.zeros(m, np.int8))
     assert ei.value.status == 4  # IVFPQ.java:358-361
+    ix.close()
+
+
+@pytest.mark.parametrize("ks,tr", [(256, 0), (256, 2), (256, 1), (512, 0)])
+def test_per_id_utilities(mi, oracle, ks, tr):
+    """computeDistanceIVFADC (IVFPQ.java:464-497), getPQCodeByte / getPQCodeShort (:801-856), getInvertedListId (:865-880)
+    against the oracle's restatement; the distance is also the one a search reports for that candidate."""
+    D, C, m, n, w, k = 32, 8, 8, 3000, 8, 50
+    p = synth.make_ivfpq_problem(n=n, D=D, C=C, m=m, ks=ks, nq=8, seed=40 + ks + tr)
+    rot = np.linalg.qr(np.random.default_rng(6).standard_normal((D, D)))[0] if tr == 1 else None
+    ix = mi.IVFPQ(D, n + 1, False, "", m, ks, tr, C, 512, rot=rot)
+    ix.loadCoarseQuantizer(p["coarse"])
+    ix.loadProductQuantizer(p["pq"])
+    ix.setW(w)
+    ref = oracle_ivfpq(oracle, p, D, m, ks, C, w, tr=tr, rot=rot)
+    ids = [f"v{i}" for i in range(n)]
+    ix.indexVectors(ids, p["base"])
+    ref.add_vectors(p["base"])
+    rng = np.random.default_rng(1)
+    for iid in rng.choice(n, 40, replace=False):
+        cell, code = ref.get_record(int(iid))
+        assert ix.getInvertedListId(ids[iid]) == cell
+        got = ix.getPQCodeByte(ids[iid]) if ks <= 256 else ix.getPQCodeShort(ids[iid])
+        assert got.dtype == (np.int8 if ks <= 256 else np.int16) and np.array_equal(got.astype(np.int32), code)
+        q = p["queries"][int(iid) % 8]
+        d = ix.computeDistanceIVFADC(q, ids[iid])
+        rd = ref.distance(q, int(iid))
+        if tr == 1:
+            assert abs(d - rd) <= 1e-9 * max(1.0, abs(rd))  # (rotation: summation order of the matrix product, assumption A2)
+        else:
+            assert d == rd
+    # the same number a search reports (w = C: every vector is a candidate)
+    iids, dists, counts = ix.search_batch(k, p["queries"][:2])
+    for qi in range(2):
+        for j in range(0, k, 7):
+            assert ix.computeDistanceIVFADC(p["queries"][qi], ids[iids[qi, j]]) == dists[qi, j]
+    # error behaviour: unknown id, wrong variant (IVFPQ.java:803-809, :835-841)
+    with pytest.raises(mi.MmidxError, match="Id does not exist!"):
+        ix.getInvertedListId("nope")
+    with pytest.raises(mi.MmidxError, match="Id does not exist!"):
+        ix.computeDistanceIVFADC(p["queries"][0], "nope")
+    with pytest.raises(mi.MmidxError, match="short variant"):
+        (ix.getPQCodeShort if ks <= 256 else ix.getPQCodeByte)(ids[0])
+    # batched C entry points + a record added through indexPQCode after the first lookups (the id map is rebuilt)
+    L = mi.lib()
+    if ks <= 256:
+        assert ix.indexPQCode("late", 3, np.full(m, -128, np.int8))
+        assert ix.getInvertedListId("late") == 3 and np.array_equal(ix.getPQCodeByte("late"), np.full(m, -128, np.int8))
+    q3 = np.ascontiguousarray(p["queries"][:3])
+    want = np.array([5, 17, 2999], np.int32)
+    out = np.zeros(3)
+    assert L.mmidx_distance(ix._h, 3, q3.ctypes.data, want.ctypes.data, out.ctypes.data) == 0
+    for i in range(3):
+        rd = ref.distance(q3[i], int(want[i]))
+        assert out[i] == rd or (tr == 1 and abs(out[i] - rd) <= 1e-9 * max(1.0, abs(rd)))
+    bad = np.array([5, n + 100], np.int32)
+    assert L.mmidx_get_codes(ix._h, 2, bad.ctypes.data, None, None) == 6 and b"Id does not exist!" in L.mmidx_last_error()
+    dims = [ctypes.c_int() for _ in range(5)]
+    assert L.mmidx_get_dims(ix._h, *[ctypes.byref(x) for x in dims]) == 0
+    assert [x.value for x in dims] == [D, m, ks, C, 1 if ks <= 256 else 2]
     ix.close()
 
 
