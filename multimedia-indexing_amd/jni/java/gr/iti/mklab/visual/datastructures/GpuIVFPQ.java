@@ -95,20 +95,29 @@ public class GpuIVFPQ extends AbstractSearchStructure {
 		MmidxNative.setPq(handle, flat);
 	}
 
-	/** hook 1 (ASS:267): encode on the GPU, append there, persist the same record as IVFPQ.java:760-772 */
+	/** hook 1 (ASS:267): encode on the GPU, append there, persist the same record as IVFPQ.java:760-792 */
 	protected void indexVectorInternal(double[] vector) throws Exception {
 		if (vector.length != vectorLength) {
 			throw new Exception("The dimensionality of the vector is wrong!");
 		}
 		int[] cell = new int[1];
-		byte[] code = new byte[numSubVectors];
-		MmidxNative.addVector(handle, loadCounter, vector, cell, code);
-		appendPersistentIndex(cell[0], code);
+		if (numProductCentroids <= 256) { // IVFPQ.java:342-347
+			byte[] code = new byte[numSubVectors];
+			MmidxNative.addVector(handle, loadCounter, vector, cell, code);
+			appendPersistentIndex(cell[0], code);
+		} else { // IVFPQ.java:349-354
+			short[] code = new short[numSubVectors];
+			MmidxNative.addVectorShort(handle, loadCounter, vector, cell, code);
+			appendPersistentIndex(cell[0], code);
+		}
 	}
 
 	public synchronized boolean indexPQCode(String id, int listId, byte[] code) throws Exception { // IVFPQ.java:357-386
 		if (numProductCentroids > 256) {
 			throw new Exception("Byte is not sufficient to enumerate the centroids of the product quantizer!");
+		}
+		if (code.length != numSubVectors) {
+			throw new Exception("The length of the code is wrong!");
 		}
 		if (loadCounter >= maxNumVectors) {
 			System.out.println("Maximum index capacity reached, no more vectors can be indexed!");
@@ -118,11 +127,65 @@ public class GpuIVFPQ extends AbstractSearchStructure {
 			System.out.println("Vector '" + id + "' already indexed!");
 			return false;
 		}
-		createMapping(id);
+		// native append first: a failure must not leave the id mapped
 		MmidxNative.addCodes(handle, 1, new int[] { loadCounter }, new int[] { listId }, code);
+		createMapping(id);
 		appendPersistentIndex(listId, code);
 		loadCounter++;
 		return true;
+	}
+
+	/** IVFPQ.java:464-497: distance between a query vector and the code of an indexed vector */
+	public double computeDistanceIVFADC(double[] qVector, String existingVecId) throws Exception {
+		int iid = getInternalId(existingVecId);
+		if (iid == -1) {
+			throw new Exception("Id does not exist!");
+		}
+		if (qVector.length != vectorLength) {
+			throw new Exception("The dimensionality of the vector is wrong!");
+		}
+		double[] out = new double[1];
+		MmidxNative.distance(handle, qVector, new int[] { iid }, out);
+		return out[0];
+	}
+
+	/** IVFPQ.java:801-824 (served from the HBM-resident lists; the BDB record holds the same bytes) */
+	public byte[] getPQCodeByte(String id) throws Exception {
+		int iid = getInternalId(id);
+		if (iid == -1) {
+			throw new Exception("Id does not exist!");
+		}
+		if (numProductCentroids > 256) {
+			throw new Exception("Call the short variant of the method!");
+		}
+		byte[] code = new byte[numSubVectors];
+		MmidxNative.getCodes(handle, new int[] { iid }, null, code);
+		return code;
+	}
+
+	/** IVFPQ.java:833-856 */
+	public short[] getPQCodeShort(String id) throws Exception {
+		int iid = getInternalId(id);
+		if (iid == -1) {
+			throw new Exception("Id does not exist!");
+		}
+		if (numProductCentroids <= 256) {
+			throw new Exception("Call the short variant of the method!"); // (sic, IVFPQ.java:839)
+		}
+		short[] code = new short[numSubVectors];
+		MmidxNative.getCodesShort(handle, new int[] { iid }, null, code);
+		return code;
+	}
+
+	/** IVFPQ.java:865-880 */
+	public int getInvertedListId(String id) throws Exception {
+		int iid = getInternalId(id);
+		if (iid == -1) {
+			throw new Exception("Id does not exist!");
+		}
+		int[] cell = new int[1];
+		MmidxNative.getCodes(handle, new int[] { iid }, cell, null);
+		return cell[0];
 	}
 
 	/** hook 2 (ASS:305): one native call; the queue is rebuilt only to satisfy the hook's type */
@@ -145,8 +208,10 @@ public class GpuIVFPQ extends AbstractSearchStructure {
 	/** loadIndexInMemory IVFPQ.java:680-728: stream the BDB records to the native bulk add */
 	private void loadIndexInMemory() throws Exception {
 		final int B = 1 << 16;
+		final boolean bytes = numProductCentroids <= 256;
 		int[] iids = new int[B], cells = new int[B];
-		byte[] codes = new byte[B * numSubVectors];
+		byte[] bcodes = bytes ? new byte[B * numSubVectors] : null;
+		short[] scodes = bytes ? null : new short[B * numSubVectors];
 		int n = 0;
 		DatabaseEntry key = new DatabaseEntry(), data = new DatabaseEntry();
 		Cursor cursor = iidToIvfpqDB.openCursor(null, null);
@@ -154,17 +219,27 @@ public class GpuIVFPQ extends AbstractSearchStructure {
 			TupleInput input = TupleBinding.entryToInput(data);
 			cells[n] = input.readInt();
 			iids[n] = IntegerBinding.entryToInt(key);
-			for (int i = 0; i < numSubVectors; i++)
-				codes[n * numSubVectors + i] = input.readByte();
+			for (int i = 0; i < numSubVectors; i++) {
+				if (bytes)
+					bcodes[n * numSubVectors + i] = input.readByte(); // IVFPQ.java:702-705
+				else
+					scodes[n * numSubVectors + i] = input.readShort(); // IVFPQ.java:707-710
+			}
 			if (++n == B) {
-				MmidxNative.addCodes(handle, n, iids, cells, codes);
+				if (bytes)
+					MmidxNative.addCodes(handle, n, iids, cells, bcodes);
+				else
+					MmidxNative.addCodesShort(handle, n, iids, cells, scodes);
 				n = 0;
 			}
 		}
 		cursor.close();
-		if (n > 0)
-			MmidxNative.addCodes(handle, n, java.util.Arrays.copyOf(iids, n), java.util.Arrays.copyOf(cells, n),
-					java.util.Arrays.copyOf(codes, n * numSubVectors));
+		if (n > 0) {
+			if (bytes)
+				MmidxNative.addCodes(handle, n, iids, cells, bcodes); // (the shim reads the first n records only)
+			else
+				MmidxNative.addCodesShort(handle, n, iids, cells, scodes);
+		}
 	}
 
 	private void appendPersistentIndex(int listId, byte[] code) { // IVFPQ.java:760-772, unchanged
@@ -172,6 +247,18 @@ public class GpuIVFPQ extends AbstractSearchStructure {
 		output.writeInt(listId);
 		for (int i = 0; i < numSubVectors; i++)
 			output.writeByte(code[i]);
+		DatabaseEntry data = new DatabaseEntry();
+		TupleBinding.outputToEntry(output, data);
+		DatabaseEntry key = new DatabaseEntry();
+		IntegerBinding.intToEntry(loadCounter, key);
+		iidToIvfpqDB.put(null, key, data);
+	}
+
+	private void appendPersistentIndex(int listId, short[] code) { // IVFPQ.java:780-792, unchanged
+		TupleOutput output = new TupleOutput();
+		output.writeInt(listId);
+		for (int i = 0; i < numSubVectors; i++)
+			output.writeShort(code[i]);
 		DatabaseEntry data = new DatabaseEntry();
 		TupleBinding.outputToEntry(output, data);
 		DatabaseEntry key = new DatabaseEntry();
@@ -195,7 +282,15 @@ public class GpuIVFPQ extends AbstractSearchStructure {
 	}
 
 	@Override
-	public void outputIndexingTimesInternal() { // hook 4 (ASS:729)
+	public void outputIndexingTimesInternal() { // hook 4 (ASS:729): empty in the reference; here the device-side timers
+		try {
+			double[] st = new double[7];
+			MmidxNative.stats(handle, st);
+			System.out.println("GPU search time since the last report (ms): total " + st[0] + ", coarse " + st[1] + ", scan "
+					+ st[2] + ", merge " + st[3] + "; codes scanned " + (long) st[4]);
+		} catch (Exception e) {
+			System.out.println("GPU statistics unavailable: " + e.getMessage());
+		}
 	}
 
 	@Override

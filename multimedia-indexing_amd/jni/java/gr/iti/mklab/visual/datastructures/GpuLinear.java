@@ -56,7 +56,7 @@ public class GpuLinear extends AbstractSearchStructure {
 		IntegerBinding.intToEntry(loadCounter, key);
 		iidToVectorDB.put(null, key, data);
 		if (loadIndexInMemory) {
-			MmidxNative.linearAdd(handle, 1, vector);
+			MmidxNative.linearAdd(handle, 1, vectorLength, vector);
 		}
 	}
 
@@ -64,7 +64,7 @@ public class GpuLinear extends AbstractSearchStructure {
 		int[] iids = new int[k];
 		double[] dists = new double[k];
 		int[] count = new int[1];
-		MmidxNative.linearSearch(handle, k, 1, queryVector, iids, dists, count); // -> mmidx_linear_search
+		MmidxNative.linearSearch(handle, k, 1, vectorLength, queryVector, iids, dists, count); // -> mmidx_linear_search
 		BoundedPriorityQueue<Result> nn = new BoundedPriorityQueue<Result>(new Result(), k);
 		for (int i = count[0] - 1; i >= 0; i--)
 			nn.offer(new Result(iids[i], dists[i])); // worst first keeps the tie order
@@ -104,12 +104,12 @@ public class GpuLinear extends AbstractSearchStructure {
 			n++;
 			counter++;
 			if (n == B) {
-				MmidxNative.linearAdd(handle, n, buf);
+				MmidxNative.linearAdd(handle, n, vectorLength, buf);
 				n = 0;
 			}
 		}
 		if (n > 0) {
-			MmidxNative.linearAdd(handle, n, java.util.Arrays.copyOf(buf, n * vectorLength));
+			MmidxNative.linearAdd(handle, n, vectorLength, java.util.Arrays.copyOf(buf, n * vectorLength));
 		}
 		cursor.close();
 	}

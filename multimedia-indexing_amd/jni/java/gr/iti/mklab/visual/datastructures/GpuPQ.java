@@ -77,11 +77,18 @@ public class GpuPQ extends AbstractSearchStructure {
 			throw new Exception("The dimensionality of the vector is wrong!");
 		}
 		int[] cell = new int[1];
-		byte[] code = new byte[numSubVectors];
-		MmidxNative.addVector(handle, loadCounter, vector, cell, code);
-		TupleOutput output = new TupleOutput(); // appendPersistentIndex PQ.java:491-502
-		for (int i = 0; i < numSubVectors; i++)
-			output.writeByte(code[i]);
+		TupleOutput output = new TupleOutput(); // appendPersistentIndex PQ.java:491-502 / :510-521
+		if (numProductCentroids <= 256) {
+			byte[] code = new byte[numSubVectors];
+			MmidxNative.addVector(handle, loadCounter, vector, cell, code);
+			for (int i = 0; i < numSubVectors; i++)
+				output.writeByte(code[i]);
+		} else {
+			short[] code = new short[numSubVectors];
+			MmidxNative.addVectorShort(handle, loadCounter, vector, cell, code);
+			for (int i = 0; i < numSubVectors; i++)
+				output.writeShort(code[i]);
+		}
 		DatabaseEntry data = new DatabaseEntry();
 		TupleBinding.outputToEntry(output, data);
 		DatabaseEntry key = new DatabaseEntry();
@@ -101,7 +108,10 @@ public class GpuPQ extends AbstractSearchStructure {
 	}
 
 	protected BoundedPriorityQueue<Result> computeNearestNeighborsInternal(int k, int iid) throws Exception {
-		// PQ.computeKnnSDC, PQ.java:334-374
+		// PQ.computeKnnSDC, PQ.java:334-374 (byte codes only: the reference dereferences pqByteCodes at :350)
+		if (numProductCentroids > 256) {
+			throw new Exception("Symmetric search needs byte codes (numProductCentroids <= 256)");
+		}
 		int[] iids = new int[k];
 		double[] dists = new double[k];
 		int[] count = new int[1];
@@ -114,25 +124,37 @@ public class GpuPQ extends AbstractSearchStructure {
 
 	private void loadIndexInMemory() throws Exception { // PQ.java:436-483
 		final int B = 1 << 16;
+		final boolean bytes = numProductCentroids <= 256;
 		int[] iids = new int[B];
-		byte[] codes = new byte[B * numSubVectors];
+		byte[] bcodes = bytes ? new byte[B * numSubVectors] : null;
+		short[] scodes = bytes ? null : new short[B * numSubVectors];
 		int n = 0, counter = 0;
 		DatabaseEntry key = new DatabaseEntry(), data = new DatabaseEntry();
 		Cursor cursor = iidToPqDB.openCursor(null, null);
 		while (cursor.getNext(key, data, LockMode.DEFAULT) == OperationStatus.SUCCESS && counter < maxNumVectors) {
 			TupleInput input = TupleBinding.entryToInput(data);
 			iids[n] = counter++; // iid == position, PQ.java:303,318
-			for (int i = 0; i < numSubVectors; i++)
-				codes[n * numSubVectors + i] = input.readByte();
+			for (int i = 0; i < numSubVectors; i++) {
+				if (bytes)
+					bcodes[n * numSubVectors + i] = input.readByte();
+				else
+					scodes[n * numSubVectors + i] = input.readShort();
+			}
 			if (++n == B) {
-				MmidxNative.addCodes(handle, n, iids, null, codes);
+				if (bytes)
+					MmidxNative.addCodes(handle, n, iids, null, bcodes);
+				else
+					MmidxNative.addCodesShort(handle, n, iids, null, scodes);
 				n = 0;
 			}
 		}
 		cursor.close();
-		if (n > 0)
-			MmidxNative.addCodes(handle, n, java.util.Arrays.copyOf(iids, n), null,
-					java.util.Arrays.copyOf(codes, n * numSubVectors));
+		if (n > 0) {
+			if (bytes)
+				MmidxNative.addCodes(handle, n, iids, null, bcodes);
+			else
+				MmidxNative.addCodesShort(handle, n, iids, null, scodes);
+		}
 	}
 
 	@Override
