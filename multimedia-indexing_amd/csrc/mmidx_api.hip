@@ -195,7 +195,13 @@ struct mmidx_index {
     int num_cus = 0;
     hipStream_t stream = nullptr;
     std::mutex mu;
-    std::mutex search_mu;  // host-pointer searches share the handle's workspaces and stream: one at a time
+    // every search / encode entry point (host or device pointers) shares the handle's workspaces: calls are serialised on the
+    // host by this mutex, and on the device by stream order -- a call arriving on another stream than the previous one first
+    // waits for that stream (DeviceCall below).  Recursive: the host entry points call the device ones.
+    std::recursive_mutex search_mu;
+    hipStream_t last_stream = nullptr;
+    bool last_stream_valid = false;
+    std::recursive_mutex add_mu;  // adds are `synchronized` in the reference (ASS:229, IVFPQ.java:357): one at a time
     Combiner comb;  // concurrent mmidx_search callers are served together (see mmidx_search)
     unsigned char *pin_stage = nullptr;  // pinned staging: queries in, (distances | ids | counts) out
     size_t pin_stage_cap = 0;
@@ -254,7 +260,7 @@ struct mmidx_index {
     mmidx_stats stats{};
     std::vector<hipEvent_t> evpool;  // groups of 6: start, coarse end, scan start, scan end, end, pass A end
     size_t ev_used = 0;
-    u64 *d_counters = nullptr;       // [0] scan codes, [1] tie fallbacks, [2] codes of the probe-rank-0 lists (pass A)
+    u64 *d_counters = nullptr;       // [0] scan codes, [1] tie fallbacks, [2] codes of the probe-rank-0 lists (pass A), [3] verified codes (K3g); [4] add-validation flag
     int64_t host_codes = 0;          // PQ: nq * n, known on the host
     int32_t launches = 0;
     int32_t passa_launches = 0;
@@ -262,6 +268,22 @@ struct mmidx_index {
 };
 
 namespace {
+
+// Serialises the calls that use a handle's workspaces (see mmidx_index::search_mu).  A _device entry point is asynchronous on
+// the caller's stream; when the previous call ran on a DIFFERENT stream its kernels may still be reading the workspaces, so
+// the new call waits for that stream first (no cost while a handle is driven from one stream, the usual case).
+struct DeviceCall {
+    mmidx_index *h;
+    hipStream_t st;
+    std::unique_lock<std::recursive_mutex> lk;
+    DeviceCall(mmidx_index *h_, hipStream_t st_) : h(h_), st(st_), lk(h_->search_mu) {
+        if (h->last_stream_valid && h->last_stream != st) (void)hipStreamSynchronize(h->last_stream);
+    }
+    ~DeviceCall() {
+        h->last_stream = st;
+        h->last_stream_valid = true;
+    }
+};
 
 int set_device(const mmidx_index *h) {
     HIPCK(hipSetDevice(h->device));
@@ -311,7 +333,10 @@ int build_csr(mmidx_index *h) {
     std::vector<int64_t> cnt((size_t)nl, 0), off_new((size_t)nl + 1, 0), cursor((size_t)nl);
     for (int64_t i = 0; i < np; i++) {
         int c = pcell[(size_t)i];
-        if (c < 0 || c >= nl) return fail(MMIDX_ERR_INVALID_ARG, "list id %d outside 0..%d", c, nl - 1);
+        if (c < 0 || c >= nl) {
+            h->n_pend = 0;  // (drop the pending batch rather than fail every later call on this handle)
+            return fail(MMIDX_ERR_INVALID_ARG, "list id %d outside 0..%d: %lld pending records dropped", c, nl - 1, (long long)np);
+        }
         cnt[(size_t)c]++;
     }
     if (h->h_off.empty()) h->h_off.assign((size_t)nl + 1, 0);
@@ -1387,7 +1412,7 @@ int mmidx_create(int kind, int D, int m, int ks, int C, int transform, const int
         delete h;
         return fail(MMIDX_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
     }
-    if (hipMalloc((void **)&h->d_counters, 4 * sizeof(u64)) != hipSuccess || hipMemset(h->d_counters, 0, 4 * sizeof(u64)) != hipSuccess) {
+    if (hipMalloc((void **)&h->d_counters, 8 * sizeof(u64)) != hipSuccess || hipMemset(h->d_counters, 0, 8 * sizeof(u64)) != hipSuccess) {
         delete h;
         return fail(MMIDX_ERR_HIP, "hipMalloc failed");
     }
@@ -1639,6 +1664,7 @@ int mmidx_encode_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) return MMIDX_OK;
+    DeviceCall call(h, st);
     if (h->code_bytes == 1) {
         // kernels produce centroid indices; the boundary carries the stored form idx - 128
         HIPCK(h->ws_tmp.reserve((size_t)n * h->m));
@@ -1687,6 +1713,8 @@ int mmidx_add_codes_device(mmidx_index *h, int64_t n, const int32_t *d_iids, con
     int rc = set_device(h);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::recursive_mutex> alk(h->add_mu);
+    DeviceCall call(h, h->stream);  // (the encoder uses the search workspaces, on the handle's own stream)
     std::lock_guard<std::mutex> lk(h->mu);
     if (st != h->stream) HIPCK(hipStreamSynchronize(st));
     rc = ensure_pending(h, n);
@@ -1705,7 +1733,24 @@ int mmidx_add_codes_device(mmidx_index *h, int64_t n, const int32_t *d_iids, con
     } else {
         HIPCK(hipMemcpyAsync((char *)h->d_pcodes + (size_t)o * h->m * 2, d_codes, (size_t)tot * 2, hipMemcpyDeviceToDevice, h->stream));
     }
+    // validate before committing: the records stay out of the index when a list id or a code value is out of range
+    HIPCK(hipMemsetAsync(h->d_counters + 4, 0, sizeof(int32_t), h->stream));
+    {
+        const unsigned grid = (unsigned)((n + 255) / 256);
+        const int32_t *pc = h->kind == MMIDX_KIND_IVFPQ ? h->d_pcell + o : nullptr;
+        if (h->code_bytes == 1)
+            hipLaunchKernelGGL(k_check_records<unsigned char>, dim3(grid), dim3(256), 0, h->stream, pc, h->nlists,
+                               (const unsigned char *)h->d_pcodes + (size_t)o * h->m, h->ks, h->m, (long long)n, (int32_t *)(h->d_counters + 4));
+        else
+            hipLaunchKernelGGL(k_check_records<unsigned short>, dim3(grid), dim3(256), 0, h->stream, pc, h->nlists,
+                               (const unsigned short *)h->d_pcodes + (size_t)o * h->m, h->ks, h->m, (long long)n, (int32_t *)(h->d_counters + 4));
+        HIPCK(hipGetLastError());
+    }
+    int32_t bad = 0;
+    HIPCK(hipMemcpyAsync(&bad, h->d_counters + 4, sizeof(bad), hipMemcpyDeviceToHost, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));
+    if (bad & 1) return fail(MMIDX_ERR_INVALID_ARG, "list id outside 0..%d: the batch was not added", h->nlists - 1);
+    if (bad & 2) return fail(MMIDX_ERR_INVALID_ARG, "code value outside 0..%d (numProductCentroids): the batch was not added", h->ks - 1);
     h->n_pend += n;
     return MMIDX_OK;
 }
@@ -1745,6 +1790,8 @@ int mmidx_add_vectors_device(mmidx_index *h, int64_t n, const double *dX, const 
     rc = set_device(h);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::recursive_mutex> alk(h->add_mu);
+    DeviceCall call(h, h->stream);  // (the encoder uses the search workspaces, on the handle's own stream)
     std::lock_guard<std::mutex> lk(h->mu);
     if (st != h->stream) HIPCK(hipStreamSynchronize(st));
     rc = ensure_pending(h, n);
@@ -1770,6 +1817,7 @@ int mmidx_add_vectors(mmidx_index *h, int64_t n, const double *X, const int32_t 
     if (n == 0) return MMIDX_OK;
     rc = set_device(h);
     if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> alk(h->add_mu);  // (the pending offset read below and the append are one step)
     const size_t cb = (size_t)h->m * h->code_bytes;
     const int64_t B = 1 << 18;
     for (int64_t i0 = 0; i0 < n; i0 += B) {
@@ -1807,6 +1855,7 @@ int mmidx_search_device(mmidx_index *h, int k, int64_t nq, const double *dQ, int
     if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
     if (nq > 0 && (!dQ || !d_iid_out || !d_dist_out || !d_count_out)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
     hipStream_t st = (hipStream_t)stream;
+    DeviceCall call(h, st);
     return search_common(h, k, nq, dQ, nullptr, 0, d_iid_out, d_dist_out, d_count_out, nullptr, nullptr, st);
 }
 
@@ -1908,7 +1957,7 @@ int mmidx_search(mmidx_index *h, int k, int64_t nq, const double *Q, int32_t *ii
     me.dist = dist_out;
     me.cnt = count_out;
     return combiner_submit(h->comb, me, MMIDX_COMB_MAX_Q, [h](SearchReq *const *batch, size_t nb) {
-        std::lock_guard<std::mutex> slk(h->search_mu);  // (id queries use the same workspaces and stream)
+        std::lock_guard<std::recursive_mutex> slk(h->search_mu);  // (id queries use the same workspaces and stream)
         return search_host_batch(h, batch, nb);
     });
 }
@@ -1923,7 +1972,7 @@ int mmidx_search_sdc(mmidx_index *h, int k, int64_t nq, const int32_t *iids, int
     int rc = check_ready(h);
     if (rc) return rc;
     if (nq == 0) return MMIDX_OK;
-    std::lock_guard<std::mutex> slk(h->search_mu);
+    std::lock_guard<std::recursive_mutex> slk(h->search_mu);
     rc = set_device(h);
     if (rc) return rc;
     {
@@ -1967,6 +2016,7 @@ int mmidx_coarse_device(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d
     rc = set_device(h);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    DeviceCall call(h, st);
     const int64_t qb = std::max<int64_t>(1, (2ll << 30) / ((int64_t)h->C * 8));
     for (int64_t q0 = 0; q0 < nq; q0 += qb) {
         const int64_t nb = std::min(qb, nq - q0);
@@ -1993,6 +2043,7 @@ int mmidx_search_partial_device(mmidx_index *h, int k, int64_t nq, const double 
     if (nq > 0 && (!dQ || !d_pdist || !d_pkey || !d_pcount)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
     if (h->kind == MMIDX_KIND_IVFPQ && nq > 0 && !d_cells) return fail(MMIDX_ERR_INVALID_ARG, "IVFPQ partial search needs the probe cells");
     hipStream_t st = (hipStream_t)stream;
+    DeviceCall call(h, st);
     return search_common(h, k, nq, dQ, h->kind == MMIDX_KIND_IVFPQ ? d_cells : nullptr, 1, nullptr, nullptr, d_pcount, d_pdist,
                          (long long *)d_pkey, st);
 }
@@ -2011,6 +2062,7 @@ static int shard_phase(mmidx_index *h, int k, int64_t nq, const double *dQ, cons
     if (nq == 0) return MMIDX_OK;
     rc = set_device(h);
     if (rc) return rc;
+    DeviceCall call(h, (hipStream_t)stream);
     {
         std::lock_guard<std::mutex> lk(h->mu);
         rc = build_csr(h);
@@ -2061,6 +2113,7 @@ int mmidx_assign_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_
     int rc = set_device(h);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    DeviceCall call(h, st);
     const int64_t step = 1 << 22;  // bounded scratch for the certified approximate path
     for (int64_t i0 = 0; i0 < n; i0 += step) {
         const int64_t nb = std::min(step, n - i0);

@@ -4303,3 +4303,17 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_pair_distance(const ScanParams 
         out[i] = d;
     }
 }
+
+// validation of appended records before they are committed (a bad list id would break every later CSR build, a code >= ks
+// would index past the lookup table): flag |= 1 for a list id outside [0, nlists), |= 2 for a code value >= ks
+template <typename CodeT>
+__global__ void k_check_records(const int32_t *__restrict__ cells, int nlists, const CodeT *__restrict__ codes, int ks, int m, long long n,
+                                int32_t *__restrict__ flag) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int bad = 0;
+    if (cells && (cells[i] < 0 || cells[i] >= nlists)) bad |= 1;
+    for (int s = 0; s < m; s++)
+        if ((int)codes[i * m + s] >= ks) bad |= 2;
+    if (bad) atomicOr(flag, bad);
+}

@@ -208,6 +208,29 @@ def test_per_id_utilities(mi, oracle, ks, tr):
     ix.close()
 
 
+def test_add_codes_validation_keeps_the_index_usable(mi, oracle):
+    """a record with a list id outside [0, C) or a code value >= ks must be rejected at add time, and the handle
+    must stay usable afterwards (the reference would throw ArrayIndexOutOfBounds at invertedLists[listId], IVFPQ.java:371)."""
+    D, C, m, ks, n, w, k = 16, 4, 4, 16, 400, 4, 5
+    p = synth.make_ivfpq_problem(n=n, D=D, C=C, m=m, ks=ks, nq=4, seed=9)
+    ix = mi.IVFPQ(D, n + 8, False, "", m, ks, 0, C, 512)
+    ix.loadCoarseQuantizer(p["coarse"])
+    ix.loadProductQuantizer(p["pq"])
+    ix.setW(w)
+    ix.indexVectors([str(i) for i in range(n)], p["base"])
+    before = ix.search_batch(k, p["queries"])
+    with pytest.raises(mi.MmidxError):
+        ix.loadIndex(np.array([n], np.int32), np.array([C + 3], np.int32), np.full((1, m), -128, np.int8))   # bad list id
+    with pytest.raises(mi.MmidxError):
+        ix.loadIndex(np.array([n], np.int32), np.array([0], np.int32), np.full((1, m), -128 + ks, np.int8))  # code == ks
+    assert ix.size() == n
+    after = ix.search_batch(k, p["queries"])
+    assert all(np.array_equal(a, b) for a, b in zip(before, after))
+    ix.loadIndex(np.array([n], np.int32), np.array([1], np.int32), np.full((1, m), -128, np.int8))
+    assert ix.size() == n + 1 and int(ix.listSizes().sum()) == n + 1
+    ix.close()
+
+
 def test_index_pq_code_roundtrip_and_incremental(mi, oracle):
     """encode -> indexPQCode == indexVector (IVFPQ.java:357-386), adds interleaved with searches."""
     D, C, m, ks, n, w, k = 32, 8, 8, 256, 1200, 8, 7
