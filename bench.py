@@ -129,12 +129,20 @@ def build_index(cx, mu, sigma, coarse_h, pq_h, nq_total, sharded_build):
     Qsrc = torch.zeros(nq_total, D, device=cx.dev, dtype=torch.float64)
     t0 = time.time()
     t_enc = 0.0
-    for c0 in range(0, N, a.chunk):
-        n = min(a.chunk, N - c0)
-        X = gen_chunk(cx, mu, sigma, c0, n)
-        sel = (qsrc >= c0) & (qsrc < c0 + n)
-        if sel.any():
-            Qsrc[sel] = X[qsrc[sel] - c0]
+    W = cx.world if sharded_build else 1
+    coll = sharded_build and cx.dist is not None
+    nchunks = (N + a.chunk - 1) // a.chunk
+    for round0 in range(0, nchunks, W):
+        # sharded build: in every round rank r encodes chunk round0 + r (1/W of the vectors per rank, not all of them) and the
+        # records travel to the rank that owns their inverted list (cell mod W) in one variable-size all-to-all per array
+        ci = round0 + (cx.rank if sharded_build else 0)
+        c0 = ci * a.chunk
+        n = max(0, min(a.chunk, N - c0)) if ci < nchunks else 0
+        X = gen_chunk(cx, mu, sigma, c0, n) if n > 0 else torch.empty(0, D, device=cx.dev, dtype=torch.float64)
+        if n > 0:
+            sel = (qsrc >= c0) & (qsrc < c0 + n)
+            if sel.any():
+                Qsrc[sel] = X[qsrc[sel] - c0]
         torch.cuda.synchronize()
         te = time.time()
         if not sharded_build:
@@ -142,16 +150,34 @@ def build_index(cx, mu, sigma, coarse_h, pq_h, nq_total, sharded_build):
         else:
             cells = torch.empty(n, dtype=torch.int32, device=cx.dev)
             codes = torch.empty(n, m, dtype=torch.int8, device=cx.dev)
-            cx.chk(L.mmidx_encode_device(h, n, X.data_ptr(), cells.data_ptr(), codes.data_ptr(), cx.stream))
-            own = sh_owner(cells, cx.world) == cx.rank
-            iids = (torch.arange(n, device=cx.dev, dtype=torch.int32) + c0)[own].contiguous()
-            oc = cells[own].contiguous()
-            ok = codes[own].contiguous()
+            if n > 0:
+                cx.chk(L.mmidx_encode_device(h, n, X.data_ptr(), cells.data_ptr(), codes.data_ptr(), cx.stream))
+            iids = torch.arange(n, device=cx.dev, dtype=torch.int32) + c0
+            owner = sh_owner(cells, cx.world).long()
+            order = torch.argsort(owner, stable=True)  # destination-major, arrival (iid) order kept inside a destination
+            iids, cells, codes = iids[order].contiguous(), cells[order].contiguous(), codes[order].contiguous()
+            send = torch.bincount(owner, minlength=cx.world)
+            if coll:
+                recv = torch.empty_like(send)
+                cx.dist.all_to_all_single(recv, send)
+                ssz, rsz = send.cpu().tolist(), recv.cpu().tolist()
+                nr = int(sum(rsz))
+                r_i = torch.empty(nr, dtype=torch.int32, device=cx.dev)
+                r_c = torch.empty(nr, dtype=torch.int32, device=cx.dev)
+                r_k = torch.empty(nr, m, dtype=torch.int8, device=cx.dev)
+                cx.dist.all_to_all_single(r_i, iids, rsz, ssz)
+                cx.dist.all_to_all_single(r_c, cells, rsz, ssz)
+                cx.dist.all_to_all_single(r_k, codes, rsz, ssz)
+                # chunks of one round arrive source-rank-major = ascending chunk index = ascending iid: arrival order kept
+                iids, cells, codes = r_i, r_c, r_k
             torch.cuda.synchronize()
-            cx.chk(L.mmidx_add_codes_device(h, iids.numel(), iids.data_ptr(), oc.data_ptr(), ok.data_ptr(), cx.stream))
+            if iids.numel():
+                cx.chk(L.mmidx_add_codes_device(h, iids.numel(), iids.data_ptr(), cells.data_ptr(), codes.data_ptr(), cx.stream))
         torch.cuda.synchronize()
         t_enc += time.time() - te
         del X
+    if coll:
+        cx.dist.all_reduce(Qsrc)  # (every query's source vector was generated on exactly one rank)
     cx.chk(L.mmidx_sync_index(h))
     torch.cuda.synchronize()
     log(f"index (sigma {sigma}) built: {N} vectors in {time.time() - t0:.1f}s (encode+append {t_enc:.1f}s)")
@@ -335,17 +361,21 @@ def main():
     dist_out = torch.empty(B, k, dtype=f64, device=dev)
     cnt_out = torch.empty(B, dtype=torch.int32, device=dev)
     sharded = None
+    per_rank = B // world
     if not single:
         sh = importlib.import_module("multimedia-indexing_amd.sharded")
-        sharded = sh.ShardedIVFPQ(sh.HipShardEngine(h, D, w, local), rank, world, dist=dist, force_collectives=args.force_sharded)
+        sharded = sh.ShardedIVFPQ(sh.HipShardEngine(h, D, w, local), rank, world, dist=dist, force_collectives=args.force_sharded,
+                                  tie_slots=int(os.environ.get("MMIDX_SHARD_TIE_SLOTS", "32")),
+                                  pipeline={"0": False, "1": True}.get(os.environ.get("MMIDX_SHARD_PIPELINE", ""), None))
 
     def step(Qx, hh=None):
         if sharded is None or hh is not None:
             chk(L.mmidx_search_device(hh if hh is not None else h, k, B, Qx.data_ptr(), iid_out.data_ptr(), dist_out.data_ptr(),
                                       cnt_out.data_ptr(), stream))
             return
-        # results stay on the rank that owns the query slice (rank r: queries [r*B/N, (r+1)*B/N))
-        i_, d_, c_ = sharded.search(k, Qx, gather=False)
+        # every rank hands in the B / N queries it owns (rank r: rows [r*B/N, (r+1)*B/N) of the step's batch); the query
+        # vectors are exchanged INSIDE the step (all-gather), and the answers stay with the owner
+        i_, d_, c_ = sharded.search_owned(k, Qx[rank * per_rank:(rank + 1) * per_rank])
         iid_out[:i_.shape[0]].copy_(i_)
         dist_out[:i_.shape[0]].copy_(d_)
         cnt_out[:i_.shape[0]].copy_(c_)
@@ -605,8 +635,9 @@ def main():
             "config": {"workload": f"IVFPQ {N}x{D}-d, {Cc} coarse cells, nprobe w={w}, m={m}x{ks}, k={k}, batch {B} queries/step",
                        "n": N, "dim": D, "cells": Cc, "nprobe": w, "m": m, "ks": ks, "k": k, "batch": B, "batch_per_gpu": B // world,
                        "mixture_sigma": args.sigma,
-                       "sharding": "single GPU" if world == 1 else f"whole inverted lists, cell mod {world}; RCCL: all-gather probe cells, MIN all-reduce thresholds, "
-                                                                      f"all-to-all partial top-k to the query's owner rank, merge there"},
+                       "sharding": "single GPU" if world == 1 else f"whole inverted lists, cell mod {world}; every rank owns batch/{world} queries; RCCL per step: all-gather "
+                                                                      f"query vectors + probe cells, MIN all-reduce thresholds, one variable-size all-to-all of partial "
+                                                                      f"top-k entries to the query's owner, merge + cross-shard tie replay there"},
             "recall_at_1": recall1, "recall_queries": ngt,
             "roofline": roofline, "roofline_whole_search": whole, "roofline_exhaustive": exhaustive,
             "cpu_baseline": cpu_baseline, "parity": parity, "hard": hard, "other_configs": other,

@@ -198,7 +198,21 @@ int mmidx_compact_partials_device(int device, int k, int64_t nq, const double *d
 int mmidx_merge_partials_device(int device, int k, int64_t nq, int nshards, const double *d_pdist,
                                 const int64_t *d_pkey, const int32_t *d_pcount, const int64_t *d_poff,
                                 int32_t *d_iid_out, double *d_dist_out, int32_t *d_count_out,
-                                void *stream);
+                                int32_t *d_flag_out, void *stream);
+/* Straddling ties across shards (ABI version 4).  mmidx_merge_partials_device sets d_flag_out[q] = 1 (d_flag_out may be NULL)
+ * when the k-th and (k+1)-th merged distances are equal: which of the equal candidates the reference's single bounded queue
+ * (IVFPQ.java:409, :445) keeps depends on the offer order over ALL probed lists, which no rank sees alone.  The owner collects
+ * the flagged queries (d_fq[nf] = query index into dQ / d_cells, -1 = unused slot; d_tau[nf] = the k-th distance) and every
+ * rank runs three passes over its own lists with a reduction over ranks in between:
+ *   phase 0  d_counts[nf][w][2] (zeroed by the caller) <- per local list: offers with d <= tau, offers with d == tau;  SUM all-reduce
+ *   phase 1  d_pB[nf] (zeroed) <- ties among the first offers of the list that holds the k-th "d <= tau" offer;          SUM all-reduce
+ *   phase 2  d_tie_iids[nf][k] (filled with -1) <- iids of this rank's kept ties at their answer slots;                 MAX all-reduce
+ * after which the owner overwrites answer slot s of a flagged query with d_tie_iids[f][s] wherever that is >= 0.  The result is
+ * the single queue's (the same closed form k_tie_resolve applies on one GPU).  Within a list, entries are replayed in list
+ * position = arrival order, as the reference appends them. */
+int mmidx_shard_tie_phase_device(mmidx_index *h, int phase, int k, int64_t nf, const double *dQ, const int32_t *d_cells,
+                                 const int32_t *d_fq, const double *d_tau, int32_t *d_counts, int32_t *d_pB,
+                                 int32_t *d_tie_iids, void *stream);
 
 /* ---- Linear: exhaustive exact search (J/datastructures/Linear.java; BASELINE config 1) ------------------------
  * add = indexVectorInternal (:111-122), search = computeNearestNeighborsInternal(k, double[]) (:138-163): exact

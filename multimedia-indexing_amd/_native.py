@@ -85,7 +85,8 @@ SIGNATURES = {
     "mmidx_shard_pass_a_device": (C.c_int, [_vp, C.c_int, C.c_int64, _dp, _i32p, _dp, _vp]),
     "mmidx_shard_pass_b_device": (C.c_int, [_vp, C.c_int, C.c_int64, _dp, _i32p, _dp, _dp, _dp, _vp, _i32p, _vp]),
     "mmidx_compact_partials_device": (C.c_int, [C.c_int, C.c_int, C.c_int64, _dp, _vp, _i32p, _vp, _dp, _vp, _vp]),
-    "mmidx_merge_partials_device": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, _dp, _vp, _i32p, _vp, _i32p, _dp, _i32p, _vp]),
+    "mmidx_merge_partials_device": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, _dp, _vp, _i32p, _vp, _i32p, _dp, _i32p, _i32p, _vp]),
+    "mmidx_shard_tie_phase_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int64, _dp, _i32p, _i32p, _dp, _i32p, _i32p, _i32p, _vp]),
     "mmidx_pca_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.POINTER(C.c_void_p)]),
     "mmidx_pca_destroy": (C.c_int, [_vp]),
     "mmidx_pca_project": (C.c_int, [_vp, C.c_int64, _dp, _dp]),

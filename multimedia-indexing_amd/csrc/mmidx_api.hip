@@ -2089,7 +2089,7 @@ int mmidx_shard_pass_b_device(mmidx_index *h, int k, int64_t nq, const double *d
 
 int mmidx_merge_partials_device(int device, int k, int64_t nq, int nshards, const double *d_pdist, const int64_t *d_pkey,
                                 const int32_t *d_pcount, const int64_t *d_poff, int32_t *d_iid_out, double *d_dist_out,
-                                int32_t *d_count_out, void *stream) {
+                                int32_t *d_count_out, int32_t *d_flag_out, void *stream) {
     if (k < 1 || k > 1023) return fail(MMIDX_ERR_INVALID_ARG, "k must be in 1..1023 (got %d)", k);
     if (nshards < 1 || nq < 0) return fail(MMIDX_ERR_INVALID_ARG, "bad shard / query count");
     if (nq > 0 && (!d_pdist || !d_pkey || !d_pcount || !d_iid_out || !d_dist_out || !d_count_out))
@@ -2100,7 +2100,64 @@ int mmidx_merge_partials_device(int device, int k, int64_t nq, int nshards, cons
     const size_t mlds = (size_t)MMIDX_MCAP * 16;
     HIPCK(hipFuncSetAttribute((const void *)k_merge_partials, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
     hipLaunchKernelGGL(k_merge_partials, dim3((unsigned)nq), dim3(MMIDX_BLOCK), mlds, (hipStream_t)stream, k, (int)nq, nshards, d_pdist,
-                       (const long long *)d_pkey, d_pcount, (const long long *)d_poff, d_iid_out, d_dist_out, d_count_out);
+                       (const long long *)d_pkey, d_pcount, (const long long *)d_poff, d_iid_out, d_dist_out, d_count_out, d_flag_out);
+    HIPCK(hipGetLastError());
+    return MMIDX_OK;
+}
+
+// one pass of the cross-shard tie replay (k_shard_tie); counts / pB / tie_iids are reduced over ranks by the caller in between
+int mmidx_shard_tie_phase_device(mmidx_index *h, int phase, int k, int64_t nf, const double *dQ, const int32_t *d_cells, const int32_t *d_fq,
+                                 const double *d_tau, int32_t *d_counts, int32_t *d_pB, int32_t *d_tie_iids, void *stream) {
+    if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    if (phase < 0 || phase > 2 || k < 1 || nf < 0) return fail(MMIDX_ERR_INVALID_ARG, "bad phase / k / count");
+    if (nf > 0 && (!dQ || !d_cells || !d_fq || !d_tau || !d_counts || (phase >= 1 && !d_pB) || (phase == 2 && !d_tie_iids)))
+        return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (h->kind != MMIDX_KIND_IVFPQ) return fail(MMIDX_ERR_INVALID_ARG, "sharded search needs an IVFPQ index");
+    if (nf == 0) return MMIDX_OK;
+    rc = set_device(h);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceCall call(h, st);
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        rc = build_csr(h);
+        if (rc) return rc;
+    }
+    TieShardParams TP{};
+    TP.S.Q = dQ;
+    TP.S.coarse = h->d_coarse;
+    TP.S.pqT = h->d_pqT;
+    TP.S.perm = h->d_perm;
+    TP.S.rot = h->d_rot;
+    TP.S.cells = d_cells;
+    TP.S.list_off = h->d_off;
+    TP.S.codes = h->d_codes;
+    TP.S.D = h->D;
+    TP.S.m = h->m;
+    TP.S.ks = h->ks;
+    TP.S.dsub = h->dsub;
+    TP.S.w = h->w;
+    TP.S.transform = h->transform;
+    TP.S.ivf = 1;
+    TP.ids = h->d_ids;
+    TP.fq = d_fq;
+    TP.tau = d_tau;
+    TP.counts = d_counts;
+    TP.pB = d_pB;
+    TP.tie_iids = d_tie_iids;
+    TP.k = k;
+    TP.phase = phase;
+    const size_t lds = (size_t)h->m * h->ks * 8 + 2 * (size_t)h->D * 8;
+    if (lds > 160 * 1024) return fail(MMIDX_ERR_UNSUPPORTED, "lookup table of %d x %d doubles does not fit the 160 KiB LDS", h->m, h->ks);
+    if (h->code_bytes == 1) {
+        HIPCK(hipFuncSetAttribute((const void *)k_shard_tie<unsigned char>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_shard_tie<unsigned char>, dim3((unsigned)nf), dim3(MMIDX_BLOCK), lds, st, TP);
+    } else {
+        HIPCK(hipFuncSetAttribute((const void *)k_shard_tie<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_shard_tie<unsigned short>, dim3((unsigned)nf), dim3(MMIDX_BLOCK), lds, st, TP);
+    }
     HIPCK(hipGetLastError());
     return MMIDX_OK;
 }

@@ -3484,7 +3484,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_merge_partials(int k, int nq, i
                                                                 const int32_t *__restrict__ pcount,
                                                                 const long long *__restrict__ poff,
                                                                 int32_t *iid_out, double *dist_out,
-                                                                int32_t *count_out) {
+                                                                int32_t *count_out, int32_t *flag_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64 *key = (u64 *)smem;
     u64 *val = key + MMIDX_MCAP;
@@ -3557,7 +3557,12 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_merge_partials(int k, int nq, i
         iid_out[(size_t)q * k + i] = iid;
         dist_out[(size_t)q * k + i] = dd;
     }
-    if (tid == 0) count_out[q] = cnt;
+    if (tid == 0) {
+        count_out[q] = cnt;
+        // a tie that straddles position k: the bounded queue's replay decides which of the equal candidates stay
+        // (mmidx_shard_tie_phase_device); everything strictly better than the k-th distance is already final
+        if (flag_out) flag_out[q] = (kept > k && key[k - 1] == key[k]) ? 1 : 0;
+    }
 }
 
 // dense partial lists [nq][K1] -> ragged: the pcount[q] valid entries of list q at out[poff[q] ...] (one wave per query)
@@ -4316,4 +4321,141 @@ __global__ void k_check_records(const int32_t *__restrict__ cells, int nlists, c
     for (int s = 0; s < m; s++)
         if ((int)codes[i * m + s] >= ks) bad |= 2;
     if (bad) atomicOr(flag, bad);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Straddling ties across shards.  The single queue of IVFPQ.java:445 sees every candidate in offer order (probe rank, list
+// position); with the lists of a query spread over ranks no rank sees that sequence.  The closed form of the bounded queue
+//  needs, for tau = the k-th smallest distance: b = #{d < tau}, p = the ties among the first k offers
+// with d <= tau, and then keeps the ties of rank e .. p-1 (e = b - (k - p)) in global offer order.  Every list lives on
+// exactly one rank, so three passes with two tiny reductions in between reproduce it:
+//   phase 0  per (flagged query, local list): n(d <= tau), n(d == tau)            -> SUM all-reduce of counts[F][w][2]
+//   phase 1  the list holding the k-th "d <= tau" offer is known to everyone; its owner counts the ties among that list's
+//            first j* such offers                                                 -> SUM all-reduce of pB[F]
+//   phase 2  owners write the iids of their ties of global rank e .. p-1 into the slots they occupy in the answer
+//            (later-offered first: slot k-1-(rank-e))                            -> MAX all-reduce of tie_iids[F][k]
+// One block per flagged query; the lists are streamed in offer order with the exact table of the search.
+// ------------------------------------------------------------------------------------------------
+struct TieShardParams {
+    ScanParams S;          // Q, coarse, pqT, perm, rot, cells, list_off, codes, D, m, ks, dsub, w, transform, ivf
+    const int32_t *ids;
+    const int32_t *fq;     // [F] query index, -1 = unused slot
+    const double *tau;     // [F]
+    int32_t *counts;       // [F][w][2]
+    int32_t *pB;           // [F]
+    int32_t *tie_iids;     // [F][k] (-1 where nothing is written)
+    int k, phase;
+};
+
+template <typename CodeT>
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_shard_tie(const TieShardParams TP) {
+    const ScanParams &P = TP.S;
+    const int f = blockIdx.x, tid = threadIdx.x, k = TP.k, w = P.w;
+    const int q = TP.fq[f];
+    if (q < 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int m = P.m, ks = P.ks;
+    double *lut = (double *)smem;
+    double *vec = lut + (size_t)m * ks;
+    __shared__ int s_wsum[MMIDX_BLOCK / 64][2];
+    __shared__ int s_run[2];   // running (d <= tau, d == tau) counts of the list being streamed
+    __shared__ int s_plan[6];  // r*, j*, ties before r*, b, e, p
+    const u64 tau = dkey(TP.tau[f]);
+    const u64 lane_lt = (1ull << (tid & 63)) - 1ull;
+    int32_t *cnt = TP.counts + (size_t)f * w * 2;
+    if (TP.phase > 0) {
+        if (tid == 0) {
+            int L = 0, TB = 0, rs = -1, js = 0, tbs = 0, b = 0;
+            for (int r = 0; r < w; r++) {
+                const int nj = cnt[2 * r], nt = cnt[2 * r + 1];
+                if (rs < 0 && L + nj >= k) {
+                    rs = r;
+                    js = k - L;
+                    tbs = TB;
+                }
+                L += nj;
+                TB += nt;
+                b += nj - nt;
+            }
+            const int p = tbs + (TP.phase == 2 ? TP.pB[f] : 0);
+            s_plan[0] = rs;
+            s_plan[1] = js;
+            s_plan[2] = tbs;
+            s_plan[3] = b;
+            s_plan[4] = b - (k - p);
+            s_plan[5] = p;
+        }
+        __syncthreads();
+    }
+    const int r_star = TP.phase > 0 ? s_plan[0] : -1, j_star = TP.phase > 0 ? s_plan[1] : 0;
+    const int e = TP.phase == 2 ? s_plan[4] : 0, pfin = TP.phase == 2 ? s_plan[5] : 0;
+    if (TP.phase > 0 && r_star < 0) return;  // fewer than k candidates with d <= tau: nothing straddles
+    int ties_before = 0;  // ties in the lists of lower probe rank (phase 2)
+    for (int pr = 0; pr < w; pr++) {
+        if (TP.phase == 2 && pr > 0) ties_before += cnt[2 * (pr - 1) + 1];
+        if (TP.phase == 1 && pr != r_star) continue;
+        const int cell = P.cells[(size_t)q * w + pr];
+        if (cell < 0) break;
+        const int64_t beg = P.list_off[cell];
+        const int64_t len = P.list_off[cell + 1] - beg;
+        if (len == 0) continue;  // (a list of another rank, or an empty one)
+        if (TP.phase == 2 && (ties_before >= pfin || ties_before + cnt[2 * pr + 1] <= e)) continue;  // no kept tie in this list
+        __syncthreads();
+        if (tid == 0) s_run[0] = s_run[1] = 0;
+        const double *tr = query_vector(P, q, cell, vec);
+        build_lut_any(lut, tr, P.pqT, m, ks, P.dsub);
+        __syncthreads();
+        const CodeT *codes = (const CodeT *)P.codes + (size_t)beg * m;
+        bool done = false;
+        for (int64_t base = 0; base < len && !done; base += MMIDX_BLOCK) {
+            const int64_t i = base + tid;
+            bool nonjunk = false, tie = false;
+            if (i < len) {
+                const CodeT *cp = codes + (size_t)i * m;
+                double a = 0.0;
+                for (int s = 0; s < m; s++) a += lut[s * ks + (int)cp[s]];
+                const u64 key = dkey(a);
+                nonjunk = key <= tau;
+                tie = key == tau;
+            }
+            const u64 mj = __ballot(nonjunk), mt = __ballot(tie);
+            const int wave = tid >> 6;
+            if ((tid & 63) == 0) {
+                s_wsum[wave][0] = __popcll(mj);
+                s_wsum[wave][1] = __popcll(mt);
+            }
+            __syncthreads();
+            int pj = s_run[0], pt = s_run[1];
+            for (int wv = 0; wv < wave; wv++) {
+                pj += s_wsum[wv][0];
+                pt += s_wsum[wv][1];
+            }
+            pj += __popcll(mj & lane_lt);  // offers with d <= tau before mine in this list
+            pt += __popcll(mt & lane_lt);  // ties before mine in this list
+            if (TP.phase == 1) {
+                if (nonjunk && pj + 1 == j_star) TP.pB[f] = pt + (tie ? 1 : 0);  // (one writer)
+            } else if (TP.phase == 2) {
+                const int rank = ties_before + pt;
+                if (tie && rank >= e && rank < pfin) TP.tie_iids[(size_t)f * k + (k - 1 - (rank - e))] = TP.ids[beg + i];
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int tj = 0, tt = 0;
+                for (int wv = 0; wv < MMIDX_BLOCK / 64; wv++) {
+                    tj += s_wsum[wv][0];
+                    tt += s_wsum[wv][1];
+                }
+                s_run[0] += tj;
+                s_run[1] += tt;
+            }
+            __syncthreads();
+            if (TP.phase == 1 && s_run[0] >= j_star) done = true;
+            if (TP.phase == 2 && ties_before + s_run[1] >= pfin) done = true;
+        }
+        if (TP.phase == 0 && tid == 0) {
+            cnt[2 * pr] = s_run[0];
+            cnt[2 * pr + 1] = s_run[1];
+        }
+    }
 }

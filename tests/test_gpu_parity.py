@@ -443,28 +443,100 @@ def test_virtual_shards_on_one_device(mi, oracle, S):
         Ts = [e.pass_a(k, Q, probe) for e in engines]
         Tmin = torch.stack(Ts).min(0).values.contiguous()
         parts2 = [e.pass_b(k, Q, probe, pdist if k != 10 else None, Tmin) for e in engines]  # (k = 10: bound from the centroids)
-        i2, d2, c2 = engines[0].merge(k, torch.stack([x[0] for x in parts2]), torch.stack([x[1] for x in parts2]),
+        i2, d2, c2, _ = engines[0].merge(k, torch.stack([x[0] for x in parts2]), torch.stack([x[1] for x in parts2]),
                                       torch.stack([x[2] for x in parts2]))
         torch.cuda.synchronize()
         assert_same((i2.cpu().numpy(), d2.cpu().numpy(), c2.cpu().numpy()), ref.search_batch(p["queries"], k))
         parts = [e.search_partial(k, Q, probe) for e in engines]
-        iid, dd, cnt = engines[0].merge(k, torch.stack([x[0] for x in parts]), torch.stack([x[1] for x in parts]),
-                                        torch.stack([x[2] for x in parts]))
+        iid, dd, cnt, _ = engines[0].merge(k, torch.stack([x[0] for x in parts]), torch.stack([x[1] for x in parts]),
+                                           torch.stack([x[2] for x in parts]))
         torch.cuda.synchronize()
         # ragged form (what the variable-size all-to-all delivers): compact every shard's lists, concatenate
         pcs = torch.stack([x[2] for x in parts])
         comp = [engines[0].compact(k, x[0], x[1], x[2], int(x[2].sum())) for x in parts]
         flat = pcs.reshape(-1).to(torch.int64)
         poff = (torch.cumsum(flat, 0) - flat).reshape(pcs.shape).contiguous()
-        ri, rd_, rcnt = engines[0].merge(k, torch.cat([c[0] for c in comp]), torch.cat([c[1] for c in comp]), pcs.contiguous(), poff)
+        ri, rd_, rcnt, _ = engines[0].merge(k, torch.cat([c[0] for c in comp]), torch.cat([c[1] for c in comp]), pcs.contiguous(), poff)
         torch.cuda.synchronize()
         assert torch.equal(ri, iid) and torch.equal(rd_, dd) and torch.equal(rcnt, cnt)
         # same merge on the host mirror
-        hi, hd, hc = sh.merge_partials_host(k, torch.stack([x[0] for x in parts]).cpu().numpy(),
+        hi, hd, hc, _ = sh.merge_partials_host(k, torch.stack([x[0] for x in parts]).cpu().numpy(),
                                             torch.stack([x[1] for x in parts]).cpu().numpy(),
                                             torch.stack([x[2] for x in parts]).cpu().numpy())
         assert np.array_equal(iid.cpu().numpy(), hi) and np.array_equal(dd.cpu().numpy(), hd)
         assert_same((iid.cpu().numpy(), dd.cpu().numpy(), cnt.cpu().numpy()), ref.search_batch(p["queries"], k))
+    for ix in shards + [full]:
+        ix.close()
+
+
+@pytest.mark.parametrize("S", [2, 3])
+def test_virtual_shards_straddling_ties(mi, oracle, S):
+    """FLAGGED tie fixture for the multi-GPU path: every vector indexed three times, so exact distance ties straddle k; the
+    cross-shard replay (mmidx_merge_partials_device flags + the three mmidx_shard_tie_phase_device passes, reductions done
+    here over S virtual shards on one device) must return the single queue's answer (IVFPQ.java:445)."""
+    import torch
+
+    sh = importlib.import_module("multimedia-indexing_amd.sharded")
+    D, C, m, ks, w = 32, 12, 8, 256, 5
+    p = synth.make_ivfpq_problem(n=1200, D=D, C=C, m=m, ks=ks, nq=48, seed=60 + S)
+    base = np.concatenate([p["base"]] * 3)
+    base = base[np.random.default_rng(2).permutation(len(base))]
+    n = len(base)
+    ref = oracle_ivfpq(oracle, p, D, m, ks, C, w)
+    ref.add_vectors(base)
+    full = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    full.loadCoarseQuantizer(p["coarse"])
+    full.loadProductQuantizer(p["pq"])
+    full.setW(w)
+    cells, codes = full.encode(base)
+    shards = []
+    for r in range(S):
+        ix = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+        ix.loadCoarseQuantizer(p["coarse"])
+        ix.loadProductQuantizer(p["pq"])
+        ix.setW(w)
+        own = np.nonzero(sh.owner_of_cell(cells, S) == r)[0]
+        ix.loadIndex(own.astype(np.int32), cells[own], codes[own])
+        shards.append(ix)
+    Q = torch.tensor(p["queries"], dtype=torch.float64, device="cuda")
+    engines = [sh.HipShardEngine(ix._h, D, w, 0) for ix in shards]
+    probe, pdist = engines[0].coarse(Q)
+    tied_total = 0
+    for k in (1, 5, 30):
+        Ts = [e.pass_a(k, Q, probe) for e in engines]
+        Tmin = torch.stack(Ts).min(0).values.contiguous()
+        parts = [e.pass_b(k, Q, probe, pdist, Tmin) for e in engines]
+        iid, dd, cnt, flag = engines[0].merge(k, torch.stack([x[0] for x in parts]), torch.stack([x[1] for x in parts]),
+                                              torch.stack([x[2] for x in parts]))
+        rid, rd, rc = ref.search_batch(p["queries"], k)
+        _, rd1, rc1 = ref.search_batch(p["queries"], k + 1)
+        want_flag = np.array([int(rc1[q] > k and rd1[q, k - 1] == rd1[q, k]) for q in range(len(rc))])
+        assert np.array_equal(flag.cpu().numpy(), want_flag)
+        tied_total += int(want_flag.sum())
+        fq = torch.nonzero(flag, as_tuple=False).reshape(-1).to(torch.int32)
+        fq = torch.cat([fq, torch.full((3,), -1, dtype=torch.int32, device="cuda")])  # (unused slots are skipped)
+        F = fq.shape[0]
+        safe = fq.clamp(min=0).long()
+        tau = dd[safe, k - 1].contiguous()
+        cnts = [torch.zeros((F, w, 2), dtype=torch.int32, device="cuda") for _ in engines]
+        for e, c in zip(engines, cnts):
+            e.tie_phase(0, k, Q, probe, fq, tau, c, torch.zeros(F, dtype=torch.int32, device="cuda"), torch.zeros((F, k), dtype=torch.int32, device="cuda"))
+        counts = torch.stack(cnts).sum(0).to(torch.int32).contiguous()
+        pbs = [torch.zeros(F, dtype=torch.int32, device="cuda") for _ in engines]
+        for e, pb in zip(engines, pbs):
+            e.tie_phase(1, k, Q, probe, fq, tau, counts, pb, torch.zeros((F, k), dtype=torch.int32, device="cuda"))
+        pB = torch.stack(pbs).sum(0).to(torch.int32).contiguous()
+        tis = [torch.full((F, k), -1, dtype=torch.int32, device="cuda") for _ in engines]
+        for e, ti in zip(engines, tis):
+            e.tie_phase(2, k, Q, probe, fq, tau, counts, pB, ti)
+        ties = torch.stack(tis).max(0).values
+        torch.cuda.synchronize()
+        out = iid.clone()
+        for f in range(F - 3):
+            row = int(fq[f])
+            out[row] = torch.where(ties[f] >= 0, ties[f], out[row])
+        assert_same((out.cpu().numpy(), dd.cpu().numpy(), cnt.cpu().numpy()), (rid, rd, rc))
+    assert tied_total >= 20
     for ix in shards + [full]:
         ix.close()
 
@@ -515,7 +587,7 @@ def test_shard_pass_a_item_compaction(mi, oracle, margin):
     Ts = [e.pass_a(k, Q, probe) for e in engines]
     Tmin = torch.stack(Ts).min(0).values.contiguous()
     parts = [e.pass_b(k, Q, probe, pdist, Tmin) for e in engines]
-    iid, dd, cnt = engines[0].merge(k, torch.stack([x[0] for x in parts]), torch.stack([x[1] for x in parts]), torch.stack([x[2] for x in parts]))
+    iid, dd, cnt, _ = engines[0].merge(k, torch.stack([x[0] for x in parts]), torch.stack([x[1] for x in parts]), torch.stack([x[2] for x in parts]))
     torch.cuda.synchronize()
     assert_same((iid.cpu().numpy(), dd.cpu().numpy(), cnt.cpu().numpy()), ref.search_batch(Qn, k))
     # the overflow really happened with margin 0: more owned queries on shard 0 than blocks launched

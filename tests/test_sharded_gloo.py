@@ -33,8 +33,10 @@ class OracleShardEngine:
         self.cell_of = cells_of
         self.coarse_np = np.asarray(p["coarse"], np.float64)
         own = np.nonzero(cells_of % world == rank)[0]
+        self.local_ids = {}
         for i in own:
             self.shard.add_code(int(i), int(cells_of[i]), codes[i])
+            self.local_ids.setdefault(int(cells_of[i]), []).append(int(i))  # arrival order = list position order
 
     def coarse(self, Qs):
         out = np.stack([self.full.nearest_coarse(q, self.w) for q in Qs.numpy()]) if Qs.shape[0] else np.zeros((0, self.w), np.int32)
@@ -88,8 +90,59 @@ class OracleShardEngine:
                     dd[s_, q_, :c_] = fd[off[s_, q_]:off[s_, q_] + c_]
                     kk[s_, q_, :c_] = fk[off[s_, q_]:off[s_, q_] + c_]
             pd_all, pk_all = torch.from_numpy(dd), torch.from_numpy(kk)
-        i, d, c = sh.merge_partials_host(k, pd_all.numpy(), pk_all.numpy(), pc_all.numpy())
-        return torch.from_numpy(i), torch.from_numpy(d), torch.from_numpy(c)
+        i, d, c, fl = sh.merge_partials_host(k, pd_all.numpy(), pk_all.numpy(), pc_all.numpy())
+        return torch.from_numpy(i), torch.from_numpy(d), torch.from_numpy(c), torch.from_numpy(fl)
+
+    def tie_phase(self, phase, k, Q, cells, fq, tau, counts, pB, ties):
+        """CPU mirror of k_shard_tie (mmidx_kernels.h): the three passes of the cross-shard tie replay over this rank's lists,
+        distances from the oracle's restatement of computeDistanceIVFADC (bit-equal to what the search sums)"""
+        w = cells.shape[1]
+        for f, q in enumerate(fq.tolist()):
+            if q < 0:
+                continue
+            t, qv, cl = float(tau[f]), Q[q].numpy(), cells[q].numpy()
+
+            def items(c):
+                return [(i, self.shard.distance(qv, i)) for i in self.local_ids.get(int(c), [])]
+
+            if phase == 0:
+                for r in range(w):
+                    it = items(cl[r])
+                    counts[f, r, 0] = sum(1 for _, d in it if d <= t)
+                    counts[f, r, 1] = sum(1 for _, d in it if d == t)
+                continue
+            cn = counts[f].numpy()
+            L = TB = b = 0
+            rs, js, tbs = -1, 0, 0
+            for r in range(w):
+                nj, nt = int(cn[r, 0]), int(cn[r, 1])
+                if rs < 0 and L + nj >= k:
+                    rs, js, tbs = r, k - L, TB
+                L, TB, b = L + nj, TB + nt, b + nj - nt
+            if rs < 0:
+                continue
+            if phase == 1:
+                seen = tcount = 0
+                for _, d in items(cl[rs]):
+                    if d <= t:
+                        seen += 1
+                        tcount += d == t
+                        if seen == js:
+                            pB[f] = tcount
+                            break
+            else:
+                p = tbs + int(pB[f])
+                e = b - (k - p)
+                tb = 0
+                for r in range(w):
+                    ti = 0
+                    for i, d in items(cl[r]):
+                        if d == t:
+                            rank = tb + ti
+                            if e <= rank < p:
+                                ties[f, k - 1 - (rank - e)] = i
+                            ti += 1
+                    tb += int(cn[r, 1])
 
 
 def _worker(rank, world, port, ret):
@@ -102,40 +155,50 @@ def _worker(rank, world, port, ret):
     from oracle import oracle as o
 
     sh = importlib.import_module("multimedia-indexing_amd.sharded")
-    D, C, m, ks, n, w = 16, 12, 8, 64, 1500, 5
-    p = synth.make_ivfpq_problem(n=n, D=D, C=C, m=m, ks=ks, nq=9, seed=31)
-    ref = o.OracleIndex(o.KIND_IVFPQ, D, m, ks, C)
-    ref.set_coarse(p["coarse"])
-    ref.set_pq(p["pq"])
-    ref.set_w(w)
-    cells_of, codes = ref.encode_batch(p["base"])
-    ref.add_vectors(p["base"])
-    eng = OracleShardEngine(o, p, D, m, ks, C, w, rank, world, cells_of, codes)
-    srch = sh.ShardedIVFPQ(eng, rank, world, dist=dist)
-    Q = torch.from_numpy(p["queries"])
-    ok, compared = True, 0
-    for k in (1, 10, 64):
-        iid, dd, cnt = srch.search(k, Q)
-        # owner-kept form: this rank's slice of the same answer, no final all-gather
-        per = (Q.shape[0] + world - 1) // world
-        si, sd, sc = srch.search(k, Q, gather=False)
-        lo, hi = min(rank * per, Q.shape[0]), min(rank * per + per, Q.shape[0])
-        ok &= bool(torch.equal(si, iid[lo:hi]) and torch.equal(sd, dd[lo:hi]) and torch.equal(sc, cnt[lo:hi]))
-        # a batch longer than max_batch is cut into collective rounds (here 4 queries each): same answer
-        small = sh.ShardedIVFPQ(eng, rank, world, dist=dist, max_batch=4)
-        ci, cd, cc = small.search(k, Q)
-        ok &= bool(torch.equal(ci, iid) and torch.equal(cd, dd) and torch.equal(cc, cnt))
-        rid, rd, rc = ref.search_batch(p["queries"], k)
-        _, rd1, rc1 = ref.search_batch(p["queries"], k + 1)
-        for qi in range(Q.shape[0]):
-            # a tie straddling position k is resolved by the single queue's replay, which a sharded
-            # index does not do (DESIGN.md "multi-GPU"): compare the queries without one
-            if rc1[qi] > k and rd1[qi, k - 1] == rd1[qi, k]:
-                continue
-            compared += 1
-            ok &= bool(np.array_equal(iid.numpy()[qi], rid[qi]) and np.array_equal(dd.numpy()[qi], rd[qi])
-                       and cnt.numpy()[qi] == rc[qi])
-    ret[rank] = ok and compared >= 20
+    D, C, m, ks, w = 16, 12, 8, 64, 5
+    ok, compared, tied = True, 0, 0
+    for case in ("plain", "duplicates"):
+        n = 1500 if case == "plain" else 500
+        p = synth.make_ivfpq_problem(n=n, D=D, C=C, m=m, ks=ks, nq=10, seed=31)
+        if case == "duplicates":  # every vector three times, shuffled: exact distance ties straddle k on most queries
+            base = np.concatenate([p["base"]] * 3)
+            p["base"] = base[np.random.default_rng(5).permutation(len(base))]
+        ref = o.OracleIndex(o.KIND_IVFPQ, D, m, ks, C)
+        ref.set_coarse(p["coarse"])
+        ref.set_pq(p["pq"])
+        ref.set_w(w)
+        cells_of, codes = ref.encode_batch(p["base"])
+        ref.add_vectors(p["base"])
+        eng = OracleShardEngine(o, p, D, m, ks, C, w, rank, world, cells_of, codes)
+        srch = sh.ShardedIVFPQ(eng, rank, world, dist=dist, pipeline=True)
+        Q = torch.from_numpy(p["queries"])
+        for k in (1, 10, 64):
+            iid, dd, cnt = srch.search(k, Q)
+            # owner-kept form: this rank's slice of the same answer, no final all-gather
+            per = (Q.shape[0] + world - 1) // world
+            si, sd, sc = srch.search(k, Q, gather=False)
+            lo, hi = min(rank * per, Q.shape[0]), min(rank * per + per, Q.shape[0])
+            ok &= bool(torch.equal(si, iid[lo:hi]) and torch.equal(sd, dd[lo:hi]) and torch.equal(sc, cnt[lo:hi]))
+            # the serving form: every rank hands in its own queries (exchanged inside), two sub-batches in flight
+            oi, od, oc = srch.search_owned(k, Q[lo:hi].contiguous())
+            ok &= bool(torch.equal(oi, iid[lo:hi]) and torch.equal(od, dd[lo:hi]) and torch.equal(oc, cnt[lo:hi]))
+            # a batch longer than max_batch is cut into collective rounds (here 4 queries each): same answer
+            small = sh.ShardedIVFPQ(eng, rank, world, dist=dist, max_batch=4)
+            ci, cd, cc = small.search(k, Q)
+            ok &= bool(torch.equal(ci, iid) and torch.equal(cd, dd) and torch.equal(cc, cnt))
+            rid, rd, rc = ref.search_batch(p["queries"], k)
+            _, rd1, rc1 = ref.search_batch(p["queries"], k + 1)
+            for qi in range(Q.shape[0]):
+                # ties straddling position k included: the cross-shard replay must reproduce the single queue (IVFPQ.java:445)
+                tied += int(rc1[qi] > k and rd1[qi, k - 1] == rd1[qi, k])
+                compared += 1
+                good = bool(np.array_equal(iid.numpy()[qi], rid[qi]) and np.array_equal(dd.numpy()[qi], rd[qi])
+                            and cnt.numpy()[qi] == rc[qi])
+                if not good and rank == 0:
+                    print("MISMATCH", case, k, qi, iid.numpy()[qi], rid[qi], flush=True)
+                ok &= good
+            ok &= int(srch.tie_overflow) == 0
+    ret[rank] = ok and compared >= 50 and tied >= 10
     dist.barrier()
     dist.destroy_process_group()
 
@@ -162,7 +225,8 @@ def test_merge_partials_host_ties():
     pd = np.array([[[1.0, 2.0, 2.0, 9.0]], [[2.0, 3.0, np.inf, np.inf]]])
     pk = np.array([[[(0 << 32) | 5, (0 << 32) | 7, (1 << 32) | 2, (1 << 32) | 9]], [[(0 << 32) | 6, (2 << 32) | 1, -1, -1]]], np.int64)
     pc = np.array([[4], [2]], np.int32)
-    iid, dd, cnt = sh.merge_partials_host(3, pd, pk, pc)
+    iid, dd, cnt, flag = sh.merge_partials_host(3, pd, pk, pc)
+    assert flag.tolist() == [1]  # the 3rd and 4th merged distances are both 2.0
     assert cnt.tolist() == [3] and dd[0].tolist() == [1.0, 2.0, 2.0]
     # candidates at distance 2 in offer order: (0,6), (0,7), (1,2); the merged top-4 holds the first
     # two... top-(k+1) = [1.0(5), 2.0(6), 2.0(7), 2.0(2)], first k = 5, 6, 7 -> run reversed: 7, 6
