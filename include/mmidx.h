@@ -142,7 +142,8 @@ int mmidx_distance(mmidx_index *h, int64_t n, const double *Q, const int32_t *ii
  * computeKnnADC PQ.java:290-322, for nq queries Q[nq][D].  Row i of iid_out / dist_out holds
  * count_out[i] = min(k, #candidates) results, best first: ascending squared distance, equal
  * distances in the bounded queue's order (ASS.lookUp, ASS:345-358).  Unused tail entries are
- * iid -1 / +inf.  k must be in 1..1023.
+ * iid -1 / +inf.  k must be in 1..4095 (the reference's queue has no bound, IVFPQ.java:409; here the per-block
+ * candidate buffers share the 160 KiB LDS with the lookup table: larger k -> MMIDX_ERR_INVALID_ARG).
  * mmidx_search may be called from any number of threads (computeNearestNeighbors is not synchronized,
  * ASS:281-291): callers that arrive while a batch is running are served together as one device batch
  * (same k), each with the answer of its own call. */

@@ -586,7 +586,7 @@ struct SearchPlan {
 };
 
 int make_plan(mmidx_index *h, int k, int64_t nq, SearchPlan &pl, bool need_coarse = true) {
-    if (k < 1 || k > 1023) return fail(MMIDX_ERR_INVALID_ARG, "k must be in 1..1023 (got %d)", k);
+    if (k < 1 || k > MMIDX_K_MAX) return fail(MMIDX_ERR_INVALID_ARG, "k must be in 1..%d (got %d)", MMIDX_K_MAX, k);
     pl.K1 = k + 1;
     int cap = 1;
     while (cap < pl.K1 + MMIDX_SEG) cap <<= 1;
@@ -1275,7 +1275,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
     M.pdist = d_pdist;
     M.pkey = d_pkey;
     int mcap = 512;
-    while (mcap < 2 * pl.K1) mcap <<= 1;  // <= 2048
+    while (mcap < 2 * pl.K1) mcap <<= 1;  // <= 8192 (k <= MMIDX_K_MAX)
     M.cap = mcap;
     const size_t mlds = (size_t)mcap * 16 + ((ivf && P.w <= 1024) ? (size_t)P.w * 8 : 0);
     if (pl.K1 <= 128) {
@@ -1945,7 +1945,7 @@ static int search_host_batch(mmidx_index *h, SearchReq *const *batch, size_t nb)
 int mmidx_search(mmidx_index *h, int k, int64_t nq, const double *Q, int32_t *iid_out, double *dist_out, int32_t *count_out) {
     if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
     if (nq > 0 && (!Q || !iid_out || !dist_out || !count_out)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
-    if (k < 1 || k > 1023) return fail(MMIDX_ERR_INVALID_ARG, "k must be in 1..1023 (got %d)", k);
+    if (k < 1 || k > MMIDX_K_MAX) return fail(MMIDX_ERR_INVALID_ARG, "k must be in 1..%d (got %d)", MMIDX_K_MAX, k);
     int rc = check_ready(h);
     if (rc) return rc;
     if (nq == 0) return MMIDX_OK;
@@ -1968,7 +1968,7 @@ int mmidx_search_sdc(mmidx_index *h, int k, int64_t nq, const int32_t *iids, int
     if (nq > 0 && (!iids || !iid_out || !dist_out || !count_out)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
     if (h->kind != MMIDX_KIND_PQ) return fail(MMIDX_ERR_UNSUPPORTED, "id queries: IVFPQ.computeKnnIVFSDC is unimplemented in the reference (IVFPQ.java:509-511)");
     if (h->code_bytes != 1) return fail(MMIDX_ERR_UNSUPPORTED, "SDC needs byte codes (the reference dereferences pqByteCodes unconditionally, PQ.java:350)");
-    if (k < 1 || k > 1023) return fail(MMIDX_ERR_INVALID_ARG, "k must be in 1..1023 (got %d)", k);
+    if (k < 1 || k > MMIDX_K_MAX) return fail(MMIDX_ERR_INVALID_ARG, "k must be in 1..%d (got %d)", MMIDX_K_MAX, k);
     int rc = check_ready(h);
     if (rc) return rc;
     if (nq == 0) return MMIDX_OK;
@@ -2090,16 +2090,18 @@ int mmidx_shard_pass_b_device(mmidx_index *h, int k, int64_t nq, const double *d
 int mmidx_merge_partials_device(int device, int k, int64_t nq, int nshards, const double *d_pdist, const int64_t *d_pkey,
                                 const int32_t *d_pcount, const int64_t *d_poff, int32_t *d_iid_out, double *d_dist_out,
                                 int32_t *d_count_out, int32_t *d_flag_out, void *stream) {
-    if (k < 1 || k > 1023) return fail(MMIDX_ERR_INVALID_ARG, "k must be in 1..1023 (got %d)", k);
+    if (k < 1 || k > MMIDX_K_MAX) return fail(MMIDX_ERR_INVALID_ARG, "k must be in 1..%d (got %d)", MMIDX_K_MAX, k);
     if (nshards < 1 || nq < 0) return fail(MMIDX_ERR_INVALID_ARG, "bad shard / query count");
     if (nq > 0 && (!d_pdist || !d_pkey || !d_pcount || !d_iid_out || !d_dist_out || !d_count_out))
         return fail(MMIDX_ERR_INVALID_ARG, "null argument");
     if (mmidx_device_count() < 1) return fail(MMIDX_ERR_NO_DEVICE, "no HIP device: libmmidx_hip has no CPU fallback");
     if (nq == 0) return MMIDX_OK;
     HIPCK(hipSetDevice(device));
-    const size_t mlds = (size_t)MMIDX_MCAP * 16;
+    int mcap = MMIDX_MCAP;  // room for the kept prefix plus at least one more shard's list
+    while (mcap < 2 * (k + 1)) mcap <<= 1;
+    const size_t mlds = (size_t)mcap * 16;
     HIPCK(hipFuncSetAttribute((const void *)k_merge_partials, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
-    hipLaunchKernelGGL(k_merge_partials, dim3((unsigned)nq), dim3(MMIDX_BLOCK), mlds, (hipStream_t)stream, k, (int)nq, nshards, d_pdist,
+    hipLaunchKernelGGL(k_merge_partials, dim3((unsigned)nq), dim3(MMIDX_BLOCK), mlds, (hipStream_t)stream, k, (int)nq, nshards, mcap, d_pdist,
                        (const long long *)d_pkey, d_pcount, (const long long *)d_poff, d_iid_out, d_dist_out, d_count_out, d_flag_out);
     HIPCK(hipGetLastError());
     return MMIDX_OK;
@@ -2182,7 +2184,7 @@ int mmidx_assign_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_
 
 int mmidx_compact_partials_device(int device, int k, int64_t nq, const double *d_pdist, const int64_t *d_pkey, const int32_t *d_pcount,
                                   const int64_t *d_poff, double *d_out_dist, int64_t *d_out_key, void *stream) {
-    if (k < 1 || k > 1023 || nq < 0) return fail(MMIDX_ERR_INVALID_ARG, "bad k / query count");
+    if (k < 1 || k > MMIDX_K_MAX || nq < 0) return fail(MMIDX_ERR_INVALID_ARG, "bad k / query count");
     if (nq > 0 && (!d_pdist || !d_pkey || !d_pcount || !d_poff)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
     if (mmidx_device_count() < 1) return fail(MMIDX_ERR_NO_DEVICE, "no HIP device: libmmidx_hip has no CPU fallback");
     if (nq == 0) return MMIDX_OK;

@@ -3290,7 +3290,9 @@ __global__ void k_pair_scatter(const int32_t *__restrict__ cells, int w, int ran
 // mode 0: final results (iid / dist / count / tie flag); mode 1: sorted partial list for the
 // cross-shard merge (pdist, pkey = probe_rank << 32 | iid, pcount).
 // ------------------------------------------------------------------------------------------------
-#define MMIDX_MCAP 2048  // > K1 (k <= 1023): the chunked fallback needs room beyond the kept prefix
+#define MMIDX_MCAP 2048  // smallest K5 buffer (entries); the host doubles it until it exceeds 2 (k + 1)
+#define MMIDX_K_MAX 4095  // largest k: the candidate buffers (pow2 >= k + 1 + segment) and the merge buffers (pow2 >= 2 (k + 1)) must fit
+                          // the 160 KiB LDS next to the lookup table
 struct MergeParams {
     const u64 *T;            // [nq] final thresholds (null: no filtering)
     const u32 *pool_cnt;
@@ -3478,7 +3480,7 @@ __global__ __launch_bounds__(NT) void k_merge(const MergeParams P) {
 // across shards is (probe_rank, iid): inside one inverted list the reference appends in iid order
 // (IVFPQ.java:339, :699-700), so this equals the single-queue offer order.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MMIDX_BLOCK) void k_merge_partials(int k, int nq, int nshards,
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_merge_partials(int k, int nq, int nshards, int mcap,
                                                                 const double *__restrict__ pdist,
                                                                 const long long *__restrict__ pkey,
                                                                 const int32_t *__restrict__ pcount,
@@ -3487,7 +3489,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_merge_partials(int k, int nq, i
                                                                 int32_t *count_out, int32_t *flag_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64 *key = (u64 *)smem;
-    u64 *val = key + MMIDX_MCAP;
+    u64 *val = key + mcap;
     const int q = blockIdx.x, tid = threadIdx.x;
     const int K1 = k + 1;
     int kept = 0;
@@ -3497,7 +3499,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_merge_partials(int k, int nq, i
         while (s < nshards) {
             int c = pcount[(size_t)s * nq + q];
             if (c > K1) c = K1;
-            if (filled + c > MMIDX_MCAP) break;
+            if (filled + c > mcap) break;
             // dense [nshards][nq][K1] or, with poff, ragged: list (s, q) starts at poff[s * nq + q]
             const size_t base = poff ? (size_t)poff[(size_t)s * nq + q] : ((size_t)s * nq + q) * K1;
             for (int i = tid; i < c; i += MMIDX_BLOCK) {

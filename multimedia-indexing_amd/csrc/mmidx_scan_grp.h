@@ -144,6 +144,13 @@ __global__ __launch_bounds__(1024) void k_group_build(const int32_t *__restrict_
                                                       int4 *__restrict__ gdesc, int32_t *__restrict__ n_groups, u32 *__restrict__ fb_count) {
     __shared__ u32 s_wave[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (start[C] == 0) {  // no pair survived the coarse bound (the separable benchmark): nothing to read, nothing to scan
+        if (tid == 0) {
+            *n_groups = 0;
+            *fb_count = 0u;
+        }
+        return;
+    }
     const int per = (C + 1023) / 1024;
     const int lo = tid * per, hi = (lo + per < C) ? lo + per : C;
     u32 sum = 0;

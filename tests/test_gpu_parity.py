@@ -148,6 +148,66 @@ def test_short_codes(mi, oracle):
     ix.close()
 
 
+@pytest.mark.parametrize("k", [1500, 4095])
+def test_large_k(mi, oracle, k):
+    """k beyond 1023 (the reference's queue is unbounded, IVFPQ.java:409): candidate and merge buffers grow with k up to 4095;
+    IVFPQ (w = C so that more than k candidates exist), flat PQ, and the sharded merge K5."""
+    import torch
+
+    sh = importlib.import_module("multimedia-indexing_amd.sharded")
+    D, C, m, ks, n, w = 16, 6, 8, 256, 9000, 6
+    p = synth.make_ivfpq_problem(n=n, D=D, C=C, m=m, ks=ks, nq=6, seed=70)
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal((n, D)) * 2.0  # (spread out: distinct codes, few exact ties)
+    ix = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    ix.loadCoarseQuantizer(p["coarse"])
+    ix.loadProductQuantizer(p["pq"])
+    ix.setW(w)
+    ref = oracle_ivfpq(oracle, p, D, m, ks, C, w)
+    ix.indexVectors([str(i) for i in range(n)], base)
+    ref.add_vectors(base)
+    assert_same(ix.search_batch(k, p["queries"]), ref.search_batch(p["queries"], k))
+    cells, codes = ix.encode(base)
+    ix.close()
+    pq = mi.PQ(D, n, False, "", m, ks, 0, 512)
+    pq.loadProductQuantizer(p["pq"])
+    rpq = oracle.OracleIndex(oracle.KIND_PQ, D, m, ks)
+    rpq.set_pq(p["pq"])
+    pq.indexVectors([str(i) for i in range(n)], base)
+    rpq.add_vectors(base)
+    assert_same(pq.search_batch(k, p["queries"]), rpq.search_batch(p["queries"], k))
+    pq.close()
+    with pytest.raises(mi.MmidxError):
+        bad = mi.PQ(D, 10, False, "", m, ks, 0, 512)
+        bad.loadProductQuantizer(p["pq"])
+        bad.indexVectors(["0"], base[:1])
+        bad.search_batch(4096, p["queries"])
+    # two virtual shards: partial lists of k + 1 entries each, merged by K5 with the larger buffer
+    shards = []
+    for r in range(2):
+        sx = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+        sx.loadCoarseQuantizer(p["coarse"])
+        sx.loadProductQuantizer(p["pq"])
+        sx.setW(w)
+        own = np.nonzero(sh.owner_of_cell(cells, 2) == r)[0]
+        sx.loadIndex(own.astype(np.int32), cells[own], codes[own])
+        shards.append(sx)
+    Q = torch.tensor(p["queries"], dtype=torch.float64, device="cuda")
+    engines = [sh.HipShardEngine(sx._h, D, w, 0) for sx in shards]
+    probe, _ = engines[0].coarse(Q)
+    parts = [e.search_partial(k, Q, probe) for e in engines]
+    iid, dd, cnt, _ = engines[0].merge(k, torch.stack([x[0] for x in parts]), torch.stack([x[1] for x in parts]), torch.stack([x[2] for x in parts]))
+    torch.cuda.synchronize()
+    rid, rd, rc = ref.search_batch(p["queries"], k)
+    _, rd1, rc1 = ref.search_batch(p["queries"], k + 1)
+    for qi in range(len(rc)):
+        if rc1[qi] > k and rd1[qi, k - 1] == rd1[qi, k]:
+            continue  # (a straddling tie is the tie replay's business: test_virtual_shards_straddling_ties)
+        assert np.array_equal(iid.cpu().numpy()[qi], rid[qi]) and np.array_equal(dd.cpu().numpy()[qi], rd[qi])
+    for sx in shards:
+        sx.close()
+
+
 @pytest.mark.parametrize("ks,tr", [(256, 0), (256, 2), (256, 1), (512, 0)])
 def test_per_id_utilities(mi, oracle, ks, tr):
     """computeDistanceIVFADC (IVFPQ.java:464-497), getPQCodeByte / getPQCodeShort (:801-856), getInvertedListId (:865-880)
@@ -286,7 +346,7 @@ def test_edge_cases(mi, oracle):
     for k in (1, 399, 1023):
         assert_same(ix.search_batch(k, p["queries"]), ref.search_batch(p["queries"], k))
     # invalid k / w (LingPipe ctor rejects 0; w > C is an NPE at IVFPQ.java:597-599)
-    for bad_k in (0, 1024):
+    for bad_k in (0, 4096):
         with pytest.raises(mi.MmidxError) as ei:
             ix.search_batch(bad_k, p["queries"])
         assert ei.value.status == 6

@@ -4,7 +4,7 @@
 #   usage: tools/profile_on_box.sh <tag> [kernel-regex]
 set -u
 TAG=${1:-r01x}
-KRE=${2:-k_scan}
+KRE=${2:-k_scan|k_coarse|k_merge}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT" /tmp/prof_$TAG
