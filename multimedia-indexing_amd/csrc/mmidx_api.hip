@@ -846,7 +846,7 @@ int launch_scan_grouped(mmidx_index *h, const ScanParams &P, const SearchPlan &p
     GP.fb_items = h->ws_gfb.p + 4;
     GP.fb_ch = h->ws_gfb.p + 4 + nfb;
     GP.cb = cb;
-    GP.stat = (h->profiling == 1 || h->debug_sync) ? (unsigned long long *)(h->d_counters + 3) : nullptr;
+    GP.stat = (h->profiling == 1 || h->debug_sync) ? (unsigned long long *)(h->d_counters + 3) : nullptr;  // [0] verified, [1] flag (adds), [2..3] item statistics
     int rc;
     const int ds = h->dsub;
     switch (h->m) {
@@ -2249,7 +2249,7 @@ int mmidx_set_profiling(mmidx_index *h, int enabled) {
     h->launches = 0;
     h->passa_launches = 0;
     h->host_passa_codes = 0;
-    HIPCK(hipMemset(h->d_counters, 0, 4 * sizeof(u64)));
+    HIPCK(hipMemset(h->d_counters, 0, 8 * sizeof(u64)));
     return MMIDX_OK;
 }
 
@@ -2281,7 +2281,7 @@ int mmidx_get_stats(mmidx_index *h, mmidx_stats *out) {
         s.total_ms += t;
         s.passa_ms += pa;
     }
-    u64 cnt[4] = {0, 0, 0, 0};
+    u64 cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIPCK(hipMemcpy(cnt, h->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));
     s.scan_codes = (int64_t)cnt[0] + h->host_codes;
     s.tie_fallbacks = (int32_t)cnt[1];
@@ -2289,6 +2289,9 @@ int mmidx_get_stats(mmidx_index *h, mmidx_stats *out) {
     s.passa_codes = (int64_t)cnt[2] + h->host_passa_codes;
     s.passa_launches = h->passa_launches;
     s.verified_codes = (int64_t)cnt[3];
+    if (h->debug_sync || getenv("MMIDX_GRP_STATS"))
+        fprintf(stderr, "[mmidx] K3g: %llu pairs in groups, %llu alive after the table build (Smin < T), %llu codes verified\n", (unsigned long long)cnt[5],
+                (unsigned long long)cnt[6], (unsigned long long)cnt[3]);
     s.passb_items_last = h->pin_hint ? *(volatile int32_t *)h->pin_hint : -1;
     *out = s;
     h->ev_used = 0;
@@ -2296,7 +2299,7 @@ int mmidx_get_stats(mmidx_index *h, mmidx_stats *out) {
     h->launches = 0;
     h->passa_launches = 0;
     h->host_passa_codes = 0;
-    HIPCK(hipMemset(h->d_counters, 0, 4 * sizeof(u64)));
+    HIPCK(hipMemset(h->d_counters, 0, 8 * sizeof(u64)));
     return MMIDX_OK;
 }
 

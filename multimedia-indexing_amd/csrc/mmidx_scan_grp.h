@@ -26,12 +26,17 @@
 #include "mmidx_kernels.h"
 
 #define GRP_NT 512     // threads per block (8 wave64: 4 per SIMD at two blocks per CU)
-#define GRP_QCAP 2048  // survivor queue entries (>= 64 lanes x 2 codes x 8 queries = one wave's worst case)
+#define GRP_QCAP 2048  // survivor queue entries (>= 64 lanes x GRP_SEGU codes x 8 queries = one wave's worst case, GRP_SEGU <= 4)
 #define GRP_VR 128     // survivors verified per round: 4 lanes each
+#ifndef GRP_SEGU
 #define GRP_SEGU 2     // codes per thread per segment
+#endif
 #define GRP_SEG (GRP_NT * GRP_SEGU)
 #ifndef GRP_BIS
 #define GRP_BIS 0
+#endif
+#ifndef GRP_EPOCH
+#define GRP_EPOCH 4  // segments between two block barriers of the scan
 #endif
 #ifndef GRP_WPS
 #define GRP_WPS 4  // waves per SIMD the register allocation is held to (blocks per CU x 2)
@@ -419,6 +424,10 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
         }
         alive0 = (u32)__builtin_amdgcn_readfirstlane((int)alive0);
         __syncthreads();
+        if (tid == 0 && P.stat) {  // (profiling runs only) pairs of this item, pairs that survive the table build's Smin >= T test
+            atomicAdd(P.stat + 2, (unsigned long long)np);
+            atomicAdd(P.stat + 3, (unsigned long long)__popc(alive0));
+        }
         if (alive0 == 0) continue;
 #if defined(GRP_TIMING_STOP_AFTER_BUILD) || GRP_BIS == 5  // (timing experiments only: results are wrong)
         continue;
@@ -434,7 +443,41 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
         u32 carried = 0;  // queue entries carried over from earlier segments (block-uniform)
         u32 n_verified = 0;
         int par = 0;
-        for (int64_t seg = c0; seg < c1; seg += GRP_SEG) {
+        // reserve room in the queue for this wave's survivors of one segment and write them; on failure (the queue is full) the
+        // bits stay set and the lowest failing base marks where the valid entries of this round end
+        auto append_try = [&](u32 &pend, const u32 segbase) {
+            u32 nw = 0;
+#pragma unroll
+            for (int b = 0; b < G * GRP_SEGU; b++) nw += (u32)__popcll(__builtin_amdgcn_ballot_w64((pend >> b) & 1u));
+            if (nw == 0) return;
+            u32 base = 0;
+            if (lane == 0) base = atomicAdd(s_new + par, nw);
+            base = carried + (u32)__builtin_amdgcn_readfirstlane((int)base);
+            if (base + nw <= GRP_QCAP) {
+                u32 off = base;
+#pragma unroll
+                for (int b = 0; b < G * GRP_SEGU; b++) {
+                    const bool mine = (pend >> b) & 1u;
+                    const u64 mk = __builtin_amdgcn_ballot_w64(mine);
+                    if (mine) s_queue[off + (u32)__popcll(mk & lane_lt)] = ((u32)(b / GRP_SEGU) << 24) | (segbase + (u32)((b % GRP_SEGU) * GRP_NT) + (u32)tid);
+                    off += (u32)__popcll(mk);
+                }
+                pend = 0;
+            } else if (lane == 0) {
+                atomicMin(s_qvalid + par, base);  // everything from here on in this round failed
+            }
+        };
+        // The block synchronises once per EPOCH of GRP_EPOCH segments, not per segment: a wave whose codes die early does not
+        // wait for the wave next to it after every 128 codes.  Survivors are appended to the queue right away (atomic
+        // reservation); a wave whose reservation does not fit keeps the survivor bits of that segment (pendq) until the epoch's
+        // barrier, where the queue is verified and emptied and the reservation retried.
+        for (int64_t eseg = c0; eseg < c1; eseg += (int64_t)GRP_EPOCH * GRP_SEG) {
+          u32 pendq[GRP_EPOCH];
+#pragma unroll
+          for (int ej = 0; ej < GRP_EPOCH; ej++) {
+            pendq[ej] = 0;
+            const int64_t seg = eseg + (int64_t)ej * GRP_SEG;
+            if (seg >= c1) continue;  // (uniform)
             const bool more = seg + GRP_SEG < c1;
             if (more) {
 #pragma unroll
@@ -445,11 +488,9 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
             }
             // one code of the lane at a time (64 codes per wave and early-out test); only the survivor bits outlive a code
             u32 pend = 0;  // bit i * GRP_SEGU + u: code u of this lane survives query i's filter
-            u32 posv[GRP_SEGU];
 #pragma unroll
             for (int u = 0; u < GRP_SEGU; u++) {
                 const int64_t p = seg + u * GRP_NT + tid;
-                posv[u] = (u32)p;
                 const u32 a0 = p < c1 ? 0u : 0x10000u;
                 u32 acc[G];
 #pragma unroll
@@ -467,11 +508,16 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
                     }
 #pragma unroll
                     for (int i = 0; i < G; i++) {
-                        if ((al >> i) & 1u) {  // wave-uniform; (one branch per query also keeps the compiler from fusing two queries'
-                                            //  rows into ds_read2st64_b64, which costs 8 LDS cycles against 2 x 2: measured 13.6 vs 11.1 ms)
+                        if ((al >> i) & 1u) {  // wave-uniform.  (One branch per query also keeps the compiler from fusing two queries' rows
+                                            //  into ds_read2st64_b64 -- 8 LDS cycles against 2 x 2: 13.6 vs 11.1 ms per step.  Sixteen hand-issued
+                                            //  reads behind ONE wait for the first four sub-quantizers measured no faster: the loop is bound by
+                                            //  instruction issue -- ~475 instructions per 64 codes and wave, 140 of them scalar -- not by LDS latency.)
                             uint2 rv[4];
 #pragma unroll
                             for (int k = 0; k < 4; k++) rv[k] = *(const uint2 *)(lut8 + i * LQ + (sb * 4 + k) * 256 + slot[k]);
+#ifdef GRP_ONE_WAIT
+                            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): one wait for the four reads instead of one per byte
+#endif
 #pragma unroll
                             for (int k = 0; k < 4; k++) acc[i] += __builtin_amdgcn_perm(rv[k].y, rv[k].x, sel[k]);
                             if (sb + 1 < M / 4) {
@@ -490,28 +536,21 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
             if (pend == 0x2345u) s_queue[1] = 1;  // (keeps the scan alive)
             pend = 0;
 #endif
-            // ---- append to the queue; verify when a round is full, at the end, or when the queue overflowed ----
-            for (;;) {
-                u32 nw = 0;
+            // ---- survivors go to the queue at once when they fit; what does not fit waits for the epoch's barrier ----
+            pendq[ej] = pend;
+            if (__builtin_amdgcn_ballot_w64(pend != 0)) append_try(pendq[ej], (u32)seg);
+            if (more) {
 #pragma unroll
-                for (int b = 0; b < G * GRP_SEGU; b++) nw += (u32)__popcll(__builtin_amdgcn_ballot_w64((pend >> b) & 1u));
-                if (nw) {
-                    u32 base = 0;
-                    if (lane == 0) base = atomicAdd(s_new + par, nw);
-                    base = carried + (u32)__builtin_amdgcn_readfirstlane((int)base);
-                    if (base + nw <= GRP_QCAP) {
-                        u32 off = base;
+                for (int u = 0; u < GRP_SEGU; u++) cur[u] = nxt[u];
+            }
+          }  // segments of the epoch
+            const bool more = eseg + (int64_t)GRP_EPOCH * GRP_SEG < c1;
+            // ---- epoch end: verify when a round is full, at the end of the list, or when the queue overflowed ----
+            for (bool first = true;; first = false) {
+                if (!first) {  // retry what did not fit (the queue has just been emptied)
 #pragma unroll
-                        for (int b = 0; b < G * GRP_SEGU; b++) {
-                            const bool mine = (pend >> b) & 1u;
-                            const u64 mk = __builtin_amdgcn_ballot_w64(mine);
-                            if (mine) s_queue[off + (u32)__popcll(mk & lane_lt)] = ((u32)(b / GRP_SEGU) << 24) | posv[b % GRP_SEGU];
-                            off += (u32)__popcll(mk);
-                        }
-                        pend = 0;
-                    } else if (lane == 0) {
-                        atomicMin(s_qvalid + par, base);  // everything from here on in this round failed
-                    }
+                    for (int ej = 0; ej < GRP_EPOCH; ej++)
+                        if (__builtin_amdgcn_ballot_w64(pendq[ej] != 0)) append_try(pendq[ej], (u32)(eseg + (int64_t)ej * GRP_SEG));
                 }
                 __syncthreads();
                 const u32 cnt = carried + s_new[par], qv = s_qvalid[par];
@@ -592,11 +631,7 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
                 carried = 0;
                 if (!failed) break;
             }
-            if (more) {
-#pragma unroll
-                for (int u = 0; u < GRP_SEGU; u++) cur[u] = nxt[u];
-            }
-        }
+        }  // epochs
         // ---- (h) hand the candidates to the queries' pools (at most K1 per item) ------------------------------------
         __syncthreads();
         if (tid == 0 && P.stat) atomicAdd(P.stat, (unsigned long long)n_verified);
