@@ -1047,12 +1047,12 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
         // thresholds, pool counters, per-cell pair counters and the K3h fallback header in one launch
         int32_t *pc = nullptr;
         if (ivf) {
-            HIPCK(h->ws_pcount.reserve((size_t)h->C));
+            HIPCK(h->ws_pcount.reserve((size_t)h->C + 1));
             pc = h->ws_pcount.p;
             pcount_zeroed = phase == 0;  // (phase 1 ends before the pair sort; phase 2 zeroes them itself)
         }
         HIPCK(h->ws_fb.reserve(2 * (size_t)nq * (size_t)std::max(1, pl.nchunks) + 4));
-        const long long span = std::max<long long>((long long)nq, ivf ? (long long)h->C : 0);
+        const long long span = std::max<long long>((long long)nq, ivf ? (long long)h->C + 1 : 0);
         hipLaunchKernelGGL(k_step_init, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, st, h->ws_T.p, h->ws_pcnt.p, (long long)nq, pc,
                            h->C, h->ws_fb.p);
         HIPCK(hipGetLastError());
@@ -1179,12 +1179,12 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
         if (two_pass && ivf) {
             // pass B order: pairs with probe rank >= 1 that survive the coarse bound, sorted by cell
             // (device counting sort; needs the thresholds pass A just produced)
-            HIPCK(h->ws_pcount.reserve((size_t)h->C));
+            HIPCK(h->ws_pcount.reserve((size_t)h->C + 1));
             HIPCK(h->ws_pstart.reserve((size_t)h->C + 1));
             HIPCK(h->ws_pcursor.reserve((size_t)h->C));
             HIPCK(h->ws_order.reserve((size_t)npairs));
             HIPCK(h->ws_keep.reserve((size_t)npairs));
-            if (!pcount_zeroed) HIPCK(hipMemsetAsync(h->ws_pcount.p, 0, (size_t)h->C * sizeof(int32_t), st));
+            if (!pcount_zeroed) HIPCK(hipMemsetAsync(h->ws_pcount.p, 0, ((size_t)h->C + 1) * sizeof(int32_t), st));
             PairBound PB{};
             PB.Q = dQ;
             PB.coarse = h->d_coarse;

@@ -3189,7 +3189,7 @@ __global__ void k_step_init(u64 *__restrict__ T, u32 *__restrict__ pool_cnt, lon
         T[i] = MMIDX_KEY_MAX;
         pool_cnt[i] = 0;
     }
-    if (pcount && i < C) pcount[i] = 0;
+    if (pcount && i <= C) pcount[i] = 0;  // ([C] = number of surviving pairs of the step)
     if (fb_header && i < 4) fb_header[i] = 0;
 }
 // Pass A on a shard: most queries' nearest cell lives on another rank, and a block per query that only finds an empty
@@ -3243,6 +3243,10 @@ __global__ void k_pair_hist(const int32_t *__restrict__ cells, int w, int rank_l
     const bool k = (c >= 0) & pair_keep(B, e, q, (int)cu);
     keep[e] = k ? 1 : 0;
     if (k) atomicAdd(cnt + (size_t)cu, 1);
+    // total of the step in cnt[C]: one atomic per wave that kept anything (none at all on separable data, where the
+    // kernels behind this one then leave at once)
+    const u64 mk = __builtin_amdgcn_ballot_w64(k);
+    if (mk && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)mk) - 1)) atomicAdd(cnt + B.C, (int)__popcll(mk));
 }
 // single block: exclusive scan of cnt[C] -> start[C]; start[C] = total; cursor zeroed
 // (host_hint: pinned host word that receives the total as well -- the next call sizes pass B's launch from it; written
@@ -3251,6 +3255,13 @@ __global__ __launch_bounds__(1024) void k_pair_scan(const int32_t *__restrict__ 
                                                     int32_t *__restrict__ cursor, int32_t *host_hint) {
     __shared__ u32 s_wave[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (cnt[C] == 0) {  // nothing survived the coarse bound: no order to build (k_pair_scatter keeps nothing either)
+        if (tid == 0) {
+            start[C] = 0;
+            if (host_hint) *host_hint = 0;
+        }
+        return;
+    }
     const int per = (C + 1023) / 1024;
     const int lo = tid * per, hi = (lo + per < C) ? lo + per : C;
     u32 sum = 0;
