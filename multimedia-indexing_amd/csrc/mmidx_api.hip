@@ -180,6 +180,7 @@ struct mmidx_index {
     int32_t *pin_hint = nullptr;  // pinned host word: pass B's item count of the previous call (launch sizing hint)
     int passb_main_grid = 0;      // > 0: fixed size of pass B's main launch (tests: force the looping tail kernel)
     int passa_hist = -1;     // MMIDX_PASSA_HIST: 1 = always use K3h in pass A, 0 = never, -1 = lists of >= 4096 codes on average
+    int passa_wide = 0;      // option "passa_wide" / MMIDX_PASSA_WIDE=1: K3h with 512-thread blocks
     int passa_prefix = 0;    // MMIDX_PASSA_PREFIX=n: pass A scans n codes exactly, the rest of the list filtered
     bool passa_su2 = false;  // MMIDX_PASSA_SU2=1: pass A with 2 codes per thread per segment (A/B switch)
     bool passa_filter = false;  // MMIDX_PASSA_FILTER=1
@@ -675,17 +676,29 @@ int launch_seed_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t st) {
     return MMIDX_OK;
 }
 
-template <int M>
-int launch_hist_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t st) {
-    if (P.ks == 256) {
-        HIPCK(hipFuncSetAttribute((const void *)k_scan_hist<M, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_scan_hist<M, 256>), grid, dim3(MMIDX_BLOCK), lds, st, P);
-    } else {
-        HIPCK(hipFuncSetAttribute((const void *)k_scan_hist<M, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_scan_hist<M, 0>), grid, dim3(MMIDX_BLOCK), lds, st, P);
+template <int M, int KS, int NT>
+int launch_hist_nt(const ScanParams &P, dim3 grid, size_t lds, hipStream_t st) {
+    if (KS == 256) {
+        // the KS = 256 kernel addresses its table from LDS address 0 (byte_x8): it must not own static LDS
+        static int static_lds = -1;
+        if (static_lds < 0) {
+            hipFuncAttributes fa{};
+            HIPCK(hipFuncGetAttributes(&fa, (const void *)k_scan_hist<M, KS, NT>));
+            static_lds = (int)fa.sharedSizeBytes;
+        }
+        if (static_lds != 0)
+            return fail(MMIDX_ERR_UNSUPPORTED, "k_scan_hist owns %d bytes of static LDS: its table is not at LDS address 0", static_lds);
     }
+    HIPCK(hipFuncSetAttribute((const void *)k_scan_hist<M, KS, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_scan_hist<M, KS, NT>), grid, dim3(NT), lds, st, P);
     HIPCK(hipGetLastError());
     return MMIDX_OK;
+}
+
+template <int M>
+int launch_hist_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t st, bool wide) {
+    if (P.ks == 256) return wide ? launch_hist_nt<M, 256, 512>(P, grid, lds, st) : launch_hist_nt<M, 256, 256>(P, grid, lds, st);
+    return wide ? launch_hist_nt<M, 0, 512>(P, grid, lds, st) : launch_hist_nt<M, 0, 256>(P, grid, lds, st);
 }
 
 // pass A over long lists: histogram-thresholded exact scan (K3h) + a K3 launch over the items it hands back.
@@ -697,10 +710,12 @@ int launch_scan_hist(mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 gr
     // a shard (at most half of the lists live here): launch over the queries whose nearest list is non-empty only
     const bool compact_items = P.ivf && P.nrank == 1 && P.rank_lo == 0 && grid.y == 1 && !h->no_item_compaction &&
                                h->nonempty_lists * 2 <= (int64_t)h->C && (int64_t)grid.x >= (int64_t)h->passa_item_min;
-    const size_t fixed = (size_t)h->m * h->ks * 8 + (h->transform ? 2 : 1) * (size_t)h->D * 8 + 64 + 16 + MMIDX_HB * 4 + 32;
-    // position buffer: what is left of a quarter of the CU's LDS (4 blocks per CU), within [768, 1536] entries
-    int64_t room = (int64_t)(160 * 1024 / 4) - 256 - (int64_t)fixed;
-    int cap = (int)std::min<int64_t>(4096, std::max<int64_t>(768, room / 4)) & ~3;  // a quarter per wave
+    const size_t fixed = (size_t)h->m * h->ks * 8 + (h->transform ? 2 : 1) * (size_t)h->D * 8 + 128 + 16 + MMIDX_HB * 4 + 48;
+    // 256 threads: four blocks per CU; 512 threads (option "passa_wide"): three, six waves per SIMD
+    const bool wide = h->passa_wide != 0;
+    // position buffer: what is left of the block's share of the CU's LDS, within [768, 4096] entries
+    int64_t room = (int64_t)(160 * 1024 / (wide ? 3 : 4)) - 256 - (int64_t)fixed;
+    int cap = (int)std::min<int64_t>(4096, std::max<int64_t>(768, room / 4)) & ~7;  // an equal share per wave
     const size_t lds = fixed + (size_t)cap * 4;
     if (lds > 64 * 1024) return 1;
     const size_t nfb = (size_t)grid.x * grid.y;
@@ -729,9 +744,9 @@ int launch_scan_hist(mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 gr
     }
     int rc;
     switch (h->m) {
-        case 8: rc = launch_hist_t<8>(P, grid, lds, st); break;
-        case 16: rc = launch_hist_t<16>(P, grid, lds, st); break;
-        default: rc = launch_hist_t<32>(P, grid, lds, st); break;
+        case 8: rc = launch_hist_t<8>(P, grid, lds, st, wide); break;
+        case 16: rc = launch_hist_t<16>(P, grid, lds, st, wide); break;
+        default: rc = launch_hist_t<32>(P, grid, lds, st, wide); break;
     }
     if (rc) return rc;
     if (h->debug_sync) {
@@ -1453,6 +1468,8 @@ int mmidx_create(int kind, int D, int m, int ks, int C, int transform, const int
         h->coarse_v1 = cv1 && cv1[0] == '1';
         const char *ph = getenv("MMIDX_PASSA_HIST");
         if (ph) h->passa_hist = atoi(ph);
+        const char *pw = getenv("MMIDX_PASSA_WIDE");
+        if (pw) h->passa_wide = atoi(pw);
         const char *pp = getenv("MMIDX_PASSA_PREFIX");
         if (pp) h->passa_prefix = atoi(pp);
         const char *pf = getenv("MMIDX_PASSA_FILTER");
@@ -2225,6 +2242,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->passa_item_margin = value;
     } else if (n == "passa_hist") {
         h->passa_hist = value;
+    } else if (n == "passa_wide") {
+        h->passa_wide = value;
     } else if (n == "no_grp") {  // pass B through K3f (one block per (query, list)) instead of the grouped K3g
         h->no_grp = value != 0;
     } else if (n == "grp_blocks") {

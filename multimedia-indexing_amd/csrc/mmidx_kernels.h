@@ -297,7 +297,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_reg(const double 
 #define MMIDX_HIST_DEBUG 0  // debug: K3h adds overflow / appended / kept totals to the fallback header
 #endif
 #ifndef MMIDX_HIST_STOP
-#define MMIDX_HIST_STOP 0  // debug: truncate k_scan_hist (1 = after the scan loop, 2 = before the final sort)
+#define MMIDX_HIST_STOP 0  // debug: truncate k_scan_hist (1 = after the scan loop, 3 = same with no candidates, 4 = after the table build, 5 = as 3 on a synthetic table: the loop alone)
 #endif
 #ifndef MMIDX_SCAN_STOP
 #define MMIDX_SCAN_STOP 0  // debug: truncate k_scan (1 = after the LUT build, 2 = no candidate handling)
@@ -1672,6 +1672,21 @@ struct ScanParams {
 #define MMIDX_SEGU 2  // codes per thread per segment
 #define MMIDX_SEG (MMIDX_BLOCK * MMIDX_SEGU)
 
+// 8 * (byte b of w) in ONE VALU instruction (SDWA byte select on the shift's operand): the byte offset of a fp64 table
+// entry.  (The compiler's own sequence is v_bfe_u32 + v_lshl_add_u32.)  b is a constant after unrolling.
+__device__ __forceinline__ u32 byte_x8(u32 w, int b) {
+    u32 r;
+    const u32 three = 3u;
+    switch (b & 3) {
+        case 0: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "s"(three), "v"(w)); break;
+        case 1: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "s"(three), "v"(w)); break;
+        case 2: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "s"(three), "v"(w)); break;
+        default: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "s"(three), "v"(w)); break;
+    }
+    return r;
+}
+typedef __attribute__((address_space(3))) const double lds_cdouble;
+
 template <int M, typename CodeT>
 struct CodeVec {
     static constexpr int BYTES = M * (int)sizeof(CodeT);
@@ -2068,8 +2083,17 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
 #define MMIDX_HB 256
 #define MMIDX_HKEEP 256  // most entries one item may emit (>= K1 required: the host checks; the pool has room for them)
 #define MMIDX_HPOS 4     // appended positions re-evaluated per thread per round at the end
+#ifndef MMIDX_K3H_SDWA
+#define MMIDX_K3H_SDWA 1  // K3h: table offsets by SDWA byte select (1 VALU per lookup instead of 2)
+#endif
 #ifndef MMIDX_K3H_PAIR
 #define MMIDX_K3H_PAIR 2  // K3h: 1 + this many segments per round of the scan loop (0 = the one-segment loop; 3 costs a block per CU)
+#endif
+#ifndef MMIDX_K3H_PAIR512
+#define MMIDX_K3H_PAIR512 1  // the same for 512-thread blocks (80 VGPRs at six waves per SIMD)
+#endif
+#ifndef MMIDX_K3H_WPS512
+#define MMIDX_K3H_WPS512 6
 #endif
 #ifndef MMIDX_HREF_EARLY
 #define MMIDX_HREF_EARLY 16  // the threshold bucket is re-derived every segment at first ...
@@ -2080,20 +2104,20 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
 
 // KS = 256: the usual codebook size as a compile-time constant (the table row of sub-quantizer s then sits at an
 // immediate offset of the gather's ds_read instead of costing a VALU add per lookup); KS = 0: ks from the parameters.
-template <int M, int KS>
-__global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
+template <int M, int KS, int NT>
+__global__ __launch_bounds__(NT, NT == 512 ? MMIDX_K3H_WPS512 : 1) void k_scan_hist(const ScanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NT = MMIDX_BLOCK;
+    constexpr int WV = NT / 64;  // waves: 4, or 8 (NT = 512: three blocks per CU, six waves per SIMD over the same tables)
     const int ks = KS > 0 ? KS : P.ks, D = P.D;
     double *lut = (double *)smem;                                        // [M*ks]
     double *vec = lut + (size_t)M * ks;                                  // [D] or [2D]
-    double *s_red = vec + (P.transform ? 2 : 1) * (size_t)D;             // [8] wave minima / maxima of segment 0
+    double *s_red = vec + (P.transform ? 2 : 1) * (size_t)D;             // [16] wave minima / r-th values of segment 0
     // [HB], 16-byte aligned (read as uint4).  The offset is computed on the index, not on the pointer value: a cast
     // through uintptr_t loses the LDS address space and every access below becomes a FLAT instruction
-    const size_t hist_off = ((((size_t)M * ks + (P.transform ? 2 : 1) * (size_t)D + 8) * 8) + 15) & ~(size_t)15;
+    const size_t hist_off = ((((size_t)M * ks + (P.transform ? 2 : 1) * (size_t)D + 16) * 8) + 15) & ~(size_t)15;
     u32 *hist = (u32 *)(smem + hist_off);
-    u32 *s_cnt = hist + MMIDX_HB;                                        // [8]: 0-3 appended per wave, 4-5 largest kept key (u64)
-    u32 *posbuf = s_cnt + 8;                                             // [cap] list positions, one quarter per wave
+    u32 *s_cnt = hist + MMIDX_HB;                                        // [12]: 0-7 appended per wave, 8-9 largest kept key (u64), 10 kept, 11 pool base
+    u32 *posbuf = s_cnt + 12;                                            // [cap] list positions, one quarter per wave
 
     int item = blockIdx.x;
     if (P.order) {  // (a shard's pass A: the queries whose nearest list is here, k_passa_items)
@@ -2126,19 +2150,36 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
         const int64_t i = c0 + tid;
         cur.load(codes + (size_t)(i < c1 ? i : c1 - 1) * M);
     }
-    for (int i = tid; i < MMIDX_HB + 8; i += NT) hist[i] = 0;  // histogram and the counters
+    for (int i = tid; i < MMIDX_HB + 12; i += NT) hist[i] = 0;  // histogram and the counters
     const double *tr = query_vector(P, q, cell, vec);
+#if MMIDX_HIST_STOP == 5  // timing experiment: no table build (the loop alone, on a synthetic table)
+    for (int i = tid; i < M * ks; i += NT) lut[i] = 1e-3 * (double)((i * 37) & 255) + tr[i & 7];
+#else
     build_lut_any(lut, tr, P.pqT, M, ks, P.dsub);
+#endif
     __syncthreads();
 
     // (0.0 + x == x bit for bit: the table entries are sums of squares from +0.0, never -0.0, so the reference's
     //  `d = 0; d += LUT[0][..]` is the first entry itself)
+    // table entry of sub-quantizer s for the code's byte s.  KS = 256: the byte offset 8 * byte comes from one SDWA shift and
+    // the row from the ds_read's immediate offset (the table starts the block's LDS: the kernel has no static LDS, so
+    // the dynamic segment begins at LDS address 0 -- checked by the host against the function's static size)
+    auto entry = [&](const CodeVec<M, unsigned char> &cv, const int s) -> double {
+#if MMIDX_K3H_SDWA
+        if constexpr (KS == 256) return *(lds_cdouble *)(size_t)(byte_x8(cv.wd[s >> 2], s & 3) + (u32)s * 2048u);
+#endif
+        return lut[s * ks + cv.get(s)];
+    };
     auto exact = [&](const CodeVec<M, unsigned char> &cv) -> double {
-        double d = lut[cv.get(0)];
+        double d = entry(cv, 0);
 #pragma unroll
-        for (int s = 1; s < M; s++) d += lut[s * ks + cv.get(s)];
+        for (int s = 1; s < M; s++) d += entry(cv, s);
         return d;
     };
+#if MMIDX_HIST_STOP == 4
+    if (lut[tid] == 12345.678) P.pool_cnt[q] = 1;
+    return;
+#endif
 
     // ---- segment 0: the bucket map and the first threshold bucket ---------------------------------
     // Each wave sorts its 64 distances in registers and reports its minimum and its r-th smallest,
@@ -2160,7 +2201,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
         const double wq = wave_read_f64(v, __ffsll((long long)__ballot(rank == r_sel - 1)) - 1);
         if (lane == 0) {
             s_red[wv] = wmin;
-            s_red[4 + wv] = wq;
+            s_red[WV + wv] = wq;
         }
     }
     __syncthreads();
@@ -2169,18 +2210,18 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
     {
         const double inf = __longlong_as_double(0x7FF0000000000000ll);
         double mn = s_red[0];
-        qr = s_red[4];
+        qr = s_red[WV];
 #pragma unroll
         for (int i = 1; i < NT / 64; i++) {
             mn = s_red[i] < mn ? s_red[i] : mn;
-            qr = s_red[4 + i] > qr ? s_red[4 + i] : qr;
+            qr = s_red[WV + i] > qr ? s_red[WV + i] : qr;
         }
         if (!(qr < inf)) {  // a wave with fewer than r entries (short list): no first threshold, scale from what there is
             qr_valid = false;
             qr = -inf;
 #pragma unroll
             for (int i = 0; i < NT / 64; i++) {
-                const double a = s_red[4 + i];
+                const double a = s_red[WV + i];
                 qr = (a < inf && a > qr) ? a : qr;
             }
             if (!(qr > -inf)) qr = mn;
@@ -2225,7 +2266,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
     u32 *mybuf = posbuf + (size_t)wv * capw;
     u32 wcnt = 0;  // wave-uniform
     int Tb = qr_valid ? bucket(qr) : MMIDX_HB - 1;
-#if MMIDX_HIST_STOP == 3
+#if MMIDX_HIST_STOP == 3 || MMIDX_HIST_STOP == 5
     Tb = -1;
 #endif
     // The loop is VALU-bound as much as LDS-bound (PMC: VALU ~78 % busy, LDS ~73 %), so its bookkeeping is kept in
@@ -2247,7 +2288,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
     // U = MMIDX_K3H_PAIR + 1 segments per round: their table gathers are independent chains (U times the LDS requests in
     // flight per wave) and the round's bookkeeping -- loop control, prefetch addresses, the threshold refresh -- is paid
     // once.  Segment 0 (already summed into d) is candidate-tested first, on its own.
-    constexpr int U = MMIDX_K3H_PAIR + 1;
+    constexpr int U = (NT == 512 ? MMIDX_K3H_PAIR512 : MMIDX_K3H_PAIR) + 1;
     auto offer = [&](const double dd, const u32 pos) {
         const int b = bucket_fast(dd);
         const bool pass = (pos < n_seg) && b <= Tb;
@@ -2276,16 +2317,16 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
 #pragma unroll
             for (int u = 0; u < U; u++) fetch(nx[u], seg + (u32)(U + u) * NT + (u32)tid);
         }
-        const bool refresh = MMIDX_HIST_STOP != 3 && (g < MMIDX_HREF_EARLY / U || (g & 1) == 0);
+        const bool refresh = MMIDX_HIST_STOP != 3 && MMIDX_HIST_STOP != 5 && (g < MMIDX_HREF_EARLY / U || (g & 1) == 0);
         uint4 hv;  // live only on refresh rounds
         if (refresh) hv = ((const uint4 *)hist)[lane];  // buckets 4*lane .. 4*lane+3
         double dd[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) dd[u] = lut[cu[u].get(0)];
+        for (int u = 0; u < U; u++) dd[u] = entry(cu[u], 0);
 #pragma unroll
         for (int sq = 1; sq < M; sq++) {
 #pragma unroll
-            for (int u = 0; u < U; u++) dd[u] += lut[sq * ks + cu[u].get(sq)];
+            for (int u = 0; u < U; u++) dd[u] += entry(cu[u], sq);
         }
 #pragma unroll
         for (int u = 0; u < U; u++) offer(dd[u], seg + (u32)u * NT + (u32)tid);
@@ -2332,7 +2373,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
 #endif
     if (lane == 0) s_cnt[wv] = wcnt;
     __syncthreads();
-#if MMIDX_HIST_STOP == 1 || MMIDX_HIST_STOP == 3
+#if MMIDX_HIST_STOP == 1 || MMIDX_HIST_STOP == 3 || MMIDX_HIST_STOP == 5
     if (Tb < -1) P.pool_cnt[q] = 1;
     return;
 #endif
@@ -2401,7 +2442,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
         __syncthreads();
         // the pool space of all kept_total entries is reserved now, so that the reservation's round trip overlaps the
         // compaction and the code loads (entries above another chunk's threshold are written too: harmless)
-        if (tid == 0) s_cnt[7] = atomicAdd(P.pool_cnt + q, kept_total);
+        if (tid == 0) s_cnt[11] = atomicAdd(P.pool_cnt + q, kept_total);
         const u32 mine = s_cnt[wv];  // <= capw here
         for (u32 e0 = 0; e0 < mine; e0 += 64) {
             const u32 e = e0 + (u32)lane;
@@ -2411,13 +2452,13 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
             if (mask) {
                 u32 base = 0;
                 const int leader = __ffsll((long long)mask) - 1;
-                if (lane == leader) base = atomicAdd(s_cnt + 6, (u32)__popcll(mask));
+                if (lane == leader) base = atomicAdd(s_cnt + 10, (u32)__popcll(mask));
                 base = wave_read_u32(base, leader);
                 if (keep) keptpos[base + (u32)__popcll(mask & lane_lt)] = v & 0xFFFFFFu;
             }
         }
         __syncthreads();
-        const bool have = (u32)tid < kept_total;  // == s_cnt[6]
+        const bool have = (u32)tid < kept_total;  // == s_cnt[10]
         const u32 p = have ? (u32)c0 + keptpos[tid] : (u32)c0;
         CodeVec<M, unsigned char> cv;
         cv.load(codes + (size_t)p * M);
@@ -2425,7 +2466,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
         const u64 key = dkey(dd);
         if (have) {
             kmax = key;
-            const u32 slot = s_cnt[7] + (u32)tid;  // (written before the barrier above)
+            const u32 slot = s_cnt[11] + (u32)tid;  // (written before the barrier above)
             if (slot < (u32)P.poolq) {
                 P.pool_key[(size_t)q * P.poolq + slot] = key;
                 P.pool_val[(size_t)q * P.poolq + slot] = ((u64)pr << 32) | (u64)p;
@@ -2457,7 +2498,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_hist(const ScanParams P) {
             const u64 o = __shfl_xor(kmax, off);
             kmax = o > kmax ? o : kmax;
         }
-        u64 *s_max = (u64 *)(s_cnt + 4);  // zeroed with the histogram, 8-byte aligned
+        u64 *s_max = (u64 *)(s_cnt + 8);  // zeroed with the histogram, 8-byte aligned
         if (lane == 0) atomicMax(s_max, kmax);
         __syncthreads();
         if (tid == 0) atomicMin(Tq, *s_max);

@@ -816,6 +816,10 @@ def test_pass_a_histogram_kernel(mi, oracle, case):
     ks_list = (1023,) if case == "k1023_falls_back" else (1, 10, 100, 255)
     for k in ks_list:
         assert_same(ix.search_batch(k, q), ref.search_batch(q, k))
+    # the 512-thread form of K3h (eight waves over one table; measured slower on cfg4, kept as a switch)
+    ix.set_option("passa_wide", 1)
+    for k in ks_list[-2:]:
+        assert_same(ix.search_batch(k, q), ref.search_batch(q, k))
     ix.close()
 
 
