@@ -64,6 +64,18 @@ def gpu_kmeans(cx, X, k, iters, seed=1, init=None, plus_plus=False):
     return out
 
 
+def same_codebooks(cx, coarse_h, pq_h):
+    """every rank learns the codebooks from the same seeds; rank 0's copy is broadcast so that the shards agree bit for bit
+    on the quantizers (list ownership = cell mod N) whatever the reduction order of a rank's k-means was"""
+    if cx.dist is None:
+        return coarse_h, pq_h
+    torch = cx.torch
+    tc, tp = torch.from_numpy(coarse_h).to(cx.dev), torch.from_numpy(pq_h).to(cx.dev)
+    cx.dist.broadcast(tc, src=0)
+    cx.dist.broadcast(tp, src=0)
+    return tc.cpu().numpy(), tp.cpu().numpy()
+
+
 def learn_codebooks(cx, sigma):
     """mixture means, coarse quantizer (Lloyd from the means, 2 iterations) and residual PQ codebooks (k-means++ per
     sub-space on centroid - vector, ResidualVectorComputation.java:34)"""
@@ -278,7 +290,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=100_000_000)
+    ap.add_argument("--n", "--vectors", dest="n", type=int, default=100_000_000)  # (--vectors: `--n` is an ambiguous prefix for torch.distributed.run)
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--cells", type=int, default=8192)
     ap.add_argument("--w", type=int, default=32)
@@ -304,6 +316,7 @@ def main():
                     help="extra untimed-for-value steps with pruning off, reported as roofline_exhaustive (0 = skip)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
                     help="mmidx_set_option(NAME, INT) on the index before the timed steps (kernel A/B switches)")
+    ap.add_argument("--dump", default="", metavar="PREFIX", help="write batch 0's answers of every rank to PREFIX.rank<r>.npz")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path (encode -> owner filter -> add_codes, two-phase shard search, "
                          "merge) even with one rank: exercises it on a single GPU")
@@ -328,7 +341,10 @@ def main():
 
     cx.world = world = int(os.environ.get("WORLD_SIZE", "1"))
     cx.rank = rank = int(os.environ.get("RANK", "0"))
-    cx.local = local = int(os.environ.get("LOCAL_RANK", "0"))
+    # MMIDX_BENCH_ONE_GPU=1 (tests/test_gpu_two_ranks.py): every rank on GPU 0, gloo collectives staged through the host --
+    # a functional run of the N > 1 path on a one-GPU box (RCCL refuses two ranks on one device); never a measurement
+    one_gpu = os.environ.get("MMIDX_BENCH_ONE_GPU") == "1"
+    cx.local = local = 0 if one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local)
@@ -338,7 +354,11 @@ def main():
         # (--force-sharded under torch.distributed.run with one rank: the RCCL calls run on a 1-rank group)
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+            dist = importlib.import_module("multimedia-indexing_amd.sharded").HostStagedDist(dist)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     cx.dist = dist
 
     N, D, Cc, w, m, k = args.n, args.dim, args.cells, args.w, args.m, args.k
@@ -351,6 +371,7 @@ def main():
 
     # ---------------------------------------------------------------- headline workload
     mu, coarse_h, pq_h = learn_codebooks(cx, args.sigma)
+    coarse_h, pq_h = same_codebooks(cx, coarse_h, pq_h)
     nq_total = B * args.nbatches
     h, Q = build_index(cx, mu, args.sigma, coarse_h, pq_h, nq_total, sharded_build=not single)
     Qb = [Q[i * B:(i + 1) * B].contiguous() for i in range(args.nbatches)]
@@ -420,6 +441,12 @@ def main():
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
     qps = B * args.steps / elapsed
+    if args.dump:  # the answers of batch 0 as this rank holds them (its B / N queries): compared across world sizes by the tests
+        step(Qb[0])
+        barrier()
+        n_own = B if sharded is None else per_rank
+        np.savez(f"{args.dump}.rank{rank}.npz", iid=iid_out[:n_own].cpu().numpy(), dist=dist_out[:n_own].cpu().numpy(),
+                 cnt=cnt_out[:n_own].cpu().numpy())
 
     # the same steps with every exact shortcut switched off (each probed code read and summed in fp64):
     # the configuration on which the exact scan kernel's HBM roofline fraction is a meaningful figure

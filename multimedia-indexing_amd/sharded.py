@@ -159,6 +159,46 @@ class HipShardEngine:
                                                     tau.data_ptr(), counts.data_ptr(), pB.data_ptr(), tie_iids.data_ptr(), self._stream()))
 
 
+class HostStagedDist:
+    """torch.distributed look-alike for FUNCTIONAL runs of the N > 1 path where RCCL cannot form the group -- two ranks on one
+    GPU (RCCL refuses duplicate devices): the collectives of a gloo group, device tensors staged through host memory.
+    Same call signatures as the torch.distributed functions ShardedIVFPQ and bench.py use; everything else is passed through.
+    Not a performance path: bench.py selects it only under MMIDX_BENCH_ONE_GPU=1 (tests/test_gpu_two_ranks.py)."""
+
+    def __init__(self, dist):
+        self._d = dist
+        self.ReduceOp = dist.ReduceOp
+
+    def __getattr__(self, name):
+        return getattr(self._d, name)
+
+    def all_reduce(self, x, op=None, group=None):
+        c = x.cpu()
+        self._d.all_reduce(c, op=self._d.ReduceOp.SUM if op is None else op, group=group)
+        x.copy_(c)
+
+    def all_gather(self, parts, x, group=None):
+        self._d.all_gather(parts, x, group=group)
+
+    def all_gather_into_tensor(self, out, x, group=None):
+        torch = __import__("torch")
+        c = x.cpu().contiguous()
+        parts = [torch.empty_like(c) for _ in range(self._d.get_world_size(group))]
+        self._d.all_gather(parts, c, group=group)
+        out.copy_(torch.stack(parts).reshape(out.shape))
+
+    def all_to_all_single(self, out, x, output_split_sizes=None, input_split_sizes=None, group=None):
+        torch = __import__("torch")
+        co = torch.empty(out.shape, dtype=out.dtype)
+        self._d.all_to_all_single(co, x.cpu().contiguous(), output_split_sizes, input_split_sizes, group=group)
+        out.copy_(co)
+
+    def broadcast(self, x, src=0, group=None):
+        c = x.cpu()
+        self._d.broadcast(c, src=src, group=group)
+        x.copy_(c)
+
+
 class ShardedIVFPQ:
     """computeNearestNeighbors over `world` shards (IVFPQ.computeKnnIVFADC, IVFPQ.java:408-450).
 
