@@ -2087,7 +2087,7 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
 #define MMIDX_K3H_SDWA 1  // K3h: table offsets by SDWA byte select (1 VALU per lookup instead of 2)
 #endif
 #ifndef MMIDX_K3H_PAIR
-#define MMIDX_K3H_PAIR 2  // K3h: 1 + this many segments per round of the scan loop (0 = the one-segment loop; 3 costs a block per CU)
+#define MMIDX_K3H_PAIR 2  // K3h: 1 + this many segments per round of the scan loop (3 costs a block per CU)
 #endif
 #ifndef MMIDX_K3H_PAIR512
 #define MMIDX_K3H_PAIR512 1  // the same for 512-thread blocks (80 VGPRs at six waves per SIMD)
@@ -2095,11 +2095,11 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
 #ifndef MMIDX_K3H_WPS512
 #define MMIDX_K3H_WPS512 6
 #endif
-#ifndef MMIDX_HREF_EARLY
-#define MMIDX_HREF_EARLY 16  // the threshold bucket is re-derived every segment at first ...
+#ifndef MMIDX_HREF_LATE
+#define MMIDX_HREF_LATE 12  // ... and from this round (of U segments) on every fourth
 #endif
-#ifndef MMIDX_HREF_MASK
-#define MMIDX_HREF_MASK 3    // ... then every (mask + 1)-th
+#ifndef MMIDX_HREF_EARLY
+#define MMIDX_HREF_EARLY 16  // the threshold bucket is re-derived every round for this many segments, then every second round ...
 #endif
 
 // KS = 256: the usual codebook size as a compile-time constant (the table row of sub-quantizer s then sits at an
@@ -2189,19 +2189,23 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMIDX_K3H_WPS512 : 1) void k_scan_h
     double d = exact(cur);
     const int r_sel = (P.K1 + NT / 64 - 1) / (NT / 64);  // <= 64: the host launches K3h for K1 <= 256 only
     {
-        const double inf = __longlong_as_double(0x7FF0000000000000ll);
-        const double v = (c0 + tid < c1) ? d : inf;
-        int rank = 0;  // position of this lane's value in the wave's ascending order (ties by lane)
-#pragma unroll 16
-        for (int j = 0; j < 64; j++) {
-            const double o = wave_read_f64(v, j);
-            rank += (o < v) || (o == v && j < lane);
+        // wmin / the r-th smallest to 2^-20 relative: distances are >= 0, so the high words of their bit patterns order them;
+        // the wave bisects on that word (one compare + scalar popcount per step) instead of ranking 64 values against each
+        // other (64 x two v_readlane + compares: 8 % of the kernel's VALU instructions).  Reported: the smallest pattern with
+        // that high word (a lower bound of the minimum) and the largest pattern whose high word has >= r values at or under
+        // it (>= r values of the wave are at or below it: all that the first threshold needs).
+        const u32 hw = (c0 + tid < c1) ? (u32)(dkey(d) >> 32) : 0x7FF00000u;  // (NaN / inf / padding: above everything finite)
+        u32 lo_k = wave_min_u32(hw), hi_k = wave_max_u32(hw);
+        const u32 mn_k = lo_k;
+        while (lo_k < hi_k) {  // smallest word with at least r_sel values at or below it
+            const u32 mid = lo_k + ((hi_k - lo_k) >> 1);
+            if ((int)__popcll(__builtin_amdgcn_ballot_w64(hw <= mid)) >= r_sel) hi_k = mid;
+            else lo_k = mid + 1;
         }
-        const double wmin = wave_read_f64(v, __ffsll((long long)__ballot(rank == 0)) - 1);
-        const double wq = wave_read_f64(v, __ffsll((long long)__ballot(rank == r_sel - 1)) - 1);
+        const bool enough = (int)__popcll(__builtin_amdgcn_ballot_w64(hw <= hi_k)) >= r_sel && hi_k < 0x7FF00000u;
         if (lane == 0) {
-            s_red[wv] = wmin;
-            s_red[WV + wv] = wq;
+            s_red[wv] = mn_k < 0x7FF00000u ? keyd((u64)mn_k << 32) : __longlong_as_double(0x7FF0000000000000ll);
+            s_red[WV + wv] = enough ? keyd(((u64)hi_k << 32) | 0xFFFFFFFFull) : __longlong_as_double(0x7FF0000000000000ll);
         }
     }
     __syncthreads();
@@ -2280,20 +2284,21 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMIDX_K3H_WPS512 : 1) void k_scan_h
         const u32 lo32 = (u32)__builtin_amdgcn_readfirstlane((int)(u32)e0), hi32 = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(e0 >> 32));
         codes0 = (const unsigned char *)P.codes + (size_t)(((u64)hi32 << 32) | lo32) * M;
     }
-    auto bucket_fast = [&](double dd) -> int {  // == bucket(dd): the same monotone map, clamped in fp64 before the conversion
-        const double x = (dd - lo) * inv;
-        return (int)__builtin_fmax(__builtin_fmin(x, (double)(MMIDX_HB - 1)), 0.0);
-    };
-#if MMIDX_K3H_PAIR
     // U = MMIDX_K3H_PAIR + 1 segments per round: their table gathers are independent chains (U times the LDS requests in
     // flight per wave) and the round's bookkeeping -- loop control, prefetch addresses, the threshold refresh -- is paid
     // once.  Segment 0 (already summed into d) is candidate-tested first, on its own.
     constexpr int U = (NT == 512 ? MMIDX_K3H_PAIR512 : MMIDX_K3H_PAIR) + 1;
+    // bucket(dd) <= Tb  <=>  (dd - lo) * inv < Tb + 1 (the clamp to [0, HB - 1] cannot change the comparison unless
+    // Tb = HB - 1, where everything passes: the bound is NaN then and `!(x >= NaN)` holds).  Two fp64 operations and a compare
+    // per code; the bucket itself (clamp, convert) is computed by the candidates only.  A NaN distance passes and lands in
+    // the last bucket, which is harmless: appended entries above the final bucket are dropped at the end.
+    double TbP1 = Tb >= MMIDX_HB - 1 ? __longlong_as_double(0x7FF8000000000000ll) : (double)(Tb + 1);
     auto offer = [&](const double dd, const u32 pos) {
-        const int b = bucket_fast(dd);
-        const bool pass = (pos < n_seg) && b <= Tb;
+        const double x = (dd - lo) * inv;
+        const bool pass = (pos < n_seg) && !(x >= TbP1);
         const u64 mask = __builtin_amdgcn_ballot_w64(pass);
         if (pass) {
+            const int b = (int)__builtin_fmax(__builtin_fmin(x, (double)(MMIDX_HB - 1)), 0.0);
             atomicAdd(hist + b, 1u);
             const u32 slot = wcnt + (u32)__popcll(mask & lane_lt);
             if (slot < capw) mybuf[slot] = ((u32)b << 24) | pos;
@@ -2317,7 +2322,8 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMIDX_K3H_WPS512 : 1) void k_scan_h
 #pragma unroll
             for (int u = 0; u < U; u++) fetch(nx[u], seg + (u32)(U + u) * NT + (u32)tid);
         }
-        const bool refresh = MMIDX_HIST_STOP != 3 && MMIDX_HIST_STOP != 5 && (g < MMIDX_HREF_EARLY / U || (g & 1) == 0);
+        const bool refresh = MMIDX_HIST_STOP != 3 && MMIDX_HIST_STOP != 5 &&
+                             (g < MMIDX_HREF_EARLY / U || (g < MMIDX_HREF_LATE ? (g & 1) == 0 : (g & 3) == 0));
         uint4 hv;  // live only on refresh rounds
         if (refresh) hv = ((const uint4 *)hist)[lane];  // buckets 4*lane .. 4*lane+3
         double dd[U];
@@ -2334,43 +2340,13 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMIDX_K3H_WPS512 : 1) void k_scan_h
             u32 upto, total;
             const int cand = threshold_bucket(hv, upto, total);
             Tb = cand < Tb ? cand : Tb;
+            TbP1 = Tb >= MMIDX_HB - 1 ? __longlong_as_double(0x7FF8000000000000ll) : (double)(Tb + 1);
         }
         if (more) {
 #pragma unroll
             for (int u = 0; u < U; u++) cu[u] = nx[u];
         }
     }
-#else
-    u32 g = 0;
-    for (u32 seg = 0; seg < n_seg; seg += NT, g++) {
-        const bool more = seg + NT < n_seg;  // scalar
-        if (more) {
-            const u32 i = seg + NT + (u32)tid;
-            const u32 ic = i < n_seg ? i : n_seg - 1u;
-            nxt.load(codes0 + ic * (u32)M);  // (32-bit offset from a uniform base)
-        }
-        const bool refresh = MMIDX_HIST_STOP != 3 && g > 0 && (g < MMIDX_HREF_EARLY || (g & MMIDX_HREF_MASK) == 0);
-        uint4 hv;  // live only on refresh rounds
-        if (refresh) hv = ((const uint4 *)hist)[lane];  // buckets 4*lane .. 4*lane+3
-        if (g > 0) d = exact(cur);
-        const u32 pos = seg + (u32)tid;
-        const int b = bucket_fast(d);
-        const bool pass = (pos < n_seg) && b <= Tb;
-        const u64 mask = __builtin_amdgcn_ballot_w64(pass);
-        if (pass) {
-            atomicAdd(hist + b, 1u);
-            const u32 slot = wcnt + (u32)__popcll(mask & lane_lt);
-            if (slot < capw) mybuf[slot] = ((u32)b << 24) | pos;
-        }
-        wcnt += (u32)__popcll(mask);  // > capw: overflow, seen at the end
-        if (refresh) {
-            u32 upto, total;
-            const int cand = threshold_bucket(hv, upto, total);
-            Tb = cand < Tb ? cand : Tb;
-        }
-        if (more) cur = nxt;
-    }
-#endif
     if (lane == 0) s_cnt[wv] = wcnt;
     __syncthreads();
 #if MMIDX_HIST_STOP == 1 || MMIDX_HIST_STOP == 3 || MMIDX_HIST_STOP == 5

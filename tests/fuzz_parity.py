@@ -42,7 +42,9 @@ for case in range(cases):
     dup = rng.random() < 0.3
     hist = int(rng.choice([-1, 1, 0]))
     v1 = int(rng.random() < 0.25)
-    desc = dict(kind=kind, D=D, m=m, ks=ks, n=n, k=k, C=C, w=w, tr=tr, dup=dup, hist=hist, v1=v1)
+    wide = int(rng.random() < 0.3)
+    nogrp = int(rng.random() < 0.2)
+    desc = dict(kind=kind, D=D, m=m, ks=ks, n=n, k=k, C=C, w=w, tr=tr, dup=dup, hist=hist, v1=v1, wide=wide, nogrp=nogrp)
     try:
         nb = min(n, 3000)
         if kind == "ivfpq":
@@ -68,6 +70,8 @@ for case in range(cases):
         ref.set_pq(p["pq"])
         ix.set_option("passa_hist", hist)
         ix.set_option("coarse_v1", v1)
+        ix.set_option("passa_wide", wide)
+        ix.set_option("no_grp", nogrp)
         half = n // 2
         ix.indexVectors([str(i) for i in range(half)], base[:half])
         if half:
