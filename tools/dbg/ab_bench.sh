@@ -10,7 +10,8 @@ for v in "$@"; do
 import json
 try:
     j = json.loads(open("$out/$v.json").read().strip().splitlines()[-1])
-    print("$v", j["value"], j["ms_per_step"], "passA ms", j["roofline"].get("avg_launch_ms"), "frac", j["roofline"].get("frac"))
+    w = j.get("roofline_whole_search") or {}
+    print("$v", j["value"], j["ms_per_step"], "passA ms", j["roofline"].get("avg_launch_ms"), "frac", j["roofline"].get("frac"), "coarse ms", w.get("coarse_ms_per_step"), "merge ms", w.get("merge_ms_per_step"))
 except Exception as e:
     print("$v failed", e)
 PY
