@@ -815,6 +815,15 @@ int build_grp_tables(mmidx_index *h) {
 
 template <int M, int G, int DSUB>
 int launch_grp_t(mmidx_index *h, const GrpParams &GP, size_t lds, hipStream_t st) {
+    {   // the scan addresses the u8 rows from LDS address 0 (GrpLds::lut8 == 0, byte_x8): the kernel must not own static LDS
+        static int static_lds = -1;
+        if (static_lds < 0) {
+            hipFuncAttributes fa{};
+            HIPCK(hipFuncGetAttributes(&fa, (const void *)k_scan_grp<M, G, DSUB>));
+            static_lds = (int)fa.sharedSizeBytes;
+        }
+        if (static_lds != 0) return 1;  // (K3f takes the pairs)
+    }
     HIPCK(hipFuncSetAttribute((const void *)k_scan_grp<M, G, DSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int blocks = h->grp_blocks;
     if (blocks <= 0) {

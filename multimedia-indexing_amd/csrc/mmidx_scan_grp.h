@@ -38,6 +38,12 @@
 #ifndef GRP_EPOCH
 #define GRP_EPOCH 4  // segments between two block barriers of the scan
 #endif
+#ifndef GRP_INTERLEAVED
+#define GRP_INTERLEAVED 1  // u8 rows entry-major: the group's bytes of one entry side by side, one table read per code and sub-quantizer
+#endif
+#ifndef GRP_RW
+#define GRP_RW 4  // table reads in flight per code in the interleaved scan (2, 4 or 8)
+#endif
 #ifndef GRP_WPS
 #define GRP_WPS 4  // waves per SIMD the register allocation is held to (blocks per CU x 2)
 #endif
@@ -247,7 +253,7 @@ template <int M, int G, int DSUB>
 __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P) {
     static_assert(M % 8 == 0 && G <= 8 && G * M * 256 <= 65536, "imm offsets of the table reads");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int LQ = M * 256;  // bytes of one query's u8 table
+    [[maybe_unused]] constexpr int LQ = M * 256;  // bytes of one query's u8 table (query-major layout)
     constexpr int SPW = M / 8;   // sub-quantizers per wave in the table build
     constexpr int EPL = M / 4;   // exact entries per lane of a verifying quad
     const int D = P.S.D, ks = P.S.ks, dsub = DSUB > 0 ? DSUB : P.S.dsub, cb = P.cb, K1 = P.S.K1;
@@ -407,6 +413,29 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
             for (int ss = 0; ss < SPW; ss++) {
                 float Av[G][4];
                 grp_entries<M, G, DSUB>(Av, wv * SPW + ss, lane, P.pq32T, P.pn32, s_tr32, s_nrf, D, dsub);
+#if GRP_INTERLEAVED
+                // entry-major rows: the G queries' bytes of entry j are adjacent (one ds_read serves the whole group);
+                // a query that is not scanned gets 255 everywhere -- its sums can never pass
+                u32 w0[4] = {0, 0, 0, 0}, w1[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < G; i++) {
+                    const bool on = (alive0 >> i) & 1u;
+                    const float inv = s_inv[i];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const float x = fminf((Av[i][k] - mnv[i][ss]) * inv, 255.f);  // >= 0; +inf beyond ks -> 255
+                        const u32 b = on ? (u32)x : 255u;
+                        if (i < 4) w0[k] |= b << (8 * i);
+                        else w1[k] |= b << (8 * (i - 4));
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    unsigned char *dst = lut8 + (wv * SPW + ss) * (256 * G) + (4 * lane + k) * G;
+                    if constexpr (G == 8) *(uint2 *)dst = make_uint2(w0[k], w1[k]);
+                    else *(u32 *)dst = w0[k];
+                }
+#else
 #pragma unroll
                 for (int i = 0; i < G; i++) {
                     if ((alive0 >> i) & 1u) {
@@ -420,6 +449,7 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
                         *(u32 *)(lut8 + i * LQ + (wv * SPW + ss) * 256 + 4 * lane) = pk;
                     }
                 }
+#endif
             }
         }
         alive0 = (u32)__builtin_amdgcn_readfirstlane((int)alive0);
@@ -486,6 +516,58 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
                     nxt[u].load(codes + (size_t)(p < c1 ? p : c1 - 1) * M);
                 }
             }
+#if GRP_INTERLEAVED
+            // one code of the lane at a time: per sub-quantizer ONE table read (address = 8 x byte from one SDWA shift, row in
+            // the immediate offset) brings the byte of every query of the group; the bytes are spread into 16-bit fields
+            // (queries 0|2, 1|3, 4|6, 5|7: sums stay below 2^16, so plain 32-bit adds carry nothing across fields) -- about
+            // 1.1 instructions per (query, sub-quantizer) instead of 3, and an eighth of the LDS requests
+            u32 pend = 0;  // bit i * GRP_SEGU + u: code u of this lane survives query i's filter
+#pragma unroll
+            for (int u = 0; u < GRP_SEGU; u++) {
+                const int64_t p = seg + u * GRP_NT + tid;
+                u32 acc[G / 2];
+#pragma unroll
+                for (int i = 0; i < G / 2; i++) acc[i] = 0;
+                // GRP_RW table reads are issued together, then spread and added: the wave has GRP_RW LDS requests in flight
+                // instead of waiting for every pair
+#pragma unroll
+                for (int sq = 0; sq < M; sq += GRP_RW) {
+                    if constexpr (G == 8) {
+                        u64 v[GRP_RW];
+#pragma unroll
+                        for (int k = 0; k < GRP_RW; k++)
+                            v[k] = *(const __attribute__((address_space(3))) u64 *)(size_t)(byte_x8(cur[u].wd[(sq + k) >> 2], (sq + k) & 3) + (u32)(sq + k) * 2048u);
+#pragma unroll
+                        for (int k = 0; k < GRP_RW; k += 2) {
+                            const u32 v0x = (u32)v[k], v0y = (u32)(v[k] >> 32), v1x = (u32)v[k + 1], v1y = (u32)(v[k + 1] >> 32);
+                            acc[0] += (v0x & 0x00FF00FFu) + (v1x & 0x00FF00FFu);
+                            acc[1] += __builtin_amdgcn_perm(0u, v0x, 0x0C030C01u) + __builtin_amdgcn_perm(0u, v1x, 0x0C030C01u);
+                            acc[2] += (v0y & 0x00FF00FFu) + (v1y & 0x00FF00FFu);
+                            acc[3] += __builtin_amdgcn_perm(0u, v0y, 0x0C030C01u) + __builtin_amdgcn_perm(0u, v1y, 0x0C030C01u);
+                        }
+                    } else {
+                        u32 v[GRP_RW];
+#pragma unroll
+                        for (int k = 0; k < GRP_RW; k++)
+                            v[k] = *(const __attribute__((address_space(3))) u32 *)(size_t)((byte_x8(cur[u].wd[(sq + k) >> 2], (sq + k) & 3) >> 1) + (u32)(sq + k) * 1024u);
+#pragma unroll
+                        for (int k = 0; k < GRP_RW; k += 2) {
+                            acc[0] += (v[k] & 0x00FF00FFu) + (v[k + 1] & 0x00FF00FFu);
+                            acc[1] += __builtin_amdgcn_perm(0u, v[k], 0x0C030C01u) + __builtin_amdgcn_perm(0u, v[k + 1], 0x0C030C01u);
+                        }
+                    }
+                }
+                // survivors: sum of lower bounds <= 254 (255 already certifies d > T); query i sits in field (i & 2) >> 1 of
+                // register (i >> 2) * 2 + (i & 1)
+                const bool valid = p < c1;
+#pragma unroll
+                for (int i = 0; i < G; i++) {
+                    const u32 f = (acc[(i >> 2) * 2 + (i & 1)] >> (8 * (i & 2))) & 0xFFFFu;
+                    if (valid && f <= 254u) pend |= 1u << (i * GRP_SEGU + u);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#else
             // one code of the lane at a time (64 codes per wave and early-out test); only the survivor bits outlive a code
             u32 pend = 0;  // bit i * GRP_SEGU + u: code u of this lane survives query i's filter
 #pragma unroll
@@ -532,6 +614,7 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
                     if (((al >> i) & 1u) && acc[i] <= 254u) pend |= 1u << (i * GRP_SEGU + u);
                 __builtin_amdgcn_sched_barrier(0);
             }
+#endif
 #ifdef GRP_TIMING_NO_VERIFY
             if (pend == 0x2345u) s_queue[1] = 1;  // (keeps the scan alive)
             pend = 0;
