@@ -38,8 +38,8 @@
 #ifndef GRP_EPOCH
 #define GRP_EPOCH 4  // segments between two block barriers of the scan
 #endif
-#ifndef GRP_INTERLEAVED
-#define GRP_INTERLEAVED 1  // u8 rows entry-major: the group's bytes of one entry side by side, one table read per code and sub-quantizer
+#ifndef GRP_QMAX
+#define GRP_QMAX 127  // largest table byte: two bytes add without a carry into the neighbouring query's byte (255: every read spread on its own)
 #endif
 #ifndef GRP_RW
 #define GRP_RW 4  // table reads in flight per code in the interleaved scan (2, 4 or 8)
@@ -79,7 +79,7 @@ struct GrpLds {
         nrf = o; o += (size_t)G * M * 4;
         mn = o; o += (size_t)G * M * 4;
         inv = o; o += (size_t)G * 4;
-        misc = o; o += 64 * 4;  // [0..G) q, [G..2G) rank, [2G..3G) state, [3G..4G) candidate counts, [32..35) new, [36..39) valid
+        misc = o; o += 64 * 4;  // [0..G) q, [G..2G) rank, [2G..3G) state, [3G..4G) candidate counts, [32..35) new, [36..39) valid, [40..40+G) survivor bounds
         total = (o + 15) & ~(size_t)15;
     }
 };
@@ -223,6 +223,67 @@ __device__ __forceinline__ void grp_entries(float (&Av)[G][4], const int s, cons
     }
 }
 
+// One sub-quantizer's u8 rows for the whole group, entry-major (the G queries' bytes of entry j side by side), written by one
+// wave: lane l owns entries 4l .. 4l+3.  Per query: the fp32 entries (as in grp_entries: fl(fl(nrf + pn) - 2 dot), t ascending),
+// the row minimum (reported in s_mn), and q8 = RNE-and-saturate((entry - mn) * inv - 0.5) through v_cvt_pk_u8_f32 -- never
+// above floor((entry - mn) * inv) + 1e-3 (the bound th of phase (e) allows for it); NaN -> 0 or the largest byte, +inf (entries beyond ks) -> the largest byte GRP_QMAX.
+// The codebook columns are loaded once and stay in registers for the G queries.
+__device__ __forceinline__ float grp_q(const float a, const float inv, const float c) {
+    const float x = fmaf(a, inv, c);
+    return GRP_QMAX < 255 ? fminf(x, (float)GRP_QMAX) : x;  // (v_cvt_pk_u8_f32 saturates at 255 itself; NaN -> GRP_QMAX or 0: both valid)
+}
+template <int M, int G, int DSUB>
+__device__ __forceinline__ void grp_rows(unsigned char *lut8, const int s, const int lane, const float *__restrict__ pq32T,
+                                         const float *__restrict__ pn32, const float *s_tr32, const float *s_nrf, const float *s_inv,
+                                         float *s_mn, const int D) {
+    static_assert(DSUB > 0, "compile-time dsub");
+    const u32 col = (u32)s * 256u + 4u * (u32)lane;
+    const float4 pn4 = *(const float4 *)(pn32 + col);
+    const u32 pbase = (u32)s * (u32)DSUB * 256u + 4u * (u32)lane;
+    float4 p4[DSUB];
+#pragma unroll
+    for (int t = 0; t < DSUB; t++) p4[t] = *(const float4 *)(pq32T + (pbase + (u32)t * 256u));
+    u32 w0[4] = {0, 0, 0, 0}, w1[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < G; i++) {
+        const float *rr = s_tr32 + i * D + s * DSUB;  // (broadcast reads)
+        float4 dot = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < DSUB; t++) {
+            const float r = rr[t];
+            dot.x = fmaf(r, p4[t].x, dot.x);
+            dot.y = fmaf(r, p4[t].y, dot.y);
+            dot.z = fmaf(r, p4[t].z, dot.z);
+            dot.w = fmaf(r, p4[t].w, dot.w);
+        }
+        const float nrf = s_nrf[i * M + s];
+        const float a0 = fmaf(-2.f, dot.x, nrf + pn4.x), a1 = fmaf(-2.f, dot.y, nrf + pn4.y), a2 = fmaf(-2.f, dot.z, nrf + pn4.z),
+                    a3 = fmaf(-2.f, dot.w, nrf + pn4.w);
+        const float mn = wave_min_f32(fminf(fminf(a0, a1), fminf(a2, a3)));
+        if (lane == 0) s_mn[i * M + s] = mn;
+        const float inv = s_inv[i];
+        const float c = fmaf(-mn, inv, -0.5f);
+        if (i < 4) {
+            w0[0] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q(a0, inv, c), (u32)i, w0[0]);
+            w0[1] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q(a1, inv, c), (u32)i, w0[1]);
+            w0[2] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q(a2, inv, c), (u32)i, w0[2]);
+            w0[3] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q(a3, inv, c), (u32)i, w0[3]);
+        } else {
+            w1[0] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q(a0, inv, c), (u32)(i - 4), w1[0]);
+            w1[1] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q(a1, inv, c), (u32)(i - 4), w1[1]);
+            w1[2] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q(a2, inv, c), (u32)(i - 4), w1[2]);
+            w1[3] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q(a3, inv, c), (u32)(i - 4), w1[3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // (one query at a time: the scheduler otherwise interleaves all G and spills)
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        unsigned char *dst = lut8 + s * (256 * G) + (4 * lane + k) * G;
+        if constexpr (G == 8) *(uint2 *)dst = make_uint2(w0[k], w1[k]);
+        else *(u32 *)dst = w0[k];
+    }
+}
+
 template <int DSUB>
 __device__ __forceinline__ double grp_exact_entry(const double *tv, const double *__restrict__ pp, int dsub_rt) {
     double acc = 0.0;
@@ -253,7 +314,6 @@ template <int M, int G, int DSUB>
 __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P) {
     static_assert(M % 8 == 0 && G <= 8 && G * M * 256 <= 65536, "imm offsets of the table reads");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    [[maybe_unused]] constexpr int LQ = M * 256;  // bytes of one query's u8 table (query-major layout)
     constexpr int SPW = M / 8;   // sub-quantizers per wave in the table build
     constexpr int EPL = M / 4;   // exact entries per lane of a verifying quad
     const int D = P.S.D, ks = P.S.ks, dsub = DSUB > 0 ? DSUB : P.S.dsub, cb = P.cb, K1 = P.S.K1;
@@ -275,6 +335,7 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
     u32 *s_ccnt = (u32 *)(s_q + 3 * G);
     u32 *s_new = (u32 *)(s_q + 32);
     u32 *s_qvalid = (u32 *)(s_q + 36);
+    u32 *s_th = (u32 *)(s_q + 40);  // [G] survivor bound of the query: sum of its u8 lower bounds <= th
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u64 lane_lt = (1ull << lane) - 1ull;
@@ -310,6 +371,14 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
                 s_pr[tid] = pr;
                 s_T[tid] = tid < np ? T : 0;
                 s_ccnt[tid] = 0;
+                // quantisation step of the query's u8 rows: T / (GRP_QMAX - 1), known before any entry is (0: no finite positive
+                // threshold -- the pair goes back to K3f in (e))
+                float inv = 0.f;
+                if (tid < np && T < 0x7FF0000000000000ull) {
+                    const double iv = (double)(GRP_QMAX - 1) / keyd(T);  // (T = 0: inf)
+                    if (iv < 1e30) inv = (float)iv;
+                }
+                s_inv[tid] = inv;
             }
         }
         if (tid < 3) {
@@ -348,30 +417,49 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
 #if GRP_BIS == 2
         continue;
 #endif
-        // ---- (d)-(f) u8 rows.  Two passes over the fp32 entries (minima, then quantisation): recomputing an entry is 2 dsub
-        //      flops and one L2-resident 16-byte load per dimension, cheaper than carrying G x M x 256 floats across the barriers
+        // ---- (d) u8 rows, ONE pass over the fp32 entries: q8 = min(255, floor((entry - row minimum) * 254 / T)).  The step
+        //      depends on the query's threshold only, so a row is quantised as soon as its minimum is known (a wave owns
+        //      whole rows: no barrier); what depends on the other rows -- Smin = the sum of the minima -- moves into the
+        //      query's survivor bound th (e): d <= T  =>  sum_s q8 <= (T - Smin) * 254 / T.  Entry-major rows: the G queries'
+        //      bytes of entry j are adjacent, one ds_read serves the whole group.
         u32 alive0 = 0;
-        float mnv[G][SPW];
-        // (d) per-sub-quantizer minima
-#pragma unroll
+#pragma unroll 1
         for (int ss = 0; ss < SPW; ss++) {
-            float Av[G][4];
+            if constexpr (DSUB > 0) {
+                grp_rows<M, G, DSUB>(lut8, wv * SPW + ss, lane, P.pq32T, P.pn32, s_tr32, s_nrf, s_inv, s_mn, D);
+                continue;
+            }
+            float Av[G][4];  // (run-time dsub: the generic form)
             grp_entries<M, G, DSUB>(Av, wv * SPW + ss, lane, P.pq32T, P.pn32, s_tr32, s_nrf, D, dsub);
+            u32 w0[4] = {0, 0, 0, 0}, w1[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int i = 0; i < G; i++) {
                 const float m4 = fminf(fminf(Av[i][0], Av[i][1]), fminf(Av[i][2], Av[i][3]));
-                mnv[i][ss] = wave_min_f32(m4);
-                if (lane == 0) s_mn[i * M + wv * SPW + ss] = mnv[i][ss];
+                const float mn = wave_min_f32(m4);
+                if (lane == 0) s_mn[i * M + wv * SPW + ss] = mn;
+                const float inv = s_inv[i];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const u32 b = (u32)fminf((Av[i][k] - mn) * inv, (float)GRP_QMAX);  // >= 0; +inf beyond ks and NaN -> the largest byte
+                    if (i < 4) w0[k] |= b << (8 * i);
+                    else w1[k] |= b << (8 * (i - 4));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                unsigned char *dst = lut8 + (wv * SPW + ss) * (256 * G) + (4 * lane + k) * G;
+                if constexpr (G == 8) *(uint2 *)dst = make_uint2(w0[k], w1[k]);
+                else *(u32 *)dst = w0[k];
             }
         }
         __syncthreads();
 #if GRP_BIS == 3
         continue;
 #endif
-        // (e) per query: lower bound of the sum of minima, state, quantisation step
+        // ---- (e) per query: lower bound of the sum of minima, state, survivor bound --------------------------------------
         if (tid < G) {
             int state = 1;  // 0 scan, 1 nothing to do (no pair / list exhausted: Smin >= T), 2 hand back to K3f
-            float inv = 0.f;
+            u32 th = 0;
             if (tid < np) {
                 double smin = 0.0, es = 0.0;
                 for (int s = 0; s < M; s++) {
@@ -381,15 +469,17 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
                 const double smin_lo = smin - fabs(smin) * 0x1p-40;
                 const u64 T = s_T[tid];
                 const double Td = keyd(T);
-                if (!(T < 0x7FF0000000000000ull) || !(es < 1e24) || !(fabs(smin_lo) < 1e30)) {
-                    state = 2;  // no finite threshold yet, or magnitudes beyond what fp32 carries
+                const float invf = s_inv[tid];
+                if (!(T < 0x7FF0000000000000ull) || !(es < 1e24) || !(fabs(smin_lo) < 1e30) || !(invf > 0.f)) {
+                    state = 2;  // no finite positive threshold yet, or magnitudes beyond what fp32 carries
                 } else if (!(smin_lo < Td)) {
                     state = 1;
-                } else if (!((Td - smin_lo) > Td * 0x1p-20)) {
-                    state = 2;  // degenerate step
                 } else {
+                    // a code with d <= T: sum_s (entry32_s - mn_s) <= d + es - sum_s mn_s <= T - Smin, every product rounded once in
+                    // fp32 and truncated: sum_s q8 <= (T - Smin) * inv * (1 + 2^-23); 2^-20 covers the fp64 evaluation here
+                    const double t = (Td - smin_lo) * (double)invf * (1.0 + 0x1p-20) + 0.02;  // (+: the fused roundings of grp_rows)
                     state = 0;
-                    inv = (float)((254.0 / (Td - smin_lo)) * (1.0 - 0x1p-18));
+                    th = t < 32000.0 ? (u32)t : 32000u;  // (the packed 16-bit test treats the fields as signed)
                 }
                 if (state == 2) {
                     const u32 f = atomicAdd(P.fb_count, 1u);
@@ -398,62 +488,16 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
                 }
             }
             s_state[tid] = state;
-            s_inv[tid] = inv;
+            s_th[tid] = th;
         }
         __syncthreads();
 #if GRP_BIS == 4
         continue;
 #endif
-        // (f) u8 rows: q8 = min(255, floor((entry - min) * inv)), packed four per store
 #pragma unroll
         for (int i = 0; i < G; i++)
             if (s_state[i] == 0) alive0 |= 1u << i;
-        if (alive0) {
-#pragma unroll
-            for (int ss = 0; ss < SPW; ss++) {
-                float Av[G][4];
-                grp_entries<M, G, DSUB>(Av, wv * SPW + ss, lane, P.pq32T, P.pn32, s_tr32, s_nrf, D, dsub);
-#if GRP_INTERLEAVED
-                // entry-major rows: the G queries' bytes of entry j are adjacent (one ds_read serves the whole group);
-                // a query that is not scanned gets 255 everywhere -- its sums can never pass
-                u32 w0[4] = {0, 0, 0, 0}, w1[4] = {0, 0, 0, 0};
-#pragma unroll
-                for (int i = 0; i < G; i++) {
-                    const bool on = (alive0 >> i) & 1u;
-                    const float inv = s_inv[i];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const float x = fminf((Av[i][k] - mnv[i][ss]) * inv, 255.f);  // >= 0; +inf beyond ks -> 255
-                        const u32 b = on ? (u32)x : 255u;
-                        if (i < 4) w0[k] |= b << (8 * i);
-                        else w1[k] |= b << (8 * (i - 4));
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    unsigned char *dst = lut8 + (wv * SPW + ss) * (256 * G) + (4 * lane + k) * G;
-                    if constexpr (G == 8) *(uint2 *)dst = make_uint2(w0[k], w1[k]);
-                    else *(u32 *)dst = w0[k];
-                }
-#else
-#pragma unroll
-                for (int i = 0; i < G; i++) {
-                    if ((alive0 >> i) & 1u) {
-                        const float inv = s_inv[i];
-                        u32 pk = 0;
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const float x = fminf((Av[i][k] - mnv[i][ss]) * inv, 255.f);  // >= 0; +inf beyond ks -> 255
-                            pk |= (u32)x << (8 * k);
-                        }
-                        *(u32 *)(lut8 + i * LQ + (wv * SPW + ss) * 256 + 4 * lane) = pk;
-                    }
-                }
-#endif
-            }
-        }
         alive0 = (u32)__builtin_amdgcn_readfirstlane((int)alive0);
-        __syncthreads();
         if (tid == 0 && P.stat) {  // (profiling runs only) pairs of this item, pairs that survive the table build's Smin >= T test
             atomicAdd(P.stat + 2, (unsigned long long)np);
             atomicAdd(P.stat + 3, (unsigned long long)__popc(alive0));
@@ -464,6 +508,16 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
 #endif
 
         // ---- (g) filter scan ---------------------------------------------------------------------------------------
+        u32 thr[G];  // (scalar registers)
+#pragma unroll
+        for (int i = 0; i < G; i++) thr[i] = (u32)__builtin_amdgcn_readfirstlane((int)s_th[i]);
+        u32 thrp[G / 2];  // the same as packed 16-bit fields in the layout of the sums; -1: the query is not scanned
+#pragma unroll
+        for (int r = 0; r < G / 2; r++) {
+            const int i0 = (r >> 1) * 4 + (r & 1), i1 = i0 + 2;
+            const u32 t0 = ((alive0 >> i0) & 1u) ? thr[i0] : 0xFFFFu, t1 = ((alive0 >> i1) & 1u) ? thr[i1] : 0xFFFFu;
+            thrp[r] = (t0 & 0xFFFFu) | (t1 << 16);
+        }
         CodeVec<M, unsigned char> cur[GRP_SEGU], nxt[GRP_SEGU];
 #pragma unroll
         for (int u = 0; u < GRP_SEGU; u++) {
@@ -516,7 +570,6 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
                     nxt[u].load(codes + (size_t)(p < c1 ? p : c1 - 1) * M);
                 }
             }
-#if GRP_INTERLEAVED
             // one code of the lane at a time: per sub-quantizer ONE table read (address = 8 x byte from one SDWA shift, row in
             // the immediate offset) brings the byte of every query of the group; the bytes are spread into 16-bit fields
             // (queries 0|2, 1|3, 4|6, 5|7: sums stay below 2^16, so plain 32-bit adds carry nothing across fields) -- about
@@ -528,93 +581,74 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
                 u32 acc[G / 2];
 #pragma unroll
                 for (int i = 0; i < G / 2; i++) acc[i] = 0;
-                // GRP_RW table reads are issued together, then spread and added: the wave has GRP_RW LDS requests in flight
-                // instead of waiting for every pair
+                // GRP_RW table reads are issued together.  With bytes <= 127 two reads are first added byte-wise (no carry can
+                // leave a byte), then spread and added to the fields: 6 instructions per sub-quantizer and code for the group
+                static_assert(GRP_RW % 4 == 0 || GRP_QMAX > 127, "byte-wise pre-add takes the reads in pairs of pairs");
+                auto spread = [&](const u32 lo, const u32 hi) {
+                    acc[0] += lo & 0x00FF00FFu;
+                    acc[1] += __builtin_amdgcn_perm(0u, lo, 0x0C030C01u);
+                    if constexpr (G == 8) {
+                        acc[2] += hi & 0x00FF00FFu;
+                        acc[3] += __builtin_amdgcn_perm(0u, hi, 0x0C030C01u);
+                    }
+                };
+                auto spread2 = [&](const u32 lo0, const u32 hi0, const u32 lo1, const u32 hi1) {  // (two spreads, v_add3)
+                    acc[0] += (lo0 & 0x00FF00FFu) + (lo1 & 0x00FF00FFu);
+                    acc[1] += __builtin_amdgcn_perm(0u, lo0, 0x0C030C01u) + __builtin_amdgcn_perm(0u, lo1, 0x0C030C01u);
+                    if constexpr (G == 8) {
+                        acc[2] += (hi0 & 0x00FF00FFu) + (hi1 & 0x00FF00FFu);
+                        acc[3] += __builtin_amdgcn_perm(0u, hi0, 0x0C030C01u) + __builtin_amdgcn_perm(0u, hi1, 0x0C030C01u);
+                    }
+                };
 #pragma unroll
                 for (int sq = 0; sq < M; sq += GRP_RW) {
-                    if constexpr (G == 8) {
-                        u64 v[GRP_RW];
+                    u32 lo[GRP_RW], hi[GRP_RW];
 #pragma unroll
-                        for (int k = 0; k < GRP_RW; k++)
-                            v[k] = *(const __attribute__((address_space(3))) u64 *)(size_t)(byte_x8(cur[u].wd[(sq + k) >> 2], (sq + k) & 3) + (u32)(sq + k) * 2048u);
-#pragma unroll
-                        for (int k = 0; k < GRP_RW; k += 2) {
-                            const u32 v0x = (u32)v[k], v0y = (u32)(v[k] >> 32), v1x = (u32)v[k + 1], v1y = (u32)(v[k + 1] >> 32);
-                            acc[0] += (v0x & 0x00FF00FFu) + (v1x & 0x00FF00FFu);
-                            acc[1] += __builtin_amdgcn_perm(0u, v0x, 0x0C030C01u) + __builtin_amdgcn_perm(0u, v1x, 0x0C030C01u);
-                            acc[2] += (v0y & 0x00FF00FFu) + (v1y & 0x00FF00FFu);
-                            acc[3] += __builtin_amdgcn_perm(0u, v0y, 0x0C030C01u) + __builtin_amdgcn_perm(0u, v1y, 0x0C030C01u);
+                    for (int k = 0; k < GRP_RW; k++) {
+                        const u32 off8 = byte_x8(cur[u].wd[(sq + k) >> 2], (sq + k) & 3);
+                        if constexpr (G == 8) {
+                            const u64 v = *(const __attribute__((address_space(3))) u64 *)(size_t)(off8 + (u32)(sq + k) * 2048u);
+                            lo[k] = (u32)v;
+                            hi[k] = (u32)(v >> 32);
+                        } else {
+                            lo[k] = *(const __attribute__((address_space(3))) u32 *)(size_t)((off8 >> 1) + (u32)(sq + k) * 1024u);
+                            hi[k] = 0;
                         }
+                    }
+                    if constexpr (GRP_QMAX <= 127) {
+#pragma unroll
+                        for (int k = 0; k < GRP_RW; k += 4)
+                            spread2(lo[k] + lo[k + 1], hi[k] + hi[k + 1], lo[k + 2] + lo[k + 3], hi[k + 2] + hi[k + 3]);
                     } else {
-                        u32 v[GRP_RW];
 #pragma unroll
-                        for (int k = 0; k < GRP_RW; k++)
-                            v[k] = *(const __attribute__((address_space(3))) u32 *)(size_t)((byte_x8(cur[u].wd[(sq + k) >> 2], (sq + k) & 3) >> 1) + (u32)(sq + k) * 1024u);
-#pragma unroll
-                        for (int k = 0; k < GRP_RW; k += 2) {
-                            acc[0] += (v[k] & 0x00FF00FFu) + (v[k + 1] & 0x00FF00FFu);
-                            acc[1] += __builtin_amdgcn_perm(0u, v[k], 0x0C030C01u) + __builtin_amdgcn_perm(0u, v[k + 1], 0x0C030C01u);
-                        }
+                        for (int k = 0; k < GRP_RW; k += 2) spread2(lo[k], hi[k], lo[k + 1], hi[k + 1]);
                     }
                 }
-                // survivors: sum of lower bounds <= 254 (255 already certifies d > T); query i sits in field (i & 2) >> 1 of
-                // register (i >> 2) * 2 + (i & 1)
+                (void)spread;
+                // survivors: sum of lower bounds <= the query's bound th (e).  Query i sits in field (i & 2) >> 1 of register
+                // (i >> 2) * 2 + (i & 1).  First one packed test for the whole group (thrp - acc per 16-bit field: a field
+                // that stays >= 0 survives; queries that are not scanned carry -1): survivors are rare -- about one (code,
+                // query) pair in 2500 -- so most waves leave here
                 const bool valid = p < c1;
+                u32 neg = 0xFFFFFFFFu;
 #pragma unroll
-                for (int i = 0; i < G; i++) {
-                    const u32 f = (acc[(i >> 2) * 2 + (i & 1)] >> (8 * (i & 2))) & 0xFFFFu;
-                    if (valid && f <= 254u) pend |= 1u << (i * GRP_SEGU + u);
+                for (int r = 0; r < G / 2; r++) {
+                    typedef short s16x2 __attribute__((ext_vector_type(2)));
+                    union { u32 w; s16x2 v; } ta, aa, dd;
+                    ta.w = thrp[r];
+                    aa.w = acc[r];
+                    dd.v = ta.v - aa.v;
+                    neg &= dd.w;
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#else
-            // one code of the lane at a time (64 codes per wave and early-out test); only the survivor bits outlive a code
-            u32 pend = 0;  // bit i * GRP_SEGU + u: code u of this lane survives query i's filter
-#pragma unroll
-            for (int u = 0; u < GRP_SEGU; u++) {
-                const int64_t p = seg + u * GRP_NT + tid;
-                const u32 a0 = p < c1 ? 0u : 0x10000u;
-                u32 acc[G];
-#pragma unroll
-                for (int i = 0; i < G; i++) acc[i] = a0;
-                u32 al = alive0;
-#pragma unroll
-                for (int sb = 0; sb < M / 4; sb++) {
-                    u32 slot[4], sel[4];
-                    const u32 wd = cur[u].wd[sb];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const u32 b = (wd >> (8 * k)) & 0xFFu;
-                        slot[k] = b & 0xF8u;
-                        sel[k] = (b & 7u) | 0x0C0C0C00u;
-                    }
+                if (__builtin_amdgcn_ballot_w64(valid && (~neg & 0x80008000u) != 0u)) {
 #pragma unroll
                     for (int i = 0; i < G; i++) {
-                        if ((al >> i) & 1u) {  // wave-uniform.  (One branch per query also keeps the compiler from fusing two queries' rows
-                                            //  into ds_read2st64_b64 -- 8 LDS cycles against 2 x 2: 13.6 vs 11.1 ms per step.  Sixteen hand-issued
-                                            //  reads behind ONE wait for the first four sub-quantizers measured no faster: the loop is bound by
-                                            //  instruction issue -- ~475 instructions per 64 codes and wave, 140 of them scalar -- not by LDS latency.)
-                            uint2 rv[4];
-#pragma unroll
-                            for (int k = 0; k < 4; k++) rv[k] = *(const uint2 *)(lut8 + i * LQ + (sb * 4 + k) * 256 + slot[k]);
-#ifdef GRP_ONE_WAIT
-                            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): one wait for the four reads instead of one per byte
-#endif
-#pragma unroll
-                            for (int k = 0; k < 4; k++) acc[i] += __builtin_amdgcn_perm(rv[k].y, rv[k].x, sel[k]);
-                            if (sb + 1 < M / 4) {
-                                if (__builtin_amdgcn_ballot_w64(acc[i] <= 254u) == 0) al &= ~(1u << i);
-                            }
-                        }
+                        const u32 f = (acc[(i >> 2) * 2 + (i & 1)] >> (8 * (i & 2))) & 0xFFFFu;
+                        if (((alive0 >> i) & 1u) && valid && f <= thr[i]) pend |= 1u << (i * GRP_SEGU + u);
                     }
                 }
-                // survivors: sum of lower bounds <= 254 (255 already certifies d > T)
-#pragma unroll
-                for (int i = 0; i < G; i++)
-                    if (((al >> i) & 1u) && acc[i] <= 254u) pend |= 1u << (i * GRP_SEGU + u);
                 __builtin_amdgcn_sched_barrier(0);
             }
-#endif
 #ifdef GRP_TIMING_NO_VERIFY
             if (pend == 0x2345u) s_queue[1] = 1;  // (keeps the scan alive)
             pend = 0;
