@@ -41,6 +41,9 @@
 #ifndef GRP_QMAX
 #define GRP_QMAX 127  // largest table byte: two bytes add without a carry into the neighbouring query's byte (255: every read spread on its own)
 #endif
+#ifndef GRP_BQ
+#define GRP_BQ 2  // queries whose row arithmetic the table build lets the scheduler interleave
+#endif
 #ifndef GRP_RW
 #define GRP_RW 4  // table reads in flight per code in the interleaved scan (2, 4 or 8)
 #endif
@@ -247,18 +250,19 @@ __device__ __forceinline__ void grp_rows(unsigned char *lut8, const int s, const
 #pragma unroll
     for (int i = 0; i < G; i++) {
         const float *rr = s_tr32 + i * D + s * DSUB;  // (broadcast reads)
-        float4 dot = make_float4(0.f, 0.f, 0.f, 0.f);
+        // (two v_pk_fma_f32 per dimension: the same fused operations on the same operands as four v_fma_f32)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 d01 = {0.f, 0.f}, d23 = {0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < DSUB; t++) {
             const float r = rr[t];
-            dot.x = fmaf(r, p4[t].x, dot.x);
-            dot.y = fmaf(r, p4[t].y, dot.y);
-            dot.z = fmaf(r, p4[t].z, dot.z);
-            dot.w = fmaf(r, p4[t].w, dot.w);
+            const f32x2 r2 = {r, r}, p01 = {p4[t].x, p4[t].y}, p23 = {p4[t].z, p4[t].w};
+            d01 = __builtin_elementwise_fma(r2, p01, d01);
+            d23 = __builtin_elementwise_fma(r2, p23, d23);
         }
         const float nrf = s_nrf[i * M + s];
-        const float a0 = fmaf(-2.f, dot.x, nrf + pn4.x), a1 = fmaf(-2.f, dot.y, nrf + pn4.y), a2 = fmaf(-2.f, dot.z, nrf + pn4.z),
-                    a3 = fmaf(-2.f, dot.w, nrf + pn4.w);
+        const float a0 = fmaf(-2.f, d01.x, nrf + pn4.x), a1 = fmaf(-2.f, d01.y, nrf + pn4.y), a2 = fmaf(-2.f, d23.x, nrf + pn4.z),
+                    a3 = fmaf(-2.f, d23.y, nrf + pn4.w);
         const float mn = wave_min_f32(fminf(fminf(a0, a1), fminf(a2, a3)));
         if (lane == 0) s_mn[i * M + s] = mn;
         const float inv = s_inv[i];
@@ -274,7 +278,7 @@ __device__ __forceinline__ void grp_rows(unsigned char *lut8, const int s, const
             w1[2] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q(a2, inv, c), (u32)(i - 4), w1[2]);
             w1[3] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q(a3, inv, c), (u32)(i - 4), w1[3]);
         }
-        __builtin_amdgcn_sched_barrier(0);  // (one query at a time: the scheduler otherwise interleaves all G and spills)
+        if ((i % GRP_BQ) == GRP_BQ - 1) __builtin_amdgcn_sched_barrier(0);  // (GRP_BQ queries at a time: the scheduler otherwise interleaves all G and spills)
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -457,19 +461,21 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
         continue;
 #endif
         // ---- (e) per query: lower bound of the sum of minima, state, survivor bound --------------------------------------
-        if (tid < G) {
+        if (tid < G * M) {  // M lanes per query: the sums over the sub-quantizers by butterfly (M is a power of two <= 32)
+            const int qi = tid / M;
+            double smin = (double)s_mn[tid] - s_err[tid], es = s_err[tid];
+#pragma unroll
+            for (int off = M / 2; off > 0; off >>= 1) {
+                smin += __shfl_xor(smin, off);
+                es += __shfl_xor(es, off);
+            }
             int state = 1;  // 0 scan, 1 nothing to do (no pair / list exhausted: Smin >= T), 2 hand back to K3f
             u32 th = 0;
-            if (tid < np) {
-                double smin = 0.0, es = 0.0;
-                for (int s = 0; s < M; s++) {
-                    smin += (double)s_mn[tid * M + s] - s_err[tid * M + s];
-                    es += s_err[tid * M + s];
-                }
-                const double smin_lo = smin - fabs(smin) * 0x1p-40;
-                const u64 T = s_T[tid];
+            if (qi < np) {
+                const double smin_lo = smin - fabs(smin) * 0x1p-40;  // (also covers the order of the butterfly's additions)
+                const u64 T = s_T[qi];
                 const double Td = keyd(T);
-                const float invf = s_inv[tid];
+                const float invf = s_inv[qi];
                 if (!(T < 0x7FF0000000000000ull) || !(es < 1e24) || !(fabs(smin_lo) < 1e30) || !(invf > 0.f)) {
                     state = 2;  // no finite positive threshold yet, or magnitudes beyond what fp32 carries
                 } else if (!(smin_lo < Td)) {
@@ -481,14 +487,16 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
                     state = 0;
                     th = t < 32000.0 ? (u32)t : 32000u;  // (the packed 16-bit test treats the fields as signed)
                 }
+            }
+            if (tid % M == 0) {
                 if (state == 2) {
                     const u32 f = atomicAdd(P.fb_count, 1u);
-                    P.fb_items[f] = s_q[tid] * P.S.w + s_pr[tid];
+                    P.fb_items[f] = s_q[qi] * P.S.w + s_pr[qi];
                     P.fb_ch[f] = ch;
                 }
+                s_state[qi] = state;
+                s_th[qi] = th;
             }
-            s_state[tid] = state;
-            s_th[tid] = th;
         }
         __syncthreads();
 #if GRP_BIS == 4
