@@ -4,22 +4,23 @@
 // lookup table :427 -> :525-538, scan :429-446).  Results are those of K3 / K3f bit for bit; what changes is who
 // shares what:
 //   * a block takes ONE inverted list (or one chunk of it) and a GROUP of up to G queries that probe it (the pairs of
-//     pass B are already sorted by cell).  A code is loaded once, its m bytes are split into (8-byte slot, byte
-//     selector) once, and every query of the group pays only one conflict-free ds_read_b64 + v_perm + v_add per
-//     sub-quantizer (K3f: one block per (query, list), 5 VALU per lookup).
-//   * the quantised lower-bound table (the q8 rows of K3f) is built from an fp32 evaluation of the entries
-//     instead of the exact fp64 table: with the exact residual r = c - q held in LDS,
+//     pass B are already sorted by cell).  The quantised lower-bound rows are entry-major -- the G queries' bytes of entry j
+//     of sub-quantizer s are adjacent -- so a code costs ONE ds_read_b64 per sub-quantizer for the whole group (address
+//     8 x byte by one SDWA shift, row in the immediate offset); bytes are <= 127, two reads add byte-wise, and the sums are
+//     spread into 16-bit fields: 6 instructions per sub-quantizer and code for eight queries (K3f: 5 per query).
+//   * the rows (the q8 rows of K3f) are built from an fp32 evaluation of the entries instead of the exact fp64
+//     table: with the exact residual r = c - q held in LDS,
 //         ||r_s - p||^2 = ||r_s||^2 + ||p||^2 - 2 r_s.p
 //     the dot products run on an fp32 copy of the codebook (128 KiB for 16 x 256 x 8, L2-resident, transposed so that a
 //     lane's four entries are one 16-byte load per dimension), ||p||^2 comes from a 16 KiB table, ||r_s||^2 is computed in
-//     fp64 once per (query, sub-quantizer).  The fp32 evaluation is certified: a rigorous error term is subtracted from
-//     the minima, every rounding of the quantisation is directed downwards, so the filter can only under-estimate (it
-//     never drops a code with d <= T).  Nothing is precomputed per cell or per query.
+//     fp64 once per (query, sub-quantizer).  The quantisation step is T / 126, known before any entry is, so a row is
+//     quantised in the pass that finds its minimum; the sum of the minima becomes a per-query bound on the byte sums of a
+//     survivor.  The fp32 evaluation is certified: a rigorous error term is subtracted from the minima and every rounding
+//     of the quantisation is allowed for in the bound, so the filter can only under-estimate (it never drops a code with
+//     d <= T).  Nothing is precomputed per cell or per query.
 //   * the EXACT distance is computed only for the filter's survivors, four lanes per survivor, each lane building the
 //     m/4 table entries it needs in the reference's order (t ascending, IVFPQ.java:531-534) and the sum passed
 //     through the quad in sub-quantizer order (s ascending, :435-438) -- same bits as a lookup in the fp64 table.
-//   * a wave stops looking a query's bytes up as soon as none of its 128 codes can still pass (checked after every
-//     four sub-quantizers): far lists die after 4-8 of the m lookups.
 // Items the kernel does not handle (no finite threshold yet, degenerate or huge magnitudes) are handed to K3f through
 // a device-side list, so results never depend on the heuristics.
 #pragma once
