@@ -255,6 +255,8 @@ struct mmidx_index {
     bool inv_valid = false;
     int64_t inv_size = 0;
     DevBuf<int32_t> ws_gfb;
+    DevBuf<int64_t> ws_flatoff;  // flat PQ through K3g: chunk offsets standing in for list offsets
+    double *d_zero = nullptr;    // ... and the zero "centroid"
 
     // profiling: HIP events recorded on the launch stream, resolved lazily by mmidx_get_stats
     int profiling = 0;  // 0 off, 1 full (six events per call + code counters), 2 light (the pass-A pair only)
@@ -799,7 +801,7 @@ int launch_scan_seeded(const mmidx_index *h, ScanParams P, const SearchPlan &pl,
 // index-side tables: built once per (coarse, product) quantizer pair, on the handle's stream, synchronously
 int build_grp_tables(mmidx_index *h) {
     if (h->grp_valid) return MMIDX_OK;
-    const bool shape_ok = h->kind == MMIDX_KIND_IVFPQ && h->code_bytes == 1 && h->ks <= 256 && (h->m == 8 || h->m == 16 || h->m == 32) &&
+    const bool shape_ok = (h->kind == MMIDX_KIND_IVFPQ || h->kind == MMIDX_KIND_PQ) && h->code_bytes == 1 && h->ks <= 256 && (h->m == 8 || h->m == 16 || h->m == 32) &&
                           h->transform != MMIDX_TR_ROTATION;
     if (!shape_ok || !h->pq_set) return MMIDX_OK;
     if (!h->d_pq32T) HIPCK(hipMalloc((void **)&h->d_pq32T, (size_t)h->m * h->dsub * 256 * sizeof(float)));
@@ -842,30 +844,31 @@ int launch_grp_t(mmidx_index *h, const GrpParams &GP, size_t lds, hipStream_t st
 
 // pass B over the sorted pairs (P.order / P.n_order as for K3f; per-cell counts and starts in ws_pcount / ws_pstart).
 // Returns 1 when K3g does not apply (the caller uses K3f).
-int launch_scan_grouped(mmidx_index *h, const ScanParams &P, const SearchPlan &pl, long long nq, long long npairs, hipStream_t st) {
-    if (h->no_grp || !h->grp_valid || !h->d_pq32T || h->no_filter || P.sdc_tt || !P.ivf || h->max_list_len >= (1 << 24)) return 1;
+// S: the scan parameters K3g runs with; F: those of the K3f launch that serves the handed-back (pair, chunk) items
+int launch_grouped_common(mmidx_index *h, const ScanParams &S, ScanParams F, const SearchPlan &pl, int nlists, int nchunks, long long npairs,
+                          hipStream_t st) {
     const int G = h->m == 32 ? 4 : 8;
     int cb = 1;
     while (cb < pl.K1 + GRP_VR) cb <<= 1;
     const GrpLds L(h->m, G, h->D, cb);
     if (L.total > 160 * 1024 || pl.K1 + GRP_VR > GRP_NT) return 1;
-    const size_t nfb = (size_t)npairs * (size_t)pl.nchunks;
-    HIPCK(h->ws_gdesc.reserve((size_t)npairs / G + (size_t)h->C + 8));
+    const size_t nfb = (size_t)npairs * (size_t)nchunks;
+    HIPCK(h->ws_gdesc.reserve((size_t)npairs / G + (size_t)nlists + 8));
     HIPCK(h->ws_gfb.reserve(4 + 2 * nfb + 16));
     if (h->debug_sync) HIPCK(hipMemsetAsync(h->ws_gfb.p, 0, (4 + 2 * nfb + 16) * sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_group_build, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, h->ws_pstart.p, h->C, G, h->ws_gdesc.p, h->ws_gfb.p,
+    hipLaunchKernelGGL(k_group_build, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, h->ws_pstart.p, nlists, G, h->ws_gdesc.p, h->ws_gfb.p,
                        (u32 *)(h->ws_gfb.p + 1));
     HIPCK(hipGetLastError());
     DBG_SYNC("K3g group build");
     GrpParams GP{};
-    GP.S = P;
+    GP.S = S;
     GP.pq = h->d_pq;
     GP.pq32T = h->d_pq32T;
     GP.pn32 = h->d_pn32;
     GP.pnmax = h->d_pnmax;
     GP.gdesc = h->ws_gdesc.p;
     GP.n_groups = h->ws_gfb.p;
-    GP.nchunks = pl.nchunks;
+    GP.nchunks = nchunks;
     GP.fb_count = (u32 *)(h->ws_gfb.p + 1);
     GP.fb_items = h->ws_gfb.p + 4;
     GP.fb_ch = h->ws_gfb.p + 4 + nfb;
@@ -899,13 +902,48 @@ int launch_scan_grouped(mmidx_index *h, const ScanParams &P, const SearchPlan &p
                 L.total, cb);
     }
     // the handed-back items (device-side count; normally few): a small main grid, the looping tail covers the rest
-    ScanParams F = P;
     F.order = GP.fb_items;
     F.n_order = (const int32_t *)GP.fb_count;
     F.order_ch = GP.fb_ch;
     F.n_items = (int)std::min<size_t>(nfb, (size_t)0x7fffff00);
     F.xcd_remap = 0;
     return launch_scan_filtered(h, F, pl, dim3((unsigned)F.n_items, 1), st, 1024);
+}
+
+// pass B over the sorted pairs (P.order / P.n_order as for K3f; per-cell counts and starts in ws_pcount / ws_pstart).
+// Returns 1 when K3g does not apply (the caller uses K3f).
+int launch_scan_grouped(mmidx_index *h, const ScanParams &P, const SearchPlan &pl, long long nq, long long npairs, hipStream_t st) {
+    if (h->no_grp || !h->grp_valid || !h->d_pq32T || h->no_filter || P.sdc_tt || !P.ivf || h->max_list_len >= (1 << 24)) return 1;
+    return launch_grouped_common(h, P, P, pl, h->C, pl.nchunks, npairs, st);
+}
+
+// flat PQ pass B (chunks 1 .. of every query) through K3g: the chunks stand in for inverted lists (k_flat_pairs), the
+// residual is the query itself.  P: the flat scan parameters (P.w = number of chunks).  Returns 1 when K3g does not apply.
+int launch_scan_grouped_flat(mmidx_index *h, const ScanParams &P, const SearchPlan &pl, long long nq, hipStream_t st) {
+    const int nch = P.w;
+    const long long npairs = nq * (long long)(nch - 1);
+    if (h->no_grp || !h->grp_valid || !h->d_pq32T || h->no_filter || P.sdc_tt || P.ivf || nch < 2 || pl.chunk >= (1 << 24) ||
+        npairs >= 0x7fffff00ll || nq * (long long)nch >= 0x7fffff00ll)
+        return 1;
+    HIPCK(h->ws_pcount.reserve((size_t)nch + 1));
+    HIPCK(h->ws_pstart.reserve((size_t)nch + 1));
+    HIPCK(h->ws_order.reserve((size_t)npairs));
+    HIPCK(h->ws_flatoff.reserve((size_t)nch + 1));
+    if (!h->d_zero) {
+        HIPCK(hipMalloc((void **)&h->d_zero, (size_t)h->D * sizeof(double)));
+        HIPCK(hipMemsetAsync(h->d_zero, 0, (size_t)h->D * sizeof(double), st));
+    }
+    const long long work = std::max<long long>(npairs, nch + 1);
+    hipLaunchKernelGGL(k_flat_pairs, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, (long long)nq, nch, (long long)pl.chunk,
+                       (long long)h->n_csr, h->ws_order.p, h->ws_pcount.p, h->ws_pstart.p, h->ws_flatoff.p);
+    HIPCK(hipGetLastError());
+    ScanParams S = P;
+    S.coarse = h->d_zero;
+    S.list_off = h->ws_flatoff.p;
+    S.order = h->ws_order.p;
+    S.n_order = nullptr;
+    S.chunk = pl.chunk;
+    return launch_grouped_common(h, S, P, pl, nch, 1, npairs, st);
 }
 
 int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, hipStream_t st) {
@@ -1196,7 +1234,8 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
             P.nrank = P.w - 1;
             P.n_items = (int)(nq * P.nrank);
             P.xcd_remap = 0;
-            rc = launch_scan_filtered(h, P, pl, dim3((unsigned)P.n_items, 1), st);
+            rc = launch_scan_grouped_flat(h, P, pl, (long long)nq, st);
+            if (rc == 1) rc = launch_scan_filtered(h, P, pl, dim3((unsigned)P.n_items, 1), st);
             if (rc) return rc;
             DBG_SYNC("pass B scan (flat)");
         }
@@ -1542,10 +1581,12 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_dest.release();
     h->ws_gdesc.release();
     h->ws_gfb.release();
+    h->ws_flatoff.release();
     h->ws_inv.release();
     if (h->d_pq32T) (void)hipFree(h->d_pq32T);
     if (h->d_pn32) (void)hipFree(h->d_pn32);
     if (h->d_pnmax) (void)hipFree(h->d_pnmax);
+    if (h->d_zero) (void)hipFree(h->d_zero);
     for (auto &ev : h->evpool)
         if (ev) (void)hipEventDestroy(ev);
     if (h->d_counters) (void)hipFree(h->d_counters);

@@ -153,6 +153,24 @@ __global__ __launch_bounds__(256) void k_pn_max(const double *__restrict__ pqT, 
         pnmax[m + s] = a * (1.0 + 1e-12);
     }
 }
+// ---- flat PQ (PQ.computeKnnADC, PQ.java:290-322): the chunks 1 .. nch-1 of the single list play the role of inverted lists,
+// every query "probes" all of them: pair id q * nch + c at order[(c - 1) * nq + q], counts / starts per chunk, and the
+// chunk offsets in place of list offsets (chunk 0 belongs to pass A)
+__global__ void k_flat_pairs(long long nq, int nch, long long chunk, long long n, int32_t *__restrict__ order, int32_t *__restrict__ cnt,
+                             int32_t *__restrict__ start, int64_t *__restrict__ off) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long np = nq * (long long)(nch - 1);
+    if (i < np) {
+        const long long c = 1 + i / nq, q = i - (c - 1) * nq;
+        order[i] = (int32_t)(q * nch + c);
+    }
+    if (i <= nch) {
+        cnt[i] = (i >= 1 && i < nch) ? (int32_t)nq : (i == nch ? (int32_t)np : 0);
+        start[i] = i >= 1 ? (int32_t)((i - 1) * nq) : 0;
+        const long long o = i * chunk;
+        off[i] = o < n ? o : n;
+    }
+}
 // ---- groups: the pairs of a cell (contiguous in order[]) in runs of G -----------------------------------------------
 // single block; also zeroes the hand-back counter of this step
 __global__ __launch_bounds__(1024) void k_group_build(const int32_t *__restrict__ cnt, const int32_t *__restrict__ start, int C, int G,
@@ -395,7 +413,10 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
         for (int idx = tid; idx < G * D; idx += GRP_NT) {
             const int i = idx / D, d = idx - i * D;
             const int src = P.S.perm ? P.S.perm[d] : d;
-            const double r = P.S.coarse[(size_t)cell * D + src] - P.S.Q[(size_t)s_q[i] * D + src];
+            // (flat PQ: the "centroid" is a zero vector and the sign turns round -- q - 0 = q exactly, PQ.java:294-300; both loads
+            //  unconditional)
+            const double cv = P.S.coarse[(size_t)(P.S.ivf ? cell : 0) * D + src], qv = P.S.Q[(size_t)s_q[i] * D + src];
+            const double r = P.S.ivf ? cv - qv : qv - cv;
             s_tr[idx] = r;
             s_tr32[idx] = (float)r;
         }
@@ -493,7 +514,7 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
                 if (state == 2) {
                     const u32 f = atomicAdd(P.fb_count, 1u);
                     P.fb_items[f] = s_q[qi] * P.S.w + s_pr[qi];
-                    P.fb_ch[f] = ch;
+                    P.fb_ch[f] = P.S.ivf ? ch : s_pr[qi];  // (flat PQ: K3f's chunk is the pair's rank)
                 }
                 s_state[qi] = state;
                 s_th[qi] = th;
@@ -780,7 +801,8 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
                     const u32 slot = base + (u32)__popcll(mask & lane_lt);
                     if (slot < (u32)P.S.poolq) {
                         P.S.pool_key[(size_t)q * P.S.poolq + slot] = ckey[(size_t)i * cb + tid];
-                        P.S.pool_val[(size_t)q * P.S.poolq + slot] = ((u64)s_pr[i] << 32) | (u64)cpos[(size_t)i * cb + tid];
+                        // (flat PQ: positions in the pool are those of the single list, as K3f writes them)
+                        P.S.pool_val[(size_t)q * P.S.poolq + slot] = ((u64)s_pr[i] << 32) | (u64)(cpos[(size_t)i * cb + tid] + (P.S.ivf ? 0u : (u32)beg));
                     }
                 }
             }
