@@ -722,6 +722,12 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
                     u32 full = 0;     // queries whose buffer may not take another round
 #pragma unroll
                     for (int i = 0; i < G; i++) full |= (s_ccnt[i] > (u32)(cb - GRP_VR)) ? 1u << i : 0u;
+#ifdef GRP_TIMING_NO_PRUNE  // (timing experiment: results are wrong)
+                    if (full) {
+                        if (tid < G && ((full >> tid) & 1u)) s_ccnt[tid] = 0;
+                        full = 0;
+                    }
+#endif
                     __syncthreads();  // every thread has its snapshot before this round's appends start
 #pragma unroll 1
                     for (int i = 0; i < G; i++)
@@ -785,7 +791,11 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
 #pragma unroll 1
         for (int i = 0; i < G; i++) {
             if (!((alive0 >> i) & 1u)) continue;
+#ifdef GRP_TIMING_NO_PRUNE
+            if (s_ccnt[i] > (u32)K1) { __syncthreads(); if (tid == 0) s_ccnt[i] = (u32)K1; __syncthreads(); }
+#else
             if (s_ccnt[i] > (u32)K1) grp_prune(ckey + (size_t)i * cb, cpos + (size_t)i * cb, s_ccnt + i, s_T + i, K1, P.S.T + s_q[i]);
+#endif
             const int n = (int)s_ccnt[i];
             if (n == 0) continue;
             const int q = s_q[i];
