@@ -107,6 +107,13 @@ __device__ __forceinline__ double quad_prev_f64(double x) {
     const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(b >> 32), 0x90, 0xf, 0xf, false);
     return __longlong_as_double((long long)(((u64)hi << 32) | lo));
 }
+// value of the previous lane of the quad, lane 0 takes lane 3's (a rotation)
+__device__ __forceinline__ double quad_rot_f64(double x) {
+    const u64 b = (u64)__double_as_longlong(x);
+    const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)b, 0x93, 0xf, 0xf, false);  // quad_perm [3,0,1,2]
+    const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(b >> 32), 0x93, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
 __device__ __forceinline__ double quad_last_f64(double x) {
     const u64 b = (u64)__double_as_longlong(x);
     const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)b, 0xFF, 0xf, 0xf, false);  // quad_perm [3,3,3,3]
@@ -743,6 +750,68 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
                     const u32 ent = s_queue[e];
                     const int i = (int)(ent >> 24);
                     const u32 pos = ent & 0xFFFFFFu;
+                    double d = 0.0;
+                    if constexpr (DSUB == 8 || DSUB == 16) {
+                        // Quad-wide entries: the four lanes read the survivor's whole code (one request per quad) and every
+                        // codebook entry TOGETHER -- lane ql holds doubles 8r + 2ql, 8r + 2ql + 1 of round r, 64 contiguous bytes
+                        // per quad and load -- instead of each lane fetching its own entries 16 bytes at a time (64 separate
+                        // lines per wave instruction: the verification rounds were bound by the address unit, 4 x this).  The
+                        // running sum of an entry travels round the quad in dimension order (t ascending from 0.0,
+                        // IVFPQ.java:531-534): at hop h lane h & 3 adds its two terms to what lane (h - 1) & 3 handed on; the
+                        // other lanes compute along on values nobody reads.  After the last hop lane 3 holds the entry and adds it
+                        // to its d: ((0 + e_0) + e_1) + ... in sub-quantizer order (:435-438).
+                        constexpr int R = DSUB / 8;
+                        u32 cw[M / 4];
+                        if constexpr (M % 16 == 0) {
+#pragma unroll
+                            for (int x = 0; x < M / 16; x++) {
+                                const uint4 v = *(const uint4 *)(codes + pos * (u32)M + 16 * x);
+                                cw[4 * x] = v.x, cw[4 * x + 1] = v.y, cw[4 * x + 2] = v.z, cw[4 * x + 3] = v.w;
+                            }
+                        } else {
+                            const uint2 v = *(const uint2 *)(codes + pos * (u32)M);
+                            cw[0] = v.x, cw[1] = v.y;
+                        }
+                        // (eight entries of the code in a rolled loop -- unrolled over all M the loads are hoisted together and the
+                        //  kernel spills 100+ registers into the scan loop -- with the next entry's codebook doubles requested before
+                        //  the current entry's hops)
+#pragma unroll
+                        for (int x = 0; x < M / 8; x++) {
+                            u64 wrem = ((u64)cw[2 * x + 1] << 32) | (u64)cw[2 * x];
+                            double2 pvn[R];
+                            {
+                                const double *pp = P.pq + ((u32)((8 * x * ks + (int)((u32)wrem & 0xFFu)) * DSUB) + 2u * (u32)ql);
+#pragma unroll
+                                for (int r = 0; r < R; r++) pvn[r] = *(const double2 *)(pp + 8 * r);
+                            }
+#pragma unroll 1
+                            for (int s = 8 * x; s < 8 * x + 8; s++) {
+                                double2 pv[R];
+#pragma unroll
+                                for (int r = 0; r < R; r++) pv[r] = pvn[r];
+                                wrem >>= 8;
+                                {   // (the entry after the half's last one repeats it: a valid address, the value is not used)
+                                    const int sn = s + 1 < 8 * x + 8 ? s + 1 : s;
+                                    const u32 cn = s + 1 < 8 * x + 8 ? (u32)wrem & 0xFFu : 0u;
+                                    const double *pp = P.pq + ((u32)((sn * ks + (int)cn) * DSUB) + 2u * (u32)ql);
+#pragma unroll
+                                    for (int r = 0; r < R; r++) pvn[r] = *(const double2 *)(pp + 8 * r);
+                                }
+                                const double *tv = s_tr + i * D + s * DSUB + 2 * ql;
+                                double t0[R], t1[R];
+#pragma unroll
+                                for (int r = 0; r < R; r++) {
+                                    const double a = tv[8 * r] - pv[r].x, b2 = tv[8 * r + 1] - pv[r].y;
+                                    t0[r] = a * a;
+                                    t1[r] = b2 * b2;
+                                }
+                                double acc = 0.0;
+#pragma unroll
+                                for (int h = 0; h < 4 * R; h++) acc = (quad_rot_f64(acc) + t0[h >> 2]) + t1[h >> 2];
+                                d += acc;
+                            }
+                        }
+                    } else {
                     // the lane's EPL code bytes (sub-quantizers ql*EPL ..): one aligned load, no indexed register array
                     const u32 coff = pos * (u32)M + (u32)(ql * EPL);  // (< 2^24 * M: list positions are below 2^24)
                     u32 cw[(EPL + 3) / 4];
@@ -763,7 +832,6 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
                         en[k] = grp_exact_entry<DSUB>(tv, pp, dsub);
                     }
                     // d = ((0 + e_0) + e_1) + ... in sub-quantizer order: lane 0's partial sum moves down the quad
-                    double d = 0.0;
 #pragma unroll
                     for (int ph = 0; ph < 4; ph++) {
                         const double din = quad_prev_f64(d);
@@ -772,6 +840,7 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
 #pragma unroll
                             for (int k = 0; k < EPL; k++) d += en[k];
                         }
+                    }
                     }
                     const u64 key = dkey(d);
                     if (act && ql == 3 && key <= s_T[i]) {
