@@ -641,8 +641,9 @@ int launch_filt_t(const mmidx_index *h, ScanParams P, dim3 grid, size_t lds, hip
                                             : (h->passb_main_grid > 0 ? (unsigned)h->passb_main_grid : 2u * hint + 2048u);
         g1 = std::min(worst, (want + 7u) & ~7u);
     }
+    if (P.order && main_grid < 0) g1 = 0;  // (the looping kernel alone: what K3g hands back is normally nothing)
     grid.x = g1;
-    hipLaunchKernelGGL((k_scan_filt<M>), grid, dim3(MMIDX_BLOCK), lds, st, P);
+    if (g1 > 0) hipLaunchKernelGGL((k_scan_filt<M>), grid, dim3(MMIDX_BLOCK), lds, st, P);
     if (g1 < worst) {
         HIPCK(hipFuncSetAttribute((const void *)k_scan_filt_tail<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         P.vb_base = g1;
@@ -907,7 +908,7 @@ int launch_grouped_common(mmidx_index *h, const ScanParams &S, ScanParams F, con
     F.order_ch = GP.fb_ch;
     F.n_items = (int)std::min<size_t>(nfb, (size_t)0x7fffff00);
     F.xcd_remap = 0;
-    return launch_scan_filtered(h, F, pl, dim3((unsigned)F.n_items, 1), st, 1024);
+    return launch_scan_filtered(h, F, pl, dim3((unsigned)F.n_items, 1), st, -1);
 }
 
 // pass B over the sorted pairs (P.order / P.n_order as for K3f; per-cell counts and starts in ws_pcount / ws_pstart).
