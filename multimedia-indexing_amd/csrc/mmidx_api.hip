@@ -215,6 +215,7 @@ struct mmidx_index {
     double *d_cn_pad = nullptr;  // [Cp] |c|^2, +inf on the padding rows
     int Cp = 0, Dp = 0;          // C rounded up to 128, D rounded up to 32
     bool coarse_v1 = false;      // MMIDX_COARSE_V1=1: K1c/K1d (fp32 MFMA, full d~ matrix) instead
+    bool coarse_fused = false;   // option "coarse_fused": K1f as one kernel (front end + selection), as in round 1 (A/B switch)
     bool coarse_nodma = false;   // option "coarse_nodma": K1e with register staging also when Dp == 128 (A/B switch)
     bool no_item_compaction = false;  // option "no_item_compaction": a shard's pass A over every query (A/B switch)
     int passa_item_min = 4096;        // option "passa_item_min": fewest queries per call for that compaction
@@ -241,6 +242,7 @@ struct mmidx_index {
     DevBuf<int32_t> ws_fb;
     DevBuf<unsigned short> ws_Qh, ws_Ql;
     DevBuf<float> ws_gmin;
+    DevBuf<int32_t> ws_clist, ws_cn;  // K1f in two kernels: candidate lists [nq][MMIDX_CLIST] and their lengths
     DevBuf<double> ws_Q, ws_cdist, ws_odist, ws_X, ws_Xa, ws_qn, ws_cdsel, ws_sdc;
     DevBuf<float> ws_Q32, ws_S;
     DevBuf<int32_t> ws_cells, ws_oiid, ws_ocnt, ws_flag, ws_ecell, ws_pcount, ws_pstart, ws_pcursor, ws_order;
@@ -999,7 +1001,20 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
         A.gpair = (const float2 *)h->ws_gmin.p;
         A.G = G;
         A.Dp = h->Dp;
-        if (h->C <= 8 * MMIDX_BLOCK)
+        A.nq = (int)nq;
+        // front end and selection as two kernels where a query's candidates fit the list between them (about 1.3 (w + 1))
+        const bool split = !h->coarse_fused && G <= 1024 && 2 * (h->w + 1) + 32 <= MMIDX_CLIST;
+        if (split) {
+            HIPCK(h->ws_clist.reserve((size_t)nq * MMIDX_CLIST));
+            HIPCK(h->ws_cn.reserve((size_t)nq));
+            A.clist = (u32 *)h->ws_clist.p;
+            A.cn = h->ws_cn.p;
+            hipLaunchKernelGGL(k_coarse_front, dim3((unsigned)((nq + 3) / 4)), dim3(MMIDX_BLOCK), 0, st, A);
+            if (h->C <= 8 * MMIDX_BLOCK)
+                hipLaunchKernelGGL(k_coarse_select_list<8>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), glds, st, A);
+            else
+                hipLaunchKernelGGL(k_coarse_select_list<32>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), glds, st, A);
+        } else if (h->C <= 8 * MMIDX_BLOCK)
             hipLaunchKernelGGL(k_coarse_select_grp<8>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), glds, st, A);
         else if (h->C <= 32 * MMIDX_BLOCK)
             hipLaunchKernelGGL(k_coarse_select_grp<32>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), glds, st, A);
@@ -1557,6 +1572,8 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_Qh.release();
     h->ws_Ql.release();
     h->ws_gmin.release();
+    h->ws_clist.release();
+    h->ws_cn.release();
     h->ws_cdsel.release();
     h->ws_Q32.release();
     h->ws_S.release();
@@ -2283,6 +2300,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->passb_main_grid = value;
     } else if (n == "coarse_v1") {
         h->coarse_v1 = value != 0;
+    } else if (n == "coarse_fused") {
+        h->coarse_fused = value != 0;
     } else if (n == "coarse_nodma") {
         h->coarse_nodma = value != 0;
     } else if (n == "no_item_compaction") {

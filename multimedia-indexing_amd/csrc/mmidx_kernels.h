@@ -548,7 +548,12 @@ struct ApproxSel {
     // K1f (group minima front end)
     const float2 *gpair;     // [nq][G] (smallest, runner-up | position) of d~ over each group of 8 centroids (K1e)
     int G, Dp;               // groups per query (Cp / 8), k padded to a multiple of 32
+    // K1f split in two (k_coarse_front -> k_coarse_select_list): the certified candidates of every query
+    u32 *clist;              // [nq][MMIDX_CLIST]
+    int32_t *cn;             // [nq] number of candidates (> MMIDX_CLIST: the exact-row path)
+    int nq;
 };
+#define MMIDX_CLIST 256
 
 // Second half of the certified coarse selection, shared by the two front ends (K1d over the full d~ row,
 // K1f over group minima): the n candidates in cidx[] get the exact sequential fp64 distance, are ordered
@@ -1614,6 +1619,113 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_grp(const ApproxS
     return;
 #endif
     coarse_select_finish<PER>(A, q, (int)s_n4[0], ckey, cidx, sel_k, sel_i, s_k, s_i);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1f in two kernels.  The front end of k_coarse_select_grp (read the query's group minima, find tau, nominate) is a
+// stream over 8 KiB per query between block barriers, held to four blocks per CU by the registers of the selection
+// behind it: 0.09 of the kernel's 0.18 ms per 16384 queries at 1.5 TB/s.  k_coarse_front does it with ONE WAVE per
+// query and no barrier -- the 256 partial minima of the bisection are four per lane, candidates are compacted with
+// ballots -- and leaves the candidate list in global memory; k_coarse_select_list is the selection alone.
+// Same tau (the R-th smallest of 256 minima over disjoint sets of groups), same cut, same candidates.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_front(const ApproxSel A) {
+    constexpr int GPL = 16;  // groups per lane: G <= 1024 (the host checks)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int q = (int)blockIdx.x * (MMIDX_BLOCK / 64) + wv;
+    if (q >= A.nq) return;  // (wave-uniform; the kernel has no barrier)
+    const int C = A.C, w = A.w, G = A.G;
+    const int R = w + 1;
+    const double qn = A.qn[q];
+    const double qnorm = sqrt(qn);
+    const double sumn = A.cnorm_max + qnorm;
+    // (the error bound of k_coarse_select_grp)
+    const double eps16 = (2.0 * 3.1 * 0x1p-16 * qnorm * A.cnorm_max + 2.0 * (3.0 * (double)A.Dp + 16.0) * 0x1p-22 * qnorm * A.cnorm_max +
+                          1e-12 * (A.cn_max + qn) + (0x1p-21 + 0x1p-20) * sumn * sumn) * (1.0 + 1e-9);
+    const float inf = __int_as_float(0x7f800000);
+    float m1[GPL], ry[GPL];
+    float km[4] = {inf, inf, inf, inf};
+#pragma unroll
+    for (int i = 0; i < GPL; i++) {
+        const int g = lane + 64 * i;
+        const int gc = g < G ? g : G - 1;
+        const float2 v = A.gpair[(size_t)q * G + gc];  // (unconditional load on a clamped index)
+        m1[i] = g < G ? (v.x < 0.0f ? 0.0f : v.x) : inf;  // exact distances are >= 0
+        ry[i] = g < G ? v.y : inf;
+        km[i & 3] = m1[i] < km[i & 3] ? m1[i] : km[i & 3];
+    }
+    // ---- tau: the R-th smallest of the 256 partial minima (R distinct centroids lie at or below it): bisection on the bit
+    //      patterns (values >= 0; NaN / inf order above everything finite)
+    float tau;
+    {
+        const u32 k0 = (u32)__float_as_int(km[0]) & 0x7fffffffu, k1 = (u32)__float_as_int(km[1]) & 0x7fffffffu,
+                  k2 = (u32)__float_as_int(km[2]) & 0x7fffffffu, k3 = (u32)__float_as_int(km[3]) & 0x7fffffffu;
+        const u32 mn01 = k0 < k1 ? k0 : k1, mn23 = k2 < k3 ? k2 : k3, mx01 = k0 < k1 ? k1 : k0, mx23 = k2 < k3 ? k3 : k2;
+        u32 lo_k = wave_min_u32(mn01 < mn23 ? mn01 : mn23), hi_k = wave_max_u32(mx01 < mx23 ? mx23 : mx01);
+        while (lo_k < hi_k) {
+            const u32 mid = lo_k + ((hi_k - lo_k) >> 1);
+            const int c = (int)__popcll(__builtin_amdgcn_ballot_w64(k0 <= mid)) + (int)__popcll(__builtin_amdgcn_ballot_w64(k1 <= mid)) +
+                          (int)__popcll(__builtin_amdgcn_ballot_w64(k2 <= mid)) + (int)__popcll(__builtin_amdgcn_ballot_w64(k3 <= mid));
+            if (c >= R) hi_k = mid;
+            else lo_k = mid + 1;
+        }
+        tau = __int_as_float((int)hi_k);
+    }
+    // any centroid with exact distance <= tau has d~ <= tau + eps16
+    const double cut = ((double)tau + eps16) + eps16;
+    if (!(cut < (double)inf) || !(sumn * sumn < 1e37)) {  // nothing can be certified: the exact row
+        if (lane == 0) A.cn[q] = MMIDX_CSEL_CAP + 1;
+        return;
+    }
+    // ---- candidates: the minimum of every group at or under the cut; the whole group when its runner-up is too
+    const u64 lane_lt = (1ull << lane) - 1ull;
+    u32 *list = A.clist + (size_t)q * MMIDX_CLIST;
+    u32 n = 0;  // wave-uniform
+    auto push = [&](const bool pass, const int c) {
+        const u64 mask = __builtin_amdgcn_ballot_w64(pass);
+        if (pass) {
+            const u32 slot = n + (u32)__popcll(mask & lane_lt);
+            if (slot < MMIDX_CLIST) list[slot] = (u32)c;
+        }
+        n += (u32)__popcll(mask);
+    };
+#pragma unroll
+    for (int i = 0; i < GPL; i++) {
+        const int g = lane + 64 * i;
+        const int cb = (g >> 4) * G16_BC + (g & 15);  // column ct of the group is centroid cb + 16 ct
+        const int a1 = __float_as_int(ry[i]) & 7;
+        const float m2 = __int_as_float(__float_as_int(ry[i]) & ~7);  // rounded towards zero: never above the true runner-up
+        const bool hot = (double)m1[i] <= cut;
+        push(hot && cb + 16 * a1 < C, cb + 16 * a1);
+        const bool all = hot && (double)m2 <= cut;
+        if (__builtin_amdgcn_ballot_w64(all)) {  // rare: two of the w+1 nearest in one group of 8
+#pragma unroll
+            for (int ct = 0; ct < 8; ct++) push(all && ct != a1 && cb + 16 * ct < C, cb + 16 * ct);
+        }
+    }
+    if (lane == 0) A.cn[q] = (int32_t)(n <= MMIDX_CLIST ? n : (u32)(MMIDX_CSEL_CAP + 1));
+}
+
+template <int PER>
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_list(const ApproxSel A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *ckey = (u64 *)smem;                       // [CSEL_CAP] exact candidate keys
+    u32 *cidx = (u32 *)(ckey + MMIDX_CSEL_CAP);    // [CSEL_CAP]
+    u64 *sel_k = (u64 *)(cidx + MMIDX_CSEL_CAP);   // [w+1]
+    int *sel_i = (int *)(sel_k + (A.w + 1));       // [w+1]
+    __shared__ u64 s_k[MMIDX_BLOCK / 64];
+    __shared__ int s_i[MMIDX_BLOCK / 64];
+    __shared__ u32 s_pad[8];  // (statics total 80 B as in k_coarse_select_grp: the dynamic LDS base stays 16-byte aligned)
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int n = A.cn[q];
+    {
+        const int tc = tid < n && n <= MMIDX_CLIST ? tid : 0;
+        const u32 c = A.clist[(size_t)q * MMIDX_CLIST + tc];  // (unconditional load on a clamped index)
+        if (tid < n && n <= MMIDX_CLIST) cidx[tid] = c;
+        if (tid == 0) s_pad[0] = 0;
+    }
+    __syncthreads();
+    coarse_select_finish<PER>(A, q, n, ckey, cidx, sel_k, sel_i, s_k, s_i);
 }
 
 // ------------------------------------------------------------------------------------------------

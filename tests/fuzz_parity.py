@@ -44,7 +44,8 @@ for case in range(cases):
     v1 = int(rng.random() < 0.25)
     wide = int(rng.random() < 0.3)
     nogrp = int(rng.random() < 0.2)
-    desc = dict(kind=kind, D=D, m=m, ks=ks, n=n, k=k, C=C, w=w, tr=tr, dup=dup, hist=hist, v1=v1, wide=wide, nogrp=nogrp)
+    fused = int(rng.random() < 0.3)
+    desc = dict(kind=kind, D=D, m=m, ks=ks, n=n, k=k, C=C, w=w, tr=tr, dup=dup, hist=hist, v1=v1, wide=wide, nogrp=nogrp, fused=fused)
     try:
         nb = min(n, 3000)
         if kind == "ivfpq":
@@ -72,6 +73,7 @@ for case in range(cases):
         ix.set_option("coarse_v1", v1)
         ix.set_option("passa_wide", wide)
         ix.set_option("no_grp", nogrp)
+        ix.set_option("coarse_fused", fused)
         half = n // 2
         ix.indexVectors([str(i) for i in range(half)], base[:half])
         if half:
