@@ -18,9 +18,11 @@
 //     survivor.  The fp32 evaluation is certified: a rigorous error term is subtracted from the minima and every rounding
 //     of the quantisation is allowed for in the bound, so the filter can only under-estimate (it never drops a code with
 //     d <= T).  Nothing is precomputed per cell or per query.
-//   * the EXACT distance is computed only for the filter's survivors, four lanes per survivor, each lane building the
-//     m/4 table entries it needs in the reference's order (t ascending, IVFPQ.java:531-534) and the sum passed
-//     through the quad in sub-quantizer order (s ascending, :435-438) -- same bits as a lookup in the fp64 table.
+//   * the EXACT distance is computed only for the filter's survivors, four lanes per survivor: the quad reads every
+//     table entry's codebook row together (64 contiguous bytes per load) and hands the entry's running sum round the
+//     quad in the reference's order (t ascending from 0.0, IVFPQ.java:531-534); the entries are added in sub-quantizer
+//     order (s ascending, :435-438) -- same bits as a lookup in the fp64 table.  (dsub not 8 or 16: each lane builds the
+//     m/4 entries it owns and the sum is passed down the quad.)
 // Items the kernel does not handle (no finite threshold yet, degenerate or huge magnitudes) are handed to K3f through
 // a device-side list, so results never depend on the heuristics.
 #pragma once
