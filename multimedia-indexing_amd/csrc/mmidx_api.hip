@@ -242,7 +242,7 @@ struct mmidx_index {
     DevBuf<int32_t> ws_fb;
     DevBuf<unsigned short> ws_Qh, ws_Ql;
     DevBuf<float> ws_gmin;
-    DevBuf<int32_t> ws_clist, ws_cn;  // K1f in two kernels: candidate lists [nq][MMIDX_CLIST] and their lengths
+    DevBuf<int32_t> ws_clist;  // K1f in two kernels: candidate lists [nq][MMIDX_CLIST], entry 0 = length
     DevBuf<double> ws_Q, ws_cdist, ws_odist, ws_X, ws_Xa, ws_qn, ws_cdsel, ws_sdc;
     DevBuf<float> ws_Q32, ws_S;
     DevBuf<int32_t> ws_cells, ws_oiid, ws_ocnt, ws_flag, ws_ecell, ws_pcount, ws_pstart, ws_pcursor, ws_order;
@@ -1003,12 +1003,10 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
         A.Dp = h->Dp;
         A.nq = (int)nq;
         // front end and selection as two kernels where a query's candidates fit the list between them (about 1.3 (w + 1))
-        const bool split = !h->coarse_fused && G <= 1024 && 2 * (h->w + 1) + 32 <= MMIDX_CLIST;
+        const bool split = !h->coarse_fused && G <= 1024 && 2 * (h->w + 1) + 32 < MMIDX_CLIST;
         if (split) {
             HIPCK(h->ws_clist.reserve((size_t)nq * MMIDX_CLIST));
-            HIPCK(h->ws_cn.reserve((size_t)nq));
             A.clist = (u32 *)h->ws_clist.p;
-            A.cn = h->ws_cn.p;
             hipLaunchKernelGGL(k_coarse_front, dim3((unsigned)((nq + 3) / 4)), dim3(MMIDX_BLOCK), 0, st, A);
             if (h->C <= 8 * MMIDX_BLOCK)
                 hipLaunchKernelGGL(k_coarse_select_list<8>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), glds, st, A);
@@ -1573,7 +1571,6 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_Ql.release();
     h->ws_gmin.release();
     h->ws_clist.release();
-    h->ws_cn.release();
     h->ws_cdsel.release();
     h->ws_Q32.release();
     h->ws_S.release();

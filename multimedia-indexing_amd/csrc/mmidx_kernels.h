@@ -549,8 +549,7 @@ struct ApproxSel {
     const float2 *gpair;     // [nq][G] (smallest, runner-up | position) of d~ over each group of 8 centroids (K1e)
     int G, Dp;               // groups per query (Cp / 8), k padded to a multiple of 32
     // K1f split in two (k_coarse_front -> k_coarse_select_list): the certified candidates of every query
-    u32 *clist;              // [nq][MMIDX_CLIST]
-    int32_t *cn;             // [nq] number of candidates (> MMIDX_CLIST: the exact-row path)
+    u32 *clist;              // [nq][MMIDX_CLIST]: entry 0 = number of candidates (MMIDX_CSEL_CAP + 1: the exact-row path), then the candidates
     int nq;
 };
 #define MMIDX_CLIST 256
@@ -1673,19 +1672,19 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_front(const ApproxSel A)
     }
     // any centroid with exact distance <= tau has d~ <= tau + eps16
     const double cut = ((double)tau + eps16) + eps16;
+    u32 *list = A.clist + (size_t)q * MMIDX_CLIST;
     if (!(cut < (double)inf) || !(sumn * sumn < 1e37)) {  // nothing can be certified: the exact row
-        if (lane == 0) A.cn[q] = MMIDX_CSEL_CAP + 1;
+        if (lane == 0) list[0] = MMIDX_CSEL_CAP + 1;
         return;
     }
     // ---- candidates: the minimum of every group at or under the cut; the whole group when its runner-up is too
     const u64 lane_lt = (1ull << lane) - 1ull;
-    u32 *list = A.clist + (size_t)q * MMIDX_CLIST;
     u32 n = 0;  // wave-uniform
     auto push = [&](const bool pass, const int c) {
         const u64 mask = __builtin_amdgcn_ballot_w64(pass);
         if (pass) {
             const u32 slot = n + (u32)__popcll(mask & lane_lt);
-            if (slot < MMIDX_CLIST) list[slot] = (u32)c;
+            if (slot < MMIDX_CLIST - 1) list[1 + slot] = (u32)c;  // (entry 0 is the count: one row read in the selection kernel)
         }
         n += (u32)__popcll(mask);
     };
@@ -1703,7 +1702,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_front(const ApproxSel A)
             for (int ct = 0; ct < 8; ct++) push(all && ct != a1 && cb + 16 * ct < C, cb + 16 * ct);
         }
     }
-    if (lane == 0) A.cn[q] = (int32_t)(n <= MMIDX_CLIST ? n : (u32)(MMIDX_CSEL_CAP + 1));
+    if (lane == 0) list[0] = n <= MMIDX_CLIST - 1 ? n : (u32)(MMIDX_CSEL_CAP + 1);
 }
 
 template <int PER>
@@ -1717,14 +1716,13 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_list(const Approx
     __shared__ int s_i[MMIDX_BLOCK / 64];
     __shared__ u32 s_pad[8];  // (statics total 80 B as in k_coarse_select_grp: the dynamic LDS base stays 16-byte aligned)
     const int q = blockIdx.x, tid = threadIdx.x;
-    const int n = A.cn[q];
-    {
-        const int tc = tid < n && n <= MMIDX_CLIST ? tid : 0;
-        const u32 c = A.clist[(size_t)q * MMIDX_CLIST + tc];  // (unconditional load on a clamped index)
-        if (tid < n && n <= MMIDX_CLIST) cidx[tid] = c;
-        if (tid == 0) s_pad[0] = 0;
+    {   // one coalesced row: the count in entry 0, the candidates behind it (entries past the count are never looked at)
+        const u32 c = A.clist[(size_t)q * MMIDX_CLIST + tid];
+        if (tid == 0) s_pad[0] = c;
+        else cidx[tid - 1] = c;
     }
     __syncthreads();
+    const int n = (int)s_pad[0];
     coarse_select_finish<PER>(A, q, n, ckey, cidx, sel_k, sel_i, s_k, s_i);
 }
 
