@@ -1,3 +1,4 @@
+// build: hipcc --offload-arch=gfx950 -O2 -o cvt_pk_u8 cvt_pk_u8.hip
 // rounding / saturation of v_cvt_pk_u8_f32 on gfx950 (used by K3g's table build): prints the byte for a few inputs
 #include <hip/hip_runtime.h>
 #include <cmath>
