@@ -278,7 +278,8 @@ int mmidx_set_profiling(mmidx_index *h, int enabled);
  * configuration the HBM roofline of the scan kernel is quoted on; "no_filter", "no_bound",
  * "exact_coarse" switch the individual devices (DESIGN.md sections 5.2, 5.4, 5.5); "combine" = 0:
  * concurrent mmidx_search callers are served one at a time instead of together (section 5.11).
- * A/B and test switches: "coarse_v1" (K1c/K1d instead of K1e/K1f), "coarse_nodma" (K1e with register staging
+ * A/B and test switches: "coarse_v1" (K1c/K1d instead of K1e/K1f), "coarse_fused" (K1f as one kernel instead of
+ * front end + selection), "coarse_nodma" (K1e with register staging
  * instead of the LDS-DMA kernel), "passa_hist" (1 / 0 / -1: K3h always / never / for long lists), "passa_wide" (K3h with
  * 512-thread blocks), "passa_prefix", "no_grp" (pass B through K3f only), "grp_blocks",
  * "passb_main_grid", "no_item_compaction", "passa_item_min", "passa_item_margin" (a shard's pass-A item list,
