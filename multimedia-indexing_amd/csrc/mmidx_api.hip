@@ -242,6 +242,8 @@ struct mmidx_index {
     DevBuf<int32_t> ws_fb;
     DevBuf<unsigned short> ws_Qh, ws_Ql;
     DevBuf<float> ws_gmin;
+    DevBuf<double> ws_glut;   // lookup tables in global memory when m * ks * 8 bytes do not fit the LDS: one per block
+    size_t glut_slots = 0;
     DevBuf<int32_t> ws_clist;  // K1f in two kernels: candidate lists [nq][MMIDX_CLIST], entry 0 = length
     DevBuf<double> ws_Q, ws_cdist, ws_odist, ws_X, ws_Xa, ws_qn, ws_cdsel, ws_sdc;
     DevBuf<float> ws_Q32, ws_S;
@@ -530,16 +532,23 @@ int encode_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_cell, 
     return MMIDX_OK;
 }
 
-template <int M, typename CodeT, int SU, int NT = MMIDX_BLOCK, bool SDC = false>
+template <int M, typename CodeT, int SU, int NT = MMIDX_BLOCK, bool SDC = false, bool GLUT = false>
 int launch_scan_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t st) {
-    HIPCK(hipFuncSetAttribute((const void *)k_scan<M, CodeT, SU, NT, SDC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_scan<M, CodeT, SU, NT, SDC>), grid, dim3(NT), lds, st, P);
+    HIPCK(hipFuncSetAttribute((const void *)k_scan<M, CodeT, SU, NT, SDC, GLUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_scan<M, CodeT, SU, NT, SDC, GLUT>), grid, dim3(NT), lds, st, P);
     HIPCK(hipGetLastError());
     return MMIDX_OK;
 }
 
 // su = codes per thread per segment (1 or 2; 11 = 1 with 512-thread blocks); P.cap and lds sized for it
 int launch_scan(const mmidx_index *h, const ScanParams &P, dim3 grid, size_t lds, hipStream_t st, int su = 2) {
+    if (P.glut) {  // the table lives in global scratch (make_plan: it does not fit the LDS): generic kernels, LDS = vectors + candidates
+        if ((size_t)grid.x * grid.y > h->glut_slots) return fail(MMIDX_ERR_UNSUPPORTED, "lookup-table scratch too small for %u x %u blocks", grid.x, grid.y);
+        const size_t l = lds - (size_t)h->m * h->ks * 8;
+        if (P.sdc_tt) return launch_scan_t<0, unsigned char, 2, MMIDX_BLOCK, true, true>(P, grid, l, st);
+        if (h->code_bytes == 1) return launch_scan_t<0, unsigned char, 2, MMIDX_BLOCK, false, true>(P, grid, l, st);
+        return launch_scan_t<0, unsigned short, 2, MMIDX_BLOCK, false, true>(P, grid, l, st);
+    }
     if (P.sdc_tt) {  // symmetric distances: byte codes only (the reference NPEs on short codes, PQ.java:350)
         switch (h->m) {
             case 8: return launch_scan_t<8, unsigned char, 2, MMIDX_BLOCK, true>(P, grid, lds, st);
@@ -586,6 +595,7 @@ int launch_scan_filtered(const mmidx_index *h, ScanParams P, const SearchPlan &p
 
 struct SearchPlan {
     int K1, cap, chunk, nchunks, nitems, poolq;
+    bool glut;   // the lookup table goes to global scratch (pl.lds still counts it: launch_scan subtracts)
     size_t lds;
     int64_t qb;  // queries per sub-batch
 };
@@ -597,8 +607,9 @@ int make_plan(mmidx_index *h, int k, int64_t nq, SearchPlan &pl, bool need_coars
     while (cap < pl.K1 + MMIDX_SEG) cap <<= 1;
     pl.cap = cap;
     pl.lds = scan_lds_bytes(h, cap);
-    if (pl.lds > 160 * 1024)
-        return fail(MMIDX_ERR_UNSUPPORTED, "lookup table of %d x %d doubles does not fit the 160 KiB LDS", h->m, h->ks);
+    pl.glut = pl.lds > 160 * 1024;  // table in global scratch, the generic exact-scan kernels only (IVFPQ.java has no such limit)
+    if (pl.glut && pl.lds - (size_t)h->m * h->ks * 8 > 160 * 1024)
+        return fail(MMIDX_ERR_UNSUPPORTED, "vectors and candidate buffer of k = %d do not fit the 160 KiB LDS", k);
     const int ivf = h->kind == MMIDX_KIND_IVFPQ;
     const int nprobe = ivf ? h->w : 1;
     int64_t chunk = 16384;
@@ -623,6 +634,13 @@ int make_plan(mmidx_index *h, int k, int64_t nq, SearchPlan &pl, bool need_coars
     const int64_t pool_bytes_q = (int64_t)pl.poolq * 16;
     qb = std::min<int64_t>(qb, std::max<int64_t>(1, (16ll << 30) / std::max<int64_t>(pool_bytes_q, 1)));
     if (ivf && need_coarse) qb = std::min<int64_t>(qb, std::max<int64_t>(1, (2ll << 30) / ((int64_t)h->C * 8)));
+    if (pl.glut) {  // one table per block in global scratch: at most 2 GiB of it
+        const int64_t lut_bytes = (int64_t)h->m * h->ks * 8;
+        qb = std::min<int64_t>(qb, std::max<int64_t>(1, (2ll << 30) / (lut_bytes * std::max(pl.nitems, 1))));
+        const size_t slots = (size_t)qb * (size_t)std::max(pl.nitems, 1);
+        HIPCK(h->ws_glut.reserve(slots * (size_t)h->m * h->ks));
+        h->glut_slots = slots;
+    }
     pl.qb = qb;
     return MMIDX_OK;
 }
@@ -1155,6 +1173,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
     P.w = ivf ? h->w : 1;
     P.transform = h->transform;
     P.ivf = ivf;
+    P.glut = pl.glut ? h->ws_glut.p : nullptr;
     P.chunk = pl.chunk;
     P.code_lo = 0;
     P.code_hi = 0x7fffffff;
@@ -1373,8 +1392,17 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
         TP.iid_out = d_iid;
         TP.dist_out = d_dist;
         TP.k = k;
-        const size_t tlds = (size_t)h->m * h->ks * 8 + 2 * (size_t)h->D * 8;
-        if (sdc_tt) {
+        const size_t tlds = (P.glut ? 0 : (size_t)h->m * h->ks * 8) + 2 * (size_t)h->D * 8;
+        if (P.glut) {  // (the table in global scratch: one slot per query of the sub-batch)
+            if ((size_t)nq > h->glut_slots) return fail(MMIDX_ERR_UNSUPPORTED, "lookup-table scratch too small for the tie replay");
+            if (sdc_tt) {
+                hipLaunchKernelGGL((k_tie_resolve<unsigned char, true, true>), dim3((unsigned)nq), dim3(MMIDX_BLOCK), tlds, st, TP);
+            } else if (h->code_bytes == 1) {
+                hipLaunchKernelGGL((k_tie_resolve<unsigned char, false, true>), dim3((unsigned)nq), dim3(MMIDX_BLOCK), tlds, st, TP);
+            } else {
+                hipLaunchKernelGGL((k_tie_resolve<unsigned short, false, true>), dim3((unsigned)nq), dim3(MMIDX_BLOCK), tlds, st, TP);
+            }
+        } else if (sdc_tt) {
             HIPCK(hipFuncSetAttribute((const void *)k_tie_resolve<unsigned char, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
             hipLaunchKernelGGL((k_tie_resolve<unsigned char, true>), dim3((unsigned)nq), dim3(MMIDX_BLOCK), tlds, st, TP);
         } else if (h->code_bytes == 1) {
@@ -1571,6 +1599,7 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_Ql.release();
     h->ws_gmin.release();
     h->ws_clist.release();
+    h->ws_glut.release();
     h->ws_cdsel.release();
     h->ws_Q32.release();
     h->ws_S.release();
@@ -2233,9 +2262,15 @@ int mmidx_shard_tie_phase_device(mmidx_index *h, int phase, int k, int64_t nf, c
     TP.tie_iids = d_tie_iids;
     TP.k = k;
     TP.phase = phase;
-    const size_t lds = (size_t)h->m * h->ks * 8 + 2 * (size_t)h->D * 8;
-    if (lds > 160 * 1024) return fail(MMIDX_ERR_UNSUPPORTED, "lookup table of %d x %d doubles does not fit the 160 KiB LDS", h->m, h->ks);
-    if (h->code_bytes == 1) {
+    size_t lds = (size_t)h->m * h->ks * 8 + 2 * (size_t)h->D * 8;
+    if (lds > 160 * 1024) {  // the table in global scratch: one slot per flagged query
+        HIPCK(h->ws_glut.reserve((size_t)nf * (size_t)h->m * h->ks));
+        h->glut_slots = std::max(h->glut_slots, (size_t)nf);
+        TP.S.glut = h->ws_glut.p;
+        lds = 2 * (size_t)h->D * 8;
+        if (h->code_bytes == 1) hipLaunchKernelGGL((k_shard_tie<unsigned char, true>), dim3((unsigned)nf), dim3(MMIDX_BLOCK), lds, st, TP);
+        else hipLaunchKernelGGL((k_shard_tie<unsigned short, true>), dim3((unsigned)nf), dim3(MMIDX_BLOCK), lds, st, TP);
+    } else if (h->code_bytes == 1) {
         HIPCK(hipFuncSetAttribute((const void *)k_shard_tie<unsigned char>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_shard_tie<unsigned char>, dim3((unsigned)nf), dim3(MMIDX_BLOCK), lds, st, TP);
     } else {

@@ -1774,6 +1774,7 @@ struct ScanParams {
     u32 *fb_count;           // K3h: items handed back to K3
     int32_t *fb_items, *fb_ch;
     int code_lo, code_hi;    // only list positions [code_lo, code_hi) are scanned by this launch (pass A prefix / remainder)
+    double *glut;            // GLUT kernels (table larger than the LDS): scratch of m * ks doubles per block, else null
     int K1;                  // k + 1
     int cap;                 // LDS candidate capacity (>= K1 + SEG, power of two)
     int poolq;
@@ -1974,13 +1975,22 @@ __device__ __forceinline__ double *query_vector(const ScanParams &P, int q, int 
 // SDC = symmetric distances (PQ.computeKnnSDC PQ.java:334-374): instead of the LUT sum, the distance is ONE chain
 // over all D dimensions of (pq[s][code_s][t] - pq[s][querycode_s][t])^2, s outer, t inner (PQ.java:349-363); the
 // squared terms come from a per-query table in global memory (L2-resident, 256 KiB at m*ks*dsub = 32768).
-template <int M, typename CodeT, int SU, int NT, bool SDC>
+// GLUT: the lookup table does not fit the LDS (m * ks * 8 bytes beyond ~140 KiB: short codes with many sub-quantizers) and
+// lives in the block's slice of a global scratch buffer instead (L2-resident; the gather becomes global loads).  The slow,
+// complete path: same arithmetic, same order.
+template <int M, typename CodeT, int SU, int NT, bool SDC, bool GLUT = false>
 __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int m = (M > 0) ? M : P.m;
     const int ks = P.ks, D = P.D;
-    double *lut = (double *)smem;                 // [m*ks]
-    double *vec = lut + (size_t)m * ks;           // [2*D]
+    double *lut, *vec;
+    if constexpr (GLUT) {
+        lut = P.glut + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)m * ks;
+        vec = (double *)smem;
+    } else {
+        lut = (double *)smem;                     // [m*ks]
+        vec = lut + (size_t)m * ks;               // [2*D]
+    }
     u64 *bkey = (u64 *)(vec + (P.transform ? 2 : 1) * (size_t)D);  // [cap] (the transform needs a second vector)
     u32 *bval = (u32 *)(bkey + P.cap);            // [cap]
     u32 *s_cnt = bval + P.cap;                    // [4]
@@ -3737,15 +3747,21 @@ struct TieParams {
     int k;
 };
 
-template <typename CodeT, bool SDC>
+template <typename CodeT, bool SDC, bool GLUT = false>
 __global__ __launch_bounds__(MMIDX_BLOCK) void k_tie_resolve(const TieParams TP) {
     const ScanParams &P = TP.S;
     const int q = blockIdx.x, tid = threadIdx.x, k = TP.k;
     if (!TP.flag[q]) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int m = P.m, ks = P.ks;
-    double *lut = (double *)smem;
-    double *vec = lut + (size_t)m * ks;
+    double *lut, *vec;
+    if constexpr (GLUT) {  // (table in the block's slice of the global scratch, see k_scan)
+        lut = P.glut + (size_t)blockIdx.x * (size_t)m * ks;
+        vec = (double *)smem;
+    } else {
+        lut = (double *)smem;
+        vec = lut + (size_t)m * ks;
+    }
     __shared__ int s_wsum[MMIDX_BLOCK / 64][2];
     __shared__ int s_state[4];  // nonjunk, ties, p (or -1), emitted
     const u64 tau = dkey(TP.dist_out[(size_t)q * k + (k - 1)]);
@@ -4488,7 +4504,7 @@ struct TieShardParams {
     int k, phase;
 };
 
-template <typename CodeT>
+template <typename CodeT, bool GLUT = false>
 __global__ __launch_bounds__(MMIDX_BLOCK) void k_shard_tie(const TieShardParams TP) {
     const ScanParams &P = TP.S;
     const int f = blockIdx.x, tid = threadIdx.x, k = TP.k, w = P.w;
@@ -4496,8 +4512,14 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_shard_tie(const TieShardParams 
     if (q < 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int m = P.m, ks = P.ks;
-    double *lut = (double *)smem;
-    double *vec = lut + (size_t)m * ks;
+    double *lut, *vec;
+    if constexpr (GLUT) {  // (table in the block's slice of the global scratch, see k_scan)
+        lut = P.glut + (size_t)blockIdx.x * (size_t)m * ks;
+        vec = (double *)smem;
+    } else {
+        lut = (double *)smem;
+        vec = lut + (size_t)m * ks;
+    }
     __shared__ int s_wsum[MMIDX_BLOCK / 64][2];
     __shared__ int s_run[2];   // running (d <= tau, d == tau) counts of the list being streamed
     __shared__ int s_plan[6];  // r*, j*, ties before r*, b, e, p

@@ -148,6 +148,38 @@ def test_short_codes(mi, oracle):
     ix.close()
 
 
+@pytest.mark.parametrize("kind", ["ivfpq", "ivfpq_ties", "pq"])
+def test_lookup_table_larger_than_lds(mi, oracle, kind):
+    """m x ks x 8 bytes beyond the 160 KiB LDS (here 32 x 1024 doubles = 256 KiB, short codes): the reference has no such limit
+    (IVFPQ.java:525-538 allocates double[m][ks]); the table then lives in global scratch (k_scan / k_tie_resolve with GLUT).
+    Same ids and distance bits as the oracle, straddling ties (every vector three times) included."""
+    D, C, m, ks, n, w, k = 64, 6, 32, 1024, 4000, 4, 10
+    if kind == "pq":
+        p = synth.make_pq_problem(n=n, D=D, m=m, ks=ks, nq=8, seed=11)
+        ix = mi.PQ(D, 3 * n, False, "", m, ks, 0, 512)
+        ref = oracle.OracleIndex(oracle.KIND_PQ, D, m, ks)
+    else:
+        p = synth.make_ivfpq_problem(n=n, D=D, C=C, m=m, ks=ks, nq=8, seed=11)
+        ix = mi.IVFPQ(D, 3 * n, False, "", m, ks, 0, C, 512)
+        ix.loadCoarseQuantizer(p["coarse"])
+        ix.setW(w)
+        ref = oracle_ivfpq(oracle, p, D, m, ks, C, w)
+    ix.loadProductQuantizer(p["pq"])
+    if kind == "pq":
+        ref.set_pq(p["pq"])
+    base = p["base"]
+    if kind == "ivfpq_ties":
+        base = np.concatenate([base] * 3)[np.random.default_rng(2).permutation(3 * n)]
+    ix.indexVectors([str(i) for i in range(len(base))], base)
+    ref.add_vectors(base)
+    got, want = ix.search_batch(k, p["queries"]), ref.search_batch(p["queries"], k)
+    assert_same(got, want)
+    if kind == "ivfpq_ties":  # the comparison covers the replay: some query's k-th and (k+1)-th distances tie
+        w1 = ref.search_batch(p["queries"], k + 1)
+        assert any(w1[2][i] > k and w1[1][i, k - 1] == w1[1][i, k] for i in range(len(p["queries"])))
+    ix.close()
+
+
 @pytest.mark.parametrize("k", [1500, 4095])
 def test_large_k(mi, oracle, k):
     """k beyond 1023 (the reference's queue is unbounded, IVFPQ.java:409): candidate and merge buffers grow with k up to 4095;
@@ -529,8 +561,8 @@ def test_virtual_shards_on_one_device(mi, oracle, S):
         ix.close()
 
 
-@pytest.mark.parametrize("S", [2, 3])
-def test_virtual_shards_straddling_ties(mi, oracle, S):
+@pytest.mark.parametrize("S,shape", [(2, "bytes"), (3, "bytes"), (2, "big_table")])
+def test_virtual_shards_straddling_ties(mi, oracle, S, shape):
     """FLAGGED tie fixture for the multi-GPU path: every vector indexed three times, so exact distance ties straddle k; the
     cross-shard replay (mmidx_merge_partials_device flags + the three mmidx_shard_tie_phase_device passes, reductions done
     here over S virtual shards on one device) must return the single queue's answer (IVFPQ.java:445)."""
@@ -538,6 +570,8 @@ def test_virtual_shards_straddling_ties(mi, oracle, S):
 
     sh = importlib.import_module("multimedia-indexing_amd.sharded")
     D, C, m, ks, w = 32, 12, 8, 256, 5
+    if shape == "big_table":  # short codes, 32 x 1024 doubles = 256 KiB: the table in global scratch (k_shard_tie with GLUT)
+        D, m, ks = 64, 32, 1024
     p = synth.make_ivfpq_problem(n=1200, D=D, C=C, m=m, ks=ks, nq=48, seed=60 + S)
     base = np.concatenate([p["base"]] * 3)
     base = base[np.random.default_rng(2).permutation(len(base))]
