@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MMIDX_ABI_VERSION 4
+#define MMIDX_ABI_VERSION 5
 
 typedef struct mmidx_index mmidx_index; /* opaque handle: one index on one GPU */
 
@@ -162,7 +162,8 @@ int mmidx_search_sdc(mmidx_index *h, int k, int64_t nq, const int32_t *iids, int
  * fp64 argmin cell, first index wins ties.  Needs only the coarse quantizer (used by the codebook learner). */
 int mmidx_assign_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_cell_out, void *stream);
 
-/* ---- sharded search (one process per GPU; lists partitioned across ranks) ---------------------
+/* ---- sharded search, building blocks (one process per GPU over torch.distributed / MPI; the single-process form is
+ * mmidx_create_sharded below, which drives these same phases itself) ---------------------
  * mmidx_coarse_device: computeNearestCoarseIndices IVFPQ.java:575-601 for nq queries ->
  *   d_cells_out[nq][w] (nearest first) and, when d_cdist_out is not NULL, the exact squared distance
  *   of every selected cell, d_cdist_out[nq][w] (what pass B's coarse bound needs: ranks that did not
@@ -214,6 +215,42 @@ int mmidx_merge_partials_device(int device, int k, int64_t nq, int nshards, cons
 int mmidx_shard_tie_phase_device(mmidx_index *h, int phase, int k, int64_t nf, const double *dQ, const int32_t *d_cells,
                                  const int32_t *d_fq, const double *d_tau, int32_t *d_counts, int32_t *d_pB,
                                  int32_t *d_tie_iids, void *stream);
+
+/* ---- one index over several GPUs, ONE process (ABI version 5) --------------------------------------------------------------
+ * The reference's caller is a single JVM that holds the whole index and queries it through one object
+ * (YFCC100MExample.java:93-99, :155; Example.java:96-110).  mmidx_create_sharded makes that object span n_dev GPUs of one node:
+ * whole inverted lists are partitioned (list c lives on shard c mod n_dev -- invertedLists[c] / pqByteCodes[c], IVFPQ.java:72-83,
+ * stay intact, so the offer order inside a list is the reference's), the codebooks are replicated, and every entry point that
+ * takes host pointers works on the returned handle exactly as on a plain one:
+ *   mmidx_set_coarse / mmidx_set_pq / mmidx_set_w / mmidx_set_option / mmidx_set_profiling   applied to every shard
+ *   mmidx_encode / mmidx_add_vectors     the batch is encoded 1/n_dev per GPU, each record goes to the shard that owns its list
+ *   mmidx_add_codes                      indexPQCode / loadIndexInMemory: records routed by list id
+ *   mmidx_search                         computeKnnIVFADC over all shards (below); concurrent callers are combined as usual
+ *   mmidx_size / mmidx_list_sizes / mmidx_export / mmidx_get_codes / mmidx_distance / mmidx_get_stats / mmidx_sync_index
+ * Search, per round of queries: shard r owns 1/n_dev of the queries; RCCL all-gather of the query vectors and of the probe cells
+ * (each shard runs the coarse stage for its own queries), pass A on every shard's local lists, RCCL all-reduce (MIN) of the
+ * thresholds, pass B under the global thresholds, every sorted partial top-(k+1) list stored straight into its owner's buffers
+ * over xGMI (peer access; option "shard_exchange" = 1: ncclSend / ncclRecv of the dense lists instead), merge at the owner,
+ * cross-shard replay of the bounded queue for queries whose k-th and (k+1)-th distances tie (RCCL all-reduces).  Results are
+ * those of a plain handle holding the same records: ids bit-exact, distances bit-equal, ties included.
+ * devs[i] = HIP device of shard i.  Pairwise distinct devices (the production form, n_dev = 1 included) use RCCL
+ * (ncclCommInitAll, one communicator per device, one host thread per device); a device listed more than once makes virtual
+ * shards on it with in-process collectives (RCCL refuses duplicate devices): the functional test form on a one-GPU box.
+ * The _device entry points of a plain handle take ONE device's pointers and are refused on a sharded handle
+ * (MMIDX_ERR_UNSUPPORTED); the _sliced_device forms below are their counterparts: slice r lives in the HBM of shard r's device.
+ *   mmidx_search_sliced_device   shard r hands in nq_per_shard queries dQ[r][nq_per_shard][D] and receives their answers in
+ *                                d_iid_out[r] / d_dist_out[r] / d_count_out[r] (synchronous: the answers are complete on return)
+ *   mmidx_add_vectors_sliced_device   the batch is the concatenation of the slices dX[r][n_per_shard[r]][D]; row i of it gets
+ *                                iid0 + i (arrival order = batch order, as indexVector calls in that order would give)
+ *   mmidx_shard_count / mmidx_shard_info   number of shards (1 for a plain handle); a shard's device, its number of records,
+ *                                and whether the group's collectives run on RCCL */
+int mmidx_create_sharded(int kind, int D, int m, int ks, int C, int transform, const int32_t *perm, const double *rot, int n_dev,
+                         const int *devs, mmidx_index **out);
+int mmidx_shard_count(const mmidx_index *h, int *n_out);
+int mmidx_shard_info(const mmidx_index *h, int shard, int *device_out, int64_t *size_out, int *uses_rccl_out);
+int mmidx_search_sliced_device(mmidx_index *h, int k, int64_t nq_per_shard, const double *const *dQ, int32_t *const *d_iid_out,
+                               double *const *d_dist_out, int32_t *const *d_count_out);
+int mmidx_add_vectors_sliced_device(mmidx_index *h, const int64_t *n_per_shard, const double *const *dX, int32_t iid0);
 
 /* ---- Linear: exhaustive exact search (J/datastructures/Linear.java; BASELINE config 1) ------------------------
  * add = indexVectorInternal (:111-122), search = computeNearestNeighborsInternal(k, double[]) (:138-163): exact
@@ -283,7 +320,9 @@ int mmidx_set_profiling(mmidx_index *h, int enabled);
  * instead of the LDS-DMA kernel), "passa_hist" (1 / 0 / -1: K3h always / never / for long lists), "passa_wide" (K3h with
  * 512-thread blocks), "passa_prefix", "no_grp" (pass B through K3f only), "grp_blocks",
  * "passb_main_grid", "no_item_compaction", "passa_item_min", "passa_item_margin" (a shard's pass-A item list,
- * section 6). */
+ * section 6).  On a sharded handle: "shard_exchange" (0: partial lists stored into the owners' buffers over xGMI, 1: ncclSend /
+ * ncclRecv), "tie_slots" (flagged queries per owner and replay round, 0 = no replay), "shard_max_round"; every other option goes
+ * to every shard. */
 int mmidx_set_option(mmidx_index *h, const char *name, int value);
 int mmidx_get_stats(mmidx_index *h, mmidx_stats *out);
 

@@ -42,7 +42,7 @@ class Stats(C.Structure):
 
 def build(force=False):
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("mmidx_api.hip", "mmidx_learn.hip", "mmidx_kernels.h", "mmidx_scan_grp.h", "mmidx_frontend.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("mmidx_api.hip", "mmidx_learn.hip", "mmidx_kernels.h", "mmidx_scan_grp.h", "mmidx_frontend.h", "mmidx_sharded.h")]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "mmidx.h"))
     stale = not os.path.exists(SO_PATH) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
     if force or stale:
@@ -108,6 +108,11 @@ SIGNATURES = {
                                       _i32p, _i32p, _vp]),
     "mmidx_kmeans": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, _dp, _dp, _dp, _i32p, _dp, _i32p,
                                _i32p]),
+    "mmidx_create_sharded": (C.c_int, [C.c_int] * 6 + [_vp, _vp, C.c_int, _vp, C.POINTER(C.c_void_p)]),
+    "mmidx_shard_count": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "mmidx_shard_info": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "mmidx_search_sliced_device": (C.c_int, [_vp, C.c_int, C.c_int64, _vp, _vp, _vp, _vp]),
+    "mmidx_add_vectors_sliced_device": (C.c_int, [_vp, _vp, _vp, C.c_int32]),
     "mmidx_set_profiling": (C.c_int, [_vp, C.c_int]),
     "mmidx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "mmidx_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
@@ -127,6 +132,24 @@ def _preload_hip_runtime():
         if spec is None or not spec.submodule_search_locations:
             return
         cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
+def preload_rccl():
+    """A sharded handle (mmidx_create_sharded) loads RCCL with dlopen("librccl.so.1") on first use.  PyTorch-ROCm wheels bundle
+    their own librccl.so next to their HIP runtime; when torch is installed bind to THAT pair (a library with the same SONAME that
+    is already mapped is what dlopen returns), as _preload_hip_runtime does for libamdhip64.  Without torch (the JNI shim) the
+    library resolves to /opt/rocm/lib through libmmidx_hip.so's RUNPATH."""
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
         if os.path.exists(cand):
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
     except Exception:

@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <limits>
@@ -168,7 +169,14 @@ int combiner_submit(Combiner &c, SearchReq &me, int64_t max_q, Serve serve) {
 
 }  // namespace
 
+struct ShardGroup;  // mmidx_sharded.h
+
 struct mmidx_index {
+    // a handle made by mmidx_create_sharded is a parent: it owns no device memory itself, `grp` holds one sub-index per shard
+    ShardGroup *grp = nullptr;
+    // a sub-index of such a group: where pass B's partial lists go (MergeParams::dest), set per search round by the group
+    const ShardDest *shard_dest = nullptr;
+    int shard_dest_per = 0, shard_dest_me = 0;
     int kind = 0, D = 0, m = 0, ks = 0, dsub = 0, C = 0, transform = 0, w = 0, device = 0;
     int nlists = 1;
     size_t code_bytes = 1;  // per sub-quantizer
@@ -275,6 +283,29 @@ struct mmidx_index {
 };
 
 namespace {
+
+// a handle made by mmidx_create_sharded (h->grp != null): mmidx_sharded.h, included at the end of this file
+int sharded_search(mmidx_index *h, int k, int64_t nq, const double *Q, int32_t *iid_out, double *dist_out, int32_t *count_out);
+int sharded_add_vectors(mmidx_index *h, int64_t n, const double *X, const double *const *dXs, const int64_t *ns, const int32_t *iids,
+                        int32_t iid0, int32_t *cell_out, void *code_out);
+int sharded_add_codes(mmidx_index *h, int64_t n, const int32_t *iids, const int32_t *cells, const void *codes);
+int sharded_encode(mmidx_index *h, int64_t n, const double *X, int32_t *cell_out, void *code_out);
+int sharded_sync(mmidx_index *h);
+int sharded_list_sizes(mmidx_index *h, int32_t *sizes_out);
+int sharded_export(mmidx_index *h, int64_t *list_off_out, int32_t *iids_out, void *codes_out);
+int sharded_get_codes(mmidx_index *h, int64_t n, const int32_t *iids, int32_t *cell_out, void *code_out);
+int sharded_distance(mmidx_index *h, int64_t n, const double *Q, const int32_t *iids, double *dist_out);
+int sharded_get_stats(mmidx_index *h, mmidx_stats *out);
+int sharded_set_option(mmidx_index *h, const char *name, int value);
+int sharded_for_each(mmidx_index *h, const std::function<int(mmidx_index *)> &f);
+int64_t sharded_total(const mmidx_index *h);
+void sharded_destroy(mmidx_index *h);
+#define NOT_ON_SHARDED(h, name)                                                                                              \
+    do {                                                                                                                     \
+        if ((h) && (h)->grp)                                                                                                 \
+            return fail(MMIDX_ERR_UNSUPPORTED, name " takes a plain handle: a sharded handle has one device per shard (use the " \
+                                                    "host-pointer entry points or the _sliced_device forms)");              \
+    } while (0)
 
 // Serialises the calls that use a handle's workspaces (see mmidx_index::search_mu).  A _device entry point is asynchronous on
 // the caller's stream; when the previous call ran on a DIFFERENT stream its kernels may still be reading the workspaces, so
@@ -544,6 +575,7 @@ int launch_scan_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t st) {
 int launch_scan(const mmidx_index *h, const ScanParams &P, dim3 grid, size_t lds, hipStream_t st, int su = 2) {
     if (P.glut) {  // the table lives in global scratch (make_plan: it does not fit the LDS): generic kernels, LDS = vectors + candidates
         if ((size_t)grid.x * grid.y > h->glut_slots) return fail(MMIDX_ERR_UNSUPPORTED, "lookup-table scratch too small for %u x %u blocks", grid.x, grid.y);
+        if (P.cap < P.K1 + MMIDX_SEG) return fail(MMIDX_ERR_UNSUPPORTED, "candidate buffer of %d entries too small for k + 1 = %d and a %d-code segment", P.cap, P.K1, MMIDX_SEG);
         const size_t l = lds - (size_t)h->m * h->ks * 8;
         if (P.sdc_tt) return launch_scan_t<0, unsigned char, 2, MMIDX_BLOCK, true, true>(P, grid, l, st);
         if (h->code_bytes == 1) return launch_scan_t<0, unsigned char, 2, MMIDX_BLOCK, false, true>(P, grid, l, st);
@@ -637,7 +669,8 @@ int make_plan(mmidx_index *h, int k, int64_t nq, SearchPlan &pl, bool need_coars
     if (pl.glut) {  // one table per block in global scratch: at most 2 GiB of it
         const int64_t lut_bytes = (int64_t)h->m * h->ks * 8;
         qb = std::min<int64_t>(qb, std::max<int64_t>(1, (2ll << 30) / (lut_bytes * std::max(pl.nitems, 1))));
-        const size_t slots = (size_t)qb * (size_t)std::max(pl.nitems, 1);
+        // (pass B's grid is the pair count rounded up to a multiple of 8: the slots cover the padded grid)
+        const size_t slots = (((size_t)qb * (size_t)std::max(nprobe, 1) + 7) / 8 * 8 + 8) * (size_t)std::max(pl.nchunks, 1);
         HIPCK(h->ws_glut.reserve(slots * (size_t)h->m * h->ks));
         h->glut_slots = slots;
     }
@@ -1216,7 +1249,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
                 ScanParams PA = P;
                 int su = 2;
                 size_t lds_a = pl.lds;
-                if (two_pass && ivf && !h->passa_su2 && h->code_bytes == 1 && (h->m == 8 || h->m == 16 || h->m == 32)) {
+                if (two_pass && ivf && !h->passa_su2 && !pl.glut && h->code_bytes == 1 && (h->m == 8 || h->m == 16 || h->m == 32)) {  // (the GLUT kernels are SU = 2 only: their buffer keeps pl.cap)
                     const int nt = h->passa_512 ? 512 : MMIDX_BLOCK;
                     int cap1 = 1;
                     while (cap1 < pl.K1 + nt) cap1 <<= 1;
@@ -1370,6 +1403,11 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
     M.flag_out = h->ws_flag.p;
     M.pdist = d_pdist;
     M.pkey = d_pkey;
+    if (mode == 1 && phase == 2 && h->shard_dest) {  // a shard of a sharded handle: the lists go to the queries' owners
+        M.dest = h->shard_dest;
+        M.dest_per = h->shard_dest_per;
+        M.dest_me = h->shard_dest_me;
+    }
     int mcap = 512;
     while (mcap < 2 * pl.K1) mcap <<= 1;  // <= 8192 (k <= MMIDX_K_MAX)
     M.cap = mcap;
@@ -1457,6 +1495,29 @@ int search_common(mmidx_index *h, int k, int64_t nq, const double *dQ, const int
                                  sdc_tt ? sdc_tt + (size_t)q0 * h->m * h->ks * h->dsub : nullptr);
         if (rc) return rc;
     }
+    return MMIDX_OK;
+}
+
+// K5 on `st` (the device is current): dense [nshards][nq][k+1] lists, or ragged with d_poff
+int launch_merge_partials(int k, int64_t nq, int nshards, const double *d_pdist, const int64_t *d_pkey, const int32_t *d_pcount,
+                          const int64_t *d_poff, int32_t *d_iid_out, double *d_dist_out, int32_t *d_count_out, int32_t *d_flag_out,
+                          int32_t *d_nflag_out, hipStream_t st) {
+    // buffer: room for the kept prefix plus at least one more shard's list.  With at most 128 entries over all shards in the
+    // usual case (pass B drops everything above the global threshold) small blocks keep more queries in flight per CU.
+    const bool small = k + 1 <= 128;
+    int mcap = small ? 512 : MMIDX_MCAP;
+    while (mcap < 2 * (k + 1)) mcap <<= 1;
+    const size_t mlds = (size_t)mcap * 16;
+    if (small) {
+        HIPCK(hipFuncSetAttribute((const void *)k_merge_partials<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+        hipLaunchKernelGGL(k_merge_partials<128>, dim3((unsigned)nq), dim3(128), mlds, st, k, (int)nq, nshards, mcap, d_pdist,
+                           (const long long *)d_pkey, d_pcount, (const long long *)d_poff, d_iid_out, d_dist_out, d_count_out, d_flag_out, d_nflag_out);
+    } else {
+        HIPCK(hipFuncSetAttribute((const void *)k_merge_partials<MMIDX_BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+        hipLaunchKernelGGL(k_merge_partials<MMIDX_BLOCK>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), mlds, st, k, (int)nq, nshards, mcap, d_pdist,
+                           (const long long *)d_pkey, d_pcount, (const long long *)d_poff, d_iid_out, d_dist_out, d_count_out, d_flag_out, d_nflag_out);
+    }
+    HIPCK(hipGetLastError());
     return MMIDX_OK;
 }
 
@@ -1573,6 +1634,11 @@ int mmidx_create(int kind, int D, int m, int ks, int C, int transform, const int
 
 int mmidx_destroy(mmidx_index *h) {
     if (!h) return MMIDX_OK;
+    if (h->grp) {  // a sharded parent owns nothing but its group
+        sharded_destroy(h);
+        delete h;
+        return MMIDX_OK;
+    }
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->pin_hint) {
@@ -1642,6 +1708,11 @@ int mmidx_destroy(mmidx_index *h) {
 int mmidx_set_coarse(mmidx_index *h, const double *coarse) {
     if (!h || !coarse) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
     if (h->kind != MMIDX_KIND_IVFPQ) return fail(MMIDX_ERR_INVALID_ARG, "PQ index has no coarse quantizer");
+    if (h->grp) {  // codebooks are replicated on every shard
+        int rcs = sharded_for_each(h, [&](mmidx_index *s) { return mmidx_set_coarse(s, coarse); });
+        if (!rcs) h->coarse_set = true;
+        return rcs;
+    }
     int rc = set_device(h);
     if (rc) return rc;
     const size_t n = (size_t)h->C * h->D;
@@ -1704,6 +1775,11 @@ int mmidx_set_coarse(mmidx_index *h, const double *coarse) {
 
 int mmidx_set_pq(mmidx_index *h, const double *pq) {
     if (!h || !pq) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (h->grp) {
+        int rcs = sharded_for_each(h, [&](mmidx_index *s) { return mmidx_set_pq(s, pq); });
+        if (!rcs) h->pq_set = true;
+        return rcs;
+    }
     int rc = set_device(h);
     if (rc) return rc;
     const size_t n = (size_t)h->m * h->ks * h->dsub;
@@ -1738,6 +1814,7 @@ int mmidx_set_pq(mmidx_index *h, const double *pq) {
 int mmidx_set_w(mmidx_index *h, int w) {
     if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
     h->w = w;  // validated at search time, as the reference does (IVFPQ.java:95-97)
+    if (h->grp) return sharded_for_each(h, [&](mmidx_index *s) { return mmidx_set_w(s, w); });
     return MMIDX_OK;
 }
 int mmidx_get_w(const mmidx_index *h, int *w_out) {
@@ -1747,12 +1824,13 @@ int mmidx_get_w(const mmidx_index *h, int *w_out) {
 }
 int mmidx_size(const mmidx_index *h, int64_t *n_out) {
     if (!h || !n_out) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
-    *n_out = total_size(h);
+    *n_out = h->grp ? sharded_total(h) : total_size(h);
     return MMIDX_OK;
 }
 
 int mmidx_sync_index(mmidx_index *h) {
     if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    if (h->grp) return sharded_sync(h);
     int rc = set_device(h);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(h->mu);
@@ -1761,6 +1839,7 @@ int mmidx_sync_index(mmidx_index *h) {
 
 int mmidx_list_sizes(mmidx_index *h, int32_t *sizes_out) {
     if (!h || !sizes_out) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (h->grp) return sharded_list_sizes(h, sizes_out);
     int rc = mmidx_sync_index(h);
     if (rc) return rc;
     for (int c = 0; c < h->nlists; c++) sizes_out[c] = (int32_t)(h->h_off[(size_t)c + 1] - h->h_off[(size_t)c]);
@@ -1768,6 +1847,7 @@ int mmidx_list_sizes(mmidx_index *h, int32_t *sizes_out) {
 }
 
 int mmidx_encode_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_cell_out, void *d_code_out, void *stream) {
+    NOT_ON_SHARDED(h, "mmidx_encode_device");
     int rc = check_ready(h);
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!dX || !d_cell_out || !d_code_out))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
@@ -1790,6 +1870,10 @@ int mmidx_encode_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_
 }
 
 int mmidx_encode(mmidx_index *h, int64_t n, const double *X, int32_t *cell_out, void *code_out) {
+    if (h && h->grp) {
+        if (n < 0 || (n > 0 && (!X || !code_out))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+        return sharded_encode(h, n, X, cell_out, code_out);
+    }
     int rc = check_ready(h);
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!X || !code_out))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
@@ -1817,6 +1901,7 @@ int mmidx_encode(mmidx_index *h, int64_t n, const double *X, int32_t *cell_out, 
 // append n device-resident records; codes in stored form (int8 biased / int16)
 int mmidx_add_codes_device(mmidx_index *h, int64_t n, const int32_t *d_iids, const int32_t *d_cells, const void *d_codes, void *stream) {
     if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    NOT_ON_SHARDED(h, "mmidx_add_codes_device");
     if (n < 0 || (n > 0 && (!d_iids || !d_codes))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
     if (h->kind == MMIDX_KIND_IVFPQ && n > 0 && !d_cells) return fail(MMIDX_ERR_INVALID_ARG, "IVFPQ needs list ids");
     if (n == 0) return MMIDX_OK;
@@ -1871,6 +1956,7 @@ int mmidx_add_codes(mmidx_index *h, int64_t n, const int32_t *iids, const int32_
     if (n < 0 || (n > 0 && (!iids || !codes))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
     if (h->kind == MMIDX_KIND_IVFPQ && n > 0 && !cells) return fail(MMIDX_ERR_INVALID_ARG, "IVFPQ needs list ids");
     if (n == 0) return MMIDX_OK;
+    if (h->grp) return sharded_add_codes(h, n, iids, cells, codes);
     if (h->kind == MMIDX_KIND_IVFPQ)
         for (int64_t i = 0; i < n; i++)
             if (cells[i] < 0 || cells[i] >= h->C) return fail(MMIDX_ERR_INVALID_ARG, "list id %d outside 0..%d", cells[i], h->C - 1);
@@ -1893,6 +1979,7 @@ int mmidx_add_codes(mmidx_index *h, int64_t n, const int32_t *iids, const int32_
 }
 
 int mmidx_add_vectors_device(mmidx_index *h, int64_t n, const double *dX, const int32_t *d_iids, int32_t iid0, void *stream) {
+    NOT_ON_SHARDED(h, "mmidx_add_vectors_device");
     int rc = check_ready(h);
     if (rc) return rc;
     if (n < 0 || (n > 0 && !dX)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
@@ -1922,6 +2009,10 @@ int mmidx_add_vectors_device(mmidx_index *h, int64_t n, const double *dX, const 
 }
 
 int mmidx_add_vectors(mmidx_index *h, int64_t n, const double *X, const int32_t *iids, int32_t *cell_out, void *code_out) {
+    if (h && h->grp) {
+        if (n < 0 || (n > 0 && !X)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+        return sharded_add_vectors(h, n, X, nullptr, nullptr, iids, (int32_t)sharded_total(h), cell_out, code_out);
+    }
     int rc = check_ready(h);
     if (rc) return rc;
     if (n < 0 || (n > 0 && !X)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
@@ -1965,6 +2056,7 @@ int mmidx_search_device(mmidx_index *h, int k, int64_t nq, const double *dQ, int
                         int32_t *d_count_out, void *stream) {
     if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
     if (nq > 0 && (!dQ || !d_iid_out || !d_dist_out || !d_count_out)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    NOT_ON_SHARDED(h, "mmidx_search_device");
     hipStream_t st = (hipStream_t)stream;
     DeviceCall call(h, st);
     return search_common(h, k, nq, dQ, nullptr, 0, d_iid_out, d_dist_out, d_count_out, nullptr, nullptr, st);
@@ -2057,6 +2149,7 @@ int mmidx_search(mmidx_index *h, int k, int64_t nq, const double *Q, int32_t *ii
     if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
     if (nq > 0 && (!Q || !iid_out || !dist_out || !count_out)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
     if (k < 1 || k > MMIDX_K_MAX) return fail(MMIDX_ERR_INVALID_ARG, "k must be in 1..%d (got %d)", MMIDX_K_MAX, k);
+    if (h->grp) return sharded_search(h, k, nq, Q, iid_out, dist_out, count_out);
     int rc = check_ready(h);
     if (rc) return rc;
     if (nq == 0) return MMIDX_OK;
@@ -2077,6 +2170,7 @@ int mmidx_search(mmidx_index *h, int k, int64_t nq, const double *Q, int32_t *ii
 int mmidx_search_sdc(mmidx_index *h, int k, int64_t nq, const int32_t *iids, int32_t *iid_out, double *dist_out, int32_t *count_out) {
     if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
     if (nq > 0 && (!iids || !iid_out || !dist_out || !count_out)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    NOT_ON_SHARDED(h, "mmidx_search_sdc");
     if (h->kind != MMIDX_KIND_PQ) return fail(MMIDX_ERR_UNSUPPORTED, "id queries: IVFPQ.computeKnnIVFSDC is unimplemented in the reference (IVFPQ.java:509-511)");
     if (h->code_bytes != 1) return fail(MMIDX_ERR_UNSUPPORTED, "SDC needs byte codes (the reference dereferences pqByteCodes unconditionally, PQ.java:350)");
     if (k < 1 || k > MMIDX_K_MAX) return fail(MMIDX_ERR_INVALID_ARG, "k must be in 1..%d (got %d)", MMIDX_K_MAX, k);
@@ -2119,6 +2213,7 @@ int mmidx_search_sdc(mmidx_index *h, int k, int64_t nq, const int32_t *iids, int
 }
 
 int mmidx_coarse_device(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells_out, double *d_cdist_out, void *stream) {
+    NOT_ON_SHARDED(h, "mmidx_coarse_device");
     int rc = check_ready(h);
     if (rc) return rc;
     if (h->kind != MMIDX_KIND_IVFPQ) return fail(MMIDX_ERR_INVALID_ARG, "PQ index has no coarse quantizer");
@@ -2151,6 +2246,7 @@ int mmidx_coarse_device(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d
 int mmidx_search_partial_device(mmidx_index *h, int k, int64_t nq, const double *dQ, const int32_t *d_cells, double *d_pdist,
                                 int64_t *d_pkey, int32_t *d_pcount, void *stream) {
     if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    NOT_ON_SHARDED(h, "mmidx_search_partial_device");
     if (nq > 0 && (!dQ || !d_pdist || !d_pkey || !d_pcount)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
     if (h->kind == MMIDX_KIND_IVFPQ && nq > 0 && !d_cells) return fail(MMIDX_ERR_INVALID_ARG, "IVFPQ partial search needs the probe cells");
     hipStream_t st = (hipStream_t)stream;
@@ -2163,6 +2259,7 @@ int mmidx_search_partial_device(mmidx_index *h, int k, int64_t nq, const double 
 static int shard_phase(mmidx_index *h, int k, int64_t nq, const double *dQ, const int32_t *d_cells, const double *d_cdist, int phase,
                        double *d_T, double *d_pdist, int64_t *d_pkey, int32_t *d_pcount, void *stream) {
     if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    NOT_ON_SHARDED(h, "the shard phases");
     if (nq > 0 && (!dQ || !d_T)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
     if (phase == 2 && nq > 0 && (!d_pdist || !d_pkey || !d_pcount)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
     int rc = check_ready(h);
@@ -2208,20 +2305,15 @@ int mmidx_merge_partials_device(int device, int k, int64_t nq, int nshards, cons
     if (mmidx_device_count() < 1) return fail(MMIDX_ERR_NO_DEVICE, "no HIP device: libmmidx_hip has no CPU fallback");
     if (nq == 0) return MMIDX_OK;
     HIPCK(hipSetDevice(device));
-    int mcap = MMIDX_MCAP;  // room for the kept prefix plus at least one more shard's list
-    while (mcap < 2 * (k + 1)) mcap <<= 1;
-    const size_t mlds = (size_t)mcap * 16;
-    HIPCK(hipFuncSetAttribute((const void *)k_merge_partials, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
-    hipLaunchKernelGGL(k_merge_partials, dim3((unsigned)nq), dim3(MMIDX_BLOCK), mlds, (hipStream_t)stream, k, (int)nq, nshards, mcap, d_pdist,
-                       (const long long *)d_pkey, d_pcount, (const long long *)d_poff, d_iid_out, d_dist_out, d_count_out, d_flag_out);
-    HIPCK(hipGetLastError());
-    return MMIDX_OK;
+    return launch_merge_partials(k, nq, nshards, d_pdist, d_pkey, d_pcount, d_poff, d_iid_out, d_dist_out, d_count_out, d_flag_out, nullptr,
+                                 (hipStream_t)stream);
 }
 
 // one pass of the cross-shard tie replay (k_shard_tie); counts / pB / tie_iids are reduced over ranks by the caller in between
 int mmidx_shard_tie_phase_device(mmidx_index *h, int phase, int k, int64_t nf, const double *dQ, const int32_t *d_cells, const int32_t *d_fq,
                                  const double *d_tau, int32_t *d_counts, int32_t *d_pB, int32_t *d_tie_iids, void *stream) {
     if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    NOT_ON_SHARDED(h, "mmidx_shard_tie_phase_device");
     if (phase < 0 || phase > 2 || k < 1 || nf < 0) return fail(MMIDX_ERR_INVALID_ARG, "bad phase / k / count");
     if (nf > 0 && (!dQ || !d_cells || !d_fq || !d_tau || !d_counts || (phase >= 1 && !d_pB) || (phase == 2 && !d_tie_iids)))
         return fail(MMIDX_ERR_INVALID_ARG, "null argument");
@@ -2283,6 +2375,7 @@ int mmidx_shard_tie_phase_device(mmidx_index *h, int phase, int k, int64_t nf, c
 
 int mmidx_assign_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_cell_out, void *stream) {
     if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    NOT_ON_SHARDED(h, "mmidx_assign_device");
     if (h->kind != MMIDX_KIND_IVFPQ) return fail(MMIDX_ERR_INVALID_ARG, "PQ index has no coarse quantizer");
     if (!h->coarse_set) return fail(MMIDX_ERR_NOT_READY, "coarse quantizer not loaded (loadCoarseQuantizer)");
     if (n < 0 || (n > 0 && (!dX || !d_cell_out))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
@@ -2316,6 +2409,7 @@ int mmidx_compact_partials_device(int device, int k, int64_t nq, const double *d
 // runtime switches for measurements (same meaning as the MMIDX_* environment variables read at create)
 int mmidx_set_option(mmidx_index *h, const char *name, int value) {
     if (!h || !name) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (h->grp) return sharded_set_option(h, name, value);
     const std::string n(name);
     if (n == "exhaustive") {  // every probed code is read and summed in fp64: no filter, no coarse bound
         h->no_filter = value != 0;
@@ -2360,6 +2454,7 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
 
 int mmidx_set_profiling(mmidx_index *h, int enabled) {
     if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    if (h->grp) return sharded_for_each(h, [&](mmidx_index *s) { return mmidx_set_profiling(s, enabled); });
     int rc = set_device(h);
     if (rc) return rc;
     HIPCK(hipDeviceSynchronize());
@@ -2378,6 +2473,7 @@ int mmidx_set_profiling(mmidx_index *h, int enabled) {
 // returns the accumulated statistics; the accumulation restarts afterwards.
 int mmidx_get_stats(mmidx_index *h, mmidx_stats *out) {
     if (!h || !out) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (h->grp) return sharded_get_stats(h, out);
     int rc = set_device(h);
     if (rc) return rc;
     mmidx_stats s{};
@@ -2453,7 +2549,7 @@ int ensure_inverse(mmidx_index *h) {
 
 // device lookup of n records: d_pos[n], d_code[n][m] (stored form); host cells from the list offsets
 int lookup_records(mmidx_index *h, int64_t n, const int32_t *iids, int32_t **d_pos_out, void **d_code_out, std::vector<int32_t> &pos,
-                   std::vector<int32_t> &cells) {
+                   std::vector<int32_t> &cells, bool allow_missing = false) {
     int rc = build_csr(h);
     if (rc) return rc;
     rc = ensure_inverse(h);
@@ -2493,6 +2589,7 @@ int lookup_records(mmidx_index *h, int64_t n, const int32_t *iids, int32_t **d_p
     }
     for (int64_t i = 0; i < n; i++) {
         if (pos[(size_t)i] < 0) {
+            if (allow_missing) continue;  // (a shard of a sharded handle: the id lives on another shard)
             cleanup();
             return fail(MMIDX_ERR_INVALID_ARG, "Id does not exist!");  // IVFPQ.java:803-805, :868-870
         }
@@ -2521,6 +2618,7 @@ int mmidx_get_codes(mmidx_index *h, int64_t n, const int32_t *iids, int32_t *cel
     if (!h || (n > 0 && !iids)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
     if (n < 0) return fail(MMIDX_ERR_INVALID_ARG, "n < 0");
     if (n == 0) return MMIDX_OK;
+    if (h->grp) return sharded_get_codes(h, n, iids, cell_out, code_out);
     int rc = set_device(h);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(h->mu);
@@ -2542,6 +2640,7 @@ int mmidx_get_codes(mmidx_index *h, int64_t n, const int32_t *iids, int32_t *cel
 int mmidx_distance(mmidx_index *h, int64_t n, const double *Q, const int32_t *iids, double *dist_out) {
     if (!h || (n > 0 && (!Q || !iids || !dist_out))) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
     if (n < 0) return fail(MMIDX_ERR_INVALID_ARG, "n < 0");
+    if (h->grp) return n == 0 ? MMIDX_OK : sharded_distance(h, n, Q, iids, dist_out);
     int rc = check_ready(h);
     if (rc) return rc;
     if (n == 0) return MMIDX_OK;
@@ -2594,6 +2693,7 @@ int mmidx_distance(mmidx_index *h, int64_t n, const double *Q, const int32_t *ii
 /* snapshot of the in-memory index, list-major (the layout loadIndexInMemory builds) */
 int mmidx_export(mmidx_index *h, int64_t *list_off_out, int32_t *iids_out, void *codes_out) {
     if (!h || !list_off_out) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (h->grp) return sharded_export(h, list_off_out, iids_out, codes_out);
     int rc = mmidx_sync_index(h);
     if (rc) return rc;
     for (int c = 0; c <= h->nlists; c++) list_off_out[c] = h->h_off[(size_t)c];
@@ -3035,3 +3135,5 @@ int mmidx_linear_search(mmidx_linear *l, int k, int64_t nq, const double *Q, int
 }
 
 }  // extern "C"
+
+#include "mmidx_sharded.h"

@@ -3441,6 +3441,11 @@ __global__ void k_pair_scatter(const int32_t *__restrict__ cells, int w, int ran
 #define MMIDX_MCAP 2048  // smallest K5 buffer (entries); the host doubles it until it exceeds 2 (k + 1)
 #define MMIDX_K_MAX 4095  // largest k: the candidate buffers (pow2 >= k + 1 + segment) and the merge buffers (pow2 >= 2 (k + 1)) must fit
                           // the 160 KiB LDS next to the lookup table
+struct ShardDest {
+    double *pd;
+    long long *pk;
+    int32_t *pc;
+};
 struct MergeParams {
     const u64 *T;            // [nq] final thresholds (null: no filtering)
     const u32 *pool_cnt;
@@ -3458,6 +3463,12 @@ struct MergeParams {
     int32_t *flag_out;       // [nq] tie straddles k (mode 0)
     double *pdist;           // [nq][k+1] (mode 1)
     long long *pkey;         // [nq][k+1]
+    // mode 1 inside a sharded handle (mmidx_create_sharded): query q belongs to shard q / dest_per, and its partial list goes
+    // straight into THAT shard's receive buffers -- dest[o].pd / .pk laid out [n_shards][dest_per][k+1], dest[o].pc
+    // [n_shards][dest_per], row (dest_me, q % dest_per) -- by stores over xGMI (peer access; the same device for virtual
+    // shards).  Only the valid entries travel.  dest == null: the dense local arrays above.
+    const ShardDest *dest;
+    int dest_per, dest_me;
 };
 
 // NT = threads per block: 128 when k + 1 <= 128 (the survivors fit one per thread and twice as many queries are in
@@ -3479,8 +3490,25 @@ __global__ __launch_bounds__(NT) void k_merge(const MergeParams P) {
     // Entries above the query's final threshold cannot be among the K1 best (at least K1 candidates are at or
     // below it): drop them while loading.  What is left is K1 plus a few entries, small enough to be ordered
     // by counting ranks -- one pass of broadcast LDS reads, no 36-stage sorting network.
+    // where this query's partial list goes (mode 1): the local dense arrays, or the owner shard's receive buffers
+    double *o_pd = P.pdist;
+    long long *o_pk = P.pkey;
+    int32_t *o_pc = P.count_out + q;
+    if (P.mode == 1) {
+        size_t row = (size_t)q * K1;
+        if (P.dest) {
+            const int o = q / P.dest_per, ql = q - o * P.dest_per;
+            const ShardDest d = P.dest[o];
+            row = ((size_t)P.dest_me * P.dest_per + ql) * K1;
+            o_pd = d.pd;
+            o_pk = d.pk;
+            o_pc = d.pc + (size_t)P.dest_me * P.dest_per + ql;
+        }
+        o_pd += row;
+        o_pk += row;
+    }
     if (n == 0 && P.mode == 1) {  // nothing on this shard for this query (the usual case for most queries of a rank):
-        if (tid == 0) P.count_out[q] = 0;  // the merge reads count entries, the list itself stays unwritten
+        if (tid == 0) *o_pc = 0;  // the merge reads count entries, the list itself stays unwritten
         return;
     }
     const u64 T = P.T ? __hip_atomic_load(P.T + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : MMIDX_KEY_MAX;
@@ -3581,7 +3609,8 @@ __global__ __launch_bounds__(NT) void k_merge(const MergeParams P) {
     const int total = kept;  // min(n, K1), sorted by (key, offer order)
     const int cnt = total < P.k ? total : P.k;
     if (P.mode == 1) {
-        for (int i = tid; i < K1; i += NT) {
+        const int nwrite = P.dest ? total : K1;  // (over xGMI only what the merge will read)
+        for (int i = tid; i < nwrite; i += NT) {
             double dd = __longlong_as_double(0x7FF0000000000000ll);
             long long kk = -1;
             if (i < total) {
@@ -3592,10 +3621,10 @@ __global__ __launch_bounds__(NT) void k_merge(const MergeParams P) {
                 dd = keyd(key[i]);
                 kk = (long long)(((u64)rank << 32) | (u32)iid);
             }
-            P.pdist[(size_t)q * K1 + i] = dd;
-            P.pkey[(size_t)q * K1 + i] = kk;
+            o_pd[i] = dd;
+            o_pk[i] = kk;
         }
-        if (tid == 0) P.count_out[q] = total;
+        if (tid == 0) *o_pc = total;
         return;
     }
     for (int i = tid; i < P.k; i += NT) {
@@ -3628,13 +3657,17 @@ __global__ __launch_bounds__(NT) void k_merge(const MergeParams P) {
 // across shards is (probe_rank, iid): inside one inverted list the reference appends in iid order
 // (IVFPQ.java:339, :699-700), so this equals the single-queue offer order.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MMIDX_BLOCK) void k_merge_partials(int k, int nq, int nshards, int mcap,
-                                                                const double *__restrict__ pdist,
-                                                                const long long *__restrict__ pkey,
-                                                                const int32_t *__restrict__ pcount,
-                                                                const long long *__restrict__ poff,
-                                                                int32_t *iid_out, double *dist_out,
-                                                                int32_t *count_out, int32_t *flag_out) {
+// NT = threads per block: 128 when everything of a query fits one entry per thread (as in K4), else 256.
+// nflag_out (may be null): number of flagged queries of the launch (what the sharded handle reads back to decide
+// whether the tie replay has to run).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_merge_partials(int k, int nq, int nshards, int mcap,
+                                                       const double *__restrict__ pdist,
+                                                       const long long *__restrict__ pkey,
+                                                       const int32_t *__restrict__ pcount,
+                                                       const long long *__restrict__ poff,
+                                                       int32_t *iid_out, double *dist_out,
+                                                       int32_t *count_out, int32_t *flag_out, int32_t *nflag_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64 *key = (u64 *)smem;
     u64 *val = key + mcap;
@@ -3650,14 +3683,14 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_merge_partials(int k, int nq, i
             if (filled + c > mcap) break;
             // dense [nshards][nq][K1] or, with poff, ragged: list (s, q) starts at poff[s * nq + q]
             const size_t base = poff ? (size_t)poff[(size_t)s * nq + q] : ((size_t)s * nq + q) * K1;
-            for (int i = tid; i < c; i += MMIDX_BLOCK) {
+            for (int i = tid; i < c; i += NT) {
                 key[filled + i] = dkey(pdist[base + i]);
                 val[filled + i] = (u64)pkey[base + i];
             }
             filled += c;
             s++;
         }
-        if (kept == 0 && s == nshards && filled <= MMIDX_BLOCK) {
+        if (kept == 0 && s == nshards && filled <= NT) {
             // the usual case (phase 2 drops everything above the global threshold: about k + 1 entries over all
             // shards): one entry per thread, ordered by counting ranks as in K4 -- keys only unless a wave sees a tie
             __syncthreads();
@@ -3684,7 +3717,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_merge_partials(int k, int nq, i
             __syncthreads();
         } else {
             const int Pn = pow2ceil(filled < 2 ? 2 : filled);
-            for (int i = filled + tid; i < Pn; i += MMIDX_BLOCK) {
+            for (int i = filled + tid; i < Pn; i += NT) {
                 key[i] = MMIDX_KEY_MAX;
                 val[i] = MMIDX_KEY_MAX;
             }
@@ -3693,7 +3726,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_merge_partials(int k, int nq, i
         kept = filled < K1 ? filled : K1;
     }
     const int cnt = kept < k ? kept : k;
-    for (int i = tid; i < k; i += MMIDX_BLOCK) {
+    for (int i = tid; i < k; i += NT) {
         int iid = -1;
         double dd = __longlong_as_double(0x7FF0000000000000ll);
         if (i < cnt) {
@@ -3711,7 +3744,9 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_merge_partials(int k, int nq, i
         count_out[q] = cnt;
         // a tie that straddles position k: the bounded queue's replay decides which of the equal candidates stay
         // (mmidx_shard_tie_phase_device); everything strictly better than the k-th distance is already final
-        if (flag_out) flag_out[q] = (kept > k && key[k - 1] == key[k]) ? 1 : 0;
+        const int fl = (kept > k && key[k - 1] == key[k]) ? 1 : 0;
+        if (flag_out) flag_out[q] = fl;
+        if (fl && nflag_out) atomicAdd(nflag_out, 1);
     }
 }
 

@@ -194,8 +194,16 @@ class _PQBase(AbstractSearchStructure):
         if rot is not None:
             self._rot = _f64(rot)
             rp = self._rot.ctypes.data
-        N.check(L.mmidx_create(self._kind, self.vectorLength, numSubVectors, numProductCentroids, numCoarseCentroids,
-                               transformation, pp, rp, device, C.byref(h)))
+        devices = getattr(self, "_devices", None)
+        if devices is not None:
+            # one index over several GPUs from this one process (mmidx_create_sharded; the Java form is -Dmmidx.devices=0,1,...)
+            N.preload_rccl()
+            self._devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+            N.check(L.mmidx_create_sharded(self._kind, self.vectorLength, numSubVectors, numProductCentroids, numCoarseCentroids,
+                                           transformation, pp, rp, len(devices), self._devs, C.byref(h)))
+        else:
+            N.check(L.mmidx_create(self._kind, self.vectorLength, numSubVectors, numProductCentroids, numCoarseCentroids,
+                                   transformation, pp, rp, device, C.byref(h)))
         self._h = h
         self.subVectorLength = self.vectorLength // numSubVectors
         self._code_dtype = np.int8 if numProductCentroids <= 256 else np.int16
@@ -411,8 +419,10 @@ class IVFPQ(_PQBase):
     _kind = N.KIND_IVFPQ
 
     def __init__(self, vectorLength, maxNumVectors, readOnly, BDBEnvHome, numSubVectors, numProductCentroids,
-                 transformation, numCoarseCentroids, *rest, device=0, perm=None, rot=None):
-        # IVFPQ.java:174-177 (12 args) and :261-263 (9 args: ..., cacheSize)
+                 transformation, numCoarseCentroids, *rest, device=0, perm=None, rot=None, devices=None):
+        # IVFPQ.java:174-177 (12 args) and :261-263 (9 args: ..., cacheSize); devices = [0, 1, ...]: the inverted lists are
+        # partitioned over these GPUs (a device listed twice = virtual shards: tests on a one-GPU box)
+        self._devices = list(devices) if devices is not None else None
         if len(rest) == 1:
             countSizeOnLoad, loadCounter, loadIndexInMemory, cacheSize = True, 0, True, rest[0]
         elif len(rest) == 4:
