@@ -18,11 +18,17 @@ bound removes 31 of the 32 probes):
   `cpu_baseline`  the CPU oracle (a C restatement of the Java reference, kind "port") on this host's cores;
   `other_configs` BASELINE configs 1-3 at their stated sizes (tests/bench_configs.py), parity-gated.
 
-N > 1: one process per GPU; inverted lists are partitioned whole-list across ranks (cell mod N), the coarse assignment is
-split across ranks and all-gathered, the per-shard top-(k+1) lists are sent to the query's owner rank (RCCL all-to-all
-over xGMI) and merged there.  The index is the same 100M vectors for every N; the query batch per step is `--batch` x N
-(each rank scans its 1/N of the lists for N x as many queries), so the work per GPU per step is fixed and the scaling
-reported is "weak"; `--global-batch B` pins the batch instead ("strong").
+N > 1: ONE process drives all N GPUs through the library's own sharded handle (mmidx_create_sharded, include/mmidx.h: one
+host thread and one RCCL communicator per device inside libmmidx_hip.so) -- the shape of the reference's caller, a single
+JVM holding the whole index (YFCC100MExample.java:93-99).  Under `torch.distributed.run --nproc-per-node N` rank 0 is that
+process and the other ranks wait for it; should the native handle fail to come up, all ranks fall back to the older
+one-process-per-GPU path over torch.distributed (`--torch-dist` selects it outright), and the JSON line says which ran.
+Inverted lists are partitioned whole-list across shards (cell mod N), every shard owns 1/N of the step's queries (their
+vectors and probe cells are all-gathered, thresholds MIN-all-reduced, per-shard top-(k+1) lists stored into the owner's HBM
+over xGMI and merged there).  The index is the same 100M vectors for every N; the query batch per step is `--batch` x N
+(each GPU scans its 1/N of the lists for N x as many queries), so the work per GPU per step is fixed and the scaling
+reported is "weak"; `--global-batch B` pins the batch instead ("strong").  `--native-sharded` runs the sharded handle with
+N = 1 too (one shard, a 1-rank RCCL communicator): what the multi-GPU machinery costs on one device.
 """
 import argparse
 import ctypes as C
@@ -110,15 +116,69 @@ def learn_codebooks(cx, sigma):
     return mu, coarse_h.copy(), pq.cpu().numpy()
 
 
-def gen_chunk(cx, mu, sigma, c0, n):
-    """base vectors [c0, c0 + n): component g ~ U(cells), vector = mu_g + sigma N(0, I) (regenerable from the chunk seed)"""
+def gen_chunk(cx, mu, sigma, c0, n, dev=None):
+    """base vectors [c0, c0 + n): component g ~ U(cells), vector = mu_g + sigma N(0, I) (regenerable from the chunk seed;
+    the Philox stream of a seed is the same on every device)"""
     torch = cx.torch
-    gc = torch.Generator(device=cx.dev)
+    dev = cx.dev if dev is None else dev
+    gc = torch.Generator(device=dev)
     gc.manual_seed(10_000 + c0 // cx.args.chunk)
-    g = torch.randint(0, cx.args.cells, (n,), generator=gc, device=cx.dev)
+    g = torch.randint(0, cx.args.cells, (n,), generator=gc, device=dev)
     X = mu[g]
-    X += sigma * torch.randn(n, cx.args.dim, generator=gc, device=cx.dev, dtype=torch.float64)
+    X += sigma * torch.randn(n, cx.args.dim, generator=gc, device=dev, dtype=torch.float64)
     return X
+
+
+def build_index_native(cx, mu, sigma, coarse_h, pq_h, nq_total, ndev):
+    """The sharded handle over devices 0 .. ndev-1, built from this one process: in every round device r generates chunk
+    round0 + r and hands it in as slice r (mmidx_add_vectors_sliced_device: encoded where it lies, records routed to the shard
+    that owns their list, iids in batch order -> the same index as the single-GPU build).  Returns (handle, queries on device 0)."""
+    torch, a, L, nat = cx.torch, cx.args, cx.L, cx.nat
+    N, D, Cc, m = a.n, a.dim, a.cells, a.m
+    nat.preload_rccl()
+    h = C.c_void_p()
+    devs = (C.c_int * ndev)(*range(ndev))
+    cx.chk(L.mmidx_create_sharded(nat.KIND_IVFPQ, D, m, 256, Cc, 0, None, None, ndev, devs, C.byref(h)))
+    cx.chk(L.mmidx_set_coarse(h, coarse_h.ctypes.data))
+    cx.chk(L.mmidx_set_pq(h, pq_h.ctypes.data))
+    cx.chk(L.mmidx_set_w(h, a.w))
+    for o_ in a.opt:
+        name_, val_ = o_.split("=")
+        cx.chk(L.mmidx_set_option(h, name_.encode(), int(val_)))
+    gq = torch.Generator(device=cx.dev)
+    gq.manual_seed(4321)
+    qsrc = torch.randint(0, N, (nq_total,), generator=gq, device=cx.dev)
+    Qsrc = torch.zeros(nq_total, D, device=cx.dev, dtype=torch.float64)
+    mus = [mu.to(torch.device("cuda", r)) for r in range(ndev)]
+    t0 = time.time()
+    t_enc = 0.0
+    nchunks = (N + a.chunk - 1) // a.chunk
+    for round0 in range(0, nchunks, ndev):
+        Xs, ns = [], []
+        for r in range(ndev):
+            ci = round0 + r
+            c0 = ci * a.chunk
+            n = max(0, min(a.chunk, N - c0)) if ci < nchunks else 0
+            dv = torch.device("cuda", r)
+            X = gen_chunk(cx, mus[r], sigma, c0, n, dv) if n > 0 else torch.empty(0, D, device=dv, dtype=torch.float64)
+            if n > 0:
+                sel = (qsrc >= c0) & (qsrc < c0 + n)
+                if sel.any():
+                    Qsrc[sel] = X[(qsrc[sel] - c0).to(dv)].to(cx.dev)
+            Xs.append(X)
+            ns.append(n)
+        for r in range(ndev):
+            torch.cuda.synchronize(r)
+        te = time.time()
+        cx.chk(L.mmidx_add_vectors_sliced_device(h, (C.c_int64 * ndev)(*ns), (C.c_void_p * ndev)(*[x.data_ptr() for x in Xs]),
+                                                 round0 * a.chunk))
+        t_enc += time.time() - te
+        del Xs
+    cx.chk(L.mmidx_sync_index(h))
+    log(f"index (sigma {sigma}) built on {ndev} device(s) through the sharded handle: {N} vectors in {time.time() - t0:.1f}s "
+        f"(encode + route + append {t_enc:.1f}s)")
+    Q = Qsrc + 0.01 * torch.randn(nq_total, D, generator=gq, device=cx.dev, dtype=torch.float64)
+    return h, Q
 
 
 def build_index(cx, mu, sigma, coarse_h, pq_h, nq_total, sharded_build):
@@ -317,6 +377,11 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
                     help="mmidx_set_option(NAME, INT) on the index before the timed steps (kernel A/B switches)")
     ap.add_argument("--dump", default="", metavar="PREFIX", help="write batch 0's answers of every rank to PREFIX.rank<r>.npz")
+    ap.add_argument("--native-sharded", action="store_true",
+                    help="drive the library's own sharded handle (mmidx_create_sharded: worker threads + RCCL inside libmmidx_hip.so) "
+                         "from this one process; the default for --gpus > 1, with --gpus 1 it measures one shard on a 1-rank communicator")
+    ap.add_argument("--torch-dist", action="store_true",
+                    help="--gpus > 1: the one-process-per-GPU path over torch.distributed (multimedia-indexing_amd/sharded.py) instead")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path (encode -> owner filter -> add_codes, two-phase shard search, "
                          "merge) even with one rank: exercises it on a single GPU")
@@ -345,10 +410,14 @@ def main():
     # a functional run of the N > 1 path on a one-GPU box (RCCL refuses two ranks on one device); never a measurement
     one_gpu = os.environ.get("MMIDX_BENCH_ONE_GPU") == "1"
     cx.local = local = 0 if one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
+    # N > 1: rank 0 drives all N devices through the library's sharded handle; the other ranks wait for its verdict
+    # (a plain `python bench.py --gpus N` without torch.distributed.run works as well: there is only that one process)
+    native = (args.native_sharded or args.gpus > 1) and not args.torch_dist and not args.force_sharded and not one_gpu
+    if args.gpus > 1 and world != args.gpus and not (native and world == 1):
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local)
-    cx.dev = dev = torch.device("cuda", local)
+    ndev = args.gpus if native else 1
+    if native and torch.cuda.device_count() < ndev:
+        raise SystemExit(f"--gpus {ndev} through the native sharded handle needs {ndev} visible devices, this process sees {torch.cuda.device_count()}")
     dist = None
     if world > 1 or (args.force_sharded and "MASTER_ADDR" in os.environ):
         # (--force-sharded under torch.distributed.run with one rank: the RCCL calls run on a 1-rank group)
@@ -357,8 +426,38 @@ def main():
         if one_gpu:
             dist.init_process_group("gloo")
             dist = importlib.import_module("multimedia-indexing_amd.sharded").HostStagedDist(dist)
+        elif native:
+            # gloo for the verdict below (CPU tensors); RCCL comes up lazily, only if the ranks have to fall back
+            dist.init_process_group("cpu:gloo,cuda:nccl")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    fallback_reason = None
+    if native and world > 1:
+        verdict = torch.zeros(1, dtype=torch.int32)
+        if rank == 0:
+            try:
+                run(cx, args, json_out, native=True, ndev=ndev, dist=None, rank=0, world=1, local=0)
+                verdict[0] = 1
+            except BaseException as e:  # noqa: BLE001 -- whatever went wrong, the other ranks must hear about it
+                fallback_reason = repr(e)
+                log(f"native sharded handle failed ({fallback_reason}): falling back to the torch.distributed path")
+        dist.broadcast(verdict, src=0)
+        if int(verdict[0]) == 1:
+            dist.barrier()
+            dist.destroy_process_group()
+            return
+        native = False
+    run(cx, args, json_out, native=native, ndev=ndev, dist=dist, rank=rank, world=world, local=local, fallback_reason=fallback_reason)
+
+
+def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_reason=None):
+    torch, L, nat, chk = cx.torch, cx.L, cx.nat, cx.chk
+    one_gpu = os.environ.get("MMIDX_BENCH_ONE_GPU") == "1"
+    cx.rank, cx.world, cx.local = rank, world, local
+    if native:
+        world = ndev  # (one process, ndev shards: B, per_rank and the roofline are per device all the same)
+    torch.cuda.set_device(local)
+    cx.dev = dev = torch.device("cuda", local)
     cx.dist = dist
 
     N, D, Cc, w, m, k = args.n, args.dim, args.cells, args.w, args.m, args.k
@@ -367,13 +466,16 @@ def main():
     ks = 256
     f64 = torch.float64
     cx.stream = stream = torch.cuda.current_stream().cuda_stream
-    single = world == 1 and not args.force_sharded
+    single = world == 1 and not args.force_sharded and not native
 
     # ---------------------------------------------------------------- headline workload
     mu, coarse_h, pq_h = learn_codebooks(cx, args.sigma)
     coarse_h, pq_h = same_codebooks(cx, coarse_h, pq_h)
     nq_total = B * args.nbatches
-    h, Q = build_index(cx, mu, args.sigma, coarse_h, pq_h, nq_total, sharded_build=not single)
+    if native:
+        h, Q = build_index_native(cx, mu, args.sigma, coarse_h, pq_h, nq_total, ndev)
+    else:
+        h, Q = build_index(cx, mu, args.sigma, coarse_h, pq_h, nq_total, sharded_build=not single)
     Qb = [Q[i * B:(i + 1) * B].contiguous() for i in range(args.nbatches)]
     ngt = min(args.gt, B)
     gt_arg = ground_truth(cx, mu, args.sigma, Qb[0][:ngt]) if rank == 0 and ngt > 0 else None
@@ -383,13 +485,27 @@ def main():
     cnt_out = torch.empty(B, dtype=torch.int32, device=dev)
     sharded = None
     per_rank = B // world
-    if not single:
+    nslices = None
+    if native:
+        # every shard's slice of every batch, and its answers, resident in that shard's HBM before the clock starts
+        dvs = [torch.device("cuda", r) for r in range(ndev)]
+        nslices = [[Qx[r * per_rank:(r + 1) * per_rank].to(dvs[r]).contiguous() for r in range(ndev)] for Qx in Qb]
+        n_iid = [torch.empty(per_rank, k, dtype=torch.int32, device=dvs[r]) for r in range(ndev)]
+        n_dist = [torch.empty(per_rank, k, dtype=f64, device=dvs[r]) for r in range(ndev)]
+        n_cnt = [torch.empty(per_rank, dtype=torch.int32, device=dvs[r]) for r in range(ndev)]
+        parr = lambda ts: (C.c_void_p * ndev)(*[t.data_ptr() for t in ts])
+        n_args = (parr(n_iid), parr(n_dist), parr(n_cnt))
+        n_q = {id(Qx): parr(sl) for Qx, sl in zip(Qb, nslices)}
+    if not single and not native:
         sh = importlib.import_module("multimedia-indexing_amd.sharded")
         sharded = sh.ShardedIVFPQ(sh.HipShardEngine(h, D, w, local), rank, world, dist=dist, force_collectives=args.force_sharded,
                                   tie_slots=int(os.environ.get("MMIDX_SHARD_TIE_SLOTS", "32")),
                                   pipeline={"0": False, "1": True}.get(os.environ.get("MMIDX_SHARD_PIPELINE", ""), None))
 
     def step(Qx, hh=None):
+        if native and hh is None:
+            chk(L.mmidx_search_sliced_device(h, k, per_rank, n_q[id(Qx)], n_args[0], n_args[1], n_args[2]))
+            return
         if sharded is None or hh is not None:
             chk(L.mmidx_search_device(hh if hh is not None else h, k, B, Qx.data_ptr(), iid_out.data_ptr(), dist_out.data_ptr(),
                                       cnt_out.data_ptr(), stream))
@@ -402,10 +518,20 @@ def main():
         cnt_out[:i_.shape[0]].copy_(c_)
 
     def barrier():
-        torch.cuda.synchronize()
+        for r in range(ndev if native else 1):
+            torch.cuda.synchronize(r if native else None)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def gather_native():
+        """the native handle's answers (slices on the shards' devices) into the result tensors on device 0"""
+        if native:
+            for r in range(ndev):
+                iid_out[r * per_rank:(r + 1) * per_rank].copy_(n_iid[r])
+                dist_out[r * per_rank:(r + 1) * per_rank].copy_(n_dist[r])
+                cnt_out[r * per_rank:(r + 1) * per_rank].copy_(n_cnt[r])
+            torch.cuda.synchronize()
 
     # settle the device before the W warm-up steps the caller asked for (clocks, caches, the pass-B launch hint): with a
     # small W the first timed steps otherwise run ~10 % slower than the steady state
@@ -444,6 +570,7 @@ def main():
     if args.dump:  # the answers of batch 0 as this rank holds them (its B / N queries): compared across world sizes by the tests
         step(Qb[0])
         barrier()
+        gather_native()
         n_own = B if sharded is None else per_rank
         np.savez(f"{args.dump}.rank{rank}.npz", iid=iid_out[:n_own].cpu().numpy(), dist=dist_out[:n_own].cpu().numpy(),
                  cnt=cnt_out[:n_own].cpu().numpy())
@@ -451,7 +578,7 @@ def main():
     # the same steps with every exact shortcut switched off (each probed code read and summed in fp64):
     # the configuration on which the exact scan kernel's HBM roofline fraction is a meaningful figure
     exhaustive = None
-    if sharded is None and args.exhaustive_steps > 0:
+    if single and args.exhaustive_steps > 0:
         chk(L.mmidx_set_option(h, b"exhaustive", 1))
         step(Qb[0])
         barrier()
@@ -474,7 +601,8 @@ def main():
 
     # recall@1 and results of batch 0 (for the parity gate)
     step(Qb[0])
-    torch.cuda.synchronize()
+    barrier()
+    gather_native()
     res_iid = iid_out.cpu().numpy().copy()
     res_dist = dist_out.cpu().numpy().copy()
     recall1 = None
@@ -505,6 +633,8 @@ def main():
     # HBM roofline fraction: the kernel is bound by the LDS gather and the VALU work around it, not by HBM.
     pa_ms = st_light.passa_ms / max(1, st_light.passa_launches)  # (timed region)
     pa_bytes = float(m) * st.passa_codes / max(1, st.passa_launches)  # (per launch; the detail run covers the same batches)
+    if native:
+        pa_bytes /= ndev  # (stats of a sharded handle: times = the slowest shard, code counts = the sum over shards -> per device)
     pa_ach = pa_bytes / (pa_ms * 1e-3) / 1e9 if pa_ms > 0 else 0.0
     if sharded is None and st.passa_launches > 0:
         roofline = {"bound": "hbm", "kernel": "k_scan_hist (pass A: the exact scan of every query's nearest list; the launch also "
@@ -536,14 +666,15 @@ def main():
     # ---------------------------------------------------------------- CPU baseline + parity gate (headline index)
     cpu_baseline, parity = None, None
     cores, logical, quota, cpu_model = usable_cpus()
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and (world == 1 or native) and not args.no_cpu:
         t0 = time.time()
         ref = oracle_of_index(cx, h, coarse_h, pq_h)
         Qh = Qb[0].cpu().numpy()
         tc = time.perf_counter()
         ref.search_batch(Qh[:cores], k, nthreads=cores)  # calibration
         per_round = max(time.perf_counter() - tc, 1e-4)
-        nsamp = int(min(B, max(cores, cores * int(args.cpu_seconds / per_round))))
+        # (the CPU baseline is an N = 1 figure; with more devices the oracle only serves the parity gate, on a short sample)
+        nsamp = int(min(B, max(cores, cores * int((args.cpu_seconds if world == 1 else 3.0) / per_round))))
         tc = time.perf_counter()
         rid, rd, rc = ref.search_batch(Qh[:nsamp], k, nthreads=cores)
         cpu_t = time.perf_counter() - tc
@@ -662,9 +793,17 @@ def main():
             "config": {"workload": f"IVFPQ {N}x{D}-d, {Cc} coarse cells, nprobe w={w}, m={m}x{ks}, k={k}, batch {B} queries/step",
                        "n": N, "dim": D, "cells": Cc, "nprobe": w, "m": m, "ks": ks, "k": k, "batch": B, "batch_per_gpu": B // world,
                        "mixture_sigma": args.sigma,
-                       "sharding": "single GPU" if world == 1 else f"whole inverted lists, cell mod {world}; every rank owns batch/{world} queries; RCCL per step: all-gather "
-                                                                      f"query vectors + probe cells, MIN all-reduce thresholds, one variable-size all-to-all of partial "
-                                                                      f"top-k entries to the query's owner, merge + cross-shard tie replay there"},
+                       "multi_gpu_path": ("native sharded handle (mmidx_create_sharded): one process, one host thread + one RCCL communicator per device "
+                                          "inside libmmidx_hip.so" if native else
+                                          ("none" if world == 1 and not args.force_sharded else "torch.distributed, one process per GPU (multimedia-indexing_amd/sharded.py)")),
+                       "native_fallback_reason": fallback_reason,
+                       "sharding": "single GPU" if world == 1 and not native else
+                                   (f"whole inverted lists, cell mod {world}; every shard owns batch/{world} queries; per step: RCCL all-gather of query vectors + probe "
+                                    f"cells, RCCL MIN all-reduce of thresholds, partial top-(k+1) lists stored into the owner's HBM over xGMI (peer access), merge + "
+                                    f"cross-shard tie replay (RCCL all-reduces) there" if native else
+                                    f"whole inverted lists, cell mod {world}; every rank owns batch/{world} queries; RCCL per step: all-gather "
+                                    f"query vectors + probe cells, MIN all-reduce thresholds, one variable-size all-to-all of partial "
+                                    f"top-k entries to the query's owner, merge + cross-shard tie replay there")},
             "recall_at_1": recall1, "recall_queries": ngt,
             "roofline": roofline, "roofline_whole_search": whole, "roofline_exhaustive": exhaustive,
             "cpu_baseline": cpu_baseline, "parity": parity, "hard": hard, "other_configs": other,

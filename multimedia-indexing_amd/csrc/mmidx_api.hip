@@ -753,27 +753,35 @@ int launch_hist_nt(const ScanParams &P, dim3 grid, size_t lds, hipStream_t st) {
 
 template <int M>
 int launch_hist_t(const ScanParams &P, dim3 grid, size_t lds, hipStream_t st, bool wide) {
-    if (P.ks == 256) return wide ? launch_hist_nt<M, 256, 512>(P, grid, lds, st) : launch_hist_nt<M, 256, 256>(P, grid, lds, st);
-    return wide ? launch_hist_nt<M, 0, 512>(P, grid, lds, st) : launch_hist_nt<M, 0, 256>(P, grid, lds, st);
+    if constexpr (M == 64) {  // 128 KiB of table: one block per CU, sixteen waves
+        if (P.ks == 256) return launch_hist_nt<M, 256, 1024>(P, grid, lds, st);
+        return launch_hist_nt<M, 0, 1024>(P, grid, lds, st);
+    } else {
+        if (P.ks == 256) return wide ? launch_hist_nt<M, 256, 512>(P, grid, lds, st) : launch_hist_nt<M, 256, 256>(P, grid, lds, st);
+        return wide ? launch_hist_nt<M, 0, 512>(P, grid, lds, st) : launch_hist_nt<M, 0, 256>(P, grid, lds, st);
+    }
 }
 
 // pass A over long lists: histogram-thresholded exact scan (K3h) + a K3 launch over the items it hands back.
 // Returns 1 when K3h does not apply (the caller uses K3).
 int launch_scan_hist(mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 grid, hipStream_t st) {
-    const bool ok = h->code_bytes == 1 && (h->m == 8 || h->m == 16 || h->m == 32) && !P.sdc_tt && pl.K1 <= MMIDX_HKEEP &&
+    const bool ok = h->code_bytes == 1 && (h->m == 8 || h->m == 16 || h->m == 32 || h->m == 64) && !P.sdc_tt && pl.K1 <= MMIDX_HKEEP &&
                     !P.order && !P.xcd_remap && pl.chunk <= (1 << 24);
     if (!ok) return 1;
     // a shard (at most half of the lists live here): launch over the queries whose nearest list is non-empty only
     const bool compact_items = P.ivf && P.nrank == 1 && P.rank_lo == 0 && grid.y == 1 && !h->no_item_compaction &&
                                h->nonempty_lists * 2 <= (int64_t)h->C && (int64_t)grid.x >= (int64_t)h->passa_item_min;
-    const size_t fixed = (size_t)h->m * h->ks * 8 + (h->transform ? 2 : 1) * (size_t)h->D * 8 + 128 + 16 + MMIDX_HB * 4 + 48;
-    // 256 threads: four blocks per CU; 512 threads (option "passa_wide"): three, six waves per SIMD
+    const size_t fixed = (size_t)h->m * h->ks * 8 + (h->transform ? 2 : 1) * (size_t)h->D * 8 + 2 * MMIDX_HWV * 8 + 16 + MMIDX_HB * 4 + MMIDX_HCNT * 4;
+    // 256 threads: four blocks per CU; 512 threads (option "passa_wide"): three, six waves per SIMD; m = 64 (the reference's
+    // flagship shape, YFCC100MExample.java:85-90: 64 x 256 doubles = 128 KiB of table): ONE block of 1024 threads per CU --
+    // the same sixteen waves per CU over one table instead of four
     const bool wide = h->passa_wide != 0;
+    const bool whole_cu = h->m == 64;
     // position buffer: what is left of the block's share of the CU's LDS, within [768, 4096] entries
-    int64_t room = (int64_t)(160 * 1024 / (wide ? 3 : 4)) - 256 - (int64_t)fixed;
-    int cap = (int)std::min<int64_t>(4096, std::max<int64_t>(768, room / 4)) & ~7;  // an equal share per wave
+    int64_t room = (int64_t)(160 * 1024 / (whole_cu ? 1 : (wide ? 3 : 4))) - 256 - (int64_t)fixed;
+    int cap = (int)std::min<int64_t>(4096, std::max<int64_t>(768, room / 4)) & ~15;  // an equal share per wave
     const size_t lds = fixed + (size_t)cap * 4;
-    if (lds > 64 * 1024) return 1;
+    if (lds > (whole_cu ? 160 * 1024 : 64 * 1024)) return 1;
     const size_t nfb = (size_t)grid.x * grid.y;
     if (h->ws_fb.cap < 2 * nfb + 4) {  // (search_batch_device reserves and zeroes the header; a direct caller would land here)
         HIPCK(h->ws_fb.reserve(2 * nfb + 4));
@@ -802,6 +810,7 @@ int launch_scan_hist(mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 gr
     switch (h->m) {
         case 8: rc = launch_hist_t<8>(P, grid, lds, st, wide); break;
         case 16: rc = launch_hist_t<16>(P, grid, lds, st, wide); break;
+        case 64: rc = launch_hist_t<64>(P, grid, lds, st, wide); break;
         default: rc = launch_hist_t<32>(P, grid, lds, st, wide); break;
     }
     if (rc) return rc;
@@ -855,8 +864,8 @@ int launch_scan_seeded(const mmidx_index *h, ScanParams P, const SearchPlan &pl,
 // index-side tables: built once per (coarse, product) quantizer pair, on the handle's stream, synchronously
 int build_grp_tables(mmidx_index *h) {
     if (h->grp_valid) return MMIDX_OK;
-    const bool shape_ok = (h->kind == MMIDX_KIND_IVFPQ || h->kind == MMIDX_KIND_PQ) && h->code_bytes == 1 && h->ks <= 256 && (h->m == 8 || h->m == 16 || h->m == 32) &&
-                          h->transform != MMIDX_TR_ROTATION;
+    const bool shape_ok = (h->kind == MMIDX_KIND_IVFPQ || h->kind == MMIDX_KIND_PQ) && h->code_bytes == 1 && h->ks <= 256 &&
+                          (h->m == 8 || h->m == 16 || h->m == 32 || h->m == 64) && h->transform != MMIDX_TR_ROTATION;
     if (!shape_ok || !h->pq_set) return MMIDX_OK;
     if (!h->d_pq32T) HIPCK(hipMalloc((void **)&h->d_pq32T, (size_t)h->m * h->dsub * 256 * sizeof(float)));
     if (!h->d_pn32) HIPCK(hipMalloc((void **)&h->d_pn32, (size_t)h->m * 256 * sizeof(float)));
@@ -901,7 +910,7 @@ int launch_grp_t(mmidx_index *h, const GrpParams &GP, size_t lds, hipStream_t st
 // S: the scan parameters K3g runs with; F: those of the K3f launch that serves the handed-back (pair, chunk) items
 int launch_grouped_common(mmidx_index *h, const ScanParams &S, ScanParams F, const SearchPlan &pl, int nlists, int nchunks, long long npairs,
                           hipStream_t st) {
-    const int G = h->m == 32 ? 4 : 8;
+    const int G = h->m >= 32 ? 4 : 8;  // (the u8 rows of a group: G x m x 256 bytes <= 64 KiB, the reach of a ds_read's immediate offset)
     int cb = 1;
     while (cb < pl.K1 + GRP_VR) cb <<= 1;
     const GrpLds L(h->m, G, h->D, cb);
@@ -941,6 +950,11 @@ int launch_grouped_common(mmidx_index *h, const ScanParams &S, ScanParams F, con
             rc = ds == 8   ? launch_grp_t<16, 8, 8>(h, GP, L.total, st)
                  : ds == 4 ? launch_grp_t<16, 8, 4>(h, GP, L.total, st)
                            : launch_grp_t<16, 8, 0>(h, GP, L.total, st);
+            break;
+        case 64:  // (YFCC100MExample.java:85-90: 1024 dimensions in 64 x 16)
+            rc = ds == 16  ? launch_grp_t<64, 4, 16>(h, GP, L.total, st)
+                 : ds == 8 ? launch_grp_t<64, 4, 8>(h, GP, L.total, st)
+                           : launch_grp_t<64, 4, 0>(h, GP, L.total, st);
             break;
         default:
             rc = ds == 4 ? launch_grp_t<32, 4, 4>(h, GP, L.total, st) : launch_grp_t<32, 4, 0>(h, GP, L.total, st);

@@ -2224,20 +2224,23 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
 
 // KS = 256: the usual codebook size as a compile-time constant (the table row of sub-quantizer s then sits at an
 // immediate offset of the gather's ds_read instead of costing a VALU add per lookup); KS = 0: ks from the parameters.
+#define MMIDX_HWV 16   // most waves per block (NT = 1024: m = 64, whose 128 KiB table leaves room for one block per CU)
+#define MMIDX_HCNT (MMIDX_HWV + 4)  // counters behind the histogram: [0, HWV) appended per wave, HWV..HWV+1 largest kept key (u64), +2 kept, +3 pool base
 template <int M, int KS, int NT>
 __global__ __launch_bounds__(NT, NT == 512 ? MMIDX_K3H_WPS512 : 1) void k_scan_hist(const ScanParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int WV = NT / 64;  // waves: 4, or 8 (NT = 512: three blocks per CU, six waves per SIMD over the same tables)
+    constexpr int WV = NT / 64;  // waves: 4, 8 (NT = 512: three blocks per CU, six waves per SIMD over the same tables) or 16 (NT = 1024: one block per CU)
+    static_assert(WV <= MMIDX_HWV, "counter layout");
     const int ks = KS > 0 ? KS : P.ks, D = P.D;
     double *lut = (double *)smem;                                        // [M*ks]
     double *vec = lut + (size_t)M * ks;                                  // [D] or [2D]
-    double *s_red = vec + (P.transform ? 2 : 1) * (size_t)D;             // [16] wave minima / r-th values of segment 0
+    double *s_red = vec + (P.transform ? 2 : 1) * (size_t)D;             // [2 HWV] wave minima / r-th values of segment 0
     // [HB], 16-byte aligned (read as uint4).  The offset is computed on the index, not on the pointer value: a cast
     // through uintptr_t loses the LDS address space and every access below becomes a FLAT instruction
-    const size_t hist_off = ((((size_t)M * ks + (P.transform ? 2 : 1) * (size_t)D + 16) * 8) + 15) & ~(size_t)15;
+    const size_t hist_off = ((((size_t)M * ks + (P.transform ? 2 : 1) * (size_t)D + 2 * MMIDX_HWV) * 8) + 15) & ~(size_t)15;
     u32 *hist = (u32 *)(smem + hist_off);
-    u32 *s_cnt = hist + MMIDX_HB;                                        // [12]: 0-7 appended per wave, 8-9 largest kept key (u64), 10 kept, 11 pool base
-    u32 *posbuf = s_cnt + 12;                                            // [cap] list positions, one quarter per wave
+    u32 *s_cnt = hist + MMIDX_HB;                                        // [HCNT]
+    u32 *posbuf = s_cnt + MMIDX_HCNT;                                    // [cap] list positions, an equal share per wave
 
     int item = blockIdx.x;
     if (P.order) {  // (a shard's pass A: the queries whose nearest list is here, k_passa_items)
@@ -2270,7 +2273,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMIDX_K3H_WPS512 : 1) void k_scan_h
         const int64_t i = c0 + tid;
         cur.load(codes + (size_t)(i < c1 ? i : c1 - 1) * M);
     }
-    for (int i = tid; i < MMIDX_HB + 12; i += NT) hist[i] = 0;  // histogram and the counters
+    for (int i = tid; i < MMIDX_HB + MMIDX_HCNT; i += NT) hist[i] = 0;  // histogram and the counters
     const double *tr = query_vector(P, q, cell, vec);
 #if MMIDX_HIST_STOP == 5  // timing experiment: no table build (the loop alone, on a synthetic table)
     for (int i = tid; i < M * ks; i += NT) lut[i] = 1e-3 * (double)((i * 37) & 255) + tr[i & 7];
@@ -2407,7 +2410,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMIDX_K3H_WPS512 : 1) void k_scan_h
     // U = MMIDX_K3H_PAIR + 1 segments per round: their table gathers are independent chains (U times the LDS requests in
     // flight per wave) and the round's bookkeeping -- loop control, prefetch addresses, the threshold refresh -- is paid
     // once.  Segment 0 (already summed into d) is candidate-tested first, on its own.
-    constexpr int U = (NT == 512 ? MMIDX_K3H_PAIR512 : MMIDX_K3H_PAIR) + 1;
+    constexpr int U = (NT >= 512 ? MMIDX_K3H_PAIR512 : MMIDX_K3H_PAIR) + 1;
     // bucket(dd) <= Tb  <=>  (dd - lo) * inv < Tb + 1 (the clamp to [0, HB - 1] cannot change the comparison unless
     // Tb = HB - 1, where everything passes: the bound is NaN then and `!(x >= NaN)` holds).  Two fp64 operations and a compare
     // per code; the bucket itself (clamp, convert) is computed by the candidates only.  A NaN distance passes and lands in
@@ -2538,7 +2541,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMIDX_K3H_WPS512 : 1) void k_scan_h
         __syncthreads();
         // the pool space of all kept_total entries is reserved now, so that the reservation's round trip overlaps the
         // compaction and the code loads (entries above another chunk's threshold are written too: harmless)
-        if (tid == 0) s_cnt[11] = atomicAdd(P.pool_cnt + q, kept_total);
+        if (tid == 0) s_cnt[MMIDX_HWV + 3] = atomicAdd(P.pool_cnt + q, kept_total);
         const u32 mine = s_cnt[wv];  // <= capw here
         for (u32 e0 = 0; e0 < mine; e0 += 64) {
             const u32 e = e0 + (u32)lane;
@@ -2548,13 +2551,13 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMIDX_K3H_WPS512 : 1) void k_scan_h
             if (mask) {
                 u32 base = 0;
                 const int leader = __ffsll((long long)mask) - 1;
-                if (lane == leader) base = atomicAdd(s_cnt + 10, (u32)__popcll(mask));
+                if (lane == leader) base = atomicAdd(s_cnt + MMIDX_HWV + 2, (u32)__popcll(mask));
                 base = wave_read_u32(base, leader);
                 if (keep) keptpos[base + (u32)__popcll(mask & lane_lt)] = v & 0xFFFFFFu;
             }
         }
         __syncthreads();
-        const bool have = (u32)tid < kept_total;  // == s_cnt[10]
+        const bool have = (u32)tid < kept_total;  // == s_cnt[HWV + 2]
         const u32 p = have ? (u32)c0 + keptpos[tid] : (u32)c0;
         CodeVec<M, unsigned char> cv;
         cv.load(codes + (size_t)p * M);
@@ -2562,7 +2565,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMIDX_K3H_WPS512 : 1) void k_scan_h
         const u64 key = dkey(dd);
         if (have) {
             kmax = key;
-            const u32 slot = s_cnt[11] + (u32)tid;  // (written before the barrier above)
+            const u32 slot = s_cnt[MMIDX_HWV + 3] + (u32)tid;  // (written before the barrier above)
             if (slot < (u32)P.poolq) {
                 P.pool_key[(size_t)q * P.poolq + slot] = key;
                 P.pool_val[(size_t)q * P.poolq + slot] = ((u64)pr << 32) | (u64)p;
@@ -2594,7 +2597,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMIDX_K3H_WPS512 : 1) void k_scan_h
             const u64 o = __shfl_xor(kmax, off);
             kmax = o > kmax ? o : kmax;
         }
-        u64 *s_max = (u64 *)(s_cnt + 8);  // zeroed with the histogram, 8-byte aligned
+        u64 *s_max = (u64 *)(s_cnt + MMIDX_HWV);  // zeroed with the histogram, 8-byte aligned
         if (lane == 0) atomicMax(s_max, kmax);
         __syncthreads();
         if (tid == 0) atomicMin(Tq, *s_max);

@@ -342,8 +342,10 @@ __device__ __forceinline__ double grp_exact_entry(const double *tv, const double
 }
 
 // DSUB = dimensions per sub-quantizer as a compile-time constant (4 / 8 / 16), or 0 = run-time value
+// (m = 64: the rows of a group and its residuals -- 1024 dimensions in the reference's flagship shape -- leave room for one block
+//  per CU, so the register allocation may use what two waves per SIMD leave)
 template <int M, int G, int DSUB>
-__global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P) {
+__global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(const GrpParams P) {
     static_assert(M % 8 == 0 && G <= 8 && G * M * 256 <= 65536, "imm offsets of the table reads");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int SPW = M / 8;   // sub-quantizers per wave in the table build
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(GRP_NT, GRP_WPS) void k_scan_grp(const GrpParams P)
         continue;
 #endif
         // ---- (e) per query: lower bound of the sum of minima, state, survivor bound --------------------------------------
-        if (tid < G * M) {  // M lanes per query: the sums over the sub-quantizers by butterfly (M is a power of two <= 32)
+        if (tid < G * M) {  // M lanes per query: the sums over the sub-quantizers by butterfly (M is a power of two <= 64 = a wave)
             const int qi = tid / M;
             double smin = (double)s_mn[tid] - s_err[tid], es = s_err[tid];
 #pragma unroll
