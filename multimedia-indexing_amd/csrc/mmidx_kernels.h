@@ -2410,7 +2410,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMIDX_K3H_WPS512 : 1) void k_scan_h
     // U = MMIDX_K3H_PAIR + 1 segments per round: their table gathers are independent chains (U times the LDS requests in
     // flight per wave) and the round's bookkeeping -- loop control, prefetch addresses, the threshold refresh -- is paid
     // once.  Segment 0 (already summed into d) is candidate-tested first, on its own.
-    constexpr int U = (NT >= 512 ? MMIDX_K3H_PAIR512 : MMIDX_K3H_PAIR) + 1;
+    constexpr int U = (M >= 64 ? 0 : (NT >= 512 ? MMIDX_K3H_PAIR512 : MMIDX_K3H_PAIR)) + 1;  // (m = 64: a code is sixteen registers)
     // bucket(dd) <= Tb  <=>  (dd - lo) * inv < Tb + 1 (the clamp to [0, HB - 1] cannot change the comparison unless
     // Tb = HB - 1, where everything passes: the bound is NaN then and `!(x >= NaN)` holds).  Two fp64 operations and a compare
     // per code; the bucket itself (clamp, convert) is computed by the candidates only.  A NaN distance passes and lands in

@@ -28,14 +28,19 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for case in range(cases):
     kind = rng.choice(["ivfpq", "ivfpq", "pq"])
-    m = int(rng.choice([1, 2, 4, 8, 16, 32, 6]))
+    m = int(rng.choice([1, 2, 4, 8, 16, 32, 6, 64]))
     dsub = int(rng.choice([1, 2, 4, 8, 16, 3]))
+    if m == 64 and dsub > 8 and rng.random() < 0.5:
+        dsub = 4  # (keeps most of the 64 x 16 cases' k-means short; YFCC's own 64 x 16 stays in the mix)
     D = m * dsub
-    ks = int(rng.choice([2, 16, 64, 256, 256, 300]))
-    if ks > 256 and m >= 32:
-        ks = 256
+    # (ks > 256 with m >= 32: short codes whose table -- m x ks doubles -- exceeds the LDS and lives in global scratch)
+    ks = int(rng.choice([2, 16, 64, 256, 256, 300, 700]))
+    if ks == 700 and m < 32:
+        ks = 300
     n = int(rng.integers(1, 40000))
-    k = int(rng.choice([1, 2, 10, 100, 101, 255, 256, 600]))
+    if D >= 256:
+        n = min(n, 6000)  # (the oracle's encoder is one thread: C x D + ks x D fp64 triples per vector)
+    k = int(rng.choice([1, 2, 10, 100, 101, 255, 256, 600, 384, 4095]))
     C = int(rng.choice([1, 2, 7, 40, 130, 300, 1100]))
     w = int(rng.integers(1, C + 1))
     tr = int(rng.choice([0, 0, 2, 1])) if D > 1 else 0
@@ -83,13 +88,11 @@ for case in range(cases):
         Q = np.concatenate([base[rng.integers(0, n, 4)] + 0.01 * rng.standard_normal((4, D)), p["queries"][:3]])
         got = ix.search_batch(k, Q)
         want = ref.search_batch(Q, k)
-        exact = tr != 1
-        ok = np.array_equal(got[2], want[2]) and np.array_equal(got[0], want[0])
-        if exact:
-            ok = ok and np.array_equal(got[1], want[1])
-        else:
-            fin = np.isfinite(want[1])
-            ok = ok and np.allclose(got[1][fin], want[1][fin], rtol=0, atol=1e-9)
+        # ids, counts and distance BITS, rotation included: the kernels rotate in the oracle's order (sequential over the
+        # row index, RandomRotation.java:44-49 through a plain row-vector x matrix product) -- the same statement
+        # test_ivfpq_transforms makes.  What stays an assumption (A2) is that EJML's CommonOps.mult uses that order too;
+        # against the Java classes the promise for a rotation is 1e-12, against this oracle it is equality.
+        ok = np.array_equal(got[2], want[2]) and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
         ix.close()
         if not ok:
             bad += 1

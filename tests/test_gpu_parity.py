@@ -738,6 +738,41 @@ def test_yfcc_shape_d1024_m64(mi, oracle):
     ix.close()
 
 
+@pytest.mark.parametrize("w,k,hist", [(2, 30, -1), (8, 30, -1), (8, 100, 0)])
+def test_yfcc_shape_long_lists_fast_path(mi, oracle, w, k, hist):
+    """YFCC100MExample.java:85-90, :155 -- d = 1024, m = 64 x 256, RandomPermutation, k = 30 -- with lists long enough
+    (5,000 codes) for the fast kernels: pass A through K3h with one 1024-thread block per CU (128 KiB of table), pass B
+    through K3g<64, 4, 16>.  The oracle is loaded with the device's own codes (encode parity is asserted on a sample)."""
+    D, C, m, ks, n = 1024, 8, 64, 256, 40000
+    rng = np.random.default_rng(17)
+    mu = 0.3 * rng.standard_normal((C, D))  # (cells overlap: radius 16 against 14 between the means -- far probes hold neighbours)
+    base = mu[rng.integers(0, C, n)] + 0.5 * rng.standard_normal((n, D))
+    pq = 0.5 * rng.standard_normal((m, ks, D // m))
+    ix = mi.IVFPQ(D, n, False, "", m, ks, 2, C, 512)  # RandomPermutation(1, D) derived natively
+    ix.loadCoarseQuantizer(mu)
+    ix.loadProductQuantizer(pq)
+    ix.setW(w)
+    ix.set_option("passa_hist", hist)
+    ref = oracle_ivfpq(oracle, {"coarse": mu, "pq": pq}, D, m, ks, C, w, tr=2)
+    cells, codes = ix.encode(base[:300])
+    rcell, rcode = ref.encode_batch(base[:300])
+    assert np.array_equal(cells, rcell) and np.array_equal(codes.astype(np.int32) + 128, rcode)
+    ix.indexVectors(list(range(n)), base)
+    off, iids, cds = ix.export()
+    ref.load_lists(off, iids, cds)
+    # perturbed base vectors, cell means, and points half way between two base vectors (their neighbours sit in several cells:
+    # far probes pass the lower-bound filter and are verified exactly)
+    mid = 0.5 * (base[100:124] + base[200:224])
+    Q = np.concatenate([base[:40] + 0.01 * rng.standard_normal((40, D)), mu + 0.3 * rng.standard_normal((C, D)), mid])
+    ix.set_profiling(True)
+    got = ix.search_batch(k, Q)
+    st = ix.get_stats()
+    assert_same(got, ref.search_batch(Q, k))
+    if w > 1:
+        assert st["passb_items_last"] > 0 and st["verified_codes"] > 0  # (pass B ran, through K3g: K3f cannot hold this table)
+    ix.close()
+
+
 def test_snapshot_roundtrip(mi, oracle, tmp_path):
     """saveSnapshot / loadSnapshot (flat restart path): identical answers, ids preserved."""
     D, C, m, ks, n, w, k = 32, 16, 8, 256, 3000, 4, 10
@@ -1182,12 +1217,12 @@ def test_coarse_stage_huge_magnitudes(mi, oracle, scale):
 
 def test_randomised_differential_fuzz():
     """tests/fuzz_parity.py: random small PQ / IVFPQ configurations (shapes, transforms, duplicates, k up to 600, forced
-    kernel variants, adds interleaved with a search) through the HIP path and the oracle; 300 cases over several seeds were
-    run clean when it was written, 30 run here."""
+    kernel variants, adds interleaved with a search; round 3: m = 64, lookup tables beyond the LDS -- ks = 700 with m >= 32 --,
+    k = 384 and 4095, rotation compared bit for bit) through the HIP path and the oracle; 150 cases run here."""
     import os
     import subprocess
     import sys
 
     here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, os.path.join(here, "fuzz_parity.py"), "30", "11"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(here, "fuzz_parity.py"), "150", "11"], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
