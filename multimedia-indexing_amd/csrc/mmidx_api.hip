@@ -464,13 +464,14 @@ int assign_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_cell, 
     if (n == 0) return MMIDX_OK;
     const int ivf = h->kind == MMIDX_KIND_IVFPQ;
     const size_t asg_lds = (size_t)((ASG_BM * (h->D + 2) + 3) & ~3) * 4 + (size_t)ASG_BK * ASG_BN * 4;
-    if (ivf && !h->exact_coarse && asg_lds <= 160 * 1024 && h->C >= 2) {
-        // certified approximate assignment (fp32 MFMA) + exact redo of the flagged vectors
+    const bool split16 = h->d_Ch && !h->coarse_v1;  // (K6a' stages centroid tiles only: any vector length; K6a holds whole vectors in LDS)
+    if (ivf && !h->exact_coarse && (split16 || asg_lds <= 160 * 1024) && h->C >= 2) {
+        // certified approximate assignment (bf16-split or fp32 MFMA) + exact redo of the flagged vectors
         constexpr int QT = 16;
-        HIPCK(h->ws_Q32.reserve((size_t)n * h->D));
+        if (!split16) HIPCK(h->ws_Q32.reserve((size_t)n * h->D));
         HIPCK(h->ws_qn.reserve((size_t)n));
         HIPCK(h->ws_amb.reserve((size_t)n));
-        if (h->d_Ch && !h->coarse_v1) {
+        if (split16) {
             // bf16-split dot products on the matrix cores (K6a'), 5x the rate of the fp32 MFMA
             HIPCK(h->ws_Qh.reserve((size_t)n * h->Dp));
             HIPCK(h->ws_Ql.reserve((size_t)n * h->Dp));
@@ -1018,12 +1019,16 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
     constexpr int QT = 8;
     HIPCK(h->ws_cdist.reserve((size_t)nq * h->C));
     h->cdsel_valid = false;
-    const size_t alds = (size_t)MMIDX_CSEL_CAP * 12 + (size_t)(h->w + 1) * 8 + (size_t)((h->w + 2) & ~1) * 4 +
-                        (size_t)MMIDX_CAND_CHUNK * (h->D + MMIDX_TERM_PAD) * 8 + 16;
+    // the exact stage of the certified selection stages the terms of `cch` candidates at a time in LDS: MMIDX_CAND_CHUNK of them
+    // where they fit a 64 KiB block, fewer for long vectors (D = 1024: 6 -- YFCC100MExample.java:85)
+    const size_t sel_fixed = (size_t)MMIDX_CSEL_CAP * 12 + (size_t)(h->w + 1) * 8 + (size_t)((h->w + 2) & ~1) * 4 + 16;
+    const size_t row_bytes = (size_t)(h->D + MMIDX_TERM_PAD) * 8;
+    int cch = MMIDX_CAND_CHUNK;
+    if (sel_fixed + (size_t)cch * row_bytes > 64 * 1024) cch = sel_fixed < 64 * 1024 ? (int)((64 * 1024 - sel_fixed) / row_bytes) : 0;
+    const size_t alds = sel_fixed + (size_t)std::max(cch, 1) * row_bytes;
     const bool approx = !h->exact_coarse && h->C >= MMIDX_BLOCK && h->w + 1 <= MMIDX_BLOCK && h->C <= 64 * MMIDX_BLOCK &&
-                        h->w >= 1 && alds <= 64 * 1024;
-    const size_t glds = (size_t)MMIDX_CSEL_CAP * 12 + (size_t)(h->w + 1) * 8 + (size_t)((h->w + 2) & ~1) * 4 +
-                        std::max<size_t>((size_t)MMIDX_CAND_CHUNK * (h->D + MMIDX_TERM_PAD) * 8, (size_t)MMIDX_BLOCK * 4) + 16;
+                        h->w >= 1 && cch >= 1 && alds <= 64 * 1024;
+    const size_t glds = sel_fixed + std::max<size_t>((size_t)std::max(cch, 1) * row_bytes, (size_t)MMIDX_BLOCK * 4);
     const int G = h->Cp / 8;
     if (approx && !h->coarse_v1 && h->d_Ch && G >= 4 * (h->w + 1) && glds <= 64 * 1024) {
         // K1e + K1f: bf16-split dot products on the matrix cores, group minima only, certified candidates in fp64
@@ -1051,6 +1056,7 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
         }
         HIPCK(hipGetLastError());
         ApproxSel A{};
+        A.cand_chunk = cch;
         A.qn = h->ws_qn.p;
         A.cnorm_max = h->cnorm_max;
         A.cn_max = h->cn_max;
@@ -1097,6 +1103,7 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
         dim3 g1((unsigned)((h->C + DOT_BN - 1) / DOT_BN), (unsigned)((nq + DOT_BM - 1) / DOT_BM));
         hipLaunchKernelGGL(k_coarse_dot32, g1, dim3(MMIDX_BLOCK), 0, st, h->d_coarseT32, h->ws_Q32.p, h->d_cn, h->ws_qn.p, h->ws_S.p, h->C, h->D, (int)nq);
         ApproxSel A{};
+        A.cand_chunk = cch;
         A.S = h->ws_S.p;
         A.qn = h->ws_qn.p;
         A.cnorm_max = h->cnorm_max;

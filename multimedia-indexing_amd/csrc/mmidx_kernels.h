@@ -551,6 +551,7 @@ struct ApproxSel {
     // K1f split in two (k_coarse_front -> k_coarse_select_list): the certified candidates of every query
     u32 *clist;              // [nq][MMIDX_CLIST]: entry 0 = number of candidates (MMIDX_CSEL_CAP + 1: the exact-row path), then the candidates
     int nq;
+    int cand_chunk;          // candidates per round of the exact stage (<= MMIDX_CAND_CHUNK; the launch's LDS holds that many rows of terms)
 };
 #define MMIDX_CLIST 256
 
@@ -564,12 +565,15 @@ __device__ __forceinline__ void coarse_select_finish(const ApproxSel &A, const i
     const int tid = threadIdx.x, C = A.C, D = A.D, w = A.w;
     const int R = w + 1;
     const double *qv = A.Q + (size_t)q * D;
+    // candidates whose terms are staged in LDS at a time: MMIDX_CAND_CHUNK where they fit the block's 64 KiB, fewer for long
+    // vectors (D = 1024, the reference's flagship shape: 6), chosen by the host with the launch's LDS size
+    const int CH = A.cand_chunk;
     if (n <= MMIDX_CSEL_CAP) {
         // exact fp64 distance of every candidate in the reference's order (IVFPQ.java:583).  The
         // per-dimension terms (c_j - q_j)^2 are independent and are computed by all threads with
         // coalesced loads; only their summation is order-sensitive and runs sequentially, one lane
         // per candidate, over the terms staged in LDS.
-        double *terms = (double *)(sel_i + ((A.w + 2) & ~1));  // [CAND_CHUNK][D]
+        double *terms = (double *)(sel_i + ((A.w + 2) & ~1));  // [CH][D + pad]
         // the ordered sum of one chunk: lane c adds the D staged terms of candidate base + c, j ascending (between barriers)
         auto sum_chunk = [&](const int base, const int nc_) {
             __syncthreads();
@@ -591,7 +595,7 @@ __device__ __forceinline__ void coarse_select_finish(const ApproxSel &A, const i
         };
         const int hD0 = D >> 1;
         constexpr int PUP = 6;  // candidate rows in flight per thread in the pipelined form
-        const bool pipelined = (D & 1) == 0 && (hD0 & (hD0 - 1)) == 0 && hD0 <= MMIDX_BLOCK && MMIDX_CAND_CHUNK <= PUP * (MMIDX_BLOCK / hD0);
+        const bool pipelined = (D & 1) == 0 && (hD0 & (hD0 - 1)) == 0 && hD0 <= MMIDX_BLOCK && CH <= PUP * (MMIDX_BLOCK / hD0);
         if (pipelined) {
             // D/2 a power of two and a whole chunk in one round of loads (D = 128: 4 candidates per 256 threads, 6 rounds):
             // a thread owns ONE pair of coordinates (j, j + 1) -- no division per element, the query pair is loaded once --
@@ -603,7 +607,7 @@ __device__ __forceinline__ void coarse_select_finish(const ApproxSel &A, const i
             const double2 qj = *(const double2 *)(qv + j);
             double2 cv[PUP];
             auto request = [&](const int base) {
-                const int nc_ = (n - base < MMIDX_CAND_CHUNK) ? n - base : MMIDX_CAND_CHUNK;
+                const int nc_ = (n - base < CH) ? n - base : CH;
 #pragma unroll
                 for (int u = 0; u < PUP; u++) {
                     const int ci = ci0 + u * cstep;
@@ -612,8 +616,8 @@ __device__ __forceinline__ void coarse_select_finish(const ApproxSel &A, const i
                 }
             };
             if (n > 0) request(0);
-            for (int base = 0; base < n; base += MMIDX_CAND_CHUNK) {
-                const int nc_ = (n - base < MMIDX_CAND_CHUNK) ? n - base : MMIDX_CAND_CHUNK;
+            for (int base = 0; base < n; base += CH) {
+                const int nc_ = (n - base < CH) ? n - base : CH;
 #pragma unroll
                 for (int u = 0; u < PUP; u++) {
                     const int ci = ci0 + u * cstep;
@@ -624,12 +628,12 @@ __device__ __forceinline__ void coarse_select_finish(const ApproxSel &A, const i
                         tt[1] = d1 * d1;
                     }
                 }
-                if (base + MMIDX_CAND_CHUNK < n) request(base + MMIDX_CAND_CHUNK);
+                if (base + CH < n) request(base + CH);
                 sum_chunk(base, nc_);
             }
         } else
-        for (int base = 0; base < n; base += MMIDX_CAND_CHUNK) {
-            const int nc_ = (n - base < MMIDX_CAND_CHUNK) ? n - base : MMIDX_CAND_CHUNK;
+        for (int base = 0; base < n; base += CH) {
+            const int nc_ = (n - base < CH) ? n - base : CH;
             const int hD = D >> 1;
             if ((D & 1) == 0 && (hD & (hD - 1)) == 0 && hD <= MMIDX_BLOCK) {
                 // D/2 a power of two that divides the block (the usual case, D = 128): a thread owns ONE pair of

@@ -96,6 +96,41 @@ class ResidualVectorComputation:
         return self.coarse[c] - X, c
 
 
+class RandomPermutation:
+    """J/utilities/RandomPermutation.java:29-56 on the host -- what the learner applies to its training vectors
+    (ProductQuantizationLearning.java:176-178, seed 1) so that the codebooks live in the space the index quantises in
+    (IVFPQ.java:136, :193: the same seed; libmmidx_hip derives the same indices natively).  java.util.Random's 48-bit LCG and
+    Collections.shuffle restated from the JDK's specification."""
+
+    def __init__(self, seed, dim):
+        state = (int(seed) ^ 0x5DEECE66D) & ((1 << 48) - 1)
+
+        def nxt(bits):
+            nonlocal state
+            state = (state * 0x5DEECE66D + 0xB) & ((1 << 48) - 1)
+            v = state >> (48 - bits)
+            return v - (1 << 32) if v >= (1 << 31) else v  # (int) cast: only next(32) can come out negative
+
+        def next_int(bound):
+            if bound & (-bound) == bound:
+                return (bound * nxt(31)) >> 31
+            while True:
+                bits = nxt(31)
+                val = bits % bound
+                if bits - val + (bound - 1) < (1 << 31):  # (no int overflow)
+                    return val
+
+        idx = list(range(dim))
+        for i in range(dim, 1, -1):  # Collections.shuffle: swap(i - 1, nextInt(i))
+            j = next_int(i)
+            idx[i - 1], idx[j] = idx[j], idx[i - 1]
+        self.randomlyPermutatedIndices = np.asarray(idx, np.int32)
+
+    def permute(self, v):
+        """out[i] = v[perm[i]] (RandomPermutation.java:50-56); rows of a matrix alike"""
+        return np.asarray(v)[..., self.randomlyPermutatedIndices]
+
+
 class ProductQuantizationLearning:
     @staticmethod
     def learn(vectors, m, numProductCentroids, maxIterations=100, numKmeansRepeats=1, coarseQuantizer=None, transform=None,

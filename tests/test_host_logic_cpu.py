@@ -54,3 +54,21 @@ def test_shard_ownership(mi):
         own = sh.owner_of_cell(cells, world)
         assert own.min() == 0 and own.max() == min(world, 20) - 1
         assert np.array_equal(own, cells % world)
+
+
+def test_host_random_permutation_matches_the_oracle_and_the_kats(oracle):
+    """quantization.RandomPermutation (what the learner applies, ProductQuantizationLearning.java:176-178) is a third
+    statement of java.util.Random + Collections.shuffle next to the oracle's C and the library's C++: same indices."""
+    import importlib
+
+    import numpy as np
+
+    q = importlib.import_module("multimedia-indexing_amd").quantization
+    assert list(q.RandomPermutation(1, 3).randomlyPermutatedIndices) == [1, 2, 0]
+    assert list(q.RandomPermutation(1, 8).randomlyPermutatedIndices) == [2, 6, 7, 0, 3, 1, 4, 5]
+    p128 = q.RandomPermutation(1, 128).randomlyPermutatedIndices
+    assert list(p128[:3]) == [79, 51, 4] and int((np.arange(128) * p128).sum()) == 533821
+    for seed, dim in ((1, 1024), (7, 77), (123456789, 500), (-5, 33)):
+        assert np.array_equal(q.RandomPermutation(seed, dim).randomlyPermutatedIndices, oracle.random_permutation(seed, dim))
+    v = np.arange(8.0)
+    assert np.array_equal(q.RandomPermutation(1, 8).permute(v), v[[2, 6, 7, 0, 3, 1, 4, 5]])
