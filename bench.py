@@ -371,6 +371,10 @@ def main():
     ap.add_argument("--hard-steps", type=int, default=10, help="timed steps of the `hard` object (0 = skip it)")
     ap.add_argument("--hard-parity", type=int, default=2048, help="queries of the hard workload checked against the oracle")
     ap.add_argument("--other-configs", type=int, default=1, help="1: also run BASELINE configs 1-3 (tests/bench_configs.py)")
+    ap.add_argument("--extras", type=int, default=1,
+                    help="1: also publish host_path, cfg5, yfcc and the measured ceilings (tests/bench_extras.py, tests/bench_yfcc.py)")
+    ap.add_argument("--yfcc-n", type=int, default=95_213_780, help="vectors of the `yfcc` object (0 = skip it)")
+    ap.add_argument("--cfg5-images", type=int, default=1_000_000, help="images of cfg5's end-to-end run (0 = front-end kernels only)")
     ap.add_argument("--settle", type=int, default=24)
     ap.add_argument("--exhaustive-steps", type=int, default=3,
                     help="extra untimed-for-value steps with pruning off, reported as roofline_exhaustive (0 = skip)")
@@ -467,6 +471,15 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
     f64 = torch.float64
     cx.stream = stream = torch.cuda.current_stream().cuda_stream
     single = world == 1 and not args.force_sharded and not native
+
+    # measured ceilings (a few tens of ms): what the LDS pipe delivers for pass A's gather pattern, the f64 matrix peak
+    probes = None
+    if rank == 0 and args.extras:
+        try:
+            probes = importlib.import_module("bench_extras").probes(L, nat, local)
+            log(f"probes: {probes}")
+        except Exception as e:  # noqa: BLE001
+            probes = {"error": repr(e)}
 
     # ---------------------------------------------------------------- headline workload
     mu, coarse_h, pq_h = learn_codebooks(cx, args.sigma)
@@ -636,12 +649,22 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
     if native:
         pa_bytes /= ndev  # (stats of a sharded handle: times = the slowest shard, code counts = the sum over shards -> per device)
     pa_ach = pa_bytes / (pa_ms * 1e-3) / 1e9 if pa_ms > 0 else 0.0
+    # the LDS roofline of the same kernel: its gather alone (mmidx_probe_lds_gather: m random ds_read_b64 per code over 2 KiB
+    # rows + the fp64 adds, three codes in flight per lane, four 256-thread blocks per CU as K3h runs) measured in this run
+    lds_roof = None
+    if isinstance(probes, dict) and f"lds_gather_m{m}_chains3" in probes:
+        pk = probes[f"lds_gather_m{m}_chains3"]["algorithmic_GBps"]
+        lds_roof = {"bound": "lds", "achieved": round(pa_ach, 1), "peak": pk, "unit": "GB/s of codes (m random 8-byte table reads per code)",
+                    "frac": round(pa_ach / pk, 4) if pk > 0 else None,
+                    "peak_source": "mmidx_probe_lds_gather(m, 3 chains): the scan loop with only the gather and the adds left, measured in this run",
+                    "wave_gathers_per_s_peak": probes[f"lds_gather_m{m}_chains3"]["wave_gathers_per_s"]}
     if sharded is None and st.passa_launches > 0:
         roofline = {"bound": "hbm", "kernel": "k_scan_hist (pass A: the exact scan of every query's nearest list; the launch also "
                                                "carries its empty hand-back launch)",
                     "achieved": round(pa_ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(pa_ach / 8000.0, 4),
                     "frac_of_measured_copy_ceiling": round(pa_ach / 6290.0, 4), "traffic": traffic_passa, "traffic_source": traffic_source,
                     "algorithmic_bytes_per_launch": pa_bytes, "avg_launch_ms": round(pa_ms, 4), "launches": int(st_light.passa_launches),
+                    "lds": lds_roof,
                     "note": "limited by the LDS gather (16 fp64 table entries per code, ~60 % of its LDS cycles are bank conflicts) "
                             "and the VALU work around it (both pipes ~75 % busy, profiles/), not by HBM"}
     else:
@@ -697,6 +720,16 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
         parity = parity_of(res_iid, res_dist, rid, rd)
         del ref
         log(f"cpu baseline + parity in {time.time() - t0:.1f}s: {cpu_baseline['value']} q/s on {cores} cores; parity {parity}")
+
+    # ---------------------------------------------------------------- the boundary's own path: host buffers, caller threads
+    host = None
+    if rank == 0 and single and args.extras:
+        try:
+            t0 = time.time()
+            host = importlib.import_module("bench_extras").host_path(L, nat, h, np.ascontiguousarray(Qb[0].cpu().numpy()), k)
+            log(f"host path in {time.time() - t0:.1f}s: {host}")
+        except Exception as e:  # noqa: BLE001
+            host = {"error": repr(e)}
 
     # ---------------------------------------------------------------- hard data: the coarse bound removes nothing
     hard = None
@@ -784,6 +817,30 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
         except Exception as e:  # (never lose the headline line to a side measurement)
             other = {"error": repr(e)}
 
+    # ---------------------------------------------------------------- cfg5 front end, the reference's flagship shape
+    cfg5, yfcc = None, None
+    if rank == 0 and single and args.extras:
+        if h is not None:
+            chk(L.mmidx_destroy(h))
+            h = None
+        torch.cuda.empty_cache()
+        try:
+            t0 = time.time()
+            cfg5 = importlib.import_module("bench_extras").cfg5(L, nat, cx.mi, images_e2e=args.cfg5_images, device=local)
+            log(f"cfg5 in {time.time() - t0:.1f}s")
+        except Exception as e:  # noqa: BLE001
+            cfg5 = {"error": repr(e)}
+        torch.cuda.empty_cache()
+        if args.yfcc_n > 0:
+            try:
+                t0 = time.time()
+                yfcc = importlib.import_module("bench_yfcc").run(n=args.yfcc_n, device=local, parity_queries=0 if args.no_cpu else 512)
+                log(f"yfcc in {time.time() - t0:.1f}s")
+            except Exception as e:  # noqa: BLE001
+                yfcc = {"error": repr(e)}
+        if isinstance(other, dict) and "error" not in other:
+            other["cfg5_vlad_pca_ivfpq"] = cfg5
+
     if rank == 0:
         out = {
             "metric": "queries/sec @ recall@1, IVFPQ 100Mx128-d nprobe=32",
@@ -806,7 +863,8 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
                                     f"top-k entries to the query's owner, merge + cross-shard tie replay there")},
             "recall_at_1": recall1, "recall_queries": ngt,
             "roofline": roofline, "roofline_whole_search": whole, "roofline_exhaustive": exhaustive,
-            "cpu_baseline": cpu_baseline, "parity": parity, "hard": hard, "other_configs": other,
+            "cpu_baseline": cpu_baseline, "parity": parity, "hard": hard, "other_configs": other, "cfg5": cfg5, "yfcc": yfcc,
+            "host_path": host, "measured_ceilings": probes,
         }
         print(json.dumps(out), file=json_out, flush=True)
     if h is not None:

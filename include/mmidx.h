@@ -326,6 +326,15 @@ int mmidx_set_profiling(mmidx_index *h, int enabled);
 int mmidx_set_option(mmidx_index *h, const char *name, int value);
 int mmidx_get_stats(mmidx_index *h, mmidx_stats *out);
 
+/* Measured ceilings for the rooflines bench.py reports (csrc/mmidx_probe.hip; SURVEY 8d "secondary: LDS gather rate", A5):
+ * mmidx_probe_lds_gather: the gather of the exact scan alone -- per code m random 8-byte LDS reads over 2 KiB rows, summed
+ *   in fp64, `chains` (1 or 3) codes in flight per lane, 256-thread blocks at the scan kernel's occupancy; m in {8, 16, 32}.
+ *   out[0] = wave-level ds_read_b64 per second, out[1] = GB/s of "algorithmic bytes" (codes x m), out[2] = blocks per CU,
+ *   out[3] = seconds.
+ * mmidx_probe_f64_mfma: back-to-back v_mfma_f64_16x16x4_f64 on every SIMD; out[0] = TFLOP/s, out[1] = seconds. */
+int mmidx_probe_lds_gather(int device, int m, int chains, double *out);
+int mmidx_probe_f64_mfma(int device, double *out);
+
 /* ---- front end of BASELINE config 5 ----------------------------------------------------------
  * PCA projection: PCA.loadPCAFromFile (J/dimreduction/PCA.java:257-318) + sampleToEigenSpace
  * (:188-208).  means[ss] = line 1 of the PCA file, eig[nc] = line 2 (used iff whitening: the

@@ -42,7 +42,7 @@ class Stats(C.Structure):
 
 def build(force=False):
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("mmidx_api.hip", "mmidx_learn.hip", "mmidx_kernels.h", "mmidx_scan_grp.h", "mmidx_frontend.h", "mmidx_sharded.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("mmidx_api.hip", "mmidx_learn.hip", "mmidx_probe.hip", "mmidx_kernels.h", "mmidx_scan_grp.h", "mmidx_frontend.h", "mmidx_sharded.h")]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "mmidx.h"))
     stale = not os.path.exists(SO_PATH) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
     if force or stale:
@@ -113,6 +113,8 @@ SIGNATURES = {
     "mmidx_shard_info": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "mmidx_search_sliced_device": (C.c_int, [_vp, C.c_int, C.c_int64, _vp, _vp, _vp, _vp]),
     "mmidx_add_vectors_sliced_device": (C.c_int, [_vp, _vp, _vp, C.c_int32]),
+    "mmidx_probe_lds_gather": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp]),
+    "mmidx_probe_f64_mfma": (C.c_int, [C.c_int, _dp]),
     "mmidx_set_profiling": (C.c_int, [_vp, C.c_int]),
     "mmidx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "mmidx_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
