@@ -596,7 +596,43 @@ __device__ __forceinline__ void coarse_select_finish(const ApproxSel &A, const i
         const int hD0 = D >> 1;
         constexpr int PUP = 6;  // candidate rows in flight per thread in the pipelined form
         const bool pipelined = (D & 1) == 0 && (hD0 & (hD0 - 1)) == 0 && hD0 <= MMIDX_BLOCK && CH <= PUP * (MMIDX_BLOCK / hD0);
-        if (pipelined) {
+        if (CH < MMIDX_CAND_CHUNK && (D & 1) == 0 && n > 4 * CH) {
+            // Long vectors and many candidates (D = 1024, w = 64 -- YFCC100MExample.java:85, Example.java:96: only six rows of
+            // terms fit the LDS, and six lanes summing 1024 terms each left the other 250 idle, 14 rounds of ~8 us per query):
+            // a LANE per candidate instead.  Every lane streams its own centroid row from L2 in dimension order and adds
+            // (c_j - q_j)^2 as it goes -- the same operations in the same order (IVFPQ.java:583), 256 candidates at a time,
+            // eight 16-byte loads in flight per lane; the query sits in LDS (broadcast reads).  The rows are the traffic that
+            // is left: (w + ~20) x 8 KiB per query.  (Loads run on a clamped index, only the store is predicated: see the
+            // note at pair_keep().)  Few candidates (w = 2) keep the staged form below: a handful of lanes streaming whole rows
+            // is a chain of cache misses.
+            for (int j = tid; j < D; j += MMIDX_BLOCK) terms[j] = qv[j];
+            __syncthreads();
+            for (int base = 0; base < n; base += MMIDX_BLOCK) {
+                const int ci = base + tid;
+                const int cc = ci < n ? ci : n - 1;
+                const double *row = A.coarse + (size_t)cidx[cc] * (u32)D;
+                double acc = 0.0;
+                int j = 0;
+                for (; j + 16 <= D; j += 16) {
+                    double2 cv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) cv[u] = *(const double2 *)(row + j + 2 * u);
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const double2 qq = *(const double2 *)(terms + j + 2 * u);
+                        const double d0 = cv[u].x - qq.x, d1 = cv[u].y - qq.y;
+                        acc += d0 * d0;
+                        acc += d1 * d1;
+                    }
+                }
+                for (; j < D; j++) {
+                    const double df = row[j] - terms[j];
+                    acc += df * df;
+                }
+                if (ci < n) ckey[ci] = dkey(acc);
+            }
+            __syncthreads();
+        } else if (pipelined) {
             // D/2 a power of two and a whole chunk in one round of loads (D = 128: 4 candidates per 256 threads, 6 rounds):
             // a thread owns ONE pair of coordinates (j, j + 1) -- no division per element, the query pair is loaded once --
             // and the rows of the NEXT chunk are requested before the ordered sum of the current one, so that their

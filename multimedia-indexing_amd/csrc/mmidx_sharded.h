@@ -206,6 +206,8 @@ struct ShardBufs {  // everything on the shard's device
     DevBuf<int32_t> ecell;
     DevBuf<unsigned char> ecode;
     int32_t *pin_nflag = nullptr;  // pinned host word
+    ShardDest *pin_dest = nullptr; // pinned host copy of `dest` (what was last uploaded: re-sent only when a pointer changed)
+    int dest_n = 0;
     hipEvent_t ev_b = nullptr;     // pass B of this shard has been enqueued up to here
     void release() {
         Q.release(); cdist.release(); T.release(); pd.release(); rpd.release(); odist.release(); tau_own.release(); tau.release();
@@ -214,6 +216,8 @@ struct ShardBufs {  // everything on the shard's device
         tmp.release(); dest.release(); X.release(); ecell.release(); ecode.release();
         if (pin_nflag) (void)hipHostFree(pin_nflag);
         pin_nflag = nullptr;
+        if (pin_dest) (void)hipHostFree(pin_dest);
+        pin_dest = nullptr;
         if (ev_b) (void)hipEventDestroy(ev_b);
         ev_b = nullptr;
     }
@@ -437,13 +441,22 @@ int shard_search_round(ShardGroup *g, int r, int k, int64_t per, const double *Q
     g->pub[(size_t)r] = &B;  // (the receive buffers were reserved above: publish them)
     BARRIER(g);
     if (p2p) {
-        std::vector<ShardDest> tab((size_t)W);
-        for (int o = 0; o < W; o++) {
-            ShardBufs *O = (ShardBufs *)g->pub[(size_t)o];
-            tab[(size_t)o] = ShardDest{O->rpd.p, O->rpk.p, O->rpc.p};
+        // the owners' receive buffers as a device table; it changes only when some shard's buffers grew, and only then is it
+        // uploaded again (from pinned memory that nothing rewrites while a copy may be in flight: the stream is drained first)
+        bool changed = B.dest_n != W;
+        for (int o = 0; o < W && !changed; o++) {
+            const ShardBufs *O = (const ShardBufs *)g->pub[(size_t)o];
+            changed = B.pin_dest[o].pd != O->rpd.p || B.pin_dest[o].pk != O->rpk.p || B.pin_dest[o].pc != O->rpc.p;
         }
-        HIPCK(hipMemcpyAsync(B.dest.p, tab.data(), (size_t)W * sizeof(ShardDest), hipMemcpyHostToDevice, st));
-        HIPCK(hipStreamSynchronize(st));  // (`tab` is host stack memory)
+        if (changed) {
+            HIPCK(hipStreamSynchronize(st));
+            for (int o = 0; o < W; o++) {
+                const ShardBufs *O = (const ShardBufs *)g->pub[(size_t)o];
+                B.pin_dest[o] = ShardDest{O->rpd.p, O->rpk.p, O->rpc.p};
+            }
+            B.dest_n = W;
+            HIPCK(hipMemcpyAsync(B.dest.p, B.pin_dest, (size_t)W * sizeof(ShardDest), hipMemcpyHostToDevice, st));
+        }
         s->shard_dest = B.dest.p;
         s->shard_dest_per = (int)per;
         s->shard_dest_me = r;
@@ -1045,6 +1058,7 @@ int mmidx_create_sharded(int kind, int D, int m, int ks, int C, int transform, c
         if (rc) return bail(rc);
         g->st.push_back(g->sub[(size_t)r]->stream);
         if (hipSetDevice(devs[r]) != hipSuccess || hipHostMalloc((void **)&g->buf[(size_t)r].pin_nflag, 64) != hipSuccess ||
+            hipHostMalloc((void **)&g->buf[(size_t)r].pin_dest, MMIDX_MAX_SHARDS * sizeof(ShardDest)) != hipSuccess ||
             hipEventCreateWithFlags(&g->buf[(size_t)r].ev_b, hipEventDisableTiming) != hipSuccess)
             return bail(fail(MMIDX_ERR_HIP, "shard %d: pinned word / event allocation failed", r));
     }
