@@ -82,9 +82,10 @@ def same_codebooks(cx, coarse_h, pq_h):
     return tc.cpu().numpy(), tp.cpu().numpy()
 
 
-def learn_codebooks(cx, sigma):
+def learn_codebooks(cx, sigma, iid=False):
     """mixture means, coarse quantizer (Lloyd from the means, 2 iterations) and residual PQ codebooks (k-means++ per
-    sub-space on centroid - vector, ResidualVectorComputation.java:34)"""
+    sub-space on centroid - vector, ResidualVectorComputation.java:34).  iid: no mixture at all -- every vector is
+    sigma N(0, I) (all "means" zero), the cells are plain k-means cells (Lloyd from sample points, 4 iterations)"""
     torch, a = cx.torch, cx.args
     N, D, Cc, m = a.n, a.dim, a.cells, a.m
     ks, dsub = 256, D // m
@@ -92,11 +93,13 @@ def learn_codebooks(cx, sigma):
     g0 = torch.Generator(device=cx.dev)
     g0.manual_seed(1234)
     mu = torch.randn(Cc, D, generator=g0, device=cx.dev, dtype=torch.float64)
+    if iid:
+        mu.zero_()
     ns = min(N, 1 << 20)
     gs = torch.randint(0, Cc, (ns,), generator=g0, device=cx.dev)
     Xs = mu[gs] + sigma * torch.randn(ns, D, generator=g0, device=cx.dev, dtype=torch.float64)
     torch.cuda.synchronize()
-    coarse_h = gpu_kmeans(cx, Xs, Cc, 2, init=mu.cpu().numpy())
+    coarse_h = gpu_kmeans(cx, Xs, Cc, 4, init=Xs[:Cc].cpu().numpy()) if iid else gpu_kmeans(cx, Xs, Cc, 2, init=mu.cpu().numpy())
     coarse = torch.from_numpy(coarse_h).to(cx.dev)
     hq = C.c_void_p()
     cx.chk(cx.L.mmidx_create(cx.nat.KIND_IVFPQ, D, 1, 2, Cc, 0, None, None, cx.local, C.byref(hq)))
@@ -181,9 +184,10 @@ def build_index_native(cx, mu, sigma, coarse_h, pq_h, nq_total, ndev):
     return h, Q
 
 
-def build_index(cx, mu, sigma, coarse_h, pq_h, nq_total, sharded_build):
+def build_index(cx, mu, sigma, coarse_h, pq_h, nq_total, sharded_build, independent_queries=False):
     """encode + append the N base vectors on the device; returns (handle, queries [nq_total][D]).
-    Queries are self-perturbed base vectors: base[i] + 0.01 N(0, I)."""
+    Queries are self-perturbed base vectors: base[i] + 0.01 N(0, I); independent_queries: fresh draws from the
+    base distribution instead (nobody's copy: the true neighbour is wherever it is)."""
     torch, a, L, nat = cx.torch, cx.args, cx.L, cx.nat
     N, D, Cc, m = a.n, a.dim, a.cells, a.m
     h = C.c_void_p()
@@ -253,7 +257,11 @@ def build_index(cx, mu, sigma, coarse_h, pq_h, nq_total, sharded_build):
     cx.chk(L.mmidx_sync_index(h))
     torch.cuda.synchronize()
     log(f"index (sigma {sigma}) built: {N} vectors in {time.time() - t0:.1f}s (encode+append {t_enc:.1f}s)")
-    Q = Qsrc + 0.01 * torch.randn(nq_total, D, generator=gq, device=cx.dev, dtype=torch.float64)
+    if independent_queries:
+        gi = torch.randint(0, a.cells, (nq_total,), generator=gq, device=cx.dev)
+        Q = mu[gi] + sigma * torch.randn(nq_total, D, generator=gq, device=cx.dev, dtype=torch.float64)
+    else:
+        Q = Qsrc + 0.01 * torch.randn(nq_total, D, generator=gq, device=cx.dev, dtype=torch.float64)
     return h, Q
 
 
@@ -370,6 +378,8 @@ def main():
                          "removes no probe")
     ap.add_argument("--hard-steps", type=int, default=10, help="timed steps of the `hard` object (0 = skip it)")
     ap.add_argument("--hard-parity", type=int, default=2048, help="queries of the hard workload checked against the oracle")
+    ap.add_argument("--spread-steps", type=int, default=6, help="timed steps of the `spread` object: iid Gaussian base, independent queries (0 = skip it)")
+    ap.add_argument("--spread-parity", type=int, default=1024, help="queries of the spread workload checked against the oracle")
     ap.add_argument("--other-configs", type=int, default=1, help="1: also run BASELINE configs 1-3 (tests/bench_configs.py)")
     ap.add_argument("--extras", type=int, default=1,
                     help="1: also publish host_path, cfg5, yfcc and the measured ceilings (tests/bench_extras.py, tests/bench_yfcc.py)")
@@ -731,24 +741,20 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
         except Exception as e:  # noqa: BLE001
             host = {"error": repr(e)}
 
-    # ---------------------------------------------------------------- hard data: the coarse bound removes nothing
-    hard = None
-    if rank == 0 and single and args.hard_steps > 0:
-        chk(L.mmidx_destroy(h))
-        h = None
-        del Q, Qb
-        torch.cuda.empty_cache()
-        hs = args.hard_sigma
-        mu_h, coarse_hh, pq_hh = learn_codebooks(cx, hs)
-        hh, Qh_all = build_index(cx, mu_h, hs, coarse_hh, pq_hh, B * 2, sharded_build=False)
+    # ---------------------------------------------------------------- side workloads on the same engine, same index size
+    def side_workload(sig, iid, steps_, parity_q, what):
+        """builds another 100M index (mixture noise `sig`, or iid N(0, I) vectors with independent queries), times `steps_` steps,
+        reports stage times, recall against exact ground truth and an oracle parity gate"""
+        mu_h, coarse_hh, pq_hh = learn_codebooks(cx, sig, iid=iid)
+        hh, Qh_all = build_index(cx, mu_h, sig, coarse_hh, pq_hh, B * 2, sharded_build=False, independent_queries=iid)
         Qhb = [Qh_all[i * B:(i + 1) * B].contiguous() for i in range(2)]
         ngh = min(args.gt, B, 256)
-        gt_h = ground_truth(cx, mu_h, hs, Qhb[0][:ngh]) if ngh > 0 else None
+        gt_h = ground_truth(cx, mu_h, sig, Qhb[0][:ngh]) if ngh > 0 else None
         for i in range(4):
             step(Qhb[i % 2], hh)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(args.hard_steps):
+        for i in range(steps_):
             step(Qhb[i % 2], hh)
         torch.cuda.synchronize()
         h_el = time.perf_counter() - t0
@@ -765,6 +771,7 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
         h_iid = iid_out.cpu().numpy().copy()
         h_dist = dist_out.cpu().numpy().copy()
         h_recall = float((iid_out[:ngh, 0].long() == gt_h).double().mean().item()) if ngh > 0 else None
+        h_recall_k = float((iid_out[:ngh] == gt_h[:, None].to(torch.int32)).any(1).double().mean().item()) if ngh > 0 else None
         # pass B = everything between the end of pass A and the end of the scans (pair sort + k_scan_grp + hand-back launch)
         pb_ms = (hst.scan_ms - hst.passa_ms) / hd
         pb_bytes = float(m) * (hst.scan_codes - hst.passa_codes) / hd
@@ -773,38 +780,62 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
         if not args.no_cpu:
             t0 = time.time()
             ref = oracle_of_index(cx, hh, coarse_hh, pq_hh)
-            nsh = int(min(B, args.hard_parity))
+            nsh = int(min(B, parity_q))
             Qn = Qhb[0][:nsh].cpu().numpy()
             tc = time.perf_counter()
             rid, rd, rc = ref.search_batch(Qn, k, nthreads=cores)
             h_cpu_t = time.perf_counter() - tc
             h_parity = parity_of(h_iid, h_dist, rid, rd)
             h_cpu = {"value": round(nsh / h_cpu_t, 2), "unit": "queries/s", "cores": cores, "kind": "port",
-                     "sample": f"{nsh} queries of the hard workload, {h_cpu_t:.1f}s"}
+                     "sample": f"{nsh} queries of this workload, {h_cpu_t:.1f}s"}
             del ref
-            log(f"hard: oracle parity in {time.time() - t0:.1f}s: {h_parity}")
-        hard = {"data": f"same generator and means, mixture noise sigma = {hs} (headline: {args.sigma}): cluster radius "
-                        f"{hs * D ** 0.5:.1f} against an inter-mean distance of {(2 * D) ** 0.5:.1f}; IVFPQ.java:414-447 scans all w probes, and here "
-                        f"so does the engine",
-                "value": round(B * args.hard_steps / h_el, 1), "unit": "queries/s", "steps": args.hard_steps,
-                "ms_per_step": round(h_el / args.hard_steps * 1e3, 4), "batch": B,
-                "survivors_per_query": round(int(hst.passb_items_last) / B, 3), "far_probes_per_query": w - 1,
-                "verified_codes_per_query": round(hst.verified_codes / hd / B, 2),
-                "recall_at_1": h_recall, "recall_queries": ngh,
-                "stage_ms_per_step": {"coarse": round(hst.coarse_ms / hd, 4), "pass_a": round(hst.passa_ms / hd, 4), "pass_b": round(pb_ms, 4),
-                                      "merge": round(hst.merge_ms / hd, 4)},
-                "roofline": {"bound": "hbm", "kernel": "k_scan_grp (pass B: grouped lower-bound-filtered scan of the w - 1 far probes, incl. "
-                                                       "pair sort and hand-back launch)",
-                             "achieved": round(pb_ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(pb_ach / 8000.0, 4),
-                             "algorithmic_bytes_per_launch": pb_bytes, "avg_launch_ms": round(pb_ms, 4), "traffic": None,
-                             "note": "algorithmic bytes = m x the codes of every probed far list; a batch probes every list ~64 times and "
-                                     "the list-major kernel reads it from HBM about once (the rest comes from L2), so this fraction can "
-                                     "exceed 1: the kernel is bound by LDS table lookups and instruction issue, not by HBM (DESIGN.md 5.12)"},
-                "parity": h_parity, "cpu_baseline": h_cpu}
+            log(f"{what}: oracle parity in {time.time() - t0:.1f}s: {h_parity}")
+        traffic_pb = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+            traffic_pb = tj.get(f"{what}_pass_b_fetch_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            pass
+        res = {"value": round(B * steps_ / h_el, 1), "unit": "queries/s", "steps": steps_,
+               "ms_per_step": round(h_el / steps_ * 1e3, 4), "batch": B,
+               "survivors_per_query": round(int(hst.passb_items_last) / B, 3), "far_probes_per_query": w - 1,
+               "verified_codes_per_query": round(hst.verified_codes / hd / B, 2),
+               "recall_at_1": h_recall, "true_neighbour_in_top_k": h_recall_k, "recall_queries": ngh,
+               "stage_ms_per_step": {"coarse": round(hst.coarse_ms / hd, 4), "pass_a": round(hst.passa_ms / hd, 4), "pass_b": round(pb_ms, 4),
+                                     "merge": round(hst.merge_ms / hd, 4)},
+               "roofline": {"bound": "hbm", "kernel": "k_scan_grp (pass B: grouped lower-bound-filtered scan of the w - 1 far probes, incl. "
+                                                      "pair sort and hand-back launch)",
+                            "achieved": round(pb_ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(pb_ach / 8000.0, 4),
+                            "algorithmic_bytes_per_launch": pb_bytes, "avg_launch_ms": round(pb_ms, 4), "traffic": traffic_pb,
+                            "traffic_source": "profiles/hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE pass of this workload, x 2 on gfx950)" if traffic_pb else None,
+                            "note": "algorithmic bytes = m x the codes of every probed far list; a batch probes every list ~64 times and "
+                                    "the list-major kernel reads it from HBM about once (the rest comes from L2), so this fraction can "
+                                    "exceed 1: the kernel is bound by LDS table lookups and instruction issue, not by HBM (DESIGN.md 5.12)"},
+               "parity": h_parity, "cpu_baseline": h_cpu}
         chk(L.mmidx_destroy(hh))
-        hh = None
         del Qh_all, Qhb
         torch.cuda.empty_cache()
+        return res
+
+    hard, spread = None, None
+    if rank == 0 and single and (args.hard_steps > 0 or args.spread_steps > 0):
+        chk(L.mmidx_destroy(h))
+        h = None
+        del Q, Qb
+        torch.cuda.empty_cache()
+    if rank == 0 and single and args.hard_steps > 0:
+        hs = args.hard_sigma
+        hard = side_workload(hs, False, args.hard_steps, args.hard_parity, "hard")
+        hard["data"] = (f"same generator and means, mixture noise sigma = {hs} (headline: {args.sigma}): cluster radius "
+                        f"{hs * D ** 0.5:.1f} against an inter-mean distance of {(2 * D) ** 0.5:.1f}; IVFPQ.java:414-447 scans all w probes, and here "
+                        f"so does the engine")
+    if rank == 0 and single and args.spread_steps > 0:
+        # no cluster structure at all and queries that are nobody's copy: the top-k of a query is spread over several of its
+        # probed cells, far probes FEED the queue (IVFPQ.java:429-446 offers every probed code) and recall@1 is what 16-byte
+        # codes give on such data -- reported, not required ("iid-Gaussian independent queries would not reach 0.9")
+        spread = side_workload(1.0, True, args.spread_steps, args.spread_parity, "spread")
+        spread["data"] = ("iid N(0, I) base vectors (no mixture), k-means cells, INDEPENDENT N(0, I) queries: neighbours sit in several probed "
+                          "cells, the filter's survivors are verified exactly; recall@1 is against exact fp64 brute force")
 
     # ---------------------------------------------------------------- BASELINE configs 1-3 at their stated sizes
     other = None
@@ -863,7 +894,7 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
                                     f"top-k entries to the query's owner, merge + cross-shard tie replay there")},
             "recall_at_1": recall1, "recall_queries": ngt,
             "roofline": roofline, "roofline_whole_search": whole, "roofline_exhaustive": exhaustive,
-            "cpu_baseline": cpu_baseline, "parity": parity, "hard": hard, "other_configs": other, "cfg5": cfg5, "yfcc": yfcc,
+            "cpu_baseline": cpu_baseline, "parity": parity, "hard": hard, "spread": spread, "other_configs": other, "cfg5": cfg5, "yfcc": yfcc,
             "host_path": host, "measured_ceilings": probes,
         }
         print(json.dumps(out), file=json_out, flush=True)
