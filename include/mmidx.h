@@ -262,6 +262,7 @@ int mmidx_linear_create(int D, int64_t capacity, int device, mmidx_linear **out)
 int mmidx_linear_destroy(mmidx_linear *l);
 int mmidx_linear_add(mmidx_linear *l, int64_t n, const double *X);
 int mmidx_linear_size(const mmidx_linear *l, int64_t *n_out);
+int mmidx_linear_get_dim(const mmidx_linear *l, int *D_out); /* vectorLength of the handle (bindings check array lengths against it) */
 int mmidx_linear_get_vector(const mmidx_linear *l, int64_t iid, double *out);
 int mmidx_linear_search(mmidx_linear *l, int k, int64_t nq, const double *Q, int32_t *iid_out, double *dist_out,
                         int32_t *count_out);
@@ -346,6 +347,7 @@ typedef struct mmidx_pca mmidx_pca;
 int mmidx_pca_create(int nc, int ss, int whitening, const double *means, const double *eig,
                      const double *Vt, int device, mmidx_pca **out);
 int mmidx_pca_destroy(mmidx_pca *p);
+int mmidx_pca_get_dims(const mmidx_pca *p, int *nc_out, int *ss_out); /* numComponents, sampleSize of the handle */
 int mmidx_pca_project(mmidx_pca *p, int64_t n, const double *X, double *Y);
 int mmidx_pca_project_device(mmidx_pca *p, int64_t n, const double *dX, double *dY, void *stream);
 
@@ -360,6 +362,7 @@ int mmidx_vlad_create(int nvocab, const int32_t *ncent, int dl, const double *co
                       int normalizations_on, int device, mmidx_vlad **out);
 int mmidx_vlad_destroy(mmidx_vlad *v);
 int mmidx_vlad_vector_length(const mmidx_vlad *v, int *len_out);
+int mmidx_vlad_descriptor_length(const mmidx_vlad *v, int *dl_out);
 int mmidx_vlad_aggregate(mmidx_vlad *v, int64_t nimg, const int64_t *desc_off, const double *descs,
                          double *out);
 int mmidx_vlad_aggregate_device(mmidx_vlad *v, int64_t nimg, const int64_t *d_desc_off,

@@ -113,6 +113,9 @@ SIGNATURES = {
     "mmidx_shard_info": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "mmidx_search_sliced_device": (C.c_int, [_vp, C.c_int, C.c_int64, _vp, _vp, _vp, _vp]),
     "mmidx_add_vectors_sliced_device": (C.c_int, [_vp, _vp, _vp, C.c_int32]),
+    "mmidx_pca_get_dims": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mmidx_vlad_descriptor_length": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "mmidx_linear_get_dim": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "mmidx_probe_lds_gather": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp]),
     "mmidx_probe_f64_mfma": (C.c_int, [C.c_int, _dp]),
     "mmidx_set_profiling": (C.c_int, [_vp, C.c_int]),

@@ -315,7 +315,14 @@ struct DeviceCall {
     hipStream_t st;
     std::unique_lock<std::recursive_mutex> lk;
     DeviceCall(mmidx_index *h_, hipStream_t st_) : h(h_), st(st_), lk(h_->search_mu) {
-        if (h->last_stream_valid && h->last_stream != st) (void)hipStreamSynchronize(h->last_stream);
+        if (h->last_stream_valid && h->last_stream != st) {
+            // (a caller may have destroyed the stream of its previous call -- stream pools, short-lived streams: HIP then
+            //  rejects the handle, and whatever that call left running is waited for device-wide instead)
+            if (hipStreamSynchronize(h->last_stream) != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipDeviceSynchronize();
+            }
+        }
     }
     ~DeviceCall() {
         h->last_stream = st;
@@ -2642,6 +2649,7 @@ int mmidx_get_codes(mmidx_index *h, int64_t n, const int32_t *iids, int32_t *cel
     if (h->grp) return sharded_get_codes(h, n, iids, cell_out, code_out);
     int rc = set_device(h);
     if (rc) return rc;
+    DeviceCall call(h, h->stream);  // (the CSR rebuild below must not move the arrays under a search another stream is still running)
     std::lock_guard<std::mutex> lk(h->mu);
     int32_t *d_pos = nullptr;
     void *d_code = nullptr;
@@ -2667,6 +2675,7 @@ int mmidx_distance(mmidx_index *h, int64_t n, const double *Q, const int32_t *ii
     if (n == 0) return MMIDX_OK;
     rc = set_device(h);
     if (rc) return rc;
+    DeviceCall call(h, h->stream);
     std::lock_guard<std::mutex> lk(h->mu);
     int32_t *d_pos = nullptr;
     void *d_code = nullptr;
@@ -2787,6 +2796,13 @@ int mmidx_pca_create(int nc, int ss, int whitening, const double *means, const d
     return MMIDX_OK;
 }
 
+int mmidx_pca_get_dims(const mmidx_pca *p, int *nc_out, int *ss_out) {
+    if (!p) return fail(MMIDX_ERR_INVALID_ARG, "null handle");
+    if (nc_out) *nc_out = p->nc;
+    if (ss_out) *ss_out = p->ss;
+    return MMIDX_OK;
+}
+
 int mmidx_pca_destroy(mmidx_pca *p) {
     if (!p) return MMIDX_OK;
     (void)hipSetDevice(p->device);
@@ -2873,6 +2889,12 @@ int mmidx_vlad_destroy(mmidx_vlad *v) {
     v->ws_off.release();
     if (v->stream) (void)hipStreamDestroy(v->stream);
     delete v;
+    return MMIDX_OK;
+}
+
+int mmidx_vlad_descriptor_length(const mmidx_vlad *v, int *dl_out) {
+    if (!v || !dl_out) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    *dl_out = v->dl;
     return MMIDX_OK;
 }
 
@@ -3038,6 +3060,12 @@ int mmidx_linear_add(mmidx_linear *l, int64_t n, const double *X) {  // indexVec
     const int64_t have = (int64_t)(l->X.size() / (size_t)l->D);
     if (l->capacity > 0 && have + n > l->capacity) return fail(MMIDX_ERR_CAPACITY, "Maximum index capacity reached, no more vectors can be indexed!");
     l->X.insert(l->X.end(), X, X + (size_t)n * l->D);
+    return MMIDX_OK;
+}
+
+int mmidx_linear_get_dim(const mmidx_linear *l, int *D_out) {
+    if (!l || !D_out) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    *D_out = l->D;
     return MMIDX_OK;
 }
 

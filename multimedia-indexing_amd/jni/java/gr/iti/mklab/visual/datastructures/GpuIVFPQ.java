@@ -50,8 +50,21 @@ public class GpuIVFPQ extends AbstractSearchStructure {
 					new java.util.Random(1)).getData();
 		}
 		// RandomPermutation(seed = 1, D) is derived natively with the JDK LCG (permutation == null)
-		handle = MmidxNative.create(MmidxNative.KIND_IVFPQ, vectorLength, numSubVectors, numProductCentroids,
-				numCoarseCentroids, transformation.ordinal(), null, rotation, Integer.getInteger("mmidx.device", 0));
+		// -Dmmidx.devices=0,1,...,7: the inverted lists are partitioned over these GPUs of the node (mmidx_create_sharded: one
+		// RCCL communicator and one native thread per device inside libmmidx_hip.so); otherwise one GPU, -Dmmidx.device=n
+		String devs = System.getProperty("mmidx.devices");
+		if (devs != null && !devs.trim().isEmpty()) {
+			String[] parts = devs.trim().split(",");
+			int[] devices = new int[parts.length];
+			for (int i = 0; i < parts.length; i++) {
+				devices[i] = Integer.parseInt(parts[i].trim());
+			}
+			handle = MmidxNative.createSharded(MmidxNative.KIND_IVFPQ, vectorLength, numSubVectors, numProductCentroids,
+					numCoarseCentroids, transformation.ordinal(), null, rotation, devices);
+		} else {
+			handle = MmidxNative.create(MmidxNative.KIND_IVFPQ, vectorLength, numSubVectors, numProductCentroids,
+					numCoarseCentroids, transformation.ordinal(), null, rotation, Integer.getInteger("mmidx.device", 0));
+		}
 		createOrOpenBDBEnvAndDbs(BDBEnvHome);
 		DatabaseConfig dbConf = new DatabaseConfig();
 		dbConf.setReadOnly(readOnly);

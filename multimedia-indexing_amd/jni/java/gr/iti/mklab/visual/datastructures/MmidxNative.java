@@ -16,6 +16,15 @@ public final class MmidxNative {
 			int numCoarseCentroids, int transformationOrdinal, int[] permutation, double[] rotation, int device)
 			throws Exception;
 
+	/**
+	 * mmidx_create_sharded: one index over the GPUs listed in devices (inverted list c lives on devices[c % devices.length]); every
+	 * other method takes the returned handle unchanged. One JVM drives all of them, as the reference's caller holds the whole
+	 * index in one process.
+	 */
+	public static native long createSharded(int kind, int vectorLength, int numSubVectors, int numProductCentroids,
+			int numCoarseCentroids, int transformationOrdinal, int[] permutation, double[] rotation, int[] devices)
+			throws Exception;
+
 	public static native void destroy(long handle);
 
 	public static native void setCoarse(long handle, double[] flatCoarse) throws Exception;

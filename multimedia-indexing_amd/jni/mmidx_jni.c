@@ -97,6 +97,28 @@ done:
     return (jlong)(intptr_t)h;
 }
 
+/* mmidx_create_sharded: ONE index over several GPUs of the node, driven from this JVM (the reference's caller is one process
+ * holding the whole index, YFCC100MExample.java:93-99); every other entry point takes the returned handle unchanged */
+JNIEXPORT jlong JNICALL JFN(createSharded)(JNIEnv *env, jclass c, jint kind, jint D, jint m, jint ks, jint C, jint transform, jintArray perm,
+                                           jdoubleArray rot, jintArray devices) {
+    mmidx_index *h = NULL;
+    jint *p = NULL, *dv = NULL;
+    jdouble *r = NULL;
+    jint ndev;
+    (void)c;
+    if (bad_len(env, perm, D, 1, "permutation") || bad_len(env, rot, (int64_t)D * D, 1, "rotation") || bad_len(env, devices, 1, 0, "devices")) return 0;
+    ndev = (*env)->GetArrayLength(env, devices);
+    p = perm ? (*env)->GetIntArrayElements(env, perm, NULL) : NULL;
+    r = rot ? (*env)->GetDoubleArrayElements(env, rot, NULL) : NULL;
+    dv = (*env)->GetIntArrayElements(env, devices, NULL);
+    CHECK(mmidx_create_sharded(kind, D, m, ks, C, transform, (const int32_t *)p, r, ndev, (const int *)dv, &h));
+done:
+    if (p) (*env)->ReleaseIntArrayElements(env, perm, p, JNI_ABORT);
+    if (r) (*env)->ReleaseDoubleArrayElements(env, rot, r, JNI_ABORT);
+    if (dv) (*env)->ReleaseIntArrayElements(env, devices, dv, JNI_ABORT);
+    return (jlong)(intptr_t)h;
+}
+
 JNIEXPORT void JNICALL JFN(destroy)(JNIEnv *env, jclass c, jlong h) {
     (void)env;
     (void)c;
@@ -335,7 +357,14 @@ JNIEXPORT void JNICALL JFN(linearDestroy)(JNIEnv *env, jclass c, jlong h) {
 JNIEXPORT void JNICALL JFN(linearAdd)(JNIEnv *env, jclass c, jlong h, jint n, jint D, jdoubleArray flat) {
     jdouble *a;
     (void)c;
-    if (bad_len(env, flat, (int64_t)n * D, 0, "vectors")) return;
+    {   /* the vector length is the native object's, not the caller's word for it */
+        int dn = 0;
+        if (mmidx_linear_get_dim(HL(h), &dn) != MMIDX_OK || dn != D) {
+            throw_msg(env, "java/lang/Exception", "The dimensionality of the vector is wrong!"); /* Linear.java:113 */
+            return;
+        }
+    }
+    if (n < 0 || bad_len(env, flat, (int64_t)n * D, 0, "vectors")) return;
     a = (*env)->GetDoubleArrayElements(env, flat, NULL);
     CHECK(mmidx_linear_add(HL(h), n, a));
 done:
@@ -347,7 +376,14 @@ JNIEXPORT void JNICALL JFN(linearSearch)(JNIEnv *env, jclass c, jlong h, jint k,
     jdouble *q, *dd;
     jint *ii, *cc;
     (void)c;
-    if (bad_len(env, queries, (int64_t)nq * D, 0, "queries") || bad_len(env, iidOut, (int64_t)nq * k, 0, "iidOut") ||
+    {
+        int dn = 0;
+        if (mmidx_linear_get_dim(HL(h), &dn) != MMIDX_OK || dn != D) {
+            throw_msg(env, "java/lang/Exception", "The dimensionality of the vector is wrong!");
+            return;
+        }
+    }
+    if (nq < 0 || k < 1 || bad_len(env, queries, (int64_t)nq * D, 0, "queries") || bad_len(env, iidOut, (int64_t)nq * k, 0, "iidOut") ||
         bad_len(env, distOut, (int64_t)nq * k, 0, "distOut") || bad_len(env, countOut, nq, 0, "countOut"))
         return;
     q = (*env)->GetDoubleArrayElements(env, queries, NULL);
@@ -391,7 +427,14 @@ JNIEXPORT void JNICALL JFN(pcaDestroy)(JNIEnv *env, jclass c, jlong p) {
 JNIEXPORT void JNICALL JFN(pcaProject)(JNIEnv *env, jclass c, jlong p, jint n, jint ss, jint nc, jdoubleArray x, jdoubleArray y) {
     jdouble *x_, *y_;
     (void)c;
-    if (bad_len(env, x, (int64_t)n * ss, 0, "samples") || bad_len(env, y, (int64_t)n * nc, 0, "projected")) return;
+    {   /* sampleSize / numComponents are the native object's: a wrapper that disagrees must not size the copies */
+        int nn = 0, sn = 0;
+        if (mmidx_pca_get_dims((const mmidx_pca *)(intptr_t)p, &nn, &sn) != MMIDX_OK || nn != nc || sn != ss) {
+            throw_msg(env, "java/lang/IllegalArgumentException", "sampleSize / numComponents differ from the PCA object's");
+            return;
+        }
+    }
+    if (n < 0 || bad_len(env, x, (int64_t)n * ss, 0, "samples") || bad_len(env, y, (int64_t)n * nc, 0, "projected")) return;
     x_ = (*env)->GetDoubleArrayElements(env, x, NULL);
     y_ = (*env)->GetDoubleArrayElements(env, y, NULL);
     CHECK(mmidx_pca_project((mmidx_pca *)(intptr_t)p, n, x_, y_));
@@ -445,8 +488,24 @@ JNIEXPORT void JNICALL JFN(vladAggregate)(JNIEnv *env, jclass c, jlong v, jlong 
     if (bad_len(env, descOff, 1, 0, "descOff")) return;
     nimg = (*env)->GetArrayLength(env, descOff) - 1;
     off_ = (*env)->GetLongArrayElements(env, descOff, NULL);
-    if (off_[0] != 0 || bad_len(env, descs, (int64_t)off_[nimg] * dl, 0, "descriptors") || bad_len(env, out, (int64_t)nimg * outLen, 0, "out")) {
-        if (off_[0] != 0) throw_msg(env, "java/lang/IllegalArgumentException", "descOff[0] must be 0");
+    {   /* descriptor length and output length from the native objects; the offsets must be non-decreasing from 0 */
+        int dn = 0, vn = 0, pn = 0, ps = 0, bad = 0;
+        jint i;
+        if (mmidx_vlad_descriptor_length((const mmidx_vlad *)(intptr_t)v, &dn) != MMIDX_OK || mmidx_vlad_vector_length((const mmidx_vlad *)(intptr_t)v, &vn) != MMIDX_OK ||
+            (pca && mmidx_pca_get_dims((const mmidx_pca *)(intptr_t)pca, &pn, &ps) != MMIDX_OK))
+            bad = 1;
+        if (!bad && (dn != dl || (pca ? (pn != outLen || ps != vn) : vn != outLen))) bad = 1;
+        if (!bad && off_[0] != 0) bad = 2;
+        for (i = 0; !bad && i < nimg; i++)
+            if (off_[i + 1] < off_[i]) bad = 2;
+        if (bad) {
+            throw_msg(env, "java/lang/IllegalArgumentException",
+                      bad == 2 ? "descOff must start at 0 and be non-decreasing" : "descriptor / output lengths differ from the native objects'");
+            (*env)->ReleaseLongArrayElements(env, descOff, off_, JNI_ABORT);
+            return;
+        }
+    }
+    if (bad_len(env, descs, (int64_t)off_[nimg] * dl, 0, "descriptors") || bad_len(env, out, (int64_t)nimg * outLen, 0, "out")) {
         (*env)->ReleaseLongArrayElements(env, descOff, off_, JNI_ABORT);
         return;
     }

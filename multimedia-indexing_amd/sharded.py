@@ -222,9 +222,8 @@ class ShardedIVFPQ:
         # world == 1 normally short-circuits every collective; force_collectives issues them anyway
         # (a 1-rank process group) so that the RCCL calls can be exercised on a single-GPU box
         self.force = bool(force_collectives and dist is not None)
-        self.tie_slots = int(tie_slots)   # flagged queries replayed per owner and round; more are counted in tie_overflow
-        self.tie_overflow = 0             # device / host counter of flagged queries beyond the slots (results of those follow
-        #                                   the merge's (distance, probe rank, iid) order instead of the queue's)
+        self.tie_slots = int(tie_slots)   # flagged queries replayed per owner and round; the replay runs in as many rounds as the
+        self.tie_overflow = 0             # busiest owner needs (tie_overflow stays 0: kept for callers that read it)
         # two sub-batches in flight hide the host's wait for the exchange sizes behind the second one's kernels; with one rank
         # there is nothing to hide and two half batches only cost their fixed overheads twice
         self.pipeline = (world > 1) if pipeline is None else bool(pipeline)
@@ -393,37 +392,40 @@ class ShardedIVFPQ:
         Fo = self.tie_slots
         n_own = iid.shape[0]
         dev = iid.device
-        # my flagged queries -> at most Fo slots (local row, global query index, tau = the k-th distance)
         fl = flag[:n_own].to(torch.int64)
-        pos = torch.cumsum(fl, 0) - fl                      # slot of every flagged row
-        take = (fl > 0) & (pos < Fo)
-        self.tie_overflow = self.tie_overflow + (fl.sum() - take.sum())
-        # (no nonzero(): it would synchronise with the host) every taken row scatters its index to its slot, the others to a
-        # scratch slot past the end
-        rows_x = torch.full((Fo + 1,), -1, dtype=torch.int64, device=dev)
-        rows_x.scatter_(0, torch.where(take, pos, torch.full_like(pos, Fo)), torch.arange(n_own, dtype=torch.int64, device=dev))
-        rows = rows_x[:Fo]
-        valid = rows >= 0
-        safe = torch.where(valid, rows, torch.zeros_like(rows))
-        fq_own = torch.where(valid, (safe + q0).to(torch.int32), torch.full((Fo,), -1, dtype=torch.int32, device=dev))
-        tau_own = torch.where(valid, dist_[safe, k - 1], torch.zeros(Fo, dtype=dist_.dtype, device=dev))
-        fq = self._all_gather(fq_own).reshape(-1).contiguous()          # [W * Fo]
-        tau = self._all_gather(tau_own).reshape(-1).contiguous()
-        F = fq.shape[0]
+        pos = torch.cumsum(fl, 0) - fl                      # ordinal of every flagged row
+        # every owner replays Fo flagged queries per round; the MAX all-reduce above gave all ranks the same number of rounds
+        rounds = (int(nfl.item()) + Fo - 1) // Fo
+        self.tie_rounds = getattr(self, "tie_rounds", 0) + rounds
         w = st["cells"].shape[1]
-        counts = torch.zeros((F, w, 2), dtype=torch.int32, device=dev)
-        pB = torch.zeros(F, dtype=torch.int32, device=dev)
-        ties = torch.full((F, k), -1, dtype=torch.int32, device=dev)
-        self.engine.tie_phase(0, k, st["Q"], st["cells"], fq, tau, counts, pB, ties)
-        self._all_reduce(counts, "SUM")
-        self.engine.tie_phase(1, k, st["Q"], st["cells"], fq, tau, counts, pB, ties)
-        self._all_reduce(pB, "SUM")
-        self.engine.tie_phase(2, k, st["Q"], st["cells"], fq, tau, counts, pB, ties)
-        self._all_reduce(ties, "MAX")
-        mine = ties[self.rank * Fo:(self.rank + 1) * Fo] if self._collective() or W > 1 else ties[:Fo]
-        # kept ties overwrite their slots of the flagged rows; unused slots (row -1) are routed to a scratch row
-        iid_x = torch.cat([iid, torch.zeros((1, k), dtype=iid.dtype, device=dev)], 0)
-        dst = torch.where(valid, rows, torch.full_like(rows, iid.shape[0]))
-        cur = iid_x[dst]
-        iid_x[dst] = torch.where(mine >= 0, mine, cur)
-        return iid_x[:iid.shape[0]]
+        for rnd in range(rounds):
+            take = (fl > 0) & (pos >= rnd * Fo) & (pos < (rnd + 1) * Fo)
+            # (no nonzero(): it would synchronise with the host) every taken row scatters its index to its slot, the others to a
+            # scratch slot past the end
+            rows_x = torch.full((Fo + 1,), -1, dtype=torch.int64, device=dev)
+            rows_x.scatter_(0, torch.where(take, pos - rnd * Fo, torch.full_like(pos, Fo)), torch.arange(n_own, dtype=torch.int64, device=dev))
+            rows = rows_x[:Fo]
+            valid = rows >= 0
+            safe = torch.where(valid, rows, torch.zeros_like(rows))
+            fq_own = torch.where(valid, (safe + q0).to(torch.int32), torch.full((Fo,), -1, dtype=torch.int32, device=dev))
+            tau_own = torch.where(valid, dist_[safe, k - 1], torch.zeros(Fo, dtype=dist_.dtype, device=dev))
+            fq = self._all_gather(fq_own).reshape(-1).contiguous()          # [W * Fo]
+            tau = self._all_gather(tau_own).reshape(-1).contiguous()
+            F = fq.shape[0]
+            counts = torch.zeros((F, w, 2), dtype=torch.int32, device=dev)
+            pB = torch.zeros(F, dtype=torch.int32, device=dev)
+            ties = torch.full((F, k), -1, dtype=torch.int32, device=dev)
+            self.engine.tie_phase(0, k, st["Q"], st["cells"], fq, tau, counts, pB, ties)
+            self._all_reduce(counts, "SUM")
+            self.engine.tie_phase(1, k, st["Q"], st["cells"], fq, tau, counts, pB, ties)
+            self._all_reduce(pB, "SUM")
+            self.engine.tie_phase(2, k, st["Q"], st["cells"], fq, tau, counts, pB, ties)
+            self._all_reduce(ties, "MAX")
+            mine = ties[self.rank * Fo:(self.rank + 1) * Fo] if self._collective() or W > 1 else ties[:Fo]
+            # kept ties overwrite their slots of the flagged rows; unused slots (row -1) are routed to a scratch row
+            iid_x = torch.cat([iid, torch.zeros((1, k), dtype=iid.dtype, device=dev)], 0)
+            dst = torch.where(valid, rows, torch.full_like(rows, iid.shape[0]))
+            cur = iid_x[dst]
+            iid_x[dst] = torch.where(mine >= 0, mine, cur)
+            iid = iid_x[:iid.shape[0]]
+        return iid
