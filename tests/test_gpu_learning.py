@@ -1,4 +1,4 @@
-"""GPU codebook learning (csrc/mmidx_learn.hip) against a numpy restatement of the same algorithm.
+"""GPU codebook learning (csrc/mmidx_learn.hip) against the CPU restatement of the same algorithm (oracle/kmeans_oracle.py).
 
 Weka's SimpleKMeans is an absent third-party dependency (parity with the reference unpinned for this row);
 what IS pinned here: from identical seeds the GPU path and the numpy restatement below produce bit-identical
@@ -26,64 +26,9 @@ def mi():
     return m
 
 
-class JavaRandom:
-    def __init__(self, seed):
-        self.s = (seed ^ 0x5DEECE66D) & ((1 << 48) - 1)
+from oracle import kmeans_oracle as ko  # noqa: E402  (the CPU restatement: oracle/kmeans_oracle.py, parity unpinned -- Weka is absent)
 
-    def next(self, bits):
-        self.s = (self.s * 0x5DEECE66D + 0xB) & ((1 << 48) - 1)
-        v = self.s >> (48 - bits)
-        return v - (1 << bits) if v >= (1 << (bits - 1)) and bits == 32 else v
-
-    def nextInt(self, bound):
-        r = self.next(31)
-        m = bound - 1
-        if bound & m == 0:
-            return (bound * r) >> 31
-        u = r
-        while True:
-            r = u % bound
-            if u - r + m < (1 << 31):
-                return r
-            u = self.next(31)
-
-    def nextDouble(self):
-        return ((self.next(26) << 27) + self.next(27)) * 2.0 ** -53
-
-
-def seq_sqdist(x, c):
-    acc = 0.0
-    for a, b in zip(x, c):
-        df = a - b
-        acc += df * df
-    return acc
-
-
-def lloyd_twin(X, C0, max_iter):
-    """Lloyd exactly as the kernels do it: sequential fp64 distance, first index wins, index-ordered sums."""
-    C = C0.copy()
-    a_old = np.full(len(X), -1)
-    iters = 0
-    while True:
-        iters += 1
-        a = np.array([int(np.argmin([seq_sqdist(x, c) for c in C])) for x in X])
-        changed = int((a != a_old).sum())
-        newC, keep = [], []
-        for c in range(len(C)):
-            mem = np.nonzero(a == c)[0]
-            if len(mem):
-                acc = np.zeros(X.shape[1])
-                for i in mem:
-                    acc = acc + X[i]
-                newC.append(acc / float(len(mem)))
-                keep.append(c)
-        done = changed == 0 or iters >= max_iter
-        dropped = len(keep) != len(C)
-        remap = {c: t for t, c in enumerate(keep)}
-        C = np.array(newC)
-        if done:
-            return C, np.array([remap[c] for c in a]), iters
-        a_old = np.full(len(X), -1) if dropped else a
+JavaRandom, seq_sqdist, lloyd_twin = ko.JavaRandom, ko.seq_sqdist, ko.lloyd
 
 
 def test_lloyd_matches_twin_bit_for_bit(mi):
@@ -104,14 +49,7 @@ def test_random_seeding_follows_the_jdk_stream(mi):
     rng = np.random.default_rng(5)
     X = rng.standard_normal((400, 4))
     k, seed = 7, 1
-    r = JavaRandom(seed)
-    perm, picks = list(range(len(X))), []
-    for j in range(len(X) - 1, -1, -1):
-        i = r.nextInt(j + 1)
-        picks.append(perm[i])
-        perm[j], perm[i] = perm[i], perm[j]
-        if len(picks) == k:
-            break
+    picks = ko.random_seeding(X, k, seed)
     cent, assign, _, iters = q.kmeans(X, k, maxIterations=1, seed=seed, normalize=False)
     tC, tA, _ = lloyd_twin(X, X[picks], 1)
     assert iters == 1 and np.array_equal(cent, tC) and np.array_equal(assign, tA)
@@ -122,17 +60,7 @@ def test_kmeans_plus_plus_seeding(mi):
     rng = np.random.default_rng(6)
     X = rng.standard_normal((300, 3))
     k, seed = 5, 2
-    r = JavaRandom(seed)
-    picks = [r.nextInt(len(X))]
-    d2 = None
-    for _ in range(1, k):
-        nd = np.array([seq_sqdist(x, X[picks[-1]]) for x in X])
-        d2 = nd if d2 is None else np.minimum(d2, nd)
-        cum = np.cumsum(d2)  # (the device scan may associate differently: the pick is checked with a margin below)
-        target = r.nextDouble() * cum[-1]
-        idx = int(np.searchsorted(cum, target, side="right"))
-        assert abs(cum[idx] - target) > 1e-9 * cum[-1], "fixture too close to a bucket edge"
-        picks.append(min(idx, len(X) - 1))
+    picks = ko.plus_plus_seeding(X, k, seed)  # (raises if a draw sits on a bucket edge, where a parallel scan could differ)
     cent, assign, _, _ = q.kmeans(X, k, maxIterations=1, seed=seed, kMeansPlusPlus=True, normalize=False)
     tC, tA, _ = lloyd_twin(X, X[picks], 1)
     assert np.array_equal(cent, tC) and np.array_equal(assign, tA)
@@ -149,7 +77,7 @@ def test_empty_clusters_are_dropped_and_normalisation(mi):
     # Weka's default distance normalises every attribute to [0, 1]: a badly scaled attribute no longer dominates
     Y = np.stack([np.r_[np.zeros(100), np.ones(100)] + 0.01 * rng.standard_normal(200), 1e4 * rng.standard_normal(200)], 1)
     cN, aN, _, _ = q.kmeans(Y, 2, maxIterations=50, init=Y[[0, 150]], normalize=True)
-    twin_norm = (Y - Y.min(0)) / (Y.max(0) - Y.min(0))
+    twin_norm = ko.minmax_normalise(Y)
     tC, tA, _ = lloyd_twin(twin_norm, twin_norm[[0, 150]], 50)
     assert np.array_equal(aN, tA)
     for c in range(2):  # centroids are reported in the original space: means of the un-normalised members
