@@ -268,6 +268,7 @@ struct mmidx_index {
     int64_t inv_size = 0;
     DevBuf<int32_t> ws_gfb;
     DevBuf<int64_t> ws_flatoff;  // flat PQ through K3g: chunk offsets standing in for list offsets
+    DevBuf<double> ws_flatlut;   // ... and the queries' exact lookup tables [nq][m][256] (k_flat_lut)
     double *d_zero = nullptr;    // ... and the zero "centroid"
 
     // profiling: HIP events recorded on the launch stream, resolved lazily by mmidx_get_stats
@@ -917,7 +918,7 @@ int launch_grp_t(mmidx_index *h, const GrpParams &GP, size_t lds, hipStream_t st
 // Returns 1 when K3g does not apply (the caller uses K3f).
 // S: the scan parameters K3g runs with; F: those of the K3f launch that serves the handed-back (pair, chunk) items
 int launch_grouped_common(mmidx_index *h, const ScanParams &S, ScanParams F, const SearchPlan &pl, int nlists, int nchunks, long long npairs,
-                          hipStream_t st) {
+                          hipStream_t st, const double *flat_lut = nullptr) {
     const int G = h->m >= 32 ? 4 : 8;  // (the u8 rows of a group: G x m x 256 bytes <= 64 KiB, the reach of a ds_read's immediate offset)
     int cb = 1;
     while (cb < pl.K1 + GRP_VR) cb <<= 1;
@@ -944,6 +945,7 @@ int launch_grouped_common(mmidx_index *h, const ScanParams &S, ScanParams F, con
     GP.fb_items = h->ws_gfb.p + 4;
     GP.fb_ch = h->ws_gfb.p + 4 + nfb;
     GP.cb = cb;
+    GP.flat_lut = flat_lut;
     GP.stat = (h->profiling == 1 || h->debug_sync) ? (unsigned long long *)(h->d_counters + 3) : nullptr;  // [0] verified, [1] flag (adds), [2..3] item statistics
     int rc;
     const int ds = h->dsub;
@@ -1019,7 +1021,25 @@ int launch_scan_grouped_flat(mmidx_index *h, const ScanParams &P, const SearchPl
     S.order = h->ws_order.p;
     S.n_order = nullptr;
     S.chunk = pl.chunk;
-    return launch_grouped_common(h, S, P, pl, nch, 1, npairs, st);
+    // one exact table per query for the whole list (PQ.java:300): the survivors of every chunk are verified by table reads
+    const double *flat_lut = nullptr;
+    if (h->dsub <= 64 && (size_t)nq * h->m * 256 * 8 <= ((size_t)2 << 30)) {
+        HIPCK(h->ws_flatlut.reserve((size_t)nq * h->m * 256));
+        for (long long q0 = 0; q0 < nq; q0 += 65535) {  // (grid.y <= 65535)
+            const dim3 g((unsigned)h->m, (unsigned)std::min<long long>(65535, nq - q0));
+            const double *Qc = P.Q + (size_t)q0 * h->D;
+            double *Lc = h->ws_flatlut.p + (size_t)q0 * h->m * 256;
+            switch (h->dsub) {
+                case 4: hipLaunchKernelGGL(k_flat_lut<4>, g, dim3(256), 0, st, Qc, h->d_perm, h->d_pqT, Lc, h->D, h->m, h->ks, h->dsub); break;
+                case 8: hipLaunchKernelGGL(k_flat_lut<8>, g, dim3(256), 0, st, Qc, h->d_perm, h->d_pqT, Lc, h->D, h->m, h->ks, h->dsub); break;
+                case 16: hipLaunchKernelGGL(k_flat_lut<16>, g, dim3(256), 0, st, Qc, h->d_perm, h->d_pqT, Lc, h->D, h->m, h->ks, h->dsub); break;
+                default: hipLaunchKernelGGL(k_flat_lut<0>, g, dim3(256), 0, st, Qc, h->d_perm, h->d_pqT, Lc, h->D, h->m, h->ks, h->dsub); break;
+            }
+        }
+        HIPCK(hipGetLastError());
+        flat_lut = h->ws_flatlut.p;
+    }
+    return launch_grouped_common(h, S, P, pl, nch, 1, npairs, st, flat_lut);
 }
 
 int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, hipStream_t st) {
@@ -1720,6 +1740,7 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_gdesc.release();
     h->ws_gfb.release();
     h->ws_flatoff.release();
+    h->ws_flatlut.release();
     h->ws_inv.release();
     if (h->d_pq32T) (void)hipFree(h->d_pq32T);
     if (h->d_pn32) (void)hipFree(h->d_pn32);
@@ -2822,7 +2843,8 @@ int mmidx_pca_project_device(mmidx_pca *p, int64_t n, const double *dX, double *
     HIPCK(hipSetDevice(p->device));
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)((n + PCA_BM - 1) / PCA_BM), (unsigned)((p->nc + PCA_BN - 1) / PCA_BN));
-    hipLaunchKernelGGL(k_pca_project, grid, dim3(256), 0, st, dX, p->d_mu, p->d_Vt, dY, (long long)n, p->nc, p->ss);
+    HIPCK(hipFuncSetAttribute((const void *)k_pca_project, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PCA_LDS_BYTES));
+    hipLaunchKernelGGL(k_pca_project, grid, dim3(PCA_NT), PCA_LDS_BYTES, st, dX, p->d_mu, p->d_Vt, dY, (long long)n, p->nc, p->ss);
     if (p->whitening)
         hipLaunchKernelGGL(k_rows_normalize_l2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dY, (long long)n, p->nc);
     HIPCK(hipGetLastError());

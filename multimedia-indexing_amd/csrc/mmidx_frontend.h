@@ -23,16 +23,26 @@ typedef __attribute__((ext_vector_type(4))) double f64x4;
 // (assumption A2); the MFMA chain is fused and k-blocked, so parity for this kernel is a
 // tolerance (1e-12 relative to the row norm), never bit-equality.
 // ------------------------------------------------------------------------------------------------
-#define PCA_BM 64
+#ifndef PCA_BM
+#define PCA_BM 64   // rows per block: 16 per wave
+#endif
+#define PCA_NT (PCA_BM * 4)  // threads per block
 #define PCA_BN 128
-#define PCA_BK 16
-#define PCA_LD 17  // padded row stride in doubles
+#ifndef PCA_BK
+#define PCA_BK 32   // k per staged tile: 256 contiguous bytes of every X row per request (16: 37 TF, 24: 38.8, 32: 40.3 of the 67.6 TF
+#endif              // the f64 matrix cores deliver back to back -- the X rows are 64 KiB apart, short row segments waste DRAM pages)
+#define PCA_LD (PCA_BK + 1)  // padded row stride in doubles
+#define PCA_PPR (PCA_BK / 2)  // pairs of doubles per tile row
+#define PCA_NA (PCA_BM * PCA_PPR / PCA_NT)  // pairs per thread: X tile
+#define PCA_NB (PCA_BN * PCA_PPR / PCA_NT)  // ... Vt tile
+#define PCA_LDS_BYTES ((PCA_BM + PCA_BN) * PCA_LD * 8)
 
-__global__ __launch_bounds__(256) void k_pca_project(const double *__restrict__ X, const double *__restrict__ mu,
-                                                     const double *__restrict__ Vt, double *__restrict__ Y,
-                                                     long long n, int nc, int ss) {
-    __shared__ double As[PCA_BM * PCA_LD];
-    __shared__ double Bs[PCA_BN * PCA_LD];
+__global__ __launch_bounds__(PCA_NT) void k_pca_project(const double *__restrict__ X, const double *__restrict__ mu,
+                                                        const double *__restrict__ Vt, double *__restrict__ Y,
+                                                        long long n, int nc, int ss) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pca_smem[];
+    double *As = (double *)pca_smem;         // [PCA_BM][PCA_LD]
+    double *Bs = As + PCA_BM * PCA_LD;       // [PCA_BN][PCA_LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long row0 = (long long)blockIdx.x * PCA_BM;
     const int col0 = blockIdx.y * PCA_BN;
@@ -40,11 +50,11 @@ __global__ __launch_bounds__(256) void k_pca_project(const double *__restrict__ 
 #pragma unroll
     for (int t = 0; t < 8; t++) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
     // staging: A 64 rows x 16 k = 512 pairs of doubles -> 2 per thread; B 128 x 16 = 1024 pairs -> 4 per thread
-    double2 ra[2], rb[4];
+    double2 ra[PCA_NA], rb[PCA_NB];
     auto load_tiles = [&](int k0) {
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int p = tid + u * 256, r = p >> 3, c = (p & 7) * 2;
+        for (int u = 0; u < PCA_NA; u++) {
+            const int p = tid + u * PCA_NT, r = p / PCA_PPR, c = (p % PCA_PPR) * 2;
             const long long gr = row0 + r;
             double2 v = make_double2(0.0, 0.0);
             if (gr < n) {
@@ -59,8 +69,8 @@ __global__ __launch_bounds__(256) void k_pca_project(const double *__restrict__ 
             ra[u] = v;
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int p = tid + u * 256, r = p >> 3, c = (p & 7) * 2;
+        for (int u = 0; u < PCA_NB; u++) {
+            const int p = tid + u * PCA_NT, r = p / PCA_PPR, c = (p % PCA_PPR) * 2;
             const int gc = col0 + r;
             double2 v = make_double2(0.0, 0.0);
             if (gc < nc) {
@@ -77,14 +87,14 @@ __global__ __launch_bounds__(256) void k_pca_project(const double *__restrict__ 
     };
     auto store_tiles = [&]() {
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int p = tid + u * 256, r = p >> 3, c = (p & 7) * 2;
+        for (int u = 0; u < PCA_NA; u++) {
+            const int p = tid + u * PCA_NT, r = p / PCA_PPR, c = (p % PCA_PPR) * 2;
             As[r * PCA_LD + c] = ra[u].x;
             As[r * PCA_LD + c + 1] = ra[u].y;
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int p = tid + u * 256, r = p >> 3, c = (p & 7) * 2;
+        for (int u = 0; u < PCA_NB; u++) {
+            const int p = tid + u * PCA_NT, r = p / PCA_PPR, c = (p % PCA_PPR) * 2;
             Bs[r * PCA_LD + c] = rb[u].x;
             Bs[r * PCA_LD + c + 1] = rb[u].y;
         }

@@ -67,7 +67,29 @@ struct GrpParams {
     int32_t *fb_items, *fb_ch;
     int cb;                   // candidate buffer entries per query: power of two >= K1 + GRP_VR
     unsigned long long *stat; // null, or: [0] += filter survivors that were verified exactly
+    // flat PQ only (PQ.computeKnnADC builds ONE table per query, PQ.java:300 -> :387-399, whatever part of the list is scanned):
+    // [nq][M][256] exact fp64 tables written by k_flat_lut before the scan; a survivor's distance is then M table reads summed in
+    // sub-quantizer order -- the reference's own loop (PQ.java:308-311) -- instead of M x dsub codebook terms.  null: IVF.
+    const double *flat_lut;
 };
+
+// flat PQ: the queries' exact lookup tables, block (s, q) <-> sub-quantizer s of query q, thread j <-> entry j
+// (computeLookupADC PQ.java:387-399: t ascending from 0.0; the permutation of PQ.java:294-298 applied to the query first)
+template <int DSUB>
+__global__ __launch_bounds__(256) void k_flat_lut(const double *__restrict__ Q, const int32_t *__restrict__ perm, const double *__restrict__ pqT,
+                                                  double *__restrict__ lut, int D, int m, int ks, int dsub) {
+    __shared__ double tr[64];  // the sub-vector (dsub <= 64: the host checks)
+    const int s = blockIdx.x, j = threadIdx.x;
+    const long long q = blockIdx.y;
+    if (j < dsub) {
+        const int d = s * dsub + j;
+        tr[j] = Q[(size_t)q * D + (perm ? perm[d] : d)];
+    }
+    __syncthreads();
+    // (lut_entry indexes the vector by s * dsub: hand it the sub-vector's base shifted back)
+    const double e = j < ks ? lut_entry<DSUB>(tr - s * (DSUB > 0 ? DSUB : dsub), pqT, s, j, ks, dsub) : __longlong_as_double(0x7FF0000000000000ll);
+    lut[((size_t)q * m + s) * 256 + j] = e;
+}
 
 // LDS layout, shared by host (size) and device (offsets)
 struct GrpLds {
@@ -755,7 +777,35 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
                     const int i = (int)(ent >> 24);
                     const u32 pos = ent & 0xFFFFFFu;
                     double d = 0.0;
-                    if constexpr (DSUB == 8 || DSUB == 16) {
+                    if (P.flat_lut) {
+                        // flat PQ: the query's own table (k_flat_lut), EPL reads per lane, the sum handed down the quad in
+                        // sub-quantizer order: ((0 + e_0) + e_1) + ...  (a uniform branch: P.flat_lut is a kernel argument)
+                        const u32 coff = pos * (u32)M + (u32)(ql * EPL);
+                        u32 cw[(EPL + 3) / 4];
+                        if constexpr (EPL >= 4) {
+#pragma unroll
+                            for (int x = 0; x < EPL / 4; x++) cw[x] = *(const u32 *)(codes + coff + 4 * x);
+                        } else {
+                            cw[0] = (u32) * (const unsigned short *)(codes + coff);
+                        }
+                        const double *lq = P.flat_lut + (size_t)s_q[i] * (size_t)(M * 256);
+                        double en[EPL];
+#pragma unroll
+                        for (int k = 0; k < EPL; k++) {
+                            const int s = ql * EPL + k;
+                            const u32 cs = (cw[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                            en[k] = lq[s * 256 + (int)cs];
+                        }
+#pragma unroll
+                        for (int ph = 0; ph < 4; ph++) {
+                            const double din = quad_prev_f64(d);
+                            if (ql == ph) {
+                                d = ph ? din : 0.0;
+#pragma unroll
+                                for (int k = 0; k < EPL; k++) d += en[k];
+                            }
+                        }
+                    } else if constexpr (DSUB == 8 || DSUB == 16) {
                         // Quad-wide entries: the four lanes read the survivor's whole code (one request per quad) and every
                         // codebook entry TOGETHER -- lane ql holds doubles 8r + 2ql, 8r + 2ql + 1 of round r, 64 contiguous bytes
                         // per quad and load -- instead of each lane fetching its own entries 16 bytes at a time (64 separate

@@ -13,7 +13,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COMMON = ["--vectors", "3000000", "--cells", "512", "--w", "8", "--chunk", "500000", "--nbatches", "2", "--steps", "2", "--warmup", "1",
-          "--settle", "2", "--no-cpu", "--gt", "0", "--hard-steps", "0", "--other-configs", "0", "--exhaustive-steps", "0"]
+          "--settle", "2", "--no-cpu", "--gt", "0", "--hard-steps", "0", "--spread-steps", "0", "--other-configs", "0", "--exhaustive-steps", "0", "--extras", "0"]
 
 
 def _run(cmd, env):
