@@ -269,6 +269,10 @@ struct mmidx_index {
     DevBuf<int32_t> ws_gfb;
     DevBuf<int64_t> ws_flatoff;  // flat PQ through K3g: chunk offsets standing in for list offsets
     DevBuf<double> ws_flatlut;   // ... and the queries' exact lookup tables [nq][m][256] (k_flat_lut)
+    DevBuf<u32> ws_ghist;        // K3g: per-query histogram of accepted candidates [nq][256] (thresholds from the union over lists)
+    DevBuf<u64> ws_T0;           // ... and pass A's thresholds as the launch found them
+    int no_union = 0;            // option "no_union": K3g without that histogram (A/B switch)
+    void *d_grpx = nullptr, *pin_grpx = nullptr;  // K3g's GrpExtra on the device and its pinned mirror
     double *d_zero = nullptr;    // ... and the zero "centroid"
 
     // profiling: HIP events recorded on the launch stream, resolved lazily by mmidx_get_stats
@@ -887,29 +891,29 @@ int build_grp_tables(mmidx_index *h) {
     return MMIDX_OK;
 }
 
-template <int M, int G, int DSUB>
+template <int M, int G, int DSUB, bool FLAT = false, bool UNION = false>
 int launch_grp_t(mmidx_index *h, const GrpParams &GP, size_t lds, hipStream_t st) {
     {   // the scan addresses the u8 rows from LDS address 0 (GrpLds::lut8 == 0, byte_x8): the kernel must not own static LDS
         static int static_lds = -1;
         if (static_lds < 0) {
             hipFuncAttributes fa{};
-            HIPCK(hipFuncGetAttributes(&fa, (const void *)k_scan_grp<M, G, DSUB>));
+            HIPCK(hipFuncGetAttributes(&fa, (const void *)k_scan_grp<M, G, DSUB, FLAT, UNION>));
             static_lds = (int)fa.sharedSizeBytes;
         }
         if (static_lds != 0) return 1;  // (K3f takes the pairs)
     }
-    HIPCK(hipFuncSetAttribute((const void *)k_scan_grp<M, G, DSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCK(hipFuncSetAttribute((const void *)k_scan_grp<M, G, DSUB, FLAT, UNION>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int blocks = h->grp_blocks;
     if (blocks <= 0) {
         int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_scan_grp<M, G, DSUB>, GRP_NT, lds) != hipSuccess || occ < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_scan_grp<M, G, DSUB, FLAT, UNION>, GRP_NT, lds) != hipSuccess || occ < 1) {
             (void)hipGetLastError();
             occ = 1;
         }
         blocks = occ * std::max(h->num_cus, 8);
     }
     blocks = std::max(8, (blocks + 7) & ~7);
-    hipLaunchKernelGGL((k_scan_grp<M, G, DSUB>), dim3((unsigned)blocks), dim3(GRP_NT), lds, st, GP);
+    hipLaunchKernelGGL((k_scan_grp<M, G, DSUB, FLAT, UNION>), dim3((unsigned)blocks), dim3(GRP_NT), lds, st, GP);
     HIPCK(hipGetLastError());
     return MMIDX_OK;
 }
@@ -918,7 +922,7 @@ int launch_grp_t(mmidx_index *h, const GrpParams &GP, size_t lds, hipStream_t st
 // Returns 1 when K3g does not apply (the caller uses K3f).
 // S: the scan parameters K3g runs with; F: those of the K3f launch that serves the handed-back (pair, chunk) items
 int launch_grouped_common(mmidx_index *h, const ScanParams &S, ScanParams F, const SearchPlan &pl, int nlists, int nchunks, long long npairs,
-                          hipStream_t st, const double *flat_lut = nullptr) {
+                          hipStream_t st, long long nq, const double *flat_lut = nullptr) {
     const int G = h->m >= 32 ? 4 : 8;  // (the u8 rows of a group: G x m x 256 bytes <= 64 KiB, the reach of a ds_read's immediate offset)
     int cb = 1;
     while (cb < pl.K1 + GRP_VR) cb <<= 1;
@@ -929,7 +933,7 @@ int launch_grouped_common(mmidx_index *h, const ScanParams &S, ScanParams F, con
     HIPCK(h->ws_gfb.reserve(4 + 2 * nfb + 16));
     if (h->debug_sync) HIPCK(hipMemsetAsync(h->ws_gfb.p, 0, (4 + 2 * nfb + 16) * sizeof(int32_t), st));
     hipLaunchKernelGGL(k_group_build, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, h->ws_pstart.p, nlists, G, h->ws_gdesc.p, h->ws_gfb.p,
-                       (u32 *)(h->ws_gfb.p + 1));
+                       (u32 *)(h->ws_gfb.p + 1), (unsigned long long *)(h->d_counters + 7), h->pin_hint ? h->pin_hint + 1 : nullptr);
     HIPCK(hipGetLastError());
     DBG_SYNC("K3g group build");
     GrpParams GP{};
@@ -945,31 +949,74 @@ int launch_grouped_common(mmidx_index *h, const ScanParams &S, ScanParams F, con
     GP.fb_items = h->ws_gfb.p + 4;
     GP.fb_ch = h->ws_gfb.p + 4 + nfb;
     GP.cb = cb;
-    GP.flat_lut = flat_lut;
+    GrpExtra GX{};
+    GX.flat_lut = flat_lut;
+    GX.nver = (unsigned long long *)(h->d_counters + 7);
+    // (IVF: only when the previous call left pass B something to do -- the histogram costs a 1 KiB-per-query memset, which the
+    //  separable benchmark, whose far probes all fall to the coarse bound, would pay for nothing; a stale hint costs speed, never results)
+    // ... and the UNION instance only when the call before verified more than a few codes per query (k_group_build reports it)
+    const bool union_worth = !S.ivf || (h->pin_hint && *(volatile int32_t *)h->pin_hint > 0 && (long long)*(volatile int32_t *)(h->pin_hint + 1) > 8 * nq);
+    if (!h->no_union && union_worth && nq > 0 && nq * 256 * 4 <= (1ll << 31)) {
+        HIPCK(h->ws_ghist.reserve((size_t)nq * 256));
+        HIPCK(h->ws_T0.reserve((size_t)nq));
+        HIPCK(hipMemsetAsync(h->ws_ghist.p, 0, (size_t)nq * 256 * sizeof(u32), st));
+        HIPCK(hipMemcpyAsync(h->ws_T0.p, S.T, (size_t)nq * sizeof(u64), hipMemcpyDeviceToDevice, st));
+        GX.ghist = h->ws_ghist.p;
+        GX.T0 = h->ws_T0.p;
+    }
     GP.stat = (h->profiling == 1 || h->debug_sync) ? (unsigned long long *)(h->d_counters + 3) : nullptr;  // [0] verified, [1] flag (adds), [2..3] item statistics
     int rc;
     const int ds = h->dsub;
+    // flat PQ with the queries' exact tables: its own instances (m = 8, 16 -- the others verify from the codebook as IVF does)
+    const bool flat_inst = GX.flat_lut && (h->m == 8 || h->m == 16);
+    if (!flat_inst) GX.flat_lut = nullptr;
+    // the extra pointers live in a small device struct, re-sent only when they change (pinned mirror; one search at a time per handle)
+    if (!h->d_grpx) {
+        HIPCK(hipMalloc((void **)&h->d_grpx, sizeof(GrpExtra)));
+        HIPCK(hipHostMalloc((void **)&h->pin_grpx, sizeof(GrpExtra)));
+        memset(h->pin_grpx, 0xFF, sizeof(GrpExtra));
+    }
+    if (memcmp(h->pin_grpx, &GX, sizeof(GrpExtra)) != 0) {
+        HIPCK(hipStreamSynchronize(st));  // (an earlier copy from the mirror may still be in flight)
+        memcpy(h->pin_grpx, &GX, sizeof(GrpExtra));
+        HIPCK(hipMemcpyAsync(h->d_grpx, h->pin_grpx, sizeof(GrpExtra), hipMemcpyHostToDevice, st));
+    }
+    GP.extra = (const GrpExtra *)h->d_grpx;
+    const bool un = GX.ghist != nullptr;  // (the instance that ranks the union of the verified candidates)
+#define GRP_GO(M_, G_, DS_) (un ? launch_grp_t<M_, G_, DS_, false, true>(h, GP, L.total, st) : launch_grp_t<M_, G_, DS_, false, false>(h, GP, L.total, st))
+    if (flat_inst) {
+        if (h->m == 8)
+            rc = ds == 16  ? launch_grp_t<8, 8, 16, true, true>(h, GP, L.total, st)
+                 : ds == 8 ? launch_grp_t<8, 8, 8, true, true>(h, GP, L.total, st)
+                 : ds == 4 ? launch_grp_t<8, 8, 4, true, true>(h, GP, L.total, st)
+                           : launch_grp_t<8, 8, 0, true, true>(h, GP, L.total, st);
+        else
+            rc = ds == 8   ? launch_grp_t<16, 8, 8, true, true>(h, GP, L.total, st)
+                 : ds == 4 ? launch_grp_t<16, 8, 4, true, true>(h, GP, L.total, st)
+                           : launch_grp_t<16, 8, 0, true, true>(h, GP, L.total, st);
+    } else
     switch (h->m) {
         case 8:
-            rc = ds == 16  ? launch_grp_t<8, 8, 16>(h, GP, L.total, st)
-                 : ds == 8 ? launch_grp_t<8, 8, 8>(h, GP, L.total, st)
-                 : ds == 4 ? launch_grp_t<8, 8, 4>(h, GP, L.total, st)
+            rc = ds == 16  ? GRP_GO(8, 8, 16)
+                 : ds == 8 ? GRP_GO(8, 8, 8)
+                 : ds == 4 ? GRP_GO(8, 8, 4)
                            : launch_grp_t<8, 8, 0>(h, GP, L.total, st);
             break;
         case 16:
-            rc = ds == 8   ? launch_grp_t<16, 8, 8>(h, GP, L.total, st)
-                 : ds == 4 ? launch_grp_t<16, 8, 4>(h, GP, L.total, st)
+            rc = ds == 8   ? GRP_GO(16, 8, 8)
+                 : ds == 4 ? GRP_GO(16, 8, 4)
                            : launch_grp_t<16, 8, 0>(h, GP, L.total, st);
             break;
         case 64:  // (YFCC100MExample.java:85-90: 1024 dimensions in 64 x 16)
-            rc = ds == 16  ? launch_grp_t<64, 4, 16>(h, GP, L.total, st)
-                 : ds == 8 ? launch_grp_t<64, 4, 8>(h, GP, L.total, st)
+            rc = ds == 16  ? GRP_GO(64, 4, 16)
+                 : ds == 8 ? GRP_GO(64, 4, 8)
                            : launch_grp_t<64, 4, 0>(h, GP, L.total, st);
             break;
         default:
-            rc = ds == 4 ? launch_grp_t<32, 4, 4>(h, GP, L.total, st) : launch_grp_t<32, 4, 0>(h, GP, L.total, st);
+            rc = ds == 4 ? GRP_GO(32, 4, 4) : launch_grp_t<32, 4, 0>(h, GP, L.total, st);
             break;
     }
+#undef GRP_GO
     if (rc) return rc;
     DBG_SYNC("K3g scan");
     if (h->debug_sync) {
@@ -992,7 +1039,7 @@ int launch_grouped_common(mmidx_index *h, const ScanParams &S, ScanParams F, con
 // Returns 1 when K3g does not apply (the caller uses K3f).
 int launch_scan_grouped(mmidx_index *h, const ScanParams &P, const SearchPlan &pl, long long nq, long long npairs, hipStream_t st) {
     if (h->no_grp || !h->grp_valid || !h->d_pq32T || h->no_filter || P.sdc_tt || !P.ivf || h->max_list_len >= (1 << 24)) return 1;
-    return launch_grouped_common(h, P, P, pl, h->C, pl.nchunks, npairs, st);
+    return launch_grouped_common(h, P, P, pl, h->C, pl.nchunks, npairs, st, nq);
 }
 
 // flat PQ pass B (chunks 1 .. of every query) through K3g: the chunks stand in for inverted lists (k_flat_pairs), the
@@ -1039,7 +1086,7 @@ int launch_scan_grouped_flat(mmidx_index *h, const ScanParams &P, const SearchPl
         HIPCK(hipGetLastError());
         flat_lut = h->ws_flatlut.p;
     }
-    return launch_grouped_common(h, S, P, pl, nch, 1, npairs, st, flat_lut);
+    return launch_grouped_common(h, S, P, pl, nch, 1, npairs, st, nq, flat_lut);
 }
 
 int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, hipStream_t st) {
@@ -1616,7 +1663,7 @@ int mmidx_create(int kind, int D, int m, int ks, int C, int transform, const int
         h->num_cus = ncu > 0 ? ncu : 256;
     }
     if (hipHostMalloc((void **)&h->pin_hint, 64) == hipSuccess) {
-        *h->pin_hint = 0;
+        memset(h->pin_hint, 0, 64);  // [0] pass B's pair count of the previous call, [1] codes its K3g verified
     } else {
         h->pin_hint = nullptr;  // (launches are then sized for the worst case)
         (void)hipGetLastError();
@@ -1741,6 +1788,10 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_gfb.release();
     h->ws_flatoff.release();
     h->ws_flatlut.release();
+    h->ws_ghist.release();
+    if (h->d_grpx) (void)hipFree(h->d_grpx);
+    if (h->pin_grpx) (void)hipHostFree(h->pin_grpx);
+    h->ws_T0.release();
     h->ws_inv.release();
     if (h->d_pq32T) (void)hipFree(h->d_pq32T);
     if (h->d_pn32) (void)hipFree(h->d_pn32);
@@ -2491,6 +2542,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->passa_wide = value;
     } else if (n == "no_grp") {  // pass B through K3f (one block per (query, list)) instead of the grouped K3g
         h->no_grp = value != 0;
+    } else if (n == "no_union") {  // K3g without the per-query histogram that lowers thresholds from the union over lists
+        h->no_union = value != 0;
     } else if (n == "grp_blocks") {
         h->grp_blocks = value > 0 ? value : 0;
     } else if (n == "passa_prefix") {

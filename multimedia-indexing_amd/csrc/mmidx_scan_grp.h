@@ -54,6 +54,22 @@
 #define GRP_WPS 4  // waves per SIMD the register allocation is held to (blocks per CU x 2)
 #endif
 
+struct GrpExtra {
+    // flat PQ only (PQ.computeKnnADC builds ONE table per query, PQ.java:300 -> :387-399, whatever part of the list is scanned):
+    // [nq][M][256] exact fp64 tables written by k_flat_lut before the scan; a survivor's distance is then M table reads summed in
+    // sub-quantizer order -- the reference's own loop (PQ.java:308-311) -- instead of M x dsub codebook terms.  null: IVF.
+    const double *flat_lut;
+    // Thresholds from the UNION of what the items of a query have verified so far (a block alone lowers T[q] only when ONE list
+    // fills its candidate buffer): ghist[q][256] counts the accepted candidates of query q by bucket floor(d * 256 / T0[q]), T0 =
+    // the threshold pass A left (copied before the launch: the map must not move).  K1 accepted candidates at or below a bucket
+    // mean K1 offers below that bucket's upper edge, so the edge is a valid threshold.  null: off.
+    u32 *ghist;
+    const u64 *T0;
+    // always on: codes verified exactly since k_group_build last looked (it reports the figure to the host through the pinned
+    // hint, and the host picks the UNION instance for the next call when the figure says verification is where the time goes)
+    unsigned long long *nver;
+};
+
 struct GrpParams {
     ScanParams S;             // Q, coarse, perm, list_off, codes, order (sorted pairs), T, pool_*, D, m, ks, dsub, w, transform, chunk, K1, poolq
     const double *pq;         // [m][ks][dsub] (file order)
@@ -67,10 +83,7 @@ struct GrpParams {
     int32_t *fb_items, *fb_ch;
     int cb;                   // candidate buffer entries per query: power of two >= K1 + GRP_VR
     unsigned long long *stat; // null, or: [0] += filter survivors that were verified exactly
-    // flat PQ only (PQ.computeKnnADC builds ONE table per query, PQ.java:300 -> :387-399, whatever part of the list is scanned):
-    // [nq][M][256] exact fp64 tables written by k_flat_lut before the scan; a survivor's distance is then M table reads summed in
-    // sub-quantizer order -- the reference's own loop (PQ.java:308-311) -- instead of M x dsub codebook terms.  null: IVF.
-    const double *flat_lut;
+    const struct GrpExtra *extra;  // the pointers only a few instructions off the hot path use (the kernel argument registers are full)
 };
 
 // flat PQ: the queries' exact lookup tables, block (s, q) <-> sub-quantizer s of query q, thread j <-> entry j
@@ -205,9 +218,15 @@ __global__ void k_flat_pairs(long long nq, int nch, long long chunk, long long n
 // ---- groups: the pairs of a cell (contiguous in order[]) in runs of G -----------------------------------------------
 // single block; also zeroes the hand-back counter of this step
 __global__ __launch_bounds__(1024) void k_group_build(const int32_t *__restrict__ cnt, const int32_t *__restrict__ start, int C, int G,
-                                                      int4 *__restrict__ gdesc, int32_t *__restrict__ n_groups, u32 *__restrict__ fb_count) {
+                                                      int4 *__restrict__ gdesc, int32_t *__restrict__ n_groups, u32 *__restrict__ fb_count,
+                                                      unsigned long long *__restrict__ nver, int32_t *host_hint_ver) {
     __shared__ u32 s_wave[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0 && nver) {  // what the previous launch of k_scan_grp verified, for the host's choice of instance
+        const unsigned long long v = *nver;
+        *nver = 0;
+        if (host_hint_ver) *host_hint_ver = v > 0x7fffffffull ? 0x7fffffff : (int32_t)v;
+    }
     if (start[C] == 0) {  // no pair survived the coarse bound (the separable benchmark): nothing to read, nothing to scan
         if (tid == 0) {
             *n_groups = 0;
@@ -366,7 +385,12 @@ __device__ __forceinline__ double grp_exact_entry(const double *tv, const double
 // DSUB = dimensions per sub-quantizer as a compile-time constant (4 / 8 / 16), or 0 = run-time value
 // (m = 64: the rows of a group and its residuals -- 1024 dimensions in the reference's flagship shape -- leave room for one block
 //  per CU, so the register allocation may use what two waves per SIMD leave)
-template <int M, int G, int DSUB>
+// FLAT: the flat-PQ instance (survivors verified from the queries' exact tables, P.flat_lut) -- a template parameter because
+// the IVF instances sit at their register budget and must not carry that branch
+// UNION: the instance that lowers thresholds from the union of the verified candidates (GrpExtra::ghist).  Also a template
+// parameter: with it compiled in, the plain instance spilled 32 bytes more per lane and pass B of the hard workload (where
+// nothing is verified at all) ran 6 % slower; the host picks it only when the previous call verified enough to matter.
+template <int M, int G, int DSUB, bool FLAT = false, bool UNION = false>
 __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(const GrpParams P) {
     static_assert(M % 8 == 0 && G <= 8 && G * M * 256 <= 65536, "imm offsets of the table reads");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -392,6 +416,7 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
     u32 *s_new = (u32 *)(s_q + 32);
     u32 *s_qvalid = (u32 *)(s_q + 36);
     u32 *s_th = (u32 *)(s_q + 40);  // [G] survivor bound of the query: sum of its u8 lower bounds <= th
+    [[maybe_unused]] double *s_inv0 = (double *)(s_q + 48);  // [G] 256 / T0 of the query (0: no union histogram for it); UNION only
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u64 lane_lt = (1ull << lane) - 1ull;
@@ -435,6 +460,17 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
                     if (iv < 1e30) inv = (float)iv;
                 }
                 s_inv[tid] = inv;
+                if constexpr (UNION) {
+                    double inv0 = 0.0;
+                    if (P.extra->ghist && tid < np) {
+                        const u64 t0 = P.extra->T0[q];
+                        if (t0 < 0x7FF0000000000000ull && t0 > 0) {
+                            const double iv0 = 256.0 / keyd(t0);
+                            if (iv0 < 1e300) inv0 = iv0;
+                        }
+                    }
+                    s_inv0[tid] = inv0;
+                }
             }
         }
         if (tid < 3) {
@@ -777,9 +813,9 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
                     const int i = (int)(ent >> 24);
                     const u32 pos = ent & 0xFFFFFFu;
                     double d = 0.0;
-                    if (P.flat_lut) {
+                    if constexpr (FLAT) {
                         // flat PQ: the query's own table (k_flat_lut), EPL reads per lane, the sum handed down the quad in
-                        // sub-quantizer order: ((0 + e_0) + e_1) + ...  (a uniform branch: P.flat_lut is a kernel argument)
+                        // sub-quantizer order: ((0 + e_0) + e_1) + ...
                         const u32 coff = pos * (u32)M + (u32)(ql * EPL);
                         u32 cw[(EPL + 3) / 4];
                         if constexpr (EPL >= 4) {
@@ -788,7 +824,7 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
                         } else {
                             cw[0] = (u32) * (const unsigned short *)(codes + coff);
                         }
-                        const double *lq = P.flat_lut + (size_t)s_q[i] * (size_t)(M * 256);
+                        const double *lq = P.extra->flat_lut + (size_t)s_q[i] * (size_t)(M * 256);
                         double en[EPL];
 #pragma unroll
                         for (int k = 0; k < EPL; k++) {
@@ -911,6 +947,7 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
         // ---- (h) hand the candidates to the queries' pools (at most K1 per item) ------------------------------------
         __syncthreads();
         if (tid == 0 && P.stat) atomicAdd(P.stat, (unsigned long long)n_verified);
+        if (tid == 0 && n_verified) atomicAdd(P.extra->nver, (unsigned long long)n_verified);
 #pragma unroll 1
         for (int i = 0; i < G; i++) {
             if (!((alive0 >> i) & 1u)) continue;
@@ -922,6 +959,37 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
             const int n = (int)s_ccnt[i];
             if (n == 0) continue;
             const int q = s_q[i];
+            if constexpr (UNION) if (s_inv0[i] > 0.0) {
+                // The union histogram of the query: the (at most K1) candidates this item keeps are counted by bucket -- a code
+                // beyond its own list's K1 best cannot be among the union's -- and one wave then looks whether the union holds K1
+                // candidates at or below some bucket: its upper edge is a valid threshold for every later item of the query.
+                // (Here, not in the verification rounds: the scan loop has no register to spare.)
+                if (tid < n) {
+                    const double x = keyd(ckey[(size_t)i * cb + tid]) * s_inv0[i];  // monotone map: truncation, clamped
+                    const int b = x >= 255.0 ? 255 : (x > 0.0 ? (int)x : 0);
+                    atomicAdd(P.extra->ghist + (size_t)q * 256 + b, 1u);
+                }
+                __syncthreads();  // (uniform: i, n and s_inv0[i] are the block's)
+                if (wv == 0) {
+                    const u32 *hq = P.extra->ghist + (size_t)q * 256 + 4 * lane;
+                    const u32 h0 = __hip_atomic_load(hq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), h1 = __hip_atomic_load(hq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                              h2 = __hip_atomic_load(hq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), h3 = __hip_atomic_load(hq + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const u32 incl = wave_incl_scan_u32(h0 + h1 + h2 + h3);
+                    const u64 reached = __builtin_amdgcn_ballot_w64(incl >= (u32)K1);
+                    if (reached) {
+                        const int Lr = __ffsll((long long)reached) - 1;
+                        if (lane == Lr) {
+                            u32 c = incl - (h0 + h1 + h2 + h3) + h0;
+                            int b = 4 * Lr;
+                            if (c < (u32)K1) { c += h1; b++; }
+                            if (c < (u32)K1) { c += h2; b++; }
+                            if (c < (u32)K1) { c += h3; b++; }
+                            // every counted candidate has d * inv0 < b + 1 (the clamped last bucket's edge is not used)
+                            if (b < 255) atomicMin(P.S.T + q, dkey((double)(b + 1) / s_inv0[i] * (1.0 + 1e-12)));
+                        }
+                    }
+                }
+            }
             const u64 Tfin = __hip_atomic_load(P.S.T + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // per-lane use only
             const bool pass = tid < n && ckey[(size_t)i * cb + tid] <= Tfin;
             const u64 mask = __builtin_amdgcn_ballot_w64(pass);
