@@ -868,6 +868,11 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
 #pragma unroll
                         for (int x = 0; x < M / 8; x++) {
                             u64 wrem = ((u64)cw[2 * x + 1] << 32) | (u64)cw[2 * x];
+                            // (Tried for the UNION instances, which verify thousands of codes per query: all eight codebook rows of a half
+                            //  requested at once -- 180 bytes per lane spilled into the scan loop, 30.7 -> 39.9 ms on the spread workload --
+                            //  and two rows in flight instead of one -- no change.  Timing builds say where that workload's pass B goes:
+                            //  14 of 29 ms with verification compiled out -- nearly every wave of the scan finds a survivor among its
+                            //  64 x 8 (code, query) pairs and takes the extraction path -- 1 ms of pruning, the rest verification rounds.)
                             double2 pvn[R];
                             {
                                 const double *pp = P.pq + ((u32)((8 * x * ks + (int)((u32)wrem & 0xFFu)) * DSUB) + 2u * (u32)ql);
