@@ -345,12 +345,27 @@ def parity_of(res_iid, res_dist, rid, rd):
 
 
 def java_probe():
-    """is there a JVM on this box?  (The reference also needs the LingPipe / Trove / BDB-JE / EJML jars, which
-    are not in the image either; with both present tools/java_crosscheck/ drives the real classes.)"""
+    """is there a JVM on this box?  If there is, and MMIDX_REFERENCE_CLASSPATH names the reference jar and its four
+    dependencies (LingPipe / Trove / BDB-JE / EJML: not in the image), tools/java_crosscheck/run.sh drives the REAL classes with the
+    committed fixtures and compares ids and distance bits with the oracle's answers -- the run that would turn "parity unpinned"
+    into "pinned".  Its verdict is recorded here; with no JDK nothing runs and the baseline stays the C restatement (kind 'port')."""
+    import subprocess
+
     j, jc = shutil.which("java"), shutil.which("javac")
-    return {"java": j or "absent", "javac": jc or "absent",
-            "note": "no JDK / reference jars on this box: the baseline is the C restatement (kind 'port'), never the Java classes"
-            if not (j and jc) else "JDK present: see tools/java_crosscheck/README.md for the cross-check against the reference classes"}
+    out = {"java": j or "absent", "javac": jc or "absent"}
+    if not (j and jc):
+        out["note"] = "no JDK / reference jars on this box: the baseline is the C restatement (kind 'port'), never the Java classes"
+        return out
+    try:
+        r = subprocess.run([os.path.join(ROOT, "tools", "java_crosscheck", "run.sh")], capture_output=True, text=True, timeout=600)
+        out["crosscheck_rc"] = r.returncode
+        out["crosscheck"] = (r.stdout + r.stderr)[-600:]
+        out["note"] = {0: "JDK + reference jars present: the oracle's fixtures agree with the reference classes bit for bit",
+                       2: "JDK present, reference jars not on MMIDX_REFERENCE_CLASSPATH: cross-check not run (tools/java_crosscheck/README.md)"}.get(
+            r.returncode, "JDK present: the cross-check ran and FAILED -- see `crosscheck`")
+    except Exception as e:  # noqa: BLE001
+        out["note"] = f"JDK present, cross-check could not be started: {e!r}"
+    return out
 
 
 def main():
