@@ -132,6 +132,12 @@ def gen_chunk(cx, mu, sigma, c0, n, dev=None):
     return X
 
 
+def shard_device(r):
+    """device of shard r of the native sharded handle: r, or 0 for every shard under MMIDX_BENCH_VIRTUAL_SHARDS=1 (virtual shards:
+    the functional run of the N > 1 native path on a one-GPU box, tests/test_gpu_two_ranks.py -- never a measurement)"""
+    return 0 if os.environ.get("MMIDX_BENCH_VIRTUAL_SHARDS") == "1" else r
+
+
 def build_index_native(cx, mu, sigma, coarse_h, pq_h, nq_total, ndev):
     """The sharded handle over devices 0 .. ndev-1, built from this one process: in every round device r generates chunk
     round0 + r and hands it in as slice r (mmidx_add_vectors_sliced_device: encoded where it lies, records routed to the shard
@@ -140,7 +146,7 @@ def build_index_native(cx, mu, sigma, coarse_h, pq_h, nq_total, ndev):
     N, D, Cc, m = a.n, a.dim, a.cells, a.m
     nat.preload_rccl()
     h = C.c_void_p()
-    devs = (C.c_int * ndev)(*range(ndev))
+    devs = (C.c_int * ndev)(*[shard_device(r) for r in range(ndev)])
     cx.chk(L.mmidx_create_sharded(nat.KIND_IVFPQ, D, m, 256, Cc, 0, None, None, ndev, devs, C.byref(h)))
     cx.chk(L.mmidx_set_coarse(h, coarse_h.ctypes.data))
     cx.chk(L.mmidx_set_pq(h, pq_h.ctypes.data))
@@ -152,7 +158,7 @@ def build_index_native(cx, mu, sigma, coarse_h, pq_h, nq_total, ndev):
     gq.manual_seed(4321)
     qsrc = torch.randint(0, N, (nq_total,), generator=gq, device=cx.dev)
     Qsrc = torch.zeros(nq_total, D, device=cx.dev, dtype=torch.float64)
-    mus = [mu.to(torch.device("cuda", r)) for r in range(ndev)]
+    mus = [mu.to(torch.device("cuda", shard_device(r))) for r in range(ndev)]
     t0 = time.time()
     t_enc = 0.0
     nchunks = (N + a.chunk - 1) // a.chunk
@@ -162,7 +168,7 @@ def build_index_native(cx, mu, sigma, coarse_h, pq_h, nq_total, ndev):
             ci = round0 + r
             c0 = ci * a.chunk
             n = max(0, min(a.chunk, N - c0)) if ci < nchunks else 0
-            dv = torch.device("cuda", r)
+            dv = torch.device("cuda", shard_device(r))
             X = gen_chunk(cx, mus[r], sigma, c0, n, dv) if n > 0 else torch.empty(0, D, device=dv, dtype=torch.float64)
             if n > 0:
                 sel = (qsrc >= c0) & (qsrc < c0 + n)
@@ -171,7 +177,7 @@ def build_index_native(cx, mu, sigma, coarse_h, pq_h, nq_total, ndev):
             Xs.append(X)
             ns.append(n)
         for r in range(ndev):
-            torch.cuda.synchronize(r)
+            torch.cuda.synchronize(shard_device(r))
         te = time.time()
         cx.chk(L.mmidx_add_vectors_sliced_device(h, (C.c_int64 * ndev)(*ns), (C.c_void_p * ndev)(*[x.data_ptr() for x in Xs]),
                                                  round0 * a.chunk))
@@ -445,8 +451,14 @@ def main():
     if args.gpus > 1 and world != args.gpus and not (native and world == 1):
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     ndev = args.gpus if native else 1
-    if native and torch.cuda.device_count() < ndev:
-        raise SystemExit(f"--gpus {ndev} through the native sharded handle needs {ndev} visible devices, this process sees {torch.cuda.device_count()}")
+    fallback_reason = None
+    if native and torch.cuda.device_count() < ndev and os.environ.get("MMIDX_BENCH_VIRTUAL_SHARDS") != "1":
+        # (every rank sees the same count and takes the same turn: one process cannot reach all the devices, so one process per GPU)
+        if world == ndev:
+            fallback_reason = f"this process sees {torch.cuda.device_count()} of the {ndev} devices: one process per GPU instead"
+            native, ndev = False, 1
+        else:
+            raise SystemExit(f"--gpus {ndev} through the native sharded handle needs {ndev} visible devices, this process sees {torch.cuda.device_count()}")
     dist = None
     if world > 1 or (args.force_sharded and "MASTER_ADDR" in os.environ):
         # (--force-sharded under torch.distributed.run with one rank: the RCCL calls run on a 1-rank group)
@@ -460,7 +472,6 @@ def main():
             dist.init_process_group("cpu:gloo,cuda:nccl")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    fallback_reason = None
     if native and world > 1:
         verdict = torch.zeros(1, dtype=torch.int32)
         if rank == 0:
@@ -470,9 +481,8 @@ def main():
             except BaseException as e:  # noqa: BLE001 -- whatever went wrong, the other ranks must hear about it
                 fallback_reason = repr(e)
                 log(f"native sharded handle failed ({fallback_reason}): falling back to the torch.distributed path")
-        dist.broadcast(verdict, src=0)
+        dist.broadcast(verdict, src=0)  # (a CPU tensor: gloo -- RCCL is not brought up between the ranks unless they fall back)
         if int(verdict[0]) == 1:
-            dist.barrier()
             dist.destroy_process_group()
             return
         native = False
@@ -526,7 +536,7 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
     nslices = None
     if native:
         # every shard's slice of every batch, and its answers, resident in that shard's HBM before the clock starts
-        dvs = [torch.device("cuda", r) for r in range(ndev)]
+        dvs = [torch.device("cuda", shard_device(r)) for r in range(ndev)]
         nslices = [[Qx[r * per_rank:(r + 1) * per_rank].to(dvs[r]).contiguous() for r in range(ndev)] for Qx in Qb]
         n_iid = [torch.empty(per_rank, k, dtype=torch.int32, device=dvs[r]) for r in range(ndev)]
         n_dist = [torch.empty(per_rank, k, dtype=f64, device=dvs[r]) for r in range(ndev)]
@@ -557,7 +567,7 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
 
     def barrier():
         for r in range(ndev if native else 1):
-            torch.cuda.synchronize(r if native else None)
+            torch.cuda.synchronize(shard_device(r) if native else None)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()

@@ -45,3 +45,31 @@ def test_two_ranks_on_one_gpu_match_the_single_index(tmp_path, sigma, ranks):
         assert got.shape == ref[key].shape
         assert np.array_equal(got, ref[key]), key
     assert int(ref["cnt"].min()) == 100  # full answers: the comparison is not vacuous
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sigma,ranks", [("1.0", 2), ("0.15", 3)])
+def test_native_sharded_bench_path_under_torchrun(tmp_path, sigma, ranks):
+    """`bench.py --gpus N` as the driver launches it (torch.distributed.run, N ranks): rank 0 drives the library's own sharded handle
+    over all N shards from its one process, the other ranks wait for its verdict (gloo) and leave.  On this one-GPU box the N shards
+    are virtual (MMIDX_BENCH_VIRTUAL_SHARDS=1: every shard on device 0, in-process collectives); the answers must equal the plain
+    single-GPU index's, bit for bit, and the JSON line must say that the native handle ran."""
+    env = dict(os.environ)
+    env.pop("MMIDX_LIB", None)
+    one = str(tmp_path / "one")
+    _run([sys.executable, "bench.py", "--gpus", "1", "--batch", str(ranks * 1024), "--sigma", sigma, "--dump", one] + COMMON, env)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    nat = str(tmp_path / "nat")
+    env2 = dict(env, MMIDX_BENCH_VIRTUAL_SHARDS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+                "--master-port", str(port), "bench.py", "--gpus", str(ranks), "--batch", "1024", "--sigma", sigma, "--dump", nat] + COMMON, env2)
+    assert f'"n_gpus": {ranks}' in out and "native sharded handle" in out and '"native_fallback_reason": null' in out
+    ref = np.load(one + ".rank0.npz")
+    got = np.load(nat + ".rank0.npz")
+    for key in ("cnt", "iid", "dist"):
+        assert got[key].shape == ref[key].shape
+        assert np.array_equal(got[key], ref[key]), key
+    assert int(ref["cnt"].min()) == 100
