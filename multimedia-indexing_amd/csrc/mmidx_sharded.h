@@ -122,6 +122,15 @@ __global__ void k_fill_i32(int32_t *__restrict__ p, int32_t v, long long n) {
     if (i < n) p[i] = v;
 }
 
+// The round's one word for the host: the number of flagged queries, then the round's sequence number, stored straight into pinned
+// host memory behind everything the stream has done (the host spins on the sequence number: a few microseconds after the last
+// kernel instead of a copy + hipStreamSynchronize wake-up)
+__global__ void k_publish_nflag(const int32_t *__restrict__ nflag, volatile int32_t *pin, int32_t seq) {
+    pin[0] = *nflag;
+    __threadfence_system();
+    pin[1] = seq;
+}
+
 // One wave: the flagged queries of this owner with ordinal in [round Fo, (round + 1) Fo) -> slots.  rows_own[f] = local row
 // (-1: unused slot), fq_own[f] = global query index (row + q0; -1), tau_own[f] = the query's k-th distance.
 __global__ __launch_bounds__(64) void k_tie_slots(const int32_t *__restrict__ flag, const double *__restrict__ dist, int n_own, int k, int q0,
@@ -170,11 +179,14 @@ struct HostBarrier {
     int n = 1, count = 0;
     uint64_t gen = 0;
     bool aborted = false;
+    std::atomic<uint64_t> gen_pub{0};
+    std::atomic<bool> aborted_pub{false};
     void reset(int n_) {
         std::lock_guard<std::mutex> lk(mu);
         n = n_;
         count = 0;
         aborted = false;
+        aborted_pub.store(false, std::memory_order_release);
     }
     bool wait() {
         std::unique_lock<std::mutex> lk(mu);
@@ -183,15 +195,21 @@ struct HostBarrier {
         if (++count == n) {
             count = 0;
             gen++;
+            gen_pub.store(gen, std::memory_order_release);
             cv.notify_all();
             return true;
         }
+        lk.unlock();
+        for (int spin = 0; spin < 20000 && gen_pub.load(std::memory_order_acquire) == g && !aborted_pub.load(std::memory_order_relaxed); spin++)
+            __builtin_ia32_pause();
+        lk.lock();
         cv.wait(lk, [&] { return gen != g || aborted; });
         return !aborted;
     }
     void abort() {
         std::lock_guard<std::mutex> lk(mu);
         aborted = true;
+        aborted_pub.store(true, std::memory_order_release);
         cv.notify_all();
     }
 };
@@ -205,7 +223,8 @@ struct ShardBufs {  // everything on the shard's device
     DevBuf<double> X;           // add / encode staging
     DevBuf<int32_t> ecell;
     DevBuf<unsigned char> ecode;
-    int32_t *pin_nflag = nullptr;  // pinned host word
+    int32_t *pin_nflag = nullptr;  // pinned host words: [0] flagged queries of the round, [1] the round's sequence number
+    int32_t seq = 0;
     ShardDest *pin_dest = nullptr; // pinned host copy of `dest` (what was last uploaded: re-sent only when a pointer changed)
     int dest_n = 0;
     hipEvent_t ev_b = nullptr;     // pass B of this shard has been enqueued up to here
@@ -249,6 +268,10 @@ struct ShardGroup {
     uint64_t job_gen = 0;
     int pending = 0;
     bool quit = false;
+    std::atomic<uint64_t> job_gen_pub{0};  // copies of job_gen / pending / quit that the short spins read without the mutex
+    std::atomic<int> pending_pub{0};
+    std::atomic<bool> quit_pub{false};
+    int32_t round_seq = 0;                 // sequence number of the search rounds (k_publish_nflag)
     std::vector<int> rc;
     std::vector<std::string> err;
     HostBarrier bar;
@@ -263,6 +286,10 @@ void shard_worker(ShardGroup *g, int r) {
     uint64_t seen = 0;
     for (;;) {
         std::function<int(int)> f;
+        // (a caller that searches in a loop hands over the next job within microseconds: look for it briefly before sleeping --
+        //  a condition-variable wake-up costs 10-20 us on each side of every round)
+        for (int spin = 0; spin < 20000 && g->job_gen_pub.load(std::memory_order_acquire) == seen && !g->quit_pub.load(std::memory_order_relaxed); spin++)
+            __builtin_ia32_pause();
         {
             std::unique_lock<std::mutex> lk(g->mu);
             g->cv_go.wait(lk, [&] { return g->quit || g->job_gen != seen; });
@@ -277,7 +304,10 @@ void shard_worker(ShardGroup *g, int r) {
             std::lock_guard<std::mutex> lk(g->mu);
             g->rc[(size_t)r] = rc;
             g->err[(size_t)r] = rc ? g_err : std::string();
-            if (--g->pending == 0) g->cv_done.notify_all();
+            if (--g->pending == 0) {
+                g->pending_pub.store(0, std::memory_order_release);
+                g->cv_done.notify_all();
+            }
         }
     }
 }
@@ -288,8 +318,13 @@ int shard_run(ShardGroup *g, std::function<int(int)> f) {
     g->bar.reset(g->n);
     g->job = std::move(f);
     g->pending = g->n;
+    g->pending_pub.store(g->n, std::memory_order_release);
     g->job_gen++;
+    g->job_gen_pub.store(g->job_gen, std::memory_order_release);
     g->cv_go.notify_all();
+    lk.unlock();
+    for (int spin = 0; spin < 200000 && g->pending_pub.load(std::memory_order_acquire) != 0; spin++) __builtin_ia32_pause();
+    lk.lock();
     g->cv_done.wait(lk, [&] { return g->pending == 0; });
     g->job = nullptr;
     int first = MMIDX_OK;
@@ -502,9 +537,16 @@ int shard_search_round(ShardGroup *g, int r, int k, int64_t per, const double *Q
     rc = launch_merge_partials(k, per, W, B.rpd.p, (const int64_t *)B.rpk.p, B.rpc.p, nullptr, d_iid, d_dist, d_cnt, B.flag.p, B.nflag.p, st);
     if (rc) return rc;
     // 5. any straddling tie anywhere?  (the one host read of the round; the call is synchronous anyway)
-    HIPCK(hipMemcpyAsync(B.pin_nflag, B.nflag.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIPCK(hipStreamSynchronize(st));
-    g->nflag_host[(size_t)r] = *B.pin_nflag;
+    {
+        const int32_t seq = ++B.seq;
+        hipLaunchKernelGGL(k_publish_nflag, dim3(1), dim3(1), 0, st, B.nflag.p, (volatile int32_t *)B.pin_nflag, seq);
+        HIPCK(hipGetLastError());
+        volatile int32_t *pin = (volatile int32_t *)B.pin_nflag;
+        bool seen = false;
+        for (long spin = 0; spin < 4000000 && !(seen = pin[1] == seq); spin++) __builtin_ia32_pause();  // (~ tens of ms at most)
+        if (!seen) HIPCK(hipStreamSynchronize(st));  // a long round: sleep in the runtime instead (the kernel above then has run)
+        g->nflag_host[(size_t)r] = pin[0];
+    }
     BARRIER(g);
     int mx = 0;
     for (int o = 0; o < W; o++) mx = std::max(mx, g->nflag_host[(size_t)o]);
@@ -997,6 +1039,7 @@ void sharded_destroy(mmidx_index *h) {
     {
         std::lock_guard<std::mutex> lk(g->mu);
         g->quit = true;
+        g->quit_pub.store(true, std::memory_order_release);
         g->cv_go.notify_all();
     }
     for (auto &t : g->th)
@@ -1061,6 +1104,7 @@ int mmidx_create_sharded(int kind, int D, int m, int ks, int C, int transform, c
             hipHostMalloc((void **)&g->buf[(size_t)r].pin_dest, MMIDX_MAX_SHARDS * sizeof(ShardDest)) != hipSuccess ||
             hipEventCreateWithFlags(&g->buf[(size_t)r].ev_b, hipEventDisableTiming) != hipSuccess)
             return bail(fail(MMIDX_ERR_HIP, "shard %d: pinned word / event allocation failed", r));
+        memset(g->buf[(size_t)r].pin_nflag, 0, 64);
     }
     // every shard stores pass B's lists into the owners' buffers and (in-process collectives) reads its peers': peer access
     for (int i = 0; i < n_dev; i++)

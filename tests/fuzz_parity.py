@@ -38,8 +38,6 @@ for case in range(cases):
     if ks == 700 and m < 32:
         ks = 300
     n = int(rng.integers(1, 40000))
-    if D >= 256:
-        n = min(n, 6000)  # (the oracle's encoder is one thread: C x D + ks x D fp64 triples per vector)
     k = int(rng.choice([1, 2, 10, 100, 101, 255, 256, 600, 384, 4095]))
     C = int(rng.choice([1, 2, 7, 40, 130, 300, 1100]))
     w = int(rng.integers(1, C + 1))
@@ -50,13 +48,15 @@ for case in range(cases):
     wide = int(rng.random() < 0.3)
     nogrp = int(rng.random() < 0.2)
     fused = int(rng.random() < 0.3)
+    # the oracle's encoder is one thread ((C + ks) x D fp64 triples per vector): keep a case near a second of it
+    n = max(1, min(n, int(1.5e9 / ((C + ks) * D))))
     desc = dict(kind=kind, D=D, m=m, ks=ks, n=n, k=k, C=C, w=w, tr=tr, dup=dup, hist=hist, v1=v1, wide=wide, nogrp=nogrp, fused=fused)
     try:
         nb = min(n, 3000)
         if kind == "ivfpq":
-            p = synth.make_ivfpq_problem(n=max(nb, ks + C + 8), D=D, C=C, m=m, ks=ks, nq=6, seed=int(rng.integers(1 << 30)))
+            p = synth.make_ivfpq_problem(n=max(nb, ks + C + 8), D=D, C=C, m=m, ks=ks, nq=6, seed=int(rng.integers(1 << 30)), iters=2)  # (codebook quality is irrelevant here)
         else:
-            p = synth.make_pq_problem(n=max(nb, ks + 8), D=D, m=m, ks=ks, nq=6, seed=int(rng.integers(1 << 30)))
+            p = synth.make_pq_problem(n=max(nb, ks + 8), D=D, m=m, ks=ks, nq=6, seed=int(rng.integers(1 << 30)), iters=2)
         base = rng.standard_normal((n, D)) * 0.6 + (p["coarse"][rng.integers(0, C, n)] if kind == "ivfpq" else 0.0)
         if dup and n > 10:
             base[n // 2:] = base[:n - n // 2]

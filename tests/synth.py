@@ -30,11 +30,11 @@ def mixture(n, D, G, sigma=0.15, seed=1234):
     return mu[g] + sigma * rng.standard_normal((n, D)), mu
 
 
-def make_ivfpq_problem(n=4000, D=32, C=16, m=8, ks=32, nq=24, seed=7, sigma=0.15, qsigma=0.01):
+def make_ivfpq_problem(n=4000, D=32, C=16, m=8, ks=32, nq=24, seed=7, sigma=0.15, qsigma=0.01, iters=6):
     """Returns dict(base, coarse, pq, queries). ks may be < 256 to keep tests fast."""
     rng = np.random.default_rng(seed)
     base, mu = mixture(n, D, C, sigma=sigma, seed=seed)
-    coarse = kmeans(base[: min(n, 20000)], C, iters=6, seed=seed + 1)
+    coarse = kmeans(base[: min(n, 20000)], C, iters=iters, seed=seed + 1)
     d = ((base[:, None, :] - coarse[None, :, :]) ** 2).sum(-1) if n * C * D < 5e7 else None
     if d is None:
         d = (base * base).sum(1)[:, None] - 2 * base @ coarse.T + (coarse * coarse).sum(1)[None]
@@ -43,13 +43,13 @@ def make_ivfpq_problem(n=4000, D=32, C=16, m=8, ks=32, nq=24, seed=7, sigma=0.15
     dsub = D // m
     pq = np.zeros((m, ks, dsub))
     for s in range(m):
-        pq[s] = kmeans(resid[:, s * dsub:(s + 1) * dsub], ks, iters=6, seed=seed + 10 + s)
+        pq[s] = kmeans(resid[:, s * dsub:(s + 1) * dsub], ks, iters=iters, seed=seed + 10 + s)
     qi = rng.integers(0, n, size=nq)
     queries = base[qi] + qsigma * rng.standard_normal((nq, D))
     return dict(base=base, coarse=coarse, pq=pq, queries=queries, qi=qi)
 
 
-def make_pq_problem(n=5000, D=32, m=4, ks=32, nq=16, seed=11):
+def make_pq_problem(n=5000, D=32, m=4, ks=32, nq=16, seed=11, iters=6):
     """Flat PQ: iid N(0, I) base vectors (a tight mixture would collapse to a few codes and
     create thousands of exact distance ties)."""
     rng = np.random.default_rng(seed)
@@ -57,7 +57,7 @@ def make_pq_problem(n=5000, D=32, m=4, ks=32, nq=16, seed=11):
     dsub = D // m
     pq = np.zeros((m, ks, dsub))
     for s in range(m):
-        pq[s] = kmeans(base[:, s * dsub:(s + 1) * dsub], ks, iters=6, seed=seed + s)
+        pq[s] = kmeans(base[:, s * dsub:(s + 1) * dsub], ks, iters=iters, seed=seed + s)
     queries = rng.standard_normal((nq, D))
     return dict(base=base, pq=pq, queries=queries)
 
