@@ -888,7 +888,11 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
                                 {   // (the entry after the half's last one repeats it: a valid address, the value is not used)
                                     const int sn = s + 1 < 8 * x + 8 ? s + 1 : s;
                                     const u32 cn = s + 1 < 8 * x + 8 ? (u32)wrem & 0xFFu : 0u;
+#if defined(GRP_TIMING_VFY) && GRP_TIMING_VFY == 2  // (timing experiment: every codebook read hits the same line)
+                                    const double *pp = P.pq + ((u32)((sn * 0 + (int)(cn & 0u)) * DSUB) + 2u * (u32)ql);
+#else
                                     const double *pp = P.pq + ((u32)((sn * ks + (int)cn) * DSUB) + 2u * (u32)ql);
+#endif
 #pragma unroll
                                     for (int r = 0; r < R; r++) pvn[r] = *(const double2 *)(pp + 8 * r);
                                 }
@@ -937,6 +941,9 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
                         }
                     }
                     }
+#ifdef GRP_TIMING_VFY  // (timing experiments: nothing is accepted -- results are wrong)
+                    d += 1e300;
+#endif
                     const u64 key = dkey(d);
                     if (act && ql == 3 && key <= s_T[i]) {
                         const u32 slot = atomicAdd(s_ccnt + i, 1u);
