@@ -174,6 +174,17 @@ def test_lookup_table_larger_than_lds(mi, oracle, kind):
     ref.add_vectors(base)
     got, want = ix.search_batch(k, p["queries"]), ref.search_batch(p["queries"], k)
     assert_same(got, want)
+    # one query per call -- the reference's own call shape -- and three: pass B's grid is the pair count rounded up to eight
+    # blocks, which the scratch slots must cover (nq = 1 with w = 4 used to fail with "scratch too small")
+    if kind != "pq":
+        for nq_, w_ in ((1, 4), (3, 2), (1, 6), (2, 5)):
+            ix.setW(w_)
+            ref.set_w(w_)
+            assert_same(ix.search_batch(k, p["queries"][:nq_]), ref.search_batch(p["queries"][:nq_], k))
+        ix.setW(w)
+        ref.set_w(w)
+    else:
+        assert_same(ix.search_batch(k, p["queries"][:1]), ref.search_batch(p["queries"][:1], k))
     if kind == "ivfpq_ties":  # the comparison covers the replay: some query's k-th and (k+1)-th distances tie
         w1 = ref.search_batch(p["queries"], k + 1)
         assert any(w1[2][i] > k and w1[1][i, k - 1] == w1[1][i, k] for i in range(len(p["queries"])))
@@ -238,6 +249,26 @@ def test_large_k(mi, oracle, k):
         assert np.array_equal(iid.cpu().numpy()[qi], rid[qi]) and np.array_equal(dd.cpu().numpy()[qi], rd[qi])
     for sx in shards:
         sx.close()
+
+
+@pytest.mark.parametrize("k", [3600, 3839])
+def test_large_k_with_the_table_in_global_scratch(mi, oracle, k):
+    """m = 32 x 256 byte codes and k in 3584 .. 3839: the table (64 KiB) plus the candidate buffer no longer fit the LDS, the
+    generic two-codes-per-thread kernels run with the table in global scratch, and pass A must give them their full buffer
+    (k + 1 + 512 entries -- ADVICE r2: the one-code-per-thread shrink of pass A left 4096 < k + 1 + 512)."""
+    D, C, m, ks, n, w = 64, 4, 32, 256, 12000, 3
+    p = synth.make_ivfpq_problem(n=4000, D=D, C=C, m=m, ks=ks, nq=5, seed=91, iters=2)
+    base = np.random.default_rng(4).standard_normal((n, D)) * 1.5
+    ix = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    ix.loadCoarseQuantizer(p["coarse"])
+    ix.loadProductQuantizer(p["pq"])
+    ix.setW(w)
+    ref = oracle_ivfpq(oracle, p, D, m, ks, C, w)
+    ix.indexVectors([str(i) for i in range(n)], base)
+    ref.add_vectors(base)
+    assert_same(ix.search_batch(k, p["queries"]), ref.search_batch(p["queries"], k))
+    assert_same(ix.search_batch(k, p["queries"][:1]), ref.search_batch(p["queries"][:1], k))
+    ix.close()
 
 
 @pytest.mark.parametrize("ks,tr", [(256, 0), (256, 2), (256, 1), (512, 0)])
