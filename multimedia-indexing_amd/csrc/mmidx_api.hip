@@ -272,6 +272,7 @@ struct mmidx_index {
     DevBuf<u32> ws_ghist;        // K3g: per-query histogram of accepted candidates [nq][256] (thresholds from the union over lists)
     DevBuf<u64> ws_T0;           // ... and pass A's thresholds as the launch found them
     int no_union = 0;            // option "no_union": K3g without that histogram (A/B switch)
+    int flat_chunk = 0;          // option "flat_chunk": codes per chunk of a flat PQ list (0 = sized from the batch)
     void *d_grpx = nullptr, *pin_grpx = nullptr;  // K3g's GrpExtra on the device and its pinned mirror
     double *d_zero = nullptr;    // ... and the zero "centroid"
 
@@ -659,11 +660,14 @@ int make_plan(mmidx_index *h, int k, int64_t nq, SearchPlan &pl, bool need_coars
     const int nprobe = ivf ? h->w : 1;
     int64_t chunk = 16384;
     if (!ivf) {
-        // flat PQ: every chunk of a query rebuilds the same lookup table, so chunks grow with the
-        // batch (fewer, longer work items) while a single query still spreads over the whole chip
-        const int64_t want = (h->n_csr / 32768 + 1) * std::max<int64_t>(nq, 1) / 32768;
-        chunk = 32768;
-        while (chunk < (1 << 20) && chunk < want * 32768) chunk <<= 1;
+        // flat PQ: chunk 0 is pass A (exact, LDS-gather bound: its cost grows with the chunk), the other chunks go through the
+        // grouped filtered scan under pass A's threshold (looser with a short chunk 0, but lowered from the union of the verified
+        // candidates as pass B goes).  Measured on cfg2 (1 M x 128, m = 8, k = 100; tools/dbg/cfg2_chunk.py): 65536 codes is best or
+        // within 1 % of it from 1024 to 16384 queries per call (1.16-1.17 M q/s; the batch-proportional rule of rounds 1-2 chose
+        // 131072 at 4096 queries: 1.09 M, and 524288 at 16384: 0.89 M); small batches keep 32768 so that one query still spreads
+        // over the chip
+        chunk = nq >= 512 ? 65536 : 32768;
+        if (h->flat_chunk >= 4096) chunk = std::min<int64_t>(h->flat_chunk, 1 << 23);  // option "flat_chunk" (A/B)
     }
     const int64_t maxlen = std::max<int64_t>(h->max_list_len, 1);
     pl.chunk = (int)chunk;
@@ -2542,6 +2546,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->passa_wide = value;
     } else if (n == "no_grp") {  // pass B through K3f (one block per (query, list)) instead of the grouped K3g
         h->no_grp = value != 0;
+    } else if (n == "flat_chunk") {
+        h->flat_chunk = value;
     } else if (n == "no_union") {  // K3g without the per-query histogram that lowers thresholds from the union over lists
         h->no_union = value != 0;
     } else if (n == "grp_blocks") {
