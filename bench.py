@@ -39,6 +39,15 @@ import shutil
 import sys
 import time
 
+if "OMP_NUM_THREADS" not in os.environ:  # (the box shows 256 logical CPUs and grants 16: an unbounded BLAS pool is throttled to a crawl)
+    try:
+        _q, _p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        _n = int(float(_q) / float(_p) + 0.999) if _q != "max" else (os.cpu_count() or 1)
+    except (OSError, ValueError):
+        _n = os.cpu_count() or 1
+    for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ.setdefault(_v, str(max(1, min(_n, 64))))
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -8,6 +8,9 @@ import importlib
 import os
 import sys
 
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):  # (256 BLAS threads under a 16-CPU quota crawl)
+    os.environ.setdefault(_v, "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
