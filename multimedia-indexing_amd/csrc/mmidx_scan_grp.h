@@ -477,6 +477,7 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
             s_new[tid] = 0;
             s_qvalid[tid] = 0xFFFFFFFFu;
         }
+        if (tid == 3) s_q[35] = 0;  // (UNION instances: the verification's overflow bits)
         __syncthreads();
         // ---- (b) transformed residuals (exact: centroid - q, IVFPQ.java:645, then the permutation) + fp32 copies -------
         for (int idx = tid; idx < G * D; idx += GRP_NT) {
@@ -629,6 +630,30 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
         // reserve room in the queue for this wave's survivors of one segment and write them; on failure (the queue is full) the
         // bits stay set and the lowest failing base marks where the valid entries of this round end
         auto append_try = [&](u32 &pend, const u32 segbase) {
+            if constexpr (UNION) {
+                // the instances for workloads where nearly every wave finds survivors: a prefix sum over the lanes' own survivor
+                // counts and a short loop over a lane's bits (usually one) instead of a ballot per (query, code) bit -- about
+                // 35 instructions against 150.  Survivor bit b = u * G + i here (code u of the lane, query i).
+                const u32 mine = (u32)__popc(pend);
+                const u32 incl = wave_incl_scan_u32(mine);
+                const u32 nwu = wave_read_u32(incl, 63);
+                if (nwu == 0) return;
+                u32 baseu = 0;
+                if (lane == 0) baseu = atomicAdd(s_new + par, nwu);
+                baseu = carried + (u32)__builtin_amdgcn_readfirstlane((int)baseu);
+                if (baseu + nwu <= GRP_QCAP) {
+                    u32 off = baseu + incl - mine, pb = pend;
+                    while (pb) {
+                        const int b = __ffs((int)pb) - 1;
+                        pb &= pb - 1u;
+                        s_queue[off++] = ((u32)(b & (G - 1)) << 24) | (segbase + (u32)((b / G) * GRP_NT) + (u32)tid);
+                    }
+                    pend = 0;
+                } else if (lane == 0) {
+                    atomicMin(s_qvalid + par, baseu);
+                }
+                return;
+            }
             u32 nw = 0;
 #pragma unroll
             for (int b = 0; b < G * GRP_SEGU; b++) nw += (u32)__popcll(__builtin_amdgcn_ballot_w64((pend >> b) & 1u));
@@ -730,6 +755,7 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
                 // query) pair in 2500 -- so most waves leave here
                 const bool valid = p < c1;
                 u32 neg = 0xFFFFFFFFu;
+                [[maybe_unused]] u32 sbits = 0;  // UNION: bit i = query i survives (a 16-bit field thr - sum that stays >= 0)
 #pragma unroll
                 for (int r = 0; r < G / 2; r++) {
                     typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -738,7 +764,15 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
                     aa.w = acc[r];
                     dd.v = ta.v - aa.v;
                     neg &= dd.w;
+                    if constexpr (UNION) {
+                        const int i0 = (r >> 1) * 4 + (r & 1);
+                        sbits |= (((~dd.w) >> 15) & 1u) << i0 | (((~dd.w) >> 31) & 1u) << (i0 + 2);
+                    }
                 }
+                if constexpr (UNION) {
+                    // (queries that are not scanned carry thr = -1: their fields are negative whatever the sum)
+                    if (valid) pend |= sbits << (u * G);
+                } else
                 if (__builtin_amdgcn_ballot_w64(valid && (~neg & 0x80008000u) != 0u)) {
 #pragma unroll
                     for (int i = 0; i < G; i++) {
@@ -785,6 +819,76 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
                 }
                 const u32 nvalid = failed ? (qv < cnt ? qv : cnt) : cnt;
                 n_verified += nvalid;
+                if constexpr (UNION) {
+                    // ---- the instances for workloads that verify thousands of codes per query: a LANE per survivor, GRP_NT
+                    // survivors per round (the quad form below: 128).  Every lane computes its survivor's distance alone --
+                    // the entries in the reference's order (t ascending from 0.0, IVFPQ.java:531-534), added in sub-quantizer
+                    // order (:435-438): the same additions as the quad form -- or, flat PQ, reads it from the query's exact
+                    // table.  A candidate buffer cannot promise room for a whole round any more, so appends are bounded: a
+                    // lane whose slot lies beyond the buffer raises the query's overflow bit, the buffer is pruned to k + 1
+                    // (publishing the threshold), and the lane tries again under the tighter threshold.
+                    u32 *s_ovf = (u32 *)(s_q + 35);
+                    for (u32 r0 = 0; r0 < nvalid; r0 += GRP_NT) {
+                        const u32 e_raw = r0 + (u32)tid;
+                        const bool act = e_raw < nvalid;
+                        const u32 e = act ? e_raw : nvalid - 1u;  // (loads run on a clamped index: see the note below)
+                        const u32 ent = s_queue[e];
+                        const int i = (int)(ent >> 24);
+                        const u32 pos = ent & 0xFFFFFFu;
+                        u32 cw[M / 4];
+                        if constexpr (M % 16 == 0) {
+#pragma unroll
+                            for (int x = 0; x < M / 16; x++) {
+                                const uint4 v = *(const uint4 *)(codes + pos * (u32)M + 16 * x);
+                                cw[4 * x] = v.x, cw[4 * x + 1] = v.y, cw[4 * x + 2] = v.z, cw[4 * x + 3] = v.w;
+                            }
+                        } else {
+                            const uint2 v = *(const uint2 *)(codes + pos * (u32)M);
+                            cw[0] = v.x, cw[1] = v.y;
+                        }
+                        double d = 0.0;
+                        if constexpr (FLAT) {
+                            const double *lq = P.extra->flat_lut + (size_t)s_q[i] * (size_t)(M * 256);
+                            double en[M];
+#pragma unroll
+                            for (int sx = 0; sx < M; sx++) en[sx] = lq[sx * 256 + (int)((cw[sx >> 2] >> (8 * (sx & 3))) & 0xFFu)];
+#pragma unroll
+                            for (int sx = 0; sx < M; sx++) d += en[sx];
+                        } else {
+                            const double *tvq = s_tr + i * D;
+#pragma unroll 2
+                            for (int sx = 0; sx < M; sx++) {
+                                const u32 cs = (cw[sx >> 2] >> (8 * (sx & 3))) & 0xFFu;
+                                d += grp_exact_entry<DSUB>(tvq + sx * dsub, P.pq + (u32)((sx * ks + (int)cs) * dsub), dsub);
+                            }
+                        }
+                        const u64 key = dkey(d);
+                        bool want = act && key <= s_T[i];
+                        for (;;) {
+                            if (want) {
+                                const u32 slot = atomicAdd(s_ccnt + i, 1u);
+                                if (slot < (u32)cb) {
+                                    ckey[(size_t)i * cb + slot] = key;
+                                    cpos[(size_t)i * cb + slot] = pos;
+                                    want = false;
+                                } else {
+                                    atomicOr(s_ovf, 1u << i);
+                                }
+                            }
+                            __syncthreads();
+                            const u32 ovf = *s_ovf;  // (block-uniform)
+                            if (!ovf) break;
+                            __syncthreads();
+                            if (tid == 0) *s_ovf = 0;
+                            if (tid < G && ((ovf >> tid) & 1u)) s_ccnt[tid] = (u32)cb;  // (the slots beyond the buffer were never written)
+                            __syncthreads();
+#pragma unroll 1
+                            for (int qi = 0; qi < G; qi++)
+                                if ((ovf >> qi) & 1u) grp_prune(ckey + (size_t)qi * cb, cpos + (size_t)qi * cb, s_ccnt + qi, s_T + qi, K1, P.S.T + s_q[qi]);
+                            want = want && key <= s_T[i];
+                        }
+                    }
+                } else
                 // ---- exact verification, GRP_VR survivors per round, four lanes each --------------------------
                 for (u32 r0 = 0; r0 < nvalid; r0 += GRP_VR) {
                     __syncthreads();  // candidate counts of the previous round are final
