@@ -960,7 +960,7 @@ int launch_grouped_common(mmidx_index *h, const ScanParams &S, ScanParams F, con
     //  separable benchmark, whose far probes all fall to the coarse bound, would pay for nothing; a stale hint costs speed, never results)
     // ... and the UNION instance only when the call before verified more than a few codes per query (k_group_build reports it)
     const bool union_worth = !S.ivf || (h->pin_hint && *(volatile int32_t *)h->pin_hint > 0 && (long long)*(volatile int32_t *)(h->pin_hint + 1) > 8 * nq);
-    if (!h->no_union && union_worth && nq > 0 && nq * 256 * 4 <= (1ll << 31)) {
+    if ((h->no_union < 0 || (!h->no_union && union_worth)) && nq > 0 && nq * 256 * 4 <= (1ll << 31)) {  // (no_union = -1: always, A/B)
         HIPCK(h->ws_ghist.reserve((size_t)nq * 256));
         HIPCK(h->ws_T0.reserve((size_t)nq));
         HIPCK(hipMemsetAsync(h->ws_ghist.p, 0, (size_t)nq * 256 * sizeof(u32), st));
@@ -2549,7 +2549,7 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
     } else if (n == "flat_chunk") {
         h->flat_chunk = value;
     } else if (n == "no_union") {  // K3g without the per-query histogram that lowers thresholds from the union over lists
-        h->no_union = value != 0;
+        h->no_union = value < 0 ? -1 : (value != 0);
     } else if (n == "grp_blocks") {
         h->grp_blocks = value > 0 ? value : 0;
     } else if (n == "passa_prefix") {
