@@ -51,9 +51,10 @@ for case in range(cases):
     wide = int(rng.random() < 0.3)
     nogrp = int(rng.random() < 0.2)
     fused = int(rng.random() < 0.3)
+    union = int(rng.choice([0, 0, -1, 1]))  # K3g: hint-driven / always / never the instances that rank the union of verified candidates
     # the oracle's encoder is one thread ((C + ks) x D fp64 triples per vector): keep a case near a second of it
     n = max(1, min(n, int(1.5e9 / ((C + ks) * D))))
-    desc = dict(kind=kind, D=D, m=m, ks=ks, n=n, k=k, C=C, w=w, tr=tr, dup=dup, hist=hist, v1=v1, wide=wide, nogrp=nogrp, fused=fused)
+    desc = dict(kind=kind, D=D, m=m, ks=ks, n=n, k=k, C=C, w=w, tr=tr, dup=dup, hist=hist, v1=v1, wide=wide, nogrp=nogrp, fused=fused, union=union)
     try:
         nb = min(n, 3000)
         if kind == "ivfpq":
@@ -82,6 +83,7 @@ for case in range(cases):
         ix.set_option("passa_wide", wide)
         ix.set_option("no_grp", nogrp)
         ix.set_option("coarse_fused", fused)
+        ix.set_option("no_union", union)
         half = n // 2
         ix.indexVectors([str(i) for i in range(half)], base[:half])
         if half:

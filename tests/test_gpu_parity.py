@@ -804,6 +804,48 @@ def test_yfcc_shape_long_lists_fast_path(mi, oracle, w, k, hist):
     ix.close()
 
 
+@pytest.mark.parametrize("D,m,C,n,w,k,dup", [
+    (128, 16, 6, 30000, 6, 100, 1),   # <16, 8, 8>: the headline's instance
+    (128, 8, 5, 24000, 5, 50, 3),     # <8, 8, 16>, every vector three times: ties everywhere, buffers overflow and are pruned
+    (64, 16, 4, 20000, 4, 300, 1),    # dsub 4, k = 300: candidate buffers of 512 entries
+    (128, 32, 4, 16000, 4, 20, 2),    # <32, 4, 4>: groups of four
+    (96, 8, 4, 12000, 3, 10, 1),      # dsub 12: the run-time-dsub instance has no UNION twin (the plain one must serve it)
+])
+def test_union_instances_forced(mi, oracle, D, m, C, n, w, k, dup):
+    """The K3g instances that rank the union of the verified candidates (`no_union` = -1 forces them; normally a device-reported
+    hint picks them): overlapping cells and queries between cells, so that far probes feed the queue, survivors are verified a
+    lane each, candidate buffers overflow and thresholds come down from the per-query histogram.  Same ids and distance bits as
+    the oracle, and as the plain instances (`no_union` = 1)."""
+    ks = 256
+    rng = np.random.default_rng(D + m)
+    mu = 0.5 * rng.standard_normal((C, D))
+    base = mu[rng.integers(0, C, n // dup)] + rng.standard_normal((n // dup, D))
+    base = np.concatenate([base] * dup)[rng.permutation((n // dup) * dup)]
+    n = len(base)
+    p = {"coarse": mu, "pq": np.stack([synth.kmeans((mu[rng.integers(0, C, 3000)] - base[:3000])[:, s * (D // m):(s + 1) * (D // m)], ks, iters=2, seed=s)
+                                       for s in range(m)])}
+    ix = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    ix.loadCoarseQuantizer(p["coarse"])
+    ix.loadProductQuantizer(p["pq"])
+    ix.setW(w)
+    ix.set_option("passa_hist", 1)
+    ref = oracle_ivfpq(oracle, p, D, m, ks, C, w)
+    ix.indexVectors([str(i) for i in range(n)], base)
+    ref.add_vectors(base)
+    Q = np.concatenate([0.5 * (base[:24] + base[100:124]), rng.standard_normal((8, D)), base[:8] + 0.01 * rng.standard_normal((8, D))])
+    want = ref.search_batch(Q, k)
+    got = {}
+    for mode in (-1, 1, 0):
+        ix.set_option("no_union", mode)
+        ix.set_profiling(True)
+        got[mode] = ix.search_batch(k, Q)
+        st = ix.get_stats()
+        assert_same(got[mode], want)
+        if mode == -1 and D % 8 == 0 and (D // m) in (4, 8, 16):
+            assert st["verified_codes"] > 0  # (the forced instance really had survivors to verify)
+    ix.close()
+
+
 def test_snapshot_roundtrip(mi, oracle, tmp_path):
     """saveSnapshot / loadSnapshot (flat restart path): identical answers, ids preserved."""
     D, C, m, ks, n, w, k = 32, 16, 8, 256, 3000, 4, 10
