@@ -332,8 +332,12 @@ int mmidx_get_stats(mmidx_index *h, mmidx_stats *out);
  *   in fp64, `chains` (1 or 3) codes in flight per lane, 256-thread blocks at the scan kernel's occupancy; m in {8, 16, 32}.
  *   out[0] = wave-level ds_read_b64 per second, out[1] = GB/s of "algorithmic bytes" (codes x m), out[2] = blocks per CU,
  *   out[3] = seconds.
+ * mmidx_probe_split_gather: the m = 16 loop with the last kg (1, 2 or 4) rows gathered through the vector-memory path (a
+ *   per-block copy in global memory, L1-resident) and the others from the LDS -- the experiment behind DESIGN section 9's
+ *   "share the gather between the two pipes"; out as mmidx_probe_lds_gather.
  * mmidx_probe_f64_mfma: back-to-back v_mfma_f64_16x16x4_f64 on every SIMD; out[0] = TFLOP/s, out[1] = seconds. */
 int mmidx_probe_lds_gather(int device, int m, int chains, double *out);
+int mmidx_probe_split_gather(int device, int kg, double *out);
 int mmidx_probe_f64_mfma(int device, double *out);
 
 /* ---- front end of BASELINE config 5 ----------------------------------------------------------

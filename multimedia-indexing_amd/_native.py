@@ -118,6 +118,7 @@ SIGNATURES = {
     "mmidx_linear_get_dim": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "mmidx_probe_lds_gather": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp]),
     "mmidx_probe_f64_mfma": (C.c_int, [C.c_int, _dp]),
+    "mmidx_probe_split_gather": (C.c_int, [C.c_int, C.c_int, _dp]),
     "mmidx_set_profiling": (C.c_int, [_vp, C.c_int]),
     "mmidx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "mmidx_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),

@@ -74,6 +74,62 @@ __global__ __launch_bounds__(256) void k_probe_lds_gather(int iters, double *__r
     if (acc == 12345.678) sink[0] = acc;  // (keeps the loop alive)
 }
 
+// The same loop with the LAST KG rows of the table served by the vector-memory path instead of the LDS: each block writes its own
+// KG x 2 KiB copy to global memory and gathers from it (L1-resident after the first touch: 4 blocks x KG x 2 KiB of the CU's
+// 32 KiB) -- does sharing the gather between the two pipes beat the LDS alone?  (pass A.)
+template <int M, int U, int KG>
+__global__ __launch_bounds__(256) void k_probe_split_gather(int iters, double *__restrict__ gtab, double *__restrict__ sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *lut = (double *)smem;
+    double *mine = gtab + (size_t)blockIdx.x * KG * 256;
+    for (int i = threadIdx.x; i < (M - KG) * 256; i += 256) lut[i] = 1e-3 * (double)((i * 37) & 255);
+    for (int i = threadIdx.x; i < KG * 256; i += 256) mine[i] = 1e-3 * (double)((i * 41) & 255);
+    __threadfence();
+    __syncthreads();
+    u32 st[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) st[u] = (u32)(blockIdx.x * 256 + threadIdx.x) * 2654435761u + (u32)u * 0x9E3779B9u + 1u;
+    double acc = 0.0;
+    for (int it = 0; it < iters; it++) {
+        u32 wd[U][M / 4];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+#pragma unroll
+            for (int j = 0; j < M / 4; j++) {
+                u32 x = st[u];
+                x ^= x << 13;
+                x ^= x >> 17;
+                x ^= x << 5;
+                st[u] = x;
+                wd[u][j] = x;
+            }
+        }
+        double gg[U][KG];  // the global rows first: their latency runs under the LDS rows
+#pragma unroll
+        for (int s = M - KG; s < M; s++) {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                gg[u][s - (M - KG)] = *(const double *)((const char *)(mine + (s - (M - KG)) * 256) + byte_x8(wd[u][s >> 2], s & 3));
+        }
+        double dd[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) dd[u] = *(lds_cdouble *)(size_t)(byte_x8(wd[u][0], 0));
+#pragma unroll
+        for (int s = 1; s < M - KG; s++) {
+#pragma unroll
+            for (int u = 0; u < U; u++) dd[u] += *(lds_cdouble *)(size_t)(byte_x8(wd[u][s >> 2], s & 3) + (u32)s * 2048u);
+        }
+#pragma unroll
+        for (int s = 0; s < KG; s++) {
+#pragma unroll
+            for (int u = 0; u < U; u++) dd[u] += gg[u][s];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) acc += dd[u];
+    }
+    if (acc == 12345.678) sink[0] = acc;
+}
+
 __global__ __launch_bounds__(256) void k_probe_f64_mfma(int iters, double *__restrict__ sink) {
     typedef double d4 __attribute__((ext_vector_type(4)));
     d4 acc[4];
@@ -146,6 +202,55 @@ int mmidx_probe_lds_gather(int device, int m, int chains, double *out) {
     out[0] = codes * m / 64.0 / sec;
     out[1] = codes * m / sec / 1e9;
     out[2] = (double)std::min(per_cu, 4);
+    out[3] = sec;
+    return MMIDX_OK;
+}
+
+// pass A's gather with kg of the m = 16 rows on the vector-memory path (kg = 0: the plain LDS loop through the same harness).
+// out as mmidx_probe_lds_gather.
+int mmidx_probe_split_gather(int device, int kg, double *out) {
+    if (!out) return MMIDX_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MMIDX_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return MMIDX_ERR_NO_DEVICE;
+    if (kg != 1 && kg != 2 && kg != 4) return MMIDX_ERR_INVALID_ARG;
+    int cus = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    if (cus < 1) cus = 256;
+    constexpr int M = 16;
+    const int blocks = cus * 4 * 4, iters = 2048;
+    double *sink = nullptr, *gtab = nullptr;
+    if (hipMalloc((void **)&sink, 64) != hipSuccess) return MMIDX_ERR_HIP;
+    if (hipMalloc((void **)&gtab, (size_t)blocks * 4 * 256 * 8) != hipSuccess) { (void)hipFree(sink); return MMIDX_ERR_HIP; }
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    float ms = 0.f;
+    hipError_t e = hipSuccess;
+    const size_t lds = (size_t)M * 2048;  // (the LDS footprint of the real kernel: four blocks per CU)
+    auto run = [&](auto kern) {
+        e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, nullptr, iters / 8 + 1, gtab, sink);
+        (void)hipEventRecord(e0, nullptr);
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, nullptr, iters, gtab, sink);
+        (void)hipEventRecord(e1, nullptr);
+        e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    };
+    if (kg == 1) run(k_probe_split_gather<M, 3, 1>);
+    else if (kg == 2) run(k_probe_split_gather<M, 3, 2>);
+    else run(k_probe_split_gather<M, 3, 4>);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    (void)hipFree(gtab);
+    if (e != hipSuccess) return MMIDX_ERR_HIP;
+    const double sec = (double)ms * 1e-3;
+    const double codes = (double)blocks * 256.0 * (double)iters * 3.0;
+    out[0] = codes * M / 64.0 / sec;
+    out[1] = codes * M / sec / 1e9;
+    out[2] = 4.0;
     out[3] = sec;
     return MMIDX_OK;
 }
