@@ -12,11 +12,12 @@ typedef __attribute__((ext_vector_type(4))) double f64x4;
 // K7: Y[n][nc] = (X[n][ss] - mu[ss]) * Vt[nc][ss]^T          (sampleToEigenSpace PCA.java:196-201)
 //
 // The one dense contraction of the path: v_mfma_f64_16x16x4_f64.  Block = 4 waves, tile 64 rows x
-// 128 components x 16 k; wave w owns rows 16w..16w+15 and all 8 column tiles (8 accumulators of 4
+// 128 components x PCA_BK k; wave w owns rows 16w..16w+15 and all 8 column tiles (8 accumulators of 4
 // f64 per lane).  The mean is subtracted while the X tile is staged (sample - means, :199).  Tiles
-// go through LDS with a row stride of 17 doubles, which spreads the fragment reads
-// (row = lane & 15, k = lane >> 4) over distinct bank pairs; the next tile's global loads are in
-// flight while the current one is multiplied.  A/B operand: one f64 per lane,
+// go through LDS with a padded row stride (PCA_LD doubles), which spreads the fragment reads
+// (row = lane & 15, k = lane >> 4) over the bank pairs; the next tile's global loads are in
+// flight while the current one is multiplied, and four waves per SIMD (blocks of the same CU at
+// different points of their k loops) keep the matrix cores fed across the barriers.  A/B operand: one f64 per lane,
 // A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15]; C/D: col = lane & 15,
 // row = (lane >> 4) + 4 * reg (the f64 layout, which differs from the f32 maps).
 // EJML's matrix-vector product accumulates each output sequentially with separate multiply and add
@@ -29,15 +30,24 @@ typedef __attribute__((ext_vector_type(4))) double f64x4;
 #define PCA_NT (PCA_BM * 4)  // threads per block
 #define PCA_BN 128
 #ifndef PCA_BK
-#define PCA_BK 32   // k per staged tile: 256 contiguous bytes of every X row per request (16: 37 TF, 24: 38.8, 32: 40.3 of the 67.6 TF
-#endif              // the f64 matrix cores deliver back to back -- the X rows are 64 KiB apart, short row segments waste DRAM pages)
-#define PCA_LD (PCA_BK + 1)  // padded row stride in doubles
+#define PCA_BK 8    // k per staged tile.  Round 3, same box: at TWO waves per SIMD (196 registers: 64 accumulators + the staging of a
+#endif              // wide tile) 16 / 24 / 32 gave 37 / 38.8 / 40.3 TF of the 67.9 the f64 matrix cores deliver back to back; with the
+                    // register budget held to FOUR waves per SIMD (PCA_WPS) a narrow tile needs no spill and 8 gives 47.1-47.9 TF
+                    // (0.70), 16 at three waves 44.9, 8 at three 45.3, 8 at five (spills) 37.5: the barriers between short tiles
+                    // are hidden by the other blocks of the CU, which the wide tile's registers did not leave room for
+#ifndef PCA_PAD
+#define PCA_PAD 1
+#endif
+#define PCA_LD (PCA_BK + PCA_PAD)  // padded row stride in doubles
 #define PCA_PPR (PCA_BK / 2)  // pairs of doubles per tile row
 #define PCA_NA (PCA_BM * PCA_PPR / PCA_NT)  // pairs per thread: X tile
 #define PCA_NB (PCA_BN * PCA_PPR / PCA_NT)  // ... Vt tile
 #define PCA_LDS_BYTES ((PCA_BM + PCA_BN) * PCA_LD * 8)
 
-__global__ __launch_bounds__(PCA_NT) void k_pca_project(const double *__restrict__ X, const double *__restrict__ mu,
+#ifndef PCA_WPS
+#define PCA_WPS 4  // waves per SIMD the register budget is held to (128 VGPRs: the accumulators + one narrow tile in flight)
+#endif
+__global__ __launch_bounds__(PCA_NT, PCA_WPS) void k_pca_project(const double *__restrict__ X, const double *__restrict__ mu,
                                                         const double *__restrict__ Vt, double *__restrict__ Y,
                                                         long long n, int nc, int ss) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pca_smem[];
@@ -49,7 +59,7 @@ __global__ __launch_bounds__(PCA_NT) void k_pca_project(const double *__restrict
     f64x4 acc[8];
 #pragma unroll
     for (int t = 0; t < 8; t++) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
-    // staging: A 64 rows x 16 k = 512 pairs of doubles -> 2 per thread; B 128 x 16 = 1024 pairs -> 4 per thread
+    // staging: A PCA_BM rows x PCA_BK k in pairs of doubles, PCA_NA per thread; B 128 x PCA_BK, PCA_NB per thread
     double2 ra[PCA_NA], rb[PCA_NB];
     auto load_tiles = [&](int k0) {
 #pragma unroll
@@ -89,14 +99,22 @@ __global__ __launch_bounds__(PCA_NT) void k_pca_project(const double *__restrict
 #pragma unroll
         for (int u = 0; u < PCA_NA; u++) {
             const int p = tid + u * PCA_NT, r = p / PCA_PPR, c = (p % PCA_PPR) * 2;
-            As[r * PCA_LD + c] = ra[u].x;
-            As[r * PCA_LD + c + 1] = ra[u].y;
+            if constexpr ((PCA_LD & 1) == 0) {
+                *(double2 *)(As + r * PCA_LD + c) = ra[u];
+            } else {
+                As[r * PCA_LD + c] = ra[u].x;
+                As[r * PCA_LD + c + 1] = ra[u].y;
+            }
         }
 #pragma unroll
         for (int u = 0; u < PCA_NB; u++) {
             const int p = tid + u * PCA_NT, r = p / PCA_PPR, c = (p % PCA_PPR) * 2;
-            Bs[r * PCA_LD + c] = rb[u].x;
-            Bs[r * PCA_LD + c + 1] = rb[u].y;
+            if constexpr ((PCA_LD & 1) == 0) {
+                *(double2 *)(Bs + r * PCA_LD + c) = rb[u];
+            } else {
+                Bs[r * PCA_LD + c] = rb[u].x;
+                Bs[r * PCA_LD + c + 1] = rb[u].y;
+            }
         }
     };
     load_tiles(0);
