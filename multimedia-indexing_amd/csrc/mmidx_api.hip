@@ -263,6 +263,8 @@ struct mmidx_index {
     int64_t last_ambiguous = 0;  // vectors of the last encode call that needed the exact redo
     DevBuf<long long> ws_dest;
     DevBuf<int4> ws_gdesc;
+    DevBuf<int32_t> ws_cand;  // K3s: the pairs behind the coarse bound (+ their count in the last word)
+    DevBuf<double> ws_smin;   // K3s: certified lower bounds of their Smin
     DevBuf<int32_t> ws_inv;   // iid -> position in the list-major arrays (-1: absent), built on demand
     bool inv_valid = false;
     int64_t inv_size = 0;
@@ -272,6 +274,9 @@ struct mmidx_index {
     DevBuf<u32> ws_ghist;        // K3g: per-query histogram of accepted candidates [nq][256] (thresholds from the union over lists)
     DevBuf<u64> ws_T0;           // ... and pass A's thresholds as the launch found them
     int no_union = 0;            // option "no_union": K3g without that histogram (A/B switch)
+    int smin_pre = -1;           // option "smin_pre": K3s (k_pair_smin) in front of pass B's counting sort: 1 always, 0 never, -1 when the
+                                 // device-reported figures of the call before say that at least half of the pairs end at Smin >= T
+    bool pre_on = false;         // the call before ran K3s (which pair of hint words describes it)
     int flat_chunk = 0;          // option "flat_chunk": codes per chunk of a flat PQ list (0 = sized from the batch)
     void *d_grpx = nullptr, *pin_grpx = nullptr;  // K3g's GrpExtra on the device and its pinned mirror
     double *d_zero = nullptr;    // ... and the zero "centroid"
@@ -1437,7 +1442,59 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
                 fprintf(stderr, "[mmidx] nq=%lld npairs=%lld T inf=%d cells min=%d max=%d rmax=%g D=%d w=%d keep=%p cnt=%p Q=%p coarse=%p T=%p\n", (long long)nq, npairs, ninf, cmin, cmax,
                         h->rmax, h->D, P.w, (void*)h->ws_keep.p, (void*)h->ws_pcount.p, (void*)dQ, (void*)h->d_coarse, (void*)h->ws_T.p);
             }
-            hipLaunchKernelGGL(k_pair_hist, dim3(g), dim3(256), 0, st, d_cells, P.w, 1, npairs, h->ws_pcount.p, h->ws_keep.p, PB);
+            // K3s: pairs whose certified Smin reaches the threshold leave before the sort (only where K3g would run, and only when
+            // the figures the device reported for the call before say it pays; a stale figure costs speed, never results)
+            const bool pre_ok = !h->no_grp && h->grp_valid && h->d_pq32T && !h->no_filter && !P.sdc_tt && h->max_list_len < (1 << 24) &&
+                                (h->dsub == 4 || h->dsub == 8 || h->dsub == 16) && npairs < 0x7fffff00ll;
+            bool use_pre = false;
+            if (pre_ok && h->smin_pre > 0) use_pre = true;
+            else if (pre_ok && h->smin_pre < 0 && h->pin_hint) {
+                volatile int32_t *ph = (volatile int32_t *)h->pin_hint;
+                if (h->pre_on) {  // [2] pairs K3s looked at, [0] pairs it left: it stays while it removes a quarter
+                    const long long in = ph[2], left = ph[0];
+                    use_pre = !(in > 0 && left * 4 > in * 3);
+                } else {  // [4] pairs K3g grouped, [5] pairs alive after its table build
+                    const long long in = ph[4], left = ph[5];
+                    use_pre = in > 0 && left * 2 < in;
+                }
+            }
+            h->pre_on = use_pre;
+            if (use_pre) {
+                HIPCK(h->ws_cand.reserve((size_t)npairs + 4));
+                HIPCK(h->ws_smin.reserve((size_t)npairs));
+                int32_t *ncand = h->ws_cand.p + npairs;
+                HIPCK(hipMemsetAsync(ncand, 0, sizeof(int32_t), st));
+                const int sgroups = h->m / SMIN_NW;
+                if (sgroups > 1) HIPCK(hipMemsetAsync(h->ws_smin.p, 0, (size_t)npairs * sizeof(double), st));
+                hipLaunchKernelGGL(k_pair_hist, dim3(g), dim3(256), 0, st, d_cells, P.w, 1, npairs, h->ws_pcount.p, h->ws_keep.p, PB, h->ws_cand.p, ncand);
+                DBG_SYNC("pair hist (candidates)");
+                SminParams SP{};
+                SP.Q = dQ;
+                SP.coarse = h->d_coarse;
+                SP.perm = h->d_perm;
+                SP.cells = d_cells;
+                SP.cand = h->ws_cand.p;
+                SP.ncand = ncand;
+                SP.pq32T = h->d_pq32T;
+                SP.pn32 = h->d_pn32;
+                SP.pnmax = h->d_pnmax;
+                SP.smin = h->ws_smin.p;
+                SP.D = h->D;
+                SP.w = P.w;
+                SP.M = h->m;
+                const dim3 sg((unsigned)sgroups, (unsigned)std::max(1, 2 * std::max(h->num_cus, 8) / sgroups));
+                if (h->dsub == 16) hipLaunchKernelGGL(k_pair_smin<16>, sg, dim3(SMIN_NW * 64), 0, st, SP);
+                else if (h->dsub == 8) hipLaunchKernelGGL(k_pair_smin<8>, sg, dim3(SMIN_NW * 64), 0, st, SP);
+                else hipLaunchKernelGGL(k_pair_smin<4>, sg, dim3(SMIN_NW * 64), 0, st, SP);
+                HIPCK(hipGetLastError());
+                DBG_SYNC("K3s pair smin");
+                hipLaunchKernelGGL(k_pair_recount, dim3(g), dim3(256), 0, st, h->ws_cand.p, ncand, d_cells, P.w, h->ws_T.p, h->ws_smin.p, h->ws_keep.p,
+                                   h->ws_pcount.p, h->C, h->pin_hint ? h->pin_hint + 2 : nullptr);
+                DBG_SYNC("pair recount");
+            } else {
+                hipLaunchKernelGGL(k_pair_hist, dim3(g), dim3(256), 0, st, d_cells, P.w, 1, npairs, h->ws_pcount.p, h->ws_keep.p, PB, (int32_t *)nullptr,
+                                   (int32_t *)nullptr);
+            }
             DBG_SYNC("pair hist");
             hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, h->C, h->ws_pstart.p, h->ws_pcursor.p, h->pin_hint);
             DBG_SYNC("pair scan");
@@ -1677,7 +1734,7 @@ int mmidx_create(int kind, int D, int m, int ks, int C, int transform, const int
         delete h;
         return fail(MMIDX_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
     }
-    if (hipMalloc((void **)&h->d_counters, 8 * sizeof(u64)) != hipSuccess || hipMemset(h->d_counters, 0, 8 * sizeof(u64)) != hipSuccess) {
+    if (hipMalloc((void **)&h->d_counters, 12 * sizeof(u64)) != hipSuccess || hipMemset(h->d_counters, 0, 12 * sizeof(u64)) != hipSuccess) {
         delete h;
         return fail(MMIDX_ERR_HIP, "hipMalloc failed");
     }
@@ -2548,6 +2605,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->no_grp = value != 0;
     } else if (n == "flat_chunk") {
         h->flat_chunk = value;
+    } else if (n == "smin_pre") {  // K3s in front of pass B: 1 always, 0 never, -1 by the device's figures of the call before
+        h->smin_pre = value < 0 ? -1 : (value != 0);
     } else if (n == "no_union") {  // K3g without the per-query histogram that lowers thresholds from the union over lists
         h->no_union = value < 0 ? -1 : (value != 0);
     } else if (n == "grp_blocks") {

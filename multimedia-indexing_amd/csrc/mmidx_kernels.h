@@ -3412,8 +3412,11 @@ __global__ void k_gather_cdist(const double *__restrict__ dist, const int32_t *_
     const int c = cells[e];
     out[e] = c >= 0 ? dist[(size_t)(e / w) * C + c] : 0.0;
 }
+// cand != null: the kept pairs are not counted per cell yet -- they are appended to cand[0 .. *ncand) (any order) for K3s
+// (k_pair_smin, mmidx_scan_grp.h), and k_pair_recount counts what that leaves
 __global__ void k_pair_hist(const int32_t *__restrict__ cells, int w, int rank_lo, long long npairs,
-                            int32_t *__restrict__ cnt, unsigned char *__restrict__ keep, const PairBound B) {
+                            int32_t *__restrict__ cnt, unsigned char *__restrict__ keep, const PairBound B,
+                            int32_t *__restrict__ cand, int32_t *__restrict__ ncand) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= npairs) return;
     const int q = (int)(e / w);
@@ -3422,11 +3425,21 @@ __global__ void k_pair_hist(const int32_t *__restrict__ cells, int w, int rank_l
     const unsigned cu = c >= 0 ? (unsigned)c : 0u;
     const bool k = (c >= 0) & pair_keep(B, e, q, (int)cu);
     keep[e] = k ? 1 : 0;
+    const u64 mk = __builtin_amdgcn_ballot_w64(k);
+    const int lane = (int)(threadIdx.x & 63);
+    const int leader = mk ? __ffsll((long long)mk) - 1 : 0;
+    if (cand) {
+        u32 base = 0;
+        if (mk && lane == leader) base = (u32)atomicAdd(ncand, (int)__popcll(mk));
+        base = wave_read_u32(base, leader);
+        const u32 slot = base + (u32)__popcll(mk & ((1ull << lane) - 1ull));
+        if (k) cand[slot] = (int32_t)e;
+        return;
+    }
     if (k) atomicAdd(cnt + (size_t)cu, 1);
     // total of the step in cnt[C]: one atomic per wave that kept anything (none at all on separable data, where the
     // kernels behind this one then leave at once)
-    const u64 mk = __builtin_amdgcn_ballot_w64(k);
-    if (mk && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)mk) - 1)) atomicAdd(cnt + B.C, (int)__popcll(mk));
+    if (mk && lane == leader) atomicAdd(cnt + B.C, (int)__popcll(mk));
 }
 // single block: exclusive scan of cnt[C] -> start[C]; start[C] = total; cursor zeroed
 // (host_hint: pinned host word that receives the total as well -- the next call sizes pass B's launch from it; written

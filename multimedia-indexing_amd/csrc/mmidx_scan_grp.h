@@ -50,6 +50,9 @@
 #ifndef GRP_RW
 #define GRP_RW 4  // table reads in flight per code in the interleaved scan (2, 4 or 8)
 #endif
+#ifndef GRP_EARLY
+#define GRP_EARLY 0  // > 0: the scan looks every GRP_EARLY sub-quantizers whether any (code, query) pair of the wave is still below its bound
+#endif
 #ifndef GRP_WPS
 #define GRP_WPS 4  // waves per SIMD the register allocation is held to (blocks per CU x 2)
 #endif
@@ -67,7 +70,7 @@ struct GrpExtra {
     const u64 *T0;
     // always on: codes verified exactly since k_group_build last looked (it reports the figure to the host through the pinned
     // hint, and the host picks the UNION instance for the next call when the figure says verification is where the time goes)
-    unsigned long long *nver;
+    unsigned long long *nver;  // (three words: [1] pairs grouped, [2] pairs alive after the table build, same life cycle)
 };
 
 struct GrpParams {
@@ -226,6 +229,15 @@ __global__ __launch_bounds__(1024) void k_group_build(const int32_t *__restrict_
         const unsigned long long v = *nver;
         *nver = 0;
         if (host_hint_ver) *host_hint_ver = v > 0x7fffffffull ? 0x7fffffff : (int32_t)v;
+        // ... and how many of its pairs were still alive after their table build (nver[1] grouped, nver[2] alive): the host's
+        // figures for K3s (k_pair_smin), hint words [4] and [5]
+        const unsigned long long a = nver[1], b = nver[2];
+        nver[1] = 0;
+        nver[2] = 0;
+        if (host_hint_ver) {
+            host_hint_ver[3] = a > 0x7fffffffull ? 0x7fffffff : (int32_t)a;
+            host_hint_ver[4] = b > 0x7fffffffull ? 0x7fffffff : (int32_t)b;
+        }
     }
     if (start[C] == 0) {  // no pair survived the coarse bound (the separable benchmark): nothing to read, nothing to scan
         if (tid == 0) {
@@ -355,6 +367,160 @@ __device__ __forceinline__ void grp_rows(unsigned char *lut8, const int s, const
         if constexpr (G == 8) *(uint2 *)dst = make_uint2(w0[k], w1[k]);
         else *(u32 *)dst = w0[k];
     }
+}
+
+// ---- K3s: a certified lower bound of Smin for every (query, far probe) pair BEFORE any row is built ----------------------
+// K3g drops a pair whose Smin = sum_s min_j ||r_s - p_sj||^2 reaches the query's threshold only after it has built the pair's
+// whole table -- G x m rows from m x dsub x 256 codebook floats that every item re-reads from L2 (1 MiB at 64 x 256 x 16).  On the
+// reference's flagship shape (1024 dimensions, 64 x 256: YFCC100MExample.java:85-90) EVERY far pair of the synthetic workload ends
+// there, so pass B was nothing but table builds.  This kernel computes the same row minima (same fp32 evaluation, same certified
+// error term as phase (c) / grp_rows) with the codebook held in REGISTERS: a wave owns one sub-quantizer (its lane's four entries
+// in all DSUB dimensions), a block NW of them, and the pairs stream through in batches of SMIN_NP -- the codebook is read once per
+// block instead of once per item.  Output: smin[ci] (+)= the block's part of sum_s (mn_s - err_s), every term rounded down;
+// k_pair_recount drops the pairs with smin >= T before the counting sort.  Dead pairs contribute nothing in K3g either (state 1).
+struct SminParams {
+    const double *Q, *coarse;
+    const int32_t *perm;
+    const int32_t *cells;  // [nq][w]
+    const int32_t *cand;   // pair ids (q * w + rank) that survived the coarse bound, any order
+    const int32_t *ncand;  // device-side count
+    const float *pq32T, *pn32;
+    const double *pnmax;
+    double *smin;          // [ncand]
+    int D, w, M;
+};
+#define SMIN_NP 32  // pairs per batch (a multiple of 4, at most 64: their results travel in the lanes of one register)
+#define SMIN_NW 8   // waves = sub-quantizers per block (two blocks per CU: one stages residuals while the other multiplies)
+template <int DSUB>
+__global__ __launch_bounds__(SMIN_NW * 64, 2) void k_pair_smin(const SminParams P) {
+    constexpr int NW = SMIN_NW, BD = NW * DSUB;  // BD: dimensions this block looks at
+    static_assert((SMIN_NP * BD) % (NW * 64) == 0 && (DSUB == 4 || DSUB == 8 || DSUB == 16), "whole waves in the residual phase");
+    __shared__ __attribute__((aligned(16))) float s_r[SMIN_NP][BD];
+    __shared__ float s_nrf[SMIN_NP][NW];
+    __shared__ double s_err[SMIN_NP][NW];
+    __shared__ double s_part[SMIN_NP][NW];
+    __shared__ int s_q[SMIN_NP], s_cell[SMIN_NP];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int sg = blockIdx.x, sl = sg * NW + wv;  // slice group of the block, sub-quantizer of the wave
+    const int nc = *P.ncand;
+    float4 p4[DSUB];
+#pragma unroll
+    for (int t = 0; t < DSUB; t++) p4[t] = *(const float4 *)(P.pq32T + ((size_t)sl * DSUB + t) * 256 + 4 * lane);
+    const float4 pn4 = *(const float4 *)(P.pn32 + (size_t)sl * 256 + 4 * lane);
+    for (int base = (int)blockIdx.y * SMIN_NP; base < nc; base += (int)gridDim.y * SMIN_NP) {
+        const int nb = nc - base < SMIN_NP ? nc - base : SMIN_NP;
+        if (tid < SMIN_NP) {  // (slots past the end repeat the last pair: every row of the batch holds valid numbers)
+            const int e = P.cand[base + (tid < nb ? tid : nb - 1)];
+            s_q[tid] = e / P.w;
+            s_cell[tid] = P.cells[e];
+        }
+        __syncthreads();
+        // (i) residuals of the block's dimensions (exact: centroid - q, IVFPQ.java:645, then the permutation), their fp32 copies,
+        //     ||r_s||^2 and the error term of the fp32 entries (as phase (c) of k_scan_grp)
+#pragma unroll 2
+        for (int idx = tid; idx < SMIN_NP * BD; idx += NW * 64) {
+            const int pi = idx / BD, dd = idx - pi * BD;
+            const int d = sg * BD + dd;
+            const int src = P.perm ? P.perm[d] : d;
+            const double r = P.coarse[(size_t)s_cell[pi] * P.D + src] - P.Q[(size_t)s_q[pi] * P.D + src];
+            s_r[pi][dd] = (float)r;
+            double nr = r * r;
+#pragma unroll
+            for (int off = 1; off < DSUB; off <<= 1) nr += __shfl_xor(nr, off);
+            if ((dd & (DSUB - 1)) == 0) {
+                const int sw = dd / DSUB;
+                const double pm = P.pnmax[sg * NW + sw], pm2 = P.pnmax[P.M + sg * NW + sw];
+                s_err[pi][sw] = 0x1p-24 * 1.01 * (3.0 * (nr + pm2) + (2.0 * DSUB + 9.0) * sqrt(nr) * pm) + 1e-30;
+                s_nrf[pi][sw] = (float)nr;
+            }
+        }
+        __syncthreads();
+        // (ii) the wave's row minimum for every pair of the batch: fl(fl(nrf + pn) - 2 dot), t ascending, fused -- grp_rows' entries.
+        //      Four pairs at a time: their wave-level minima run as four interleaved chains of v_min_f32_dpp (one instruction per
+        //      step and pair; the other three chains fill the two wait states a DPP read needs behind a write), and pair p's
+        //      minimum lands in lane p of one register, so that the fp64 tail runs once per batch, a lane per pair.
+        float mres = 0.f;
+#pragma unroll 1
+        for (int p0 = 0; p0 < SMIN_NP; p0 += 4) {
+            float ml[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const float4 *rr = (const float4 *)&s_r[p0 + u][wv * DSUB];  // (broadcast reads)
+                f32x2 d01 = {0.f, 0.f}, d23 = {0.f, 0.f};
+#pragma unroll
+                for (int t4 = 0; t4 < DSUB / 4; t4++) {
+                    const float4 r4 = rr[t4];
+                    const float rv[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const f32x2 r2 = {rv[k], rv[k]}, p01 = {p4[t4 * 4 + k].x, p4[t4 * 4 + k].y}, p23 = {p4[t4 * 4 + k].z, p4[t4 * 4 + k].w};
+                        d01 = __builtin_elementwise_fma(r2, p01, d01);
+                        d23 = __builtin_elementwise_fma(r2, p23, d23);
+                    }
+                }
+                const float nrf = s_nrf[p0 + u][wv];
+                const float a0 = fmaf(-2.f, d01.x, nrf + pn4.x), a1 = fmaf(-2.f, d01.y, nrf + pn4.y), a2 = fmaf(-2.f, d23.x, nrf + pn4.z),
+                            a3 = fmaf(-2.f, d23.y, nrf + pn4.w);
+                ml[u] = fminf(fminf(a0, a1), fminf(a2, a3));
+            }
+#define SMIN_STEP(pre, ctrl)                                                                                                         \
+    asm volatile(pre "v_min_f32_dpp %0, %0, %0 " ctrl "\n\tv_min_f32_dpp %1, %1, %1 " ctrl "\n\tv_min_f32_dpp %2, %2, %2 " ctrl           \
+                     "\n\tv_min_f32_dpp %3, %3, %3 " ctrl                                                                              \
+                 : "+v"(ml[0]), "+v"(ml[1]), "+v"(ml[2]), "+v"(ml[3]))
+            SMIN_STEP("s_nop 1\n\t", "row_shr:1 row_mask:0xf bank_mask:0xf");
+            SMIN_STEP("", "row_shr:2 row_mask:0xf bank_mask:0xf");
+            SMIN_STEP("", "row_shr:4 row_mask:0xf bank_mask:0xf");
+            SMIN_STEP("", "row_shr:8 row_mask:0xf bank_mask:0xf");
+            SMIN_STEP("", "row_bcast:15 row_mask:0xa bank_mask:0xf");
+            SMIN_STEP("", "row_bcast:31 row_mask:0xc bank_mask:0xf");
+#undef SMIN_STEP
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+                const float sv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ml[u]), 63));
+                mres = lane == p0 + u ? sv : mres;
+            }
+        }
+        if (lane < nb) {
+            const double err = s_err[lane][wv];
+            double term = (double)mres - err;
+            term -= fabs(term) * 0x1p-40;  // (the additions below and in k_pair_recount round by far less)
+            if (!(err < 1e22)) term = -__longlong_as_double(0x7FF0000000000000ll);  // magnitudes beyond what fp32 carries: never dropped
+            s_part[lane][wv] = term;
+        }
+        __syncthreads();
+        if (tid < nb) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < NW; i++) s += s_part[tid][i];
+            if (gridDim.x == 1) P.smin[base + tid] = s;
+            else atomicAdd(P.smin + base + tid, s);  // (the other slice groups' parts; zeroed before the launch)
+        }
+    }
+}
+// the pairs K3s found dead leave pass B; the others are counted per cell as k_pair_hist would have (cnt[C] = their total)
+__global__ void k_pair_recount(const int32_t *__restrict__ cand, const int32_t *__restrict__ ncand, const int32_t *__restrict__ cells, int w,
+                               const u64 *__restrict__ T, const double *__restrict__ smin, unsigned char *__restrict__ keep,
+                               int32_t *__restrict__ cnt, int C, int32_t *host_hint_cand) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int nc = *ncand;
+    if (i == 0 && host_hint_cand) *host_hint_cand = nc;
+    const int ic = i < nc ? i : (nc > 0 ? nc - 1 : 0);  // (loads on a clamped index, stores predicated: see pair_keep())
+    const int e = nc > 0 ? cand[ic] : 0;
+    const int c = cells[e];
+    const unsigned cu = c >= 0 ? (unsigned)c : 0u;
+    const u64 Tq = T[e / w];
+    const double s = nc > 0 ? smin[ic] : 0.0;
+    const double s_lo = s - fabs(s) * 0x1p-40;
+    const double Td = keyd(Tq);
+    // every code of the list has d >= Smin >= s_lo: with s_lo >= T > 0 (finite) none can enter the query's k + 1 best
+    const bool dead = (Tq < 0x7FF0000000000000ull) & (Td > 0.0) & (s_lo >= Td);
+    const bool alive = (i < nc) & !dead;
+    if ((i < nc) & dead) keep[e] = 0;
+    if (alive) atomicAdd(cnt + (size_t)cu, 1);
+    const u64 mk = __builtin_amdgcn_ballot_w64(alive);
+    if (mk && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)mk) - 1)) atomicAdd(cnt + C, (int)__popcll(mk));
 }
 
 template <int DSUB>
@@ -598,6 +764,11 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
         for (int i = 0; i < G; i++)
             if (s_state[i] == 0) alive0 |= 1u << i;
         alive0 = (u32)__builtin_amdgcn_readfirstlane((int)alive0);
+        if (tid == 0 && ch == 0) {  // (always: two fire-and-forget atomics per item) the figures K3s is switched on and off by
+            unsigned long long *nv = P.extra->nver;
+            atomicAdd(nv + 1, (unsigned long long)np);
+            atomicAdd(nv + 2, (unsigned long long)__popc(alive0));
+        }
         if (tid == 0 && P.stat) {  // (profiling runs only) pairs of this item, pairs that survive the table build's Smin >= T test
             atomicAdd(P.stat + 2, (unsigned long long)np);
             atomicAdd(P.stat + 3, (unsigned long long)__popc(alive0));
@@ -739,7 +910,13 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
                             hi[k] = 0;
                         }
                     }
-                    if constexpr (GRP_QMAX <= 127) {
+                    if constexpr (GRP_QMAX <= 63 && GRP_RW == 8) {  // four reads add byte-wise without a carry
+                        spread2(lo[0] + lo[1] + lo[2] + lo[3], hi[0] + hi[1] + hi[2] + hi[3], lo[4] + lo[5] + lo[6] + lo[7],
+                                hi[4] + hi[5] + hi[6] + hi[7]);
+                    } else if constexpr (GRP_QMAX <= 63) {
+#pragma unroll
+                        for (int k = 0; k < GRP_RW; k += 4) spread(lo[k] + lo[k + 1] + lo[k + 2] + lo[k + 3], hi[k] + hi[k + 1] + hi[k + 2] + hi[k + 3]);
+                    } else if constexpr (GRP_QMAX <= 127) {
 #pragma unroll
                         for (int k = 0; k < GRP_RW; k += 4)
                             spread2(lo[k] + lo[k + 1], hi[k] + hi[k + 1], lo[k + 2] + lo[k + 3], hi[k + 2] + hi[k + 3]);
@@ -747,6 +924,23 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
 #pragma unroll
                         for (int k = 0; k < GRP_RW; k += 2) spread2(lo[k], hi[k], lo[k + 1], hi[k + 1]);
                     }
+#if GRP_EARLY > 0
+                    // The byte sums only grow: when every (code, query) pair of the wave is already above its bound, the rest of
+                    // the code's lookups cannot change the outcome (the final test below fails on the partial sums just the same).
+                    if (!UNION && sq + GRP_RW < M && (sq + GRP_RW) % GRP_EARLY == 0) {
+                        u32 ng = 0xFFFFFFFFu;
+#pragma unroll
+                        for (int r = 0; r < G / 2; r++) {
+                            typedef short s16x2 __attribute__((ext_vector_type(2)));
+                            union { u32 w; s16x2 v; } ta, aa, dd;
+                            ta.w = thrp[r];
+                            aa.w = acc[r];
+                            dd.v = ta.v - aa.v;
+                            ng &= dd.w;
+                        }
+                        if (!__builtin_amdgcn_ballot_w64((~ng & 0x80008000u) != 0u)) break;
+                    }
+#endif
                 }
                 (void)spread;
                 // survivors: sum of lower bounds <= the query's bound th (e).  Query i sits in field (i & 2) >> 1 of register

@@ -52,9 +52,10 @@ for case in range(cases):
     nogrp = int(rng.random() < 0.2)
     fused = int(rng.random() < 0.3)
     union = int(rng.choice([0, 0, -1, 1]))  # K3g: hint-driven / always / never the instances that rank the union of verified candidates
+    spre = int(rng.choice([-1, 1, 1, 0]))  # K3s (certified Smin of every far pair in front of pass B's sort): hint-driven / always / never
     # the oracle's encoder is one thread ((C + ks) x D fp64 triples per vector): keep a case near a second of it
     n = max(1, min(n, int(1.5e9 / ((C + ks) * D))))
-    desc = dict(kind=kind, D=D, m=m, ks=ks, n=n, k=k, C=C, w=w, tr=tr, dup=dup, hist=hist, v1=v1, wide=wide, nogrp=nogrp, fused=fused, union=union)
+    desc = dict(kind=kind, D=D, m=m, ks=ks, n=n, k=k, C=C, w=w, tr=tr, dup=dup, hist=hist, v1=v1, wide=wide, nogrp=nogrp, fused=fused, union=union, spre=spre)
     try:
         nb = min(n, 3000)
         if kind == "ivfpq":
@@ -84,6 +85,7 @@ for case in range(cases):
         ix.set_option("no_grp", nogrp)
         ix.set_option("coarse_fused", fused)
         ix.set_option("no_union", union)
+        ix.set_option("smin_pre", spre)
         half = n // 2
         ix.indexVectors([str(i) for i in range(half)], base[:half])
         if half:

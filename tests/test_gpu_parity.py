@@ -846,6 +846,49 @@ def test_union_instances_forced(mi, oracle, D, m, C, n, w, k, dup):
     ix.close()
 
 
+@pytest.mark.parametrize("D,m,C,n,w,k,tr,sep", [
+    (128, 16, 24, 30000, 24, 100, 0, 0.8),   # <8, 16 waves>: the headline's shape; cells far enough apart that far pairs end at Smin >= T
+    (128, 8, 12, 20000, 12, 20, 2, 0.8),     # <16, 8 waves>, RandomPermutation
+    (64, 16, 10, 20000, 10, 50, 0, 0.3),     # dsub 4, overlapping cells: most pairs stay alive
+    (128, 32, 12, 16000, 12, 20, 0, 0.8),    # m = 32: two slice groups, the parts of Smin meet by atomicAdd
+    (1024, 64, 12, 24000, 12, 30, 2, 0.25),  # YFCC100MExample.java:85-90: 64 x 16, four slice groups
+    (96, 8, 6, 12000, 6, 10, 0, 0.8),        # dsub 12: K3s does not apply, the option must be harmless
+])
+def test_smin_prefilter_forced(mi, oracle, D, m, C, n, w, k, tr, sep):
+    """K3s (`k_pair_smin` + `k_pair_recount`, option `smin_pre`): the certified lower bound of every far pair's Smin, computed in
+    front of pass B's counting sort with the codebook in registers; pairs with Smin >= T leave before K3g builds a table for them.
+    Forced on (1), off (0) and hint-driven (-1, three calls so that the device's figures of one call steer the next): ids and
+    distance bits are the oracle's every time, and the forced filter never leaves more pairs than the plain path."""
+    ks = 256
+    rng = np.random.default_rng(D + m + C)
+    mu = sep * rng.standard_normal((C, D))
+    base = mu[rng.integers(0, C, n)] + 0.5 * rng.standard_normal((n, D))
+    pq = np.stack([synth.kmeans((mu[rng.integers(0, C, 2000)] - base[:2000])[:, s * (D // m):(s + 1) * (D // m)], ks, iters=1, seed=s)
+                   for s in range(m)])
+    ix = mi.IVFPQ(D, n, False, "", m, ks, tr, C, 512)
+    ix.loadCoarseQuantizer(mu)
+    ix.loadProductQuantizer(pq)
+    ix.setW(w)
+    ref = oracle_ivfpq(oracle, {"coarse": mu, "pq": pq}, D, m, ks, C, w, tr=tr)
+    ix.indexVectors(list(range(n)), base)
+    off, iids, cds = ix.export()
+    ref.load_lists(off, iids, cds)
+    Q = np.concatenate([base[:48] + 0.01 * rng.standard_normal((48, D)), 0.5 * (base[100:116] + base[200:216]), mu[:4]])
+    want = ref.search_batch(Q, k)
+    items = {}
+    for mode in (1, 0, -1, -1, -1):
+        ix.set_option("smin_pre", mode)
+        ix.set_profiling(True)
+        got = ix.search_batch(k, Q)
+        st = ix.get_stats()
+        assert_same(got, want)
+        items.setdefault(mode, st["passb_items_last"])
+    assert 0 <= items[1] <= items[0]
+    if sep >= 0.8 and m <= 16 and (D // m) in (4, 8, 16):
+        assert items[1] < items[0]  # (the filter really removed pairs the coarse bound had left)
+    ix.close()
+
+
 def test_snapshot_roundtrip(mi, oracle, tmp_path):
     """saveSnapshot / loadSnapshot (flat restart path): identical answers, ids preserved."""
     D, C, m, ks, n, w, k = 32, 16, 8, 256, 3000, 4, 10
