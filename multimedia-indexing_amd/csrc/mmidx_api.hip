@@ -265,6 +265,8 @@ struct mmidx_index {
     DevBuf<int4> ws_gdesc;
     DevBuf<int32_t> ws_cand;  // K3s: the pairs behind the coarse bound (+ their count in the last word)
     DevBuf<double> ws_smin;   // K3s: certified lower bounds of their Smin
+    DevBuf<double> ws_Qp;     // K3s: the call's queries in transformed (permuted) order
+    double *d_coarseP = nullptr;  // K3s: the centroids in transformed order (RandomPermutation only; built with the K3g tables)
     DevBuf<int32_t> ws_inv;   // iid -> position in the list-major arrays (-1: absent), built on demand
     bool inv_valid = false;
     int64_t inv_size = 0;
@@ -276,6 +278,7 @@ struct mmidx_index {
     int no_union = 0;            // option "no_union": K3g without that histogram (A/B switch)
     int smin_pre = -1;           // option "smin_pre": K3s (k_pair_smin) in front of pass B's counting sort: 1 always, 0 never, -1 when the
                                  // device-reported figures of the call before say that at least half of the pairs end at Smin >= T
+    int smin_valu = 0;           // option "smin_valu": K3s with packed VALU FMAs instead of the matrix cores (A/B)
     bool pre_on = false;         // the call before ran K3s (which pair of hint words describes it)
     int flat_chunk = 0;          // option "flat_chunk": codes per chunk of a flat PQ list (0 = sized from the batch)
     void *d_grpx = nullptr, *pin_grpx = nullptr;  // K3g's GrpExtra on the device and its pinned mirror
@@ -894,6 +897,12 @@ int build_grp_tables(mmidx_index *h) {
     if (!h->d_pnmax) HIPCK(hipMalloc((void **)&h->d_pnmax, 2 * (size_t)h->m * sizeof(double)));
     hipLaunchKernelGGL(k_pq32_table, dim3((unsigned)h->m), dim3(256), 0, h->stream, h->d_pqT, h->d_pq32T, h->d_pn32, h->m, h->ks, h->dsub);
     hipLaunchKernelGGL(k_pn_max, dim3((unsigned)h->m), dim3(256), 0, h->stream, h->d_pqT, h->d_pnmax, h->m, h->ks, h->dsub);
+    if (h->kind == MMIDX_KIND_IVFPQ && h->d_perm && h->coarse_set) {  // K3s reads contiguous dimensions
+        if (!h->d_coarseP) HIPCK(hipMalloc((void **)&h->d_coarseP, (size_t)h->C * h->D * sizeof(double)));
+        const long long tot = (long long)h->C * h->D;
+        hipLaunchKernelGGL(k_permute_cols, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->d_coarse, h->d_perm, h->d_coarseP, h->D,
+                           (long long)h->C);
+    }
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(h->stream));
     h->grp_valid = true;
@@ -1445,7 +1454,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
             // K3s: pairs whose certified Smin reaches the threshold leave before the sort (only where K3g would run, and only when
             // the figures the device reported for the call before say it pays; a stale figure costs speed, never results)
             const bool pre_ok = !h->no_grp && h->grp_valid && h->d_pq32T && !h->no_filter && !P.sdc_tt && h->max_list_len < (1 << 24) &&
-                                (h->dsub == 4 || h->dsub == 8 || h->dsub == 16) && npairs < 0x7fffff00ll;
+                                (h->dsub == 4 || h->dsub == 8 || h->dsub == 16) && npairs < 0x7fffff00ll && ((uintptr_t)dQ & 15) == 0;  // (16-byte loads of the query rows)
             bool use_pre = false;
             if (pre_ok && h->smin_pre > 0) use_pre = true;
             else if (pre_ok && h->smin_pre < 0 && h->pin_hint) {
@@ -1472,6 +1481,14 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
                 SP.Q = dQ;
                 SP.coarse = h->d_coarse;
                 SP.perm = h->d_perm;
+                if (h->d_perm && h->d_coarseP && !h->smin_valu) {  // transformed copies: contiguous loads instead of 8-byte gathers
+                    HIPCK(h->ws_Qp.reserve((size_t)nq * h->D));
+                    const long long tot = (long long)nq * h->D;
+                    hipLaunchKernelGGL(k_permute_cols, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dQ, h->d_perm, h->ws_Qp.p, h->D, (long long)nq);
+                    SP.Q = h->ws_Qp.p;
+                    SP.coarse = h->d_coarseP;
+                    SP.perm = nullptr;
+                }
                 SP.cells = d_cells;
                 SP.cand = h->ws_cand.p;
                 SP.ncand = ncand;
@@ -1483,9 +1500,15 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
                 SP.w = P.w;
                 SP.M = h->m;
                 const dim3 sg((unsigned)sgroups, (unsigned)std::max(1, 2 * std::max(h->num_cus, 8) / sgroups));
-                if (h->dsub == 16) hipLaunchKernelGGL(k_pair_smin<16>, sg, dim3(SMIN_NW * 64), 0, st, SP);
-                else if (h->dsub == 8) hipLaunchKernelGGL(k_pair_smin<8>, sg, dim3(SMIN_NW * 64), 0, st, SP);
-                else hipLaunchKernelGGL(k_pair_smin<4>, sg, dim3(SMIN_NW * 64), 0, st, SP);
+                if (h->smin_valu) {  // (A/B: the packed-FMA form)
+                    if (h->dsub == 16) hipLaunchKernelGGL(k_pair_smin<16>, sg, dim3(SMIN_NW * 64), 0, st, SP);
+                    else if (h->dsub == 8) hipLaunchKernelGGL(k_pair_smin<8>, sg, dim3(SMIN_NW * 64), 0, st, SP);
+                    else hipLaunchKernelGGL(k_pair_smin<4>, sg, dim3(SMIN_NW * 64), 0, st, SP);
+                } else {
+                    if (h->dsub == 16) hipLaunchKernelGGL(k_pair_smin_mfma<16>, sg, dim3(SMIN_NW * 64), 0, st, SP);
+                    else if (h->dsub == 8) hipLaunchKernelGGL(k_pair_smin_mfma<8>, sg, dim3(SMIN_NW * 64), 0, st, SP);
+                    else hipLaunchKernelGGL(k_pair_smin_mfma<4>, sg, dim3(SMIN_NW * 64), 0, st, SP);
+                }
                 HIPCK(hipGetLastError());
                 DBG_SYNC("K3s pair smin");
                 hipLaunchKernelGGL(k_pair_recount, dim3(g), dim3(256), 0, st, h->ws_cand.p, ncand, d_cells, P.w, h->ws_T.p, h->ws_smin.p, h->ws_keep.p,
@@ -1857,6 +1880,7 @@ int mmidx_destroy(mmidx_index *h) {
     if (h->d_pq32T) (void)hipFree(h->d_pq32T);
     if (h->d_pn32) (void)hipFree(h->d_pn32);
     if (h->d_pnmax) (void)hipFree(h->d_pnmax);
+    if (h->d_coarseP) (void)hipFree(h->d_coarseP);
     if (h->d_zero) (void)hipFree(h->d_zero);
     for (auto &ev : h->evpool)
         if (ev) (void)hipEventDestroy(ev);
@@ -1931,6 +1955,7 @@ int mmidx_set_coarse(mmidx_index *h, const double *coarse) {
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(h->stream));
     h->coarse_set = true;
+    h->grp_valid = false;  // (K3s's transformed copy of the centroids)
     return MMIDX_OK;
 }
 
@@ -2605,6 +2630,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->no_grp = value != 0;
     } else if (n == "flat_chunk") {
         h->flat_chunk = value;
+    } else if (n == "smin_valu") {
+        h->smin_valu = value != 0;
     } else if (n == "smin_pre") {  // K3s in front of pass B: 1 always, 0 never, -1 by the device's figures of the call before
         h->smin_pre = value < 0 ? -1 : (value != 0);
     } else if (n == "no_union") {  // K3g without the per-query histogram that lowers thresholds from the union over lists

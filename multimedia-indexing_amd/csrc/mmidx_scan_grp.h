@@ -378,6 +378,16 @@ __device__ __forceinline__ void grp_rows(unsigned char *lut8, const int s, const
 // in all DSUB dimensions), a block NW of them, and the pairs stream through in batches of SMIN_NP -- the codebook is read once per
 // block instead of once per item.  Output: smin[ci] (+)= the block's part of sum_s (mn_s - err_s), every term rounded down;
 // k_pair_recount drops the pairs with smin >= T before the counting sort.  Dead pairs contribute nothing in K3g either (state 1).
+// out[i][d] = X[i][perm[d]]: the rows K3s reads (centroids once per index, queries once per call) in transformed order, so that a
+// thread's dimensions are contiguous -- gathered 8 bytes at a time through the permutation, the residual phase of k_pair_smin_mfma
+// was bound by the number of cache-line requests (64 per wave-level load), not by anything it computes
+__global__ void k_permute_cols(const double *__restrict__ X, const int32_t *__restrict__ perm, double *__restrict__ out, int D, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * D) return;
+    const long long row = i / D;
+    const int d = (int)(i - row * D);
+    out[i] = X[row * D + perm[d]];
+}
 struct SminParams {
     const double *Q, *coarse;
     const int32_t *perm;
@@ -389,10 +399,13 @@ struct SminParams {
     double *smin;          // [ncand]
     int D, w, M;
 };
+#ifndef SMIN_TIMING
+#define SMIN_TIMING 0
+#endif
 #define SMIN_NP 32  // pairs per batch (a multiple of 4, at most 64: their results travel in the lanes of one register)
 #define SMIN_NW 8   // waves = sub-quantizers per block (two blocks per CU: one stages residuals while the other multiplies)
 template <int DSUB>
-__global__ __launch_bounds__(SMIN_NW * 64, 2) void k_pair_smin(const SminParams P) {
+__global__ __launch_bounds__(SMIN_NW * 64, 4) void k_pair_smin(const SminParams P) {
     constexpr int NW = SMIN_NW, BD = NW * DSUB;  // BD: dimensions this block looks at
     static_assert((SMIN_NP * BD) % (NW * 64) == 0 && (DSUB == 4 || DSUB == 8 || DSUB == 16), "whole waves in the residual phase");
     __shared__ __attribute__((aligned(16))) float s_r[SMIN_NP][BD];
@@ -496,6 +509,165 @@ __global__ __launch_bounds__(SMIN_NW * 64, 2) void k_pair_smin(const SminParams 
             for (int i = 0; i < NW; i++) s += s_part[tid][i];
             if (gridDim.x == 1) P.smin[base + tid] = s;
             else atomicAdd(P.smin + base + tid, s);  // (the other slice groups' parts; zeroed before the launch)
+        }
+    }
+}
+// K3s on the matrix cores.  The dot products of a batch are a small GEMM per sub-quantizer -- [32 pairs x DSUB] x [DSUB x 256
+// entries] -- and v_mfma_f32_16x16x4_f32 computes it as the same fused chain (t ascending, exact f32) at the rate of the packed
+// VALU FMAs but on the other pipe: the vector ALUs only keep a running maximum.  Per entry the chain starts at -||p||^2 / 2, so
+// that  entry = fl(nrf - 2 acc)  and  min_j entry_j = fl(nrf - 2 max_j acc_j)  (rounding is monotone): one maximum per (pair,
+// sub-quantizer) instead of 256 entries.  Error of an entry against the exact one, with u = 2^-24:  u nr (nrf) + u pn (pn32) +
+// 2 (2.01 u |r_s||p|) (inputs of the products) + 2 dsub 1.01 u (pn / 2 + |r_s||p|) (the chain) + u (nr + pn + 2 |r_s||p|) (the
+// last rounding)  <=  2^-24 1.01 [3 nr + (dsub + 3) max pn + (2 dsub + 9) |r_s| max|p|]: the term phase (i) stores.
+// Operand layouts (cdna_hip_programming.md): A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], C/D register v of lane l =
+// row 4 (l >> 4) + v, column l & 15.  Rows = 16 pairs (two row tiles per batch of SMIN_NP = 32), columns = 16 entries.
+template <int DSUB>
+__global__ __launch_bounds__(SMIN_NW * 64, 4) void k_pair_smin_mfma(const SminParams P) {
+    constexpr int NW = SMIN_NW, BD = NW * DSUB, KS = DSUB / 4, RS = BD + 4;  // (RS: the A-operand reads -- 16 rows x 4 k -- hit 64 different banks)
+    constexpr int VPT = DSUB / 2;  // dimensions per thread in the residual phase: a thread is (pair, sub-quantizer, half)
+    static_assert(SMIN_NP == 32 && NW == 8 && (DSUB == 4 || DSUB == 8 || DSUB == 16), "two MFMA row tiles of pairs; 32 x 8 x 2 threads stage the residuals");
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float s_r[SMIN_NP * RS];
+    __shared__ float s_pnh[NW][256];
+    __shared__ float s_nrf[SMIN_NP][NW];
+    __shared__ float s_mx[SMIN_NP][NW];
+    __shared__ double s_err[SMIN_NP][NW];
+    __shared__ double s_part[SMIN_NP][NW];
+    __shared__ int s_q[SMIN_NP], s_cell[SMIN_NP], s_src[BD];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int sg = blockIdx.x, sl = sg * NW + wv;
+    const int nc = *P.ncand;
+    const int lj = lane & 15, lk = lane >> 4;
+    float bq[16][KS];  // the wave's codebook slice as B operands: column block cb, k-step ks
+#pragma unroll
+    for (int cb = 0; cb < 16; cb++)
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) bq[cb][ks] = P.pq32T[((size_t)sl * DSUB + 4 * ks + lk) * 256 + cb * 16 + lj];
+#pragma unroll
+    for (int j = lane; j < 256; j += 64) s_pnh[wv][j] = -0.5f * P.pn32[(size_t)sl * 256 + j];  // (+inf beyond ks: -inf never wins a maximum)
+    // the source dimension of every dimension of the block (the permutation does not depend on the pair)
+    for (int j = tid; j < BD; j += NW * 64) s_src[j] = P.perm ? P.perm[sg * BD + j] : sg * BD + j;
+    // the (query, cell) of a batch's pairs are fetched one batch ahead: cand -> cells is two dependent round trips
+    int nxt_q = 0, nxt_cell = 0;
+    if (tid < SMIN_NP && (int)blockIdx.y * SMIN_NP < nc) {
+        const int b0 = (int)blockIdx.y * SMIN_NP, n0 = nc - b0 < SMIN_NP ? nc - b0 : SMIN_NP;
+        const int e = P.cand[b0 + (tid < n0 ? tid : n0 - 1)];
+        nxt_q = e / P.w;
+        nxt_cell = P.cells[e];
+    }
+    for (int base = (int)blockIdx.y * SMIN_NP; base < nc; base += (int)gridDim.y * SMIN_NP) {
+        const int nb_ = nc - base < SMIN_NP ? nc - base : SMIN_NP;
+        if (tid < SMIN_NP) {  // (slots past the end repeat the last pair: every row of the batch holds valid numbers)
+            s_q[tid] = nxt_q;
+            s_cell[tid] = nxt_cell;
+            const int b1 = base + (int)gridDim.y * SMIN_NP;
+            const int n1 = nc - b1 < SMIN_NP ? nc - b1 : SMIN_NP;
+            const int i1 = b1 < nc ? b1 + (tid < n1 ? tid : n1 - 1) : base;  // (a valid index whatever happens: loads are unconditional)
+            const int e = P.cand[i1];
+            nxt_q = e / P.w;
+            nxt_cell = P.cells[e];
+        }
+        __syncthreads();
+        {   // (i) residuals (exact: centroid - q, IVFPQ.java:645, then the permutation), their fp32 copies, ||r_s||^2 and this
+            //     kernel's error term.  A thread is (pair, sub-quantizer of the block, half of its dimensions): 32 x 8 x 2.
+            const int pi = tid >> 4, sw = (tid >> 1) & 7, half = tid & 1;
+            const int dd0 = sw * DSUB + half * VPT, d0 = sg * BD + dd0;
+            const double *cc = P.coarse + (size_t)s_cell[pi] * P.D, *qq = P.Q + (size_t)s_q[pi] * P.D;
+            double nr = 0.0;
+            float rf[VPT];
+#if SMIN_TIMING == 2  // (timing experiment: no global loads in the residual phase; results are wrong)
+#pragma unroll
+            for (int t = 0; t < VPT; t++) {
+                const double r = (double)(d0 + t + s_cell[pi]) * 1e-3 - (double)s_q[pi] * 1e-4;
+                rf[t] = (float)r;
+                nr += r * r;
+            }
+#else
+            if (P.perm) {
+#pragma unroll
+                for (int t = 0; t < VPT; t++) {
+                    const int src = s_src[dd0 + t];
+                    const double r = cc[src] - qq[src];
+                    rf[t] = (float)r;
+                    nr += r * r;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < VPT; t += 2) {
+                    const double2 c2 = *(const double2 *)(cc + d0 + t), q2 = *(const double2 *)(qq + d0 + t);
+                    const double r0 = c2.x - q2.x, r1 = c2.y - q2.y;
+                    rf[t] = (float)r0;
+                    rf[t + 1] = (float)r1;
+                    nr += r0 * r0;
+                    nr += r1 * r1;
+                }
+            }
+#endif
+#pragma unroll
+            for (int t = 0; t < VPT; t++) s_r[pi * RS + dd0 + t] = rf[t];
+            nr += __shfl_xor(nr, 1);  // (the other half)
+            if (half == 0) {
+                const double pm = P.pnmax[sg * NW + sw], pm2 = P.pnmax[P.M + sg * NW + sw];
+                s_err[pi][sw] = 0x1p-24 * 1.01 * (3.0 * nr + (DSUB + 3.0) * pm2 + (2.0 * DSUB + 9.0) * sqrt(nr) * pm) + 1e-30;
+                s_nrf[pi][sw] = (float)nr;
+            }
+        }
+        __syncthreads();
+        // (ii) 16 column blocks x 2 row tiles x KS k-steps of v_mfma_f32_16x16x4_f32; running maximum over the column blocks
+        float av[2][KS];
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) av[rt][ks] = s_r[(rt * 16 + lj) * RS + wv * DSUB + 4 * ks + lk];
+        f32x4 mx[2];
+#pragma unroll
+        for (int cb = 0; cb < (SMIN_TIMING == 1 ? 1 : 16); cb++) {  // (SMIN_TIMING 1: one column block of sixteen; results are wrong)
+            const float ph = s_pnh[wv][cb * 16 + lj];
+#pragma unroll
+            for (int rt = 0; rt < 2; rt++) {
+                f32x4 acc = {ph, ph, ph, ph};
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][ks], bq[cb][ks], acc, 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < 4; v++) mx[rt][v] = cb == 0 ? acc[v] : __builtin_fmaxf(mx[rt][v], acc[v]);
+            }
+        }
+        // maximum over the 16 columns = the 16 lanes of each row of the wave: lanes 15, 31, 47, 63 end up with their row's
+        float m_[8];
+#pragma unroll
+        for (int v = 0; v < 8; v++) m_[v] = mx[v >> 2][v & 3];
+#define SMAX_STEP(pre, q, ctrl)                                                                                                       \
+    asm volatile(pre "v_max_f32_dpp %0, %0, %0 " ctrl "\n\tv_max_f32_dpp %1, %1, %1 " ctrl "\n\tv_max_f32_dpp %2, %2, %2 " ctrl           \
+                     "\n\tv_max_f32_dpp %3, %3, %3 " ctrl                                                                              \
+                 : "+v"(m_[q]), "+v"(m_[q + 1]), "+v"(m_[q + 2]), "+v"(m_[q + 3]))
+#pragma unroll
+        for (int q4 = 0; q4 < 8; q4 += 4) {
+            SMAX_STEP("s_nop 1\n\t", q4, "row_shr:1 row_mask:0xf bank_mask:0xf");
+            SMAX_STEP("", q4, "row_shr:2 row_mask:0xf bank_mask:0xf");
+            SMAX_STEP("", q4, "row_shr:4 row_mask:0xf bank_mask:0xf");
+            SMAX_STEP("", q4, "row_shr:8 row_mask:0xf bank_mask:0xf");
+        }
+#undef SMAX_STEP
+        if (lj == 15) {
+#pragma unroll
+            for (int v = 0; v < 8; v++) s_mx[(v >> 2) * 16 + 4 * lk + (v & 3)][wv] = m_[v];
+        }
+        // (the wave reads back what its own lanes wrote: the LDS operations of one wave complete in order)
+        if (lane < nb_) {
+            const float mn = fmaf(-2.f, s_mx[lane][wv], s_nrf[lane][wv]);
+            const double err = s_err[lane][wv];
+            double term = (double)mn - err;
+            term -= fabs(term) * 0x1p-40;
+            if (!(err < 1e22)) term = -__longlong_as_double(0x7FF0000000000000ll);
+            s_part[lane][wv] = term;
+        }
+        __syncthreads();
+        if (tid < nb_) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < NW; i++) s += s_part[tid][i];
+            if (gridDim.x == 1) P.smin[base + tid] = s;
+            else atomicAdd(P.smin + base + tid, s);
         }
     }
 }

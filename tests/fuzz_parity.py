@@ -86,6 +86,7 @@ for case in range(cases):
         ix.set_option("coarse_fused", fused)
         ix.set_option("no_union", union)
         ix.set_option("smin_pre", spre)
+        ix.set_option("smin_valu", int(case % 3 == 0))
         half = n // 2
         ix.indexVectors([str(i) for i in range(half)], base[:half])
         if half:

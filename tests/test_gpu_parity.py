@@ -857,8 +857,9 @@ def test_union_instances_forced(mi, oracle, D, m, C, n, w, k, dup):
 def test_smin_prefilter_forced(mi, oracle, D, m, C, n, w, k, tr, sep):
     """K3s (`k_pair_smin` + `k_pair_recount`, option `smin_pre`): the certified lower bound of every far pair's Smin, computed in
     front of pass B's counting sort with the codebook in registers; pairs with Smin >= T leave before K3g builds a table for them.
-    Forced on (1), off (0) and hint-driven (-1, three calls so that the device's figures of one call steer the next): ids and
-    distance bits are the oracle's every time, and the forced filter never leaves more pairs than the plain path."""
+    Forced on (1; matrix-core and packed-FMA form), off (0) and hint-driven (-1, three calls so that the device's figures of one
+    call steer the next): ids and distance bits are the oracle's every time, and the forced filter never leaves more pairs than the
+    plain path."""
     ks = 256
     rng = np.random.default_rng(D + m + C)
     mu = sep * rng.standard_normal((C, D))
@@ -876,13 +877,17 @@ def test_smin_prefilter_forced(mi, oracle, D, m, C, n, w, k, tr, sep):
     Q = np.concatenate([base[:48] + 0.01 * rng.standard_normal((48, D)), 0.5 * (base[100:116] + base[200:216]), mu[:4]])
     want = ref.search_batch(Q, k)
     items = {}
-    for mode in (1, 0, -1, -1, -1):
+    for mode, valu in ((1, 0), (1, 1), (0, 0), (-1, 0), (-1, 0), (-1, 0)):
         ix.set_option("smin_pre", mode)
+        ix.set_option("smin_valu", valu)  # (1: the packed-FMA form of the kernel instead of the matrix-core one)
         ix.set_profiling(True)
         got = ix.search_batch(k, Q)
         st = ix.get_stats()
         assert_same(got, want)
-        items.setdefault(mode, st["passb_items_last"])
+        items.setdefault((mode, valu), st["passb_items_last"])
+    # the two forms bound the same minima (their entries differ in the last bits): a pair can change sides only at Smin ~ T
+    assert abs(items[(1, 0)] - items[(1, 1)]) <= 2 + items[(0, 0)] // 200
+    items = {1: items[(1, 0)], 0: items[(0, 0)]}
     assert 0 <= items[1] <= items[0]
     if sep >= 0.8 and m <= 16 and (D // m) in (4, 8, 16):
         assert items[1] < items[0]  # (the filter really removed pairs the coarse bound had left)
