@@ -1499,7 +1499,9 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
                 SP.D = h->D;
                 SP.w = P.w;
                 SP.M = h->m;
-                const dim3 sg((unsigned)sgroups, (unsigned)std::max(1, 2 * std::max(h->num_cus, 8) / sgroups));
+                // (two blocks per CU, but no more blocks than batches: a one-query call would otherwise have 500 blocks load their codebook slices for nothing)
+                const long long nbatch = (npairs + 31) / 32;
+                const dim3 sg((unsigned)sgroups, (unsigned)std::max<long long>(1, std::min<long long>(2 * std::max(h->num_cus, 8) / sgroups, nbatch)));
                 if (h->smin_valu) {  // (A/B: the packed-FMA form)
                     if (h->dsub == 16) hipLaunchKernelGGL(k_pair_smin<16>, sg, dim3(SMIN_NW * 64), 0, st, SP);
                     else if (h->dsub == 8) hipLaunchKernelGGL(k_pair_smin<8>, sg, dim3(SMIN_NW * 64), 0, st, SP);

@@ -405,6 +405,9 @@ struct SminParams {
 #define SMIN_TIMING 0
 #endif
 #define SMIN_NP 32  // pairs per batch (a multiple of 4, at most 64: their results travel in the lanes of one register)
+#ifndef SMIN_NPM
+#define SMIN_NPM 64  // pairs per batch of the matrix-core form (32 or 64)
+#endif
 #define SMIN_NW 8   // waves = sub-quantizers per block (two blocks per CU: one stages residuals while the other multiplies)
 template <int DSUB>
 __global__ __launch_bounds__(SMIN_NW * 64, 4) void k_pair_smin(const SminParams P) {
@@ -527,15 +530,16 @@ template <int DSUB>
 __global__ __launch_bounds__(SMIN_NW * 64, 4) void k_pair_smin_mfma(const SminParams P) {
     constexpr int NW = SMIN_NW, BD = NW * DSUB, KS = DSUB / 4, RS = BD + 4;  // (RS: the A-operand reads -- 16 rows x 4 k -- hit 64 different banks)
     constexpr int VPT = DSUB / 2;  // dimensions per thread in the residual phase: a thread is (pair, sub-quantizer, half)
-    static_assert(SMIN_NP == 32 && NW == 8 && (DSUB == 4 || DSUB == 8 || DSUB == 16), "two MFMA row tiles of pairs; 32 x 8 x 2 threads stage the residuals");
+    constexpr int NP = SMIN_NPM;   // pairs per batch: NP / 16 row tiles, two at a time
+    static_assert(NP % 32 == 0 && NP <= 64 && NW == 8 && (DSUB == 4 || DSUB == 8 || DSUB == 16), "MFMA row tiles of pairs in twos; 32 x 8 x 2 threads stage 32 pairs' residuals at a time");
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) float s_r[SMIN_NP * RS];
+    __shared__ __attribute__((aligned(16))) float s_r[NP * RS];
     __shared__ float s_pnh[NW][256];
-    __shared__ float s_nrf[SMIN_NP][NW];
-    __shared__ float s_mx[SMIN_NP][NW];
-    __shared__ double s_err[SMIN_NP][NW];
-    __shared__ double s_part[SMIN_NP][NW];
-    __shared__ int s_q[SMIN_NP], s_cell[SMIN_NP], s_src[BD];
+    __shared__ float s_nrf[NP][NW];
+    __shared__ float s_mx[NP][NW];
+    __shared__ double s_err[NP][NW];
+    __shared__ double s_part[NP][NW];
+    __shared__ int s_q[NP], s_cell[NP], s_src[BD];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int sg = blockIdx.x, sl = sg * NW + wv;
     const int nc = *P.ncand;
@@ -551,19 +555,19 @@ __global__ __launch_bounds__(SMIN_NW * 64, 4) void k_pair_smin_mfma(const SminPa
     for (int j = tid; j < BD; j += NW * 64) s_src[j] = P.perm ? P.perm[sg * BD + j] : sg * BD + j;
     // the (query, cell) of a batch's pairs are fetched one batch ahead: cand -> cells is two dependent round trips
     int nxt_q = 0, nxt_cell = 0;
-    if (tid < SMIN_NP && (int)blockIdx.y * SMIN_NP < nc) {
-        const int b0 = (int)blockIdx.y * SMIN_NP, n0 = nc - b0 < SMIN_NP ? nc - b0 : SMIN_NP;
+    if (tid < NP && (int)blockIdx.y * NP < nc) {
+        const int b0 = (int)blockIdx.y * NP, n0 = nc - b0 < NP ? nc - b0 : NP;
         const int e = P.cand[b0 + (tid < n0 ? tid : n0 - 1)];
         nxt_q = e / P.w;
         nxt_cell = P.cells[e];
     }
-    for (int base = (int)blockIdx.y * SMIN_NP; base < nc; base += (int)gridDim.y * SMIN_NP) {
-        const int nb_ = nc - base < SMIN_NP ? nc - base : SMIN_NP;
-        if (tid < SMIN_NP) {  // (slots past the end repeat the last pair: every row of the batch holds valid numbers)
+    for (int base = (int)blockIdx.y * NP; base < nc; base += (int)gridDim.y * NP) {
+        const int nb_ = nc - base < NP ? nc - base : NP;
+        if (tid < NP) {  // (slots past the end repeat the last pair: every row of the batch holds valid numbers)
             s_q[tid] = nxt_q;
             s_cell[tid] = nxt_cell;
-            const int b1 = base + (int)gridDim.y * SMIN_NP;
-            const int n1 = nc - b1 < SMIN_NP ? nc - b1 : SMIN_NP;
+            const int b1 = base + (int)gridDim.y * NP;
+            const int n1 = nc - b1 < NP ? nc - b1 : NP;
             const int i1 = b1 < nc ? b1 + (tid < n1 ? tid : n1 - 1) : base;  // (a valid index whatever happens: loads are unconditional)
             const int e = P.cand[i1];
             nxt_q = e / P.w;
@@ -572,7 +576,8 @@ __global__ __launch_bounds__(SMIN_NW * 64, 4) void k_pair_smin_mfma(const SminPa
         __syncthreads();
         {   // (i) residuals (exact: centroid - q, IVFPQ.java:645, then the permutation), their fp32 copies, ||r_s||^2 and this
             //     kernel's error term.  A thread is (pair, sub-quantizer of the block, half of its dimensions): 32 x 8 x 2.
-            const int pi = tid >> 4, sw = (tid >> 1) & 7, half = tid & 1;
+            for (int pi = tid >> 4; pi < NP; pi += 32) {
+            const int sw = (tid >> 1) & 7, half = tid & 1;
             const int dd0 = sw * DSUB + half * VPT, d0 = sg * BD + dd0;
             const double *cc = P.coarse + (size_t)s_cell[pi] * P.D, *qq = P.Q + (size_t)s_q[pi] * P.D;
             double nr = 0.0;
@@ -613,14 +618,17 @@ __global__ __launch_bounds__(SMIN_NW * 64, 4) void k_pair_smin_mfma(const SminPa
                 s_err[pi][sw] = 0x1p-24 * 1.01 * (3.0 * nr + (DSUB + 3.0) * pm2 + (2.0 * DSUB + 9.0) * sqrt(nr) * pm) + 1e-30;
                 s_nrf[pi][sw] = (float)nr;
             }
+            }
         }
         __syncthreads();
         // (ii) 16 column blocks x 2 row tiles x KS k-steps of v_mfma_f32_16x16x4_f32; running maximum over the column blocks
+#pragma unroll 1
+        for (int r0 = 0; r0 < NP; r0 += 32) {  // (two row tiles = 32 pairs at a time: the accumulators of four would not fit)
         float av[2][KS];
 #pragma unroll
         for (int rt = 0; rt < 2; rt++)
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) av[rt][ks] = s_r[(rt * 16 + lj) * RS + wv * DSUB + 4 * ks + lk];
+            for (int ks = 0; ks < KS; ks++) av[rt][ks] = s_r[(r0 + rt * 16 + lj) * RS + wv * DSUB + 4 * ks + lk];
         f32x4 mx[2];
 #pragma unroll
         for (int cb = 0; cb < (SMIN_TIMING == 1 ? 1 : 16); cb++) {  // (SMIN_TIMING 1: one column block of sixteen; results are wrong)
@@ -652,7 +660,8 @@ __global__ __launch_bounds__(SMIN_NW * 64, 4) void k_pair_smin_mfma(const SminPa
 #undef SMAX_STEP
         if (lj == 15) {
 #pragma unroll
-            for (int v = 0; v < 8; v++) s_mx[(v >> 2) * 16 + 4 * lk + (v & 3)][wv] = m_[v];
+            for (int v = 0; v < 8; v++) s_mx[r0 + (v >> 2) * 16 + 4 * lk + (v & 3)][wv] = m_[v];
+        }
         }
         // (the wave reads back what its own lanes wrote: the LDS operations of one wave complete in order)
         if (lane < nb_) {
