@@ -44,6 +44,12 @@
 #ifndef GRP_QMAX
 #define GRP_QMAX 127  // largest table byte: two bytes add without a carry into the neighbouring query's byte (255: every read spread on its own)
 #endif
+#ifndef GRP_QMAX_UNION
+#define GRP_QMAX_UNION 255  // largest table byte of the IVF UNION instances (0: GRP_QMAX): half the filter slack -- spread verifies 991
+                            // codes per query instead of 2,279 -- at 8 instead of 6 instructions per sub-quantizer and code: spread
+                            // 0.66 -> 0.71 M q/s.  The flat-PQ instances keep 127 (cfg2: 1.52 M against 1.47: their survivors cost
+                            // m table reads, not m x dsub codebook terms)
+#endif
 #ifndef GRP_BQ
 #define GRP_BQ 2  // queries whose row arithmetic the table build lets the scheduler interleave
 #endif
@@ -314,11 +320,12 @@ __device__ __forceinline__ void grp_entries(float (&Av)[G][4], const int s, cons
 // the row minimum (reported in s_mn), and q8 = RNE-and-saturate((entry - mn) * inv - 0.5) through v_cvt_pk_u8_f32 -- never
 // above floor((entry - mn) * inv) + 1e-3 (the bound th of phase (e) allows for it); NaN -> 0 or the largest byte, +inf (entries beyond ks) -> the largest byte GRP_QMAX.
 // The codebook columns are loaded once and stay in registers for the G queries.
+template <int QMAX>
 __device__ __forceinline__ float grp_q(const float a, const float inv, const float c) {
     const float x = fmaf(a, inv, c);
-    return GRP_QMAX < 255 ? fminf(x, (float)GRP_QMAX) : x;  // (v_cvt_pk_u8_f32 saturates at 255 itself; NaN -> GRP_QMAX or 0: both valid)
+    return QMAX < 255 ? fminf(x, (float)QMAX) : x;  // (v_cvt_pk_u8_f32 saturates at 255 itself; NaN -> GRP_QMAX or 0: both valid)
 }
-template <int M, int G, int DSUB>
+template <int M, int G, int DSUB, int QMAX>
 __device__ __forceinline__ void grp_rows(unsigned char *lut8, const int s, const int lane, const float *__restrict__ pq32T,
                                          const float *__restrict__ pn32, const float *s_tr32, const float *s_nrf, const float *s_inv,
                                          float *s_mn, const int D) {
@@ -351,15 +358,15 @@ __device__ __forceinline__ void grp_rows(unsigned char *lut8, const int s, const
         const float inv = s_inv[i];
         const float c = fmaf(-mn, inv, -0.5f);
         if (i < 4) {
-            w0[0] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q(a0, inv, c), (u32)i, w0[0]);
-            w0[1] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q(a1, inv, c), (u32)i, w0[1]);
-            w0[2] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q(a2, inv, c), (u32)i, w0[2]);
-            w0[3] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q(a3, inv, c), (u32)i, w0[3]);
+            w0[0] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q<QMAX>(a0, inv, c), (u32)i, w0[0]);
+            w0[1] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q<QMAX>(a1, inv, c), (u32)i, w0[1]);
+            w0[2] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q<QMAX>(a2, inv, c), (u32)i, w0[2]);
+            w0[3] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q<QMAX>(a3, inv, c), (u32)i, w0[3]);
         } else {
-            w1[0] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q(a0, inv, c), (u32)(i - 4), w1[0]);
-            w1[1] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q(a1, inv, c), (u32)(i - 4), w1[1]);
-            w1[2] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q(a2, inv, c), (u32)(i - 4), w1[2]);
-            w1[3] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q(a3, inv, c), (u32)(i - 4), w1[3]);
+            w1[0] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q<QMAX>(a0, inv, c), (u32)(i - 4), w1[0]);
+            w1[1] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q<QMAX>(a1, inv, c), (u32)(i - 4), w1[1]);
+            w1[2] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q<QMAX>(a2, inv, c), (u32)(i - 4), w1[2]);
+            w1[3] = __builtin_amdgcn_cvt_pk_u8_f32(grp_q<QMAX>(a3, inv, c), (u32)(i - 4), w1[3]);
         }
         if ((i % GRP_BQ) == GRP_BQ - 1) __builtin_amdgcn_sched_barrier(0);  // (GRP_BQ queries at a time: the scheduler otherwise interleaves all G and spills)
     }
@@ -743,6 +750,7 @@ template <int M, int G, int DSUB, bool FLAT = false, bool UNION = false>
 __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(const GrpParams P) {
     static_assert(M % 8 == 0 && G <= 8 && G * M * 256 <= 65536, "imm offsets of the table reads");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int QMAX = (UNION && !FLAT && GRP_QMAX_UNION > 0) ? GRP_QMAX_UNION : GRP_QMAX;  // largest table byte of this instance
     constexpr int SPW = M / 8;   // sub-quantizers per wave in the table build
     constexpr int EPL = M / 4;   // exact entries per lane of a verifying quad
     const int D = P.S.D, ks = P.S.ks, dsub = DSUB > 0 ? DSUB : P.S.dsub, cb = P.cb, K1 = P.S.K1;
@@ -805,7 +813,7 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
                 // threshold -- the pair goes back to K3f in (e))
                 float inv = 0.f;
                 if (tid < np && T < 0x7FF0000000000000ull) {
-                    const double iv = (double)(GRP_QMAX - 1) / keyd(T);  // (T = 0: inf)
+                    const double iv = (double)(QMAX - 1) / keyd(T);  // (T = 0: inf)
                     if (iv < 1e30) inv = (float)iv;
                 }
                 s_inv[tid] = inv;
@@ -871,7 +879,7 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
 #pragma unroll 1
         for (int ss = 0; ss < SPW; ss++) {
             if constexpr (DSUB > 0) {
-                grp_rows<M, G, DSUB>(lut8, wv * SPW + ss, lane, P.pq32T, P.pn32, s_tr32, s_nrf, s_inv, s_mn, D);
+                grp_rows<M, G, DSUB, QMAX>(lut8, wv * SPW + ss, lane, P.pq32T, P.pn32, s_tr32, s_nrf, s_inv, s_mn, D);
                 continue;
             }
             float Av[G][4];  // (run-time dsub: the generic form)
@@ -885,7 +893,7 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
                 const float inv = s_inv[i];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const u32 b = (u32)fminf((Av[i][k] - mn) * inv, (float)GRP_QMAX);  // >= 0; +inf beyond ks and NaN -> the largest byte
+                    const u32 b = (u32)fminf((Av[i][k] - mn) * inv, (float)QMAX);  // >= 0; +inf beyond ks and NaN -> the largest byte
                     if (i < 4) w0[k] |= b << (8 * i);
                     else w1[k] |= b << (8 * (i - 4));
                 }
@@ -1061,7 +1069,7 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
                 for (int i = 0; i < G / 2; i++) acc[i] = 0;
                 // GRP_RW table reads are issued together.  With bytes <= 127 two reads are first added byte-wise (no carry can
                 // leave a byte), then spread and added to the fields: 6 instructions per sub-quantizer and code for the group
-                static_assert(GRP_RW % 4 == 0 || GRP_QMAX > 127, "byte-wise pre-add takes the reads in pairs of pairs");
+                static_assert(GRP_RW % 4 == 0 || QMAX > 127, "byte-wise pre-add takes the reads in pairs of pairs");
                 auto spread = [&](const u32 lo, const u32 hi) {
                     acc[0] += lo & 0x00FF00FFu;
                     acc[1] += __builtin_amdgcn_perm(0u, lo, 0x0C030C01u);
@@ -1093,13 +1101,13 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
                             hi[k] = 0;
                         }
                     }
-                    if constexpr (GRP_QMAX <= 63 && GRP_RW == 8) {  // four reads add byte-wise without a carry
+                    if constexpr (QMAX <= 63 && GRP_RW == 8) {  // four reads add byte-wise without a carry
                         spread2(lo[0] + lo[1] + lo[2] + lo[3], hi[0] + hi[1] + hi[2] + hi[3], lo[4] + lo[5] + lo[6] + lo[7],
                                 hi[4] + hi[5] + hi[6] + hi[7]);
-                    } else if constexpr (GRP_QMAX <= 63) {
+                    } else if constexpr (QMAX <= 63) {
 #pragma unroll
                         for (int k = 0; k < GRP_RW; k += 4) spread(lo[k] + lo[k + 1] + lo[k + 2] + lo[k + 3], hi[k] + hi[k + 1] + hi[k + 2] + hi[k + 3]);
-                    } else if constexpr (GRP_QMAX <= 127) {
+                    } else if constexpr (QMAX <= 127) {
 #pragma unroll
                         for (int k = 0; k < GRP_RW; k += 4)
                             spread2(lo[k] + lo[k + 1], hi[k] + hi[k + 1], lo[k + 2] + lo[k + 3], hi[k + 2] + hi[k + 3]);
