@@ -1513,6 +1513,27 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
                 }
                 HIPCK(hipGetLastError());
                 DBG_SYNC("K3s pair smin");
+                if (getenv("MMIDX_SMIN_DUMP")) {  // (debugging aid: how far above the thresholds the bounds lie)
+                    (void)hipStreamSynchronize(st);
+                    int32_t nc = 0;
+                    (void)hipMemcpy(&nc, ncand, 4, hipMemcpyDeviceToHost);
+                    std::vector<double> sm((size_t)std::max(nc, 1));
+                    std::vector<int32_t> cd((size_t)std::max(nc, 1));
+                    std::vector<u64> tt((size_t)nq);
+                    (void)hipMemcpy(sm.data(), h->ws_smin.p, (size_t)nc * 8, hipMemcpyDeviceToHost);
+                    (void)hipMemcpy(cd.data(), h->ws_cand.p, (size_t)nc * 4, hipMemcpyDeviceToHost);
+                    (void)hipMemcpy(tt.data(), h->ws_T.p, (size_t)nq * 8, hipMemcpyDeviceToHost);
+                    long long hist[12] = {0};
+                    for (int i = 0; i < nc; i++) {
+                        double td;
+                        memcpy(&td, &tt[(size_t)(cd[(size_t)i] / P.w)], 8);
+                        const double r = sm[(size_t)i] / td;
+                        int b = r < 1.0 ? 0 : (r < 1.25 ? 1 : (r < 1.5 ? 2 : (r < 2 ? 3 : (r < 3 ? 4 : (r < 4 ? 5 : (r < 6 ? 6 : (r < 8 ? 7 : 8)))))));
+                        hist[b]++;
+                    }
+                    fprintf(stderr, "[mmidx] K3s: %d candidates; Smin_lo / T: <1: %lld, <1.25: %lld, <1.5: %lld, <2: %lld, <3: %lld, <4: %lld, <6: %lld, <8: %lld, more: %lld\n", nc,
+                            hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8]);
+                }
                 hipLaunchKernelGGL(k_pair_recount, dim3(g), dim3(256), 0, st, h->ws_cand.p, ncand, d_cells, P.w, h->ws_T.p, h->ws_smin.p, h->ws_keep.p,
                                    h->ws_pcount.p, h->C, h->pin_hint ? h->pin_hint + 2 : nullptr);
                 DBG_SYNC("pair recount");
@@ -2703,8 +2724,14 @@ int mmidx_get_stats(mmidx_index *h, mmidx_stats *out) {
     s.passa_launches = h->passa_launches;
     s.verified_codes = (int64_t)cnt[3];
     if (h->debug_sync || getenv("MMIDX_GRP_STATS"))
+    {
         fprintf(stderr, "[mmidx] K3g: %llu pairs in groups, %llu alive after the table build (Smin < T), %llu codes verified\n", (unsigned long long)cnt[5],
                 (unsigned long long)cnt[6], (unsigned long long)cnt[3]);
+        u64 c2[2] = {0, 0};
+        (void)hipMemcpy(c2, h->d_counters + 10, sizeof(c2), hipMemcpyDeviceToHost);
+        (void)hipMemset(h->d_counters + 10, 0, sizeof(c2));
+        if (c2[1]) fprintf(stderr, "[mmidx] K3g: %llu of %llu codes have a pair alive after half their sub-quantizers\n", (unsigned long long)c2[0], (unsigned long long)c2[1]);
+    }
     s.passb_items_last = h->pin_hint ? *(volatile int32_t *)h->pin_hint : -1;
     *out = s;
     h->ev_used = 0;

@@ -1130,6 +1130,15 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
                             dd.v = ta.v - aa.v;
                             ng &= dd.w;
                         }
+#ifdef GRP_HALF_STATS  // (measurement only: codes of the wave with a pair still alive at this check, codes looked at)
+                        if (P.stat && sq + GRP_RW == M / 2) {
+                            const u64 al = __builtin_amdgcn_ballot_w64(p < c1 && (~ng & 0x80008000u) != 0u), vl = __builtin_amdgcn_ballot_w64(p < c1);
+                            if (lane == 0) {
+                                atomicAdd(P.stat + 7, (unsigned long long)__popcll(al));
+                                atomicAdd(P.stat + 8, (unsigned long long)__popcll(vl));
+                            }
+                        }
+#endif
                         if (!__builtin_amdgcn_ballot_w64((~ng & 0x80008000u) != 0u)) break;
                     }
 #endif
