@@ -266,6 +266,8 @@ struct mmidx_index {
     DevBuf<int32_t> ws_cand;  // K3s: the pairs behind the coarse bound (+ their count in the last word)
     DevBuf<double> ws_smin;   // K3s: certified lower bounds of their Smin
     DevBuf<double> ws_Qp;     // K3s: the call's queries in transformed (permuted) order
+    DevBuf<int32_t> ws_cand2; // K3s: what the bf16 stage could not drop (+ count in the last word)
+    DevBuf<double> ws_smin1;  // K3s: the bf16 stage's bounds
     double *d_coarseP = nullptr;  // K3s: the centroids in transformed order (RandomPermutation only; built with the K3g tables)
     DevBuf<int32_t> ws_inv;   // iid -> position in the list-major arrays (-1: absent), built on demand
     bool inv_valid = false;
@@ -278,6 +280,7 @@ struct mmidx_index {
     int no_union = 0;            // option "no_union": K3g without that histogram (A/B switch)
     int smin_pre = -1;           // option "smin_pre": K3s (k_pair_smin) in front of pass B's counting sort: 1 always, 0 never, -1 when the
                                  // device-reported figures of the call before say that at least half of the pairs end at Smin >= T
+    int smin_bf16 = 1;           // option "smin_bf16": K3s's bf16 first stage for 16-dimensional sub-quantizers (0: fp32 only)
     int smin_valu = 0;           // option "smin_valu": K3s with packed VALU FMAs instead of the matrix cores (A/B)
     bool pre_on = false;         // the call before ran K3s (which pair of hint words describes it)
     int flat_chunk = 0;          // option "flat_chunk": codes per chunk of a flat PQ list (0 = sized from the batch)
@@ -1472,6 +1475,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
                 HIPCK(h->ws_cand.reserve((size_t)npairs + 4));
                 HIPCK(h->ws_smin.reserve((size_t)npairs));
                 int32_t *ncand = h->ws_cand.p + npairs;
+                const int32_t *cand_list = h->ws_cand.p;
                 HIPCK(hipMemsetAsync(ncand, 0, sizeof(int32_t), st));
                 const int sgroups = h->m / SMIN_NW;
                 if (sgroups > 1) HIPCK(hipMemsetAsync(h->ws_smin.p, 0, (size_t)npairs * sizeof(double), st));
@@ -1502,6 +1506,27 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
                 // (two blocks per CU, but no more blocks than batches: a one-query call would otherwise have 500 blocks load their codebook slices for nothing)
                 const long long nbatch = (npairs + 31) / 32;
                 const dim3 sg((unsigned)sgroups, (unsigned)std::max<long long>(1, std::min<long long>(2 * std::max(h->num_cus, 8) / sgroups, nbatch)));
+                int32_t *hint_cand = h->pin_hint ? h->pin_hint + 2 : nullptr;
+                if (h->dsub == 16 && h->smin_bf16 && !h->smin_valu) {
+                    // first stage: the bf16 bound over every candidate; what it cannot drop becomes the fp32 stage's candidate list
+                    HIPCK(h->ws_cand2.reserve((size_t)npairs + 4));
+                    HIPCK(h->ws_smin1.reserve((size_t)npairs));
+                    int32_t *ncand2 = h->ws_cand2.p + npairs;
+                    HIPCK(hipMemsetAsync(ncand2, 0, sizeof(int32_t), st));
+                    if (sgroups > 1) HIPCK(hipMemsetAsync(h->ws_smin1.p, 0, (size_t)npairs * sizeof(double), st));
+                    SminParams S1 = SP;
+                    S1.smin = h->ws_smin1.p;
+                    hipLaunchKernelGGL(k_pair_smin_bf16, sg, dim3(SMIN_NW * 64), 0, st, S1);
+                    hipLaunchKernelGGL(k_pair_filter1, dim3(g), dim3(256), 0, st, h->ws_cand.p, ncand, P.w, h->ws_T.p, h->ws_smin1.p, h->ws_keep.p,
+                                       h->ws_cand2.p, ncand2, hint_cand);
+                    HIPCK(hipGetLastError());
+                    DBG_SYNC("K3s bf16 stage");
+                    SP.cand = h->ws_cand2.p;
+                    SP.ncand = ncand2;
+                    ncand = ncand2;
+                    cand_list = h->ws_cand2.p;
+                    hint_cand = nullptr;  // (the figure the host steers by is the first stage's input)
+                }
                 if (h->smin_valu) {  // (A/B: the packed-FMA form)
                     if (h->dsub == 16) hipLaunchKernelGGL(k_pair_smin<16>, sg, dim3(SMIN_NW * 64), 0, st, SP);
                     else if (h->dsub == 8) hipLaunchKernelGGL(k_pair_smin<8>, sg, dim3(SMIN_NW * 64), 0, st, SP);
@@ -1521,7 +1546,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
                     std::vector<int32_t> cd((size_t)std::max(nc, 1));
                     std::vector<u64> tt((size_t)nq);
                     (void)hipMemcpy(sm.data(), h->ws_smin.p, (size_t)nc * 8, hipMemcpyDeviceToHost);
-                    (void)hipMemcpy(cd.data(), h->ws_cand.p, (size_t)nc * 4, hipMemcpyDeviceToHost);
+                    (void)hipMemcpy(cd.data(), cand_list, (size_t)nc * 4, hipMemcpyDeviceToHost);
                     (void)hipMemcpy(tt.data(), h->ws_T.p, (size_t)nq * 8, hipMemcpyDeviceToHost);
                     long long hist[12] = {0};
                     for (int i = 0; i < nc; i++) {
@@ -1534,8 +1559,8 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
                     fprintf(stderr, "[mmidx] K3s: %d candidates; Smin_lo / T: <1: %lld, <1.25: %lld, <1.5: %lld, <2: %lld, <3: %lld, <4: %lld, <6: %lld, <8: %lld, more: %lld\n", nc,
                             hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8]);
                 }
-                hipLaunchKernelGGL(k_pair_recount, dim3(g), dim3(256), 0, st, h->ws_cand.p, ncand, d_cells, P.w, h->ws_T.p, h->ws_smin.p, h->ws_keep.p,
-                                   h->ws_pcount.p, h->C, h->pin_hint ? h->pin_hint + 2 : nullptr);
+                hipLaunchKernelGGL(k_pair_recount, dim3(g), dim3(256), 0, st, cand_list, ncand, d_cells, P.w, h->ws_T.p, h->ws_smin.p, h->ws_keep.p,
+                                   h->ws_pcount.p, h->C, hint_cand);
                 DBG_SYNC("pair recount");
             } else {
                 hipLaunchKernelGGL(k_pair_hist, dim3(g), dim3(256), 0, st, d_cells, P.w, 1, npairs, h->ws_pcount.p, h->ws_keep.p, PB, (int32_t *)nullptr,
@@ -2653,6 +2678,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->no_grp = value != 0;
     } else if (n == "flat_chunk") {
         h->flat_chunk = value;
+    } else if (n == "smin_bf16") {
+        h->smin_bf16 = value != 0;
     } else if (n == "smin_valu") {
         h->smin_valu = value != 0;
     } else if (n == "smin_pre") {  // K3s in front of pass B: 1 always, 0 never, -1 by the device's figures of the call before

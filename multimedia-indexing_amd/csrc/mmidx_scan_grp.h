@@ -689,6 +689,182 @@ __global__ __launch_bounds__(SMIN_NW * 64, 4) void k_pair_smin_mfma(const SminPa
         }
     }
 }
+// K3s, first stage for 64 x 16-shaped codebooks: the same bound from ONE v_mfma_f32_16x16x32_bf16 per (row tile, column block)
+// instead of four fp32 MFMAs at a sixteenth of the rate.  k = 32 holds the residual's bf16 head and tail against the codebook's
+// bf16 head twice -- [r_hi | r_lo] x [p_hi | p_hi] -- so the products carry r to 2^-17 and p to 2^-9 (products of bf16 numbers are
+// exact in fp32, the accumulation is fp32).  Error of an entry against the exact one, u = 2^-24:
+//   u nr + u pn  (nrf, pn32)  +  2 [2^-9 1.01 |r_s||p|  (p's head; r's tail and fp32 rounding are inside the 1.01)
+//   + 33 u (pn / 2 + 1.01 |r_s||p|)]  (33 fp32 accumulation steps)  +  u (nr + pn + 2 |r_s||p|)  (last rounding)
+//   <=  2^-24 1.01 [3 nr + 36 max pn + 72 |r_s| max|p|] + 2^-8 1.02 |r_s| max|p| + 1e-30.
+// The bound is ~0.4 % of |r_s||p| looser than the fp32 one: pairs it cannot drop (Smin within that of T) go on to
+// k_pair_smin_mfma, pairs it drops are certified by it alone.  Layouts: A[i = l & 15][k = 8 (l >> 4) .. + 7], B[k][j = l & 15]
+// likewise, C/D as the fp32 form.  DSUB = 16 only (the shape that needs it: YFCC100MExample.java:85-90).
+__global__ __launch_bounds__(SMIN_NW * 64, 4) void k_pair_smin_bf16(const SminParams P) {
+    constexpr int DSUB = 16, NW = SMIN_NW, BD = NW * DSUB, RS = BD + 8, VPT = DSUB / 2, NP = SMIN_NPM;  // (RS in 2-byte units: rows 4 banks apart)
+    static_assert(NP % 32 == 0 && NP <= 64 && NW == 8, "MFMA row tiles of pairs in twos; 32 x 8 x 2 threads stage 32 pairs' residuals at a time");
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) unsigned short s_rh[NP * RS], s_rl[NP * RS];
+    __shared__ float s_pnh[NW][256];
+    __shared__ float s_nrf[NP][NW];
+    __shared__ float s_mx[NP][NW];
+    __shared__ double s_err[NP][NW];
+    __shared__ double s_part[NP][NW];
+    __shared__ int s_q[NP], s_cell[NP], s_src[BD];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int sg = blockIdx.x, sl = sg * NW + wv;
+    const int nc = *P.ncand;
+    const int lj = lane & 15, lk = lane >> 4;
+    // B operands: column block cb, lane (j = lj, k = 8 (lk & 1) .. + 7 of the sub-quantizer's 16 dimensions -- the same head for lk and lk + 2)
+    bf16x8 bq[16];
+#pragma unroll
+    for (int cb = 0; cb < 16; cb++)
+#pragma unroll
+        for (int t = 0; t < 8; t++) bq[cb][t] = (__bf16)P.pq32T[((size_t)sl * DSUB + 8 * (lk & 1) + t) * 256 + cb * 16 + lj];
+#pragma unroll
+    for (int j = lane; j < 256; j += 64) s_pnh[wv][j] = -0.5f * P.pn32[(size_t)sl * 256 + j];
+    for (int j = tid; j < BD; j += NW * 64) s_src[j] = P.perm ? P.perm[sg * BD + j] : sg * BD + j;
+    int nxt_q = 0, nxt_cell = 0;
+    if (tid < NP && (int)blockIdx.y * NP < nc) {
+        const int b0 = (int)blockIdx.y * NP, n0 = nc - b0 < NP ? nc - b0 : NP;
+        const int e = P.cand[b0 + (tid < n0 ? tid : n0 - 1)];
+        nxt_q = e / P.w;
+        nxt_cell = P.cells[e];
+    }
+    for (int base = (int)blockIdx.y * NP; base < nc; base += (int)gridDim.y * NP) {
+        const int nb_ = nc - base < NP ? nc - base : NP;
+        if (tid < NP) {
+            s_q[tid] = nxt_q;
+            s_cell[tid] = nxt_cell;
+            const int b1 = base + (int)gridDim.y * NP;
+            const int n1 = nc - b1 < NP ? nc - b1 : NP;
+            const int i1 = b1 < nc ? b1 + (tid < n1 ? tid : n1 - 1) : base;
+            const int e = P.cand[i1];
+            nxt_q = e / P.w;
+            nxt_cell = P.cells[e];
+        }
+        __syncthreads();
+        for (int pi = tid >> 4; pi < NP; pi += 32) {  // (i) residuals, split into bf16 head and tail; ||r_s||^2; this kernel's error term
+            const int sw = (tid >> 1) & 7, half = tid & 1;
+            const int dd0 = sw * DSUB + half * VPT, d0 = sg * BD + dd0;
+            const double *cc = P.coarse + (size_t)s_cell[pi] * P.D, *qq = P.Q + (size_t)s_q[pi] * P.D;
+            double nr = 0.0;
+            bf16x8 rh, rl;
+            if (P.perm) {
+#pragma unroll
+                for (int t = 0; t < VPT; t++) {
+                    const int src = s_src[dd0 + t];
+                    const double r = cc[src] - qq[src];
+                    const float f = (float)r;
+                    rh[t] = (__bf16)f;
+                    rl[t] = (__bf16)(f - (float)rh[t]);  // (f - head is exact in fp32)
+                    nr += r * r;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < VPT; t += 2) {
+                    const double2 c2 = *(const double2 *)(cc + d0 + t), q2 = *(const double2 *)(qq + d0 + t);
+                    const double r0 = c2.x - q2.x, r1 = c2.y - q2.y;
+                    const float f0 = (float)r0, f1 = (float)r1;
+                    rh[t] = (__bf16)f0;
+                    rl[t] = (__bf16)(f0 - (float)rh[t]);
+                    rh[t + 1] = (__bf16)f1;
+                    rl[t + 1] = (__bf16)(f1 - (float)rh[t + 1]);
+                    nr += r0 * r0;
+                    nr += r1 * r1;
+                }
+            }
+            *(bf16x8 *)(s_rh + pi * RS + dd0) = rh;
+            *(bf16x8 *)(s_rl + pi * RS + dd0) = rl;
+            nr += __shfl_xor(nr, 1);
+            if (half == 0) {
+                const double pm = P.pnmax[sg * NW + sw], pm2 = P.pnmax[P.M + sg * NW + sw];
+                const double cross = sqrt(nr) * pm;
+                s_err[pi][sw] = 0x1p-24 * 1.01 * (3.0 * nr + 36.0 * pm2 + 72.0 * cross) + 0x1p-8 * 1.02 * cross + 1e-30;
+                s_nrf[pi][sw] = (float)nr;
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int r0 = 0; r0 < NP; r0 += 32) {
+            // A operands: rows r0 + rt * 16 + lj; lanes lk < 2 take the head's dimensions 8 lk .. + 7, lanes lk >= 2 the tail's
+            bf16x8 av[2];
+#pragma unroll
+            for (int rt = 0; rt < 2; rt++)
+                av[rt] = *(const bf16x8 *)((lk < 2 ? s_rh : s_rl) + (r0 + rt * 16 + lj) * RS + wv * DSUB + 8 * (lk & 1));
+            f32x4 mx[2];
+#pragma unroll
+            for (int cb = 0; cb < 16; cb++) {
+                const float ph = s_pnh[wv][cb * 16 + lj];
+#pragma unroll
+                for (int rt = 0; rt < 2; rt++) {
+                    f32x4 acc = {ph, ph, ph, ph};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[rt], bq[cb], acc, 0, 0, 0);
+#pragma unroll
+                    for (int v = 0; v < 4; v++) mx[rt][v] = cb == 0 ? acc[v] : __builtin_fmaxf(mx[rt][v], acc[v]);
+                }
+            }
+            float m_[8];
+#pragma unroll
+            for (int v = 0; v < 8; v++) m_[v] = mx[v >> 2][v & 3];
+#define SMAX_STEP(pre, q, ctrl)                                                                                                       \
+    asm volatile(pre "v_max_f32_dpp %0, %0, %0 " ctrl "\n\tv_max_f32_dpp %1, %1, %1 " ctrl "\n\tv_max_f32_dpp %2, %2, %2 " ctrl           \
+                     "\n\tv_max_f32_dpp %3, %3, %3 " ctrl                                                                              \
+                 : "+v"(m_[q]), "+v"(m_[q + 1]), "+v"(m_[q + 2]), "+v"(m_[q + 3]))
+#pragma unroll
+            for (int q4 = 0; q4 < 8; q4 += 4) {
+                SMAX_STEP("s_nop 1\n\t", q4, "row_shr:1 row_mask:0xf bank_mask:0xf");
+                SMAX_STEP("", q4, "row_shr:2 row_mask:0xf bank_mask:0xf");
+                SMAX_STEP("", q4, "row_shr:4 row_mask:0xf bank_mask:0xf");
+                SMAX_STEP("", q4, "row_shr:8 row_mask:0xf bank_mask:0xf");
+            }
+#undef SMAX_STEP
+            if (lj == 15) {
+#pragma unroll
+                for (int v = 0; v < 8; v++) s_mx[r0 + (v >> 2) * 16 + 4 * lk + (v & 3)][wv] = m_[v];
+            }
+        }
+        if (lane < nb_) {
+            const float mn = fmaf(-2.f, s_mx[lane][wv], s_nrf[lane][wv]);
+            const double err = s_err[lane][wv];
+            double term = (double)mn - err;
+            term -= fabs(term) * 0x1p-40;
+            if (!(err < 1e22)) term = -__longlong_as_double(0x7FF0000000000000ll);
+            s_part[lane][wv] = term;
+        }
+        __syncthreads();
+        if (tid < nb_) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < NW; i++) s += s_part[tid][i];
+            if (gridDim.x == 1) P.smin[base + tid] = s;
+            else atomicAdd(P.smin + base + tid, s);
+        }
+    }
+}
+// between the two stages of K3s: the pairs the bf16 bound drops lose their keep flag, the others form the second stage's list
+__global__ void k_pair_filter1(const int32_t *__restrict__ cand, const int32_t *__restrict__ ncand, int w, const u64 *__restrict__ T,
+                               const double *__restrict__ smin, unsigned char *__restrict__ keep, int32_t *__restrict__ cand2,
+                               int32_t *__restrict__ ncand2, int32_t *host_hint_cand) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int nc = *ncand;
+    if (i == 0 && host_hint_cand) *host_hint_cand = nc;
+    const int ic = i < nc ? i : (nc > 0 ? nc - 1 : 0);
+    const int e = nc > 0 ? cand[ic] : 0;
+    const u64 Tq = T[e / w];
+    const double s = nc > 0 ? smin[ic] : 0.0;
+    const double s_lo = s - fabs(s) * 0x1p-40;
+    const double Td = keyd(Tq);
+    const bool dead = (Tq < 0x7FF0000000000000ull) & (Td > 0.0) & (s_lo >= Td);
+    const bool go = (i < nc) & !dead;
+    if ((i < nc) & dead) keep[e] = 0;
+    const u64 mk = __builtin_amdgcn_ballot_w64(go);
+    const int lane = (int)(threadIdx.x & 63);
+    const int leader = mk ? __ffsll((long long)mk) - 1 : 0;
+    u32 base = 0;
+    if (mk && lane == leader) base = (u32)atomicAdd(ncand2, (int)__popcll(mk));
+    base = wave_read_u32(base, leader);
+    if (go) cand2[base + (u32)__popcll(mk & ((1ull << lane) - 1ull))] = e;
+}
 // the pairs K3s found dead leave pass B; the others are counted per cell as k_pair_hist would have (cnt[C] = their total)
 __global__ void k_pair_recount(const int32_t *__restrict__ cand, const int32_t *__restrict__ ncand, const int32_t *__restrict__ cells, int w,
                                const u64 *__restrict__ T, const double *__restrict__ smin, unsigned char *__restrict__ keep,

@@ -87,6 +87,7 @@ for case in range(cases):
         ix.set_option("no_union", union)
         ix.set_option("smin_pre", spre)
         ix.set_option("smin_valu", int(case % 3 == 0))
+        ix.set_option("smin_bf16", int(case % 4 != 1))
         half = n // 2
         ix.indexVectors([str(i) for i in range(half)], base[:half])
         if half:

@@ -877,14 +877,16 @@ def test_smin_prefilter_forced(mi, oracle, D, m, C, n, w, k, tr, sep):
     Q = np.concatenate([base[:48] + 0.01 * rng.standard_normal((48, D)), 0.5 * (base[100:116] + base[200:216]), mu[:4]])
     want = ref.search_batch(Q, k)
     items = {}
-    for mode, valu in ((1, 0), (1, 1), (0, 0), (-1, 0), (-1, 0), (-1, 0)):
+    for mode, valu, b16 in ((1, 0, 1), (1, 1, 1), (1, 0, 0), (0, 0, 1), (-1, 0, 1), (-1, 0, 1), (-1, 0, 1)):
         ix.set_option("smin_pre", mode)
         ix.set_option("smin_valu", valu)  # (1: the packed-FMA form of the kernel instead of the matrix-core one)
+        ix.set_option("smin_bf16", b16)   # (0: without the bf16 first stage that 16-dimensional sub-quantizers get)
         ix.set_profiling(True)
         got = ix.search_batch(k, Q)
         st = ix.get_stats()
         assert_same(got, want)
-        items.setdefault((mode, valu), st["passb_items_last"])
+        items.setdefault((mode, valu) if b16 else (mode, 2), st["passb_items_last"])
+    assert items[(1, 2)] == items[(1, 0)]  # (what the bf16 stage cannot drop is decided by the fp32 stage: the same pairs are left)
     # the two forms bound the same minima (their entries differ in the last bits): a pair can change sides only at Smin ~ T
     assert abs(items[(1, 0)] - items[(1, 1)]) <= 2 + items[(0, 0)] // 200
     items = {1: items[(1, 0)], 0: items[(0, 0)]}

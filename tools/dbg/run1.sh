@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -x -q 2>&1 | grep -E "passed|failed" | tail -3
-timeout 900 python tests/fuzz_parity.py 60 21 2>&1 | tail -3
-export ABARGS="--extras 0 --spread-steps 0"; tools/dbg/ab_hard.sh ab3 base nohq base nohq
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "smin_prefilter or yfcc_shape" 2>&1 | tail -4
+timeout 600 python tests/fuzz_parity.py 40 31 2>&1 | tail -3
+export YFCC_ARGS="--w 64 --parity 0"; tools/dbg/ab_yfcc.sh aby7 base
+export YFCC_ARGS="--w 64 --parity 0 --opt smin_bf16=0"; tools/dbg/ab_yfcc.sh aby8 base
