@@ -61,6 +61,9 @@
                      // the wave is still at or below its bound, and skip the rest of the lookups when none is (hard workload: pass B
                      // 4.86 -> 4.58 ms; 0: off; n > 1: every n sub-quantizers)
 #endif
+#ifndef GRP_TOUCH
+#define GRP_TOUCH 0  // 1: touch the code lines of the segment after next (measured: see DESIGN.md 5.12)
+#endif
 #ifndef GRP_WPS
 #define GRP_WPS 4  // waves per SIMD the register allocation is held to (blocks per CU x 2)
 #endif
@@ -1232,6 +1235,20 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
                     nxt[u].load(codes + (size_t)(p < c1 ? p : c1 - 1) * M);
                 }
             }
+#if GRP_TOUCH
+            // the segment after next: one word per 128-byte line of the wave's two chunks (64 codes x M bytes each), so that the
+            // real loads a segment from now find their lines on the way (or in the L2) instead of starting the round trip
+            [[maybe_unused]] u32 touch = 0;
+            if (GRP_SEGU == 2 && M >= 8 && seg + 2 * (int64_t)GRP_SEG < c1) {
+                const int tl = lane < M ? lane : M - 1;
+                int64_t tp = seg + 2 * (int64_t)GRP_SEG + (tl / (M / 2)) * GRP_NT + wv * 64;
+                tp = tp < c1 ? tp : c1 - 1;
+                size_t to = (size_t)tp * M + (size_t)(tl % (M / 2)) * 128;
+                const size_t tmax = (size_t)(c1 - 1) * M;
+                to = to < tmax ? to : tmax;
+                touch = *(const volatile u32 *)(codes + (to & ~(size_t)3));
+            }
+#endif
             // one code of the lane at a time: per sub-quantizer ONE table read (address = 8 x byte from one SDWA shift, row in
             // the immediate offset) brings the byte of every query of the group; the bytes are spread into 16-bit fields
             // (queries 0|2, 1|3, 4|6, 5|7: sums stay below 2^16, so plain 32-bit adds carry nothing across fields) -- about
@@ -1356,6 +1373,9 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
 #ifdef GRP_TIMING_NO_VERIFY
             if (pend == 0x2345u) s_queue[1] = 1;  // (keeps the scan alive)
             pend = 0;
+#endif
+#if GRP_TOUCH
+            asm volatile("" ::"v"(touch));  // (keeps the touch load; its data is not used)
 #endif
             // ---- survivors go to the queue at once when they fit; what does not fit waits for the epoch's barrier ----
             pendq[ej] = pend;
