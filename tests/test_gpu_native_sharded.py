@@ -163,6 +163,31 @@ def test_native_sharded_load_index_and_transform(mi, oracle, devices):
     ix.close()
 
 
+@pytest.mark.parametrize("devices,tr", [([0], 0), ([0, 0], 2), ([0, 0, 0], 2)], ids=["rccl1", "virt2-perm", "virt3-perm"])
+def test_native_sharded_smin_prefilter(mi, oracle, devices, tr):
+    """K3s (the certified Smin of every far pair in front of pass B's sort) inside every shard of a sharded handle:
+    the option goes to every shard, each shard keeps its own transformed copy of the centroids and its own hint words.  Forced on
+    (with and without the bf16 first stage of 16-dimensional sub-quantizers), off, and hint-driven over three calls: the oracle's ids
+    and distance bits every time."""
+    D, C_, m, ks, n, w, k = 128, 24, 8, 256, 24000, 12, 20  # (dsub = 16: the bf16 stage runs)
+    rng = np.random.default_rng(5)
+    mu = 0.8 * rng.standard_normal((C_, D))
+    base = mu[rng.integers(0, C_, n)] + 0.5 * rng.standard_normal((n, D))
+    pq = np.stack([synth.kmeans((mu[rng.integers(0, C_, 2000)] - base[:2000])[:, s * (D // m):(s + 1) * (D // m)], ks, iters=1, seed=s) for s in range(m)])
+    p = {"coarse": mu, "pq": pq}
+    ref = make_ref(oracle, p, D, m, ks, C_, w, tr=tr)
+    ref.add_vectors(base)
+    ix = make_sharded(mi, p, D, m, ks, C_, w, n, devices, tr=tr)
+    ix.indexVectors([str(i) for i in range(n)], base)
+    Q = np.concatenate([base[:40] + 0.01 * rng.standard_normal((40, D)), 0.5 * (base[100:116] + base[200:216]), mu[:4]])
+    want = ref.search_batch(Q, k)
+    for mode, b16 in ((1, 1), (1, 0), (0, 1), (-1, 1), (-1, 1), (-1, 1)):
+        ix.set_option("smin_pre", mode)
+        ix.set_option("smin_bf16", b16)
+        assert_same(ix.search_batch(k, Q), want)
+    ix.close()
+
+
 @pytest.mark.parametrize("S", [1, 2])
 def test_native_sharded_sliced_device_entry_points(mi, oracle, S):
     """The device-resident forms: slice r of the batch lives in the HBM of shard r's device (torch tensors as plumbing)."""
