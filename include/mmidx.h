@@ -323,7 +323,8 @@ int mmidx_set_profiling(mmidx_index *h, int enabled);
  * "passb_main_grid", "no_item_compaction", "passa_item_min", "passa_item_margin" (a shard's pass-A item list,
  * section 6), "smin_pre" (K3s, the certified Smin of every far pair in front of pass B's sort, section 5.15: 1 always, 0 never,
  * -1 = default: by the figures the device reported for the call before), "smin_valu" (1: K3s with packed VALU FMAs instead of
- * the matrix cores), "smin_bf16" (0: without K3s's bf16 first stage), "no_union" (K3g's instances that rank the union of the verified candidates: -1 always, 1 never, 0 hint).  On a sharded handle: "shard_exchange" (0: partial lists stored into the owners' buffers over xGMI, 1: ncclSend /
+ * the matrix cores), "smin_bf16" (0: without K3s's bf16 first stage), "coarse_dma_kc" (0: long vectors through K1e's register staging instead of the
+ * LDS-DMA kernel), "no_union" (K3g's instances that rank the union of the verified candidates: -1 always, 1 never, 0 hint).  On a sharded handle: "shard_exchange" (0: partial lists stored into the owners' buffers over xGMI, 1: ncclSend /
  * ncclRecv), "tie_slots" (flagged queries per owner and replay round, 0 = no replay), "shard_max_round"; every other option goes
  * to every shard. */
 int mmidx_set_option(mmidx_index *h, const char *name, int value);

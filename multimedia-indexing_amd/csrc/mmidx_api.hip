@@ -224,6 +224,7 @@ struct mmidx_index {
     int Cp = 0, Dp = 0;          // C rounded up to 128, D rounded up to 32
     bool coarse_v1 = false;      // MMIDX_COARSE_V1=1: K1c/K1d (fp32 MFMA, full d~ matrix) instead
     bool coarse_fused = false;   // option "coarse_fused": K1f as one kernel (front end + selection), as in round 1 (A/B switch)
+    int coarse_dma_kc = 1;       // option "coarse_dma_kc": K1e' with LDS-DMA also for vectors of several k chunks (Dp a multiple of 128)
     bool coarse_nodma = false;   // option "coarse_nodma": K1e with register staging also when Dp == 128 (A/B switch)
     bool no_item_compaction = false;  // option "no_item_compaction": a shard's pass A over every query (A/B switch)
     int passa_item_min = 4096;        // option "passa_item_min": fewest queries per call for that compaction
@@ -1142,6 +1143,11 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
             hipLaunchKernelGGL(k_coarse_gmin16_dma, dim3((unsigned)qblocks, (unsigned)csplit), dim3(MMIDX_BLOCK), 0, st, (const __bf16 *)h->ws_Qh.p,
                                (const __bf16 *)h->ws_Ql.p, (const __bf16 *)h->d_Ch, (const __bf16 *)h->d_Cl, h->d_cn_pad, h->ws_qn.p,
                                (float2 *)h->ws_gmin.p, h->Cp, (int)nq, G);
+        } else if (h->Dp > G16_KC && h->Dp % G16_KC == 0 && h->coarse_dma_kc) {
+            // several k chunks (long vectors): the same double buffering, (chunk, half tile) after (chunk, half tile)
+            hipLaunchKernelGGL(k_coarse_gmin16_dma_kc, dim3((unsigned)qblocks, (unsigned)csplit), dim3(MMIDX_BLOCK), 0, st, (const __bf16 *)h->ws_Qh.p,
+                               (const __bf16 *)h->ws_Ql.p, (const __bf16 *)h->d_Ch, (const __bf16 *)h->d_Cl, h->d_cn_pad, h->ws_qn.p,
+                               (float2 *)h->ws_gmin.p, h->Cp, (int)nq, G, h->Dp);
         } else {
             const size_t l16 = 2 * (size_t)G16_BC * G16_STRIDE;
             HIPCK(hipFuncSetAttribute((const void *)k_coarse_gmin16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l16));
@@ -2662,6 +2668,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->coarse_v1 = value != 0;
     } else if (n == "coarse_fused") {
         h->coarse_fused = value != 0;
+    } else if (n == "coarse_dma_kc") {
+        h->coarse_dma_kc = value != 0;
     } else if (n == "coarse_nodma") {
         h->coarse_nodma = value != 0;
     } else if (n == "no_item_compaction") {

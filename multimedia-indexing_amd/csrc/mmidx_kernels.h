@@ -1365,6 +1365,149 @@ __global__ __launch_bounds__(MMIDX_BLOCK, 2) void k_coarse_gmin16_dma(const __bf
     }
 }
 
+// K1e' for long vectors (Dp a multiple of 128, e.g. the 1024 dimensions of YFCC100MExample.java:85): the same LDS-DMA double
+// buffering with the k chunks of a tile streamed through the two half-tile buffers one after the other -- (chunk, half) is the
+// unit -- the accumulators kept across the chunks of a tile, the query fragments of a chunk reloaded when the previous ones are dead.
+// K1e itself (k_coarse_gmin16) stages every chunk through registers behind two barriers.
+__global__ __launch_bounds__(MMIDX_BLOCK, 2) void k_coarse_gmin16_dma_kc(const __bf16 *__restrict__ Qh, const __bf16 *__restrict__ Ql,
+                                                                   const __bf16 *__restrict__ Ch, const __bf16 *__restrict__ Cl,
+                                                                   const double *__restrict__ cn, const double *__restrict__ qn,
+                                                                   float2 *__restrict__ gpair, int Cp, int nq, int G, int Dp) {
+    constexpr int KC = G16_KC;               // 128 bf16 = 256 B = 16 units per row and k chunk (Dp = nkc x KC)
+    constexpr int HROWS = G16_BC / 2;        // centroids per half tile
+    constexpr int HBYTES = HROWS * KC * 2;   // 16 KiB per part (head / tail)
+    const int nkc = Dp / KC;
+    __shared__ __attribute__((aligned(1024))) unsigned char buf0[2 * HBYTES];
+    __shared__ __attribute__((aligned(1024))) unsigned char buf1[2 * HBYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int q0 = blockIdx.x * G16_BQ + wave * 32;
+    const int ntiles = Cp / G16_BC;
+    const int t_per = (ntiles + gridDim.y - 1) / gridDim.y;
+    const int t_lo = blockIdx.y * t_per, t_hi = (t_lo + t_per < ntiles) ? t_lo + t_per : ntiles;
+    if (t_lo >= t_hi) return;  // block-uniform
+    float qn_r[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int q = q0 + rt * 16 + 4 * fg + r;
+            qn_r[rt][r] = q < nq ? (float)qn[q] : 0.0f;
+        }
+    bf16x8 ah[2][4], al[2][4];    // A fragments of the current k chunk: [row tile][k step of 32]
+    auto load_a = [&](bf16x8 (&xh)[2][4], bf16x8 (&xl)[2][4], const int kc) {
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++) {
+            int q = q0 + rt * 16 + fr;
+            q = q < nq ? q : nq - 1;
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                xh[rt][ks] = *(const bf16x8 *)(Qh + (size_t)q * Dp + kc * KC + ks * 32 + fg * 8);
+                xl[rt][ks] = *(const bf16x8 *)(Ql + (size_t)q * Dp + kc * KC + ks * 32 + fg * 8);
+            }
+        }
+    };
+    load_a(ah, al, 0);
+    // DMA of one half tile (first centroid row0) into a buffer: 4 + 4 wave-instructions of 1 KiB (4 rows) per wave
+    auto issue = [&](unsigned char *buf, int row0, int kbase) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int pu = (i * 4 + wave) * 64 + lane;  // 16-byte slot of the part this lane fills
+            const int row = pu >> 4, slot = pu & 15;
+            const size_t src = ((size_t)(row0 + row) * Dp + (size_t)kbase + (size_t)((slot ^ (row & 15)) * 8)) * 2;  // bytes
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const unsigned char *)Ch + src),
+                                             (__attribute__((address_space(3))) void *)(buf + (i * 4 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const unsigned char *)Cl + src),
+                                             (__attribute__((address_space(3))) void *)(buf + HBYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+        }
+    };
+    f32x4 acc[2][8];
+    // the four column tiles of one half: acc[rt][ct0 .. ct0 + 3] += A x B
+    auto half_mma = [&](const unsigned char *buf, const int ct0) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+#pragma unroll
+            for (int cp = 0; cp < 4; cp += 2) {
+                bf16x8 bh[2], bl[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int row = (cp + u) * 16 + fr;
+                    const int off = row * (KC * 2) + (((ks * 4 + fg) ^ fr) * 16);  // (row & 15 == fr)
+                    bh[u] = *(const bf16x8 *)(buf + off);
+                    bl[u] = *(const bf16x8 *)(buf + HBYTES + off);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int rt = 0; rt < 2; rt++)
+                        acc[rt][ct0 + cp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bh[u], acc[rt][ct0 + cp + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int rt = 0; rt < 2; rt++)
+                        acc[rt][ct0 + cp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bl[u], acc[rt][ct0 + cp + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int rt = 0; rt < 2; rt++)
+                        acc[rt][ct0 + cp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt][ks], bh[u], acc[rt][ct0 + cp + u], 0, 0, 0);
+            }
+        }
+    };
+    issue(buf0, t_lo * G16_BC, 0);
+    __syncthreads();
+    for (int t = t_lo; t < t_hi; t++) {
+        const int c0 = t * G16_BC;
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int ct = 0; ct < 8; ct++) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (the tile's squared norms are requested before the DMA: a wait for them then does not wait for the DMA)
+        float cn_c[8];
+#pragma unroll
+        for (int ct = 0; ct < 8; ct++) {
+            const float cf = (float)cn[c0 + ct * 16 + fr];
+            cn_c[ct] = cf < 3.0e38f ? cf : 3.0e38f;
+        }
+#pragma unroll 1
+        for (int kc = 0; kc < nkc; kc++) {
+            const bool last = kc + 1 == nkc;
+            // first half of this chunk from buf0 while its second half lands in buf1 and the next chunk's queries are requested
+            issue(buf1, c0 + HROWS, kc * KC);
+            half_mma(buf0, 0);
+            __syncthreads();  // buf1 has landed (every wave waited for its own DMA), buf0 is free
+            if (!last) issue(buf0, c0, (kc + 1) * KC);
+            else if (t + 1 < t_hi) issue(buf0, c0 + G16_BC, 0);
+            half_mma(buf1, 4);
+            load_a(ah, al, last ? 0 : kc + 1);  // (the fragments are dead here: 222 registers leave no room for a second set)
+            if (!last) __syncthreads();  // the next chunk's first half has landed in buf0, buf1 is free
+        }
+        // epilogue: as in K1e
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float m1 = __int_as_float(0x7f7ffff8), m2 = m1;
+#pragma unroll
+                for (int ct = 0; ct < 8; ct++) {
+                    const float tv = __builtin_fmaf(-2.0f, acc[rt][ct][r], cn_c[ct]);
+                    const float tp = __int_as_float((__float_as_int(tv) & ~7) | ct);
+                    m2 = __builtin_amdgcn_fmed3f(m1, m2, tp);
+                    m1 = __builtin_amdgcn_fmed3f(m1, tp, -3.0e38f);
+                }
+                const int a1 = __float_as_int(m1) & 7;
+                const float d1 = m1 + qn_r[rt][r];
+                float d2 = m2 + qn_r[rt][r];
+                d2 = d2 < 0.0f ? 0.0f : d2;
+                const float m2p = __int_as_float((__float_as_int(d2) & ~7) | a1);
+                const int q = q0 + rt * 16 + 4 * fg + r;
+                if (q < nq) gpair[(size_t)q * G + (size_t)t * 16 + fr] = make_float2(d1, m2p);
+            }
+        }
+        __syncthreads();  // the next tile's first half has landed in buf0, buf1 is free
+    }
+}
+
 // K6a': certified nearest-centroid assignment with the bf16-split dot products of K1e (the encoder's and the learner's
 // argmin).  Each block keeps 128 vectors' fragments in registers and walks ALL centroid tiles; every lane tracks the
 // smallest and second smallest d~ (and the index of the smallest) over the columns it holds for each of its rows, the 16

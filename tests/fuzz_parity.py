@@ -88,6 +88,7 @@ for case in range(cases):
         ix.set_option("smin_pre", spre)
         ix.set_option("smin_valu", int(case % 3 == 0))
         ix.set_option("smin_bf16", int(case % 4 != 1))
+        ix.set_option("coarse_dma_kc", int(case % 5 != 2))  # (K1e' with LDS-DMA for vectors of several 128-dimension chunks)
         half = n // 2
         ix.indexVectors([str(i) for i in range(half)], base[:half])
         if half:

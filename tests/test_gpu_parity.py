@@ -896,6 +896,37 @@ def test_smin_prefilter_forced(mi, oracle, D, m, C, n, w, k, tr, sep):
     ix.close()
 
 
+@pytest.mark.parametrize("D,C,m,w,k,tr,n", [
+    (1024, 300, 64, 8, 30, 2, 6000),     # YFCC100MExample.java:85-90: eight k chunks, RandomPermutation
+    (256, 260, 32, 5, 10, 0, 5000),      # two chunks
+    (384, 520, 8, 3, 20, 0, 4000),       # three chunks, dsub 48
+    (1024, 1100, 64, 64, 30, 2, 5000),   # w = 64 (Example.java:96-97): the lane-per-candidate exact stage behind it
+])
+def test_coarse_stage_long_vectors_dma(mi, oracle, D, C, m, w, k, tr, n):
+    """K1e' for vectors of several 128-dimension chunks (`k_coarse_gmin16_dma_kc`, option `coarse_dma_kc`): the centroid tiles of
+    every chunk go through the two LDS-DMA half-tile buffers, the accumulators stay across the chunks.  With and without it the
+    answers are the oracle's, ids and distance bits (the certified selection behind it does not depend on which kernel produced
+    the group minima, as long as they are within the error bound)."""
+    rng = np.random.default_rng(D + C)
+    mu = rng.standard_normal((C, D))
+    base = mu[rng.integers(0, C, n)] + 0.3 * rng.standard_normal((n, D))
+    pq = 0.3 * rng.standard_normal((m, 256, D // m))
+    ref = oracle_ivfpq(oracle, {"coarse": mu, "pq": pq}, D, m, 256, C, w, tr=tr)
+    Q = np.concatenate([base[:40] + 0.01 * rng.standard_normal((40, D)), mu[:8] + 0.2 * rng.standard_normal((8, D))])
+    ix = mi.IVFPQ(D, n, False, "", m, 256, tr, C, 512)
+    ix.loadCoarseQuantizer(mu)
+    ix.loadProductQuantizer(pq)
+    ix.setW(w)
+    ix.indexVectors(list(range(n)), base)
+    off, iids, cds = ix.export()
+    ref.load_lists(off, iids, cds)
+    want = ref.search_batch(Q, k)
+    for opt in (1, 0):
+        ix.set_option("coarse_dma_kc", opt)
+        assert_same(ix.search_batch(k, Q), want)
+    ix.close()
+
+
 def test_snapshot_roundtrip(mi, oracle, tmp_path):
     """saveSnapshot / loadSnapshot (flat restart path): identical answers, ids preserved."""
     D, C, m, ks, n, w, k = 32, 16, 8, 256, 3000, 4, 10
