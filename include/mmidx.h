@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MMIDX_ABI_VERSION 5
+#define MMIDX_ABI_VERSION 6
 
 typedef struct mmidx_index mmidx_index; /* opaque handle: one index on one GPU */
 
@@ -306,6 +306,11 @@ typedef struct mmidx_stats {
     int32_t passb_items_last;
     /* codes of pass B that survived the lower-bound filter and had their exact distance computed (ABI version 4) */
     int64_t verified_codes;
+    /* K3m, the matrix-core lower bound of pass B (csrc/mmidx_scan_mfma.h; ABI version 6): (query, code) pairs its bound could not
+     * drop (each verified exactly: they are part of verified_codes), and queries it handed back to K3f (no finite threshold yet, a
+     * full survivor list or pool) */
+    int64_t mfma_survivors;
+    int64_t mfma_redo_queries;
 } mmidx_stats;
 /* enabled: 0 off; 1 full (six events per search call and the code counters: every field below); 2 light (only the two
  * events around pass A: passa_ms / passa_launches -- an event record is a ~5 us bubble in the stream, so a throughput

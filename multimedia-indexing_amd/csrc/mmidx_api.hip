@@ -13,6 +13,7 @@
 #include "../../include/mmidx.h"
 #include "mmidx_kernels.h"
 #include "mmidx_scan_grp.h"
+#include "mmidx_scan_mfma.h"
 #include "mmidx_frontend.h"
 
 #include <algorithm>
@@ -285,6 +286,20 @@ struct mmidx_index {
     int smin_valu = 0;           // option "smin_valu": K3s with packed VALU FMAs instead of the matrix cores (A/B)
     bool pre_on = false;         // the call before ran K3s (which pair of hint words describes it)
     int flat_chunk = 0;          // option "flat_chunk": codes per chunk of a flat PQ list (0 = sized from the batch)
+    // K3m (mmidx_scan_mfma.h): pass B as a certified lower bound on the matrix cores
+    unsigned short *d_pq16 = nullptr;  // fp16 codebook [D / 8][256][8], scaled by 2^pq_ep
+    double *d_pn64 = nullptr;          // [m][256] ||p_sj||^2
+    DevBuf<float> xn;                  // ||x||^2 of every stored code (list-major)
+    bool xn_valid = false, mfma_valid = false, mfma_ok = false;
+    int pq_ep = 0;
+    double pq_maxabs = 0.0;            // largest |codebook element| (set_pq)
+    int no_mfma = 0;                   // option "no_mfma" = 1: pass B through K3g / K3f (A/B switch)
+    int mfma_sub = 0;                  // option "mfma_sub": codes per K3m item (0 = sized from the call)
+    int mfma_qcap = 0;                 // option "mfma_qcap": survivor records per launch (0 = sized from the call; tests force the redo path)
+    int mfma_blocks = 0;               // option "mfma_blocks": persistent blocks (0 = occupancy x CUs)
+    DevBuf<uint2> ws_surv;
+    DevBuf<u32> ws_mfctl, ws_psnap;
+    DevBuf<unsigned char> ws_redo;
     void *d_grpx = nullptr, *pin_grpx = nullptr;  // K3g's GrpExtra on the device and its pinned mirror
     double *d_zero = nullptr;    // ... and the zero "centroid"
 
@@ -460,6 +475,7 @@ int build_csr(mmidx_index *h) {
         h->ws_dest.release();
     }
     h->inv_valid = false;  // (iid -> position map of mmidx_get_codes / mmidx_distance)
+    h->xn_valid = false;   // (K3m's per-code norms follow the codes)
     h->max_list_len = 0;
     h->nonempty_lists = 0;
     for (int c = 0; c < nl; c++) {
@@ -1057,9 +1073,194 @@ int launch_grouped_common(mmidx_index *h, const ScanParams &S, ScanParams F, con
     return launch_scan_filtered(h, F, pl, dim3((unsigned)F.n_items, 1), st, -1);
 }
 
+// ---- K3m (mmidx_scan_mfma.h): pass B as a certified lower bound on the matrix cores ------------------------------
+// index-side tables: the fp16 codebook (per quantizer) and ||x||^2 of every stored code (per CSR build)
+int build_mfma_tables(mmidx_index *h) {
+    const bool shape_ok = (h->kind == MMIDX_KIND_IVFPQ || h->kind == MMIDX_KIND_PQ) && h->code_bytes == 1 && h->ks <= 256 && h->pq_set &&
+                          (h->dsub == 8 || h->dsub == 16) && (h->D == 32 || h->D == 64 || h->D == 128) && h->transform != MMIDX_TR_ROTATION;
+    if (!shape_ok) {
+        h->mfma_ok = false;
+        return MMIDX_OK;
+    }
+    if (!h->mfma_valid) {
+        h->mfma_ok = false;
+        h->mfma_valid = true;
+        // power-of-two scale: the largest |element| lands in [2^12, 2^13)
+        int ep = 0;
+        if (!(h->pq_maxabs < 1e30) || !(h->rmax < 1e30)) return MMIDX_OK;  // (also NaN: K3g / K3f serve such a codebook)
+        if (h->pq_maxabs > 0.0) {
+            int ex;
+            (void)std::frexp(h->pq_maxabs, &ex);
+            ep = 13 - ex;
+        }
+        if (ep < -110 || ep > 110) return MMIDX_OK;
+        h->pq_ep = ep;
+        if (!h->d_pq16) HIPCK(hipMalloc((void **)&h->d_pq16, (size_t)h->D * 512));
+        if (!h->d_pn64) HIPCK(hipMalloc((void **)&h->d_pn64, (size_t)h->m * 256 * sizeof(double)));
+        const int rows = h->D / 8 * 256;
+        hipLaunchKernelGGL(k_pq16_table, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, h->stream, h->d_pqT, h->d_pq16, h->m, h->ks, h->dsub,
+                           std::ldexp(1.0, ep));
+        hipLaunchKernelGGL(k_pn64_table, dim3((unsigned)h->m), dim3(256), 0, h->stream, h->d_pqT, h->d_pn64, h->m, h->ks, h->dsub);
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(h->stream));
+        h->mfma_ok = true;
+        h->xn_valid = false;
+    }
+    if (h->mfma_ok && !h->xn_valid && h->n_csr > 0) {
+        HIPCK(h->xn.reserve((size_t)h->n_csr));
+        hipLaunchKernelGGL(k_code_norms, dim3((unsigned)((h->n_csr + 255) / 256)), dim3(256), 0, h->stream, (const unsigned char *)h->d_codes, h->d_pn64,
+                           h->xn.p, h->m, (long long)h->n_csr);
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(h->stream));
+        h->xn_valid = true;
+    }
+    return MMIDX_OK;
+}
+
+template <int NJ, int DSUB>
+int launch_mfma_scan_t(mmidx_index *h, const MfmaParams &MP, size_t lds, hipStream_t st) {
+    HIPCK(hipFuncSetAttribute((const void *)k_scan_mfma<NJ, DSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int blocks = h->mfma_blocks;
+    if (blocks <= 0) {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_scan_mfma<NJ, DSUB>, MF_NT, lds) != hipSuccess || occ < 1) {
+            (void)hipGetLastError();
+            occ = 1;
+        }
+        blocks = occ * std::max(h->num_cus, 8);
+    }
+    blocks = std::max(8, (blocks + 7) & ~7);
+    hipLaunchKernelGGL((k_scan_mfma<NJ, DSUB>), dim3((unsigned)blocks), dim3(MF_NT), lds, st, MP);
+    HIPCK(hipGetLastError());
+    return MMIDX_OK;
+}
+template <int M, int DSUB>
+int launch_mfma_verify_t(mmidx_index *h, const MfmaParams &MP, hipStream_t st) {
+    const unsigned grid = (unsigned)(8 * std::max(h->num_cus, 8));
+    if (MP.flat_lut) hipLaunchKernelGGL((k_mfma_verify<M, DSUB, true>), dim3(grid), dim3(256), 0, st, MP);
+    else hipLaunchKernelGGL((k_mfma_verify<M, DSUB, false>), dim3(grid), dim3(256), 0, st, MP);
+    HIPCK(hipGetLastError());
+    return MMIDX_OK;
+}
+
+// pass B over the sorted pairs through K3m.  S: the scan parameters as K3g would get them (list offsets / order / centroids of the
+// IVF or the flat-PQ form); F: those of the K3f launch that redoes the queries K3m hands back.  Returns 1 when K3m does not apply.
+int launch_mfma_common(mmidx_index *h, const ScanParams &S, ScanParams F, const SearchPlan &pl, int nlists, int nchunks_f, long long npairs,
+                       long long maxlen, hipStream_t st, long long nq, const double *flat_lut) {
+    if (h->no_mfma || !h->mfma_ok || !h->xn_valid || h->no_filter || S.sdc_tt || nq <= 0 || npairs <= 0 || maxlen >= (1ll << 31) ||
+        nq * 256 * 4 > (1ll << 31) || npairs >= 0x7fffff00ll || ((uintptr_t)S.Q & 15) != 0)
+        return 1;
+    constexpr int G = MF_QG;
+    const size_t nfb = (size_t)npairs * (size_t)std::max(nchunks_f, 1);
+    HIPCK(h->ws_gdesc.reserve((size_t)npairs / G + (size_t)nlists + 8));
+    HIPCK(h->ws_gfb.reserve(4 + 2 * nfb + 16));
+    hipLaunchKernelGGL(k_group_build, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, h->ws_pstart.p, nlists, G, h->ws_gdesc.p, h->ws_gfb.p,
+                       (u32 *)(h->ws_gfb.p + 1), (unsigned long long *)(h->d_counters + 7), h->pin_hint ? h->pin_hint + 1 : nullptr);
+    HIPCK(hipGetLastError());
+    DBG_SYNC("K3m group build");
+    // items: (group, piece of `sub` codes).  One piece per list where the batch fills the chip anyway; shorter pieces when there
+    // are few groups (small calls, flat PQ's long chunks), so that the persistent blocks all find work
+    int sub = h->mfma_sub;
+    if (sub <= 0) {
+        const long long est_groups = npairs / G + std::min<long long>(npairs, nlists);
+        const long long want = 8ll * 2 * std::max(h->num_cus, 8);
+        long long pieces = std::max<long long>(1, (want + est_groups - 1) / est_groups);
+        long long sb = (maxlen + pieces - 1) / pieces;
+        sb = std::max<long long>(1024, std::min<long long>(sb, 65536));
+        sub = (int)((sb + 63) & ~63ll);
+    }
+    sub = (std::max(sub, 64) + 15) & ~15;
+    const int nsub = (int)((maxlen + sub - 1) / sub);
+    HIPCK(h->ws_ghist.reserve((size_t)nq * 256));
+    HIPCK(h->ws_T0.reserve((size_t)nq));
+    HIPCK(h->ws_redo.reserve((size_t)nq));
+    HIPCK(h->ws_psnap.reserve((size_t)nq));
+    HIPCK(h->ws_mfctl.reserve(16));
+    size_t qcap = h->mfma_qcap > 0 ? (size_t)h->mfma_qcap : std::min<size_t>((size_t)1 << 28, std::max<size_t>((size_t)1 << 20, (size_t)nq * 2048));
+    HIPCK(h->ws_surv.reserve(qcap));
+    HIPCK(hipMemsetAsync(h->ws_ghist.p, 0, (size_t)nq * 256 * sizeof(u32), st));
+    HIPCK(hipMemsetAsync(h->ws_redo.p, 0, (size_t)nq, st));
+    HIPCK(hipMemsetAsync(h->ws_mfctl.p, 0, 16 * sizeof(u32), st));
+    HIPCK(hipMemcpyAsync(h->ws_T0.p, S.T, (size_t)nq * sizeof(u64), hipMemcpyDeviceToDevice, st));
+    HIPCK(hipMemcpyAsync(h->ws_psnap.p, S.pool_cnt, (size_t)nq * sizeof(u32), hipMemcpyDeviceToDevice, st));
+    MfmaParams MP{};
+    MP.S = S;
+    if (h->d_perm) {  // rows in transformed order: contiguous loads (the centroids once per index, the queries once per call)
+        if (S.ivf && !h->d_coarseP) return 1;
+        HIPCK(h->ws_Qp.reserve((size_t)nq * h->D));
+        const long long tot = (long long)nq * h->D;
+        hipLaunchKernelGGL(k_permute_cols, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, S.Q, h->d_perm, h->ws_Qp.p, h->D, (long long)nq);
+        MP.S.Q = h->ws_Qp.p;
+        if (S.ivf) MP.S.coarse = h->d_coarseP;
+    }
+    MP.S.perm = nullptr;
+    MP.pq16 = h->d_pq16;
+    MP.xn = h->xn.p;
+    MP.pq = h->d_pq;
+    MP.flat_lut = flat_lut;
+    MP.R = nullptr;
+    MP.gdesc = h->ws_gdesc.p;
+    MP.n_groups = h->ws_gfb.p;
+    MP.sub = sub;
+    MP.nsub = nsub;
+    MP.ep = h->pq_ep;
+    MP.xmax = h->rmax;
+    MP.ghist = h->ws_ghist.p;
+    MP.T0 = h->ws_T0.p;
+    MP.surv = h->ws_surv.p;
+    MP.surv_cnt = h->ws_mfctl.p;
+    MP.surv_cap = (u32)std::min<size_t>(qcap, 0xFFFFFFF0u);
+    MP.redo = h->ws_redo.p;
+    MP.pool_snap = h->ws_psnap.p;
+    MP.work = h->ws_mfctl.p + 8;
+    MP.fb_count = (u32 *)(h->ws_gfb.p + 1);
+    MP.fb_items = h->ws_gfb.p + 4;
+    MP.fb_ch = h->ws_gfb.p + 4 + nfb;
+    MP.fb_chunk = pl.chunk;
+    MP.fb_nchunks = std::max(nchunks_f, 1);
+    MP.npairs_flat = npairs;
+    MP.stat = (h->profiling == 1 || h->debug_sync) ? (unsigned long long *)(h->d_counters + 3) : nullptr;
+    MP.nver = (unsigned long long *)(h->d_counters + 7);
+    const MfmaLds L(h->D);
+    int rc;
+    const int nj = h->D / 32;
+    if (h->dsub == 8) rc = nj == 4 ? launch_mfma_scan_t<4, 8>(h, MP, L.total, st) : nj == 2 ? launch_mfma_scan_t<2, 8>(h, MP, L.total, st) : launch_mfma_scan_t<1, 8>(h, MP, L.total, st);
+    else rc = nj == 4 ? launch_mfma_scan_t<4, 16>(h, MP, L.total, st) : nj == 2 ? launch_mfma_scan_t<2, 16>(h, MP, L.total, st) : launch_mfma_scan_t<1, 16>(h, MP, L.total, st);
+    if (rc) return rc;
+    DBG_SYNC("K3m scan");
+    if (h->dsub == 8) rc = h->m == 16 ? launch_mfma_verify_t<16, 8>(h, MP, st) : h->m == 8 ? launch_mfma_verify_t<8, 8>(h, MP, st) : launch_mfma_verify_t<4, 8>(h, MP, st);
+    else rc = h->m == 8 ? launch_mfma_verify_t<8, 16>(h, MP, st) : h->m == 4 ? launch_mfma_verify_t<4, 16>(h, MP, st) : launch_mfma_verify_t<2, 16>(h, MP, st);
+    if (rc) return rc;
+    DBG_SYNC("K3m verify");
+    const long long span = std::max<long long>(npairs, nq);
+    hipLaunchKernelGGL(k_mfma_redo, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, st, MP, (long long)nq);
+    HIPCK(hipGetLastError());
+    DBG_SYNC("K3m redo");
+    if (h->debug_sync) {
+        u32 c16[16];
+        int32_t g2[2];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(c16, h->ws_mfctl.p, sizeof(c16), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(g2, h->ws_gfb.p, sizeof(g2), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[mmidx] K3m: %d groups of <= %d pairs x %d pieces of %d codes, %u survivors (cap %u), %d (pair, chunk) items handed to K3f (lds %zu)\n", g2[0], G,
+                nsub, sub, c16[0], MP.surv_cap, g2[1], L.total);
+    }
+    // the queries K3m handed back (device-side count; normally none): the looping tail kernel alone
+    F.order = MP.fb_items;
+    F.n_order = (const int32_t *)MP.fb_count;
+    F.order_ch = MP.fb_ch;
+    F.n_items = (int)std::min<size_t>(nfb, (size_t)0x7fffff00);
+    F.xcd_remap = 0;
+    return launch_scan_filtered(h, F, pl, dim3((unsigned)F.n_items, 1), st, -1);
+}
+
 // pass B over the sorted pairs (P.order / P.n_order as for K3f; per-cell counts and starts in ws_pcount / ws_pstart).
 // Returns 1 when K3g does not apply (the caller uses K3f).
 int launch_scan_grouped(mmidx_index *h, const ScanParams &P, const SearchPlan &pl, long long nq, long long npairs, hipStream_t st) {
+    if (P.ivf) {
+        const int rcm = launch_mfma_common(h, P, P, pl, h->C, pl.nchunks, npairs, h->max_list_len, st, nq, nullptr);
+        if (rcm != 1) return rcm;
+    }
     if (h->no_grp || !h->grp_valid || !h->d_pq32T || h->no_filter || P.sdc_tt || !P.ivf || h->max_list_len >= (1 << 24)) return 1;
     return launch_grouped_common(h, P, P, pl, h->C, pl.nchunks, npairs, st, nq);
 }
@@ -1069,9 +1270,10 @@ int launch_scan_grouped(mmidx_index *h, const ScanParams &P, const SearchPlan &p
 int launch_scan_grouped_flat(mmidx_index *h, const ScanParams &P, const SearchPlan &pl, long long nq, hipStream_t st) {
     const int nch = P.w;
     const long long npairs = nq * (long long)(nch - 1);
-    if (h->no_grp || !h->grp_valid || !h->d_pq32T || h->no_filter || P.sdc_tt || P.ivf || nch < 2 || pl.chunk >= (1 << 24) ||
-        npairs >= 0x7fffff00ll || nq * (long long)nch >= 0x7fffff00ll)
-        return 1;
+    if (h->no_filter || P.sdc_tt || P.ivf || nch < 2 || pl.chunk >= (1 << 24) || npairs >= 0x7fffff00ll || nq * (long long)nch >= 0x7fffff00ll) return 1;
+    const bool grp_ok = !h->no_grp && h->grp_valid && h->d_pq32T;
+    const bool mf_ok = !h->no_mfma && h->mfma_ok && h->xn_valid;
+    if (!grp_ok && !mf_ok) return 1;
     HIPCK(h->ws_pcount.reserve((size_t)nch + 1));
     HIPCK(h->ws_pstart.reserve((size_t)nch + 1));
     HIPCK(h->ws_order.reserve((size_t)npairs));
@@ -1108,6 +1310,11 @@ int launch_scan_grouped_flat(mmidx_index *h, const ScanParams &P, const SearchPl
         HIPCK(hipGetLastError());
         flat_lut = h->ws_flatlut.p;
     }
+    if (mf_ok) {
+        const int rcm = launch_mfma_common(h, S, P, pl, nch, 1, npairs, pl.chunk, st, nq, flat_lut);
+        if (rcm != 1) return rcm;
+    }
+    if (!grp_ok) return 1;
     return launch_grouped_common(h, S, P, pl, nch, 1, npairs, st, nq, flat_lut);
 }
 
@@ -1715,6 +1922,8 @@ int search_common(mmidx_index *h, int k, int64_t nq, const double *dQ, const int
         if (rc) return rc;
         rc = build_grp_tables(h);
         if (rc) return rc;
+        rc = build_mfma_tables(h);
+        if (rc) return rc;
     }
     SearchPlan pl;
     rc = make_plan(h, k, nq, pl, d_cells == nullptr);
@@ -1811,7 +2020,7 @@ int mmidx_create(int kind, int D, int m, int ks, int C, int transform, const int
         delete h;
         return fail(MMIDX_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
     }
-    if (hipMalloc((void **)&h->d_counters, 12 * sizeof(u64)) != hipSuccess || hipMemset(h->d_counters, 0, 12 * sizeof(u64)) != hipSuccess) {
+    if (hipMalloc((void **)&h->d_counters, 16 * sizeof(u64)) != hipSuccess || hipMemset(h->d_counters, 0, 16 * sizeof(u64)) != hipSuccess) {
         delete h;
         return fail(MMIDX_ERR_HIP, "hipMalloc failed");
     }
@@ -1936,6 +2145,14 @@ int mmidx_destroy(mmidx_index *h) {
     if (h->d_pnmax) (void)hipFree(h->d_pnmax);
     if (h->d_coarseP) (void)hipFree(h->d_coarseP);
     if (h->d_zero) (void)hipFree(h->d_zero);
+    if (h->d_pq16) (void)hipFree(h->d_pq16);
+    if (h->d_pn64) (void)hipFree(h->d_pn64);
+    h->xn.release();
+    h->ws_surv.release();
+    h->ws_mfctl.release();
+    h->ws_psnap.release();
+    h->ws_redo.release();
+    h->ws_Qp.release();
     for (auto &ev : h->evpool)
         if (ev) (void)hipEventDestroy(ev);
     if (h->d_counters) (void)hipFree(h->d_counters);
@@ -2032,6 +2249,11 @@ int mmidx_set_pq(mmidx_index *h, const double *pq) {
     if (!h->d_pqT) HIPCK(hipMalloc((void **)&h->d_pqT, n * sizeof(double)));
     HIPCK(hipMemcpy(h->d_pq, pq, n * sizeof(double), hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(h->d_pqT, T.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    double amax = 0.0;
+    for (size_t i = 0; i < n; i++) amax = std::max(amax, std::fabs(pq[i]));
+    h->pq_maxabs = amax;
+    h->mfma_valid = false;
+    h->xn_valid = false;
     double r2 = 0.0;
     for (int s = 0; s < h->m; s++) {
         double mx = 0.0;
@@ -2517,6 +2739,8 @@ static int shard_phase(mmidx_index *h, int k, int64_t nq, const double *dQ, cons
         if (rc) return rc;
         rc = build_grp_tables(h);
         if (rc) return rc;
+        rc = build_mfma_tables(h);
+        if (rc) return rc;
     }
     SearchPlan pl;
     rc = make_plan(h, k, nq, pl, false);
@@ -2694,6 +2918,14 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->smin_pre = value < 0 ? -1 : (value != 0);
     } else if (n == "no_union") {  // K3g without the per-query histogram that lowers thresholds from the union over lists
         h->no_union = value < 0 ? -1 : (value != 0);
+    } else if (n == "no_mfma") {  // pass B through K3g / K3f instead of the matrix-core bound K3m
+        h->no_mfma = value != 0;
+    } else if (n == "mfma_sub") {
+        h->mfma_sub = value > 0 ? value : 0;
+    } else if (n == "mfma_qcap") {
+        h->mfma_qcap = value > 0 ? value : 0;
+    } else if (n == "mfma_blocks") {
+        h->mfma_blocks = value > 0 ? value : 0;
     } else if (n == "grp_blocks") {
         h->grp_blocks = value > 0 ? value : 0;
     } else if (n == "passa_prefix") {
@@ -2718,6 +2950,7 @@ int mmidx_set_profiling(mmidx_index *h, int enabled) {
     h->passa_launches = 0;
     h->host_passa_codes = 0;
     HIPCK(hipMemset(h->d_counters, 0, 8 * sizeof(u64)));
+    HIPCK(hipMemset(h->d_counters + 12, 0, 2 * sizeof(u64)));
     return MMIDX_OK;
 }
 
@@ -2758,6 +2991,13 @@ int mmidx_get_stats(mmidx_index *h, mmidx_stats *out) {
     s.passa_codes = (int64_t)cnt[2] + h->host_passa_codes;
     s.passa_launches = h->passa_launches;
     s.verified_codes = (int64_t)cnt[3];
+    {
+        u64 c2[2] = {0, 0};
+        HIPCK(hipMemcpy(c2, h->d_counters + 12, sizeof(c2), hipMemcpyDeviceToHost));
+        HIPCK(hipMemset(h->d_counters + 12, 0, sizeof(c2)));
+        s.mfma_survivors = (int64_t)c2[0];
+        s.mfma_redo_queries = (int64_t)c2[1];
+    }
     if (h->debug_sync || getenv("MMIDX_GRP_STATS"))
     {
         fprintf(stderr, "[mmidx] K3g: %llu pairs in groups, %llu alive after the table build (Smin < T), %llu codes verified\n", (unsigned long long)cnt[5],

@@ -1,0 +1,623 @@
+// mmidx_scan_mfma.h -- K3m: pass B of the IVFADC search (and the far chunks of flat PQ) as a list-major CERTIFIED LOWER BOUND
+// on the matrix cores (gfx950), exact fp64 only for the codes the bound cannot drop.
+//
+// Reference loop: the per-probe body of computeKnnIVFADC, J/datastructures/IVFPQ.java:414-447 (residual :417 -> :642-648,
+// lookup table :427 -> :525-538, scan :429-446) and PQ.computeKnnADC, J/datastructures/PQ.java:290-322.  The reference sums
+// m table entries per code; the table entry of sub-quantizer s is ||r_s - p_s,code_s||^2, so the distance of a code is
+//         d = ||r - x||^2 = ||r||^2 + ||x||^2 - 2 r.x ,        x = the code's m chosen sub-centroids side by side,
+// a dot product per (query, code) -- a GEMM [queries of a list x D] x [D x codes of the list].  K3g (mmidx_scan_grp.h) evaluates
+// a quantised form of the reference's table with one LDS lookup and ~1.4 vector instructions per (query, sub-quantizer); here
+//   * a block takes ONE inverted list (or a piece of it) and up to 64 queries that probe it (the pairs of pass B are sorted by
+//     cell): their residuals r = c - q (exact fp64, IVFPQ.java:645, transformed) are rounded to fp16 and held in REGISTERS as the
+//     A operands of v_mfma_f32_16x16x32_f16 for the whole item;
+//   * a code is DECODED ONCE per item: the fp16 codebook lives in LDS as [8-dimension group][entry] rows of 16 bytes -- with
+//     8-dimensional sub-quantizers a row IS a lane's B fragment (k = 8 (lane >> 4) .. + 7 of column lane & 15), so a tile of 16
+//     codes costs ONE ds_read_b128 per lane and 32 dimensions, and that fragment is multiplied against all (up to 64) queries;
+//   * the accumulators start at -||x||^2 / 2 (a 4-byte per-code array, built with the index): acc = r.x - ||x||^2 / 2, and
+//         d <= T   <=>   acc >= (||r||^2 - T) / 2
+//     is ONE v_cmp per accumulator register against a per-query constant that carries the certified error term: a code
+//     with d <= T is never dropped.  fp16 inputs have 11 significant bits (bf16: 8), so the bound is within
+//     ~2^-9 |r| |x| of the true distance -- about ten times tighter than K3g's 8-bit table rows;
+//   * survivors (lower bound <= T) are appended to a global list with their UPPER bound counted in a per-query histogram:
+//     k + 1 upper bounds at or below a bucket edge make that edge a valid threshold for every later item of the query
+//     (thresholds tighten from the union of what all probed lists have shown so far, during the scan);
+//   * k_mfma_verify computes the survivors' exact distances -- entries in the reference's order (t ascending from 0.0,
+//     IVFPQ.java:531-534), added in sub-quantizer order (:435-438): the same bits as the fp64 table lookup -- and offers those
+//     at or below the query's current threshold to its pool.
+// Whatever the bound cannot serve (no finite threshold yet, magnitudes beyond fp16 scaling, a full survivor list or pool) marks
+// the QUERY for redo: k_mfma_redo resets its pool to pass A's and hands its pairs to K3f, so results never depend on the heuristics.
+#pragma once
+#include "mmidx_kernels.h"
+
+typedef _Float16 mf_h8 __attribute__((ext_vector_type(8)));
+typedef float mf_f4 __attribute__((ext_vector_type(4)));
+
+#define MF_NT 256       // threads per block: four waves, each scanning its own code tiles against the item's queries
+#define MF_QG 64        // queries per item (four 16-row tiles)
+#define MF_ASTRIDE 272  // bytes per staged residual row: 256 + 16 (conflict-free 16-byte fragment reads)
+#ifndef MF_TIMING
+#define MF_TIMING 0     // timing experiments (results are wrong): 1 = no survivor handling, 2 = no MFMA, 3 = no gathers
+#endif
+
+struct MfmaParams {
+    ScanParams S;              // Q, coarse (rows in TRANSFORMED order: the host passes permuted copies), cells, list_off, codes, order, T, pool_*, D, m, ks, w, ivf, poolq
+    const unsigned short *pq16;  // [D / 8][256][8] fp16 codebook, scaled by 2^ep (0 beyond ks)
+    const float *xn;           // [n] ||x||^2 of every stored code (list-major, as codes)
+    const double *pq;          // [m][ks][dsub] (file order): the verification's entries
+    const double *flat_lut;    // flat PQ: the queries' exact tables [nq][m][256] (k_flat_lut), or null
+    const double *R;           // null, or the pairs' exact transformed residuals [pair slot in order[]][D] (rotation)
+    const int4 *gdesc;         // per group: {cell, first index into order[], number of pairs (1..64), 0}
+    const int32_t *n_groups;   // device-side count
+    int sub, nsub;             // codes per item, items per group = ceil(longest list / sub)
+    int ep;                    // exponent of the codebook's power-of-two scale
+    double xmax;               // >= ||x|| of every code: sqrt(sum_s max_j ||p_sj||^2) (1 + 1e-12)
+    u32 *ghist;                // [nq][256] upper bounds of the survivors by bucket floor(ub * 256 / T0)
+    const u64 *T0;             // [nq] thresholds as the launch found them (the bucket map must not move)
+    uint2 *surv;               // survivor records {slot of the pair in order[], position in the list}
+    u32 *surv_cnt;             // appended so far (may exceed surv_cap: the excess was dropped and its queries marked)
+    u32 surv_cap;
+    unsigned char *redo;       // [nq] 1: the query's pass B is redone by K3f
+    const u32 *pool_snap;      // [nq] pool counters as pass A left them
+    u32 *work;                 // [8] per-XCD item cursors (zeroed before the launch)
+    u32 *fb_count;             // the redo hand-back: (pair, chunk) items for K3f
+    int32_t *fb_items, *fb_ch;
+    int fb_chunk, fb_nchunks;  // K3f's chunking of a list
+    long long npairs_flat;     // flat PQ: number of pairs in order[] (IVF: *S.n_order)
+    unsigned long long *stat;  // null, or profiling counters: [0] += verified codes, [9] += survivors, [10] += queries handed back
+    unsigned long long *nver;  // always: [0] += verified codes (host hint)
+};
+
+struct MfmaLds {
+    size_t cb, stage, nr, err, inv0, thr, q, e, misc, total;
+    __host__ __device__ MfmaLds(int D) {
+        size_t o = 0;
+        cb = o; o += (size_t)D * 512;             // [D / 8][256] rows of 8 halfs
+        stage = o; o += 32 * (size_t)MF_ASTRIDE;  // 32 residual rows at a time
+        nr = o; o += MF_QG * 8;
+        err = o; o += MF_QG * 8;
+        inv0 = o; o += MF_QG * 8;
+        thr = o; o += MF_QG * 4;
+        q = o; o += MF_QG * 4;
+        e = o; o += MF_QG * 4;
+        misc = o; o += 64;  // [0] item, [1..2] touched mask, [3] scale ok, [4..7] wave maxima
+        total = (o + 15) & ~(size_t)15;
+    }
+};
+
+// ---- index-side tables ----------------------------------------------------------------------------------------------------
+// fp16 codebook: row (g8, e) = dimensions 8 g8 .. 8 g8 + 7 of the concatenated entry e, scaled by 2^ep (one thread per row)
+__global__ void k_pq16_table(const double *__restrict__ pqT, unsigned short *__restrict__ pq16, int m, int ks, int dsub, double scale) {
+    const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int KG = m * dsub / 8;
+    if (idx >= KG * 256) return;
+    const int g8 = idx >> 8, e = idx & 255;
+    mf_h8 v;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int d = g8 * 8 + u, s = d / dsub, t = d - s * dsub;
+        const double p = e < ks ? pqT[((size_t)s * dsub + t) * ks + e] : 0.0;
+        v[u] = (_Float16)(float)(p * scale);
+    }
+    *(mf_h8 *)(pq16 + (size_t)idx * 8) = v;
+}
+// pn64[s][j] = ||p_sj||^2 (fp64), block s, thread j
+__global__ void k_pn64_table(const double *__restrict__ pqT, double *__restrict__ pn64, int m, int ks, int dsub) {
+    const int s = blockIdx.x, j = threadIdx.x;
+    double a = 0.0;
+    if (j < ks)
+        for (int t = 0; t < dsub; t++) {
+            const double p = pqT[((size_t)s * dsub + t) * ks + j];
+            a += p * p;
+        }
+    pn64[(size_t)s * 256 + j] = a;
+}
+// xn[i] = ||x_i||^2 = sum_s ||p_s,code_is||^2 (fp64 sum, one rounding to fp32): the start value of a code's accumulators
+__global__ void k_code_norms(const unsigned char *__restrict__ codes, const double *__restrict__ pn64, float *__restrict__ xn, int m,
+                             long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned char *c = codes + (size_t)i * m;
+    double a = 0.0;
+    if ((m & 3) == 0) {
+        for (int s = 0; s < m; s += 4) {
+            const u32 w = *(const u32 *)(c + s);
+            a += pn64[(size_t)s * 256 + (w & 0xFFu)];
+            a += pn64[(size_t)(s + 1) * 256 + ((w >> 8) & 0xFFu)];
+            a += pn64[(size_t)(s + 2) * 256 + ((w >> 16) & 0xFFu)];
+            a += pn64[(size_t)(s + 3) * 256 + (w >> 24)];
+        }
+    } else {
+        for (int s = 0; s < m; s++) a += pn64[(size_t)s * 256 + c[s]];
+    }
+    xn[i] = (float)a;
+}
+
+// largest float <= x
+__device__ __forceinline__ float mf_float_down(double x) {
+    float f = (float)x;
+    if ((double)f > x) f = __int_as_float(__float_as_int(f) + (f > 0.f ? -1 : (f < 0.f ? 1 : (int)0x80000001)));
+    return f;
+}
+
+// ---- K3m ----------------------------------------------------------------------------------------------------------------
+// NJ = D / 32 (MFMA k chunks per code), DSUB = dimensions per sub-quantizer (8 or 16).  Lane (n = lane & 15, g = lane >> 4) of a
+// code tile holds column n (code n of the tile) and the 8-dimension groups g8 = NJ g + j, j = 0 .. NJ-1: the code bytes it
+// needs are contiguous (NB of them at byte offset NB g).
+template <int NJ, int DSUB, int NTL>
+__device__ __forceinline__ void mf_scan_tiles(const MfmaParams &P, const mf_h8 (&A)[4][NJ], const float (&thr)[4][4], const unsigned char *codes,
+                                              const float *xn, const long long c0, const long long c1, const float kinit, const double inv_s2,
+                                              const u32 lds_cb, const double *s_nr, const double *s_err, const double *s_inv0, const int *s_q,
+                                              const int *s_e, u32 *s_touch, const int lane, const int wv) {
+    constexpr int D = NJ * 32, M = D / DSUB;
+    constexpr int NB = (NJ * 8 >= DSUB) ? NJ * 8 / DSUB : 1;  // code bytes per lane
+    const int n = lane & 15, g = lane >> 4;
+    const u32 boff = (u32)((NJ * g * 8) / DSUB);              // first code byte of the lane
+    const u32 lane_base = lds_cb + (u32)(NJ * g) * 4096u;
+    const int ntiles = (int)((c1 - c0 + 15) >> 4);
+    auto load_tile = [&](int t, u32 &cw, float &xv) {
+        long long p = c0 + (long long)t * 16 + n;
+        p = p < c1 ? p : c1 - 1;
+        const unsigned char *cp = codes + (size_t)p * M + boff;
+        if constexpr (NB == 4) cw = *(const u32 *)cp;
+        else if constexpr (NB == 2) cw = (u32) * (const unsigned short *)cp;
+        else cw = (u32)*cp;
+        xv = xn[p];
+    };
+    u32 cw[4];
+    float xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) load_tile(wv + 4 * u, cw[u], xv[u]);
+    for (int t = wv; t < ntiles; t += 16) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int tt = t + 4 * u;
+            const u32 c = cw[u];
+            const float x = xv[u];
+            load_tile(tt + 16, cw[u], xv[u]);  // (clamped to the item's last code: always a valid address)
+            if (tt >= ntiles) continue;        // (wave-uniform)
+            mf_h8 B[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                const u32 byte = (c >> (8 * (j / (DSUB / 8)))) & 0xFFu;
+#if MF_TIMING == 3
+                const u32 addr = lane_base + ((u32)lane << 4);
+#else
+                const u32 addr = lane_base + (byte << 4);
+#endif
+                B[j] = *(const __attribute__((address_space(3))) mf_h8 *)(size_t)(addr + (u32)j * 4096u);
+            }
+            const float ci = x * kinit;
+            const mf_f4 c4 = {ci, ci, ci, ci};
+            mf_f4 acc[NTL];
+#if MF_TIMING == 2
+#pragma unroll
+            for (int rt = 0; rt < NTL; rt++) acc[rt] = c4 + __builtin_bit_cast(mf_f4, B[rt % NJ]) * 1e-30f;
+#else
+#pragma unroll
+            for (int rt = 0; rt < NTL; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[rt][0], B[0], c4, 0, 0, 0);
+#pragma unroll
+            for (int j = 1; j < NJ; j++)
+#pragma unroll
+                for (int rt = 0; rt < NTL; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[rt][j], B[j], acc[rt], 0, 0, 0);
+#endif
+            u64 any = 0;
+#pragma unroll
+            for (int rt = 0; rt < NTL; rt++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) any |= __builtin_amdgcn_ballot_w64(acc[rt][i] >= thr[rt][i]);
+#if MF_TIMING == 1
+            if (any == 0x123456789ull) s_touch[0] = 1;
+            any = 0;
+#endif
+            if (any) {
+                // ---- survivors (rare): records + upper bounds into the queries' histograms ----
+                const long long pos = c0 + (long long)tt * 16 + n;
+                const bool valid = pos < c1;
+                u32 bits = 0;
+#pragma unroll
+                for (int rt = 0; rt < NTL; rt++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) bits |= (acc[rt][i] >= thr[rt][i]) ? 1u << (rt * 4 + i) : 0u;
+                bits = valid ? bits : 0u;
+                const u32 mine = (u32)__popc(bits);
+                const u32 incl = wave_incl_scan_u32(mine);
+                const u32 tot = wave_read_u32(incl, 63);
+                if (tot) {
+                    u32 base = 0;
+                    if (lane == 0) base = atomicAdd(P.surv_cnt, tot);
+                    base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+                    const u32 off0 = base + incl - mine;
+#pragma unroll
+                    for (int rt = 0; rt < NTL; rt++)
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int b = rt * 4 + i;
+                            if ((bits >> b) & 1u) {
+                                const int qs = rt * 16 + 4 * g + i;
+                                const u32 off = off0 + (u32)__popc(bits & ((1u << b) - 1u));
+                                const int q = s_q[qs];
+                                if (off < P.surv_cap) P.surv[off] = make_uint2((u32)s_e[qs], (u32)pos);
+                                else P.redo[q] = 1;
+                                const double inv0 = s_inv0[qs];
+                                if (inv0 > 0.0) {
+                                    // d~ = ||r||^2 - 2 (acc / s^2); every code has |d - d~| <= err: ub = d~ + err
+                                    const double ub = s_nr[qs] - 2.0 * ((double)acc[rt][i] * inv_s2) + s_err[qs];
+                                    const double xb = ub * inv0 * (1.0 + 0x1p-40);
+                                    if (xb < 255.0) {
+                                        const int bk = xb > 0.0 ? (int)xb : 0;
+                                        atomicAdd(P.ghist + (size_t)q * 256 + bk, 1u);
+                                        atomicOr(s_touch + (qs >> 5), 1u << (qs & 31));
+                                    }
+                                }
+                            }
+                        }
+                }
+            }
+        }
+    }
+}
+
+template <int NJ, int DSUB>
+__global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
+    constexpr int D = NJ * 32;
+    constexpr int DPT = D / 8;  // dimensions per thread in the residual phase: a thread is (row of 32, eighth of the dimensions)
+    static_assert(NJ == 1 || NJ == 2 || NJ == 4, "D = 32, 64 or 128");
+    static_assert(DSUB == 8 || DSUB == 16, "a 16-byte codebook row is (part of) one sub-quantizer entry");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const MfmaLds L(D);
+    unsigned char *s_stage = smem + L.stage;
+    double *s_nr = (double *)(smem + L.nr), *s_err = (double *)(smem + L.err), *s_inv0 = (double *)(smem + L.inv0);
+    float *s_thr = (float *)(smem + L.thr);
+    int *s_q = (int *)(smem + L.q), *s_e = (int *)(smem + L.e);
+    u32 *s_misc = (u32 *)(smem + L.misc);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 lds_cb = (u32)(size_t)(__attribute__((address_space(3))) unsigned char *)(smem + L.cb);
+
+    // the fp16 codebook: once per block
+    for (int i = tid; i < D * 32; i += MF_NT) ((uint4 *)(smem + L.cb))[i] = ((const uint4 *)P.pq16)[i];
+    const int nv = *P.n_groups * P.nsub;
+    const int per = (nv + 7) >> 3;
+    const int xcd = blockIdx.x & 7;
+    const double xmax = P.xmax;
+    const double gam = (double)(D + 4) * 0x1p-23 * 1.01;  // fp32 accumulation of D products + the start value, any order, 2 u per step
+    __syncthreads();
+
+    for (;;) {
+        if (tid == 0) {
+            s_misc[0] = atomicAdd(P.work + xcd, 1u);
+            s_misc[1] = 0;
+            s_misc[2] = 0;
+        }
+        __syncthreads();
+        const int it = (int)s_misc[0];
+        if (it >= per) break;
+        const int v = xcd * per + it;  // consecutive items -- the groups of one list -- run on the same XCD
+        if (v >= nv) break;
+        const int gi = v / P.nsub, isub = v - gi * P.nsub;
+        const int4 gd = P.gdesc[gi];
+        const int cell = gd.x, first = gd.y, np = gd.z;
+        const long long beg = P.S.list_off[cell];
+        const long long len = P.S.list_off[cell + 1] - beg;
+        const long long c0 = (long long)isub * P.sub;
+        if (c0 >= len) {
+            __syncthreads();
+            continue;
+        }
+        const long long c1 = (c0 + P.sub < len) ? c0 + P.sub : len;
+        const unsigned char *codes = (const unsigned char *)P.S.codes + (size_t)beg * (D / DSUB);
+        const float *xn = P.xn + beg;
+
+        // ---- (a) residuals of the item's pairs: thread (row = tid >> 3 of a half, eighth = tid & 7) ----
+        // (loads on a clamped pair index, stores predicated: see the note at pair_keep() in mmidx_kernels.h)
+        double rv[2][DPT];
+        double nrp[2];
+        int qq[2];
+        float mx = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int row = h * 32 + (tid >> 3);
+            const int tl = row < np ? row : np - 1;
+            const int e = P.S.order[first + tl];
+            const int q = e / P.S.w;
+            qq[h] = q;
+            const int d0 = (tid & 7) * DPT;
+            double nr = 0.0;
+            if (P.R) {
+                const double *rr = P.R + (size_t)(first + tl) * D + d0;
+#pragma unroll
+                for (int t = 0; t < DPT; t += 2) {
+                    const double2 r2 = *(const double2 *)(rr + t);
+                    rv[h][t] = r2.x;
+                    rv[h][t + 1] = r2.y;
+                }
+            } else {
+                const double *cc = P.S.coarse + (size_t)(P.S.ivf ? cell : 0) * D + d0, *qv = P.S.Q + (size_t)q * D + d0;
+#pragma unroll
+                for (int t = 0; t < DPT; t += 2) {
+                    const double2 c2 = *(const double2 *)(cc + t), q2 = *(const double2 *)(qv + t);
+                    // (flat PQ: the "centroid" is a zero vector and the sign turns round -- q - 0 = q exactly, PQ.java:294-300)
+                    rv[h][t] = P.S.ivf ? c2.x - q2.x : q2.x - c2.x;
+                    rv[h][t + 1] = P.S.ivf ? c2.y - q2.y : q2.y - c2.y;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < DPT; t++) {
+                if (row >= np) rv[h][t] = 0.0;
+                nr += rv[h][t] * rv[h][t];
+                mx = fmaxf(mx, fabsf((float)rv[h][t]));
+            }
+            nr += __shfl_xor(nr, 1);
+            nr += __shfl_xor(nr, 2);
+            nr += __shfl_xor(nr, 4);
+            nrp[h] = nr;
+        }
+        // the item's power-of-two scale: the largest |r_i| lands in [2^12, 2^13)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        if (lane == 0) ((float *)s_misc)[4 + wv] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(((float *)s_misc)[4], ((float *)s_misc)[5]), fmaxf(((float *)s_misc)[6], ((float *)s_misc)[7]));
+        int er = 0;
+        bool scale_ok = mx < 1e30f;  // (false for NaN / inf as well)
+        if (mx > 0.f && scale_ok) {
+            int ex;
+            (void)frexpf(mx, &ex);  // mx = f 2^ex, f in [0.5, 1)
+            er = 13 - ex;
+        }
+        // (s^2 / 2 a normal float; ||r||^2 s^2 and ||x||^2 s^2 -- 2^26 D at most in their own scales -- far inside its range)
+        scale_ok = scale_ok && er + P.ep > -100 && er + P.ep < 100 && er - P.ep > -60 && er - P.ep < 60;
+        const float s_r = scale_ok ? ldexpf(1.f, er) : 1.f;
+        const double s2 = scale_ok ? ldexp(1.0, er + P.ep) : 1.0;
+        const double inv_s2 = 1.0 / s2, inv_sr = scale_ok ? ldexp(1.0, -er) : 1.0, inv_sp = ldexp(1.0, -P.ep);
+        const double sqrtD = 11.32;  // >= sqrt(128)
+        const float kinit = (float)(-0.5 * s2);
+        // per query: ||r||^2, the certified error term, the threshold constant, the histogram scale
+        if ((tid & 7) == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int row = h * 32 + (tid >> 3);
+                const int q = qq[h];
+                const double nr = nrp[h], nrm = sqrt(nr) * (1.0 + 1e-12);
+                // |acc / s^2 - (r.x - ||x||^2 / 2)| <= |r| xmax (2.01 2^-11 + 1.002 gam) + xmax^2 (0.5005 gam + 2^-25)
+                //                                       + 1.01 sqrt(D) 2^-14 (xmax / s_r + |r| / s_p) + D 2^-28 / s^2 :
+                //   fp16 inputs (an element's error is at most 2^-11 of itself -- after the fp32 step 1.001 of that -- or, where the
+                //   scaled element is subnormal or flushed, 2^-14 / scale), exact products, fp32 accumulation (gam), the fp32 start
+                //   value.  d = ||r||^2 - 2 (...), and the reference's own fp64 roundings are inside the 2^-40 term:
+                const double err = nrm * xmax * (4.02 * 0x1p-11 + 2.004 * gam) + xmax * xmax * (1.001 * gam + 0x1p-24) +
+                                   2.02 * sqrtD * 0x1p-14 * (xmax * inv_sr + nrm * inv_sp) + 2.0 * D * 0x1p-28 * inv_s2 +
+                                   0x1p-40 * (nr + xmax * xmax + 2.0 * nrm * xmax) + 1e-300;
+                const u64 T = __hip_atomic_load(P.S.T + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                float th = __int_as_float(0x7F800000);  // +inf: nothing survives (rows past np, queries handed to the redo)
+                double inv0 = 0.0;
+                if (row < np) {
+                    const bool fin = T < 0x7FF0000000000000ull;
+                    if (!fin || !scale_ok || !(err < 1e300)) {
+                        P.redo[q] = 1;
+                    } else if (!P.redo[q]) {
+                        // d <= T  =>  acc >= (||r||^2 - T - err) s^2 / 2, rounded down
+                        th = mf_float_down((nr - keyd(T) - err) * (0.5 * s2));
+                        if (!(th < 3e38f)) {  // (cannot happen inside the scale limits; never drop on an overflow)
+                            P.redo[q] = 1;
+                            th = __int_as_float(0x7F800000);
+                        }
+                        const u64 t0 = P.T0[q];
+                        if (t0 < 0x7FF0000000000000ull && t0 > 0) {
+                            const double iv = 256.0 / keyd(t0);
+                            if (iv < 1e300) inv0 = iv;
+                        }
+                    }
+                }
+                s_nr[row] = nr;
+                s_err[row] = err;
+                s_inv0[row] = inv0;
+                s_thr[row] = th;
+                s_q[row] = q;
+                s_e[row] = first + (row < np ? row : np - 1);
+            }
+        }
+        // fp16 A operands, 32 rows at a time through LDS
+        const int ntl = (np + 15) >> 4;
+        mf_h8 A[4][NJ];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if (h * 2 < ntl) {  // (block-uniform)
+                unsigned char *dst = s_stage + (size_t)(tid >> 3) * MF_ASTRIDE + (size_t)(tid & 7) * DPT * 2;
+#pragma unroll
+                for (int t = 0; t < DPT; t += 2) {
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    h2 p2;
+                    p2[0] = (_Float16)((float)rv[h][t] * s_r);
+                    p2[1] = (_Float16)((float)rv[h][t + 1] * s_r);
+                    *(h2 *)(dst + 2 * t) = p2;
+                }
+            }
+            __syncthreads();
+            if (h * 2 < ntl) {
+#pragma unroll
+                for (int r2 = 0; r2 < 2; r2++)
+#pragma unroll
+                    for (int j = 0; j < NJ; j++)
+                        A[h * 2 + r2][j] = *(const mf_h8 *)(s_stage + (size_t)(r2 * 16 + (lane & 15)) * MF_ASTRIDE + (size_t)(NJ * (lane >> 4) + j) * 16);
+            } else {
+#pragma unroll
+                for (int r2 = 0; r2 < 2; r2++)
+#pragma unroll
+                    for (int j = 0; j < NJ; j++) A[h * 2 + r2][j] = mf_h8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+            __syncthreads();
+        }
+        float thr[4][4];
+#pragma unroll
+        for (int rt = 0; rt < 4; rt++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) thr[rt][i] = s_thr[rt * 16 + 4 * (lane >> 4) + i];
+
+        // ---- (b) the scan: every wave its own code tiles against all row tiles ----
+        switch (ntl) {
+            case 1: mf_scan_tiles<NJ, DSUB, 1>(P, A, thr, codes, xn, c0, c1, kinit, inv_s2, lds_cb, s_nr, s_err, s_inv0, s_q, s_e, s_misc + 1, lane, wv); break;
+            case 2: mf_scan_tiles<NJ, DSUB, 2>(P, A, thr, codes, xn, c0, c1, kinit, inv_s2, lds_cb, s_nr, s_err, s_inv0, s_q, s_e, s_misc + 1, lane, wv); break;
+            case 3: mf_scan_tiles<NJ, DSUB, 3>(P, A, thr, codes, xn, c0, c1, kinit, inv_s2, lds_cb, s_nr, s_err, s_inv0, s_q, s_e, s_misc + 1, lane, wv); break;
+            default: mf_scan_tiles<NJ, DSUB, 4>(P, A, thr, codes, xn, c0, c1, kinit, inv_s2, lds_cb, s_nr, s_err, s_inv0, s_q, s_e, s_misc + 1, lane, wv); break;
+        }
+        __syncthreads();
+        // ---- (c) thresholds from the union of the survivors' upper bounds: K1 of them at or below a bucket's upper edge make
+        //      that edge a valid threshold (K1 offers lie at or below it) for every later item of the query ----
+        {
+            const u64 touched = ((u64)s_misc[2] << 32) | (u64)s_misc[1];
+            for (int qs = wv; qs < MF_QG; qs += MF_NT / 64) {
+                if (!((touched >> qs) & 1ull)) continue;  // (wave-uniform)
+                const int q = s_q[qs];
+                const u32 *hq = P.ghist + (size_t)q * 256 + 4 * lane;
+                const u32 h0 = __hip_atomic_load(hq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), h1 = __hip_atomic_load(hq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                          h2 = __hip_atomic_load(hq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), h3 = __hip_atomic_load(hq + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const u32 incl = wave_incl_scan_u32(h0 + h1 + h2 + h3);
+                const u64 reached = __builtin_amdgcn_ballot_w64(incl >= (u32)P.S.K1);
+                if (reached) {
+                    const int Lr = __ffsll((long long)reached) - 1;
+                    if (lane == Lr) {
+                        u32 c = incl - (h0 + h1 + h2 + h3) + h0;
+                        int b = 4 * Lr;
+                        if (c < (u32)P.S.K1) { c += h1; b++; }
+                        if (c < (u32)P.S.K1) { c += h2; b++; }
+                        if (c < (u32)P.S.K1) { c += h3; b++; }
+                        // every counted survivor has d <= ub < (b + 1) / inv0
+                        atomicMin(P.S.T + q, dkey((double)(b + 1) / s_inv0[qs] * (1.0 + 1e-12)));
+                    }
+                }
+            }
+        }
+        __syncthreads();  // LDS is reused by the next item
+    }
+}
+
+// ---- exact distances of the survivors -------------------------------------------------------------------------------------
+// LPS = M lanes per survivor (IVF, and flat PQ without tables): lane s computes the table entry of sub-quantizer s in the
+// reference's order (t ascending from 0.0, IVFPQ.java:531-534) and the entries are added in sub-quantizer order (:435-438,
+// ((0 + e_0) + e_1) + ...) down the lanes by DPP -- the bits of a lookup in the fp64 table.  FLAT: one lane per survivor reads the
+// query's own table (k_flat_lut; PQ.java:308-311).
+template <int M, int DSUB, bool FLAT>
+__global__ __launch_bounds__(256) void k_mfma_verify(const MfmaParams P) {
+    constexpr int LPS = FLAT ? 1 : M, D = M * DSUB;
+    const u32 cnt = *P.surv_cnt;
+    const u32 ns = cnt < P.surv_cap ? cnt : P.surv_cap;
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0) {
+        if (P.stat) {
+            atomicAdd(P.stat, (unsigned long long)ns);
+            atomicAdd(P.stat + 9, (unsigned long long)ns);  // (mmidx_stats::mfma_survivors)
+        }
+        atomicAdd(P.nver, (unsigned long long)ns);
+    }
+    const u32 per_block = 256 / LPS;
+    for (u32 base = blockIdx.x * per_block; base < ns; base += gridDim.x * per_block) {
+        const u32 si_raw = base + (u32)(tid / LPS);
+        const bool act = si_raw < ns;
+        const u32 si = act ? si_raw : ns - 1u;  // (loads run on a clamped index)
+        const uint2 rec = P.surv[si];
+        const int slot = (int)rec.x;
+        const u32 pos = rec.y;
+        const int e = P.S.order[slot];
+        const int q = e / P.S.w, rank = e - q * P.S.w;
+        const int cell = P.S.ivf ? P.S.cells[e] : rank;
+        const long long beg = P.S.list_off[cell];
+        const unsigned char *code = (const unsigned char *)P.S.codes + (size_t)(beg + pos) * M;
+        double d = 0.0;
+        if constexpr (FLAT) {
+            const double *lq = P.flat_lut + (size_t)q * (size_t)(M * 256);
+            double en[M];
+#pragma unroll
+            for (int s = 0; s < M; s++) en[s] = lq[s * 256 + (int)code[s]];
+#pragma unroll
+            for (int s = 0; s < M; s++) d += en[s];
+        } else {
+            const int s = tid & (M - 1);
+            const u32 cs = (u32)code[s];
+            double tv[DSUB];
+            if (P.R) {
+                const double *rr = P.R + (size_t)slot * D + s * DSUB;
+#pragma unroll
+                for (int t = 0; t < DSUB; t += 2) {
+                    const double2 r2 = *(const double2 *)(rr + t);
+                    tv[t] = r2.x;
+                    tv[t + 1] = r2.y;
+                }
+            } else {
+                const double *cc = P.S.coarse + (size_t)(P.S.ivf ? cell : 0) * D + s * DSUB, *qv = P.S.Q + (size_t)q * D + s * DSUB;
+#pragma unroll
+                for (int t = 0; t < DSUB; t += 2) {
+                    const double2 c2 = *(const double2 *)(cc + t), q2 = *(const double2 *)(qv + t);
+                    tv[t] = P.S.ivf ? c2.x - q2.x : q2.x - c2.x;
+                    tv[t + 1] = P.S.ivf ? c2.y - q2.y : q2.y - c2.y;
+                }
+            }
+            const double *pp = P.pq + ((size_t)s * P.S.ks + cs) * DSUB;
+            double pv[DSUB];
+#pragma unroll
+            for (int t = 0; t < DSUB; t += 2) {
+                const double2 v2 = *(const double2 *)(pp + t);
+                pv[t] = v2.x;
+                pv[t + 1] = v2.y;
+            }
+            double en = 0.0;
+#pragma unroll
+            for (int t = 0; t < DSUB; t++) {
+                const double df = tv[t] - pv[t];
+                en += df * df;
+            }
+            d = en;  // lane 0 of the survivor: 0.0 + e_0 = e_0
+#pragma unroll
+            for (int st = 1; st < M; st++) {
+                const u64 b = (u64)__double_as_longlong(d);
+                const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)b, 0x111, 0xf, 0xf, false);  // row_shr:1
+                const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(b >> 32), 0x111, 0xf, 0xf, false);
+                const double prev = __longlong_as_double((long long)(((u64)hi << 32) | lo));
+                if (s == st) d = prev + en;
+            }
+        }
+        const bool last = FLAT ? true : ((tid & (M - 1)) == M - 1);
+        if (act && last) {
+            const u64 key = dkey(d);
+            const u64 T = __hip_atomic_load(P.S.T + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (key <= T) {
+                const u32 slot = atomicAdd(P.S.pool_cnt + q, 1u);
+                if (slot < (u32)P.S.poolq) {
+                    P.S.pool_key[(size_t)q * P.S.poolq + slot] = key;
+                    // (flat PQ: positions in the pool are those of the single list, as K3f writes them)
+                    P.S.pool_val[(size_t)q * P.S.poolq + slot] = ((u64)rank << 32) | (u64)(pos + (P.S.ivf ? 0u : (u32)beg));
+                } else {
+                    P.redo[q] = 1;
+                }
+            }
+        }
+    }
+}
+
+// ---- redo: the queries K3m could not serve go to K3f with pass A's pool ---------------------------------------------------
+__global__ void k_mfma_redo(const MfmaParams P, long long nq) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n = P.S.n_order ? (long long)*P.S.n_order : P.npairs_flat;
+    if (i < nq && P.redo[i]) {
+        P.S.pool_cnt[i] = P.pool_snap[i];
+        if (P.stat) atomicAdd(P.stat + 10, 1ull);  // (mmidx_stats::mfma_redo_queries)
+    }
+    const long long ic = i < n ? i : (n > 0 ? n - 1 : 0);
+    const int e = n > 0 ? P.S.order[ic] : 0;
+    const int q = e / P.S.w, rank = e - q * P.S.w;
+    const bool go = i < n && P.redo[q];
+    const int cell = P.S.ivf ? P.S.cells[e] : 0;
+    const unsigned cu = cell >= 0 ? (unsigned)cell : 0u;
+    const long long len = P.S.ivf ? P.S.list_off[cu + 1] - P.S.list_off[cu] : 1;
+    if (go) {
+        if (P.S.ivf) {
+            for (int ch = 0; ch < P.fb_nchunks && (long long)ch * P.fb_chunk < len; ch++) {
+                const u32 f = atomicAdd(P.fb_count, 1u);
+                P.fb_items[f] = e;
+                P.fb_ch[f] = ch;
+            }
+        } else {  // (flat PQ: K3f's chunk is the pair's rank)
+            const u32 f = atomicAdd(P.fb_count, 1u);
+            P.fb_items[f] = e;
+            P.fb_ch[f] = rank;
+        }
+    }
+}

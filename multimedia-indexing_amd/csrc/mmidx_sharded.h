@@ -987,6 +987,8 @@ int sharded_get_stats(mmidx_index *h, mmidx_stats *out) {
         acc.scan_codes += s.scan_codes;
         acc.passa_codes += s.passa_codes;
         acc.verified_codes += s.verified_codes;
+        acc.mfma_survivors += s.mfma_survivors;
+        acc.mfma_redo_queries += s.mfma_redo_queries;
         acc.scan_launches = std::max(acc.scan_launches, s.scan_launches);
         acc.passa_launches = std::max(acc.passa_launches, s.passa_launches);
         acc.tie_fallbacks += s.tie_fallbacks;

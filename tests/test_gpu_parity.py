@@ -846,6 +846,87 @@ def test_union_instances_forced(mi, oracle, D, m, C, n, w, k, dup):
     ix.close()
 
 
+@pytest.mark.parametrize("D,m,C,n,w,k,tr,dup", [
+    (128, 16, 6, 30000, 6, 100, 0, 1),    # <NJ 4, dsub 8>: the headline's shape
+    (128, 16, 5, 24000, 5, 50, 2, 3),     # RandomPermutation; every vector three times: ties everywhere, pools fill up
+    (128, 8, 6, 24000, 6, 30, 0, 1),      # <4, 16>: cfg2's sub-quantizers in an IVF index
+    (64, 8, 4, 20000, 4, 300, 2, 1),      # <2, 8>, k = 300 (beyond K3g's candidate buffers)
+    (64, 4, 4, 16000, 3, 10, 0, 2),       # <2, 16>
+    (32, 4, 7, 12000, 7, 1, 0, 1),        # <1, 8>, k = 1
+    (32, 2, 3, 9000, 3, 700, 0, 1),       # <1, 16>, k = 700
+])
+def test_mfma_pass_b(mi, oracle, D, m, C, n, w, k, tr, dup):
+    """K3m (`k_scan_mfma` + `k_mfma_verify` + `k_mfma_redo`, csrc/mmidx_scan_mfma.h): pass B as a certified lower bound on the matrix
+    cores -- fp16 residuals x fp16 decoded codes, accumulators started at -||x||^2 / 2, one compare per (query, code) -- with exact
+    fp64 distances for the survivors only (IVFPQ.java:429-446).  Overlapping cells and queries between cells, so that far probes
+    feed the queue.  Default sizing, pieces of 64 codes (`mfma_sub`), a survivor list of 16 records (`mfma_qcap`: nearly every
+    query is handed back to K3f through the redo path) and K3m off (`no_mfma`): ids and distance bits are the oracle's every time."""
+    ks = 256
+    rng = np.random.default_rng(D + m + k)
+    mu = 0.5 * rng.standard_normal((C, D))
+    base = mu[rng.integers(0, C, n // dup)] + rng.standard_normal((n // dup, D))
+    base = np.concatenate([base] * dup)[rng.permutation((n // dup) * dup)]
+    n = len(base)
+    ds = D // m
+    pq = np.stack([synth.kmeans((mu[rng.integers(0, C, 3000)] - base[:3000])[:, s * ds:(s + 1) * ds], ks, iters=2, seed=s) for s in range(m)])
+    ix = mi.IVFPQ(D, n, False, "", m, ks, tr, C, 512)
+    ix.loadCoarseQuantizer(mu)
+    ix.loadProductQuantizer(pq)
+    ix.setW(w)
+    ref = oracle_ivfpq(oracle, {"coarse": mu, "pq": pq}, D, m, ks, C, w, tr=tr, perm=oracle.random_permutation(1, D) if tr == 2 else None)
+    ix.indexVectors([str(i) for i in range(n)], base)
+    ref.add_vectors(base)
+    Q = np.concatenate([0.5 * (base[:24] + base[100:124]), rng.standard_normal((8, D)), base[:40] + 0.01 * rng.standard_normal((40, D)), mu[:2]])
+    want = ref.search_batch(Q, k)
+    for sub, qcap, off in ((0, 0, 0), (64, 0, 0), (0, 16, 0), (4096, 0, 0), (0, 0, 1)):
+        ix.set_option("mfma_sub", sub)
+        ix.set_option("mfma_qcap", qcap)
+        ix.set_option("no_mfma", off)
+        ix.set_profiling(True)
+        got = ix.search_batch(k, Q)
+        st = ix.get_stats()
+        assert_same(got, want)
+        if off:
+            assert st["mfma_survivors"] == 0
+        elif w > 1:
+            assert st["mfma_survivors"] > 0 and st["verified_codes"] >= st["mfma_survivors"]  # (K3m ran and had survivors to verify)
+            if qcap:
+                assert st["mfma_redo_queries"] > 0  # (the short survivor list really sent queries through the redo path)
+    one = ix.search_batch(k, Q[:1])  # a one-query call: groups of one pair
+    assert_same(one, tuple(a[:1] for a in want))
+    ix.close()
+
+
+@pytest.mark.parametrize("D,m,n,k,tr,chunk", [(128, 8, 70000, 100, 0, 8192), (128, 16, 40000, 10, 2, 4096), (64, 8, 30000, 200, 0, 4096), (32, 2, 50000, 5, 0, 16384)])
+def test_mfma_flat_pq(mi, oracle, D, m, n, k, tr, chunk):
+    """Flat PQ (PQ.computeKnnADC, PQ.java:290-322) through K3m: the chunks 1 .. of the single list stand in for inverted lists, the
+    residual is the query itself, survivors are verified from the queries' exact tables (k_flat_lut)."""
+    ks = 256
+    p = synth.make_pq_problem(n=8000, D=D, m=m, ks=ks, nq=12, seed=D + m, iters=2)
+    rng = np.random.default_rng(n)
+    base = rng.standard_normal((n, D))
+    ix = mi.PQ(D, n, False, "", m, ks, tr, 512)
+    ix.loadProductQuantizer(p["pq"])
+    ix.set_option("flat_chunk", chunk)
+    ref = oracle.OracleIndex(oracle.KIND_PQ, D, m, ks, transform=tr, perm=oracle.random_permutation(1, D) if tr == 2 else None)
+    ref.set_pq(p["pq"])
+    ix.indexVectors([str(i) for i in range(n)], base)
+    ref.add_vectors(base)
+    Q = np.concatenate([base[:20] + 0.05 * rng.standard_normal((20, D)), rng.standard_normal((80, D))])
+    want = ref.search_batch(Q, k)
+    for sub, qcap, off in ((0, 0, 0), (256, 0, 0), (0, 64, 0), (0, 0, 1)):
+        ix.set_option("mfma_sub", sub)
+        ix.set_option("mfma_qcap", qcap)
+        ix.set_option("no_mfma", off)
+        ix.set_profiling(True)
+        got = ix.search_batch(k, Q)
+        st = ix.get_stats()
+        assert_same(got, want)
+        if not off:
+            assert st["mfma_survivors"] > 0
+    ix.close()
+
+
 @pytest.mark.parametrize("D,m,C,n,w,k,tr,sep", [
     (128, 16, 24, 30000, 24, 100, 0, 0.8),   # <8, 16 waves>: the headline's shape; cells far enough apart that far pairs end at Smin >= T
     (128, 8, 12, 20000, 12, 20, 2, 0.8),     # <16, 8 waves>, RandomPermutation
