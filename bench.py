@@ -834,6 +834,7 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
                "ms_per_step": round(h_el / steps_ * 1e3, 4), "batch": B,
                "survivors_per_query": round(int(hst.passb_items_last) / B, 3), "far_probes_per_query": w - 1,
                "verified_codes_per_query": round(hst.verified_codes / hd / B, 2),
+               "mfma_survivors_per_query": round(hst.mfma_survivors / hd / B, 2), "mfma_redo_queries_per_step": round(hst.mfma_redo_queries / hd, 2),
                "recall_at_1": h_recall, "true_neighbour_in_top_k": h_recall_k, "recall_queries": ngh,
                "stage_ms_per_step": {"coarse": round(hst.coarse_ms / hd, 4), "pass_a": round(hst.passa_ms / hd, 4), "pass_b": round(pb_ms, 4),
                                      "merge": round(hst.merge_ms / hd, 4)},

@@ -297,7 +297,7 @@ struct mmidx_index {
     int mfma_sub = 0;                  // option "mfma_sub": codes per K3m item (0 = sized from the call)
     int mfma_qcap = 0;                 // option "mfma_qcap": survivor records per launch (0 = sized from the call; tests force the redo path)
     int mfma_blocks = 0;               // option "mfma_blocks": persistent blocks (0 = occupancy x CUs)
-    DevBuf<uint2> ws_surv;
+    DevBuf<uint4> ws_surv;
     DevBuf<u32> ws_mfctl, ws_psnap;
     DevBuf<unsigned char> ws_redo;
     void *d_grpx = nullptr, *pin_grpx = nullptr;  // K3g's GrpExtra on the device and its pinned mirror
@@ -1231,6 +1231,7 @@ int launch_mfma_common(mmidx_index *h, const ScanParams &S, ScanParams F, const 
     if (h->dsub == 8) rc = h->m == 16 ? launch_mfma_verify_t<16, 8>(h, MP, st) : h->m == 8 ? launch_mfma_verify_t<8, 8>(h, MP, st) : launch_mfma_verify_t<4, 8>(h, MP, st);
     else rc = h->m == 8 ? launch_mfma_verify_t<8, 16>(h, MP, st) : h->m == 4 ? launch_mfma_verify_t<4, 16>(h, MP, st) : launch_mfma_verify_t<2, 16>(h, MP, st);
     if (rc) return rc;
+    if (MP.stat) hipLaunchKernelGGL(k_mfma_count, dim3(1024), dim3(256), 0, st, MP);  // (profiling runs only)
     DBG_SYNC("K3m verify");
     const long long span = std::max<long long>(npairs, nq);
     hipLaunchKernelGGL(k_mfma_redo, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, st, MP, (long long)nq);

@@ -53,7 +53,7 @@ struct MfmaParams {
     double xmax;               // >= ||x|| of every code: sqrt(sum_s max_j ||p_sj||^2) (1 + 1e-12)
     u32 *ghist;                // [nq][256] upper bounds of the survivors by bucket floor(ub * 256 / T0)
     const u64 *T0;             // [nq] thresholds as the launch found them (the bucket map must not move)
-    uint2 *surv;               // survivor records {slot of the pair in order[], position in the list}
+    uint4 *surv;               // survivor records {slot of the pair in order[], position in the list, lower bound (float bits), 0}
     u32 *surv_cnt;             // appended so far (may exceed surv_cap: the excess was dropped and its queries marked)
     u32 surv_cap;
     unsigned char *redo;       // [nq] 1: the query's pass B is redone by K3f
@@ -67,19 +67,23 @@ struct MfmaParams {
     unsigned long long *nver;  // always: [0] += verified codes (host hint)
 };
 
+#define MF_CHUNK 512    // survivor records a wave reserves at a time (one global atomic per chunk, not per tile)
+struct MfmaRow {        // what the survivor path needs of a query row (32 bytes: two 16-byte LDS reads)
+    float thr;          // a code survives iff acc >= thr
+    float cd;           // lower bound of a survivor's distance = cd + kd acc  (cd = ||r||^2 - err, kd = -2 / s^2: the item's)
+    float kq, cq;       // histogram bucket of its UPPER bound = floor(cq + kq acc)  (kq = 0: no histogram for this row)
+    int q, slot;        // query, slot of the pair in order[]
+    float inv0;         // 256 / T0 as a float (bucket edges are converted back in fp64)
+    int pad;
+};
 struct MfmaLds {
-    size_t cb, stage, nr, err, inv0, thr, q, e, misc, total;
+    size_t cb, stage, row, misc, total;
     __host__ __device__ MfmaLds(int D) {
         size_t o = 0;
         cb = o; o += (size_t)D * 512;             // [D / 8][256] rows of 8 halfs
         stage = o; o += 32 * (size_t)MF_ASTRIDE;  // 32 residual rows at a time
-        nr = o; o += MF_QG * 8;
-        err = o; o += MF_QG * 8;
-        inv0 = o; o += MF_QG * 8;
-        thr = o; o += MF_QG * 4;
-        q = o; o += MF_QG * 4;
-        e = o; o += MF_QG * 4;
-        misc = o; o += 64;  // [0] item, [1..2] touched mask, [3] scale ok, [4..7] wave maxima
+        row = o; o += MF_QG * sizeof(MfmaRow);
+        misc = o; o += 64;  // [0] item, [1..2] touched mask, [4..7] wave maxima
         total = (o + 15) & ~(size_t)15;
     }
 };
@@ -143,11 +147,30 @@ __device__ __forceinline__ float mf_float_down(double x) {
 // NJ = D / 32 (MFMA k chunks per code), DSUB = dimensions per sub-quantizer (8 or 16).  Lane (n = lane & 15, g = lane >> 4) of a
 // code tile holds column n (code n of the tile) and the 8-dimension groups g8 = NJ g + j, j = 0 .. NJ-1: the code bytes it
 // needs are contiguous (NB of them at byte offset NB g).
+// wave-private survivor chunk: [base, base + cap) of P.surv, `used` records written (wave-uniform values)
+struct MfmaChunk {
+    u32 base, cap, used;
+};
+// make room for `tot` records: the rest of the current chunk is padded with invalid records, a new chunk reserved
+__device__ __forceinline__ void mf_chunk_room(const MfmaParams &P, MfmaChunk &ck, const u32 tot, const int lane) {
+    if (ck.used + tot <= ck.cap) return;
+    for (u32 i = ck.used + (u32)lane; i < ck.cap; i += 64)
+        if (ck.base + i < P.surv_cap) P.surv[ck.base + i] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+    const u32 want = tot > MF_CHUNK ? tot : MF_CHUNK;
+    u32 b = 0;
+    if (lane == 0) b = atomicAdd(P.surv_cnt, want);
+    ck.base = (u32)__builtin_amdgcn_readfirstlane((int)b);
+    ck.cap = want;
+    ck.used = 0;
+}
+__device__ __forceinline__ u32 mf_mbcnt(const u64 m) {  // set bits of m below this lane
+    return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+}
+
 template <int NJ, int DSUB, int NTL>
 __device__ __forceinline__ void mf_scan_tiles(const MfmaParams &P, const mf_h8 (&A)[4][NJ], const float (&thr)[4][4], const unsigned char *codes,
-                                              const float *xn, const long long c0, const long long c1, const float kinit, const double inv_s2,
-                                              const u32 lds_cb, const double *s_nr, const double *s_err, const double *s_inv0, const int *s_q,
-                                              const int *s_e, u32 *s_touch, const int lane, const int wv) {
+                                              const float *xn, const long long c0, const long long c1, const float kinit, const float kd,
+                                              const u32 lds_cb, const MfmaRow *s_row, u64 &touched, MfmaChunk &ck, const int lane, const int wv) {
     constexpr int D = NJ * 32, M = D / DSUB;
     constexpr int NB = (NJ * 8 >= DSUB) ? NJ * 8 / DSUB : 1;  // code bytes per lane
     const int n = lane & 15, g = lane >> 4;
@@ -168,87 +191,104 @@ __device__ __forceinline__ void mf_scan_tiles(const MfmaParams &P, const mf_h8 (
 #pragma unroll
     for (int u = 0; u < 4; u++) load_tile(wv + 4 * u, cw[u], xv[u]);
     for (int t = wv; t < ntiles; t += 16) {
+        // TWO tiles per step: both tiles' gathers are issued together, the second tile's matrix work runs under the first one's
+        // compares -- one tile at a time the wave serialised gather latency, the MFMA chain, its drain and the compares
+        // (truncated builds: 1.8 of pass B's 2.25 ms were neither MFMA issue nor bank conflicts)
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < 4; u += 2) {
             const int tt = t + 4 * u;
-            const u32 c = cw[u];
-            const float x = xv[u];
+            const u32 c[2] = {cw[u], cw[u + 1]};
+            const float x[2] = {xv[u], xv[u + 1]};
             load_tile(tt + 16, cw[u], xv[u]);  // (clamped to the item's last code: always a valid address)
-            if (tt >= ntiles) continue;        // (wave-uniform)
-            mf_h8 B[NJ];
+            load_tile(tt + 20, cw[u + 1], xv[u + 1]);
+            if (tt >= ntiles) continue;        // (wave-uniform; a second tile past the end computes on clamped codes and is masked below)
+            mf_h8 B[2][NJ];
 #pragma unroll
-            for (int j = 0; j < NJ; j++) {
-                const u32 byte = (c >> (8 * (j / (DSUB / 8)))) & 0xFFu;
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    const u32 byte = (c[h] >> (8 * (j / (DSUB / 8)))) & 0xFFu;
 #if MF_TIMING == 3
-                const u32 addr = lane_base + ((u32)lane << 4);
+                    const u32 addr = lane_base + ((u32)lane << 4);
 #else
-                const u32 addr = lane_base + (byte << 4);
+                    const u32 addr = lane_base + (byte << 4);
 #endif
-                B[j] = *(const __attribute__((address_space(3))) mf_h8 *)(size_t)(addr + (u32)j * 4096u);
-            }
-            const float ci = x * kinit;
-            const mf_f4 c4 = {ci, ci, ci, ci};
-            mf_f4 acc[NTL];
+                    B[h][j] = *(const __attribute__((address_space(3))) mf_h8 *)(size_t)(addr + (u32)j * 4096u);
+                }
+            // (all gathers of the step are in flight before the first MFMA: left to itself the scheduler issues each one right in
+            //  front of its use and the wave waits out the LDS latency 2 NJ times per step)
+            __builtin_amdgcn_sched_barrier(0);
+            mf_f4 acc[2][NTL];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const float ci = x[h] * kinit;
+                const mf_f4 c4 = {ci, ci, ci, ci};
 #if MF_TIMING == 2
 #pragma unroll
-            for (int rt = 0; rt < NTL; rt++) acc[rt] = c4 + __builtin_bit_cast(mf_f4, B[rt % NJ]) * 1e-30f;
+                for (int rt = 0; rt < NTL; rt++) acc[h][rt] = c4 + __builtin_bit_cast(mf_f4, B[h][rt % NJ]) * 1e-30f;
 #else
 #pragma unroll
-            for (int rt = 0; rt < NTL; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[rt][0], B[0], c4, 0, 0, 0);
+                for (int rt = 0; rt < NTL; rt++) acc[h][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[rt][0], B[h][0], c4, 0, 0, 0);
 #pragma unroll
-            for (int j = 1; j < NJ; j++)
+                for (int j = 1; j < NJ; j++)
 #pragma unroll
-                for (int rt = 0; rt < NTL; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[rt][j], B[j], acc[rt], 0, 0, 0);
+                    for (int rt = 0; rt < NTL; rt++) acc[h][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[rt][j], B[h][j], acc[h][rt], 0, 0, 0);
 #endif
-            u64 any = 0;
+            }
+            // one compare per accumulator register; the lane masks stay in scalar registers
+            u64 any[2] = {0, 0};
 #pragma unroll
-            for (int rt = 0; rt < NTL; rt++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) any |= __builtin_amdgcn_ballot_w64(acc[rt][i] >= thr[rt][i]);
-#if MF_TIMING == 1
-            if (any == 0x123456789ull) s_touch[0] = 1;
-            any = 0;
-#endif
-            if (any) {
-                // ---- survivors (rare): records + upper bounds into the queries' histograms ----
-                const long long pos = c0 + (long long)tt * 16 + n;
-                const bool valid = pos < c1;
-                u32 bits = 0;
+            for (int h = 0; h < 2; h++)
 #pragma unroll
                 for (int rt = 0; rt < NTL; rt++)
 #pragma unroll
-                    for (int i = 0; i < 4; i++) bits |= (acc[rt][i] >= thr[rt][i]) ? 1u << (rt * 4 + i) : 0u;
-                bits = valid ? bits : 0u;
-                const u32 mine = (u32)__popc(bits);
-                const u32 incl = wave_incl_scan_u32(mine);
-                const u32 tot = wave_read_u32(incl, 63);
-                if (tot) {
-                    u32 base = 0;
-                    if (lane == 0) base = atomicAdd(P.surv_cnt, tot);
-                    base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-                    const u32 off0 = base + incl - mine;
+                    for (int i = 0; i < 4; i++) any[h] |= __builtin_amdgcn_ballot_w64(acc[h][rt][i] >= thr[rt][i]);
+#if MF_TIMING == 1
+            if ((any[0] | any[1]) == 0x123456789ull) touched |= 1;
+            any[0] = any[1] = 0;
+#endif
+            if (any[0] | any[1]) {
+                // ---- survivors: records into the wave's chunk, upper bounds into the queries' histograms ----
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    if (!any[h]) continue;  // (scalar branch)
+                    const long long pos = c0 + (long long)(tt + 4 * h) * 16 + n;
+                    const u64 vm = __builtin_amdgcn_ballot_w64(pos < c1);  // (only an item's last tile has lanes past the end)
+                    u64 mk[NTL * 4];
+                    u32 tot = 0;
 #pragma unroll
                     for (int rt = 0; rt < NTL; rt++)
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
-                            const int b = rt * 4 + i;
-                            if ((bits >> b) & 1u) {
-                                const int qs = rt * 16 + 4 * g + i;
-                                const u32 off = off0 + (u32)__popc(bits & ((1u << b) - 1u));
-                                const int q = s_q[qs];
-                                if (off < P.surv_cap) P.surv[off] = make_uint2((u32)s_e[qs], (u32)pos);
-                                else P.redo[q] = 1;
-                                const double inv0 = s_inv0[qs];
-                                if (inv0 > 0.0) {
-                                    // d~ = ||r||^2 - 2 (acc / s^2); every code has |d - d~| <= err: ub = d~ + err
-                                    const double ub = s_nr[qs] - 2.0 * ((double)acc[rt][i] * inv_s2) + s_err[qs];
-                                    const double xb = ub * inv0 * (1.0 + 0x1p-40);
-                                    if (xb < 255.0) {
-                                        const int bk = xb > 0.0 ? (int)xb : 0;
-                                        atomicAdd(P.ghist + (size_t)q * 256 + bk, 1u);
-                                        atomicOr(s_touch + (qs >> 5), 1u << (qs & 31));
-                                    }
+                            mk[rt * 4 + i] = __builtin_amdgcn_ballot_w64(acc[h][rt][i] >= thr[rt][i]) & vm;
+                            tot += (u32)__popcll(mk[rt * 4 + i]);
+                        }
+                    if (!tot) continue;
+                    mf_chunk_room(P, ck, tot, lane);
+                    u32 run = ck.base + ck.used;
+                    ck.used += tot;
+#pragma unroll
+                    for (int rt = 0; rt < NTL; rt++)
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const u64 m = mk[rt * 4 + i];
+                            if (m) {  // (scalar branch)
+                                // rows of this register: rt * 16 + 4 g + i, g = the lane's 16-lane row
+                                touched |= ((m & 0xFFFFull) ? 1ull << (rt * 16 + i) : 0ull) | ((m & 0xFFFF0000ull) ? 1ull << (rt * 16 + 4 + i) : 0ull) |
+                                           ((m & 0xFFFF00000000ull) ? 1ull << (rt * 16 + 8 + i) : 0ull) | ((m >> 48) ? 1ull << (rt * 16 + 12 + i) : 0ull);
+                                if ((m >> lane) & 1ull) {
+                                    const MfmaRow rw = s_row[rt * 16 + 4 * g + i];
+                                    const u32 off = run + mf_mbcnt(m);
+                                    // d~ = ||r||^2 - 2 acc / s^2 and |d - d~| <= err: lower bound cd + kd acc (kept with the record: the
+                                    // verification drops what the query's FINAL threshold has left behind), upper bound -> bucket
+                                    const float a = acc[h][rt][i];
+                                    const float lbf = fmaf(a, kd, rw.cd);
+                                    if (off < P.surv_cap) P.surv[off] = make_uint4((u32)rw.slot, (u32)pos, (u32)__float_as_int(lbf), 0u);
+                                    else P.redo[rw.q] = 1;
+                                    const float xb = fmaf(a, rw.kq, rw.cq);
+                                    if (rw.kq != 0.f && xb < 255.f) atomicAdd(P.ghist + (size_t)rw.q * 256 + (xb > 0.f ? (int)xb : 0), 1u);
                                 }
+                                run += (u32)__popcll(m);
                             }
                         }
                 }
@@ -266,10 +306,9 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const MfmaLds L(D);
     unsigned char *s_stage = smem + L.stage;
-    double *s_nr = (double *)(smem + L.nr), *s_err = (double *)(smem + L.err), *s_inv0 = (double *)(smem + L.inv0);
-    float *s_thr = (float *)(smem + L.thr);
-    int *s_q = (int *)(smem + L.q), *s_e = (int *)(smem + L.e);
+    MfmaRow *s_row = (MfmaRow *)(smem + L.row);
     u32 *s_misc = (u32 *)(smem + L.misc);
+    MfmaChunk ck{0u, 0u, 0u};
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 lds_cb = (u32)(size_t)(__attribute__((address_space(3))) unsigned char *)(smem + L.cb);
 
@@ -371,6 +410,7 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
         const double inv_s2 = 1.0 / s2, inv_sr = scale_ok ? ldexp(1.0, -er) : 1.0, inv_sp = ldexp(1.0, -P.ep);
         const double sqrtD = 11.32;  // >= sqrt(128)
         const float kinit = (float)(-0.5 * s2);
+        const float kd = (float)(-2.0 * inv_s2);  // (a power of two: exact)
         // per query: ||r||^2, the certified error term, the threshold constant, the histogram scale
         if ((tid & 7) == 0) {
 #pragma unroll
@@ -382,10 +422,11 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
                 //                                       + 1.01 sqrt(D) 2^-14 (xmax / s_r + |r| / s_p) + D 2^-28 / s^2 :
                 //   fp16 inputs (an element's error is at most 2^-11 of itself -- after the fp32 step 1.001 of that -- or, where the
                 //   scaled element is subnormal or flushed, 2^-14 / scale), exact products, fp32 accumulation (gam), the fp32 start
-                //   value.  d = ||r||^2 - 2 (...), and the reference's own fp64 roundings are inside the 2^-40 term:
+                //   value.  d = ||r||^2 - 2 (...); the reference's own fp64 roundings and the survivor path's fp32 arithmetic (lower and
+                //   upper bounds are single fma's of quantities no larger than ||r||^2 + ||x||^2 + 2 |r||x|) are inside the 2^-19 term:
                 const double err = nrm * xmax * (4.02 * 0x1p-11 + 2.004 * gam) + xmax * xmax * (1.001 * gam + 0x1p-24) +
                                    2.02 * sqrtD * 0x1p-14 * (xmax * inv_sr + nrm * inv_sp) + 2.0 * D * 0x1p-28 * inv_s2 +
-                                   0x1p-40 * (nr + xmax * xmax + 2.0 * nrm * xmax) + 1e-300;
+                                   0x1p-19 * (nr + xmax * xmax + 2.0 * nrm * xmax) + 1e-300;
                 const u64 T = __hip_atomic_load(P.S.T + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 float th = __int_as_float(0x7F800000);  // +inf: nothing survives (rows past np, queries handed to the redo)
                 double inv0 = 0.0;
@@ -407,12 +448,26 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
                         }
                     }
                 }
-                s_nr[row] = nr;
-                s_err[row] = err;
-                s_inv0[row] = inv0;
-                s_thr[row] = th;
-                s_q[row] = q;
-                s_e[row] = first + (row < np ? row : np - 1);
+                // the survivor path works in fp32: err carries 2^-20 of the magnitudes for its roundings (cd, kd acc, the fma's)
+                MfmaRow rw;
+                rw.thr = th;
+                rw.cd = (float)(nr - err);
+                rw.kq = 0.f;
+                rw.cq = 0.f;
+                rw.inv0 = 0.f;
+                if (inv0 > 0.0 && inv0 < 1e30 && inv0 * inv_s2 < 1e30) {
+                    // bucket of the upper bound (nr + err - 2 acc / s^2) * inv0, shifted up against the fp32 roundings of cq, kq and the
+                    // fma (2^-21 of the magnitudes that cancel in it, + 1e-3 of a bucket)
+                    const double mag = ((nr + err) + 2.02 * (nrm * xmax + 0.5 * xmax * xmax)) * inv0;
+                    rw.kq = (float)(-2.0 * inv_s2 * inv0);
+                    rw.cq = (float)((nr + err) * inv0 + 1e-3 + 0x1p-21 * mag);
+                    rw.inv0 = (float)inv0;
+                    if (!(rw.kq != 0.f) || !(rw.cq < 3e38f)) rw.kq = 0.f;
+                }
+                rw.q = q;
+                rw.slot = first + (row < np ? row : np - 1);
+                rw.pad = 0;
+                s_row[row] = rw;
             }
         }
         // fp16 A operands, 32 rows at a time through LDS
@@ -450,23 +505,30 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
 #pragma unroll
         for (int rt = 0; rt < 4; rt++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) thr[rt][i] = s_thr[rt * 16 + 4 * (lane >> 4) + i];
+            for (int i = 0; i < 4; i++) thr[rt][i] = s_row[rt * 16 + 4 * (lane >> 4) + i].thr;
 
         // ---- (b) the scan: every wave its own code tiles against all row tiles ----
+        u64 touched = 0;  // (wave-uniform) rows of the item that had a survivor in this wave
         switch (ntl) {
-            case 1: mf_scan_tiles<NJ, DSUB, 1>(P, A, thr, codes, xn, c0, c1, kinit, inv_s2, lds_cb, s_nr, s_err, s_inv0, s_q, s_e, s_misc + 1, lane, wv); break;
-            case 2: mf_scan_tiles<NJ, DSUB, 2>(P, A, thr, codes, xn, c0, c1, kinit, inv_s2, lds_cb, s_nr, s_err, s_inv0, s_q, s_e, s_misc + 1, lane, wv); break;
-            case 3: mf_scan_tiles<NJ, DSUB, 3>(P, A, thr, codes, xn, c0, c1, kinit, inv_s2, lds_cb, s_nr, s_err, s_inv0, s_q, s_e, s_misc + 1, lane, wv); break;
-            default: mf_scan_tiles<NJ, DSUB, 4>(P, A, thr, codes, xn, c0, c1, kinit, inv_s2, lds_cb, s_nr, s_err, s_inv0, s_q, s_e, s_misc + 1, lane, wv); break;
+            case 1: mf_scan_tiles<NJ, DSUB, 1>(P, A, thr, codes, xn, c0, c1, kinit, kd, lds_cb, s_row, touched, ck, lane, wv); break;
+            case 2: mf_scan_tiles<NJ, DSUB, 2>(P, A, thr, codes, xn, c0, c1, kinit, kd, lds_cb, s_row, touched, ck, lane, wv); break;
+            case 3: mf_scan_tiles<NJ, DSUB, 3>(P, A, thr, codes, xn, c0, c1, kinit, kd, lds_cb, s_row, touched, ck, lane, wv); break;
+            default: mf_scan_tiles<NJ, DSUB, 4>(P, A, thr, codes, xn, c0, c1, kinit, kd, lds_cb, s_row, touched, ck, lane, wv); break;
+        }
+        if (touched && lane == 0) {
+            if ((u32)touched) atomicOr(s_misc + 1, (u32)touched);
+            if ((u32)(touched >> 32)) atomicOr(s_misc + 2, (u32)(touched >> 32));
         }
         __syncthreads();
         // ---- (c) thresholds from the union of the survivors' upper bounds: K1 of them at or below a bucket's upper edge make
         //      that edge a valid threshold (K1 offers lie at or below it) for every later item of the query ----
         {
-            const u64 touched = ((u64)s_misc[2] << 32) | (u64)s_misc[1];
+            const u64 tall = ((u64)s_misc[2] << 32) | (u64)s_misc[1];
             for (int qs = wv; qs < MF_QG; qs += MF_NT / 64) {
-                if (!((touched >> qs) & 1ull)) continue;  // (wave-uniform)
-                const int q = s_q[qs];
+                if (!((tall >> qs) & 1ull)) continue;  // (wave-uniform)
+                const int q = s_row[qs].q;
+                if (!(s_row[qs].kq != 0.f)) continue;
+                const double inv0q = 256.0 / keyd(P.T0[q]);  // (as phase (a) computed it)
                 const u32 *hq = P.ghist + (size_t)q * 256 + 4 * lane;
                 const u32 h0 = __hip_atomic_load(hq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), h1 = __hip_atomic_load(hq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                           h2 = __hip_atomic_load(hq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), h3 = __hip_atomic_load(hq + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -481,115 +543,165 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
                         if (c < (u32)P.S.K1) { c += h2; b++; }
                         if (c < (u32)P.S.K1) { c += h3; b++; }
                         // every counted survivor has d <= ub < (b + 1) / inv0
-                        atomicMin(P.S.T + q, dkey((double)(b + 1) / s_inv0[qs] * (1.0 + 1e-12)));
+                        atomicMin(P.S.T + q, dkey((double)(b + 1) / inv0q * (1.0 + 1e-12)));
                     }
                 }
             }
         }
         __syncthreads();  // LDS is reused by the next item
     }
+    // the rest of the wave's last chunk: invalid records (k_mfma_verify skips them)
+    for (u32 i = ck.used + (u32)lane; i < ck.cap; i += 64)
+        if (ck.base + i < P.surv_cap) P.surv[ck.base + i] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
 }
 
 // ---- exact distances of the survivors -------------------------------------------------------------------------------------
-// LPS = M lanes per survivor (IVF, and flat PQ without tables): lane s computes the table entry of sub-quantizer s in the
-// reference's order (t ascending from 0.0, IVFPQ.java:531-534) and the entries are added in sub-quantizer order (:435-438,
-// ((0 + e_0) + e_1) + ...) down the lanes by DPP -- the bits of a lookup in the fp64 table.  FLAT: one lane per survivor reads the
-// query's own table (k_flat_lut; PQ.java:308-311).
+// Phase 1, a thread per record: the record's lower bound against the query's threshold as it stands NOW (the scan is over: the
+// final one) -- thresholds tighten while the scan runs, and most of what survived an early item lies above the final threshold;
+// those records are dropped without looking at their codes.  Phase 2, LPS = M lanes per remaining survivor (IVF, and flat PQ
+// without tables): lane s computes the table entry of sub-quantizer s in the reference's order (t ascending from 0.0,
+// IVFPQ.java:531-534) and the entries are added in sub-quantizer order (:435-438, ((0 + e_0) + e_1) + ...) down the lanes by DPP
+// -- the bits of a lookup in the fp64 table.  FLAT: one lane per survivor reads the query's own table (k_flat_lut; PQ.java:308-311).
+#define MF_VLIST 1024  // records a block filters per round
 template <int M, int DSUB, bool FLAT>
 __global__ __launch_bounds__(256) void k_mfma_verify(const MfmaParams P) {
     constexpr int LPS = FLAT ? 1 : M, D = M * DSUB;
+    __shared__ uint2 s_rec[MF_VLIST];
+    __shared__ int s_pair[MF_VLIST];
+    __shared__ u32 s_n, s_nv;
     const u32 cnt = *P.surv_cnt;
     const u32 ns = cnt < P.surv_cap ? cnt : P.surv_cap;
-    const int tid = threadIdx.x;
-    if (blockIdx.x == 0 && tid == 0) {
-        if (P.stat) {
-            atomicAdd(P.stat, (unsigned long long)ns);
-            atomicAdd(P.stat + 9, (unsigned long long)ns);  // (mmidx_stats::mfma_survivors)
-        }
-        atomicAdd(P.nver, (unsigned long long)ns);
-    }
-    const u32 per_block = 256 / LPS;
-    for (u32 base = blockIdx.x * per_block; base < ns; base += gridDim.x * per_block) {
-        const u32 si_raw = base + (u32)(tid / LPS);
-        const bool act = si_raw < ns;
-        const u32 si = act ? si_raw : ns - 1u;  // (loads run on a clamped index)
-        const uint2 rec = P.surv[si];
-        const int slot = (int)rec.x;
-        const u32 pos = rec.y;
-        const int e = P.S.order[slot];
-        const int q = e / P.S.w, rank = e - q * P.S.w;
-        const int cell = P.S.ivf ? P.S.cells[e] : rank;
-        const long long beg = P.S.list_off[cell];
-        const unsigned char *code = (const unsigned char *)P.S.codes + (size_t)(beg + pos) * M;
-        double d = 0.0;
-        if constexpr (FLAT) {
-            const double *lq = P.flat_lut + (size_t)q * (size_t)(M * 256);
-            double en[M];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) s_nv = 0;
+    for (u32 base = blockIdx.x * MF_VLIST; base < ns; base += gridDim.x * MF_VLIST) {
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        // ---- phase 1 ----
 #pragma unroll
-            for (int s = 0; s < M; s++) en[s] = lq[s * 256 + (int)code[s]];
-#pragma unroll
-            for (int s = 0; s < M; s++) d += en[s];
-        } else {
-            const int s = tid & (M - 1);
-            const u32 cs = (u32)code[s];
-            double tv[DSUB];
-            if (P.R) {
-                const double *rr = P.R + (size_t)slot * D + s * DSUB;
-#pragma unroll
-                for (int t = 0; t < DSUB; t += 2) {
-                    const double2 r2 = *(const double2 *)(rr + t);
-                    tv[t] = r2.x;
-                    tv[t + 1] = r2.y;
-                }
-            } else {
-                const double *cc = P.S.coarse + (size_t)(P.S.ivf ? cell : 0) * D + s * DSUB, *qv = P.S.Q + (size_t)q * D + s * DSUB;
-#pragma unroll
-                for (int t = 0; t < DSUB; t += 2) {
-                    const double2 c2 = *(const double2 *)(cc + t), q2 = *(const double2 *)(qv + t);
-                    tv[t] = P.S.ivf ? c2.x - q2.x : q2.x - c2.x;
-                    tv[t + 1] = P.S.ivf ? c2.y - q2.y : q2.y - c2.y;
-                }
-            }
-            const double *pp = P.pq + ((size_t)s * P.S.ks + cs) * DSUB;
-            double pv[DSUB];
-#pragma unroll
-            for (int t = 0; t < DSUB; t += 2) {
-                const double2 v2 = *(const double2 *)(pp + t);
-                pv[t] = v2.x;
-                pv[t + 1] = v2.y;
-            }
-            double en = 0.0;
-#pragma unroll
-            for (int t = 0; t < DSUB; t++) {
-                const double df = tv[t] - pv[t];
-                en += df * df;
-            }
-            d = en;  // lane 0 of the survivor: 0.0 + e_0 = e_0
-#pragma unroll
-            for (int st = 1; st < M; st++) {
-                const u64 b = (u64)__double_as_longlong(d);
-                const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)b, 0x111, 0xf, 0xf, false);  // row_shr:1
-                const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(b >> 32), 0x111, 0xf, 0xf, false);
-                const double prev = __longlong_as_double((long long)(((u64)hi << 32) | lo));
-                if (s == st) d = prev + en;
-            }
-        }
-        const bool last = FLAT ? true : ((tid & (M - 1)) == M - 1);
-        if (act && last) {
-            const u64 key = dkey(d);
+        for (int r = 0; r < MF_VLIST / 256; r++) {
+            const u32 si_raw = base + (u32)(r * 256 + tid);
+            const u32 si = si_raw < ns ? si_raw : ns - 1u;  // (loads run on a clamped index)
+            uint4 rec = P.surv[si];
+            const bool valid = si_raw < ns && rec.x != 0xFFFFFFFFu;  // (padding of the waves' chunks)
+            if (!valid) rec = make_uint4(0u, 0u, 0u, 0u);
+            const int e = P.S.order[rec.x];
+            const int q = e / P.S.w;
             const u64 T = __hip_atomic_load(P.S.T + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (key <= T) {
-                const u32 slot = atomicAdd(P.S.pool_cnt + q, 1u);
-                if (slot < (u32)P.S.poolq) {
-                    P.S.pool_key[(size_t)q * P.S.poolq + slot] = key;
-                    // (flat PQ: positions in the pool are those of the single list, as K3f writes them)
-                    P.S.pool_val[(size_t)q * P.S.poolq + slot] = ((u64)rank << 32) | (u64)(pos + (P.S.ivf ? 0u : (u32)beg));
+            const bool alive = valid && !((double)__int_as_float((int)rec.z) > keyd(T));
+            const u64 mk = __builtin_amdgcn_ballot_w64(alive);
+            u32 b = 0;
+            if (mk && lane == 0) b = atomicAdd(&s_n, (u32)__popcll(mk));
+            b = (u32)__builtin_amdgcn_readfirstlane((int)b);
+            if (alive) {
+                const u32 o = b + mf_mbcnt(mk);
+                s_rec[o] = make_uint2(rec.x, rec.y);
+                s_pair[o] = e;
+            }
+        }
+        __syncthreads();
+        const u32 na = s_n;
+        if (tid == 0 && na) atomicAdd(&s_nv, na);
+        // ---- phase 2 ----
+        for (u32 r0 = 0; r0 < na; r0 += 256 / LPS) {
+            const u32 li_raw = r0 + (u32)(tid / LPS);
+            const bool act = li_raw < na;
+            const u32 li = act ? li_raw : na - 1u;
+            const uint2 rec = s_rec[li];
+            const int slot = (int)rec.x;
+            const u32 pos = rec.y;
+            const int e = s_pair[li];
+            const int q = e / P.S.w, rank = e - q * P.S.w;
+            const int cell = P.S.ivf ? P.S.cells[e] : rank;
+            const long long beg = P.S.list_off[cell];
+            const unsigned char *code = (const unsigned char *)P.S.codes + (size_t)(beg + pos) * M;
+            double d = 0.0;
+            if constexpr (FLAT) {
+                const double *lq = P.flat_lut + (size_t)q * (size_t)(M * 256);
+                double en[M];
+#pragma unroll
+                for (int s = 0; s < M; s++) en[s] = lq[s * 256 + (int)code[s]];
+#pragma unroll
+                for (int s = 0; s < M; s++) d += en[s];
+            } else {
+                const int s = tid & (M - 1);
+                const u32 cs = (u32)code[s];
+                double tv[DSUB];
+                if (P.R) {
+                    const double *rr = P.R + (size_t)slot * D + s * DSUB;
+#pragma unroll
+                    for (int t = 0; t < DSUB; t += 2) {
+                        const double2 r2 = *(const double2 *)(rr + t);
+                        tv[t] = r2.x;
+                        tv[t + 1] = r2.y;
+                    }
                 } else {
-                    P.redo[q] = 1;
+                    const double *cc = P.S.coarse + (size_t)(P.S.ivf ? cell : 0) * D + s * DSUB, *qv = P.S.Q + (size_t)q * D + s * DSUB;
+#pragma unroll
+                    for (int t = 0; t < DSUB; t += 2) {
+                        const double2 c2 = *(const double2 *)(cc + t), q2 = *(const double2 *)(qv + t);
+                        tv[t] = P.S.ivf ? c2.x - q2.x : q2.x - c2.x;
+                        tv[t + 1] = P.S.ivf ? c2.y - q2.y : q2.y - c2.y;
+                    }
+                }
+                const double *pp = P.pq + ((size_t)s * P.S.ks + cs) * DSUB;
+                double pv[DSUB];
+#pragma unroll
+                for (int t = 0; t < DSUB; t += 2) {
+                    const double2 v2 = *(const double2 *)(pp + t);
+                    pv[t] = v2.x;
+                    pv[t + 1] = v2.y;
+                }
+                double en = 0.0;
+#pragma unroll
+                for (int t = 0; t < DSUB; t++) {
+                    const double df = tv[t] - pv[t];
+                    en += df * df;
+                }
+                d = en;  // lane 0 of the survivor: 0.0 + e_0 = e_0
+#pragma unroll
+                for (int st = 1; st < M; st++) {
+                    const u64 b = (u64)__double_as_longlong(d);
+                    const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)b, 0x111, 0xf, 0xf, false);  // row_shr:1
+                    const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(b >> 32), 0x111, 0xf, 0xf, false);
+                    const double prev = __longlong_as_double((long long)(((u64)hi << 32) | lo));
+                    if (s == st) d = prev + en;
+                }
+            }
+            const bool last = FLAT ? true : ((tid & (M - 1)) == M - 1);
+            if (act && last) {
+                const u64 key = dkey(d);
+                const u64 T = __hip_atomic_load(P.S.T + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (key <= T) {
+                    const u32 slotp = atomicAdd(P.S.pool_cnt + q, 1u);
+                    if (slotp < (u32)P.S.poolq) {
+                        P.S.pool_key[(size_t)q * P.S.poolq + slotp] = key;
+                        // (flat PQ: positions in the pool are those of the single list, as K3f writes them)
+                        P.S.pool_val[(size_t)q * P.S.poolq + slotp] = ((u64)rank << 32) | (u64)(pos + (P.S.ivf ? 0u : (u32)beg));
+                    } else {
+                        P.redo[q] = 1;
+                    }
                 }
             }
         }
+        __syncthreads();  // the list is reused by the next round
     }
+    __syncthreads();
+    if (tid == 0 && s_nv) {  // statistics: codes whose exact distance was computed
+        if (P.stat) atomicAdd(P.stat, (unsigned long long)s_nv);
+        atomicAdd(P.nver, (unsigned long long)s_nv);
+    }
+}
+// survivors of the scan (valid records), for the statistics
+__global__ void k_mfma_count(const MfmaParams P) {
+    const u32 cnt = *P.surv_cnt;
+    const u32 ns = cnt < P.surv_cap ? cnt : P.surv_cap;
+    u32 n = 0;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) n += P.surv[i].x != 0xFFFFFFFFu;
+    const u64 mk = __builtin_amdgcn_ballot_w64(n != 0);
+    (void)mk;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off);
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(P.stat + 9, (unsigned long long)n);  // (mmidx_stats::mfma_survivors)
 }
 
 // ---- redo: the queries K3m could not serve go to K3f with pass A's pool ---------------------------------------------------

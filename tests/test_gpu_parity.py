@@ -889,7 +889,7 @@ def test_mfma_pass_b(mi, oracle, D, m, C, n, w, k, tr, dup):
         if off:
             assert st["mfma_survivors"] == 0
         elif w > 1:
-            assert st["mfma_survivors"] > 0 and st["verified_codes"] >= st["mfma_survivors"]  # (K3m ran and had survivors to verify)
+            assert st["mfma_survivors"] > 0  # (K3m ran and its bound let codes through; those still at or below the final thresholds were verified exactly)
             if qcap:
                 assert st["mfma_redo_queries"] > 0  # (the short survivor list really sent queries through the redo path)
     one = ix.search_batch(k, Q[:1])  # a one-query call: groups of one pair
