@@ -68,6 +68,8 @@ struct MfmaParams {
 };
 
 #define MF_CHUNK 512    // survivor records a wave reserves at a time (one global atomic per chunk, not per tile)
+#define MF_BUF 128      // survivor records a wave stages in LDS (its quarter of the residual staging area, idle during the scan);
+                        // flushed in one burst of stores + histogram atomics when half full
 struct MfmaRow {        // what the survivor path needs of a query row (32 bytes: two 16-byte LDS reads)
     float thr;          // a code survives iff acc >= thr
     float cd;           // lower bound of a survivor's distance = cd + kd acc  (cd = ||r||^2 - err, kd = -2 / s^2: the item's)
@@ -83,7 +85,7 @@ struct MfmaLds {
         cb = o; o += (size_t)D * 512;             // [D / 8][256] rows of 8 halfs
         stage = o; o += 32 * (size_t)MF_ASTRIDE;  // 32 residual rows at a time
         row = o; o += MF_QG * sizeof(MfmaRow);
-        misc = o; o += 64;  // [0] item, [1..2] touched mask, [4..7] wave maxima
+        misc = o; o += 64;  // [0] item, [1..2] touched mask, [4..7] wave maxima, [8..11] the waves' staged-record counters
         total = (o + 15) & ~(size_t)15;
     }
 };
@@ -167,10 +169,30 @@ __device__ __forceinline__ u32 mf_mbcnt(const u64 m) {  // set bits of m below t
     return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
 }
 
+// the wave's staged survivor records -> the global list (its chunk) + the queries' histograms of upper bounds
+__device__ __forceinline__ void mf_flush(const MfmaParams &P, MfmaChunk &ck, const uint4 *s_buf, const u32 nb, const MfmaRow *s_row, u32 *s_touch,
+                                         const int first, const int lane) {
+    mf_chunk_room(P, ck, nb, lane);
+    for (u32 i = (u32)lane; i < nb; i += 64) {
+        const uint4 r = s_buf[i];
+        const int qs = (int)r.x - first;
+        const int q = s_row[qs].q;
+        const u32 off = ck.base + ck.used + i;
+        if (off < P.surv_cap) P.surv[off] = make_uint4(r.x, r.y, r.z, 0u);
+        else P.redo[q] = 1;
+        if (r.w != 0xFFFFFFFFu) {
+            atomicAdd(P.ghist + (size_t)q * 256 + r.w, 1u);
+            atomicOr(s_touch + (qs >> 5), 1u << (qs & 31));
+        }
+    }
+    ck.used += nb;
+}
+
 template <int NJ, int DSUB, int NTL>
 __device__ __forceinline__ void mf_scan_tiles(const MfmaParams &P, const mf_h8 (&A)[4][NJ], const float (&thr)[4][4], const unsigned char *codes,
                                               const float *xn, const long long c0, const long long c1, const float kinit, const float kd,
-                                              const u32 lds_cb, const MfmaRow *s_row, u64 &touched, MfmaChunk &ck, const int lane, const int wv) {
+                                              const u32 lds_cb, const MfmaRow *s_row, u32 *s_touch, uint4 *s_buf, u32 *s_wcnt, const int first, MfmaChunk &ck, const int lane,
+                                              const int wv) {
     constexpr int D = NJ * 32, M = D / DSUB;
     constexpr int NB = (NJ * 8 >= DSUB) ? NJ * 8 / DSUB : 1;  // code bytes per lane
     const int n = lane & 15, g = lane >> 4;
@@ -244,55 +266,70 @@ __device__ __forceinline__ void mf_scan_tiles(const MfmaParams &P, const mf_h8 (
 #pragma unroll
                     for (int i = 0; i < 4; i++) any[h] |= __builtin_amdgcn_ballot_w64(acc[h][rt][i] >= thr[rt][i]);
 #if MF_TIMING == 1
-            if ((any[0] | any[1]) == 0x123456789ull) touched |= 1;
+            if ((any[0] | any[1]) == 0x123456789ull) s_touch[0] = 1;
             any[0] = any[1] = 0;
 #endif
             if (any[0] | any[1]) {
-                // ---- survivors: records into the wave's chunk, upper bounds into the queries' histograms ----
+                // ---- survivors (about one per tile where far probes feed the queue).  Kept SMALL: an unrolled branch per accumulator
+                // register made this path ~400 instructions per tile (1250 cycles per survivor measured).  Each lane packs its
+                // compares into a bit mask (two instructions per register), and only the lanes that hold a survivor walk their
+                // bits: the accumulator by a select tree, the record into the wave's LDS buffer (slot from an LDS counter). ----
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     if (!any[h]) continue;  // (scalar branch)
                     const long long pos = c0 + (long long)(tt + 4 * h) * 16 + n;
-                    const u64 vm = __builtin_amdgcn_ballot_w64(pos < c1);  // (only an item's last tile has lanes past the end)
-                    u64 mk[NTL * 4];
-                    u32 tot = 0;
+                    u32 bits = 0;  // bit rt * 4 + i: the lane's code survives row rt * 16 + 4 g + i
 #pragma unroll
-                    for (int rt = 0; rt < NTL; rt++)
+                    for (int b = NTL * 4 - 1; b >= 0; b--)
+                        asm volatile("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(acc[h][b >> 2][b & 3]), "v"(thr[b >> 2][b & 3]) : "vcc");
+                    if (pos >= c1) bits = 0;  // (only an item's last tile has lanes past the end)
+                    while (bits) {  // (divergent: the few lanes with a survivor, one pass per survivor of the lane)
+                        const int b = __ffs((int)bits) - 1;
+                        bits &= bits - 1u;
+                        // (bit selects -- v_bfi_b32 -- on purpose: written as ?: the compiler turns the tree into an indexed scratch array)
+                        const u32 m0 = 0u - ((u32)b & 1u), m1 = 0u - (((u32)b >> 1) & 1u), m2 = 0u - (((u32)b >> 2) & 1u), m3 = 0u - (((u32)b >> 3) & 1u);
+                        u32 v8[8], v4[4], v2[2];
 #pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            mk[rt * 4 + i] = __builtin_amdgcn_ballot_w64(acc[h][rt][i] >= thr[rt][i]) & vm;
-                            tot += (u32)__popcll(mk[rt * 4 + i]);
+                        for (int j = 0; j < 8; j++) {
+                            const u32 lo = 2 * j < NTL * 4 ? (u32)__float_as_int(acc[h][(2 * j) >> 2][(2 * j) & 3]) : 0u,
+                                      hi = 2 * j + 1 < NTL * 4 ? (u32)__float_as_int(acc[h][(2 * j + 1) >> 2][(2 * j + 1) & 3]) : 0u;
+                            v8[j] = (hi & m0) | (lo & ~m0);
                         }
-                    if (!tot) continue;
-                    mf_chunk_room(P, ck, tot, lane);
-                    u32 run = ck.base + ck.used;
-                    ck.used += tot;
 #pragma unroll
-                    for (int rt = 0; rt < NTL; rt++)
+                        for (int j = 0; j < 4; j++) v4[j] = (v8[2 * j + 1] & m1) | (v8[2 * j] & ~m1);
 #pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            const u64 m = mk[rt * 4 + i];
-                            if (m) {  // (scalar branch)
-                                // rows of this register: rt * 16 + 4 g + i, g = the lane's 16-lane row
-                                touched |= ((m & 0xFFFFull) ? 1ull << (rt * 16 + i) : 0ull) | ((m & 0xFFFF0000ull) ? 1ull << (rt * 16 + 4 + i) : 0ull) |
-                                           ((m & 0xFFFF00000000ull) ? 1ull << (rt * 16 + 8 + i) : 0ull) | ((m >> 48) ? 1ull << (rt * 16 + 12 + i) : 0ull);
-                                if ((m >> lane) & 1ull) {
-                                    const MfmaRow rw = s_row[rt * 16 + 4 * g + i];
-                                    const u32 off = run + mf_mbcnt(m);
-                                    // d~ = ||r||^2 - 2 acc / s^2 and |d - d~| <= err: lower bound cd + kd acc (kept with the record: the
-                                    // verification drops what the query's FINAL threshold has left behind), upper bound -> bucket
-                                    const float a = acc[h][rt][i];
-                                    const float lbf = fmaf(a, kd, rw.cd);
-                                    if (off < P.surv_cap) P.surv[off] = make_uint4((u32)rw.slot, (u32)pos, (u32)__float_as_int(lbf), 0u);
-                                    else P.redo[rw.q] = 1;
-                                    const float xb = fmaf(a, rw.kq, rw.cq);
-                                    if (rw.kq != 0.f && xb < 255.f) atomicAdd(P.ghist + (size_t)rw.q * 256 + (xb > 0.f ? (int)xb : 0), 1u);
-                                }
-                                run += (u32)__popcll(m);
-                            }
-                        }
+                        for (int j = 0; j < 2; j++) v2[j] = (v4[2 * j + 1] & m2) | (v4[2 * j] & ~m2);
+                        const float a = __int_as_float((int)((v2[1] & m3) | (v2[0] & ~m3)));
+                        const int qs = (b >> 2) * 16 + 4 * g + (b & 3);  // (a live row: rows past the group's pairs never survive)
+                        const MfmaRow rw = s_row[qs];
+                        // d~ = ||r||^2 - 2 acc / s^2 and |d - d~| <= err: lower bound cd + kd acc (kept with the record: the
+                        // verification drops what the query's FINAL threshold has left behind), upper bound -> bucket
+                        const float lbf = fmaf(a, kd, rw.cd);
+                        const float xb = fmaf(a, rw.kq, rw.cq);
+                        const u32 bk = (rw.kq != 0.f && xb < 255.f) ? (xb > 0.f ? (u32)(int)xb : 0u) : 0xFFFFFFFFu;
+                        const u32 o = atomicAdd(s_wcnt, 1u);
+                        if (o < MF_BUF) s_buf[o] = make_uint4((u32)(first + qs), (u32)pos, (u32)__float_as_int(lbf), bk);
+                        else P.redo[rw.q] = 1;  // (more than half a buffer from one step: a threshold far above what the lists hold -- K3f's case)
+                    }
+                }
+                // the wave's staged records: out in one burst when the buffer is half full
+                u32 nb = *(volatile u32 *)s_wcnt;
+                nb = (u32)__builtin_amdgcn_readfirstlane((int)nb);
+                if (nb >= MF_BUF / 2) {
+                    nb = nb < MF_BUF ? nb : MF_BUF;
+                    mf_flush(P, ck, s_buf, nb, s_row, s_touch, first, lane);
+                    if (lane == 0) *s_wcnt = 0;
                 }
             }
+        }
+    }
+    {   // what is left in the buffer at the end of the item
+        u32 nb = *(volatile u32 *)s_wcnt;
+        nb = (u32)__builtin_amdgcn_readfirstlane((int)nb);
+        nb = nb < MF_BUF ? nb : MF_BUF;
+        if (nb) {
+            mf_flush(P, ck, s_buf, nb, s_row, s_touch, first, lane);
+            if (lane == 0) *s_wcnt = 0;
         }
     }
 }
@@ -312,9 +349,10 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 lds_cb = (u32)(size_t)(__attribute__((address_space(3))) unsigned char *)(smem + L.cb);
 
+    const int nv = *P.n_groups * P.nsub;
+    if (nv == 0) return;  // (the separable benchmark: the coarse bound left pass B nothing)
     // the fp16 codebook: once per block
     for (int i = tid; i < D * 32; i += MF_NT) ((uint4 *)(smem + L.cb))[i] = ((const uint4 *)P.pq16)[i];
-    const int nv = *P.n_groups * P.nsub;
     const int per = (nv + 7) >> 3;
     const int xcd = blockIdx.x & 7;
     const double xmax = P.xmax;
@@ -326,6 +364,7 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
             s_misc[0] = atomicAdd(P.work + xcd, 1u);
             s_misc[1] = 0;
             s_misc[2] = 0;
+            s_misc[8] = s_misc[9] = s_misc[10] = s_misc[11] = 0;
         }
         __syncthreads();
         const int it = (int)s_misc[0];
@@ -465,7 +504,7 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
                     if (!(rw.kq != 0.f) || !(rw.cq < 3e38f)) rw.kq = 0.f;
                 }
                 rw.q = q;
-                rw.slot = first + (row < np ? row : np - 1);
+                rw.slot = first + row;
                 rw.pad = 0;
                 s_row[row] = rw;
             }
@@ -508,16 +547,13 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
             for (int i = 0; i < 4; i++) thr[rt][i] = s_row[rt * 16 + 4 * (lane >> 4) + i].thr;
 
         // ---- (b) the scan: every wave its own code tiles against all row tiles ----
-        u64 touched = 0;  // (wave-uniform) rows of the item that had a survivor in this wave
+        uint4 *s_buf = (uint4 *)(s_stage + (size_t)wv * (MF_BUF * 16));  // (the staging area is idle until the next item)
+        u32 *s_wcnt = s_misc + 8 + wv;
         switch (ntl) {
-            case 1: mf_scan_tiles<NJ, DSUB, 1>(P, A, thr, codes, xn, c0, c1, kinit, kd, lds_cb, s_row, touched, ck, lane, wv); break;
-            case 2: mf_scan_tiles<NJ, DSUB, 2>(P, A, thr, codes, xn, c0, c1, kinit, kd, lds_cb, s_row, touched, ck, lane, wv); break;
-            case 3: mf_scan_tiles<NJ, DSUB, 3>(P, A, thr, codes, xn, c0, c1, kinit, kd, lds_cb, s_row, touched, ck, lane, wv); break;
-            default: mf_scan_tiles<NJ, DSUB, 4>(P, A, thr, codes, xn, c0, c1, kinit, kd, lds_cb, s_row, touched, ck, lane, wv); break;
-        }
-        if (touched && lane == 0) {
-            if ((u32)touched) atomicOr(s_misc + 1, (u32)touched);
-            if ((u32)(touched >> 32)) atomicOr(s_misc + 2, (u32)(touched >> 32));
+            case 1: mf_scan_tiles<NJ, DSUB, 1>(P, A, thr, codes, xn, c0, c1, kinit, kd, lds_cb, s_row, s_misc + 1, s_buf, s_wcnt, first, ck, lane, wv); break;
+            case 2: mf_scan_tiles<NJ, DSUB, 2>(P, A, thr, codes, xn, c0, c1, kinit, kd, lds_cb, s_row, s_misc + 1, s_buf, s_wcnt, first, ck, lane, wv); break;
+            case 3: mf_scan_tiles<NJ, DSUB, 3>(P, A, thr, codes, xn, c0, c1, kinit, kd, lds_cb, s_row, s_misc + 1, s_buf, s_wcnt, first, ck, lane, wv); break;
+            default: mf_scan_tiles<NJ, DSUB, 4>(P, A, thr, codes, xn, c0, c1, kinit, kd, lds_cb, s_row, s_misc + 1, s_buf, s_wcnt, first, ck, lane, wv); break;
         }
         __syncthreads();
         // ---- (c) thresholds from the union of the survivors' upper bounds: K1 of them at or below a bucket's upper edge make
