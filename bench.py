@@ -830,6 +830,33 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
             traffic_pb = tj.get(f"{what}_pass_b_fetch_bytes_per_launch")
         except Exception:  # noqa: BLE001
             pass
+        # pass B's dominant kernel.  K3m (k_scan_mfma): a GEMM-shaped certified lower bound on the matrix cores -- priced against the
+        # dense fp16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF); algorithmic flops = 2 D per (query, probed far code) pair.  Its launch
+        # duration comes from HIP events around the kernel in the profiled steps (mmidx_stats::mfma_scan_ms).  The physical HBM
+        # figure next to it is a separate PMC pass (profiles/hbm_traffic.json): a list is read from HBM about once per batch.
+        pairs_pb = float(hst.scan_codes - hst.passa_codes) / hd
+        if hst.mfma_launches > 0 and hst.mfma_scan_ms > 0:
+            mf_ms = hst.mfma_scan_ms / hst.mfma_launches
+            vf_ms = hst.mfma_verify_ms / hst.mfma_launches
+            flops = 2.0 * D * pairs_pb
+            tf = flops / (mf_ms * 1e-3) / 1e12
+            pb_roofline = {"bound": "mfma", "kernel": "k_scan_mfma (pass B: fp16 MFMA lower bound of every (query, far code) pair, list-major, "
+                                                      "one decode of a code per 64 queries; survivors verified in fp64 by k_mfma_verify)",
+                           "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+                           "flops_per_launch": flops, "avg_launch_ms": round(mf_ms, 4), "verify_launch_ms": round(vf_ms, 4),
+                           "pass_b_ms_incl_pair_sort_verify_redo": round(pb_ms, 4),
+                           "algorithmic_bytes_per_launch": pb_bytes, "algorithmic_GBps": round(pb_bytes / (mf_ms * 1e-3) / 1e9, 1),
+                           "traffic": traffic_pb,
+                           "hbm_frac_physical": round(traffic_pb / (mf_ms * 1e-3) / 8e12, 4) if traffic_pb else None,
+                           "traffic_source": "profiles/hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE pass of this workload, x 2 on gfx950)" if traffic_pb else None,
+                           "note": "peak = dense fp16/bf16 MFMA (MI355X_MICROARCH.md); besides the matrix work a tile of 16 codes costs four random 16-byte "
+                                   "LDS gathers (the decode) and ~50 vector instructions per wave (compares, addresses), which co-limit the kernel "
+                                   "(DESIGN.md 5.16)"}
+        else:
+            pb_roofline = {"bound": "issue", "kernel": "k_scan_grp (pass B: grouped u8 lower-bound filter; vector-instruction issue and LDS bound, DESIGN.md 5.12)",
+                           "achieved": round(pb_ach, 1), "peak": None, "unit": "GB/s of algorithmic bytes", "frac": None,
+                           "algorithmic_bytes_per_launch": pb_bytes, "avg_launch_ms": round(pb_ms, 4), "traffic": traffic_pb,
+                           "hbm_frac_physical": round(traffic_pb / (pb_ms * 1e-3) / 8e12, 4) if traffic_pb else None}
         res = {"value": round(B * steps_ / h_el, 1), "unit": "queries/s", "steps": steps_,
                "ms_per_step": round(h_el / steps_ * 1e3, 4), "batch": B,
                "survivors_per_query": round(int(hst.passb_items_last) / B, 3), "far_probes_per_query": w - 1,
@@ -838,14 +865,7 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
                "recall_at_1": h_recall, "true_neighbour_in_top_k": h_recall_k, "recall_queries": ngh,
                "stage_ms_per_step": {"coarse": round(hst.coarse_ms / hd, 4), "pass_a": round(hst.passa_ms / hd, 4), "pass_b": round(pb_ms, 4),
                                      "merge": round(hst.merge_ms / hd, 4)},
-               "roofline": {"bound": "hbm", "kernel": "k_scan_grp (pass B: grouped lower-bound-filtered scan of the w - 1 far probes, incl. "
-                                                      "pair sort and hand-back launch)",
-                            "achieved": round(pb_ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(pb_ach / 8000.0, 4),
-                            "algorithmic_bytes_per_launch": pb_bytes, "avg_launch_ms": round(pb_ms, 4), "traffic": traffic_pb,
-                            "traffic_source": "profiles/hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE pass of this workload, x 2 on gfx950)" if traffic_pb else None,
-                            "note": "algorithmic bytes = m x the codes of every probed far list; a batch probes every list ~64 times and "
-                                    "the list-major kernel reads it from HBM about once (the rest comes from L2), so this fraction can "
-                                    "exceed 1: the kernel is bound by LDS table lookups and instruction issue, not by HBM (DESIGN.md 5.12)"},
+               "roofline": pb_roofline,
                "parity": h_parity, "cpu_baseline": h_cpu}
         chk(L.mmidx_destroy(hh))
         del Qh_all, Qhb

@@ -311,6 +311,11 @@ typedef struct mmidx_stats {
      * full survivor list or pool) */
     int64_t mfma_survivors;
     int64_t mfma_redo_queries;
+    /* ... and, with full profiling, the launch durations of its scan kernel (k_scan_mfma) and of the exact verification
+     * (k_mfma_verify) from HIP events around them, summed over mfma_launches calls */
+    double mfma_scan_ms, mfma_verify_ms;
+    int32_t mfma_launches;
+    int32_t reserved0;
 } mmidx_stats;
 /* enabled: 0 off; 1 full (six events per search call and the code counters: every field below); 2 light (only the two
  * events around pass A: passa_ms / passa_launches -- an event record is a ~5 us bubble in the stream, so a throughput

@@ -38,7 +38,8 @@ class Stats(C.Structure):
                 ("merge_ms", C.c_double), ("scan_codes", C.c_int64), ("scan_launches", C.c_int32),
                 ("tie_fallbacks", C.c_int32), ("passa_ms", C.c_double), ("passa_codes", C.c_int64),
                 ("passa_launches", C.c_int32), ("passb_items_last", C.c_int32), ("verified_codes", C.c_int64),
-                ("mfma_survivors", C.c_int64), ("mfma_redo_queries", C.c_int64)]
+                ("mfma_survivors", C.c_int64), ("mfma_redo_queries", C.c_int64),
+                ("mfma_scan_ms", C.c_double), ("mfma_verify_ms", C.c_double), ("mfma_launches", C.c_int32), ("reserved0", C.c_int32)]
 
 
 def build(force=False):

@@ -308,6 +308,8 @@ struct mmidx_index {
     mmidx_stats stats{};
     std::vector<hipEvent_t> evpool;  // groups of 6: start, coarse end, scan start, scan end, end, pass A end
     size_t ev_used = 0;
+    std::vector<hipEvent_t> mf_ev;   // K3m, full profiling: groups of 3 (scan start, scan end, verification end)
+    size_t mf_ev_used = 0;
     u64 *d_counters = nullptr;       // [0] scan codes, [1] tie fallbacks, [2] codes of the probe-rank-0 lists (pass A), [3] verified codes (K3g); [4] add-validation flag
     int64_t host_codes = 0;          // PQ: nq * n, known on the host
     int32_t launches = 0;
@@ -1223,14 +1225,27 @@ int launch_mfma_common(mmidx_index *h, const ScanParams &S, ScanParams F, const 
     MP.nver = (unsigned long long *)(h->d_counters + 7);
     const MfmaLds L(h->D);
     int rc;
+    hipEvent_t *mev = nullptr;
+    if (h->profiling == 1 && h->mf_ev_used + 3 <= 3 * 4096) {
+        while (h->mf_ev.size() < h->mf_ev_used + 3) {
+            hipEvent_t e;
+            HIPCK(hipEventCreate(&e));
+            h->mf_ev.push_back(e);
+        }
+        mev = h->mf_ev.data() + h->mf_ev_used;
+        h->mf_ev_used += 3;
+        HIPCK(hipEventRecord(mev[0], st));
+    }
     const int nj = h->D / 32;
     if (h->dsub == 8) rc = nj == 4 ? launch_mfma_scan_t<4, 8>(h, MP, L.total, st) : nj == 2 ? launch_mfma_scan_t<2, 8>(h, MP, L.total, st) : launch_mfma_scan_t<1, 8>(h, MP, L.total, st);
     else rc = nj == 4 ? launch_mfma_scan_t<4, 16>(h, MP, L.total, st) : nj == 2 ? launch_mfma_scan_t<2, 16>(h, MP, L.total, st) : launch_mfma_scan_t<1, 16>(h, MP, L.total, st);
     if (rc) return rc;
+    if (mev) HIPCK(hipEventRecord(mev[1], st));
     DBG_SYNC("K3m scan");
     if (h->dsub == 8) rc = h->m == 16 ? launch_mfma_verify_t<16, 8>(h, MP, st) : h->m == 8 ? launch_mfma_verify_t<8, 8>(h, MP, st) : launch_mfma_verify_t<4, 8>(h, MP, st);
     else rc = h->m == 8 ? launch_mfma_verify_t<8, 16>(h, MP, st) : h->m == 4 ? launch_mfma_verify_t<4, 16>(h, MP, st) : launch_mfma_verify_t<2, 16>(h, MP, st);
     if (rc) return rc;
+    if (mev) HIPCK(hipEventRecord(mev[2], st));
     if (MP.stat) hipLaunchKernelGGL(k_mfma_count, dim3(1024), dim3(256), 0, st, MP);  // (profiling runs only)
     DBG_SYNC("K3m verify");
     const long long span = std::max<long long>(npairs, nq);
@@ -2156,6 +2171,8 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_Qp.release();
     for (auto &ev : h->evpool)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : h->mf_ev)
+        if (ev) (void)hipEventDestroy(ev);
     if (h->d_counters) (void)hipFree(h->d_counters);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -2946,6 +2963,7 @@ int mmidx_set_profiling(mmidx_index *h, int enabled) {
     h->profiling = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
     h->stats = mmidx_stats{};
     h->ev_used = 0;
+    h->mf_ev_used = 0;
     h->host_codes = 0;
     h->launches = 0;
     h->passa_launches = 0;
@@ -2992,6 +3010,16 @@ int mmidx_get_stats(mmidx_index *h, mmidx_stats *out) {
     s.passa_codes = (int64_t)cnt[2] + h->host_passa_codes;
     s.passa_launches = h->passa_launches;
     s.verified_codes = (int64_t)cnt[3];
+    for (size_t g = 0; g + 3 <= h->mf_ev_used; g += 3) {
+        float a = 0.f, b = 0.f;
+        HIPCK(hipEventSynchronize(h->mf_ev[g + 2]));
+        HIPCK(hipEventElapsedTime(&a, h->mf_ev[g], h->mf_ev[g + 1]));
+        HIPCK(hipEventElapsedTime(&b, h->mf_ev[g + 1], h->mf_ev[g + 2]));
+        s.mfma_scan_ms += a;
+        s.mfma_verify_ms += b;
+        s.mfma_launches += 1;
+    }
+    h->mf_ev_used = 0;
     {
         u64 c2[2] = {0, 0};
         HIPCK(hipMemcpy(c2, h->d_counters + 12, sizeof(c2), hipMemcpyDeviceToHost));

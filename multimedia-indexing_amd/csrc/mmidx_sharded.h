@@ -989,6 +989,9 @@ int sharded_get_stats(mmidx_index *h, mmidx_stats *out) {
         acc.verified_codes += s.verified_codes;
         acc.mfma_survivors += s.mfma_survivors;
         acc.mfma_redo_queries += s.mfma_redo_queries;
+        acc.mfma_scan_ms += s.mfma_scan_ms;
+        acc.mfma_verify_ms += s.mfma_verify_ms;
+        acc.mfma_launches += s.mfma_launches;
         acc.scan_launches = std::max(acc.scan_launches, s.scan_launches);
         acc.passa_launches = std::max(acc.passa_launches, s.passa_launches);
         acc.tie_fallbacks += s.tie_fallbacks;

@@ -165,8 +165,15 @@ def run(n=95_213_780, D=1024, m=64, ks=256, Cc=8192, k=30, ws=(2, 64), batch=409
         except (OSError, ValueError):
             pass
 
+    # a second query set that defeats the pair pre-filter K3s: midpoints of two indexed vectors -- a query BETWEEN clusters sees its
+    # probed cells at similar distances, far pairs stay alive after their Smin bound and pass B really scans far lists with the
+    # m = 64 instance of K3g (the reference offers every probed code, IVFPQ.java:429-446; Example.java:96-97 probes 64 lists)
+    Qmid = 0.5 * (Qsrc + Qsrc.roll(1, 0))
+    Qmb = [Qmid[i * batch:(i + 1) * batch].contiguous() for i in range(2)]
+    legs = [(w, Qb, f"w{w}", True) for w in ws] + [(max(ws), Qmb, f"w{max(ws)}_between_clusters", False)]
     st = nat.Stats()
-    for w in ws:
+    for w, Qb, tag, self_queries in legs:
+        Qh = Qb[0].cpu().numpy()
         chk(L.mmidx_set_w(h, w))
         step = lambda Qx: chk(L.mmidx_search_device(h, k, batch, Qx.data_ptr(), iid.data_ptr(), dd.data_ptr(), cc.data_ptr(), None))
         for i in range(2):
@@ -187,7 +194,7 @@ def run(n=95_213_780, D=1024, m=64, ks=256, Cc=8192, k=30, ws=(2, 64), batch=409
         step(Qb[0])
         torch.cuda.synchronize()
         g_iid, g_dd = iid.cpu().numpy().copy(), dd.cpu().numpy().copy()
-        recall = float(np.mean(g_iid[:, 0] == qsrc[:batch].cpu().numpy()))
+        recall = float(np.mean(g_iid[:, 0] == qsrc[:batch].cpu().numpy())) if self_queries else None
         # one query per call with host buffers: the reference's own call shape
         one_i, one_d, one_c = np.empty((1, k), np.int32), np.empty((1, k)), np.empty(1, np.int32)
         for i in range(3):
@@ -206,6 +213,22 @@ def run(n=95_213_780, D=1024, m=64, ks=256, Cc=8192, k=30, ws=(2, 64), batch=409
              "algorithmic_GBps": round(codes_q * m * batch * steps / el / 1e9, 1),
              "far_pairs_scanned_per_query": round(int(st.passb_items_last) / batch, 3),
              "verified_codes_per_query": round(st.verified_codes / nd / batch, 2)}
+        # pass A's kernel (k_scan_hist<64, 256, 1024>: the exact fp64 scan of every query's nearest list, one 1024-thread block per CU
+        # over a 128 KiB table): algorithmic bytes = m x the codes of the nearest lists / its launch time (HIP events of the profiled steps)
+        pa_ms = st.passa_ms / max(1, st.passa_launches)
+        pa_bytes = float(m) * st.passa_codes / max(1, st.passa_launches)
+        if pa_ms > 0:
+            gbps = pa_bytes / (pa_ms * 1e-3) / 1e9
+            r["roofline"] = {"bound": "hbm", "kernel": "k_scan_hist<64, 256, 1024> (pass A)", "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s",
+                             "frac": round(gbps / 8000.0, 4), "algorithmic_bytes_per_launch": pa_bytes, "avg_launch_ms": round(pa_ms, 4), "traffic": None,
+                             "note": "bound by the LDS gather of the exact fp64 table (64 random 8-byte reads per code) and by the exposed table build "
+                                     "(2 MiB of codebook per query from L2, one block per CU), not by HBM: DESIGN.md 5.13"}
+        pb_ms_ = (st.scan_ms - st.passa_ms) / nd
+        if int(st.passb_items_last) > 0 and pb_ms_ > 0:
+            far_codes = (st.scan_codes - st.passa_codes) / nd  # codes of every probed far list (scanned or not)
+            r["pass_b"] = {"kernel": "k_pair_smin_* (K3s) + k_scan_grp<64, 4, 16> (K3g) + hand-back", "ms": round(pb_ms_, 3),
+                           "far_pairs_scanned_per_query": round(int(st.passb_items_last) / batch, 3),
+                           "algorithmic_GBps_over_all_far_probes": round(far_codes * m / (pb_ms_ * 1e-3) / 1e9, 1)}
         if ref is not None:
             ref.set_w(w)
             nsq = min(batch, parity_queries)
@@ -217,8 +240,8 @@ def run(n=95_213_780, D=1024, m=64, ks=256, Cc=8192, k=30, ws=(2, 64), batch=409
                            "max_abs_ddist": float(np.max(np.abs(g_dd[:nsq][fin] - rd[fin]), initial=0.0))}
             r["cpu_port"] = {"queries_per_s": round(nsq / ct, 2), "threads": cpu_threads,
                              "one_query_ms_per_thread": round(ct / nsq * cpu_threads * 1e3, 1)}
-        out[f"w{w}"] = r
-        log(f"w = {w}: {r}")
+        out[tag] = r
+        log(f"{tag}: {r}")
     chk(L.mmidx_destroy(h))
     return out
 
