@@ -421,6 +421,8 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
                     help="mmidx_set_option(NAME, INT) on the index before the timed steps (kernel A/B switches)")
     ap.add_argument("--dump", default="", metavar="PREFIX", help="write batch 0's answers of every rank to PREFIX.rank<r>.npz")
+    ap.add_argument("--sharded-self-test", action="store_true",
+                    help="(internal) build a small index on the sharded handle over --gpus devices and on a plain handle, compare the answers, exit 0 / 1")
     ap.add_argument("--native-sharded", action="store_true",
                     help="drive the library's own sharded handle (mmidx_create_sharded: worker threads + RCCL inside libmmidx_hip.so) "
                          "from this one process; the default for --gpus > 1, with --gpus 1 it measures one shard on a 1-rank communicator")
@@ -430,6 +432,14 @@ def main():
                     help="run the multi-GPU code path (encode -> owner filter -> add_codes, two-phase shard search, "
                          "merge) even with one rank: exercises it on a single GPU")
     args = ap.parse_args()
+    if args.sharded_self_test:
+        try:
+            import torch
+
+            torch.cuda.init()
+        except Exception:  # noqa: BLE001
+            pass
+        raise SystemExit(sharded_self_test(args.gpus))
 
     # stdout carries exactly one JSON line: everything else that writes to fd 1 (RCCL prints its
     # version banner there) is routed to stderr
@@ -481,10 +491,18 @@ def main():
             dist.init_process_group("cpu:gloo,cuda:nccl")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    virtual = os.environ.get("MMIDX_BENCH_VIRTUAL_SHARDS") == "1"
+    if native and world == 1 and ndev > 1 and not virtual:
+        why = run_sharded_self_test(ndev)
+        if why:
+            raise SystemExit(f"{why}; run under torch.distributed.run for the one-process-per-GPU path")
     if native and world > 1:
         verdict = torch.zeros(1, dtype=torch.int32)
         if rank == 0:
             try:
+                why = None if virtual else run_sharded_self_test(ndev)
+                if why:
+                    raise RuntimeError(why)
                 run(cx, args, json_out, native=True, ndev=ndev, dist=None, rank=0, world=1, local=0)
                 verdict[0] = 1
             except BaseException as e:  # noqa: BLE001 -- whatever went wrong, the other ranks must hear about it
@@ -496,6 +514,53 @@ def main():
             return
         native = False
     run(cx, args, json_out, native=native, ndev=ndev, dist=dist, rank=rank, world=world, local=local, fallback_reason=fallback_reason)
+
+
+def sharded_self_test(ndev):
+    """The first thing a multi-GPU run does (in a subprocess, under a timeout, so that a hang in a collective ends as a reported
+    fallback reason): one small IVFPQ index on the sharded handle over `ndev` physical devices and on a plain handle, the same
+    queries through both -- ids, distance bits and counts must be identical (ties included: every vector is indexed twice)."""
+    import numpy as np
+
+    mi = importlib.import_module("multimedia-indexing_amd")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import synth
+
+    D, C_, m, ks, w, k = 32, 64, 8, 256, 9, 20
+    p = synth.make_ivfpq_problem(n=6000, D=D, C=C_, m=m, ks=ks, nq=96, seed=7, iters=3)
+    base = np.concatenate([p["base"], p["base"][:3000]])
+    out = []
+    for devs in (None, list(range(ndev))):
+        ix = mi.IVFPQ(D, len(base), False, "", m, ks, 0, C_, 512, **({} if devs is None else {"devices": devs}))
+        ix.loadCoarseQuantizer(p["coarse"])
+        ix.loadProductQuantizer(p["pq"])
+        ix.setW(w)
+        ix.indexVectors([str(i) for i in range(len(base))], base)
+        if devs is not None:
+            ix.set_option("tie_slots", 4)
+        out.append([ix.search_batch(k, p["queries"]), ix.search_batch(1, p["queries"][:1])])
+        ix.close()
+    for a, b in zip(out[0], out[1]):
+        for x, y in zip(a, b):
+            if not np.array_equal(x, y):
+                print("sharded self-test: answers differ from the plain handle's", file=sys.stderr)
+                return 1
+    print(f"sharded self-test over {ndev} devices: identical to the plain handle", file=sys.stderr)
+    return 0
+
+
+def run_sharded_self_test(ndev, timeout_s=240):
+    """None when the sharded handle over ndev devices passes its self-test, else the reason (a string)"""
+    import subprocess
+
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--sharded-self-test", "--gpus", str(ndev)], timeout=timeout_s,
+                           capture_output=True, text=True)
+    except subprocess.TimeoutExpired:
+        return f"sharded self-test over {ndev} devices did not finish in {timeout_s}s (a collective hung?)"
+    if r.returncode != 0:
+        return f"sharded self-test over {ndev} devices failed (rc {r.returncode}): {(r.stderr or '').strip()[-300:]}"
+    return None
 
 
 def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_reason=None):

@@ -334,6 +334,7 @@ int sharded_get_stats(mmidx_index *h, mmidx_stats *out);
 int sharded_set_option(mmidx_index *h, const char *name, int value);
 int sharded_for_each(mmidx_index *h, const std::function<int(mmidx_index *)> &f);
 int64_t sharded_total(const mmidx_index *h);
+constexpr int32_t MMIDX_IID_AUTO = INT32_MIN;  // sharded_add_vectors: number the vectors from the handle's total, read under its lock
 void sharded_destroy(mmidx_index *h);
 #define NOT_ON_SHARDED(h, name)                                                                                              \
     do {                                                                                                                     \
@@ -2491,7 +2492,7 @@ int mmidx_add_vectors_device(mmidx_index *h, int64_t n, const double *dX, const 
 int mmidx_add_vectors(mmidx_index *h, int64_t n, const double *X, const int32_t *iids, int32_t *cell_out, void *code_out) {
     if (h && h->grp) {
         if (n < 0 || (n > 0 && !X)) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
-        return sharded_add_vectors(h, n, X, nullptr, nullptr, iids, (int32_t)sharded_total(h), cell_out, code_out);
+        return sharded_add_vectors(h, n, X, nullptr, nullptr, iids, MMIDX_IID_AUTO, cell_out, code_out);
     }
     int rc = check_ready(h);
     if (rc) return rc;

@@ -38,6 +38,7 @@ struct RcclApi {
     void *so = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -72,6 +73,7 @@ RcclApi *rccl_api() {
         };
         api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
         api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+        api.CommAbort = (decltype(api.CommAbort))sym("ncclCommAbort");
         api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
         api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
         api.Send = (decltype(api.Send))sym("ncclSend");
@@ -115,6 +117,13 @@ __global__ void k_reduce_peers(const PeerPtrs src, int n_src, T *__restrict__ ou
         if (OP == 2) acc = v > acc ? v : acc;
     }
     out[i] = acc;
+}
+
+// rows [from, to) of X := row 0 (the padding of a round's last slices)
+__global__ void k_repeat_row(double *__restrict__ X, int D, long long from, long long to) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (to - from) * D) return;
+    X[from * D + i] = X[i % D];
 }
 
 __global__ void k_fill_i32(int32_t *__restrict__ p, int32_t v, long long n) {
@@ -259,7 +268,8 @@ struct ShardGroup {
     // what the shards publish to each other between barriers (in-process collectives, peer tables)
     std::vector<void *> pub;
     std::vector<int32_t> nflag_host;
-    int64_t tie_rounds = 0, tie_queries = 0;  // statistics: replay rounds run, flagged queries seen
+    std::atomic<int64_t> tie_rounds{0}, tie_queries{0};  // statistics: replay rounds run, flagged queries seen
+    bool broken = false;     // a worker failed while RCCL collectives may have been in flight: the communicators were aborted
     // worker threads
     std::vector<std::thread> th;
     std::mutex mu;
@@ -341,6 +351,27 @@ int shard_run(ShardGroup *g, std::function<int(int)> f) {
     return first;
 }
 
+// A worker that fails between two collectives leaves its peers' streams inside an RCCL kernel that waits for it: no host barrier
+// can release those.  The failing call aborts the communicators (which ends the kernels) and the handle refuses further
+// collective calls; mmidx_destroy still works.
+void shard_poison(ShardGroup *g) {
+    if (!g->rccl || g->broken) return;
+    RcclApi *R = rccl_api();
+    g->broken = true;
+    if (!R || !R->CommAbort) return;
+    for (size_t r = 0; r < g->comm.size(); r++) {
+        if (!g->comm[r]) continue;
+        (void)hipSetDevice(g->dev[r]);
+        (void)R->CommAbort(g->comm[r]);
+        g->comm[r] = nullptr;
+    }
+}
+#define SHARD_ALIVE(g)                                                                                                       \
+    do {                                                                                                                     \
+        if ((g)->broken)                                                                                                     \
+            return fail(MMIDX_ERR_HIP, "this sharded handle's communicators were aborted after a failed collective round: destroy it"); \
+    } while (0)
+
 #define BARRIER(g)                                                                          \
     do {                                                                                    \
         if (!(g)->bar.wait()) return fail(MMIDX_ERR_HIP, "shard barrier aborted: another shard failed"); \
@@ -353,6 +384,7 @@ int coll_allgather(ShardGroup *g, int r, void *buf, size_t bytes) {
     hipStream_t st = g->st[(size_t)r];
     if (g->rccl) {
         RcclApi *R = rccl_api();
+        BARRIER(g);  // (a worker that failed on the way never enqueues: its peers must not either, or their streams hang in the collective)
         NCCLCK(R->AllGather((const char *)buf + (size_t)r * bytes, buf, bytes, ncclInt8, g->comm[(size_t)r], st));
         return MMIDX_OK;
     }
@@ -375,6 +407,7 @@ int coll_allreduce(ShardGroup *g, int r, void *buf, long long n, int op) {
     hipStream_t st = g->st[(size_t)r];
     if (g->rccl) {
         RcclApi *R = rccl_api();
+        BARRIER(g);
         if (op == 0) NCCLCK(R->AllReduce(buf, buf, (size_t)n, ncclFloat64, ncclMin, g->comm[(size_t)r], st));
         else NCCLCK(R->AllReduce(buf, buf, (size_t)n, ncclInt32, op == 1 ? ncclSum : ncclMax, g->comm[(size_t)r], st));
         return MMIDX_OK;
@@ -398,15 +431,32 @@ int coll_allreduce(ShardGroup *g, int r, void *buf, long long n, int op) {
     return MMIDX_OK;
 }
 
-// largest number of queries one collective round may carry (the shard phases take one sub-batch per call)
+// largest number of queries one collective round may carry (the shard phases take one sub-batch per call).  Computed on the
+// workers: a shard's plan depends on its CSR (longest list, pool size), which is rebuilt there -- device current -- when records
+// were added since the last search; the caller's thread has neither the device nor an up-to-date CSR.
 int shard_round_cap(ShardGroup *g, int k, int64_t *cap_out) {
-    int64_t cap = g->max_round;
-    for (int r = 0; r < g->n; r++) {
+    std::vector<int64_t> qb((size_t)g->n, 0);
+    const int64_t want = g->max_round;
+    int rc = shard_run(g, [&qb, g, k, want](int r) -> int {
+        mmidx_index *s = g->sub[(size_t)r];
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            int rc2 = build_csr(s);
+            if (rc2) return rc2;
+            rc2 = build_grp_tables(s);
+            if (rc2) return rc2;
+            rc2 = build_mfma_tables(s);
+            if (rc2) return rc2;
+        }
         SearchPlan pl;
-        int rc = make_plan(g->sub[(size_t)r], k, cap, pl, false);
-        if (rc) return rc;
-        cap = std::min<int64_t>(cap, pl.qb);
-    }
+        int rc2 = make_plan(s, k, want, pl, false);
+        if (rc2) return rc2;
+        qb[(size_t)r] = pl.qb;
+        return MMIDX_OK;
+    });
+    if (rc) return rc;
+    int64_t cap = want;
+    for (int r = 0; r < g->n; r++) cap = std::min<int64_t>(cap, qb[(size_t)r]);
     cap = std::max<int64_t>(g->n, cap - cap % g->n);
     *cap_out = cap;
     return MMIDX_OK;
@@ -455,8 +505,14 @@ int shard_search_round(ShardGroup *g, int r, int k, int64_t per, const double *Q
         HIPCK(hipMemcpyAsync(Qown, dQ_own, (size_t)per * D * 8, hipMemcpyDeviceToDevice, st));
     } else {
         if (nreal > 0) HIPCK(hipMemcpyAsync(Qown, Qh, (size_t)nreal * D * 8, hipMemcpyHostToDevice, st));
-        for (int64_t i = nreal; i < per; i++)  // (padding rows of the last slices: any valid query)
-            HIPCK(hipMemcpyAsync(Qown + (size_t)i * D, Qh, (size_t)D * 8, hipMemcpyHostToDevice, st));
+        if (nreal < per) {  // padding rows of the last slices: any valid query -- the slice's first row, replicated by one kernel
+            if (nreal == 0) HIPCK(hipMemcpyAsync(Qown, Qh, (size_t)D * 8, hipMemcpyHostToDevice, st));
+            const long long first_pad = std::max<int64_t>(nreal, 1), tot = ((long long)per - first_pad) * D;
+            if (tot > 0) {
+                hipLaunchKernelGGL(k_repeat_row, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Qown, D, first_pad, (long long)per);
+                HIPCK(hipGetLastError());
+            }
+        }
     }
     int rc = coll_allgather(g, r, B.Q.p, (size_t)per * D * 8);
     if (rc) return rc;
@@ -510,6 +566,7 @@ int shard_search_round(ShardGroup *g, int r, int k, int64_t per, const double *Q
         if (g->rccl) {
             RcclApi *R = rccl_api();
             const size_t ne = (size_t)per * K1;
+            BARRIER(g);
             NCCLCK(R->GroupStart());
             for (int o = 0; o < W; o++) {
                 NCCLCK(R->Send(B.pd.p + (size_t)o * ne, ne, ncclFloat64, o, g->comm[(size_t)r], st));
@@ -561,8 +618,8 @@ int shard_search_round(ShardGroup *g, int r, int k, int64_t per, const double *Q
     HIPCK(B.ties.reserve((size_t)F * k));
     const int rounds = (mx + Fo - 1) / Fo;
     if (r == 0) {
-        g->tie_rounds += rounds;
-        for (int o = 0; o < W; o++) g->tie_queries += g->nflag_host[(size_t)o];
+        g->tie_rounds.fetch_add(rounds, std::memory_order_relaxed);
+        for (int o = 0; o < W; o++) g->tie_queries.fetch_add(g->nflag_host[(size_t)o], std::memory_order_relaxed);
     }
     for (int round = 0; round < rounds; round++) {
         hipLaunchKernelGGL(k_tie_slots, dim3(1), dim3(64), 0, st, B.flag.p, d_dist, (int)per, k, (int)(r * per), round, Fo, B.rows_own.p,
@@ -609,6 +666,7 @@ int sharded_search_host(mmidx_index *h, int k, int64_t nq, const double *Q, int3
     ShardGroup *g = h->grp;
     int rc = sharded_check_search(h, k);
     if (rc) return rc;
+    SHARD_ALIVE(g);
     int64_t cap = 0;
     rc = shard_round_cap(g, k, &cap);
     if (rc) return rc;
@@ -633,7 +691,12 @@ int sharded_search_host(mmidx_index *h, int k, int64_t nq, const double *Q, int3
             }
             return MMIDX_OK;
         });
-        if (rc) return rc;
+        if (rc) {
+            const std::string keep = g_err;
+            shard_poison(g);
+            g_err = keep;
+            return rc;
+        }
     }
     return MMIDX_OK;
 }
@@ -747,6 +810,9 @@ int sharded_add_vectors(mmidx_index *h, int64_t n, const double *X, const double
     if (n == 0) return MMIDX_OK;
     std::lock_guard<std::mutex> lk(g->call_mu);
     if (sharded_total(h) + n > 2147483647LL) return fail(MMIDX_ERR_CAPACITY, "Maximum index capacity reached, no more vectors can be indexed!");
+    // (loadCounter: read under the lock that serialises the adds -- two callers that let the library number their vectors must
+    //  not see the same total; the plain handle reads its offset under add_mu likewise)
+    if (iid0 == MMIDX_IID_AUTO) iid0 = (int32_t)sharded_total(h);
     const int W = g->n;
     const size_t cb = (size_t)h->m * h->code_bytes;
     const int64_t R = X ? (int64_t)W * (1 << 18) : n;  // host batches in rounds; device slices in one
@@ -777,6 +843,17 @@ int sharded_add_vectors(mmidx_index *h, int64_t n, const double *X, const double
         rc = shard_run(g, [=, &lo](int r) -> int {
             int rc2 = shard_encode_slice(g, r, Xr, dXs ? dXs[r] : nullptr, lo[(size_t)r], lo[(size_t)r + 1], hc, hk);
             if (rc2) return rc2;
+            BARRIER(g);
+            // all or nothing: every shard makes room for its share of the round first (the one step of an append that can fail
+            // for lack of memory); a shard that cannot aborts the barrier and nobody appends
+            {
+                mmidx_index *s = g->sub[(size_t)r];
+                int64_t mine = 0;
+                for (int64_t i = 0; i < nr; i++) mine += (hc[i] >= 0 && hc[i] % g->n == r);
+                std::lock_guard<std::recursive_mutex> alk(s->add_mu);
+                rc2 = ensure_pending(s, mine);
+                if (rc2) return rc2;
+            }
             BARRIER(g);
             return shard_append_owned(g, r, nr, ir, base, hc, hk);
         });
@@ -838,15 +915,17 @@ int sharded_encode(mmidx_index *h, int64_t n, const double *X, int32_t *cell_out
     return MMIDX_OK;
 }
 
+int sharded_sync_locked(ShardGroup *g) { return shard_run(g, [=](int r) -> int { return mmidx_sync_index(g->sub[(size_t)r]); }); }
 int sharded_sync(mmidx_index *h) {
     ShardGroup *g = h->grp;
     std::lock_guard<std::mutex> lk(g->call_mu);
-    return shard_run(g, [=](int r) -> int { return mmidx_sync_index(g->sub[(size_t)r]); });
+    return sharded_sync_locked(g);
 }
 
 int sharded_list_sizes(mmidx_index *h, int32_t *sizes_out) {
     ShardGroup *g = h->grp;
-    int rc = sharded_sync(h);
+    std::lock_guard<std::mutex> lk(g->call_mu);  // (held from the sync to the last offset read: no add in between)
+    int rc = sharded_sync_locked(g);
     if (rc) return rc;
     for (int c = 0; c < h->nlists; c++) {
         const mmidx_index *s = g->sub[(size_t)(c % g->n)];
@@ -858,7 +937,8 @@ int sharded_list_sizes(mmidx_index *h, int32_t *sizes_out) {
 // list-major snapshot over all shards: list c comes from shard c mod n
 int sharded_export(mmidx_index *h, int64_t *list_off_out, int32_t *iids_out, void *codes_out) {
     ShardGroup *g = h->grp;
-    int rc = sharded_sync(h);
+    std::lock_guard<std::mutex> lk(g->call_mu);  // (held across the sync, the offsets and the copies: a concurrent add cannot grow the lists in between)
+    int rc = sharded_sync_locked(g);
     if (rc) return rc;
     const size_t cb = (size_t)h->m * h->code_bytes;
     list_off_out[0] = 0;
@@ -867,7 +947,6 @@ int sharded_export(mmidx_index *h, int64_t *list_off_out, int32_t *iids_out, voi
         list_off_out[c + 1] = list_off_out[c] + (s->h_off[(size_t)c + 1] - s->h_off[(size_t)c]);
     }
     if (!iids_out && !codes_out) return MMIDX_OK;
-    std::lock_guard<std::mutex> lk(g->call_mu);
     return shard_run(g, [=](int r) -> int {
         mmidx_index *s = g->sub[(size_t)r];
         const int64_t n = s->n_csr;
@@ -997,9 +1076,8 @@ int sharded_get_stats(mmidx_index *h, mmidx_stats *out) {
         acc.tie_fallbacks += s.tie_fallbacks;
         if (s.passb_items_last >= 0) acc.passb_items_last = std::max(0, acc.passb_items_last) + s.passb_items_last;
     }
-    acc.tie_fallbacks += (int32_t)g->tie_queries;
-    g->tie_queries = 0;
-    g->tie_rounds = 0;
+    acc.tie_fallbacks += (int32_t)g->tie_queries.exchange(0, std::memory_order_relaxed);
+    g->tie_rounds.store(0, std::memory_order_relaxed);
     *out = acc;
     return MMIDX_OK;
 }
@@ -1187,6 +1265,7 @@ int mmidx_search_sliced_device(mmidx_index *h, int k, int64_t nq_per_shard, cons
     for (int r = 0; r < g->n; r++)
         if (!dQ[r] || !d_iid_out[r] || !d_dist_out[r] || !d_count_out[r]) return fail(MMIDX_ERR_INVALID_ARG, "null slice pointer (shard %d)", r);
     std::lock_guard<std::mutex> lk(g->call_mu);
+    SHARD_ALIVE(g);
     int64_t cap = 0;
     rc = shard_round_cap(g, k, &cap);
     if (rc) return rc;
@@ -1198,7 +1277,12 @@ int mmidx_search_sliced_device(mmidx_index *h, int k, int64_t nq_per_shard, cons
             return shard_search_round(g, r, k, per, nullptr, 0, dQ[r] + (size_t)p0 * D, d_iid_out[r] + (size_t)p0 * k, d_dist_out[r] + (size_t)p0 * k,
                                       d_count_out[r] + p0);
         });
-        if (rc) return rc;
+        if (rc) {
+            const std::string keep = g_err;
+            shard_poison(g);
+            g_err = keep;
+            return rc;
+        }
     }
     return MMIDX_OK;
 }
