@@ -224,7 +224,7 @@ struct HostBarrier {
 };
 
 struct ShardBufs {  // everything on the shard's device
-    DevBuf<double> Q, cdist, T, pd, rpd, odist, tau_own, tau;
+    DevBuf<double> Q, Q2, cdist, T, pd, rpd, odist, tau_own, tau;  // (Q / Q2: the rounds' query buffers alternate)
     DevBuf<long long> pk, rpk;
     DevBuf<int32_t> cells, pc, rpc, oiid, ocnt, flag, nflag, rows_own, fq_own, fq, counts, pB, ties;
     DevBuf<unsigned char> tmp;  // in-process reductions
@@ -237,7 +237,19 @@ struct ShardBufs {  // everything on the shard's device
     ShardDest *pin_dest = nullptr; // pinned host copy of `dest` (what was last uploaded: re-sent only when a pointer changed)
     int dest_n = 0;
     hipEvent_t ev_b = nullptr;     // pass B of this shard has been enqueued up to here
+    // the query exchange runs on the shard's SECOND stream (its own communicator), next to the coarse stage of the own slice and,
+    // in a call of several rounds, under the previous round's scans.  Per buffer: own slice landed / everybody's landed / the
+    // main stream has finished reading it
+    hipEvent_t ev_own[2] = {nullptr, nullptr}, ev_q[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+    bool free_valid[2] = {false, false};
     void release() {
+        for (int i = 0; i < 2; i++) {
+            if (ev_own[i]) (void)hipEventDestroy(ev_own[i]);
+            if (ev_q[i]) (void)hipEventDestroy(ev_q[i]);
+            if (ev_free[i]) (void)hipEventDestroy(ev_free[i]);
+            ev_own[i] = ev_q[i] = ev_free[i] = nullptr;
+        }
+        Q2.release();
         Q.release(); cdist.release(); T.release(); pd.release(); rpd.release(); odist.release(); tau_own.release(); tau.release();
         pk.release(); rpk.release(); cells.release(); pc.release(); rpc.release(); oiid.release(); ocnt.release(); flag.release();
         nflag.release(); rows_own.release(); fq_own.release(); fq.release(); counts.release(); pB.release(); ties.release();
@@ -258,6 +270,9 @@ struct ShardGroup {
     std::vector<int> dev;
     std::vector<mmidx_index *> sub;
     std::vector<hipStream_t> st;
+    std::vector<hipStream_t> st2;   // the query exchange's streams
+    std::vector<ncclComm_t> comm2;  // ... and communicators (null: in-process collectives)
+    int pipeline = 1;               // option "shard_pipeline": 1 = query exchange on the second stream (overlapped), 0 = everything on one stream
     bool rccl = false;       // collectives through RCCL (devices pairwise distinct); else in-process (virtual shards)
     bool peer_ok = true;     // every shard can store into every other shard's memory
     int exchange = 0;        // option "shard_exchange": 0 = pass B stores into the owners' buffers, 1 = ncclSend / ncclRecv of dense lists
@@ -360,10 +375,11 @@ void shard_poison(ShardGroup *g) {
     g->broken = true;
     if (!R || !R->CommAbort) return;
     for (size_t r = 0; r < g->comm.size(); r++) {
-        if (!g->comm[r]) continue;
         (void)hipSetDevice(g->dev[r]);
-        (void)R->CommAbort(g->comm[r]);
+        if (g->comm[r]) (void)R->CommAbort(g->comm[r]);
         g->comm[r] = nullptr;
+        if (r < g->comm2.size() && g->comm2[r]) (void)R->CommAbort(g->comm2[r]);
+        if (r < g->comm2.size()) g->comm2[r] = nullptr;
     }
 }
 #define SHARD_ALIVE(g)                                                                                                       \
@@ -379,13 +395,13 @@ void shard_poison(ShardGroup *g) {
 
 // ---- collectives (in place), worker r, on the shard's stream ------------------------------------------------------------
 // all-gather: slice s of `buf` (bytes each) comes from shard s
-int coll_allgather(ShardGroup *g, int r, void *buf, size_t bytes) {
+int coll_allgather(ShardGroup *g, int r, void *buf, size_t bytes, bool second = false) {
     if (bytes == 0) return MMIDX_OK;
-    hipStream_t st = g->st[(size_t)r];
+    hipStream_t st = second ? g->st2[(size_t)r] : g->st[(size_t)r];
     if (g->rccl) {
         RcclApi *R = rccl_api();
         BARRIER(g);  // (a worker that failed on the way never enqueues: its peers must not either, or their streams hang in the collective)
-        NCCLCK(R->AllGather((const char *)buf + (size_t)r * bytes, buf, bytes, ncclInt8, g->comm[(size_t)r], st));
+        NCCLCK(R->AllGather((const char *)buf + (size_t)r * bytes, buf, bytes, ncclInt8, second ? g->comm2[(size_t)r] : g->comm[(size_t)r], st));
         return MMIDX_OK;
     }
     g->pub[(size_t)r] = buf;
@@ -465,8 +481,48 @@ int shard_round_cap(ShardGroup *g, int k, int64_t *cap_out) {
 // One collective round on worker r.  The shard's own queries: host rows Qh (nreal of them, the rest of the slice repeats the
 // last row) or a device pointer dQ_own (per rows).  Answers: device pointers (d_iid / d_dist / d_cnt, per rows) or, when those
 // are null, the shard's own buffers (the caller copies them out).
+// The round's query rows on worker r: the own slice into buffer `slot` (host rows Qh -- nreal of them, the rest of the slice repeats
+// the first row -- or the device rows dQ_own), then the in-place all-gather of everybody's.  On the shard's second stream and
+// communicator ("shard_pipeline" = 1): the main stream only waits for the events -- own rows before the coarse stage, all rows
+// before pass A -- and a call of several rounds enqueues round i + 1's exchange before round i's kernels.
+int shard_queries(ShardGroup *g, int r, int64_t per, const double *Qh, int64_t nreal, const double *dQ_own, int slot) {
+    const int W = g->n;
+    mmidx_index *s = g->sub[(size_t)r];
+    ShardBufs &B = g->buf[(size_t)r];
+    const bool two = g->pipeline != 0;
+    hipStream_t st = two ? g->st2[(size_t)r] : g->st[(size_t)r];
+    const int D = s->D;
+    DevBuf<double> &QB = slot ? B.Q2 : B.Q;
+    if (QB.cap < (size_t)per * W * D) {  // (growing the buffer frees the old one: nothing may still be reading it)
+        HIPCK(hipStreamSynchronize(g->st[(size_t)r]));
+        HIPCK(hipStreamSynchronize(g->st2[(size_t)r]));
+        HIPCK(QB.reserve((size_t)per * W * D));
+        B.free_valid[slot] = false;
+    }
+    if (two && B.free_valid[slot]) HIPCK(hipStreamWaitEvent(st, B.ev_free[slot], 0));  // the round that last used this buffer has finished with it
+    double *Qown = QB.p + (size_t)r * per * D;
+    if (dQ_own) {
+        HIPCK(hipMemcpyAsync(Qown, dQ_own, (size_t)per * D * 8, hipMemcpyDeviceToDevice, st));
+    } else {
+        if (nreal > 0) HIPCK(hipMemcpyAsync(Qown, Qh, (size_t)nreal * D * 8, hipMemcpyHostToDevice, st));
+        if (nreal < per) {  // padding rows of the last slices: any valid query -- the slice's first row, replicated by one kernel
+            if (nreal == 0) HIPCK(hipMemcpyAsync(Qown, Qh, (size_t)D * 8, hipMemcpyHostToDevice, st));
+            const long long first_pad = std::max<int64_t>(nreal, 1), tot = ((long long)per - first_pad) * D;
+            if (tot > 0) {
+                hipLaunchKernelGGL(k_repeat_row, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Qown, D, first_pad, (long long)per);
+                HIPCK(hipGetLastError());
+            }
+        }
+    }
+    if (two) HIPCK(hipEventRecord(B.ev_own[slot], st));
+    int rc = coll_allgather(g, r, QB.p, (size_t)per * D * 8, two);
+    if (rc) return rc;
+    if (two) HIPCK(hipEventRecord(B.ev_q[slot], st));
+    return MMIDX_OK;
+}
+
 int shard_search_round(ShardGroup *g, int r, int k, int64_t per, const double *Qh, int64_t nreal, const double *dQ_own, int32_t *d_iid,
-                       double *d_dist, int32_t *d_cnt) {
+                       double *d_dist, int32_t *d_cnt, int slot = 0, bool prefetched = false) {
     const int W = g->n;
     mmidx_index *s = g->sub[(size_t)r];
     ShardBufs &B = g->buf[(size_t)r];
@@ -474,7 +530,6 @@ int shard_search_round(ShardGroup *g, int r, int k, int64_t per, const double *Q
     const int D = s->D, w = s->w, K1 = k + 1;
     const int64_t nq = per * W;
     const bool p2p = g->exchange == 0 && g->peer_ok;
-    HIPCK(B.Q.reserve((size_t)nq * D));
     HIPCK(B.cells.reserve((size_t)nq * w));
     HIPCK(B.cdist.reserve((size_t)nq * w));
     HIPCK(B.T.reserve((size_t)nq));
@@ -499,32 +554,28 @@ int shard_search_round(ShardGroup *g, int r, int k, int64_t per, const double *Q
     HIPCK(B.dest.reserve((size_t)W));
     HIPCK(hipMemsetAsync(B.nflag.p, 0, sizeof(int32_t), st));
 
-    // 0. the own slice of the queries, then everybody's
-    double *Qown = B.Q.p + (size_t)r * per * D;
-    if (dQ_own) {
-        HIPCK(hipMemcpyAsync(Qown, dQ_own, (size_t)per * D * 8, hipMemcpyDeviceToDevice, st));
-    } else {
-        if (nreal > 0) HIPCK(hipMemcpyAsync(Qown, Qh, (size_t)nreal * D * 8, hipMemcpyHostToDevice, st));
-        if (nreal < per) {  // padding rows of the last slices: any valid query -- the slice's first row, replicated by one kernel
-            if (nreal == 0) HIPCK(hipMemcpyAsync(Qown, Qh, (size_t)D * 8, hipMemcpyHostToDevice, st));
-            const long long first_pad = std::max<int64_t>(nreal, 1), tot = ((long long)per - first_pad) * D;
-            if (tot > 0) {
-                hipLaunchKernelGGL(k_repeat_row, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Qown, D, first_pad, (long long)per);
-                HIPCK(hipGetLastError());
-            }
-        }
+    // 0. the own slice of the queries, then everybody's (shard_queries: on the second stream unless the caller already enqueued it
+    //    for this round, i.e. under the previous round's scans)
+    double *Qall = slot ? B.Q2.p : B.Q.p;
+    double *Qown = Qall + (size_t)r * per * D;
+    int rc = MMIDX_OK;
+    if (!prefetched) {
+        rc = shard_queries(g, r, per, Qh, nreal, dQ_own, slot);
+        if (rc) return rc;
     }
-    int rc = coll_allgather(g, r, B.Q.p, (size_t)per * D * 8);
-    if (rc) return rc;
-    // 1. coarse stage of the own slice; cells and exact coarse distances of everybody's
+    const bool two = g->pipeline != 0;
+    // 1. coarse stage of the own slice -- it needs the own rows only, so it runs NEXT TO the exchange of everybody's rows --;
+    //    cells and exact coarse distances of everybody's
+    if (two) HIPCK(hipStreamWaitEvent(st, B.ev_own[slot], 0));
     rc = mmidx_coarse_device(s, per, Qown, B.cells.p + (size_t)r * per * w, B.cdist.p + (size_t)r * per * w, st);
     if (rc) return rc;
     rc = coll_allgather(g, r, B.cells.p, (size_t)per * w * 4);
     if (rc) return rc;
     rc = coll_allgather(g, r, B.cdist.p, (size_t)per * w * 8);
     if (rc) return rc;
+    if (two) HIPCK(hipStreamWaitEvent(st, B.ev_q[slot], 0));  // pass A reads everybody's rows
     // 2. pass A on the local lists, thresholds shared
-    rc = mmidx_shard_pass_a_device(s, k, nq, B.Q.p, B.cells.p, B.T.p, st);
+    rc = mmidx_shard_pass_a_device(s, k, nq, Qall, B.cells.p, B.T.p, st);
     if (rc) return rc;
     rc = coll_allreduce(g, r, B.T.p, nq, 0);
     if (rc) return rc;
@@ -551,7 +602,7 @@ int shard_search_round(ShardGroup *g, int r, int k, int64_t per, const double *Q
         s->shard_dest = B.dest.p;
         s->shard_dest_per = (int)per;
         s->shard_dest_me = r;
-        rc = mmidx_shard_pass_b_device(s, k, nq, B.Q.p, B.cells.p, B.cdist.p, B.T.p, B.rpd.p, (int64_t *)B.rpk.p, B.rpc.p, st);
+        rc = mmidx_shard_pass_b_device(s, k, nq, Qall, B.cells.p, B.cdist.p, B.T.p, B.rpd.p, (int64_t *)B.rpk.p, B.rpc.p, st);
         s->shard_dest = nullptr;
         if (rc) return rc;
         // 4. the owner's merge waits for every shard's pass B
@@ -561,7 +612,7 @@ int shard_search_round(ShardGroup *g, int r, int k, int64_t per, const double *Q
             if (o != r) HIPCK(hipStreamWaitEvent(st, g->buf[(size_t)o].ev_b, 0));
     } else {
         s->shard_dest = nullptr;
-        rc = mmidx_shard_pass_b_device(s, k, nq, B.Q.p, B.cells.p, B.cdist.p, B.T.p, B.pd.p, (int64_t *)B.pk.p, B.pc.p, st);
+        rc = mmidx_shard_pass_b_device(s, k, nq, Qall, B.cells.p, B.cdist.p, B.T.p, B.pd.p, (int64_t *)B.pk.p, B.pc.p, st);
         if (rc) return rc;
         if (g->rccl) {
             RcclApi *R = rccl_api();
@@ -607,8 +658,14 @@ int shard_search_round(ShardGroup *g, int r, int k, int64_t per, const double *Q
     BARRIER(g);
     int mx = 0;
     for (int o = 0; o < W; o++) mx = std::max(mx, g->nflag_host[(size_t)o]);
-    if (mx == 0) return MMIDX_OK;
-    if (g->tie_slots <= 0) return MMIDX_OK;  // (replay switched off: the merge's (distance, probe rank, iid) order stays)
+    auto done_with_queries = [&]() -> int {  // (the buffer may be refilled by the round after next)
+        if (g->pipeline) {
+            HIPCK(hipEventRecord(B.ev_free[slot], st));
+            B.free_valid[slot] = true;
+        }
+        return MMIDX_OK;
+    };
+    if (mx == 0 || g->tie_slots <= 0) return done_with_queries();  // (replay switched off: the merge's (distance, probe rank, iid) order stays)
     const int Fo = g->tie_slots, F = Fo * W;
     HIPCK(B.rows_own.reserve((size_t)Fo));
     HIPCK(B.fq.reserve((size_t)F));
@@ -633,15 +690,15 @@ int shard_search_round(ShardGroup *g, int r, int k, int64_t per, const double *Q
         HIPCK(hipMemsetAsync(B.pB.p, 0, (size_t)F * 4, st));
         hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)(((size_t)F * k + 255) / 256)), dim3(256), 0, st, B.ties.p, -1, (long long)F * k);
         HIPCK(hipGetLastError());
-        rc = mmidx_shard_tie_phase_device(s, 0, k, F, B.Q.p, B.cells.p, B.fq.p, B.tau.p, B.counts.p, B.pB.p, B.ties.p, st);
+        rc = mmidx_shard_tie_phase_device(s, 0, k, F, Qall, B.cells.p, B.fq.p, B.tau.p, B.counts.p, B.pB.p, B.ties.p, st);
         if (rc) return rc;
         rc = coll_allreduce(g, r, B.counts.p, (long long)F * w * 2, 1);
         if (rc) return rc;
-        rc = mmidx_shard_tie_phase_device(s, 1, k, F, B.Q.p, B.cells.p, B.fq.p, B.tau.p, B.counts.p, B.pB.p, B.ties.p, st);
+        rc = mmidx_shard_tie_phase_device(s, 1, k, F, Qall, B.cells.p, B.fq.p, B.tau.p, B.counts.p, B.pB.p, B.ties.p, st);
         if (rc) return rc;
         rc = coll_allreduce(g, r, B.pB.p, (long long)F, 1);
         if (rc) return rc;
-        rc = mmidx_shard_tie_phase_device(s, 2, k, F, B.Q.p, B.cells.p, B.fq.p, B.tau.p, B.counts.p, B.pB.p, B.ties.p, st);
+        rc = mmidx_shard_tie_phase_device(s, 2, k, F, Qall, B.cells.p, B.fq.p, B.tau.p, B.counts.p, B.pB.p, B.ties.p, st);
         if (rc) return rc;
         rc = coll_allreduce(g, r, B.ties.p, (long long)F * k, 2);
         if (rc) return rc;
@@ -649,7 +706,7 @@ int shard_search_round(ShardGroup *g, int r, int k, int64_t per, const double *Q
         HIPCK(hipGetLastError());
     }
     HIPCK(hipStreamSynchronize(st));
-    return MMIDX_OK;
+    return done_with_queries();
 }
 
 int sharded_check_search(mmidx_index *h, int k) {
@@ -671,15 +728,34 @@ int sharded_search_host(mmidx_index *h, int k, int64_t nq, const double *Q, int3
     rc = shard_round_cap(g, k, &cap);
     if (rc) return rc;
     const int W = g->n, D = h->D;
-    for (int64_t q0 = 0; q0 < nq; q0 += cap) {
-        const int64_t nr = std::min<int64_t>(cap, nq - q0);
-        const int64_t per = (nr + W - 1) / W;
-        rc = shard_run(g, [=](int r) -> int {
-            const int64_t lo = std::min<int64_t>((int64_t)r * per, nr), hi = std::min<int64_t>(lo + per, nr);
-            const int64_t nreal = hi - lo;
+    // ONE job for the whole call: every worker walks the rounds, and enqueues round i + 1's query exchange (second stream, other
+    // buffer) before round i's kernels
+    rc = shard_run(g, [=](int r) -> int {
+        auto slice = [&](int64_t q0, int64_t &per, int64_t &lo, int64_t &nreal) {
+            const int64_t nr = std::min<int64_t>(cap, nq - q0);
+            per = (nr + W - 1) / W;
+            lo = std::min<int64_t>((int64_t)r * per, nr);
+            nreal = std::min<int64_t>(lo + per, nr) - lo;
+        };
+        int round = 0;
+        for (int64_t q0 = 0; q0 < nq; q0 += cap, round++) {
+            int64_t per, lo, nreal;
+            slice(q0, per, lo, nreal);
+            const int slot = round & 1;
             // (a slice with no real query still takes part in every collective: it repeats the round's first query)
             const double *Qh = Q + (size_t)(q0 + (nreal > 0 ? lo : 0)) * D;
-            int rc2 = shard_search_round(g, r, k, per, Qh, nreal, nullptr, nullptr, nullptr, nullptr);
+            int rc2;
+            if (round == 0) {
+                rc2 = shard_queries(g, r, per, Qh, nreal, nullptr, slot);
+                if (rc2) return rc2;
+            }
+            if (q0 + cap < nq && g->pipeline) {
+                int64_t per1, lo1, nreal1;
+                slice(q0 + cap, per1, lo1, nreal1);
+                rc2 = shard_queries(g, r, per1, Q + (size_t)(q0 + cap + (nreal1 > 0 ? lo1 : 0)) * D, nreal1, nullptr, slot ^ 1);
+                if (rc2) return rc2;
+            }
+            rc2 = shard_search_round(g, r, k, per, Qh, nreal, nullptr, nullptr, nullptr, nullptr, slot, round == 0 || g->pipeline != 0);
             if (rc2) return rc2;
             if (nreal > 0) {
                 ShardBufs &B = g->buf[(size_t)r];
@@ -689,14 +765,14 @@ int sharded_search_host(mmidx_index *h, int k, int64_t nq, const double *Q, int3
                 HIPCK(hipMemcpyAsync(count_out + (q0 + lo), B.ocnt.p, (size_t)nreal * 4, hipMemcpyDeviceToHost, st));
                 HIPCK(hipStreamSynchronize(st));
             }
-            return MMIDX_OK;
-        });
-        if (rc) {
-            const std::string keep = g_err;
-            shard_poison(g);
-            g_err = keep;
-            return rc;
         }
+        return MMIDX_OK;
+    });
+    if (rc) {
+        const std::string keep = g_err;
+        shard_poison(g);
+        g_err = keep;
+        return rc;
     }
     return MMIDX_OK;
 }
@@ -1113,6 +1189,12 @@ int sharded_set_option(mmidx_index *h, const char *name, int value) {
         g->comb.enabled = value != 0;
         return MMIDX_OK;
     }
+    if (n == "shard_pipeline") {  // 1: the query exchange on the shards' second streams (overlapped); 0: one stream per shard (A/B switch)
+        std::lock_guard<std::mutex> lk(g->call_mu);
+        g->pipeline = value != 0;
+        for (auto &b : g->buf) b.free_valid[0] = b.free_valid[1] = false;
+        return MMIDX_OK;
+    }
     return sharded_for_each(h, [&](mmidx_index *s) { return mmidx_set_option(s, name, value); });
 }
 
@@ -1130,11 +1212,17 @@ void sharded_destroy(mmidx_index *h) {
     for (int r = 0; r < (int)g->buf.size(); r++) {
         (void)hipSetDevice(g->dev[(size_t)r]);
         if (r < (int)g->st.size() && g->st[(size_t)r]) (void)hipStreamSynchronize(g->st[(size_t)r]);
+        if (r < (int)g->st2.size() && g->st2[(size_t)r]) {
+            (void)hipStreamSynchronize(g->st2[(size_t)r]);
+            (void)hipStreamDestroy(g->st2[(size_t)r]);
+        }
         g->buf[(size_t)r].release();
     }
-    if (g->rccl) {
-        RcclApi *R = rccl_api();
+    {
+        RcclApi *R = (g->rccl || !g->comm.empty() || !g->comm2.empty()) ? rccl_api() : nullptr;
         for (ncclComm_t c : g->comm)
+            if (R && c) (void)R->CommDestroy(c);
+        for (ncclComm_t c : g->comm2)
             if (R && c) (void)R->CommDestroy(c);
     }
     for (mmidx_index *s : g->sub)
@@ -1187,6 +1275,14 @@ int mmidx_create_sharded(int kind, int D, int m, int ks, int C, int transform, c
             hipHostMalloc((void **)&g->buf[(size_t)r].pin_dest, MMIDX_MAX_SHARDS * sizeof(ShardDest)) != hipSuccess ||
             hipEventCreateWithFlags(&g->buf[(size_t)r].ev_b, hipEventDisableTiming) != hipSuccess)
             return bail(fail(MMIDX_ERR_HIP, "shard %d: pinned word / event allocation failed", r));
+        hipStream_t s2 = nullptr;
+        if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) return bail(fail(MMIDX_ERR_HIP, "shard %d: second stream", r));
+        g->st2.push_back(s2);
+        for (int i = 0; i < 2; i++)
+            if (hipEventCreateWithFlags(&g->buf[(size_t)r].ev_own[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&g->buf[(size_t)r].ev_q[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&g->buf[(size_t)r].ev_free[i], hipEventDisableTiming) != hipSuccess)
+                return bail(fail(MMIDX_ERR_HIP, "shard %d: event allocation failed", r));
         memset(g->buf[(size_t)r].pin_nflag, 0, 64);
     }
     // every shard stores pass B's lists into the owners' buffers and (in-process collectives) reads its peers': peer access
@@ -1210,6 +1306,9 @@ int mmidx_create_sharded(int kind, int D, int m, int ks, int C, int transform, c
         g->comm.assign((size_t)n_dev, nullptr);
         ncclResult_t nr = R->CommInitAll(g->comm.data(), n_dev, devs);
         if (nr != ncclSuccess) return bail(fail(MMIDX_ERR_HIP, "ncclCommInitAll over %d devices failed: %s", n_dev, R->GetErrorString(nr)));
+        g->comm2.assign((size_t)n_dev, nullptr);  // the query exchange's own communicators: it runs next to the main stream's collectives
+        nr = R->CommInitAll(g->comm2.data(), n_dev, devs);
+        if (nr != ncclSuccess) return bail(fail(MMIDX_ERR_HIP, "ncclCommInitAll (second set) over %d devices failed: %s", n_dev, R->GetErrorString(nr)));
         g->rccl = true;
     } else if (!g->peer_ok) {
         return bail(fail(MMIDX_ERR_UNSUPPORTED, "shards on repeated devices use in-process collectives, which need peer access between all of them"));
@@ -1271,18 +1370,32 @@ int mmidx_search_sliced_device(mmidx_index *h, int k, int64_t nq_per_shard, cons
     if (rc) return rc;
     const int64_t per_cap = std::max<int64_t>(1, cap / g->n);
     const int D = h->D;
-    for (int64_t p0 = 0; p0 < nq_per_shard; p0 += per_cap) {
-        const int64_t per = std::min<int64_t>(per_cap, nq_per_shard - p0);
-        rc = shard_run(g, [=](int r) -> int {
-            return shard_search_round(g, r, k, per, nullptr, 0, dQ[r] + (size_t)p0 * D, d_iid_out[r] + (size_t)p0 * k, d_dist_out[r] + (size_t)p0 * k,
-                                      d_count_out[r] + p0);
-        });
-        if (rc) {
-            const std::string keep = g_err;
-            shard_poison(g);
-            g_err = keep;
-            return rc;
+    rc = shard_run(g, [=](int r) -> int {
+        int round = 0;
+        for (int64_t p0 = 0; p0 < nq_per_shard; p0 += per_cap, round++) {
+            const int64_t per = std::min<int64_t>(per_cap, nq_per_shard - p0);
+            const int slot = round & 1;
+            int rc2;
+            if (round == 0) {
+                rc2 = shard_queries(g, r, per, nullptr, 0, dQ[r] + (size_t)p0 * D, slot);
+                if (rc2) return rc2;
+            }
+            if (p0 + per_cap < nq_per_shard && g->pipeline) {  // the next round's query exchange, under this round's kernels
+                const int64_t p1 = p0 + per_cap, per1 = std::min<int64_t>(per_cap, nq_per_shard - p1);
+                rc2 = shard_queries(g, r, per1, nullptr, 0, dQ[r] + (size_t)p1 * D, slot ^ 1);
+                if (rc2) return rc2;
+            }
+            rc2 = shard_search_round(g, r, k, per, nullptr, 0, dQ[r] + (size_t)p0 * D, d_iid_out[r] + (size_t)p0 * k, d_dist_out[r] + (size_t)p0 * k,
+                                     d_count_out[r] + p0, slot, round == 0 || g->pipeline != 0);
+            if (rc2) return rc2;
         }
+        return MMIDX_OK;
+    });
+    if (rc) {
+        const std::string keep = g_err;
+        shard_poison(g);
+        g_err = keep;
+        return rc;
     }
     return MMIDX_OK;
 }

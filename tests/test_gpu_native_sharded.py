@@ -344,3 +344,43 @@ def test_native_sharded_search_right_after_a_large_add(mi, oracle):
     Q = np.concatenate([p["queries"]] * 40)[:2500]
     assert_same(ix.search_batch(k, Q), ref.search_batch(Q, k))
     ix.close()
+
+
+@pytest.mark.parametrize("devices", DEVS, ids=["rccl1", "virt2", "virt3"])
+def test_native_sharded_query_exchange_pipeline(mi, oracle, devices):
+    """`shard_pipeline`: the rounds' query exchange on the shards' second streams and communicators -- next to the coarse stage of
+    the own slice, and round i + 1's under round i's scans (two query buffers) -- against the one-stream form (0).  Calls of 1, 2,
+    3 and 7 rounds (`shard_max_round`), host rows and device slices, ties included: the single queue's answer every time."""
+    import torch
+
+    D, C_, m, ks, w, k = 32, 20, 8, 256, 5, 10
+    p = synth.make_ivfpq_problem(n=2500, D=D, C=C_, m=m, ks=ks, nq=32, seed=31 + len(devices))
+    base = np.concatenate([p["base"]] * 2)
+    n, W = len(base), len(devices)
+    ref = make_ref(oracle, p, D, m, ks, C_, w)
+    ref.add_vectors(base)
+    ix = make_sharded(mi, p, D, m, ks, C_, w, n, devices)
+    ix.indexVectors([str(i) for i in range(n)], base)
+    Q = np.concatenate([p["queries"], base[:52]])  # 84 queries
+    want = ref.search_batch(Q, k)
+    L = mi.lib()
+    for pl in (1, 0, 1):
+        ix.set_option("shard_pipeline", pl)
+        for max_round in (262144, 48, 30, 12):
+            ix.set_option("shard_max_round", max_round)
+            assert_same(ix.search_batch(k, Q), want)
+            # device slices (mmidx_search_sliced_device): slice r = rows [r per, (r + 1) per) of the batch
+            per = len(Q) // W
+            dev = torch.device("cuda", 0)
+            Qd = [torch.from_numpy(np.ascontiguousarray(Q[r * per:(r + 1) * per])).to(dev) for r in range(W)]
+            oi = [torch.empty(per, k, dtype=torch.int32, device=dev) for _ in range(W)]
+            od = [torch.empty(per, k, dtype=torch.float64, device=dev) for _ in range(W)]
+            oc = [torch.empty(per, dtype=torch.int32, device=dev) for _ in range(W)]
+            arr = lambda ts: (C.c_void_p * W)(*[t.data_ptr() for t in ts])
+            torch.cuda.synchronize()
+            rc = L.mmidx_search_sliced_device(ix._h, k, per, arr(Qd), arr(oi), arr(od), arr(oc))
+            assert rc == 0, mi.lib().mmidx_last_error()
+            torch.cuda.synchronize()
+            got = (np.concatenate([t.cpu().numpy() for t in oi]), np.concatenate([t.cpu().numpy() for t in od]), np.concatenate([t.cpu().numpy() for t in oc]))
+            assert_same(got, tuple(a[:per * W] for a in want))
+    ix.close()
