@@ -377,6 +377,10 @@ int mmidx_pca_project_device(mmidx_pca *p, int64_t n, const double *dX, double *
 typedef struct mmidx_vlad mmidx_vlad;
 int mmidx_vlad_create(int nvocab, const int32_t *ncent, int dl, const double *codebooks,
                       int normalizations_on, int device, mmidx_vlad **out);
+/* "exact" = 1: the one-kernel form (fp64 brute-force nearest centroid inside the image's block) instead of the default -- the
+ * nearest centroid of every descriptor of the call by the encoder's certified bf16-MFMA argmin (identical result: first index wins,
+ * AFA:136-155; flagged descriptors redone in fp64), then the ordered accumulation.  A/B and test switch (ABI version 6). */
+int mmidx_vlad_set_option(mmidx_vlad *v, const char *name, int value);
 int mmidx_vlad_destroy(mmidx_vlad *v);
 int mmidx_vlad_vector_length(const mmidx_vlad *v, int *len_out);
 int mmidx_vlad_descriptor_length(const mmidx_vlad *v, int *dl_out);

@@ -95,6 +95,7 @@ SIGNATURES = {
     "mmidx_pca_project_device": (C.c_int, [_vp, C.c_int64, _dp, _dp, _vp]),
     "mmidx_vlad_create": (C.c_int, [C.c_int, _i32p, C.c_int, _dp, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "mmidx_vlad_destroy": (C.c_int, [_vp]),
+    "mmidx_vlad_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "mmidx_vlad_vector_length": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "mmidx_vlad_aggregate": (C.c_int, [_vp, C.c_int64, _vp, _dp, _dp]),
     "mmidx_vlad_aggregate_device": (C.c_int, [_vp, C.c_int64, _vp, _dp, C.c_int, _dp, _vp]),

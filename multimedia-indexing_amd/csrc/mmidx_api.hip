@@ -515,17 +515,28 @@ int assign_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_cell, 
         if (!split16) HIPCK(h->ws_Q32.reserve((size_t)n * h->D));
         HIPCK(h->ws_qn.reserve((size_t)n));
         HIPCK(h->ws_amb.reserve((size_t)n));
+        HIPCK(h->ws_aidx.reserve((size_t)n + 1));
+        HIPCK(hipMemsetAsync(h->ws_aidx.p + n, 0, sizeof(int32_t), st));
         if (split16) {
             // bf16-split dot products on the matrix cores (K6a'), 5x the rate of the fp32 MFMA
-            HIPCK(h->ws_Qh.reserve((size_t)n * h->Dp));
-            HIPCK(h->ws_Ql.reserve((size_t)n * h->Dp));
-            hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)((n + 3) / 4)), dim3(MMIDX_BLOCK), 0, st, dX, (__bf16 *)h->ws_Qh.p, (__bf16 *)h->ws_Ql.p,
-                               (float *)nullptr, h->ws_qn.p, h->D, h->Dp, (long long)n);
             const size_t l16 = 2 * (size_t)G16_BC * G16_STRIDE;
-            HIPCK(hipFuncSetAttribute((const void *)k_assign_gmin16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l16));
-            hipLaunchKernelGGL(k_assign_gmin16, dim3((unsigned)((n + G16_BQ - 1) / G16_BQ)), dim3(MMIDX_BLOCK), l16, st, (const __bf16 *)h->ws_Qh.p,
-                               (const __bf16 *)h->ws_Ql.p, (const __bf16 *)h->d_Ch, (const __bf16 *)h->d_Cl, h->d_cn_pad, h->ws_qn.p, d_cell,
-                               h->ws_amb.p, h->cnorm_max, h->cn_max, h->Cp, h->Dp, (long long)n);
+            const bool fromx = h->Dp <= G16_KC && (h->D % 8) == 0 && ((uintptr_t)dX & 15) == 0 && !getenv("MMIDX_ASSIGN_SPLIT");
+            if (fromx) {  // one k chunk: the kernel splits the fp64 rows itself (no k_split_bf16 round trip through HBM)
+                HIPCK(hipFuncSetAttribute((const void *)k_assign_gmin16_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l16));
+                hipLaunchKernelGGL(k_assign_gmin16_t<true>, dim3((unsigned)((n + G16_BQ - 1) / G16_BQ)), dim3(MMIDX_BLOCK), l16, st, (const __bf16 *)nullptr,
+                                   (const __bf16 *)nullptr, (const __bf16 *)h->d_Ch, (const __bf16 *)h->d_Cl, h->d_cn_pad, (const double *)nullptr, d_cell,
+                                   h->ws_amb.p, h->cnorm_max, h->cn_max, h->Cp, h->Dp, (long long)n, dX, h->D, h->ws_aidx.p, h->ws_aidx.p + n);
+            } else {
+                HIPCK(h->ws_Qh.reserve((size_t)n * h->Dp));
+                HIPCK(h->ws_Ql.reserve((size_t)n * h->Dp));
+                hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)((n + 3) / 4)), dim3(MMIDX_BLOCK), 0, st, dX, (__bf16 *)h->ws_Qh.p, (__bf16 *)h->ws_Ql.p,
+                                   (float *)nullptr, h->ws_qn.p, h->D, h->Dp, (long long)n);
+                HIPCK(hipFuncSetAttribute((const void *)k_assign_gmin16_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l16));
+                hipLaunchKernelGGL(k_assign_gmin16_t<false>, dim3((unsigned)((n + G16_BQ - 1) / G16_BQ)), dim3(MMIDX_BLOCK), l16, st, (const __bf16 *)h->ws_Qh.p,
+                                   (const __bf16 *)h->ws_Ql.p, (const __bf16 *)h->d_Ch, (const __bf16 *)h->d_Cl, h->d_cn_pad, h->ws_qn.p, d_cell,
+                                   h->ws_amb.p, h->cnorm_max, h->cn_max, h->Cp, h->Dp, (long long)n, (const double *)nullptr, h->D, h->ws_aidx.p,
+                                   h->ws_aidx.p + n);
+            }
         } else {
             hipLaunchKernelGGL(k_query_prep, dim3((unsigned)((n + 3) / 4)), dim3(MMIDX_BLOCK), 0, st, dX, h->ws_Q32.p, h->ws_qn.p, h->D, (long long)n);
             HIPCK(hipFuncSetAttribute((const void *)k_assign_approx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)asg_lds));
@@ -533,26 +544,28 @@ int assign_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_cell, 
                                h->ws_Q32.p, h->d_cn, h->ws_qn.p, d_cell, h->ws_amb.p, h->cnorm_max, h->cn_max, h->C, h->D, (long long)n);
         }
         HIPCK(hipGetLastError());
-        std::vector<unsigned char> amb((size_t)n);
-        HIPCK(hipMemcpyAsync(amb.data(), h->ws_amb.p, (size_t)n, hipMemcpyDeviceToHost, st));
+        // the flagged vectors (second - best within the certified error: ~1e-4 of them) are listed ON THE DEVICE and only their
+        // number travels to the host -- the flags themselves (a byte per vector: 10 MB per 10 M SURF descriptors of a VLAD call,
+        // 100 MB per 100 M indexed vectors) used to be copied out and scanned by one host thread
+        int32_t *d_na = h->ws_aidx.p + n;
+        if (!split16) {  // (the fp32-MFMA kernel only writes flags; the bf16-split kernels list the flagged vectors themselves)
+            hipLaunchKernelGGL(k_compact_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->ws_amb.p, (long long)n, h->ws_aidx.p, d_na);
+            HIPCK(hipGetLastError());
+        }
+        int32_t na32 = 0;
+        HIPCK(hipMemcpyAsync(&na32, d_na, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
-        std::vector<int32_t> idx;
-        for (int64_t i = 0; i < n; i++)
-            if (amb[(size_t)i]) idx.push_back((int32_t)i);
-        h->last_ambiguous = (int64_t)idx.size();
-        if (!idx.empty()) {
-            const int64_t na = (int64_t)idx.size();
-            HIPCK(h->ws_aidx.reserve((size_t)na));
+        h->last_ambiguous = (int64_t)na32;
+        if (na32 > 0) {
+            const int64_t na = (int64_t)na32;
             HIPCK(h->ws_acell.reserve((size_t)na));
             HIPCK(h->ws_Xa.reserve((size_t)na * h->D));
-            HIPCK(hipMemcpyAsync(h->ws_aidx.p, idx.data(), (size_t)na * 4, hipMemcpyHostToDevice, st));
             const long long tot = (long long)na * h->D;
             hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dX, h->ws_aidx.p, h->ws_Xa.p, h->D, (long long)na);
             hipLaunchKernelGGL(k_assign_coarse<QT>, dim3((unsigned)((na + QT - 1) / QT)), dim3(MMIDX_BLOCK), 0, st, h->d_coarseT, h->ws_Xa.p,
                                h->ws_acell.p, h->C, h->D, (long long)na);
             hipLaunchKernelGGL(k_scatter_cells, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, st, h->ws_aidx.p, h->ws_acell.p, d_cell, (long long)na);
             HIPCK(hipGetLastError());
-            HIPCK(hipStreamSynchronize(st));  // idx (host) must outlive the copy
         }
     } else if (ivf) {
         constexpr int QT = 16;
@@ -2866,7 +2879,7 @@ int mmidx_assign_device(mmidx_index *h, int64_t n, const double *dX, int32_t *d_
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     DeviceCall call(h, st);
-    const int64_t step = 1 << 22;  // bounded scratch for the certified approximate path
+    const int64_t step = std::max<int64_t>(1 << 20, ((int64_t)1 << 29) / std::max(h->Dp, 32));  // bounded scratch for the certified approximate path
     for (int64_t i0 = 0; i0 < n; i0 += step) {
         const int64_t nb = std::min(step, n - i0);
         rc = assign_device(h, nb, dX + (size_t)i0 * h->D, d_cell_out + i0, st);
@@ -3262,6 +3275,11 @@ struct mmidx_vlad {
     hipStream_t stream = nullptr;
     DevBuf<double> ws_desc, ws_out;
     DevBuf<long long> ws_off;
+    // K8': the assignment of every descriptor of a launch through the encoder's certified MFMA argmin -- one hidden index handle
+    // per vocabulary whose "coarse quantizer" is the vocabulary
+    std::vector<mmidx_index *> asg;
+    DevBuf<int32_t> ws_nn;
+    int exact = 0;  // option "exact" / MMIDX_VLAD_EXACT=1: the one-kernel form (k_vlad: fp64 brute-force assignment inside the block)
 };
 
 extern "C" {
@@ -3377,14 +3395,36 @@ int mmidx_vlad_create(int nvocab, const int32_t *ncent, int dl, const double *co
     HIPCK(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
     HIPCK(hipMalloc((void **)&v->d_cb, tot * 8));
     HIPCK(hipMemcpy(v->d_cb, codebooks, tot * 8, hipMemcpyHostToDevice));
+    v->exact = getenv("MMIDX_VLAD_EXACT") ? 1 : 0;
+    for (int i = 0; i < nvocab; i++) {  // (a vocabulary the assignment kernels cannot take leaves its slot empty: k_vlad serves it)
+        mmidx_index *a = nullptr;
+        if (ncent[i] >= 2 && mmidx_create(MMIDX_KIND_IVFPQ, dl, 1, 2, ncent[i], MMIDX_TR_NONE, nullptr, nullptr, device, &a) == MMIDX_OK &&
+            mmidx_set_coarse(a, codebooks + v->cb_off[(size_t)i]) != MMIDX_OK) {
+            mmidx_destroy(a);
+            a = nullptr;
+        }
+        v->asg.push_back(a);
+    }
     *out = v;
     return MMIDX_OK;
+}
+
+int mmidx_vlad_set_option(mmidx_vlad *v, const char *name, int value) {
+    if (!v || !name) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    if (std::string(name) == "exact") {
+        v->exact = value != 0;
+        return MMIDX_OK;
+    }
+    return fail(MMIDX_ERR_INVALID_ARG, "unknown option '%s'", name);
 }
 
 int mmidx_vlad_destroy(mmidx_vlad *v) {
     if (!v) return MMIDX_OK;
     (void)hipSetDevice(v->device);
     if (v->d_cb) (void)hipFree(v->d_cb);
+    for (mmidx_index *a : v->asg)
+        if (a) mmidx_destroy(a);
+    v->ws_nn.release();
     v->ws_desc.release();
     v->ws_out.release();
     v->ws_off.release();
@@ -3414,8 +3454,33 @@ int mmidx_vlad_aggregate_device(mmidx_vlad *v, int64_t nimg, const int64_t *d_de
     HIPCK(hipSetDevice(v->device));
     hipStream_t st = (hipStream_t)stream;
     const int maxnd = (std::max(max_desc, 2) + 1) & ~1;
+    long long ndesc = -1;  // descriptors of the launch (read back once when the assignment runs as its own stage)
     for (int i = 0; i < v->nvocab; i++) {
         const int nc = v->nc[(size_t)i];
+        if (!v->exact && v->asg[(size_t)i] && d_descs) {
+            // K8': nearest centroid of EVERY descriptor on the matrix cores (certified, exact redo of the flagged few), then one
+            // block per image for the ordered accumulation
+            if (ndesc < 0) {
+                HIPCK(hipMemcpyAsync(&ndesc, d_desc_off + nimg, sizeof(long long), hipMemcpyDeviceToHost, st));
+                HIPCK(hipStreamSynchronize(st));
+                HIPCK(v->ws_nn.reserve((size_t)std::max<long long>(ndesc, 1)));
+            }
+            if (ndesc > 0) {
+                int rca = mmidx_assign_device(v->asg[(size_t)i], ndesc, d_descs, v->ws_nn.p, st);
+                if (rca) return rca;
+                HIPCK(hipSetDevice(v->device));
+            }
+            const size_t lds2 = 2 * (size_t)maxnd * 4 + (size_t)((nc + 2) & ~1) * 4 + 32;
+            if (lds2 > 64 * 1024) return fail(MMIDX_ERR_UNSUPPORTED, "%d descriptors per image exceed the accumulation kernel's LDS", max_desc);
+            if (v->dl == 64)
+                hipLaunchKernelGGL(k_vlad_accum<64>, dim3((unsigned)nimg), dim3(256), lds2, st, v->d_cb + v->cb_off[(size_t)i], nc, v->dl, maxnd, v->ws_nn.p,
+                                   (const long long *)d_desc_off, d_descs, d_out, v->veclen, (int)v->cb_off[(size_t)i], v->norms);
+            else
+                hipLaunchKernelGGL(k_vlad_accum<0>, dim3((unsigned)nimg), dim3(256), lds2, st, v->d_cb + v->cb_off[(size_t)i], nc, v->dl, maxnd, v->ws_nn.p,
+                                   (const long long *)d_desc_off, d_descs, d_out, v->veclen, (int)v->cb_off[(size_t)i], v->norms);
+            HIPCK(hipGetLastError());
+            continue;
+        }
         const size_t lds = (size_t)nc * v->dl * 8 + 2 * (size_t)maxnd * 4 + (size_t)((nc + 2) & ~1) * 4 + 32;
         if (lds > 160 * 1024)
             return fail(MMIDX_ERR_UNSUPPORTED, "codebook %d x %d plus %d descriptors per image exceed the 160 KiB LDS", nc, v->dl, max_desc);

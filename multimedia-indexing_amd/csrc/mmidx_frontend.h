@@ -278,6 +278,84 @@ __global__ __launch_bounds__(256) void k_vlad(const double *__restrict__ codeboo
     for (int e = tid; e < veclen; e += 256) vout[e] = (norm == 0.0) ? 1.0 : vout[e] / norm;
 }
 
+// K8': VLAD with the nearest centroids already known (nn[descriptor], from the encoder's certified bf16-MFMA assignment over ALL
+// descriptors of the launch: k_split_bf16 + k_assign_gmin16 + exact redo of the flagged few, first index wins as AFA:136-155).
+// One block per image: phases 2-4 of k_vlad -- the stable per-centroid descriptor lists, the accumulation in DESCRIPTOR ORDER
+// (VladAggregator.java:63-68: the raw VLAD vector is bit-exact), power + L2.  The codebook is read from global memory once per
+// element (coalesced), so the block's LDS is three small integer arrays and a CU holds many images.
+template <int DL>
+__global__ __launch_bounds__(256) void k_vlad_accum(const double *__restrict__ codebook, int nc, int dl_rt, int maxnd, const int32_t *__restrict__ nn_g,
+                                                    const long long *__restrict__ desc_off, const double *__restrict__ descs,
+                                                    double *__restrict__ out, int out_stride, int out_shift, int norms_on) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int dl = DL > 0 ? DL : dl_rt;
+    int *nn = (int *)smem;                       // [maxnd]
+    int *lst = nn + maxnd;                       // [maxnd] descriptors grouped by centroid
+    int *cstart = lst + maxnd;                   // [nc + 1]
+    double *red = (double *)(cstart + ((nc + 2) & ~1));  // [4]
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const long long d0 = desc_off[img];
+    const int nd = (int)(desc_off[img + 1] - d0);
+    const double *D = descs + (size_t)d0 * dl;
+    double *vout = out + (size_t)img * out_stride + out_shift;
+    const int veclen = nc * dl;
+    for (int d = tid; d < nd; d += 256) {
+        const int c = nn_g[d0 + d];
+        nn[d] = c < 0 ? 0 : (c < nc ? c : nc - 1);
+    }
+    for (int c = tid; c <= nc; c += 256) cstart[c] = 0;
+    __syncthreads();
+    // phase 2: counts (LDS atomics: order does not matter) -> starts -> stable fill (a thread per centroid walks the image's
+    // assignments in descriptor order: broadcast LDS reads)
+    for (int d = tid; d < nd; d += 256) atomicAdd(cstart + nn[d] + 1, 1);
+    __syncthreads();
+    if (tid == 0) {
+        cstart[0] = 0;
+        for (int c = 0; c < nc; c++) cstart[c + 1] += cstart[c];
+    }
+    __syncthreads();
+    for (int c = tid; c < nc; c += 256) {
+        int p = cstart[c];
+        for (int d = 0; d < nd; d++)
+            if (nn[d] == c) lst[p++] = d;
+    }
+    __syncthreads();
+    // phase 3: thread <-> (centroid, dim): a wave reads whole descriptor rows (coalesced), in descriptor order
+    double ss = 0.0;
+    for (int e = tid; e < veclen; e += 256) {
+        const int c = e / dl, i = e - c * dl;
+        const double cv = codebook[e];
+        double v = 0.0;
+        // (four descriptor rows requested together, added in descriptor order: the same additions, more loads in flight)
+        int p = cstart[c];
+        const int pe = cstart[c + 1];
+        for (; p + 4 <= pe; p += 4) {
+            const double a0 = D[(size_t)lst[p] * dl + i], a1 = D[(size_t)lst[p + 1] * dl + i], a2 = D[(size_t)lst[p + 2] * dl + i],
+                         a3 = D[(size_t)lst[p + 3] * dl + i];
+            v += a0 - cv;
+            v += a1 - cv;
+            v += a2 - cv;
+            v += a3 - cv;
+        }
+        for (; p < pe; p++) v += D[(size_t)lst[p] * dl + i] - cv;
+        if (norms_on) {
+            const double a = sqrt(fabs(v));  // normalizePower(0.5): signum(v) * pow(|v|, 0.5)   (Normalization.java:74-79)
+            v = (v > 0.0) ? a : ((v < 0.0) ? -a : v);
+            ss += v * v;
+        }
+        vout[e] = v;
+    }
+    if (!norms_on) return;
+    // phase 4: L2 over the sub-vector (zero norm -> ones)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const double norm = sqrt(red[0] + red[1] + red[2] + red[3]);
+    __syncthreads();
+    for (int e = tid; e < veclen; e += 256) vout[e] = (norm == 0.0) ? 1.0 : vout[e] / norm;
+}
+
 // L2 over the concatenation when more than one vocabulary (VladAggregatorMultipleVocabularies.java:97-99)
 __global__ __launch_bounds__(256) void k_rows_normalize_l2_block(double *__restrict__ Y, int len) {
     __shared__ double red[4];

@@ -1513,11 +1513,17 @@ __global__ __launch_bounds__(MMIDX_BLOCK, 2) void k_coarse_gmin16_dma_kc(const _
 // smallest and second smallest d~ (and the index of the smallest) over the columns it holds for each of its rows, the 16
 // lanes of a row are merged at the end (DPP), and the vector is certified when second - best > 2 eps16 -- otherwise
 // (exact ties included) it is flagged and the exact fp64 kernel redoes it, exactly as with K6a.
-__global__ __launch_bounds__(MMIDX_BLOCK, 2) void k_assign_gmin16(const __bf16 *__restrict__ Xh, const __bf16 *__restrict__ Xl,
-                                                               const __bf16 *__restrict__ Ch, const __bf16 *__restrict__ Cl,
-                                                               const double *__restrict__ cn, const double *__restrict__ xn,
-                                                               int32_t *__restrict__ cell_out, unsigned char *__restrict__ amb,
-                                                               double cnorm_max, double cn_max, int Cp, int Dp, long long n) {
+// FROMX: the vectors come straight from their fp64 rows X[n][D] (D a multiple of 8, one k chunk: D <= 128) -- head / tail split and
+// squared norms in registers -- instead of from k_split_bf16's copies: one pass over the input instead of a 1.5 x larger round trip
+// through HBM (VLAD assigns ten million 64-d descriptors per call, the encoder two million 128-d vectors per chunk).
+template <bool FROMX>
+__global__ __launch_bounds__(MMIDX_BLOCK, 2) void k_assign_gmin16_t(const __bf16 *__restrict__ Xh, const __bf16 *__restrict__ Xl,
+                                                                 const __bf16 *__restrict__ Ch, const __bf16 *__restrict__ Cl,
+                                                                 const double *__restrict__ cn, const double *__restrict__ xn,
+                                                                 int32_t *__restrict__ cell_out, unsigned char *__restrict__ amb,
+                                                                 double cnorm_max, double cn_max, int Cp, int Dp, long long n,
+                                                                 const double *__restrict__ X, int D, int32_t *__restrict__ aidx,
+                                                                 int32_t *__restrict__ acount) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *Bh = smem, *Bl = smem + G16_BC * G16_STRIDE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1526,15 +1532,55 @@ __global__ __launch_bounds__(MMIDX_BLOCK, 2) void k_assign_gmin16(const __bf16 *
     const int ntiles = Cp / G16_BC;
     const int nkc = (Dp + G16_KC - 1) / G16_KC;
     float xn_r[2][4];
+    [[maybe_unused]] double xrow[2] = {0.0, 0.0};  // FROMX: ||x||^2 (rounded up) of row rt * 16 + fr, in all four lanes that share fr
+    if constexpr (!FROMX) {
 #pragma unroll
-    for (int rt = 0; rt < 2; rt++)
+        for (int rt = 0; rt < 2; rt++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const long long q = q0 + rt * 16 + 4 * fg + r;
-            xn_r[rt][r] = q < n ? (float)xn[q] : 0.0f;
-        }
+            for (int r = 0; r < 4; r++) {
+                const long long q = q0 + rt * 16 + 4 * fg + r;
+                xn_r[rt][r] = q < n ? (float)xn[q] : 0.0f;
+            }
+    }
     bf16x8 ah[2][4], al[2][4];
     auto load_a = [&](int kc) {
+        if constexpr (FROMX) {
+#pragma unroll
+            for (int rt = 0; rt < 2; rt++) {
+                long long q = q0 + rt * 16 + fr;
+                q = q < n ? q : n - 1;
+                double pn = 0.0;
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) {
+                    const int k = ks * 32 + fg * 8;
+                    if (k < D) {  // (D a multiple of 8: a lane's eight values are all inside the row or all padding)
+                        const double2 *xp = (const double2 *)(X + (size_t)q * D + k);
+                        const double2 v0 = xp[0], v1 = xp[1], v2 = xp[2], v3 = xp[3];
+                        const double vv[8] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y};
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            const float f = (float)vv[e];
+                            const __bf16 hh = (__bf16)f;
+                            ah[rt][ks][e] = hh;
+                            al[rt][ks][e] = (__bf16)(f - (float)hh);  // f - head is exact in fp32
+                            pn += vv[e] * vv[e];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            ah[rt][ks][e] = (__bf16)0.0f;
+                            al[rt][ks][e] = (__bf16)0.0f;
+                        }
+                    }
+                }
+                pn += __shfl_xor(pn, 16);
+                pn += __shfl_xor(pn, 32);
+                xrow[rt] = pn * (1.0 + 1e-12);  // only ever used inside error bounds: round up (as k_split_bf16)
+#pragma unroll
+                for (int r = 0; r < 4; r++) xn_r[rt][r] = (float)__shfl(xrow[rt], 4 * fg + r);
+            }
+            return;
+        }
 #pragma unroll
         for (int rt = 0; rt < 2; rt++) {
             long long q = q0 + rt * 16 + fr;
@@ -1686,15 +1732,19 @@ __global__ __launch_bounds__(MMIDX_BLOCK, 2) void k_assign_gmin16(const __bf16 *
                 m1 = take ? o1 : m1;
             }
             const long long q = q0 + rt * 16 + 4 * fg + r;
+            double xnd_x = 0.0;
+            if constexpr (FROMX) xnd_x = __shfl(xrow[rt], 4 * fg + r);
             if (fr == 0 && q < n) {
-                const double xnd = xn[q];
+                const double xnd = FROMX ? xnd_x : xn[q];
                 const double xnorm = sqrt(xnd), sumn = cnorm_max + xnorm;
                 const double eps = (2.0 * 3.1 * 0x1p-16 * xnorm * cnorm_max + 2.0 * (3.0 * (double)Dp + 16.0) * 0x1p-22 * xnorm * cnorm_max +
                                     1e-12 * (cn_max + xnd) + 0x1p-21 * sumn * sumn) * (1.0 + 1e-9);
                 cell_out[q] = ix;
                 // (beyond 1e37 the fp32 quantities above may have overflowed -- an infinite dot product would even make a
                 //  far centroid look nearest: such vectors go to the exact kernel)
-                amb[q] = (((double)m2 - (double)m1) > 2.0 * eps && sumn * sumn < 1e37) ? 0 : 1;  // inf - x = inf > ... when there is one centroid
+                const bool sure = ((double)m2 - (double)m1) > 2.0 * eps && sumn * sumn < 1e37;  // inf - x = inf > ... when there is one centroid
+                amb[q] = sure ? 0 : 1;
+                if (!sure && aidx) aidx[atomicAdd(acount, 1)] = (int32_t)q;  // (the list the exact kernel redoes: ~1e-4 of the vectors)
             }
         }
 }
@@ -4303,6 +4353,18 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_assign_approx(const float *__re
 }
 
 // compaction of the flagged vectors and write-back of their exact cells
+// indices of the set flags, any order (one atomic per wave)
+__global__ void k_compact_flags(const unsigned char *__restrict__ flag, long long n, int32_t *__restrict__ idx, int32_t *__restrict__ count) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool f = i < n && flag[i] != 0;
+    const u64 mk = __builtin_amdgcn_ballot_w64(f);
+    if (!mk) return;
+    const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)mk) - 1;
+    u32 base = 0;
+    if (lane == leader) base = (u32)atomicAdd(count, (int)__popcll(mk));
+    base = wave_read_u32(base, leader);
+    if (f) idx[base + (u32)__popcll(mk & ((1ull << lane) - 1ull))] = (int32_t)i;
+}
 __global__ void k_gather_rows(const double *__restrict__ X, const int32_t *__restrict__ idx, double *__restrict__ out, int D,
                               long long n) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;

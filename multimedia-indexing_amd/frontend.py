@@ -121,6 +121,10 @@ class VladAggregatorMultipleVocabularies:
         N.check(N.lib().mmidx_vlad_aggregate(self._h, nimg, off.ctypes.data, descs.ctypes.data, out.ctypes.data))
         return out
 
+    def set_option(self, name, value):
+        """measurement / test switch: "exact" = 1 -> the one-kernel form with the fp64 brute-force assignment"""
+        N.check(N.lib().mmidx_vlad_set_option(self._h, name.encode(), int(value)))
+
     def aggregate(self, descriptors):
         """VladAggregatorMultipleVocabularies.aggregate(double[][]), :84-101"""
         return self.aggregate_batch([descriptors])[0]

@@ -152,8 +152,15 @@ def cfg5(L, nat, mi, images_e2e=1_000_000, device=0):
         nat.check(L.mmidx_vlad_aggregate_device(hv, nimg, d_off.data_ptr(), Dd.data_ptr(), int(nd.max()), V.data_ptr(), None))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / R
+    vb = float(tot) * dl * 8
     out["vlad_surf64_128_centroids"] = {"images": nimg, "descriptors": tot, "ms": round(dt * 1e3, 3), "images_per_s": round(nimg / dt, 1),
-                                        "f64_triples_per_s": round(tot * ncent * dl / dt, 1)}
+                                        "f64_triples_per_s": round(tot * ncent * dl / dt, 1),
+                                        "roofline": {"bound": "hbm", "kernel": "k_assign_gmin16_t<true> (nearest centroid of every descriptor: bf16-split MFMA, certified, "
+                                                                             "fp64 rows split in registers) + k_vlad_accum (ordered accumulation)",
+                                                     "achieved": round(vb / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(vb / dt / 8e12, 4),
+                                                     "algorithmic_bytes_per_launch": vb, "traffic": None,
+                                                     "note": "algorithmic bytes = the descriptors once (n x 64 x 8); the two kernels each stream them (the accumulation needs "
+                                                             "every assignment of an image first), so 0.5 is this formulation's ceiling; round 3's one-kernel fp64 brute force: 0.94 M images/s"}}
     hp2 = C.c_void_p()
     mean_v = V.mean(0).cpu().numpy()
     nat.check(L.mmidx_pca_create(nc, ss, 1, mean_v.ctypes.data, eig_h.ctypes.data, Vt_h.ctypes.data, device, C.byref(hp2)))

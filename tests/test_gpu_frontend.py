@@ -33,12 +33,33 @@ def test_vlad_raw_bit_exact(mi, oracle, nc, dl):
         if len(s):
             s /= np.linalg.norm(s, axis=1, keepdims=True)
     agg = mi.VladAggregator(cb)
-    out = agg.aggregate_batch(sets)
-    assert out.shape == (len(sets), nc * dl)
-    for i, s in enumerate(sets):
-        ref = oracle.vlad_aggregate(cb, s)
-        assert np.array_equal(out[i], ref), i
-    assert np.array_equal(agg.aggregate(sets[3]), oracle.vlad_aggregate(cb, sets[3]))
+    for exact in (0, 1):  # 0: nearest centroids by the certified bf16-MFMA argmin over all descriptors of the call; 1: fp64 brute force in the block
+        agg.set_option("exact", exact)
+        out = agg.aggregate_batch(sets)
+        assert out.shape == (len(sets), nc * dl)
+        for i, s in enumerate(sets):
+            ref = oracle.vlad_aggregate(cb, s)
+            assert np.array_equal(out[i], ref), (exact, i)
+        assert np.array_equal(agg.aggregate(sets[3]), oracle.vlad_aggregate(cb, sets[3]))
+    agg.close()
+
+
+def test_vlad_assignment_ties_first_centroid_wins(mi, oracle):
+    """computeNearestCentroid (AFA:136-155) updates on `<` only: of several equally near centroids the FIRST wins.  Duplicate
+    centroids and descriptors that coincide with centroids: the MFMA assignment cannot certify those and redoes them in fp64."""
+    rng = np.random.default_rng(9)
+    nc, dl = 64, 64
+    cb = rng.standard_normal((nc, dl))
+    cb[40] = cb[3]
+    cb[41] = cb[3]
+    cb[10] = cb[50]
+    sets = [np.concatenate([cb[[3, 50, 7]], cb[3:4] + 1e-9, rng.standard_normal((200, dl))]), cb[[40, 41, 10, 50]].copy()]
+    agg = mi.VladAggregator(cb)
+    for exact in (0, 1):
+        agg.set_option("exact", exact)
+        out = agg.aggregate_batch(sets)
+        for i, s in enumerate(sets):
+            assert np.array_equal(out[i], oracle.vlad_aggregate(cb, s)), (exact, i)
     agg.close()
 
 
