@@ -196,6 +196,7 @@ struct mmidx_index {
     bool no_seed = true;        // MMIDX_SEED=1: pass A with the seeded scan K3s (measured slower than K3: 1.45 vs 1.22 ms
                                 // per 8192 queries -- one block per query is latency-bound, not LDS-bound; kept for study)
     double rmax = 0.0;       // sqrt(sum_s max_j ||pq[s][j]||^2) * (1 + 1e-12)
+    double rot_shrink = 0.0; // RandomRotation: |v R| >= rot_shrink |v| for every v (0: the matrix is too far from orthogonal to say)
     // K3g (grouped pass B, mmidx_scan_grp.h): fp32 copy of the codebook (entry index innermost), ||p||^2 and their maxima
     float *d_pq32T = nullptr, *d_pn32 = nullptr;
     double *d_pnmax = nullptr;
@@ -298,6 +299,7 @@ struct mmidx_index {
     int mfma_qcap = 0;                 // option "mfma_qcap": survivor records per launch (0 = sized from the call; tests force the redo path)
     int mfma_blocks = 0;               // option "mfma_blocks": persistent blocks (0 = occupancy x CUs)
     DevBuf<uint4> ws_surv;
+    DevBuf<double> ws_R;               // RandomRotation: the kept pairs' exact rotated residuals [pairs][D]
     DevBuf<u32> ws_mfctl, ws_psnap;
     DevBuf<unsigned char> ws_redo;
     void *d_grpx = nullptr, *pin_grpx = nullptr;  // K3g's GrpExtra on the device and its pinned mirror
@@ -1093,7 +1095,7 @@ int launch_grouped_common(mmidx_index *h, const ScanParams &S, ScanParams F, con
 // index-side tables: the fp16 codebook (per quantizer) and ||x||^2 of every stored code (per CSR build)
 int build_mfma_tables(mmidx_index *h) {
     const bool shape_ok = (h->kind == MMIDX_KIND_IVFPQ || h->kind == MMIDX_KIND_PQ) && h->code_bytes == 1 && h->ks <= 256 && h->pq_set &&
-                          (h->dsub == 8 || h->dsub == 16) && (h->D == 32 || h->D == 64 || h->D == 128) && h->transform != MMIDX_TR_ROTATION;
+                          (h->dsub == 8 || h->dsub == 16) && (h->D == 32 || h->D == 64 || h->D == 128);
     if (!shape_ok) {
         h->mfma_ok = false;
         return MMIDX_OK;
@@ -1210,11 +1212,21 @@ int launch_mfma_common(mmidx_index *h, const ScanParams &S, ScanParams F, const 
         if (S.ivf) MP.S.coarse = h->d_coarseP;
     }
     MP.S.perm = nullptr;
+    MP.R = nullptr;
+    if (h->transform == MMIDX_TR_ROTATION) {
+        // the pairs' exact rotated residuals, once per call (16 k multiply-adds per pair at D = 128 instead of one per survivor)
+        if (!h->d_rot || (size_t)npairs * h->D * 8 > ((size_t)8 << 30)) return 1;
+        HIPCK(h->ws_R.reserve((size_t)npairs * h->D));
+        hipLaunchKernelGGL(k_pair_rotate, dim3((unsigned)((npairs + 7) / 8)), dim3(128), 8 * (size_t)h->D * sizeof(double), st, S.Q, S.coarse, h->d_rot, S.cells,
+                           S.order, S.n_order, (long long)npairs, S.w, h->D, S.ivf, h->ws_R.p);
+        HIPCK(hipGetLastError());
+        MP.R = h->ws_R.p;
+        MP.flat_lut = nullptr;  // (k_flat_lut knows permutations only: the survivors' entries come from the rotated rows)
+    }
     MP.pq16 = h->d_pq16;
     MP.xn = h->xn.p;
     MP.pq = h->d_pq;
-    MP.flat_lut = flat_lut;
-    MP.R = nullptr;
+    if (h->transform != MMIDX_TR_ROTATION) MP.flat_lut = flat_lut;
     MP.gdesc = h->ws_gdesc.p;
     MP.n_groups = h->ws_gfb.p;
     MP.sub = sub;
@@ -1683,7 +1695,8 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
             PB.rmax = h->rmax;
             PB.D = h->D;
             PB.C = h->C;
-            PB.enabled = (h->transform != MMIDX_TR_ROTATION && !h->no_bound) ? 1 : 0;
+            PB.enabled = ((h->transform != MMIDX_TR_ROTATION || h->rot_shrink > 0.0) && !h->no_bound) ? 1 : 0;
+            PB.shrink = h->transform == MMIDX_TR_ROTATION ? h->rot_shrink : 1.0;
             const unsigned g = (unsigned)((npairs + 255) / 256);
             DBG_SYNC("pair memset");
             if (h->debug_sync) {
@@ -2072,6 +2085,20 @@ int mmidx_create(int kind, int D, int m, int ks, int C, int transform, const int
     } else if (transform == MMIDX_TR_ROTATION) {
         HIPCK(hipMalloc((void **)&h->d_rot, (size_t)D * D * sizeof(double)));
         HIPCK(hipMemcpy(h->d_rot, rot, (size_t)D * D * sizeof(double), hipMemcpyHostToDevice));
+        // The matrix is an input (EJML's createOrthogonal stream cannot be reproduced: SURVEY 8c): how far is it from orthogonal?
+        // v -> v R keeps lengths up to |v| sqrt(||R R^T - I||_2) <= |v| sqrt(D max|R R^T - I|): with that measured, the coarse bound
+        // (which compares ||c - q|| with the codes' norms in the ROTATED space) applies with a margin instead of being switched off.
+        if (D <= 512) {
+            double emax = 0.0;
+            for (int i = 0; i < D; i++)
+                for (int j = i; j < D; j++) {
+                    double a = 0.0;
+                    for (int t = 0; t < D; t++) a += rot[(size_t)i * D + t] * rot[(size_t)j * D + t];
+                    emax = std::max(emax, std::fabs(a - (i == j ? 1.0 : 0.0)));
+                }
+            const double dev = emax * D;
+            if (dev < 1e-6) h->rot_shrink = 1.0 - 2.0 * dev - 1e-12;  // |v R| >= |v| sqrt(1 - dev) >= |v| (1 - dev)
+        }
     }
     h->h_off.assign((size_t)h->nlists + 1, 0);
     {
@@ -2179,6 +2206,7 @@ int mmidx_destroy(mmidx_index *h) {
     if (h->d_pn64) (void)hipFree(h->d_pn64);
     h->xn.release();
     h->ws_surv.release();
+    h->ws_R.release();
     h->ws_mfctl.release();
     h->ws_psnap.release();
     h->ws_redo.release();

@@ -3526,6 +3526,7 @@ struct PairBound {
     double rmax;           // sqrt(sum_s max_j ||pq[s][j]||^2) * (1 + 1e-12)
     int D, C;
     int enabled;
+    double shrink;         // RandomRotation: lengths shrink by at most this factor under the (nearly orthogonal) matrix; 1 otherwise
 };
 // Written branch-free on purpose: with early returns hipcc (ROCm 7.2) sank the zero-extension of
 // the cell index into a divergent region and the later atomicAdd(cnt + c) used a garbage high
@@ -3546,7 +3547,7 @@ __device__ __forceinline__ bool pair_keep(const PairBound &B, long long e, int q
             cd += df * df;
         }
     }
-    const double r = sqrt(cd) * (1.0 - 1e-12);
+    const double r = sqrt(cd) * (1.0 - 1e-12) * B.shrink;
     const double gap = r - B.rmax;
     const double lb = gap * gap * (1.0 - 1e-9);
     const bool prune = (B.enabled != 0) & (T < 0x7FF0000000000000ull) & (gap > 0.0) & (lb > keyd(T));

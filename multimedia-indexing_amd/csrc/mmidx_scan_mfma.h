@@ -138,6 +138,43 @@ __global__ void k_code_norms(const unsigned char *__restrict__ codes, const doub
     xn[i] = (float)a;
 }
 
+// RandomRotation (RandomRotation.java:44-49: out = v (1 x D) . R (D x D), sequential over the row index): the exact transformed
+// residuals of the pairs pass B kept, R[slot][j] = sum_i (c - q)[i] rot[i][j], i ascending from 0.0 -- the order of the oracle and
+// of query_vector() in mmidx_kernels.h.  Eight pairs per block share every load of the matrix (128 KiB at D = 128: L2-resident);
+// thread j owns output column j.  K3m reads its fp16 operands AND the survivors' exact entries from these rows.
+__global__ __launch_bounds__(128) void k_pair_rotate(const double *__restrict__ Q, const double *__restrict__ coarse, const double *__restrict__ rot,
+                                                     const int32_t *__restrict__ cells, const int32_t *__restrict__ order, const int32_t *__restrict__ n_order,
+                                                     long long n_flat, int w, int D, int ivf, double *__restrict__ R) {
+    extern __shared__ double s_r[];  // [8][D]
+    const long long n = n_order ? (long long)*n_order : n_flat;
+    const long long s0 = (long long)blockIdx.x * 8;
+    if (s0 >= n) return;
+    const int np = (int)(n - s0 < 8 ? n - s0 : 8);
+    for (int idx = threadIdx.x; idx < 8 * D; idx += 128) {
+        const int pi = idx / D, i = idx - pi * D;
+        const long long sl = s0 + (pi < np ? pi : np - 1);
+        const int e = order[sl];
+        const int q = e / w;
+        const int cell = ivf ? cells[e] : 0;
+        const double cv = coarse[(size_t)(cell < 0 ? 0 : cell) * D + i], qv = Q[(size_t)q * D + i];
+        s_r[idx] = ivf ? cv - qv : qv - cv;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < D; j += 128) {
+        double acc[8];
+#pragma unroll
+        for (int p = 0; p < 8; p++) acc[p] = 0.0;
+        for (int i = 0; i < D; i++) {
+            const double m = rot[(size_t)i * D + j];
+#pragma unroll
+            for (int p = 0; p < 8; p++) acc[p] += s_r[p * D + i] * m;
+        }
+#pragma unroll
+        for (int p = 0; p < 8; p++)
+            if (p < np) R[(size_t)(s0 + p) * D + j] = acc[p];
+    }
+}
+
 // largest float <= x
 __device__ __forceinline__ float mf_float_down(double x) {
     float f = (float)x;

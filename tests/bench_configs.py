@@ -132,6 +132,68 @@ def run_all():
                             "cpu_qps": round(cpu_qps, 1), "cpu_threads": cpu_nt}
     ix.close()
 
+    # ---- the same shape behind a RandomRotation (IVFPQ.java:420-421, RandomRotation.java:44-49), cells that overlap (sigma 0.6) so that
+    #      far probes are really scanned: pass B through K3m on the pairs' exact rotated residuals, coarse bound with its measured margin
+    base, mu = synth.mixture(N, D, C_, sigma=0.6, seed=77)
+    rot = np.linalg.qr(rng.standard_normal((D, D)))[0]
+    ix = mi.IVFPQ(D, N, False, "", m, ks, 1, C_, 512, rot=rot)
+    ix.loadCoarseQuantizer(mu)
+    cell = ((base[:40000] * base[:40000]).sum(1)[:, None] - 2 * base[:40000] @ mu.T + (mu * mu).sum(1)[None]).argmin(1)
+    resid = (mu[cell] - base[:40000]) @ rot
+    pq = np.stack([synth.kmeans(resid[:, s * 8:(s + 1) * 8], ks, iters=4, seed=s) for s in range(m)])
+    ix.loadProductQuantizer(pq)
+    ix.setW(w)
+    ix.indexVectors(list(range(N)), base)
+    qi = rng.choice(N, 8192, replace=False)
+    Q = base[qi] + 0.01 * rng.standard_normal((8192, D))
+    qps, iid, dd, cc = timed_search(ix, Q, k)
+    ix.set_profiling(True)
+    ix.search_batch(k, Q[:4096])
+    st_ = ix.get_stats()
+    ref = o.OracleIndex(o.KIND_IVFPQ, D, m, ks, C_, transform=1, rot=rot)
+    ref.set_coarse(mu)
+    ref.set_pq(pq)
+    ref.set_w(w)
+    off, ids_e, codes_e = ix.export()
+    ref.load_lists(off, ids_e, codes_e)
+    ns = 512
+    cpu_qps, cpu_nt, (rid, rd, rc) = cpu_best(lambda nt: ref.search_batch(Q[:ns], k, nthreads=nt), ns)
+    out["ivfpq_1M_random_rotation"] = {"qps_gpu": round(qps, 1), "mixture_sigma": 0.6, "far_pairs_scanned_per_query": round(st_["passb_items_last"] / 4096, 2),
+                                       "mfma_survivors_per_query": round(st_["mfma_survivors"] / 4096, 1), "recall_at_1": float(np.mean(iid[:, 0] == qi)),
+                                       "ids_match": bool(np.array_equal(iid[:ns], rid)), "max_abs_ddist": float(np.max(np.abs(dd[:ns] - rd))),
+                                       "cpu_qps": round(cpu_qps, 1), "cpu_threads": cpu_nt}
+    ix.close()
+    del ref
+
+    # ---- a 128 x 256 product quantizer over 1024 dimensions (Example.java:74 names a pq_1024_128x8 codebook): the exact table is
+    #      256 KiB -- beyond the LDS -- so this shape takes the complete, slow kernels (table in global scratch); measured, not tuned
+    N8, D8, m8, C8, w8, k8 = 100_000, 1024, 128, 128, 8, 30
+    base8, mu8 = synth.mixture(N8, D8, C8, sigma=0.3, seed=5)
+    ix = mi.IVFPQ(D8, N8, False, "", m8, ks, 0, C8, 512)
+    ix.loadCoarseQuantizer(mu8)
+    cell = ((base8[:20000] * base8[:20000]).sum(1)[:, None] - 2 * base8[:20000] @ mu8.T + (mu8 * mu8).sum(1)[None]).argmin(1)
+    resid = mu8[cell] - base8[:20000]
+    pq8 = np.stack([synth.kmeans(resid[:, s * 8:(s + 1) * 8], ks, iters=2, seed=s) for s in range(m8)])
+    ix.loadProductQuantizer(pq8)
+    ix.setW(w8)
+    ix.indexVectors(list(range(N8)), base8)
+    qi = rng.choice(N8, 1024, replace=False)
+    Q8 = base8[qi] + 0.01 * rng.standard_normal((1024, D8))
+    qps, iid, dd, cc = timed_search(ix, Q8, k8, reps=3)
+    ref = o.OracleIndex(o.KIND_IVFPQ, D8, m8, ks, C8)
+    ref.set_coarse(mu8)
+    ref.set_pq(pq8)
+    ref.set_w(w8)
+    off, ids_e, codes_e = ix.export()
+    ref.load_lists(off, ids_e, codes_e)
+    ns = 64
+    cpu_qps, cpu_nt, (rid, rd, rc) = cpu_best(lambda nt: ref.search_batch(Q8[:ns], k8, nthreads=nt), ns)
+    out["ivfpq_100k_1024d_m128"] = {"qps_gpu": round(qps, 1), "note": "m = 128: lookup table in global scratch (slow, complete path)",
+                                    "recall_at_1": float(np.mean(iid[:, 0] == qi)), "ids_match": bool(np.array_equal(iid[:ns], rid)),
+                                    "max_abs_ddist": float(np.max(np.abs(dd[:ns] - rd))), "cpu_qps": round(cpu_qps, 1), "cpu_threads": cpu_nt}
+    ix.close()
+    del ref, base8
+
     # ---- cfg1: Linear 10k x 128, k = 10 (host pointers in and out: PCIe-inclusive)
     n1, k1 = 10000, 10
     X1 = rng.standard_normal((n1, D))

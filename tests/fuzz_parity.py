@@ -53,9 +53,12 @@ for case in range(cases):
     fused = int(rng.random() < 0.3)
     union = int(rng.choice([0, 0, -1, 1]))  # K3g: hint-driven / always / never the instances that rank the union of verified candidates
     spre = int(rng.choice([-1, 1, 1, 0]))  # K3s (certified Smin of every far pair in front of pass B's sort): hint-driven / always / never
+    nomf = int(rng.random() < 0.3)  # K3m (the matrix-core bound of pass B) off: K3g / K3f
+    mfsub = int(rng.choice([0, 0, 64, 1024]))  # K3m: codes per item (0 = sized from the call)
+    mfq = int(rng.choice([0, 0, 0, 8]))  # K3m: survivor records per launch (8: nearly every query goes through the redo path)
     # the oracle's encoder is one thread ((C + ks) x D fp64 triples per vector): keep a case near a second of it
     n = max(1, min(n, int(1.5e9 / ((C + ks) * D))))
-    desc = dict(kind=kind, D=D, m=m, ks=ks, n=n, k=k, C=C, w=w, tr=tr, dup=dup, hist=hist, v1=v1, wide=wide, nogrp=nogrp, fused=fused, union=union, spre=spre)
+    desc = dict(kind=kind, D=D, m=m, ks=ks, n=n, k=k, C=C, w=w, tr=tr, dup=dup, hist=hist, v1=v1, wide=wide, nogrp=nogrp, fused=fused, union=union, spre=spre, nomf=nomf, mfsub=mfsub, mfq=mfq)
     try:
         nb = min(n, 3000)
         if kind == "ivfpq":
@@ -86,6 +89,9 @@ for case in range(cases):
         ix.set_option("coarse_fused", fused)
         ix.set_option("no_union", union)
         ix.set_option("smin_pre", spre)
+        ix.set_option("no_mfma", nomf)
+        ix.set_option("mfma_sub", mfsub)
+        ix.set_option("mfma_qcap", mfq)
         ix.set_option("smin_valu", int(case % 3 == 0))
         ix.set_option("smin_bf16", int(case % 4 != 1))
         ix.set_option("coarse_dma_kc", int(case % 5 != 2))  # (K1e' with LDS-DMA for vectors of several 128-dimension chunks)

@@ -854,6 +854,8 @@ def test_union_instances_forced(mi, oracle, D, m, C, n, w, k, dup):
     (64, 4, 4, 16000, 3, 10, 0, 2),       # <2, 16>
     (32, 4, 7, 12000, 7, 1, 0, 1),        # <1, 8>, k = 1
     (32, 2, 3, 9000, 3, 700, 0, 1),       # <1, 16>, k = 700
+    (128, 16, 6, 24000, 6, 100, 1, 1),    # RandomRotation (an orthogonal matrix: the coarse bound applies with its measured margin)
+    (64, 8, 5, 16000, 5, 20, 3, 2),       # a "rotation" matrix that is NOT orthogonal (columns stretched): the coarse bound stays off, K3m serves it
 ])
 def test_mfma_pass_b(mi, oracle, D, m, C, n, w, k, tr, dup):
     """K3m (`k_scan_mfma` + `k_mfma_verify` + `k_mfma_redo`, csrc/mmidx_scan_mfma.h): pass B as a certified lower bound on the matrix
@@ -869,11 +871,17 @@ def test_mfma_pass_b(mi, oracle, D, m, C, n, w, k, tr, dup):
     n = len(base)
     ds = D // m
     pq = np.stack([synth.kmeans((mu[rng.integers(0, C, 3000)] - base[:3000])[:, s * ds:(s + 1) * ds], ks, iters=2, seed=s) for s in range(m)])
-    ix = mi.IVFPQ(D, n, False, "", m, ks, tr, C, 512)
+    rot = None
+    if tr in (1, 3):  # RandomRotation.java:44-49: the matrix is an input of the library
+        rot = np.linalg.qr(rng.standard_normal((D, D)))[0]
+        if tr == 3:
+            rot = rot * np.linspace(1.0, 1.3, D)[None, :]
+            tr = 1
+    ix = mi.IVFPQ(D, n, False, "", m, ks, tr, C, 512, rot=rot)
     ix.loadCoarseQuantizer(mu)
     ix.loadProductQuantizer(pq)
     ix.setW(w)
-    ref = oracle_ivfpq(oracle, {"coarse": mu, "pq": pq}, D, m, ks, C, w, tr=tr, perm=oracle.random_permutation(1, D) if tr == 2 else None)
+    ref = oracle_ivfpq(oracle, {"coarse": mu, "pq": pq}, D, m, ks, C, w, tr=tr, perm=oracle.random_permutation(1, D) if tr == 2 else None, rot=rot)
     ix.indexVectors([str(i) for i in range(n)], base)
     ref.add_vectors(base)
     Q = np.concatenate([0.5 * (base[:24] + base[100:124]), rng.standard_normal((8, D)), base[:40] + 0.01 * rng.standard_normal((40, D)), mu[:2]])
