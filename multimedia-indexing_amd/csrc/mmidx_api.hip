@@ -1196,11 +1196,9 @@ int launch_mfma_common(mmidx_index *h, const ScanParams &S, ScanParams F, const 
     HIPCK(h->ws_mfctl.reserve(16));
     size_t qcap = h->mfma_qcap > 0 ? (size_t)h->mfma_qcap : std::min<size_t>((size_t)1 << 28, std::max<size_t>((size_t)1 << 20, (size_t)nq * 2048));
     HIPCK(h->ws_surv.reserve(qcap));
-    HIPCK(hipMemsetAsync(h->ws_ghist.p, 0, (size_t)nq * 256 * sizeof(u32), st));
-    HIPCK(hipMemsetAsync(h->ws_redo.p, 0, (size_t)nq, st));
-    HIPCK(hipMemsetAsync(h->ws_mfctl.p, 0, 16 * sizeof(u32), st));
-    HIPCK(hipMemcpyAsync(h->ws_T0.p, S.T, (size_t)nq * sizeof(u64), hipMemcpyDeviceToDevice, st));
-    HIPCK(hipMemcpyAsync(h->ws_psnap.p, S.pool_cnt, (size_t)nq * sizeof(u32), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_mfma_prep, dim3((unsigned)std::min<long long>(4096, (nq * 64 + 255) / 256)), dim3(256), 0, st, (const int32_t *)h->ws_gfb.p, h->ws_ghist.p,
+                       h->ws_redo.p, h->ws_mfctl.p, S.T, h->ws_T0.p, S.pool_cnt, h->ws_psnap.p, (long long)nq);
+    HIPCK(hipGetLastError());
     MfmaParams MP{};
     MP.S = S;
     if (h->d_perm) {  // rows in transformed order: contiguous loads (the centroids once per index, the queries once per call)

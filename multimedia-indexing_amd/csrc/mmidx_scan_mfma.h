@@ -175,6 +175,24 @@ __global__ __launch_bounds__(128) void k_pair_rotate(const double *__restrict__ 
     }
 }
 
+// one launch instead of three memsets and two copies in front of the scan: the upper-bound histograms, the redo flags and the
+// control words zeroed, the thresholds and pool counters as pass A left them saved -- and nothing at all when the coarse bound left
+// pass B no pair (the separable benchmark: the 16 MB histogram memset alone was 7 us of a 1.2 ms step)
+__global__ void k_mfma_prep(const int32_t *__restrict__ n_groups, u32 *__restrict__ ghist, unsigned char *__restrict__ redo, u32 *__restrict__ ctl,
+                            const u64 *__restrict__ T, u64 *__restrict__ T0, const u32 *__restrict__ pool_cnt, u32 *__restrict__ snap, long long nq) {
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i0 < 16) ctl[i0] = 0;
+    if (*n_groups == 0) return;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    uint4 *h4 = (uint4 *)ghist;
+    for (long long i = i0; i < nq * 64; i += stride) h4[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (long long i = i0; i < nq; i += stride) {
+        redo[i] = 0;
+        T0[i] = T[i];
+        snap[i] = pool_cnt[i];
+    }
+}
+
 // largest float <= x
 __device__ __forceinline__ float mf_float_down(double x) {
     float f = (float)x;
@@ -779,6 +797,7 @@ __global__ void k_mfma_count(const MfmaParams P) {
 
 // ---- redo: the queries K3m could not serve go to K3f with pass A's pool ---------------------------------------------------
 __global__ void k_mfma_redo(const MfmaParams P, long long nq) {
+    if (*P.n_groups == 0) return;  // (nothing was scanned; the flags were not even cleared: k_mfma_prep)
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long n = P.S.n_order ? (long long)*P.S.n_order : P.npairs_flat;
     if (i < nq && P.redo[i]) {
