@@ -254,14 +254,18 @@ __device__ __forceinline__ void mf_scan_tiles(const MfmaParams &P, const mf_h8 (
     const u32 boff = (u32)((NJ * g * 8) / DSUB);              // first code byte of the lane
     const u32 lane_base = lds_cb + (u32)(NJ * g) * 4096u;
     const int ntiles = (int)((c1 - c0 + 15) >> 4);
+    // (32-bit lane offsets from the item's wave-uniform base pointers: an item spans at most 2^31 bytes of codes)
+    const unsigned char *cbase = codes + (size_t)c0 * M + boff;
+    const float *xbase = xn + c0;
+    const u32 last = (u32)(c1 - c0 - 1);
     auto load_tile = [&](int t, u32 &cw, float &xv) {
-        long long p = c0 + (long long)t * 16 + n;
-        p = p < c1 ? p : c1 - 1;
-        const unsigned char *cp = codes + (size_t)p * M + boff;
+        u32 p = (u32)t * 16u + (u32)n;
+        p = p < last ? p : last;
+        const unsigned char *cp = cbase + p * (u32)M;
         if constexpr (NB == 4) cw = *(const u32 *)cp;
         else if constexpr (NB == 2) cw = (u32) * (const unsigned short *)cp;
         else cw = (u32)*cp;
-        xv = xn[p];
+        xv = xbase[p];
     };
     u32 cw[4];
     float xv[4];
