@@ -916,7 +916,7 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
                            "traffic_source": "profiles/hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE pass of this workload, x 2 on gfx950)" if traffic_pb else None,
                            "note": "peak = dense fp16/bf16 MFMA (MI355X_MICROARCH.md); besides the matrix work a tile of 16 codes costs four random 16-byte "
                                    "LDS gathers (the decode) and ~50 vector instructions per wave (compares, addresses), which co-limit the kernel "
-                                   "(DESIGN.md 5.16)"}
+                                   "(DESIGN.md 5.3)"}
         else:
             pb_roofline = {"bound": "issue", "kernel": "k_scan_grp (pass B: grouped u8 lower-bound filter; vector-instruction issue and LDS bound, DESIGN.md 5.12)",
                            "achieved": round(pb_ach, 1), "peak": None, "unit": "GB/s of algorithmic bytes", "frac": None,

@@ -19,6 +19,10 @@ typedef unsigned int u32;
 __device__ __forceinline__ u64 dkey(double d) { return (u64)__double_as_longlong(d); }
 __device__ __forceinline__ double keyd(u64 k) { return __longlong_as_double((long long)k); }
 
+// The timing-experiment switches of rounds 1-3 (MMIDX_HIST_STOP / MMIDX_SCAN_STOP / MMIDX_SEL_STOP truncated builds, GRP_BIS,
+// GRP_TOUCH, GRP_TIMING_*, GRP_HALF_STATS, SMIN_TIMING) were removed from the kernels in round 4: what they measured is in
+// DESIGN_NOTEBOOK.md, the code in the history before commit "housekeeping: experiment switches".  What is left under #ifndef are
+// tunables with measured defaults (GRP_EPOCH, GRP_QMAX, MMIDX_K3H_PAIR ...) and K3m's MF_TIMING.
 // ------------------------------------------------------------------------------------------------
 // Block-wide bitonic sort of (key, val) pairs held in LDS, ascending by (key, val).  n must be a
 // power of two; every thread of the block must call it.
@@ -292,18 +296,6 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_reg(const double 
 #endif
 #ifndef MMIDX_LUT_PAIRS
 #define MMIDX_LUT_PAIRS 1  // table build: two adjacent entries per thread (16-byte loads)
-#endif
-#ifndef MMIDX_HIST_DEBUG
-#define MMIDX_HIST_DEBUG 0  // debug: K3h adds overflow / appended / kept totals to the fallback header
-#endif
-#ifndef MMIDX_HIST_STOP
-#define MMIDX_HIST_STOP 0  // debug: truncate k_scan_hist (1 = after the scan loop, 3 = same with no candidates, 4 = after the table build, 5 = as 3 on a synthetic table: the loop alone)
-#endif
-#ifndef MMIDX_SCAN_STOP
-#define MMIDX_SCAN_STOP 0  // debug: truncate k_scan (1 = after the LUT build, 2 = no candidate handling)
-#endif
-#ifndef MMIDX_SEL_STOP
-#define MMIDX_SEL_STOP 0  // debug: truncate k_coarse_select_approx after phase n (timing breakdown)
 #endif
 #ifndef MMIDX_TERM_PAD
 #define MMIDX_TERM_PAD 1  // row stride D + 1 doubles: the per-candidate sequential sums read LDS conflict-free
@@ -753,10 +745,6 @@ __device__ __forceinline__ void coarse_select_finish(const ApproxSel &A, const i
             }
             sum_chunk(base, nc_);
         }
-#if MMIDX_SEL_STOP == 4
-        if (tid == 0) A.cdsel[(size_t)q * w] = keyd(ckey[0]);
-        return;
-#endif
         if (n <= 64) {
             // the usual case: one wave ranks the candidates by (distance, index) in registers (readlane,
             // no LDS round trips, no barriers) and writes them back in order
@@ -802,10 +790,6 @@ __device__ __forceinline__ void coarse_select_finish(const ApproxSel &A, const i
             }
         }
         __syncthreads();
-#if MMIDX_SEL_STOP == 5
-        if (tid == 0) A.cdsel[(size_t)q * w] = keyd(sel_k[0]);
-        return;
-#endif
         // no two equal keys among the w+1 best (the usual case): the answer is the sorted prefix
         bool plain = false;
         if (w < 64 && tid < 64) {
@@ -942,10 +926,6 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_approx(const Appr
         dt[i] = v;
         lmin = v < lmin ? v : lmin;
     }
-#if MMIDX_SEL_STOP == 1
-    if (lmin < -1.0f) A.cells[(size_t)q * w] = tid;
-    return;
-#endif
     // tau: (R-th smallest per-thread minimum of d~) + eps >= the R-th smallest upper bound d~ + eps
     // R-th smallest of the 256 minima by rank counting (one barrier instead of a 36-stage sort)
     float *fmin = (float *)ckey;
@@ -965,10 +945,6 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_approx(const Appr
     __syncthreads();
     const double tau = keyd(sel_k[0]) + eps;
     __syncthreads();
-#if MMIDX_SEL_STOP == 2
-    if (tau < -1.0) A.cells[(size_t)q * w] = tid;
-    return;
-#endif
     const u64 lane_lt = (1ull << (tid & 63)) - 1ull;
     const double cut = tau + eps;  // candidate iff d~ - eps <= tau
 #pragma unroll
@@ -1846,10 +1822,6 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_grp(const ApproxS
         }
     }
     __syncthreads();
-#if MMIDX_SEL_STOP == 3
-    if (tid == 0) A.cells[(size_t)q * w] = (int)s_n4[0] + (int)cidx[0];
-    return;
-#endif
     coarse_select_finish<PER>(A, q, (int)s_n4[0], ckey, cidx, sel_k, sel_i, s_k, s_i);
 }
 
@@ -2284,10 +2256,6 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
     u64 *Tq = P.T + q;
     u64 T = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-#if MMIDX_SCAN_STOP == 1
-    if (lut[tid] < -1.0) P.pool_cnt[q] = cur[0].get(0);
-    return;
-#endif
 
     // ---- scan -----------------------------------------------------------------------------------
     const int limit = P.cap - NT * SU;
@@ -2337,16 +2305,6 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
                 d[u] = a;
             }
         }
-#if MMIDX_SCAN_STOP == 2
-        if (d[0] < -1.0) P.pool_cnt[q] = 1;
-        if constexpr (M > 0) {
-            if (more) {
-#pragma unroll
-                for (int u = 0; u < SU; u++) cur[u] = nxt[u];
-            }
-        }
-        continue;
-#endif
 #pragma unroll
         for (int u = 0; u < SU; u++) {
             const int64_t i = seg + u * NT + tid;
@@ -2508,11 +2466,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMIDX_K3H_WPS512 : 1) void k_scan_h
     }
     for (int i = tid; i < MMIDX_HB + MMIDX_HCNT; i += NT) hist[i] = 0;  // histogram and the counters
     const double *tr = query_vector(P, q, cell, vec);
-#if MMIDX_HIST_STOP == 5  // timing experiment: no table build (the loop alone, on a synthetic table)
-    for (int i = tid; i < M * ks; i += NT) lut[i] = 1e-3 * (double)((i * 37) & 255) + tr[i & 7];
-#else
     build_lut_any(lut, tr, P.pqT, M, ks, P.dsub);
-#endif
     __syncthreads();
 
     // (0.0 + x == x bit for bit: the table entries are sums of squares from +0.0, never -0.0, so the reference's
@@ -2532,10 +2486,6 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMIDX_K3H_WPS512 : 1) void k_scan_h
         for (int s = 1; s < M; s++) d += entry(cv, s);
         return d;
     };
-#if MMIDX_HIST_STOP == 4
-    if (lut[tid] == 12345.678) P.pool_cnt[q] = 1;
-    return;
-#endif
 
     // ---- segment 0: the bucket map and the first threshold bucket ---------------------------------
     // Each wave sorts its 64 distances in registers and reports its minimum and its r-th smallest,
@@ -2626,9 +2576,6 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMIDX_K3H_WPS512 : 1) void k_scan_h
     u32 *mybuf = posbuf + (size_t)wv * capw;
     u32 wcnt = 0;  // wave-uniform
     int Tb = qr_valid ? bucket(qr) : MMIDX_HB - 1;
-#if MMIDX_HIST_STOP == 3 || MMIDX_HIST_STOP == 5
-    Tb = -1;
-#endif
     // The loop is VALU-bound as much as LDS-bound (PMC: VALU ~78 % busy, LDS ~73 %), so its bookkeeping is kept in
     // scalar registers and 32-bit arithmetic: the list bounds are made wave-uniform explicitly (they come from vector
     // loads), positions are relative to c0 (chunk <= 2^24 codes: the host checks), the bucket clamp is two fp64
@@ -2678,8 +2625,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMIDX_K3H_WPS512 : 1) void k_scan_h
 #pragma unroll
             for (int u = 0; u < U; u++) fetch(nx[u], seg + (u32)(U + u) * NT + (u32)tid);
         }
-        const bool refresh = MMIDX_HIST_STOP != 3 && MMIDX_HIST_STOP != 5 &&
-                             (g < MMIDX_HREF_EARLY / U || (g < MMIDX_HREF_LATE ? (g & 1) == 0 : (g & 3) == 0));
+        const bool refresh = (g < MMIDX_HREF_EARLY / U || (g < MMIDX_HREF_LATE ? (g & 1) == 0 : (g & 3) == 0));
         uint4 hv;  // live only on refresh rounds
         if (refresh) hv = ((const uint4 *)hist)[lane];  // buckets 4*lane .. 4*lane+3
         double dd[U];
@@ -2705,10 +2651,6 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMIDX_K3H_WPS512 : 1) void k_scan_h
     }
     if (lane == 0) s_cnt[wv] = wcnt;
     __syncthreads();
-#if MMIDX_HIST_STOP == 1 || MMIDX_HIST_STOP == 3 || MMIDX_HIST_STOP == 5
-    if (Tb < -1) P.pool_cnt[q] = 1;
-    return;
-#endif
     // ---- final threshold bucket from the complete histogram (identical in every wave) ------------
     u32 kept_total;
     {
@@ -2725,14 +2667,6 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMIDX_K3H_WPS512 : 1) void k_scan_h
         overflow |= c > capw;
         woff[i + 1] = woff[i] + (c > capw ? capw : c);
     }
-#if MMIDX_HIST_DEBUG
-    const u32 n_app = woff[NT / 64];
-    if (tid == 0) {
-        atomicAdd(P.fb_count + 1, overflow ? 1u : 0u);
-        atomicAdd(P.fb_count + 2, n_app);
-        atomicAdd(P.fb_count + 3, kept_total);
-    }
-#endif
     if (kept_total > (u32)MMIDX_HKEEP) {  // block-uniform: redo this item with K3
         if (tid == 0) {
             const u32 slot = atomicAdd(P.fb_count, 1u);

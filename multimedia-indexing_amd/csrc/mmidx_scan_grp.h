@@ -35,9 +35,6 @@
 #define GRP_SEGU 2     // codes per thread per segment
 #endif
 #define GRP_SEG (GRP_NT * GRP_SEGU)
-#ifndef GRP_BIS
-#define GRP_BIS 0
-#endif
 #ifndef GRP_EPOCH
 #define GRP_EPOCH 8  // segments between two block barriers of the scan (8: hard 2.84 -> 2.91 M q/s against 4, spread unchanged; 2: -3 %)
 #endif
@@ -60,9 +57,6 @@
 #define GRP_EARLY 1  // 1: the plain instances look after every quarter of a code's sub-quantizers whether any (code, query) pair of
                      // the wave is still at or below its bound, and skip the rest of the lookups when none is (hard workload: pass B
                      // 4.86 -> 4.58 ms; 0: off; n > 1: every n sub-quantizers)
-#endif
-#ifndef GRP_TOUCH
-#define GRP_TOUCH 0  // 1: touch the code lines of the segment after next (measured: see DESIGN.md 5.12)
 #endif
 #ifndef GRP_WPS
 #define GRP_WPS 4  // waves per SIMD the register allocation is held to (blocks per CU x 2)
@@ -411,9 +405,6 @@ struct SminParams {
     double *smin;          // [ncand]
     int D, w, M;
 };
-#ifndef SMIN_TIMING
-#define SMIN_TIMING 0
-#endif
 #define SMIN_NP 32  // pairs per batch (a multiple of 4, at most 64: their results travel in the lanes of one register)
 #ifndef SMIN_NPM
 #define SMIN_NPM 64  // pairs per batch of the matrix-core form (32 or 64)
@@ -592,14 +583,6 @@ __global__ __launch_bounds__(SMIN_NW * 64, 4) void k_pair_smin_mfma(const SminPa
             const double *cc = P.coarse + (size_t)s_cell[pi] * P.D, *qq = P.Q + (size_t)s_q[pi] * P.D;
             double nr = 0.0;
             float rf[VPT];
-#if SMIN_TIMING == 2  // (timing experiment: no global loads in the residual phase; results are wrong)
-#pragma unroll
-            for (int t = 0; t < VPT; t++) {
-                const double r = (double)(d0 + t + s_cell[pi]) * 1e-3 - (double)s_q[pi] * 1e-4;
-                rf[t] = (float)r;
-                nr += r * r;
-            }
-#else
             if (P.perm) {
 #pragma unroll
                 for (int t = 0; t < VPT; t++) {
@@ -619,7 +602,6 @@ __global__ __launch_bounds__(SMIN_NW * 64, 4) void k_pair_smin_mfma(const SminPa
                     nr += r1 * r1;
                 }
             }
-#endif
 #pragma unroll
             for (int t = 0; t < VPT; t++) s_r[pi * RS + dd0 + t] = rf[t];
             nr += __shfl_xor(nr, 1);  // (the other half)
@@ -641,7 +623,7 @@ __global__ __launch_bounds__(SMIN_NW * 64, 4) void k_pair_smin_mfma(const SminPa
             for (int ks = 0; ks < KS; ks++) av[rt][ks] = s_r[(r0 + rt * 16 + lj) * RS + wv * DSUB + 4 * ks + lk];
         f32x4 mx[2];
 #pragma unroll
-        for (int cb = 0; cb < (SMIN_TIMING == 1 ? 1 : 16); cb++) {  // (SMIN_TIMING 1: one column block of sixteen; results are wrong)
+        for (int cb = 0; cb < 16; cb++) {
             const float ph = s_pnh[wv][cb * 16 + lj];
 #pragma unroll
             for (int rt = 0; rt < 2; rt++) {
@@ -1027,9 +1009,6 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
             s_tr32[idx] = (float)r;
         }
         __syncthreads();
-#if GRP_BIS == 1
-        continue;
-#endif
         // ---- (c) per (query, sub-quantizer): ||r_s||^2 and the error term of the fp32 table ----------------------
         if (tid < G * M) {
             const int i = tid / M, s = tid - i * M;
@@ -1046,9 +1025,6 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
             s_nrf[tid] = (float)nr;
         }
         __syncthreads();
-#if GRP_BIS == 2
-        continue;
-#endif
         // ---- (d) u8 rows, ONE pass over the fp32 entries: q8 = min(255, floor((entry - row minimum) * 254 / T)).  The step
         //      depends on the query's threshold only, so a row is quantised as soon as its minimum is known (a wave owns
         //      whole rows: no barrier); what depends on the other rows -- Smin = the sum of the minima -- moves into the
@@ -1085,9 +1061,6 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
             }
         }
         __syncthreads();
-#if GRP_BIS == 3
-        continue;
-#endif
         // ---- (e) per query: lower bound of the sum of minima, state, survivor bound --------------------------------------
         if (tid < G * M) {  // M lanes per query: the sums over the sub-quantizers by butterfly (M is a power of two <= 64 = a wave)
             const int qi = tid / M;
@@ -1127,9 +1100,6 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
             }
         }
         __syncthreads();
-#if GRP_BIS == 4
-        continue;
-#endif
 #pragma unroll
         for (int i = 0; i < G; i++)
             if (s_state[i] == 0) alive0 |= 1u << i;
@@ -1144,9 +1114,6 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
             atomicAdd(P.stat + 3, (unsigned long long)__popc(alive0));
         }
         if (alive0 == 0) continue;
-#if defined(GRP_TIMING_STOP_AFTER_BUILD) || GRP_BIS == 5  // (timing experiments only: results are wrong)
-        continue;
-#endif
 
         // ---- (g) filter scan ---------------------------------------------------------------------------------------
         u32 thr[G];  // (scalar registers)
@@ -1235,20 +1202,6 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
                     nxt[u].load(codes + (size_t)(p < c1 ? p : c1 - 1) * M);
                 }
             }
-#if GRP_TOUCH
-            // the segment after next: one word per 128-byte line of the wave's two chunks (64 codes x M bytes each), so that the
-            // real loads a segment from now find their lines on the way (or in the L2) instead of starting the round trip
-            [[maybe_unused]] u32 touch = 0;
-            if (GRP_SEGU == 2 && M >= 8 && seg + 2 * (int64_t)GRP_SEG < c1) {
-                const int tl = lane < M ? lane : M - 1;
-                int64_t tp = seg + 2 * (int64_t)GRP_SEG + (tl / (M / 2)) * GRP_NT + wv * 64;
-                tp = tp < c1 ? tp : c1 - 1;
-                size_t to = (size_t)tp * M + (size_t)(tl % (M / 2)) * 128;
-                const size_t tmax = (size_t)(c1 - 1) * M;
-                to = to < tmax ? to : tmax;
-                touch = *(const volatile u32 *)(codes + (to & ~(size_t)3));
-            }
-#endif
             // one code of the lane at a time: per sub-quantizer ONE table read (address = 8 x byte from one SDWA shift, row in
             // the immediate offset) brings the byte of every query of the group; the bytes are spread into 16-bit fields
             // (queries 0|2, 1|3, 4|6, 5|7: sums stay below 2^16, so plain 32-bit adds carry nothing across fields) -- about
@@ -1323,15 +1276,6 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
                             dd.v = ta.v - aa.v;
                             ng &= dd.w;
                         }
-#ifdef GRP_HALF_STATS  // (measurement only: codes of the wave with a pair still alive at this check, codes looked at)
-                        if (P.stat && sq + GRP_RW == M / 2) {
-                            const u64 al = __builtin_amdgcn_ballot_w64(p < c1 && (~ng & 0x80008000u) != 0u), vl = __builtin_amdgcn_ballot_w64(p < c1);
-                            if (lane == 0) {
-                                atomicAdd(P.stat + 7, (unsigned long long)__popcll(al));
-                                atomicAdd(P.stat + 8, (unsigned long long)__popcll(vl));
-                            }
-                        }
-#endif
                         if (!__builtin_amdgcn_ballot_w64((~ng & 0x80008000u) != 0u)) break;
                     }
 #endif
@@ -1370,13 +1314,6 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-#ifdef GRP_TIMING_NO_VERIFY
-            if (pend == 0x2345u) s_queue[1] = 1;  // (keeps the scan alive)
-            pend = 0;
-#endif
-#if GRP_TOUCH
-            asm volatile("" ::"v"(touch));  // (keeps the touch load; its data is not used)
-#endif
             // ---- survivors go to the queue at once when they fit; what does not fit waits for the epoch's barrier ----
             pendq[ej] = pend;
             if (__builtin_amdgcn_ballot_w64(pend != 0)) append_try(pendq[ej], (u32)seg);
@@ -1486,12 +1423,6 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
                     u32 full = 0;     // queries whose buffer may not take another round
 #pragma unroll
                     for (int i = 0; i < G; i++) full |= (s_ccnt[i] > (u32)(cb - GRP_VR)) ? 1u << i : 0u;
-#ifdef GRP_TIMING_NO_PRUNE  // (timing experiment: results are wrong)
-                    if (full) {
-                        if (tid < G && ((full >> tid) & 1u)) s_ccnt[tid] = 0;
-                        full = 0;
-                    }
-#endif
                     __syncthreads();  // every thread has its snapshot before this round's appends start
 #pragma unroll 1
                     for (int i = 0; i < G; i++)
@@ -1583,11 +1514,7 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
                                 {   // (the entry after the half's last one repeats it: a valid address, the value is not used)
                                     const int sn = s + 1 < 8 * x + 8 ? s + 1 : s;
                                     const u32 cn = s + 1 < 8 * x + 8 ? (u32)wrem & 0xFFu : 0u;
-#if defined(GRP_TIMING_VFY) && GRP_TIMING_VFY == 2  // (timing experiment: every codebook read hits the same line)
-                                    const double *pp = P.pq + ((u32)((sn * 0 + (int)(cn & 0u)) * DSUB) + 2u * (u32)ql);
-#else
                                     const double *pp = P.pq + ((u32)((sn * ks + (int)cn) * DSUB) + 2u * (u32)ql);
-#endif
 #pragma unroll
                                     for (int r = 0; r < R; r++) pvn[r] = *(const double2 *)(pp + 8 * r);
                                 }
@@ -1636,9 +1563,6 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
                         }
                     }
                     }
-#ifdef GRP_TIMING_VFY  // (timing experiments: nothing is accepted -- results are wrong)
-                    d += 1e300;
-#endif
                     const u64 key = dkey(d);
                     if (act && ql == 3 && key <= s_T[i]) {
                         const u32 slot = atomicAdd(s_ccnt + i, 1u);
@@ -1658,11 +1582,7 @@ __global__ __launch_bounds__(GRP_NT, M >= 64 ? 2 : GRP_WPS) void k_scan_grp(cons
 #pragma unroll 1
         for (int i = 0; i < G; i++) {
             if (!((alive0 >> i) & 1u)) continue;
-#ifdef GRP_TIMING_NO_PRUNE
-            if (s_ccnt[i] > (u32)K1) { __syncthreads(); if (tid == 0) s_ccnt[i] = (u32)K1; __syncthreads(); }
-#else
             if (s_ccnt[i] > (u32)K1) grp_prune(ckey + (size_t)i * cb, cpos + (size_t)i * cb, s_ccnt + i, s_T + i, K1, P.S.T + s_q[i]);
-#endif
             const int n = (int)s_ccnt[i];
             if (n == 0) continue;
             const int q = s_q[i];
