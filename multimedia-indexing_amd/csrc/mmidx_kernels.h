@@ -2939,7 +2939,8 @@ __device__ __forceinline__ void scan_filt_body(const ScanParams &P, const unsign
         const bool finiteT = Tn < 0x7FF0000000000000ull;
         const double Td = keyd(Tn);
         if (finiteT && !(smin_lo < Td)) return false;
-        const bool nofilter = !finiteT || !((Td - smin_lo) > Td * 0x1p-30);
+        // (a threshold in fp64's denormal range makes 254 / (T - Smin) overflow: no filter for such an item either)
+        const bool nofilter = !finiteT || !((Td - smin_lo) > Td * 0x1p-30) || !(254.0 / (Td - smin_lo) < 1e300);
         if (tid < ks) {
             const double inv = nofilter ? 0.0 : (254.0 / (Td - smin_lo)) * (1.0 - 0x1p-40);
 #pragma unroll
@@ -3274,7 +3275,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_scan_seed(const ScanParams P) {
     bool run_filter = clen > n0;
     // (if the whole chunk was covered, or no threshold exists and none can be built, skip ahead)
     double inv = 0.0, Td = keyd(T);
-    bool usable = finiteT && (smin_lo < Td) && ((Td - smin_lo) > Td * 0x1p-30);
+    bool usable = finiteT && (smin_lo < Td) && ((Td - smin_lo) > Td * 0x1p-30) && (254.0 / (Td - smin_lo) < 1e300);
     if (run_filter && finiteT && !(smin_lo < Td)) run_filter = false;  // nothing else can qualify
     if (run_filter) {
         inv = usable ? (254.0 / (Td - smin_lo)) * (1.0 - 0x1p-40) : 0.0;

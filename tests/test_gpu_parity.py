@@ -1469,3 +1469,28 @@ def test_randomised_differential_fuzz():
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, os.path.join(here, "fuzz_parity.py"), "150", "11"], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("scale,qscale", [(1e-25, 1.0), (1e-9, 1.0), (1e9, 1.0), (1e25, 1.0), (1.0, 1e6), (1e-160, 1.0), (1e140, 1.0)])
+def test_mfma_pass_b_magnitudes(mi, oracle, scale, qscale):
+    """K3m scales residuals and codebook by powers of two before the fp16 rounding (per item / per index): data 25 orders of
+    magnitude away from 1, queries far outside the data (residuals a million times the codebook's scale: the exponent difference
+    between the two scales is limited, such queries go to the redo), and magnitudes whose squares leave fp32 or fp64's normal range.
+    The bound must never drop a true neighbour: ids and distance bits are the oracle's."""
+    D, m, C, n, w, k, ks = 64, 8, 6, 12000, 6, 20, 256
+    rng = np.random.default_rng(11)
+    mu = 0.5 * rng.standard_normal((C, D))
+    base = mu[rng.integers(0, C, n)] + rng.standard_normal((n, D))
+    ds = D // m
+    pq = np.stack([synth.kmeans((mu[rng.integers(0, C, 3000)] - base[:3000])[:, s * ds:(s + 1) * ds], ks, iters=2, seed=s) for s in range(m)])
+    mu, base, pq = mu * scale, base * scale, pq * scale
+    ix = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    ix.loadCoarseQuantizer(mu)
+    ix.loadProductQuantizer(pq)
+    ix.setW(w)
+    ref = oracle_ivfpq(oracle, {"coarse": mu, "pq": pq}, D, m, ks, C, w)
+    ix.indexVectors([str(i) for i in range(n)], base)
+    ref.add_vectors(base)
+    Q = np.concatenate([0.5 * (base[:24] + base[100:124]), base[:24] + 0.01 * scale * rng.standard_normal((24, D))]) * qscale
+    assert_same(ix.search_batch(k, Q), ref.search_batch(Q, k))
+    ix.close()
