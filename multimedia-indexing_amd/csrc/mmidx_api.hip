@@ -713,6 +713,9 @@ int make_plan(mmidx_index *h, int k, int64_t nq, SearchPlan &pl, bool need_coars
         // 131072 at 4096 queries: 1.09 M, and 524288 at 16384: 0.89 M); small batches keep 32768 so that one query still spreads
         // over the chip
         chunk = nq >= 512 ? 65536 : 32768;
+        // (with K3m behind it -- thresholds tighten from the survivors' upper bounds as the scan goes -- the exact, LDS-bound pass over
+        //  chunk 0 can be half as long: cfg2 2.06 -> 1.93 ms per 4096 queries; 16384 and 8192 measure the same)
+        if (h->mfma_ok && !h->no_mfma) chunk = 32768;
         if (h->flat_chunk >= 4096) chunk = std::min<int64_t>(h->flat_chunk, 1 << 23);  // option "flat_chunk" (A/B)
     }
     const int64_t maxlen = std::max<int64_t>(h->max_list_len, 1);

@@ -254,6 +254,9 @@ __device__ __forceinline__ void mf_scan_tiles(const MfmaParams &P, const mf_h8 (
     const u32 boff = (u32)((NJ * g * 8) / DSUB);              // first code byte of the lane
     const u32 lane_base = lds_cb + (u32)(NJ * g) * 4096u;
     const int ntiles = (int)((c1 - c0 + 15) >> 4);
+    float thrmin = thr[0][0];
+#pragma unroll
+    for (int b = 1; b < NTL * 4; b++) thrmin = __builtin_fminf(thrmin, thr[b >> 2][b & 3]);
     // (32-bit lane offsets from the item's wave-uniform base pointers: an item spans at most 2^31 bytes of codes)
     const unsigned char *cbase = codes + (size_t)c0 * M + boff;
     const float *xbase = xn + c0;
@@ -316,14 +319,18 @@ __device__ __forceinline__ void mf_scan_tiles(const MfmaParams &P, const mf_h8 (
                     for (int rt = 0; rt < NTL; rt++) acc[h][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[rt][j], B[h][j], acc[h][rt], 0, 0, 0);
 #endif
             }
-            // one compare per accumulator register; the lane masks stay in scalar registers
-            u64 any[2] = {0, 0};
+            // Pre-test: the largest of the lane's accumulators against the SMALLEST of its rows' constants -- v_max3 over the 4 NTL
+            // registers and one compare (9 vector instructions per tile instead of 16 compares + 16 scalar ORs).  Conservative: a
+            // tile that passes it is looked at register by register below (the exact compares), and survivors are rare.
+            u64 any[2];
 #pragma unroll
-            for (int h = 0; h < 2; h++)
+            for (int h = 0; h < 2; h++) {
+                float mxa = acc[h][0][0];
 #pragma unroll
-                for (int rt = 0; rt < NTL; rt++)
-#pragma unroll
-                    for (int i = 0; i < 4; i++) any[h] |= __builtin_amdgcn_ballot_w64(acc[h][rt][i] >= thr[rt][i]);
+                for (int b = 1; b + 1 < NTL * 4; b += 2) mxa = __builtin_fmaxf(__builtin_fmaxf(mxa, acc[h][b >> 2][b & 3]), acc[h][(b + 1) >> 2][(b + 1) & 3]);
+                mxa = __builtin_fmaxf(mxa, acc[h][NTL - 1][3]);
+                any[h] = __builtin_amdgcn_ballot_w64(mxa >= thrmin);
+            }
 #if MF_TIMING == 1
             if ((any[0] | any[1]) == 0x123456789ull) s_touch[0] = 1;
             any[0] = any[1] = 0;
