@@ -254,6 +254,7 @@ __device__ __forceinline__ void mf_scan_tiles(const MfmaParams &P, const mf_h8 (
     const u32 boff = (u32)((NJ * g * 8) / DSUB);              // first code byte of the lane
     const u32 lane_base = lds_cb + (u32)(NJ * g) * 4096u;
     const int ntiles = (int)((c1 - c0 + 15) >> 4);
+    u32 bufn = 0;  // records staged in the wave's LDS buffer (wave-uniform)
     float thrmin = thr[0][0];
 #pragma unroll
     for (int b = 1; b < NTL * 4; b++) thrmin = __builtin_fminf(thrmin, thr[b >> 2][b & 3]);
@@ -349,55 +350,51 @@ __device__ __forceinline__ void mf_scan_tiles(const MfmaParams &P, const mf_h8 (
                     for (int b = NTL * 4 - 1; b >= 0; b--)
                         asm volatile("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(acc[h][b >> 2][b & 3]), "v"(thr[b >> 2][b & 3]) : "vcc");
                     if (pos >= c1) bits = 0;  // (only an item's last tile has lanes past the end)
-                    while (bits) {  // (divergent: the few lanes with a survivor, one pass per survivor of the lane)
-                        const int b = __ffs((int)bits) - 1;
-                        bits &= bits - 1u;
-                        // (bit selects -- v_bfi_b32 -- on purpose: written as ?: the compiler turns the tree into an indexed scratch array)
-                        const u32 m0 = 0u - ((u32)b & 1u), m1 = 0u - (((u32)b >> 1) & 1u), m2 = 0u - (((u32)b >> 2) & 1u), m3 = 0u - (((u32)b >> 3) & 1u);
-                        u32 v8[8], v4[4], v2[2];
+                    // (a wave-uniform loop -- one pass per survivor of the busiest lane, usually one -- so that the buffer slots come from
+                    //  a ballot and a counter in a scalar register: no LDS atomic, no round trip before the record is written)
+                    u64 act = __builtin_amdgcn_ballot_w64(bits != 0);
+                    while (act) {
+                        if (bits) {
+                            const int b = __ffs((int)bits) - 1;
+                            bits &= bits - 1u;
+                            // (bit selects -- v_bfi_b32 -- on purpose: written as ?: the compiler turns the tree into an indexed scratch array)
+                            const u32 m0 = 0u - ((u32)b & 1u), m1 = 0u - (((u32)b >> 1) & 1u), m2 = 0u - (((u32)b >> 2) & 1u), m3 = 0u - (((u32)b >> 3) & 1u);
+                            u32 v8[8], v4[4], v2[2];
 #pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            const u32 lo = 2 * j < NTL * 4 ? (u32)__float_as_int(acc[h][(2 * j) >> 2][(2 * j) & 3]) : 0u,
-                                      hi = 2 * j + 1 < NTL * 4 ? (u32)__float_as_int(acc[h][(2 * j + 1) >> 2][(2 * j + 1) & 3]) : 0u;
-                            v8[j] = (hi & m0) | (lo & ~m0);
+                            for (int j = 0; j < 8; j++) {
+                                const u32 lo = 2 * j < NTL * 4 ? (u32)__float_as_int(acc[h][(2 * j) >> 2][(2 * j) & 3]) : 0u,
+                                          hi = 2 * j + 1 < NTL * 4 ? (u32)__float_as_int(acc[h][(2 * j + 1) >> 2][(2 * j + 1) & 3]) : 0u;
+                                v8[j] = (hi & m0) | (lo & ~m0);
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; j++) v4[j] = (v8[2 * j + 1] & m1) | (v8[2 * j] & ~m1);
+#pragma unroll
+                            for (int j = 0; j < 2; j++) v2[j] = (v4[2 * j + 1] & m2) | (v4[2 * j] & ~m2);
+                            const float a = __int_as_float((int)((v2[1] & m3) | (v2[0] & ~m3)));
+                            const int qs = (b >> 2) * 16 + 4 * g + (b & 3);  // (a live row: rows past the group's pairs never survive)
+                            const MfmaRow rw = s_row[qs];
+                            // d~ = ||r||^2 - 2 acc / s^2 and |d - d~| <= err: lower bound cd + kd acc (kept with the record: the
+                            // verification drops what the query's FINAL threshold has left behind), upper bound -> bucket
+                            const float lbf = fmaf(a, kd, rw.cd);
+                            const float xb = fmaf(a, rw.kq, rw.cq);
+                            const u32 bk = (rw.kq != 0.f && xb < 255.f) ? (xb > 0.f ? (u32)(int)xb : 0u) : 0xFFFFFFFFu;
+                            const u32 o = bufn + mf_mbcnt(act);
+                            if (o < MF_BUF) s_buf[o] = make_uint4((u32)(first + qs), (u32)pos, (u32)__float_as_int(lbf), bk);
+                            else P.redo[rw.q] = 1;  // (more than half a buffer from one step: a threshold far above what the lists hold -- K3f's case)
                         }
-#pragma unroll
-                        for (int j = 0; j < 4; j++) v4[j] = (v8[2 * j + 1] & m1) | (v8[2 * j] & ~m1);
-#pragma unroll
-                        for (int j = 0; j < 2; j++) v2[j] = (v4[2 * j + 1] & m2) | (v4[2 * j] & ~m2);
-                        const float a = __int_as_float((int)((v2[1] & m3) | (v2[0] & ~m3)));
-                        const int qs = (b >> 2) * 16 + 4 * g + (b & 3);  // (a live row: rows past the group's pairs never survive)
-                        const MfmaRow rw = s_row[qs];
-                        // d~ = ||r||^2 - 2 acc / s^2 and |d - d~| <= err: lower bound cd + kd acc (kept with the record: the
-                        // verification drops what the query's FINAL threshold has left behind), upper bound -> bucket
-                        const float lbf = fmaf(a, kd, rw.cd);
-                        const float xb = fmaf(a, rw.kq, rw.cq);
-                        const u32 bk = (rw.kq != 0.f && xb < 255.f) ? (xb > 0.f ? (u32)(int)xb : 0u) : 0xFFFFFFFFu;
-                        const u32 o = atomicAdd(s_wcnt, 1u);
-                        if (o < MF_BUF) s_buf[o] = make_uint4((u32)(first + qs), (u32)pos, (u32)__float_as_int(lbf), bk);
-                        else P.redo[rw.q] = 1;  // (more than half a buffer from one step: a threshold far above what the lists hold -- K3f's case)
+                        bufn += (u32)__popcll(act);
+                        act = __builtin_amdgcn_ballot_w64(bits != 0);
                     }
                 }
                 // the wave's staged records: out in one burst when the buffer is half full
-                u32 nb = *(volatile u32 *)s_wcnt;
-                nb = (u32)__builtin_amdgcn_readfirstlane((int)nb);
-                if (nb >= MF_BUF / 2) {
-                    nb = nb < MF_BUF ? nb : MF_BUF;
-                    mf_flush(P, ck, s_buf, nb, s_row, s_touch, first, lane);
-                    if (lane == 0) *s_wcnt = 0;
+                if (bufn >= MF_BUF / 2) {
+                    mf_flush(P, ck, s_buf, bufn < MF_BUF ? bufn : MF_BUF, s_row, s_touch, first, lane);
+                    bufn = 0;
                 }
             }
         }
     }
-    {   // what is left in the buffer at the end of the item
-        u32 nb = *(volatile u32 *)s_wcnt;
-        nb = (u32)__builtin_amdgcn_readfirstlane((int)nb);
-        nb = nb < MF_BUF ? nb : MF_BUF;
-        if (nb) {
-            mf_flush(P, ck, s_buf, nb, s_row, s_touch, first, lane);
-            if (lane == 0) *s_wcnt = 0;
-        }
-    }
+    if (bufn) mf_flush(P, ck, s_buf, bufn < MF_BUF ? bufn : MF_BUF, s_row, s_touch, first, lane);  // what is left at the end of the item
 }
 
 template <int NJ, int DSUB>

@@ -384,3 +384,31 @@ def test_native_sharded_query_exchange_pipeline(mi, oracle, devices):
             got = (np.concatenate([t.cpu().numpy() for t in oi]), np.concatenate([t.cpu().numpy() for t in od]), np.concatenate([t.cpu().numpy() for t in oc]))
             assert_same(got, tuple(a[:per * W] for a in want))
     ix.close()
+
+
+@pytest.mark.parametrize("devices", DEVS, ids=["rccl1", "virt2", "virt3"])
+def test_native_sharded_pass_b_on_the_matrix_cores(mi, oracle, devices):
+    """A shape K3m takes (8-dimensional sub-quantizers, D = 64): every shard's pass B -- under the all-reduced thresholds, answers as
+    sorted partial lists for the owners -- runs k_scan_mfma / k_mfma_verify; overlapping cells so that far probes are scanned, every
+    vector twice so that ties straddle shards.  The single queue's answer, with K3m and without."""
+    D, C_, m, ks, w, k = 64, 16, 8, 256, 7, 20
+    rng = np.random.default_rng(3 + len(devices))
+    mu = 0.5 * rng.standard_normal((C_, D))
+    half = mu[rng.integers(0, C_, 6000)] + rng.standard_normal((6000, D))
+    base = np.concatenate([half, half])[rng.permutation(12000)]
+    ds = D // m
+    pq = np.stack([synth.kmeans((mu[rng.integers(0, C_, 3000)] - base[:3000])[:, s * ds:(s + 1) * ds], ks, iters=2, seed=s) for s in range(m)])
+    p = {"coarse": mu, "pq": pq}
+    ref = make_ref(oracle, p, D, m, ks, C_, w)
+    ref.add_vectors(base)
+    ix = make_sharded(mi, p, D, m, ks, C_, w, len(base), devices)
+    ix.indexVectors([str(i) for i in range(len(base))], base)
+    Q = np.concatenate([0.5 * (base[:30] + base[100:130]), base[:30] + 0.01 * rng.standard_normal((30, D))])
+    want = ref.search_batch(Q, k)
+    for off in (0, 1):
+        ix.set_option("no_mfma", off)
+        ix.set_profiling(True)
+        assert_same(ix.search_batch(k, Q), want)
+        st = ix.get_stats()
+        assert (st["mfma_survivors"] > 0) == (off == 0)
+    ix.close()
