@@ -298,6 +298,8 @@ struct mmidx_index {
     int mfma_sub = 0;                  // option "mfma_sub": codes per K3m item (0 = sized from the call)
     int mfma_qcap = 0;                 // option "mfma_qcap": survivor records per launch (0 = sized from the call; tests force the redo path)
     int mfma_blocks = 0;               // option "mfma_blocks": persistent blocks (0 = occupancy x CUs)
+    int lut_pre = -1;                  // option "lut_pre": pass A's tables built ahead of K3h by k_lut_pre: 1 always, 0 never, -1 = where it pays (m >= 32)
+    DevBuf<double> ws_lutpre;
     DevBuf<uint4> ws_surv;
     DevBuf<double> ws_R;               // RandomRotation: the kept pairs' exact rotated residuals [pairs][D]
     DevBuf<u32> ws_mfctl, ws_psnap;
@@ -854,6 +856,24 @@ int launch_scan_hist(mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 gr
         HIPCK(hipMemsetAsync(h->ws_fb.p, 0, 4 * sizeof(int32_t), st));
     }
     P.cap = cap;
+    // the queries' exact tables ahead of the scan (k_lut_pre: a codebook row read once per 64 queries instead of once per query)
+    {
+        const bool want = h->lut_pre > 0 || (h->lut_pre < 0 && h->m >= 32);
+        const long long nqa = (long long)grid.x;  // (pass A: one item per query)
+        const size_t tab = (size_t)h->m * h->ks;
+        if (want && P.nrank == 1 && P.rank_lo == 0 && grid.y == 1 && h->transform != MMIDX_TR_ROTATION && (tab & 1) == 0 && (h->dsub == 8 || h->dsub == 16 || h->dsub == 4) &&
+            h->ks <= 256 && (size_t)nqa * tab * 8 <= ((size_t)4 << 30)) {
+            HIPCK(h->ws_lutpre.reserve((size_t)nqa * tab));
+            const dim3 g((unsigned)h->m, (unsigned)((nqa + LUTPRE_QB - 1) / LUTPRE_QB));
+            if (g.y <= 65535) {
+                if (h->dsub == 16) hipLaunchKernelGGL(k_lut_pre<16>, g, dim3(256), 0, st, P.Q, P.coarse, P.cells, P.perm, P.pqT, h->ws_lutpre.p, h->D, h->m, h->ks, P.w, P.ivf, nqa);
+                else if (h->dsub == 8) hipLaunchKernelGGL(k_lut_pre<8>, g, dim3(256), 0, st, P.Q, P.coarse, P.cells, P.perm, P.pqT, h->ws_lutpre.p, h->D, h->m, h->ks, P.w, P.ivf, nqa);
+                else hipLaunchKernelGGL(k_lut_pre<4>, g, dim3(256), 0, st, P.Q, P.coarse, P.cells, P.perm, P.pqT, h->ws_lutpre.p, h->D, h->m, h->ks, P.w, P.ivf, nqa);
+                HIPCK(hipGetLastError());
+                P.lut_pre = h->ws_lutpre.p;
+            }
+        }
+    }
     P.fb_count = (u32 *)h->ws_fb.p;
     P.fb_items = h->ws_fb.p + 4;
     P.fb_ch = h->ws_fb.p + 4 + nfb;
@@ -2208,6 +2228,7 @@ int mmidx_destroy(mmidx_index *h) {
     h->xn.release();
     h->ws_surv.release();
     h->ws_R.release();
+    h->ws_lutpre.release();
     h->ws_mfctl.release();
     h->ws_psnap.release();
     h->ws_redo.release();
@@ -2985,6 +3006,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->mfma_sub = value > 0 ? value : 0;
     } else if (n == "mfma_qcap") {
         h->mfma_qcap = value > 0 ? value : 0;
+    } else if (n == "lut_pre") {
+        h->lut_pre = value < 0 ? -1 : (value != 0);
     } else if (n == "mfma_blocks") {
         h->mfma_blocks = value > 0 ? value : 0;
     } else if (n == "grp_blocks") {

@@ -1980,6 +1980,7 @@ struct ScanParams {
     int32_t *fb_items, *fb_ch;
     int code_lo, code_hi;    // only list positions [code_lo, code_hi) are scanned by this launch (pass A prefix / remainder)
     double *glut;            // GLUT kernels (table larger than the LDS): scratch of m * ks doubles per block, else null
+    const double *lut_pre;   // K3h: the queries' exact tables of their nearest cell [nq][m][ks], built by k_lut_pre (null: every block builds its own)
     int K1;                  // k + 1
     int cap;                 // LDS candidate capacity (>= K1 + SEG, power of two)
     int poolq;
@@ -2391,6 +2392,47 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
 // ties, or a segment 0 that is not representative) are not handled here: the item is appended to a
 // fallback list and a K3 launch over that list redoes it, so results never depend on the heuristics.
 // ------------------------------------------------------------------------------------------------
+// Pass A's exact tables for a whole batch, ahead of the scan: LUT[q][s][j] = sum_t (r[s dsub + t] - pq[s][j][t])^2 for the query's
+// NEAREST cell, t ascending from 0.0 (computeLookupADC, IVFPQ.java:525-538) -- the same operations in the same order as build_lut.
+// A block is (sub-quantizer s, QB queries); thread j holds entry j's dsub coordinates in registers and walks the queries, whose
+// sub-residuals sit in LDS (broadcast reads).  A block of k_scan_hist that builds its own table re-reads the whole codebook from
+// L2 -- 256 KiB per query at 16 x 256 x 8, 2 MiB at 64 x 256 x 16 (the 1024-d shape: 8.6 GB of L2 reads per 4096 queries, the
+// whole exposed table build of its one-block-per-CU pass A) -- here a codebook row is read once per QB queries.
+#define LUTPRE_QB 64
+template <int DSUB>
+__global__ __launch_bounds__(256) void k_lut_pre(const double *__restrict__ Q, const double *__restrict__ coarse, const int32_t *__restrict__ cells,
+                                                 const int32_t *__restrict__ perm, const double *__restrict__ pqT, double *__restrict__ lut, int D,
+                                                 int m, int ks, int w, int ivf, long long nq) {
+    __shared__ double s_r[LUTPRE_QB * DSUB];
+    const int s = blockIdx.x, j = threadIdx.x;
+    const long long q0 = (long long)blockIdx.y * LUTPRE_QB;
+    const int nb = (int)(nq - q0 < LUTPRE_QB ? nq - q0 : LUTPRE_QB);
+    for (int idx = j; idx < LUTPRE_QB * DSUB; idx += 256) {
+        const int qi = idx / DSUB, t = idx - qi * DSUB;
+        const long long q = q0 + (qi < nb ? qi : nb - 1);
+        const int d = s * DSUB + t, src = perm ? perm[d] : d;
+        const double qv = Q[(size_t)q * D + src];
+        int cell = ivf ? cells[(size_t)q * w] : 0;
+        cell = cell < 0 ? 0 : cell;
+        s_r[idx] = ivf ? coarse[(size_t)cell * D + src] - qv : qv;
+    }
+    double pv[DSUB];
+#pragma unroll
+    for (int t = 0; t < DSUB; t++) pv[t] = j < ks ? pqT[((size_t)s * DSUB + t) * ks + j] : 0.0;
+    __syncthreads();
+    if (j >= ks) return;
+    for (int qi = 0; qi < nb; qi++) {
+        const double *tv = s_r + qi * DSUB;
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < DSUB; t++) {
+            const double df = tv[t] - pv[t];
+            acc += df * df;
+        }
+        lut[((size_t)(q0 + qi) * m + s) * ks + j] = acc;
+    }
+}
+
 #define MMIDX_HB 256
 #define MMIDX_HKEEP 256  // most entries one item may emit (>= K1 required: the host checks; the pool has room for them)
 #define MMIDX_HPOS 4     // appended positions re-evaluated per thread per round at the end
@@ -2465,8 +2507,13 @@ __global__ __launch_bounds__(NT, NT == 512 ? MMIDX_K3H_WPS512 : 1) void k_scan_h
         cur.load(codes + (size_t)(i < c1 ? i : c1 - 1) * M);
     }
     for (int i = tid; i < MMIDX_HB + MMIDX_HCNT; i += NT) hist[i] = 0;  // histogram and the counters
-    const double *tr = query_vector(P, q, cell, vec);
-    build_lut_any(lut, tr, P.pqT, M, ks, P.dsub);
+    if (P.lut_pre) {  // the table was built ahead of the launch (k_lut_pre): 16-byte loads straight into LDS
+        const double2 *src = (const double2 *)(P.lut_pre + (size_t)q * M * ks);
+        for (int i = tid; i < (M * ks) >> 1; i += NT) ((double2 *)lut)[i] = src[i];
+    } else {
+        const double *tr = query_vector(P, q, cell, vec);
+        build_lut_any(lut, tr, P.pqT, M, ks, P.dsub);
+    }
     __syncthreads();
 
     // (0.0 + x == x bit for bit: the table entries are sums of squares from +0.0, never -0.0, so the reference's
