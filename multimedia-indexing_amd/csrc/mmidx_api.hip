@@ -1118,7 +1118,7 @@ int launch_grouped_common(mmidx_index *h, const ScanParams &S, ScanParams F, con
 // index-side tables: the fp16 codebook (per quantizer) and ||x||^2 of every stored code (per CSR build)
 int build_mfma_tables(mmidx_index *h) {
     const bool shape_ok = (h->kind == MMIDX_KIND_IVFPQ || h->kind == MMIDX_KIND_PQ) && h->code_bytes == 1 && h->ks <= 256 && h->pq_set &&
-                          (h->dsub == 8 || h->dsub == 16) && (h->D == 32 || h->D == 64 || h->D == 128);
+                          (h->dsub == 4 || h->dsub == 8 || h->dsub == 16) && (h->D == 32 || h->D == 64 || h->D == 128);
     if (!shape_ok) {
         h->mfma_ok = false;
         return MMIDX_OK;
@@ -1284,12 +1284,14 @@ int launch_mfma_common(mmidx_index *h, const ScanParams &S, ScanParams F, const 
         HIPCK(hipEventRecord(mev[0], st));
     }
     const int nj = h->D / 32;
-    if (h->dsub == 8) rc = nj == 4 ? launch_mfma_scan_t<4, 8>(h, MP, L.total, st) : nj == 2 ? launch_mfma_scan_t<2, 8>(h, MP, L.total, st) : launch_mfma_scan_t<1, 8>(h, MP, L.total, st);
+    if (h->dsub == 4) rc = nj == 4 ? launch_mfma_scan_t<4, 4>(h, MP, L.total, st) : nj == 2 ? launch_mfma_scan_t<2, 4>(h, MP, L.total, st) : launch_mfma_scan_t<1, 4>(h, MP, L.total, st);
+    else if (h->dsub == 8) rc = nj == 4 ? launch_mfma_scan_t<4, 8>(h, MP, L.total, st) : nj == 2 ? launch_mfma_scan_t<2, 8>(h, MP, L.total, st) : launch_mfma_scan_t<1, 8>(h, MP, L.total, st);
     else rc = nj == 4 ? launch_mfma_scan_t<4, 16>(h, MP, L.total, st) : nj == 2 ? launch_mfma_scan_t<2, 16>(h, MP, L.total, st) : launch_mfma_scan_t<1, 16>(h, MP, L.total, st);
     if (rc) return rc;
     if (mev) HIPCK(hipEventRecord(mev[1], st));
     DBG_SYNC("K3m scan");
-    if (h->dsub == 8) rc = h->m == 16 ? launch_mfma_verify_t<16, 8>(h, MP, st) : h->m == 8 ? launch_mfma_verify_t<8, 8>(h, MP, st) : launch_mfma_verify_t<4, 8>(h, MP, st);
+    if (h->dsub == 4) rc = h->m == 32 ? launch_mfma_verify_t<32, 4>(h, MP, st) : h->m == 16 ? launch_mfma_verify_t<16, 4>(h, MP, st) : launch_mfma_verify_t<8, 4>(h, MP, st);
+    else if (h->dsub == 8) rc = h->m == 16 ? launch_mfma_verify_t<16, 8>(h, MP, st) : h->m == 8 ? launch_mfma_verify_t<8, 8>(h, MP, st) : launch_mfma_verify_t<4, 8>(h, MP, st);
     else rc = h->m == 8 ? launch_mfma_verify_t<8, 16>(h, MP, st) : h->m == 4 ? launch_mfma_verify_t<4, 16>(h, MP, st) : launch_mfma_verify_t<2, 16>(h, MP, st);
     if (rc) return rc;
     if (mev) HIPCK(hipEventRecord(mev[2], st));

@@ -29,6 +29,8 @@
 #pragma once
 #include "mmidx_kernels.h"
 
+#include <type_traits>
+
 typedef _Float16 mf_h8 __attribute__((ext_vector_type(8)));
 typedef float mf_f4 __attribute__((ext_vector_type(4)));
 
@@ -262,16 +264,18 @@ __device__ __forceinline__ void mf_scan_tiles(const MfmaParams &P, const mf_h8 (
     const unsigned char *cbase = codes + (size_t)c0 * M + boff;
     const float *xbase = xn + c0;
     const u32 last = (u32)(c1 - c0 - 1);
-    auto load_tile = [&](int t, u32 &cw, float &xv) {
+    typedef typename std::conditional<NB == 8, u64, u32>::type CW;  // (4-dimensional sub-quantizers at D = 128: eight code bytes per lane)
+    auto load_tile = [&](int t, CW &cw, float &xv) {
         u32 p = (u32)t * 16u + (u32)n;
         p = p < last ? p : last;
         const unsigned char *cp = cbase + p * (u32)M;
-        if constexpr (NB == 4) cw = *(const u32 *)cp;
+        if constexpr (NB == 8) cw = *(const u64 *)cp;
+        else if constexpr (NB == 4) cw = *(const u32 *)cp;
         else if constexpr (NB == 2) cw = (u32) * (const unsigned short *)cp;
         else cw = (u32)*cp;
         xv = xbase[p];
     };
-    u32 cw[4];
+    CW cw[4];
     float xv[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) load_tile(wv + 4 * u, cw[u], xv[u]);
@@ -282,7 +286,7 @@ __device__ __forceinline__ void mf_scan_tiles(const MfmaParams &P, const mf_h8 (
 #pragma unroll
         for (int u = 0; u < 4; u += 2) {
             const int tt = t + 4 * u;
-            const u32 c[2] = {cw[u], cw[u + 1]};
+            const CW c[2] = {cw[u], cw[u + 1]};
             const float x[2] = {xv[u], xv[u + 1]};
             load_tile(tt + 16, cw[u], xv[u]);  // (clamped to the item's last code: always a valid address)
             load_tile(tt + 20, cw[u + 1], xv[u + 1]);
@@ -292,13 +296,25 @@ __device__ __forceinline__ void mf_scan_tiles(const MfmaParams &P, const mf_h8 (
             for (int h = 0; h < 2; h++)
 #pragma unroll
                 for (int j = 0; j < NJ; j++) {
-                    const u32 byte = (c[h] >> (8 * (j / (DSUB / 8)))) & 0xFFu;
+                    if constexpr (DSUB == 4) {
+                        // two sub-quantizers per 8-dimension group: entry (2 g8, b0) is the low half of row b0, entry (2 g8 + 1, b1) the
+                        // high half of row b1 -- two 8-byte gathers make the fragment
+                        const u32 b0 = (u32)(c[h] >> (16 * j)) & 0xFFu, b1 = (u32)(c[h] >> (16 * j + 8)) & 0xFFu;
+                        typedef u64 __attribute__((address_space(3))) lds_u64;
+                        const u64 lo = *(const lds_u64 *)(size_t)(lane_base + (b0 << 4) + (u32)j * 4096u);
+                        const u64 hi = *(const lds_u64 *)(size_t)(lane_base + (b1 << 4) + 8u + (u32)j * 4096u);
+                        typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+                        const u64x2 both = {lo, hi};
+                        B[h][j] = __builtin_bit_cast(mf_h8, both);
+                    } else {
+                        const u32 byte = (u32)(c[h] >> (8 * (j / (DSUB >= 8 ? DSUB / 8 : 1)))) & 0xFFu;
 #if MF_TIMING == 3
-                    const u32 addr = lane_base + ((u32)lane << 4);
+                        const u32 addr = lane_base + ((u32)lane << 4);
 #else
-                    const u32 addr = lane_base + (byte << 4);
+                        const u32 addr = lane_base + (byte << 4);
 #endif
-                    B[h][j] = *(const __attribute__((address_space(3))) mf_h8 *)(size_t)(addr + (u32)j * 4096u);
+                        B[h][j] = *(const __attribute__((address_space(3))) mf_h8 *)(size_t)(addr + (u32)j * 4096u);
+                    }
                 }
             // (all gathers of the step are in flight before the first MFMA: left to itself the scheduler issues each one right in
             //  front of its use and the wave waits out the LDS latency 2 NJ times per step)
@@ -402,7 +418,7 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
     constexpr int D = NJ * 32;
     constexpr int DPT = D / 8;  // dimensions per thread in the residual phase: a thread is (row of 32, eighth of the dimensions)
     static_assert(NJ == 1 || NJ == 2 || NJ == 4, "D = 32, 64 or 128");
-    static_assert(DSUB == 8 || DSUB == 16, "a 16-byte codebook row is (part of) one sub-quantizer entry");
+    static_assert(DSUB == 4 || DSUB == 8 || DSUB == 16, "a 16-byte codebook row is two, one or half a sub-quantizer entry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const MfmaLds L(D);
     unsigned char *s_stage = smem + L.stage;
@@ -759,10 +775,15 @@ __global__ __launch_bounds__(256) void k_mfma_verify(const MfmaParams P) {
                 d = en;  // lane 0 of the survivor: 0.0 + e_0 = e_0
 #pragma unroll
                 for (int st = 1; st < M; st++) {
-                    const u64 b = (u64)__double_as_longlong(d);
-                    const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)b, 0x111, 0xf, 0xf, false);  // row_shr:1
-                    const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(b >> 32), 0x111, 0xf, 0xf, false);
-                    const double prev = __longlong_as_double((long long)(((u64)hi << 32) | lo));
+                    double prev;
+                    if constexpr (M <= 16) {
+                        const u64 b = (u64)__double_as_longlong(d);
+                        const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)b, 0x111, 0xf, 0xf, false);  // row_shr:1
+                        const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(b >> 32), 0x111, 0xf, 0xf, false);
+                        prev = __longlong_as_double((long long)(((u64)hi << 32) | lo));
+                    } else {
+                        prev = __shfl_up(d, 1);  // (32 lanes per survivor span two DPP rows)
+                    }
                     if (s == st) d = prev + en;
                 }
             }

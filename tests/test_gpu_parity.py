@@ -854,6 +854,9 @@ def test_union_instances_forced(mi, oracle, D, m, C, n, w, k, dup):
     (64, 4, 4, 16000, 3, 10, 0, 2),       # <2, 16>
     (32, 4, 7, 12000, 7, 1, 0, 1),        # <1, 8>, k = 1
     (32, 2, 3, 9000, 3, 700, 0, 1),       # <1, 16>, k = 700
+    (128, 32, 5, 20000, 5, 100, 0, 1),    # <4, 4>: 4-dimensional sub-quantizers (32-byte codes): two 8-byte gathers per fragment, 32 lanes per verified survivor
+    (64, 16, 4, 16000, 4, 30, 2, 2),      # <2, 4>, RandomPermutation, ties
+    (32, 8, 3, 9000, 3, 10, 0, 1),        # <1, 4>
     (128, 16, 6, 24000, 6, 100, 1, 1),    # RandomRotation (an orthogonal matrix: the coarse bound applies with its measured margin)
     (64, 8, 5, 16000, 5, 20, 3, 2),       # a "rotation" matrix that is NOT orthogonal (columns stretched): the coarse bound stays off, K3m serves it
 ])
@@ -905,7 +908,8 @@ def test_mfma_pass_b(mi, oracle, D, m, C, n, w, k, tr, dup):
     ix.close()
 
 
-@pytest.mark.parametrize("D,m,n,k,tr,chunk", [(128, 8, 70000, 100, 0, 8192), (128, 16, 40000, 10, 2, 4096), (64, 8, 30000, 200, 0, 4096), (32, 2, 50000, 5, 0, 16384)])
+@pytest.mark.parametrize("D,m,n,k,tr,chunk", [(128, 8, 70000, 100, 0, 8192), (128, 16, 40000, 10, 2, 4096), (64, 8, 30000, 200, 0, 4096), (32, 2, 50000, 5, 0, 16384),
+                                                  (128, 32, 30000, 50, 0, 4096)])
 def test_mfma_flat_pq(mi, oracle, D, m, n, k, tr, chunk):
     """Flat PQ (PQ.computeKnnADC, PQ.java:290-322) through K3m: the chunks 1 .. of the single list stand in for inverted lists, the
     residual is the query itself, survivors are verified from the queries' exact tables (k_flat_lut)."""
