@@ -14,6 +14,7 @@
 #include "mmidx_kernels.h"
 #include "mmidx_scan_grp.h"
 #include "mmidx_scan_mfma.h"
+#include "mmidx_scan_mfma_kc.h"
 #include "mmidx_frontend.h"
 
 #include <algorithm>
@@ -302,6 +303,10 @@ struct mmidx_index {
     DevBuf<double> ws_lutpre;
     DevBuf<uint4> ws_surv;
     DevBuf<double> ws_R;               // RandomRotation: the kept pairs' exact rotated residuals [pairs][D]
+    DevBuf<unsigned short> ws_R16;     // K3mk: the kept pairs' fp16 residuals [pairs][D]
+    DevBuf<double> ws_nrow;            // ... and ||r||^2
+    double coarse_maxabs = 0.0;        // largest |centroid element| (set_coarse)
+    int mfma_kc_tpw = 8;               // option "mfma_kc_tpw": code tiles per wave of K3mk (8 or 16)
     DevBuf<u32> ws_mfctl, ws_psnap;
     DevBuf<unsigned char> ws_redo;
     void *d_grpx = nullptr, *pin_grpx = nullptr;  // K3g's GrpExtra on the device and its pinned mirror
@@ -1118,7 +1123,8 @@ int launch_grouped_common(mmidx_index *h, const ScanParams &S, ScanParams F, con
 // index-side tables: the fp16 codebook (per quantizer) and ||x||^2 of every stored code (per CSR build)
 int build_mfma_tables(mmidx_index *h) {
     const bool shape_ok = (h->kind == MMIDX_KIND_IVFPQ || h->kind == MMIDX_KIND_PQ) && h->code_bytes == 1 && h->ks <= 256 && h->pq_set &&
-                          (h->dsub == 4 || h->dsub == 8 || h->dsub == 16) && (h->D == 32 || h->D == 64 || h->D == 128);
+                          (((h->dsub == 4 || h->dsub == 8 || h->dsub == 16) && (h->D == 32 || h->D == 64 || h->D == 128)) ||
+                           ((h->dsub == 8 || h->dsub == 16) && h->D > 128 && h->D % 128 == 0 && h->D <= 2048 && h->m <= 128));  // (long vectors: K3mk, mmidx_scan_mfma_kc.h)
     if (!shape_ok) {
         h->mfma_ok = false;
         return MMIDX_OK;
@@ -1184,6 +1190,158 @@ int launch_mfma_verify_t(mmidx_index *h, const MfmaParams &MP, hipStream_t st) {
     return MMIDX_OK;
 }
 
+template <int DSUB, int TPW>
+int launch_mfma_kc_scan_t(mmidx_index *h, const MfmaKcParams &KP, size_t lds, hipStream_t st) {
+    HIPCK(hipFuncSetAttribute((const void *)k_scan_mfma_kc<DSUB, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int blocks = h->mfma_blocks;
+    if (blocks <= 0) {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_scan_mfma_kc<DSUB, TPW>, MF_NT, lds) != hipSuccess || occ < 1) {
+            (void)hipGetLastError();
+            occ = 1;
+        }
+        blocks = occ * std::max(h->num_cus, 8);
+    }
+    blocks = std::max(8, (blocks + 7) & ~7);
+    hipLaunchKernelGGL((k_scan_mfma_kc<DSUB, TPW>), dim3((unsigned)blocks), dim3(MF_NT), lds, st, KP);
+    HIPCK(hipGetLastError());
+    return MMIDX_OK;
+}
+
+// K3mk (mmidx_scan_mfma_kc.h): pass B through the matrix-core bound for vectors of several 128-dimension chunks.  Same contract as
+// launch_mfma_common (which dispatches here); returns 1 when it does not apply.
+int launch_mfma_kc(mmidx_index *h, const ScanParams &S, ScanParams F, const SearchPlan &pl, int nlists, int nchunks_f, long long npairs, long long maxlen,
+                   hipStream_t st, long long nq, const double *flat_lut) {
+    if (h->transform == MMIDX_TR_ROTATION || (size_t)npairs * h->D * 2 > ((size_t)16 << 30) || h->m % 16 != 0 || h->m > 128) return 1;
+    constexpr int G = MFK_G;
+    const size_t nfb = (size_t)npairs * (size_t)std::max(nchunks_f, 1);
+    HIPCK(h->ws_gdesc.reserve((size_t)npairs / G + (size_t)nlists + 8));
+    HIPCK(h->ws_gfb.reserve(4 + 2 * nfb + 16));
+    hipLaunchKernelGGL(k_group_build, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, h->ws_pstart.p, nlists, G, h->ws_gdesc.p, h->ws_gfb.p,
+                       (u32 *)(h->ws_gfb.p + 1), (unsigned long long *)(h->d_counters + 7), h->pin_hint ? h->pin_hint + 1 : nullptr);
+    HIPCK(hipGetLastError());
+    const int tpw = h->mfma_kc_tpw == 16 ? 16 : 8;
+    int sub = h->mfma_sub > 0 ? ((h->mfma_sub + 63) & ~63) : 64 * tpw;
+    sub = std::min(sub, 64 * tpw);  // (a wave holds at most TPW tiles' accumulators)
+    const int nsub = (int)((maxlen + sub - 1) / sub);
+    if ((long long)(npairs / G + nlists) * nsub > 0x7fffff00ll) return 1;
+    HIPCK(h->ws_ghist.reserve((size_t)nq * 256));
+    HIPCK(h->ws_T0.reserve((size_t)nq));
+    HIPCK(h->ws_redo.reserve((size_t)nq));
+    HIPCK(h->ws_psnap.reserve((size_t)nq));
+    HIPCK(h->ws_mfctl.reserve(32));
+    size_t qcap = h->mfma_qcap > 0 ? (size_t)h->mfma_qcap : std::min<size_t>((size_t)1 << 28, std::max<size_t>((size_t)1 << 20, (size_t)nq * 4096));
+    HIPCK(h->ws_surv.reserve(qcap));
+    HIPCK(h->ws_R16.reserve((size_t)npairs * h->D));
+    HIPCK(h->ws_nrow.reserve((size_t)npairs));
+    hipLaunchKernelGGL(k_mfma_prep, dim3((unsigned)std::min<long long>(4096, (nq * 64 + 255) / 256)), dim3(256), 0, st, (const int32_t *)h->ws_gfb.p, h->ws_ghist.p,
+                       h->ws_redo.p, h->ws_mfctl.p, S.T, h->ws_T0.p, S.pool_cnt, h->ws_psnap.p, (long long)nq);
+    HIPCK(hipGetLastError());
+    MfmaKcParams KP{};
+    MfmaParams &MP = KP.M;
+    MP.S = S;
+    if (h->d_perm) {
+        if (S.ivf && !h->d_coarseP) return 1;
+        HIPCK(h->ws_Qp.reserve((size_t)nq * h->D));
+        const long long tot = (long long)nq * h->D;
+        hipLaunchKernelGGL(k_permute_cols, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, S.Q, h->d_perm, h->ws_Qp.p, h->D, (long long)nq);
+        MP.S.Q = h->ws_Qp.p;
+        if (S.ivf) MP.S.coarse = h->d_coarseP;
+    }
+    MP.S.perm = nullptr;
+    // the launch's residual scale: |r_i| <= max |centroid element| + max |query element| (ctl words 16: query maximum, 20..21: scale)
+    u32 *d_qmax = h->ws_mfctl.p + 16;
+    int32_t *d_scale = (int32_t *)(h->ws_mfctl.p + 20);
+    HIPCK(hipMemsetAsync(d_qmax, 0, sizeof(u32), st));
+    hipLaunchKernelGGL(k_maxabs_f64, dim3(256), dim3(256), 0, st, S.Q, (long long)nq * h->D, d_qmax);
+    float cmaxf = S.ivf ? (float)h->coarse_maxabs : 0.f;
+    if (S.ivf && (double)cmaxf < h->coarse_maxabs) cmaxf = std::nextafter(cmaxf, INFINITY);
+    hipLaunchKernelGGL(k_resid_scale, dim3(1), dim3(1), 0, st, (const u32 *)d_qmax, cmaxf, h->pq_ep, d_scale);
+    hipLaunchKernelGGL(k_pair_resid16, dim3((unsigned)((npairs + 3) / 4)), dim3(256), 0, st, MP.S.Q, MP.S.coarse, S.cells, S.order, S.n_order, (long long)npairs, S.w,
+                       h->D, S.ivf, (const int32_t *)d_scale, h->ws_R16.p, h->ws_nrow.p);
+    HIPCK(hipGetLastError());
+    MP.pq16 = h->d_pq16;
+    MP.xn = h->xn.p;
+    MP.pq = h->d_pq;
+    MP.flat_lut = flat_lut;
+    MP.R = nullptr;
+    MP.gdesc = h->ws_gdesc.p;
+    MP.n_groups = h->ws_gfb.p;
+    MP.sub = sub;
+    MP.nsub = nsub;
+    MP.ep = h->pq_ep;
+    MP.xmax = h->rmax;
+    MP.ghist = h->ws_ghist.p;
+    MP.T0 = h->ws_T0.p;
+    MP.surv = h->ws_surv.p;
+    MP.surv_cnt = h->ws_mfctl.p;
+    MP.surv_cap = (u32)std::min<size_t>(qcap, 0xFFFFFFF0u);
+    MP.redo = h->ws_redo.p;
+    MP.pool_snap = h->ws_psnap.p;
+    MP.work = h->ws_mfctl.p + 8;
+    MP.fb_count = (u32 *)(h->ws_gfb.p + 1);
+    MP.fb_items = h->ws_gfb.p + 4;
+    MP.fb_ch = h->ws_gfb.p + 4 + nfb;
+    MP.fb_chunk = pl.chunk;
+    MP.fb_nchunks = std::max(nchunks_f, 1);
+    MP.npairs_flat = npairs;
+    MP.stat = (h->profiling == 1 || h->debug_sync) ? (unsigned long long *)(h->d_counters + 3) : nullptr;
+    MP.nver = (unsigned long long *)(h->d_counters + 7);
+    KP.R16 = h->ws_R16.p;
+    KP.nrow = h->ws_nrow.p;
+    KP.scale = d_scale;
+    KP.D = h->D;
+    const MfmaKcLds L;
+    hipEvent_t *mev = nullptr;
+    if (h->profiling == 1 && h->mf_ev_used + 3 <= 3 * 4096) {
+        while (h->mf_ev.size() < h->mf_ev_used + 3) {
+            hipEvent_t e;
+            HIPCK(hipEventCreate(&e));
+            h->mf_ev.push_back(e);
+        }
+        mev = h->mf_ev.data() + h->mf_ev_used;
+        h->mf_ev_used += 3;
+        HIPCK(hipEventRecord(mev[0], st));
+    }
+    int rc;
+    if (h->dsub == 16) rc = tpw == 8 ? launch_mfma_kc_scan_t<16, 8>(h, KP, L.total, st) : launch_mfma_kc_scan_t<16, 16>(h, KP, L.total, st);
+    else rc = tpw == 8 ? launch_mfma_kc_scan_t<8, 8>(h, KP, L.total, st) : launch_mfma_kc_scan_t<8, 16>(h, KP, L.total, st);
+    if (rc) return rc;
+    if (mev) HIPCK(hipEventRecord(mev[1], st));
+    DBG_SYNC("K3mk scan");
+    rc = 1;
+#define KC_VER(MM)                                                                                                     \
+    case MM: rc = h->dsub == 16 ? launch_mfma_verify_t<MM, 16>(h, MP, st) : launch_mfma_verify_t<MM, 8>(h, MP, st); break;
+    switch (h->m) {  // (16 lanes per survivor, m / 16 sub-quantizers each)
+        KC_VER(16) KC_VER(32) KC_VER(48) KC_VER(64) KC_VER(80) KC_VER(96) KC_VER(112) KC_VER(128)
+        default: break;
+    }
+#undef KC_VER
+    if (rc) return rc < 0 ? rc : fail(MMIDX_ERR_UNSUPPORTED, "K3mk: no verification instance for m = %d", h->m);
+    if (mev) HIPCK(hipEventRecord(mev[2], st));
+    if (MP.stat) hipLaunchKernelGGL(k_mfma_count, dim3(1024), dim3(256), 0, st, MP);
+    DBG_SYNC("K3mk verify");
+    const long long span = std::max<long long>(npairs, nq);
+    hipLaunchKernelGGL(k_mfma_redo, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, st, MP, (long long)nq);
+    HIPCK(hipGetLastError());
+    if (h->debug_sync) {
+        u32 c16[16];
+        int32_t g2[2], sc[2];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(c16, h->ws_mfctl.p, sizeof(c16), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(g2, h->ws_gfb.p, sizeof(g2), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(sc, d_scale, sizeof(sc), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[mmidx] K3mk: %d groups of <= %d pairs x %d pieces of %d codes, %u survivor slots (cap %u), %d items handed to the redo, scale 2^%d ok %d\n", g2[0], G, nsub, sub,
+                c16[0], MP.surv_cap, g2[1], sc[0], sc[1]);
+    }
+    F.order = MP.fb_items;
+    F.n_order = (const int32_t *)MP.fb_count;
+    F.order_ch = MP.fb_ch;
+    F.n_items = (int)std::min<size_t>(nfb, (size_t)0x7fffff00);
+    F.xcd_remap = 0;
+    return launch_scan_filtered(h, F, pl, dim3((unsigned)F.n_items, 1), st, -1);
+}
+
 // pass B over the sorted pairs through K3m.  S: the scan parameters as K3g would get them (list offsets / order / centroids of the
 // IVF or the flat-PQ form); F: those of the K3f launch that redoes the queries K3m hands back.  Returns 1 when K3m does not apply.
 int launch_mfma_common(mmidx_index *h, const ScanParams &S, ScanParams F, const SearchPlan &pl, int nlists, int nchunks_f, long long npairs,
@@ -1191,6 +1349,7 @@ int launch_mfma_common(mmidx_index *h, const ScanParams &S, ScanParams F, const 
     if (h->no_mfma || !h->mfma_ok || !h->xn_valid || h->no_filter || S.sdc_tt || nq <= 0 || npairs <= 0 || maxlen >= (1ll << 31) ||
         nq * 256 * 4 > (1ll << 31) || npairs >= 0x7fffff00ll || ((uintptr_t)S.Q & 15) != 0)
         return 1;
+    if (h->D > 128) return launch_mfma_kc(h, S, F, pl, nlists, nchunks_f, npairs, maxlen, st, nq, flat_lut);
     constexpr int G = MF_QG;
     const size_t nfb = (size_t)npairs * (size_t)std::max(nchunks_f, 1);
     HIPCK(h->ws_gdesc.reserve((size_t)npairs / G + (size_t)nlists + 8));
@@ -2230,6 +2389,8 @@ int mmidx_destroy(mmidx_index *h) {
     h->xn.release();
     h->ws_surv.release();
     h->ws_R.release();
+    h->ws_R16.release();
+    h->ws_nrow.release();
     h->ws_lutpre.release();
     h->ws_mfctl.release();
     h->ws_psnap.release();
@@ -2266,6 +2427,7 @@ int mmidx_set_coarse(mmidx_index *h, const double *coarse) {
     // certified approximate coarse stage: |c|^2, |c| (fp64) and an fp32 transposed copy
     h->cn_max = 0.0;
     h->cnorm_max = 0.0;
+    h->coarse_maxabs = 0.0;
     std::vector<double> cn((size_t)h->C), cnorm((size_t)h->C);
     std::vector<float> T32(n);
     for (int c = 0; c < h->C; c++) {
@@ -2273,6 +2435,7 @@ int mmidx_set_coarse(mmidx_index *h, const double *coarse) {
         for (int j = 0; j < h->D; j++) {
             const double v = coarse[(size_t)c * h->D + j];
             s2 += v * v;
+            if (!(std::fabs(v) <= h->coarse_maxabs)) h->coarse_maxabs = v == v ? std::fabs(v) : INFINITY;
             T32[(size_t)j * h->C + c] = (float)v;
         }
         cn[(size_t)c] = s2;
@@ -3008,6 +3171,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->mfma_sub = value > 0 ? value : 0;
     } else if (n == "mfma_qcap") {
         h->mfma_qcap = value > 0 ? value : 0;
+    } else if (n == "mfma_kc_tpw") {
+        h->mfma_kc_tpw = value == 16 ? 16 : 8;
     } else if (n == "lut_pre") {
         h->lut_pre = value < 0 ? -1 : (value != 0);
     } else if (n == "mfma_blocks") {

@@ -680,7 +680,8 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
 #define MF_VLIST 1024  // records a block filters per round
 template <int M, int DSUB, bool FLAT>
 __global__ __launch_bounds__(256) void k_mfma_verify(const MfmaParams P) {
-    constexpr int LPS = FLAT ? 1 : M, D = M * DSUB;
+    // lanes per survivor and sub-quantizers per lane: up to 16 lanes (one DPP row), each with SPL consecutive sub-quantizers
+    constexpr int LPS = FLAT ? 1 : (M <= 16 ? M : 16), SPL = FLAT ? M : M / LPS, D = M * DSUB;
     __shared__ uint2 s_rec[MF_VLIST];
     __shared__ int s_pair[MF_VLIST];
     __shared__ u32 s_n, s_nv;
@@ -738,56 +739,64 @@ __global__ __launch_bounds__(256) void k_mfma_verify(const MfmaParams P) {
 #pragma unroll
                 for (int s = 0; s < M; s++) d += en[s];
             } else {
-                const int s = tid & (M - 1);
-                const u32 cs = (u32)code[s];
-                double tv[DSUB];
-                if (P.R) {
-                    const double *rr = P.R + (size_t)slot * D + s * DSUB;
+                const int ls = tid & (LPS - 1);
+                double en[SPL];  // the lane's table entries, each in the reference's order (t ascending from 0.0)
 #pragma unroll
-                    for (int t = 0; t < DSUB; t += 2) {
-                        const double2 r2 = *(const double2 *)(rr + t);
-                        tv[t] = r2.x;
-                        tv[t + 1] = r2.y;
-                    }
-                } else {
-                    const double *cc = P.S.coarse + (size_t)(P.S.ivf ? cell : 0) * D + s * DSUB, *qv = P.S.Q + (size_t)q * D + s * DSUB;
+                for (int i = 0; i < SPL; i++) {
+                    const int s = ls * SPL + i;
+                    const u32 cs = (u32)code[s];
+                    double tv[DSUB];
+                    if (P.R) {
+                        const double *rr = P.R + (size_t)slot * D + s * DSUB;
 #pragma unroll
-                    for (int t = 0; t < DSUB; t += 2) {
-                        const double2 c2 = *(const double2 *)(cc + t), q2 = *(const double2 *)(qv + t);
-                        tv[t] = P.S.ivf ? c2.x - q2.x : q2.x - c2.x;
-                        tv[t + 1] = P.S.ivf ? c2.y - q2.y : q2.y - c2.y;
-                    }
-                }
-                const double *pp = P.pq + ((size_t)s * P.S.ks + cs) * DSUB;
-                double pv[DSUB];
-#pragma unroll
-                for (int t = 0; t < DSUB; t += 2) {
-                    const double2 v2 = *(const double2 *)(pp + t);
-                    pv[t] = v2.x;
-                    pv[t + 1] = v2.y;
-                }
-                double en = 0.0;
-#pragma unroll
-                for (int t = 0; t < DSUB; t++) {
-                    const double df = tv[t] - pv[t];
-                    en += df * df;
-                }
-                d = en;  // lane 0 of the survivor: 0.0 + e_0 = e_0
-#pragma unroll
-                for (int st = 1; st < M; st++) {
-                    double prev;
-                    if constexpr (M <= 16) {
-                        const u64 b = (u64)__double_as_longlong(d);
-                        const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)b, 0x111, 0xf, 0xf, false);  // row_shr:1
-                        const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(b >> 32), 0x111, 0xf, 0xf, false);
-                        prev = __longlong_as_double((long long)(((u64)hi << 32) | lo));
+                        for (int t = 0; t < DSUB; t += 2) {
+                            const double2 r2 = *(const double2 *)(rr + t);
+                            tv[t] = r2.x;
+                            tv[t + 1] = r2.y;
+                        }
                     } else {
-                        prev = __shfl_up(d, 1);  // (32 lanes per survivor span two DPP rows)
+                        const double *cc = P.S.coarse + (size_t)(P.S.ivf ? cell : 0) * D + s * DSUB, *qv = P.S.Q + (size_t)q * D + s * DSUB;
+#pragma unroll
+                        for (int t = 0; t < DSUB; t += 2) {
+                            const double2 c2 = *(const double2 *)(cc + t), q2 = *(const double2 *)(qv + t);
+                            tv[t] = P.S.ivf ? c2.x - q2.x : q2.x - c2.x;
+                            tv[t + 1] = P.S.ivf ? c2.y - q2.y : q2.y - c2.y;
+                        }
                     }
-                    if (s == st) d = prev + en;
+                    const double *pp = P.pq + ((size_t)s * P.S.ks + cs) * DSUB;
+                    double pv[DSUB];
+#pragma unroll
+                    for (int t = 0; t < DSUB; t += 2) {
+                        const double2 v2 = *(const double2 *)(pp + t);
+                        pv[t] = v2.x;
+                        pv[t + 1] = v2.y;
+                    }
+                    double e1 = 0.0;
+#pragma unroll
+                    for (int t = 0; t < DSUB; t++) {
+                        const double df = tv[t] - pv[t];
+                        e1 += df * df;
+                    }
+                    en[i] = e1;
+                }
+                // ((0 + e_0) + e_1) + ... in sub-quantizer order: the running sum travels down the survivor's lanes, every lane adds its own
+                d = en[0];  // lane 0: 0.0 + e_0 = e_0
+#pragma unroll
+                for (int i = 1; i < SPL; i++) d += en[i];
+#pragma unroll
+                for (int st = 1; st < LPS; st++) {
+                    const u64 b = (u64)__double_as_longlong(d);
+                    const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)b, 0x111, 0xf, 0xf, false);  // row_shr:1
+                    const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(b >> 32), 0x111, 0xf, 0xf, false);
+                    const double prev = __longlong_as_double((long long)(((u64)hi << 32) | lo));
+                    if (ls == st) {
+                        d = prev;
+#pragma unroll
+                        for (int i = 0; i < SPL; i++) d += en[i];
+                    }
                 }
             }
-            const bool last = FLAT ? true : ((tid & (M - 1)) == M - 1);
+            const bool last = FLAT ? true : ((tid & (LPS - 1)) == LPS - 1);
             if (act && last) {
                 const u64 key = dkey(d);
                 const u64 T = __hip_atomic_load(P.S.T + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -859,6 +859,10 @@ def test_union_instances_forced(mi, oracle, D, m, C, n, w, k, dup):
     (32, 8, 3, 9000, 3, 10, 0, 1),        # <1, 4>
     (128, 16, 6, 24000, 6, 100, 1, 1),    # RandomRotation (an orthogonal matrix: the coarse bound applies with its measured margin)
     (64, 8, 5, 16000, 5, 20, 3, 2),       # a "rotation" matrix that is NOT orthogonal (columns stretched): the coarse bound stays off, K3m serves it
+    (256, 16, 5, 12000, 5, 50, 0, 1),     # K3mk (mmidx_scan_mfma_kc.h): two 128-dimension chunks, 16-dimensional sub-quantizers
+    (256, 32, 4, 10000, 4, 30, 2, 2),     # K3mk, 8-dimensional sub-quantizers, RandomPermutation, ties
+    (384, 48, 4, 8000, 4, 20, 0, 1),      # K3mk, three chunks, 48-byte codes (three sub-quantizers per verifying lane)
+    (1024, 64, 6, 8000, 6, 30, 2, 1),     # K3mk at YFCC100MExample.java:85-90's shape: eight chunks, 64 x 16
 ])
 def test_mfma_pass_b(mi, oracle, D, m, C, n, w, k, tr, dup):
     """K3m (`k_scan_mfma` + `k_mfma_verify` + `k_mfma_redo`, csrc/mmidx_scan_mfma.h): pass B as a certified lower bound on the matrix
@@ -903,13 +907,22 @@ def test_mfma_pass_b(mi, oracle, D, m, C, n, w, k, tr, dup):
             assert st["mfma_survivors"] > 0  # (K3m ran and its bound let codes through; those still at or below the final thresholds were verified exactly)
             if qcap:
                 assert st["mfma_redo_queries"] > 0  # (the short survivor list really sent queries through the redo path)
+    if D > 128:  # K3mk with 16 code tiles per wave (one block per CU)
+        ix.set_option("mfma_sub", 0)
+        ix.set_option("mfma_qcap", 0)
+        ix.set_option("no_mfma", 0)
+        ix.set_option("mfma_kc_tpw", 16)
+        ix.set_profiling(True)
+        assert_same(ix.search_batch(k, Q), want)
+        assert ix.get_stats()["mfma_survivors"] > 0
+        ix.set_option("mfma_kc_tpw", 8)
     one = ix.search_batch(k, Q[:1])  # a one-query call: groups of one pair
     assert_same(one, tuple(a[:1] for a in want))
     ix.close()
 
 
 @pytest.mark.parametrize("D,m,n,k,tr,chunk", [(128, 8, 70000, 100, 0, 8192), (128, 16, 40000, 10, 2, 4096), (64, 8, 30000, 200, 0, 4096), (32, 2, 50000, 5, 0, 16384),
-                                                  (128, 32, 30000, 50, 0, 4096)])
+                                                  (128, 32, 30000, 50, 0, 4096), (256, 16, 30000, 20, 0, 4096), (512, 64, 20000, 10, 2, 4096)])
 def test_mfma_flat_pq(mi, oracle, D, m, n, k, tr, chunk):
     """Flat PQ (PQ.computeKnnADC, PQ.java:290-322) through K3m: the chunks 1 .. of the single list stand in for inverted lists, the
     residual is the query itself, survivors are verified from the queries' exact tables (k_flat_lut)."""
