@@ -306,6 +306,7 @@ struct mmidx_index {
     DevBuf<unsigned short> ws_R16;     // K3mk: the kept pairs' fp16 residuals [pairs][D]
     DevBuf<double> ws_nrow;            // ... and ||r||^2
     double coarse_maxabs = 0.0;        // largest |centroid element| (set_coarse)
+    int mfma_kc_v1 = 0;                // option "mfma_kc_v1": 1 = K3mk without LDS-DMA (k_scan_mfma_kc) also where k_scan_mfma_kc2 applies
     int mfma_kc_tpw = 8;               // option "mfma_kc_tpw": code tiles per wave of K3mk (8 or 16)
     DevBuf<u32> ws_mfctl, ws_psnap;
     DevBuf<unsigned char> ws_redo;
@@ -1208,6 +1209,15 @@ int launch_mfma_kc_scan_t(mmidx_index *h, const MfmaKcParams &KP, size_t lds, hi
     return MMIDX_OK;
 }
 
+template <int DSUB, int CG>
+int launch_mfma_kc2_scan_t(mmidx_index *h, const MfmaKcParams &KP, hipStream_t st) {
+    int blocks = h->mfma_blocks > 0 ? h->mfma_blocks : std::max(h->num_cus, 8);  // one block of 512 threads per CU (156 KiB of LDS)
+    blocks = std::max(8, (blocks + 7) & ~7);
+    hipLaunchKernelGGL((k_scan_mfma_kc2<DSUB, CG>), dim3((unsigned)blocks), dim3(MFK2_NT), 0, st, KP);
+    HIPCK(hipGetLastError());
+    return MMIDX_OK;
+}
+
 // K3mk (mmidx_scan_mfma_kc.h): pass B through the matrix-core bound for vectors of several 128-dimension chunks.  Same contract as
 // launch_mfma_common (which dispatches here); returns 1 when it does not apply.
 int launch_mfma_kc(mmidx_index *h, const ScanParams &S, ScanParams F, const SearchPlan &pl, int nlists, int nchunks_f, long long npairs, long long maxlen,
@@ -1220,7 +1230,13 @@ int launch_mfma_kc(mmidx_index *h, const ScanParams &S, ScanParams F, const Sear
     hipLaunchKernelGGL(k_group_build, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, h->ws_pstart.p, nlists, G, h->ws_gdesc.p, h->ws_gfb.p,
                        (u32 *)(h->ws_gfb.p + 1), (unsigned long long *)(h->d_counters + 7), h->pin_hint ? h->pin_hint + 1 : nullptr);
     HIPCK(hipGetLastError());
-    const int tpw = h->mfma_kc_tpw == 16 ? 16 : 8;
+    // the DMA form (k_scan_mfma_kc2) where the lanes' code bytes come in aligned words: D a multiple of 256
+    const int nb = 32 / h->dsub, quarter = h->m / 4;
+    int cg = 0;
+    if (!h->mfma_kc_v1 && h->D % 256 == 0 && h->m % 4 == 0)
+        for (int c : {16, 8, 4})
+            if (!cg && quarter % c == 0 && c >= 2 * nb) cg = c;
+    const int tpw = cg ? MFK2_TPW * (MFK2_NT / 64) / 4 : (h->mfma_kc_tpw == 16 ? 16 : 8);  // tiles of a piece / 4
     int sub = h->mfma_sub > 0 ? ((h->mfma_sub + 63) & ~63) : 64 * tpw;
     sub = std::min(sub, 64 * tpw);  // (a wave holds at most TPW tiles' accumulators)
     const int nsub = (int)((maxlen + sub - 1) / sub);
@@ -1304,7 +1320,9 @@ int launch_mfma_kc(mmidx_index *h, const ScanParams &S, ScanParams F, const Sear
         HIPCK(hipEventRecord(mev[0], st));
     }
     int rc;
-    if (h->dsub == 16) rc = tpw == 8 ? launch_mfma_kc_scan_t<16, 8>(h, KP, L.total, st) : launch_mfma_kc_scan_t<16, 16>(h, KP, L.total, st);
+    if (cg && h->dsub == 16) rc = cg == 16 ? launch_mfma_kc2_scan_t<16, 16>(h, KP, st) : cg == 8 ? launch_mfma_kc2_scan_t<16, 8>(h, KP, st) : launch_mfma_kc2_scan_t<16, 4>(h, KP, st);
+    else if (cg) rc = cg == 16 ? launch_mfma_kc2_scan_t<8, 16>(h, KP, st) : launch_mfma_kc2_scan_t<8, 8>(h, KP, st);
+    else if (h->dsub == 16) rc = tpw == 8 ? launch_mfma_kc_scan_t<16, 8>(h, KP, L.total, st) : launch_mfma_kc_scan_t<16, 16>(h, KP, L.total, st);
     else rc = tpw == 8 ? launch_mfma_kc_scan_t<8, 8>(h, KP, L.total, st) : launch_mfma_kc_scan_t<8, 16>(h, KP, L.total, st);
     if (rc) return rc;
     if (mev) HIPCK(hipEventRecord(mev[1], st));
@@ -1898,7 +1916,9 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
                                 (h->dsub == 4 || h->dsub == 8 || h->dsub == 16) && npairs < 0x7fffff00ll && ((uintptr_t)dQ & 15) == 0;  // (16-byte loads of the query rows)
             bool use_pre = false;
             if (pre_ok && h->smin_pre > 0) use_pre = true;
-            else if (pre_ok && h->smin_pre < 0 && h->pin_hint) {
+            else if (pre_ok && h->smin_pre < 0 && h->D > 128 && h->mfma_ok && !h->no_mfma && h->xn_valid) {
+                use_pre = true;  // in front of K3mk always: the bound costs a few per cent of the scan it can save (no K3g figures to go by)
+            } else if (pre_ok && h->smin_pre < 0 && h->pin_hint) {
                 volatile int32_t *ph = (volatile int32_t *)h->pin_hint;
                 if (h->pre_on) {  // [2] pairs K3s looked at, [0] pairs it left: it stays while it removes a quarter
                     const long long in = ph[2], left = ph[0];
@@ -3171,6 +3191,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->mfma_sub = value > 0 ? value : 0;
     } else if (n == "mfma_qcap") {
         h->mfma_qcap = value > 0 ? value : 0;
+    } else if (n == "mfma_kc_v1") {
+        h->mfma_kc_v1 = value != 0;
     } else if (n == "mfma_kc_tpw") {
         h->mfma_kc_tpw = value == 16 ? 16 : 8;
     } else if (n == "lut_pre") {

@@ -229,6 +229,13 @@ def run(n=95_213_780, D=1024, m=64, ks=256, Cc=8192, k=30, ws=(2, 64), batch=409
             r["pass_b"] = {"kernel": "k_pair_smin_* (K3s) + k_scan_grp<64, 4, 16> (K3g) + hand-back", "ms": round(pb_ms_, 3),
                            "far_pairs_scanned_per_query": round(int(st.passb_items_last) / batch, 3),
                            "algorithmic_GBps_over_all_far_probes": round(far_codes * m / (pb_ms_ * 1e-3) / 1e9, 1)}
+            if int(st.mfma_launches) > 0:  # K3mk (mmidx_scan_mfma_kc.h): the matrix-core bound over the pairs K3s left
+                ml = int(st.mfma_launches)
+                scan_ms = st.mfma_scan_ms / ml
+                r["pass_b"].update({"kernel": "k_pair_smin_* (K3s) + k_scan_mfma_kc (K3mk) + k_mfma_verify", "mfma_scan_launch_ms": round(scan_ms, 3),
+                                    "mfma_verify_launch_ms": round(st.mfma_verify_ms / ml, 3),
+                                    "mfma_survivors_per_query": round(st.mfma_survivors / nd / batch, 1),
+                                    "mfma_redo_queries_per_step": round(st.mfma_redo_queries / nd, 1)})
         if ref is not None:
             ref.set_w(w)
             nsq = min(batch, parity_queries)
