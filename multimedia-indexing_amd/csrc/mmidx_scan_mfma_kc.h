@@ -434,7 +434,7 @@ __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams
     __shared__ u32 s_misc[8];
     const MfmaParams &P = K.M;
     MfmaChunk ck{0u, 0u, 0u};
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: addresses and branches by wave)
     const int n = lane & 15, g = lane >> 4;
     uint4 *s_buf = s_bufs + (size_t)wv * MFK2_CAP;
     const int D = K.D, NK = D / 128, M = D / DSUB;
@@ -590,17 +590,6 @@ __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams
                         cw[ti][CG / 4 - 1] >>= 8 * NB;
                     }
                 }
-                if (kc == 0) {
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        u32 pp = (u32)((t2 + u) * NW + wv) * 16u + (u32)n;
-                        pp = pp < last ? pp : last;
-                        const float ci = xn[pp] * kinit;
-                        const mf_f4 c4 = {ci, ci, ci, ci};
-#pragma unroll
-                        for (int rt = 0; rt < NTL; rt++) acc[t2 + u][rt] = c4;
-                    }
-                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
@@ -614,6 +603,15 @@ __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
+#pragma unroll
+        for (int ti = 0; ti < TPW; ti++) {  // the accumulators start at -||x||^2 s^2 / 2 (no global load may be waited for between the DMA
+            u32 pp = (u32)(ti * NW + wv) * 16u + (u32)n;  // of a chunk and the barrier behind it: the counter is in order)
+            pp = pp < last ? pp : last;
+            const float ci = xn[pp] * kinit;
+            const mf_f4 c4 = {ci, ci, ci, ci};
+#pragma unroll
+            for (int rt = 0; rt < NTL; rt++) acc[ti][rt] = c4;
+        }
         for (int kc = 0; kc < NK; kc += 2) {
             if (kc % CPG == 0) {  // the lane's next CG code bytes of every tile
 #pragma unroll
@@ -632,9 +630,14 @@ __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams
                     }
                 }
             }
-            __syncthreads();  // chunk kc has landed in buffer 0 (every wave waited for its own DMA); nobody reads buffer 1 any more
+            // every wave waits for ITS part of chunk kc's DMA, then the barrier: the chunk has landed in buffer 0 and nobody reads buffer 1
+            // any more.  (The wait is explicit: a workgroup barrier does not drain the vector-memory counter by itself, and a wait
+            // the compiler places later -- in front of the first LDS read -- would also wait for the DMA issued in between.)
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
             stage(cb1, ab1, kc + 1);
             chunk(cb0, ab0, kc);
+            __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
             if (kc + 2 < NK) stage(cb0, ab0, kc + 2);
             chunk(cb1, ab1, kc + 1);
