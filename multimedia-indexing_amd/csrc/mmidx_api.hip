@@ -1238,7 +1238,8 @@ int launch_mfma_kc(mmidx_index *h, const ScanParams &S, ScanParams F, const Sear
             if (!cg && quarter % c == 0 && c >= 2 * nb) cg = c;
     const int tpw = cg ? MFK2_TPW * (MFK2_NT / 64) / 4 : (h->mfma_kc_tpw == 16 ? 16 : 8);  // tiles of a piece / 4
     int sub = h->mfma_sub > 0 ? ((h->mfma_sub + 63) & ~63) : 64 * tpw;
-    sub = std::min(sub, 64 * tpw);  // (a wave holds at most TPW tiles' accumulators)
+    if (cg) sub = h->mfma_sub > 0 ? std::min(sub, 1 << 20) : 8 * MFK2_TPW * (MFK2_NT / 64) * 16;  // k_scan_mfma_kc2 walks an item in passes of 1024 codes
+    else sub = std::min(sub, 64 * tpw);  // (a wave holds at most TPW tiles' accumulators)
     const int nsub = (int)((maxlen + sub - 1) / sub);
     if ((long long)(npairs / G + nlists) * nsub > 0x7fffff00ll) return 1;
     HIPCK(h->ws_ghist.reserve((size_t)nq * 256));

@@ -551,15 +551,18 @@ __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams
 #pragma unroll
         for (int b = 1; b < NTL * 4; b++) thrmin = __builtin_fminf(thrmin, thr[b >> 2][b & 3]);
 
-        // ---- (b) the wave's TPW tiles (tile ti * NW + wv of the piece) through all chunks ----
-        const int ntiles = (int)((c1 - c0 + 15) >> 4);
-        const u32 last = (u32)(c1 - c0 - 1);
+        // ---- (b) the item's codes in PASSES of TPW NW tiles (tile ti * NW + wv of a pass is this wave's), each through all chunks ----
+        // The rows' constants, the residual rows and the chunk rotation carry over from pass to pass: chunk 0 of the next pass is
+        // fetched while the last chunk of this one is worked on, the next pass's code words and accumulator start values are loaded
+        // while this pass's accumulators are compared.
+        constexpr int PASS = TPW * NW * 16;
         const bool two_rt = np > 16;
         const unsigned char *cbase = codes + (size_t)c0 * M + (size_t)g * (size_t)(M >> 2);  // the lane's quarter of a code
         mf_f4 acc[TPW][NTL];
         u32 cw[TPW][CG / 4];
+        int ntiles;
         // one chunk from a buffer pair: the chunk's code bytes are the LOW bytes of the lane's code words, which then move down
-        auto chunk = [&](const unsigned char *cb, const unsigned char *ab, const int kc) {
+        auto chunk = [&](const unsigned char *cb, const unsigned char *ab) {
             mf_h8 A[NTL][4];
 #pragma unroll
             for (int rt = 0; rt < NTL; rt++)
@@ -603,59 +606,86 @@ __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
+        // the lane's CG code bytes from byte kb of its quarter, for the tiles of the pass at code offset po (tiles beyond the item read
+        // its last code: never compared)
+        auto load_codes = [&](const u32 po, const u32 lastp, const int kb) {
 #pragma unroll
-        for (int ti = 0; ti < TPW; ti++) {  // the accumulators start at -||x||^2 s^2 / 2 (no global load may be waited for between the DMA
-            u32 pp = (u32)(ti * NW + wv) * 16u + (u32)n;  // of a chunk and the barrier behind it: the counter is in order)
-            pp = pp < last ? pp : last;
-            const float ci = xn[pp] * kinit;
-            const mf_f4 c4 = {ci, ci, ci, ci};
-#pragma unroll
-            for (int rt = 0; rt < NTL; rt++) acc[ti][rt] = c4;
-        }
-        for (int kc = 0; kc < NK; kc += 2) {
-            if (kc % CPG == 0) {  // the lane's next CG code bytes of every tile
-#pragma unroll
-                for (int ti = 0; ti < TPW; ti++) {
-                    u32 pp = (u32)(ti * NW + wv) * 16u + (u32)n;  // (tiles beyond the piece read its last code: never compared)
-                    pp = pp < last ? pp : last;
-                    const unsigned char *cp = cbase + (size_t)pp * M + (size_t)kc * NB;
-                    if constexpr (CG == 16) {
-                        const uint4 t4 = *(const uint4 *)cp;
-                        cw[ti][0] = t4.x; cw[ti][1] = t4.y; cw[ti][2] = t4.z; cw[ti][3] = t4.w;
-                    } else if constexpr (CG == 8) {
-                        const uint2 t2 = *(const uint2 *)cp;
-                        cw[ti][0] = t2.x; cw[ti][1] = t2.y;
-                    } else {
-                        cw[ti][0] = *(const u32 *)cp;
-                    }
+            for (int ti = 0; ti < TPW; ti++) {
+                u32 pp = po + (u32)(ti * NW + wv) * 16u + (u32)n;
+                pp = pp < lastp ? pp : lastp;
+                const unsigned char *cp = cbase + (size_t)pp * M + (size_t)kb;
+                if constexpr (CG == 16) {
+                    const uint4 t4 = *(const uint4 *)cp;
+                    cw[ti][0] = t4.x; cw[ti][1] = t4.y; cw[ti][2] = t4.z; cw[ti][3] = t4.w;
+                } else if constexpr (CG == 8) {
+                    const uint2 t2 = *(const uint2 *)cp;
+                    cw[ti][0] = t2.x; cw[ti][1] = t2.y;
+                } else {
+                    cw[ti][0] = *(const u32 *)cp;
                 }
             }
-            // every wave waits for ITS part of chunk kc's DMA, then the barrier: the chunk has landed in buffer 0 and nobody reads buffer 1
-            // any more.  (The wait is explicit: a workgroup barrier does not drain the vector-memory counter by itself, and a wait
-            // the compiler places later -- in front of the first LDS read -- would also wait for the DMA issued in between.)
-            __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
-            stage(cb1, ab1, kc + 1);
-            chunk(cb0, ab0, kc);
-            __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
-            if (kc + 2 < NK) stage(cb0, ab0, kc + 2);
-            chunk(cb1, ab1, kc + 1);
+        };
+        const u32 lastp = (u32)(c1 - c0 - 1);  // last code of the item
+        float ci[TPW];
+        load_codes(0u, lastp, 0);
+#pragma unroll
+        for (int ti = 0; ti < TPW; ti++) {  // the accumulators start at -||x||^2 s^2 / 2
+            u32 pp = (u32)(ti * NW + wv) * 16u + (u32)n;
+            pp = pp < lastp ? pp : lastp;
+            ci[ti] = xn[pp] * kinit;
         }
-        // ---- (c) compares, survivors ----
         u32 bufn = 0;
+        for (u32 po = 0;; po += PASS) {  // code offset of the pass within the item
 #pragma unroll
-        for (int ti = 0; ti < TPW; ti++) {
-            const int tt = ti * NW + wv;
-            if (tt >= ntiles) continue;
-            float mxa = acc[ti][0][0];
+            for (int ti = 0; ti < TPW; ti++) {
+                const mf_f4 c4 = {ci[ti], ci[ti], ci[ti], ci[ti]};
 #pragma unroll
-            for (int b = 1; b + 1 < NTL * 4; b += 2) mxa = __builtin_fmaxf(__builtin_fmaxf(mxa, acc[ti][b >> 2][b & 3]), acc[ti][(b + 1) >> 2][(b + 1) & 3]);
-            mxa = __builtin_fmaxf(mxa, acc[ti][NTL - 1][3]);
-            if (__builtin_amdgcn_ballot_w64(mxa >= thrmin)) {
-                const long long pos = c0 + (long long)tt * 16 + n;
-                mfk2_tile_survivors<NTL, MFK2_CAP>(P, ck, acc[ti], thr, pos, c1, kd, s_row, s_buf, s_misc + 1, bufn, first, g, lane);
+                for (int rt = 0; rt < NTL; rt++) acc[ti][rt] = c4;
             }
+            const u32 left = (u32)(c1 - c0) - po;
+            const bool more = left > (u32)PASS;
+            ntiles = (int)(((more ? (u32)PASS : left) + 15u) >> 4);
+            for (int kc = 0; kc < NK; kc += 2) {
+                if (kc % CPG == 0 && kc > 0) load_codes(po, lastp, kc * NB);  // (where a quarter has more than CG bytes)
+                // every wave waits for ITS part of chunk kc's DMA, then the barrier: the chunk has landed in buffer 0 and nobody reads
+                // buffer 1 any more.  (The wait is explicit: a workgroup barrier does not drain the vector-memory counter by itself, and
+                // a wait the compiler places later -- in front of the first LDS read -- would also wait for the DMA issued in between.
+                // For the same reason no global load may be waited for between a DMA issue and the barrier behind it: the counter is
+                // in order.)
+                __builtin_amdgcn_s_waitcnt(0);
+                __syncthreads();
+                stage(cb1, ab1, kc + 1);
+                chunk(cb0, ab0);
+                __builtin_amdgcn_s_waitcnt(0);
+                __syncthreads();
+                if (kc + 2 < NK) stage(cb0, ab0, kc + 2);
+                else if (more) stage(cb0, ab0, 0);
+                chunk(cb1, ab1);
+            }
+            if (more) {  // the next pass's code words and start values: in flight while this pass's accumulators are compared
+                load_codes(po + PASS, lastp, 0);
+#pragma unroll
+                for (int ti = 0; ti < TPW; ti++) {
+                    u32 pp = po + (u32)PASS + (u32)(ti * NW + wv) * 16u + (u32)n;
+                    pp = pp < lastp ? pp : lastp;
+                    ci[ti] = xn[pp] * kinit;
+                }
+            }
+            // ---- (c) compares, survivors ----
+#pragma unroll
+            for (int ti = 0; ti < TPW; ti++) {
+                const int tt = ti * NW + wv;
+                if (tt >= ntiles) continue;
+                float mxa = acc[ti][0][0];
+#pragma unroll
+                for (int b = 1; b + 1 < NTL * 4; b += 2) mxa = __builtin_fmaxf(__builtin_fmaxf(mxa, acc[ti][b >> 2][b & 3]), acc[ti][(b + 1) >> 2][(b + 1) & 3]);
+                mxa = __builtin_fmaxf(mxa, acc[ti][NTL - 1][3]);
+                if (__builtin_amdgcn_ballot_w64(mxa >= thrmin)) {
+                    const long long pos = c0 + (long long)po + (long long)tt * 16 + n;
+                    mfk2_tile_survivors<NTL, MFK2_CAP>(P, ck, acc[ti], thr, pos, c1, kd, s_row, s_buf, s_misc + 1, bufn, first, g, lane);
+                }
+            }
+            if (!more) break;
         }
         if (bufn) mf_flush(P, ck, s_buf, bufn, s_row, s_misc + 1, first, lane);
         __syncthreads();
