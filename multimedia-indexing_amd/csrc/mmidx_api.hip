@@ -1213,8 +1213,24 @@ template <int DSUB, int CG>
 int launch_mfma_kc2_scan_t(mmidx_index *h, const MfmaKcParams &KP, hipStream_t st) {
     int blocks = h->mfma_blocks > 0 ? h->mfma_blocks : std::max(h->num_cus, 8);  // one block of 512 threads per CU (156 KiB of LDS)
     blocks = std::max(8, (blocks + 7) & ~7);
+#ifdef MFK_PROF
+    {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mfk_prof), z, sizeof(z));
+    }
+#endif
     hipLaunchKernelGGL((k_scan_mfma_kc2<DSUB, CG>), dim3((unsigned)blocks), dim3(MFK2_NT), 0, st, KP);
     HIPCK(hipGetLastError());
+#ifdef MFK_PROF
+    {
+        unsigned long long z[16];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_mfk_prof), sizeof(z));
+        const double b = 1.0 / blocks;
+        fprintf(stderr, "[mfk prof] Mcycles per block (wave 0): item prologue %.2f | compute(+issue) %.2f dma-wait %.2f barrier %.2f | next loads issue %.2f compares %.2f acc init %.2f | item end %.2f\n",
+                z[0] * b * 1e-6, z[1] * b * 1e-6, z[2] * b * 1e-6, z[3] * b * 1e-6, z[6] * b * 1e-6, z[4] * b * 1e-6, z[7] * b * 1e-6, z[5] * b * 1e-6);
+    }
+#endif
     return MMIDX_OK;
 }
 
@@ -1234,7 +1250,7 @@ int launch_mfma_kc(mmidx_index *h, const ScanParams &S, ScanParams F, const Sear
     const int nb = 32 / h->dsub, quarter = h->m / 4;
     int cg = 0;
     if (!h->mfma_kc_v1 && h->D % 256 == 0 && h->m % 4 == 0)
-        for (int c : {16, 8, 4})
+        for (int c : {8, 4})  // (16 bytes per load would hold 32 registers per wave for the code words: the chunk loop spills)
             if (!cg && quarter % c == 0 && c >= 2 * nb) cg = c;
     const int tpw = cg ? MFK2_TPW * (MFK2_NT / 64) / 4 : (h->mfma_kc_tpw == 16 ? 16 : 8);  // tiles of a piece / 4
     int sub = h->mfma_sub > 0 ? ((h->mfma_sub + 63) & ~63) : 64 * tpw;
@@ -1321,8 +1337,8 @@ int launch_mfma_kc(mmidx_index *h, const ScanParams &S, ScanParams F, const Sear
         HIPCK(hipEventRecord(mev[0], st));
     }
     int rc;
-    if (cg && h->dsub == 16) rc = cg == 16 ? launch_mfma_kc2_scan_t<16, 16>(h, KP, st) : cg == 8 ? launch_mfma_kc2_scan_t<16, 8>(h, KP, st) : launch_mfma_kc2_scan_t<16, 4>(h, KP, st);
-    else if (cg) rc = cg == 16 ? launch_mfma_kc2_scan_t<8, 16>(h, KP, st) : launch_mfma_kc2_scan_t<8, 8>(h, KP, st);
+    if (cg && h->dsub == 16) rc = cg == 8 ? launch_mfma_kc2_scan_t<16, 8>(h, KP, st) : launch_mfma_kc2_scan_t<16, 4>(h, KP, st);
+    else if (cg) rc = launch_mfma_kc2_scan_t<8, 8>(h, KP, st);
     else if (h->dsub == 16) rc = tpw == 8 ? launch_mfma_kc_scan_t<16, 8>(h, KP, L.total, st) : launch_mfma_kc_scan_t<16, 16>(h, KP, L.total, st);
     else rc = tpw == 8 ? launch_mfma_kc_scan_t<8, 8>(h, KP, L.total, st) : launch_mfma_kc_scan_t<8, 16>(h, KP, L.total, st);
     if (rc) return rc;

@@ -366,8 +366,9 @@ __global__ __launch_bounds__(MF_NT, TPW > 8 ? 1 : 2) void k_scan_mfma_kc(const M
 // code loads (2 bytes per lane out of 64-byte rows, the rows touched again in every chunk) 7 ms, removing the matrix instructions
 // nothing.  Here
 //   * the dimensions are dealt out in QUARTERS: lane group g owns dimensions [g D/4, (g+1) D/4) (any bijection of the k index works
-//     as long as A and B agree), so that the code bytes a lane needs over all chunks are CONTIGUOUS: one 16-byte load per lane and
-//     16 code bytes (CG; 8 or 4 where m / 4 is not a multiple of 16) -- a tile of 16 codes x 64 bytes is read once, whole lines;
+//     as long as A and B agree), so that the code bytes a lane needs over all chunks are CONTIGUOUS: one 8-byte load per lane and
+//     8 code bytes (CG; 4 where m / 4 is not a multiple of 8; 16 compiles but its 32 registers of code words make the chunk loop
+//     spill) -- a tile of 16 codes x 64 bytes comes in whole lines, the second half of a line from L1 / L2;
 //   * chunk kc = the 8-dimension units {g NK 4 + 4 kc + j}; its codebook rows (64 KiB) and the 32 residual rows' units (8 KiB,
 //     XOR-swizzled: the 16 lanes of a fragment read 16 different slots) arrive by LDS-DMA (global_load_lds_dwordx4) in the buffer
 //     the matrix cores are NOT working from: two static buffer pairs, the chunk loop unrolled by two, one barrier per chunk;
@@ -418,6 +419,17 @@ __device__ __forceinline__ void mfk2_tile_survivors(const MfmaParams &P, MfmaChu
     }
 }
 
+#ifdef MFK_PROF
+__device__ unsigned long long g_mfk_prof[16];
+#define MFK_TICK(i)                                                         \
+    do {                                                                    \
+        const unsigned long long t_ = __builtin_readcyclecounter();         \
+        if (tid == 0) s_prof[i] += t_ - t_prev;                             \
+        t_prev = t_;                                                        \
+    } while (0)
+#else
+#define MFK_TICK(i)
+#endif
 template <int DSUB, int CG>
 __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams K) {
     static_assert(DSUB == 8 || DSUB == 16, "sub-quantizers of 8 or 16 dimensions");
@@ -432,6 +444,11 @@ __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams
     __shared__ uint4 s_bufs[NW * MFK2_CAP];
     __shared__ MfmaRow s_row[MFK_G];
     __shared__ u32 s_misc[8];
+#ifdef MFK_PROF
+    __shared__ unsigned long long s_prof[8];
+    if (threadIdx.x < 8) s_prof[threadIdx.x] = 0;
+    unsigned long long t_prev = __builtin_readcyclecounter();
+#endif
     const MfmaParams &P = K.M;
     MfmaChunk ck{0u, 0u, 0u};
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: addresses and branches by wave)
@@ -452,6 +469,7 @@ __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams
     const unsigned char *pqb = (const unsigned char *)P.pq16;
 
     for (;;) {
+        MFK_TICK(5);
         __syncthreads();  // (the previous item's LDS reads are done)
         if (tid == 0) {
             s_misc[0] = atomicAdd(P.work + xcd, 1u);
@@ -542,15 +560,6 @@ __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams
             s_row[row] = rw;
         }
         __syncthreads();
-        float thr[NTL][4];
-#pragma unroll
-        for (int rt = 0; rt < NTL; rt++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) thr[rt][i] = s_row[rt * 16 + 4 * g + i].thr;
-        float thrmin = thr[0][0];
-#pragma unroll
-        for (int b = 1; b < NTL * 4; b++) thrmin = __builtin_fminf(thrmin, thr[b >> 2][b & 3]);
-
         // ---- (b) the item's codes in PASSES of TPW NW tiles (tile ti * NW + wv of a pass is this wave's), each through all chunks ----
         // The rows' constants, the residual rows and the chunk rotation carry over from pass to pass: chunk 0 of the next pass is
         // fetched while the last chunk of this one is worked on, the next pass's code words and accumulator start values are loaded
@@ -632,16 +641,19 @@ __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams
         for (int ti = 0; ti < TPW; ti++) {  // the accumulators start at -||x||^2 s^2 / 2
             u32 pp = (u32)(ti * NW + wv) * 16u + (u32)n;
             pp = pp < lastp ? pp : lastp;
-            ci[ti] = xn[pp] * kinit;
+            ci[ti] = xn[pp];
         }
         u32 bufn = 0;
+        MFK_TICK(0);
         for (u32 po = 0;; po += PASS) {  // code offset of the pass within the item
 #pragma unroll
             for (int ti = 0; ti < TPW; ti++) {
-                const mf_f4 c4 = {ci[ti], ci[ti], ci[ti], ci[ti]};
+                const float c1v = ci[ti] * kinit;
+                const mf_f4 c4 = {c1v, c1v, c1v, c1v};
 #pragma unroll
                 for (int rt = 0; rt < NTL; rt++) acc[ti][rt] = c4;
             }
+            MFK_TICK(7);
             const u32 left = (u32)(c1 - c0) - po;
             const bool more = left > (u32)PASS;
             ntiles = (int)(((more ? (u32)PASS : left) + 15u) >> 4);
@@ -652,12 +664,18 @@ __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams
                 // a wait the compiler places later -- in front of the first LDS read -- would also wait for the DMA issued in between.
                 // For the same reason no global load may be waited for between a DMA issue and the barrier behind it: the counter is
                 // in order.)
+                MFK_TICK(1);
                 __builtin_amdgcn_s_waitcnt(0);
+                MFK_TICK(2);
                 __syncthreads();
+                MFK_TICK(3);
                 stage(cb1, ab1, kc + 1);
                 chunk(cb0, ab0);
+                MFK_TICK(1);
                 __builtin_amdgcn_s_waitcnt(0);
+                MFK_TICK(2);
                 __syncthreads();
+                MFK_TICK(3);
                 if (kc + 2 < NK) stage(cb0, ab0, kc + 2);
                 else if (more) stage(cb0, ab0, 0);
                 chunk(cb1, ab1);
@@ -668,10 +686,19 @@ __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams
                 for (int ti = 0; ti < TPW; ti++) {
                     u32 pp = po + (u32)PASS + (u32)(ti * NW + wv) * 16u + (u32)n;
                     pp = pp < lastp ? pp : lastp;
-                    ci[ti] = xn[pp] * kinit;
+                    ci[ti] = xn[pp];  // (used -- and waited for -- when the next pass starts)
                 }
             }
-            // ---- (c) compares, survivors ----
+            MFK_TICK(6);
+            // ---- (c) compares, survivors (the rows' thresholds come back from LDS: no registers held across the chunks) ----
+            float thr[NTL][4];
+#pragma unroll
+            for (int rt = 0; rt < NTL; rt++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) thr[rt][i] = s_row[rt * 16 + 4 * g + i].thr;
+            float thrmin = thr[0][0];
+#pragma unroll
+            for (int b = 1; b < NTL * 4; b++) thrmin = __builtin_fminf(thrmin, thr[b >> 2][b & 3]);
 #pragma unroll
             for (int ti = 0; ti < TPW; ti++) {
                 const int tt = ti * NW + wv;
@@ -685,6 +712,7 @@ __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams
                     mfk2_tile_survivors<NTL, MFK2_CAP>(P, ck, acc[ti], thr, pos, c1, kd, s_row, s_buf, s_misc + 1, bufn, first, g, lane);
                 }
             }
+            MFK_TICK(4);
             if (!more) break;
         }
         if (bufn) mf_flush(P, ck, s_buf, bufn, s_row, s_misc + 1, first, lane);
@@ -718,4 +746,7 @@ __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams
     }
     for (u32 i = ck.used + (u32)lane; i < ck.cap; i += 64)
         if (ck.base + i < P.surv_cap) P.surv[ck.base + i] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+#ifdef MFK_PROF
+    if (tid < 8) atomicAdd(&g_mfk_prof[tid], s_prof[tid]);
+#endif
 }

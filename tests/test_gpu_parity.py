@@ -862,9 +862,9 @@ def test_union_instances_forced(mi, oracle, D, m, C, n, w, k, dup):
     (256, 16, 5, 12000, 5, 50, 0, 1),     # K3mk (mmidx_scan_mfma_kc.h): two 128-dimension chunks, 16-dimensional sub-quantizers
     (256, 32, 4, 10000, 4, 30, 2, 2),     # K3mk, 8-dimensional sub-quantizers, RandomPermutation, ties
     (384, 48, 4, 8000, 4, 20, 0, 1),      # K3mk, three chunks, 48-byte codes (three sub-quantizers per verifying lane)
-    (1024, 64, 6, 8000, 6, 30, 2, 1),     # K3mk at YFCC100MExample.java:85-90's shape: eight chunks, 64 x 16 (16 code bytes per lane load)
+    (1024, 64, 6, 8000, 6, 30, 2, 1),     # K3mk at YFCC100MExample.java:85-90's shape: eight chunks, 64 x 16 (8 code bytes per lane load)
     (512, 32, 5, 9000, 5, 40, 0, 1),      # K3mk, 32 x 16: 8 code bytes per lane load
-    (1024, 128, 4, 6000, 4, 10, 0, 1),    # K3mk, 128 x 8: two 16-byte loads per lane and tile
+    (1024, 128, 4, 6000, 4, 10, 0, 1),    # K3mk, 128 x 8: four 8-byte loads per lane and tile
 ])
 def test_mfma_pass_b(mi, oracle, D, m, C, n, w, k, tr, dup):
     """K3m (`k_scan_mfma` + `k_mfma_verify` + `k_mfma_redo`, csrc/mmidx_scan_mfma.h): pass B as a certified lower bound on the matrix
