@@ -287,6 +287,7 @@ struct mmidx_index {
     int smin_bf16 = 1;           // option "smin_bf16": K3s's bf16 first stage for 16-dimensional sub-quantizers (0: fp32 only)
     int smin_valu = 0;           // option "smin_valu": K3s with packed VALU FMAs instead of the matrix cores (A/B)
     bool pre_on = false;         // the call before ran K3s (which pair of hint words describes it)
+    int pre_skip = 0;            // calls K3s still sits out in front of K3mk (it removed next to nothing the last time)
     int flat_chunk = 0;          // option "flat_chunk": codes per chunk of a flat PQ list (0 = sized from the batch)
     // K3m (mmidx_scan_mfma.h): pass B as a certified lower bound on the matrix cores
     unsigned short *d_pq16 = nullptr;  // fp16 codebook [D / 8][256][8], scaled by 2^pq_ep
@@ -1213,24 +1214,8 @@ template <int DSUB, int CG>
 int launch_mfma_kc2_scan_t(mmidx_index *h, const MfmaKcParams &KP, hipStream_t st) {
     int blocks = h->mfma_blocks > 0 ? h->mfma_blocks : std::max(h->num_cus, 8);  // one block of 512 threads per CU (156 KiB of LDS)
     blocks = std::max(8, (blocks + 7) & ~7);
-#ifdef MFK_PROF
-    {
-        unsigned long long z[16] = {0};
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mfk_prof), z, sizeof(z));
-    }
-#endif
     hipLaunchKernelGGL((k_scan_mfma_kc2<DSUB, CG>), dim3((unsigned)blocks), dim3(MFK2_NT), 0, st, KP);
     HIPCK(hipGetLastError());
-#ifdef MFK_PROF
-    {
-        unsigned long long z[16];
-        (void)hipStreamSynchronize(st);
-        (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_mfk_prof), sizeof(z));
-        const double b = 1.0 / blocks;
-        fprintf(stderr, "[mfk prof] Mcycles per block (wave 0): item prologue %.2f | compute(+issue) %.2f dma-wait %.2f barrier %.2f | next loads issue %.2f compares %.2f acc init %.2f | item end %.2f\n",
-                z[0] * b * 1e-6, z[1] * b * 1e-6, z[2] * b * 1e-6, z[3] * b * 1e-6, z[6] * b * 1e-6, z[4] * b * 1e-6, z[7] * b * 1e-6, z[5] * b * 1e-6);
-    }
-#endif
     return MMIDX_OK;
 }
 
@@ -1934,7 +1919,22 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
             bool use_pre = false;
             if (pre_ok && h->smin_pre > 0) use_pre = true;
             else if (pre_ok && h->smin_pre < 0 && h->D > 128 && h->mfma_ok && !h->no_mfma && h->xn_valid) {
-                use_pre = true;  // in front of K3mk always: the bound costs a few per cent of the scan it can save (no K3g figures to go by)
+                // in front of K3mk: the bound costs a tenth of the scan it can save, and there are no K3g figures to go by -- on, unless
+                // the last run removed less than an eighth of the pairs it looked at ([2] in, [0] left): then seven calls go without
+                use_pre = true;
+                if (h->pin_hint) {
+                    volatile int32_t *ph = (volatile int32_t *)h->pin_hint;
+                    if (h->pre_skip > 0) {
+                        h->pre_skip--;
+                        use_pre = false;
+                    } else if (h->pre_on) {
+                        const long long in = ph[2], left = ph[0];
+                        if (in > 0 && left * 8 > in * 7) {
+                            h->pre_skip = 7;
+                            use_pre = false;
+                        }
+                    }
+                }
             } else if (pre_ok && h->smin_pre < 0 && h->pin_hint) {
                 volatile int32_t *ph = (volatile int32_t *)h->pin_hint;
                 if (h->pre_on) {  // [2] pairs K3s looked at, [0] pairs it left: it stays while it removes a quarter

@@ -419,17 +419,6 @@ __device__ __forceinline__ void mfk2_tile_survivors(const MfmaParams &P, MfmaChu
     }
 }
 
-#ifdef MFK_PROF
-__device__ unsigned long long g_mfk_prof[16];
-#define MFK_TICK(i)                                                         \
-    do {                                                                    \
-        const unsigned long long t_ = __builtin_readcyclecounter();         \
-        if (tid == 0) s_prof[i] += t_ - t_prev;                             \
-        t_prev = t_;                                                        \
-    } while (0)
-#else
-#define MFK_TICK(i)
-#endif
 template <int DSUB, int CG>
 __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams K) {
     static_assert(DSUB == 8 || DSUB == 16, "sub-quantizers of 8 or 16 dimensions");
@@ -444,11 +433,6 @@ __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams
     __shared__ uint4 s_bufs[NW * MFK2_CAP];
     __shared__ MfmaRow s_row[MFK_G];
     __shared__ u32 s_misc[8];
-#ifdef MFK_PROF
-    __shared__ unsigned long long s_prof[8];
-    if (threadIdx.x < 8) s_prof[threadIdx.x] = 0;
-    unsigned long long t_prev = __builtin_readcyclecounter();
-#endif
     const MfmaParams &P = K.M;
     MfmaChunk ck{0u, 0u, 0u};
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: addresses and branches by wave)
@@ -469,7 +453,6 @@ __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams
     const unsigned char *pqb = (const unsigned char *)P.pq16;
 
     for (;;) {
-        MFK_TICK(5);
         __syncthreads();  // (the previous item's LDS reads are done)
         if (tid == 0) {
             s_misc[0] = atomicAdd(P.work + xcd, 1u);
@@ -644,7 +627,6 @@ __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams
             ci[ti] = xn[pp];
         }
         u32 bufn = 0;
-        MFK_TICK(0);
         for (u32 po = 0;; po += PASS) {  // code offset of the pass within the item
 #pragma unroll
             for (int ti = 0; ti < TPW; ti++) {
@@ -653,7 +635,6 @@ __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams
 #pragma unroll
                 for (int rt = 0; rt < NTL; rt++) acc[ti][rt] = c4;
             }
-            MFK_TICK(7);
             const u32 left = (u32)(c1 - c0) - po;
             const bool more = left > (u32)PASS;
             ntiles = (int)(((more ? (u32)PASS : left) + 15u) >> 4);
@@ -664,18 +645,12 @@ __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams
                 // a wait the compiler places later -- in front of the first LDS read -- would also wait for the DMA issued in between.
                 // For the same reason no global load may be waited for between a DMA issue and the barrier behind it: the counter is
                 // in order.)
-                MFK_TICK(1);
                 __builtin_amdgcn_s_waitcnt(0);
-                MFK_TICK(2);
                 __syncthreads();
-                MFK_TICK(3);
                 stage(cb1, ab1, kc + 1);
                 chunk(cb0, ab0);
-                MFK_TICK(1);
                 __builtin_amdgcn_s_waitcnt(0);
-                MFK_TICK(2);
                 __syncthreads();
-                MFK_TICK(3);
                 if (kc + 2 < NK) stage(cb0, ab0, kc + 2);
                 else if (more) stage(cb0, ab0, 0);
                 chunk(cb1, ab1);
@@ -689,7 +664,6 @@ __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams
                     ci[ti] = xn[pp];  // (used -- and waited for -- when the next pass starts)
                 }
             }
-            MFK_TICK(6);
             // ---- (c) compares, survivors (the rows' thresholds come back from LDS: no registers held across the chunks) ----
             float thr[NTL][4];
 #pragma unroll
@@ -712,7 +686,6 @@ __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams
                     mfk2_tile_survivors<NTL, MFK2_CAP>(P, ck, acc[ti], thr, pos, c1, kd, s_row, s_buf, s_misc + 1, bufn, first, g, lane);
                 }
             }
-            MFK_TICK(4);
             if (!more) break;
         }
         if (bufn) mf_flush(P, ck, s_buf, bufn, s_row, s_misc + 1, first, lane);
@@ -746,7 +719,4 @@ __global__ __launch_bounds__(MFK2_NT, 1) void k_scan_mfma_kc2(const MfmaKcParams
     }
     for (u32 i = ck.used + (u32)lane; i < ck.cap; i += 64)
         if (ck.base + i < P.surv_cap) P.surv[ck.base + i] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
-#ifdef MFK_PROF
-    if (tid < 8) atomicAdd(&g_mfk_prof[tid], s_prof[tid]);
-#endif
 }

@@ -232,7 +232,16 @@ def run(n=95_213_780, D=1024, m=64, ks=256, Cc=8192, k=30, ws=(2, 64), batch=409
             if int(st.mfma_launches) > 0:  # K3mk (mmidx_scan_mfma_kc.h): the matrix-core bound over the pairs K3s left
                 ml = int(st.mfma_launches)
                 scan_ms = st.mfma_scan_ms / ml
-                r["pass_b"].update({"kernel": "k_pair_smin_* (K3s) + k_scan_mfma_kc (K3mk) + k_mfma_verify", "mfma_scan_launch_ms": round(scan_ms, 3),
+                # the matrix-core work of the scan: 2 D flops per (kept pair, code of its list); the kept pairs' codes are taken as the
+                # far probes' codes x the fraction of far pairs kept (exact when all are kept, as on the between-clusters leg)
+                kept = int(st.passb_items_last) / max(1.0, batch * (w - 1.0))
+                tf = 2.0 * D * far_codes * kept / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
+                r["pass_b"]["roofline"] = {"bound": "mfma", "kernel": "k_scan_mfma_kc2 (K3mk)", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                                           "frac": round(tf / 2500.0, 4), "avg_launch_ms": round(scan_ms, 3), "traffic": None,
+                                           "note": "fp16 MFMA lower bound over all codes of the kept pairs' lists; co-limited by the LDS gather of the "
+                                                   "decoded codebook rows (16 bytes per code, 8 dimensions and 32 queries; ~3-way bank conflicts "
+                                                   "of random 16-byte rows), DESIGN.md 5.3"}
+                r["pass_b"].update({"kernel": "k_pair_smin_* (K3s) + k_scan_mfma_kc2 (K3mk) + k_mfma_verify", "mfma_scan_launch_ms": round(scan_ms, 3),
                                     "mfma_verify_launch_ms": round(st.mfma_verify_ms / ml, 3),
                                     "mfma_survivors_per_query": round(st.mfma_survivors / nd / batch, 1),
                                     "mfma_redo_queries_per_step": round(st.mfma_redo_queries / nd, 1)})
