@@ -304,9 +304,11 @@ struct mmidx_index {
     DevBuf<double> ws_lutpre;
     DevBuf<uint4> ws_surv;
     DevBuf<double> ws_R;               // RandomRotation: the kept pairs' exact rotated residuals [pairs][D]
+    DevBuf<u32> ws_defer;              // k_coarse_front_sel: count + list of the queries left to k_coarse_select_defer
     DevBuf<unsigned short> ws_R16;     // K3mk: the kept pairs' fp16 residuals [pairs][D]
     DevBuf<double> ws_nrow;            // ... and ||r||^2
     double coarse_maxabs = 0.0;        // largest |centroid element| (set_coarse)
+    int coarse_wave_sel = 1;           // option "coarse_wave_sel": 0 = the coarse stage's exact selection always by k_coarse_select_list (a block per query)
     int mfma_kc_v1 = 0;                // option "mfma_kc_v1": 1 = K3mk without LDS-DMA (k_scan_mfma_kc) also where k_scan_mfma_kc2 applies
     int mfma_kc_tpw = 8;               // option "mfma_kc_tpw": code tiles per wave of K3mk (8 or 16)
     DevBuf<u32> ws_mfctl, ws_psnap;
@@ -1584,8 +1586,9 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
         HIPCK(h->ws_Ql.reserve((size_t)nq * h->Dp));
         HIPCK(h->ws_gmin.reserve((size_t)nq * G * 2));
         HIPCK(h->ws_cdsel.reserve((size_t)nq * h->w));
+        HIPCK(h->ws_defer.reserve((size_t)nq + 1));
         hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)((nq + 3) / 4)), dim3(MMIDX_BLOCK), 0, st, dQ, (__bf16 *)h->ws_Qh.p, (__bf16 *)h->ws_Ql.p,
-                           (float *)nullptr, h->ws_qn.p, h->D, h->Dp, (long long)nq);
+                           (float *)nullptr, h->ws_qn.p, h->D, h->Dp, (long long)nq, h->ws_defer.p);
         const int ntiles = h->Cp / G16_BC;
         const int qblocks = (int)((nq + G16_BQ - 1) / G16_BQ);
         const int csplit = std::max(1, std::min(ntiles, (512 + qblocks - 1) / qblocks));
@@ -1630,8 +1633,20 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
         if (split) {
             HIPCK(h->ws_clist.reserve((size_t)nq * MMIDX_CLIST));
             A.clist = (u32 *)h->ws_clist.p;
-            hipLaunchKernelGGL(k_coarse_front, dim3((unsigned)((nq + 3) / 4)), dim3(MMIDX_BLOCK), 0, st, A);
-            if (h->C <= 8 * MMIDX_BLOCK)
+            // front end + exact stage by one wave per query where its LDS tile applies (option "coarse_wave_sel", default on); what it
+            // leaves (more than 64 candidates) goes through the block-per-query form
+            A.defer = h->ws_defer.p;
+            const bool wave_sel = h->coarse_wave_sel && h->w < 64 && (h->D == 64 || h->D == 128 || h->D == 256);
+            const unsigned fgrid = (unsigned)((nq + 3) / 4);
+            if (wave_sel && h->D == 128) hipLaunchKernelGGL((k_coarse_front_sel<8>), dim3(fgrid), dim3(MMIDX_BLOCK), 0, st, A);
+            else if (wave_sel && h->D == 64) hipLaunchKernelGGL((k_coarse_front_sel<4>), dim3(fgrid), dim3(MMIDX_BLOCK), 0, st, A);
+            else if (wave_sel) hipLaunchKernelGGL((k_coarse_front_sel<16>), dim3(fgrid), dim3(MMIDX_BLOCK), 0, st, A);
+            else hipLaunchKernelGGL(k_coarse_front, dim3(fgrid), dim3(MMIDX_BLOCK), 0, st, A);
+            if (wave_sel) {
+                const unsigned dgrid = (unsigned)std::min<long long>(nq, 2ll * std::max(h->num_cus, 8));
+                if (h->C <= 8 * MMIDX_BLOCK) hipLaunchKernelGGL(k_coarse_select_defer<8>, dim3(dgrid), dim3(MMIDX_BLOCK), glds, st, A);
+                else hipLaunchKernelGGL(k_coarse_select_defer<32>, dim3(dgrid), dim3(MMIDX_BLOCK), glds, st, A);
+            } else if (h->C <= 8 * MMIDX_BLOCK)
                 hipLaunchKernelGGL(k_coarse_select_list<8>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), glds, st, A);
             else
                 hipLaunchKernelGGL(k_coarse_select_list<32>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), glds, st, A);
@@ -2427,6 +2442,7 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_surv.release();
     h->ws_R.release();
     h->ws_R16.release();
+    h->ws_defer.release();
     h->ws_nrow.release();
     h->ws_lutpre.release();
     h->ws_mfctl.release();
@@ -3208,6 +3224,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->mfma_sub = value > 0 ? value : 0;
     } else if (n == "mfma_qcap") {
         h->mfma_qcap = value > 0 ? value : 0;
+    } else if (n == "coarse_wave_sel") {
+        h->coarse_wave_sel = value != 0;
     } else if (n == "mfma_kc_v1") {
         h->mfma_kc_v1 = value != 0;
     } else if (n == "mfma_kc_tpw") {

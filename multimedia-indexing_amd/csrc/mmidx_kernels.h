@@ -542,6 +542,7 @@ struct ApproxSel {
     int G, Dp;               // groups per query (Cp / 8), k padded to a multiple of 32
     // K1f split in two (k_coarse_front -> k_coarse_select_list): the certified candidates of every query
     u32 *clist;              // [nq][MMIDX_CLIST]: entry 0 = number of candidates (MMIDX_CSEL_CAP + 1: the exact-row path), then the candidates
+    u32 *defer;              // k_coarse_front_sel: [0] number of queries it left to k_coarse_select_defer, [1 ..] those queries
     int nq;
     int cand_chunk;          // candidates per round of the exact stage (<= MMIDX_CAND_CHUNK; the launch's LDS holds that many rows of terms)
 };
@@ -998,7 +999,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 // one wave per row: X (fp64) -> bf16 head / tail (zero padded to Dp), optional fp32 copy and squared norm
 __global__ __launch_bounds__(MMIDX_BLOCK) void k_split_bf16(const double *__restrict__ X, __bf16 *__restrict__ H,
                                                             __bf16 *__restrict__ L, float *__restrict__ X32,
-                                                            double *__restrict__ nrm2, int D, int Dp, long long n) {
+                                                            double *__restrict__ nrm2, int D, int Dp, long long n, u32 *__restrict__ zero_word = nullptr) {
+    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;  // (a counter of a later kernel of the same stream: saves a memset launch)
     const long long r = (long long)blockIdx.x * (MMIDX_BLOCK / 64) + (threadIdx.x >> 6);
     if (r >= n) return;
     const int lane = threadIdx.x & 63;
@@ -1910,6 +1912,248 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_front(const ApproxSel A)
     if (lane == 0) list[0] = n <= MMIDX_CLIST - 1 ? n : (u32)(MMIDX_CSEL_CAP + 1);
 }
 
+// K1f in ONE kernel where the exact stage fits a wave: front end as k_coarse_front, then -- for a query with at most 64 candidates
+// (the usual 1.3 (w + 1)) -- the exact distances, the ranking and the bounded-queue rule by the same wave, no block barrier and no
+// block-wide staging (k_coarse_select_list spent 117 us per 16384 queries of the headline workload between barriers: one block per
+// query, 24 rows of terms through LDS, then one lane per candidate adding them up while 230 lanes wait).  NJB = D / 16 blocks of
+// dimensions; the keys are the staged form's bit for bit (same operations in the same order).  The queries it cannot serve keep their
+// candidate list and are appended to A.defer: k_coarse_select_defer (k_coarse_select_list over that list) answers them.
+template <int NJB>
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_front_sel(const ApproxSel A) {
+    constexpr int GPL = 16;  // groups per lane: G <= 1024 (the host checks)
+    constexpr int NW = MMIDX_BLOCK / 64;
+    __shared__ double s_terms[NW][16][65];
+    __shared__ u64 s_ckey[NW][64], s_selk[NW][64];
+    __shared__ u32 s_cidx[NW][64];
+    __shared__ int s_seli[NW][64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int q = (int)blockIdx.x * NW + wv;
+    if (q >= A.nq) return;  // (wave-uniform; the kernel has no block barrier)
+    u64 *ckey = s_ckey[wv], *sel_k = s_selk[wv];
+    u32 *cidx = s_cidx[wv];
+    int *sel_i = s_seli[wv];
+    const int C = A.C, w = A.w, G = A.G, D = A.D;
+    const int R = w + 1;
+    const double qn = A.qn[q];
+    const double qnorm = sqrt(qn);
+    const double sumn = A.cnorm_max + qnorm;
+    const double eps16 = (2.0 * 3.1 * 0x1p-16 * qnorm * A.cnorm_max + 2.0 * (3.0 * (double)A.Dp + 16.0) * 0x1p-22 * qnorm * A.cnorm_max +
+                          1e-12 * (A.cn_max + qn) + (0x1p-21 + 0x1p-20) * sumn * sumn) * (1.0 + 1e-9);
+    const float inf = __int_as_float(0x7f800000);
+    u32 *list = A.clist + (size_t)q * MMIDX_CLIST;
+    u32 n = 0;  // wave-uniform
+    {
+        float m1[GPL], ry[GPL];
+        float km[4] = {inf, inf, inf, inf};
+#pragma unroll
+        for (int i = 0; i < GPL; i++) {
+            const int g = lane + 64 * i;
+            const int gc = g < G ? g : G - 1;
+            const float2 v = A.gpair[(size_t)q * G + gc];  // (unconditional load on a clamped index)
+            m1[i] = g < G ? (v.x < 0.0f ? 0.0f : v.x) : inf;  // exact distances are >= 0
+            ry[i] = g < G ? v.y : inf;
+            km[i & 3] = m1[i] < km[i & 3] ? m1[i] : km[i & 3];
+        }
+        // ---- tau: the R-th smallest of the 256 partial minima, by bisection on the bit patterns (as k_coarse_front)
+        float tau;
+        {
+            const u32 k0 = (u32)__float_as_int(km[0]) & 0x7fffffffu, k1 = (u32)__float_as_int(km[1]) & 0x7fffffffu,
+                      k2 = (u32)__float_as_int(km[2]) & 0x7fffffffu, k3 = (u32)__float_as_int(km[3]) & 0x7fffffffu;
+            const u32 mn01 = k0 < k1 ? k0 : k1, mn23 = k2 < k3 ? k2 : k3, mx01 = k0 < k1 ? k1 : k0, mx23 = k2 < k3 ? k3 : k2;
+            u32 lo_k = wave_min_u32(mn01 < mn23 ? mn01 : mn23), hi_k = wave_max_u32(mx01 < mx23 ? mx23 : mx01);
+            while (lo_k < hi_k) {
+                const u32 mid = lo_k + ((hi_k - lo_k) >> 1);
+                const int c = (int)__popcll(__builtin_amdgcn_ballot_w64(k0 <= mid)) + (int)__popcll(__builtin_amdgcn_ballot_w64(k1 <= mid)) +
+                              (int)__popcll(__builtin_amdgcn_ballot_w64(k2 <= mid)) + (int)__popcll(__builtin_amdgcn_ballot_w64(k3 <= mid));
+                if (c >= R) hi_k = mid;
+                else lo_k = mid + 1;
+            }
+            tau = __int_as_float((int)hi_k);
+        }
+        const double cut = ((double)tau + eps16) + eps16;
+        if (!(cut < (double)inf) || !(sumn * sumn < 1e37)) {  // nothing can be certified: the exact row
+            if (lane == 0) {
+                list[0] = MMIDX_CSEL_CAP + 1;
+                A.defer[1 + atomicAdd(A.defer, 1u)] = (u32)q;
+            }
+            return;
+        }
+        // ---- candidates (as k_coarse_front), the first 64 also into the wave's LDS list
+        const u64 lane_lt = (1ull << lane) - 1ull;
+        auto push = [&](const bool pass, const int c) {
+            const u64 mask = __builtin_amdgcn_ballot_w64(pass);
+            if (pass) {
+                const u32 slot = n + (u32)__popcll(mask & lane_lt);
+                if (slot < MMIDX_CLIST - 1) list[1 + slot] = (u32)c;
+                if (slot < 64) cidx[slot] = (u32)c;
+            }
+            n += (u32)__popcll(mask);
+        };
+#pragma unroll
+        for (int i = 0; i < GPL; i++) {
+            const int g = lane + 64 * i;
+            const int cb = (g >> 4) * G16_BC + (g & 15);  // column ct of the group is centroid cb + 16 ct
+            const int a1 = __float_as_int(ry[i]) & 7;
+            const float m2 = __int_as_float(__float_as_int(ry[i]) & ~7);  // rounded towards zero: never above the true runner-up
+            const bool hot = (double)m1[i] <= cut;
+            push(hot && cb + 16 * a1 < C, cb + 16 * a1);
+            const bool all = hot && (double)m2 <= cut;
+            if (__builtin_amdgcn_ballot_w64(all)) {  // rare: two of the w+1 nearest in one group of 8
+#pragma unroll
+                for (int ct = 0; ct < 8; ct++) push(all && ct != a1 && cb + 16 * ct < C, cb + 16 * ct);
+            }
+        }
+    }
+    if (n > 64 || (int)n < R) {  // (fewer than w + 1 candidates cannot happen with a valid cut; k_coarse_select_list's business either way)
+        if (lane == 0) {
+            list[0] = n <= MMIDX_CLIST - 1 ? n : (u32)(MMIDX_CSEL_CAP + 1);
+            A.defer[1 + atomicAdd(A.defer, 1u)] = (u32)q;
+        }
+        return;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- exact distances: a LANE per candidate adds the terms (c_j - q_j)^2 in dimension order (IVFPQ.java:583); the terms of 16
+    //      dimensions at a time come through the wave's LDS tile, computed by all lanes from coalesced loads (8 lanes x 16 bytes = one
+    //      128-byte line of a candidate's row, 8 candidates per load instruction); the next 16 dimensions' rows are requested before
+    //      the current ones are summed
+    {
+        double(*terms)[65] = s_terms[wv];  // [16][64 + 1]: lane c reads terms[j][c] (consecutive banks), the 8 lanes of a row write two apart
+        const int cl = lane >> 3, jp = lane & 7;
+        const int ng = ((int)n + 7) >> 3;  // load instructions per 16 dimensions (<= 8)
+        const double *rowp[8];
+#pragma unroll
+        for (int gq = 0; gq < 8; gq++) {
+            const int ci = gq * 8 + cl;
+            const int cc = ci < (int)n ? ci : (int)n - 1;  // (loads run on a clamped index)
+            rowp[gq] = A.coarse + (size_t)cidx[cc] * (u32)D + 2 * jp;
+        }
+        const double *qp = A.Q + (size_t)q * D + 2 * jp;
+        double2 cur[8], nxt[8], qc, qx;
+#pragma unroll
+        for (int gq = 0; gq < 8; gq++) {
+            cur[gq] = make_double2(0.0, 0.0);
+            if (gq < ng) cur[gq] = *(const double2 *)(rowp[gq]);
+        }
+        qc = *(const double2 *)qp;
+        double acc = 0.0;
+#pragma unroll 1
+        for (int jb = 0; jb < NJB; jb++) {
+            if (jb + 1 < NJB) {
+#pragma unroll
+                for (int gq = 0; gq < 8; gq++) {
+                    nxt[gq] = make_double2(0.0, 0.0);
+                    if (gq < ng) nxt[gq] = *(const double2 *)(rowp[gq] + (jb + 1) * 16);
+                }
+                qx = *(const double2 *)(qp + (jb + 1) * 16);
+            }
+#pragma unroll
+            for (int gq = 0; gq < 8; gq++) {
+                if (gq < ng) {
+                    const double d0 = cur[gq].x - qc.x, d1 = cur[gq].y - qc.y;
+                    terms[2 * jp][gq * 8 + cl] = d0 * d0;
+                    terms[2 * jp + 1][gq * 8 + cl] = d1 * d1;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            {
+                double tv[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++) tv[j] = terms[j][lane];
+#pragma unroll
+                for (int j = 0; j < 16; j++) acc += tv[j];  // (lane >= n: junk, never used)
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int gq = 0; gq < 8; gq++) cur[gq] = nxt[gq];
+            qc = qx;
+        }
+        if (lane < (int)n) ckey[lane] = dkey(acc);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- ranking by (distance, index) in registers, bounded-queue rule: coarse_select_finish's n <= 64 branch, a lane for a thread
+    {
+        const bool have = lane < (int)n;
+        const u64 mk = have ? ckey[lane] : MMIDX_KEY_MAX;
+        const u32 mv = have ? cidx[lane] : 0xFFFFFFFFu;
+        int rank = 0, eqc = 0;
+        for (int j = 0; j < (int)n; j++) {
+            const u32 olo = wave_read_u32((u32)mk, j), ohi = wave_read_u32((u32)(mk >> 32), j);
+            const u64 ok = ((u64)ohi << 32) | olo;
+            rank += ok < mk;
+            eqc += ok == mk;
+        }
+        if (__builtin_amdgcn_ballot_w64(have && eqc > 1)) {  // wave-uniform
+            rank = 0;
+            for (int j = 0; j < (int)n; j++) {
+                const u32 olo = wave_read_u32((u32)mk, j), ohi = wave_read_u32((u32)(mk >> 32), j), ov = wave_read_u32(mv, j);
+                const u64 ok = ((u64)ohi << 32) | olo;
+                rank += (ok < mk) || (ok == mk && (ov < mv || (ov == mv && j < lane)));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // (every lane has read its entry before any lane writes)
+        if (have) {
+            ckey[rank] = mk;
+            cidx[rank] = mv;
+            if (rank < R) {
+                sel_k[rank] = mk;
+                sel_i[rank] = (int)mv;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    bool plain;
+    {
+        const bool eq = lane < w && sel_k[lane] == sel_k[lane + 1];
+        plain = __builtin_amdgcn_ballot_w64(eq) == 0;
+        if (plain && lane < w) {
+            A.cells[(size_t)q * w + lane] = sel_i[lane];
+            A.cdsel[(size_t)q * w + lane] = keyd(sel_k[lane]);
+        }
+    }
+    if (lane == 0 && !plain) {  // equal keys among the w + 1 best: coarse_select_finish's closed form
+        int32_t *out = A.cells + (size_t)q * w;
+        double *dout = A.cdsel + (size_t)q * w;
+        if (sel_k[w - 1] == sel_k[w]) {
+            const u64 tk = sel_k[w - 1];
+            int b = 0;
+            while (b < w && sel_k[b] < tk) b++;
+            int last = w;
+            while (last + 1 < (int)n && ckey[last + 1] == tk) last++;
+            int p = 0, nonjunk = 0, prev = -1;
+            while (nonjunk < w) {
+                int best = 0x7fffffff, bpos = -1;
+                for (int t = 0; t <= last; t++) {
+                    const int ci = (int)cidx[t];
+                    if (ci > prev && ci < best) {
+                        best = ci;
+                        bpos = t;
+                    }
+                }
+                if (bpos < 0) break;
+                prev = best;
+                nonjunk++;
+                if (ckey[bpos] == tk) p++;
+            }
+            const int e = b - (w - p);
+            for (int r = 0; r < w - b; r++) sel_i[b + r] = (int)cidx[b + e + r];
+        }
+        int a = 0;
+        while (a < w) {
+            int bnd = a;
+            while (bnd + 1 < w && sel_k[bnd + 1] == sel_k[a]) bnd++;
+            for (int t = a; t <= bnd; t++) {
+                out[t] = sel_i[bnd - (t - a)];
+                dout[t] = keyd(sel_k[a]);
+            }
+            a = bnd + 1;
+        }
+    }
+}
+
 template <int PER>
 __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_list(const ApproxSel A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1929,6 +2173,30 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_list(const Approx
     __syncthreads();
     const int n = (int)s_pad[0];
     coarse_select_finish<PER>(A, q, n, ckey, cidx, sel_k, sel_i, s_k, s_i);
+}
+
+// the queries k_coarse_front_sel left (more than 64 candidates, or nothing certifiable): k_coarse_select_list over its list of them
+template <int PER>
+__global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_select_defer(const ApproxSel A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *ckey = (u64 *)smem;
+    u32 *cidx = (u32 *)(ckey + MMIDX_CSEL_CAP);
+    u64 *sel_k = (u64 *)(cidx + MMIDX_CSEL_CAP);
+    int *sel_i = (int *)(sel_k + (A.w + 1));
+    __shared__ u64 s_k[MMIDX_BLOCK / 64];
+    __shared__ int s_i[MMIDX_BLOCK / 64];
+    __shared__ u32 s_pad[8];
+    const int tid = threadIdx.x;
+    const u32 nd = *A.defer;
+    for (u32 i = blockIdx.x; i < nd; i += gridDim.x) {
+        __syncthreads();  // (the previous query's LDS is done with)
+        const int q = (int)A.defer[1 + i];
+        const u32 c = A.clist[(size_t)q * MMIDX_CLIST + tid];
+        if (tid == 0) s_pad[0] = c;
+        else cidx[tid - 1] = c;
+        __syncthreads();
+        coarse_select_finish<PER>(A, q, (int)s_pad[0], ckey, cidx, sel_k, sel_i, s_k, s_i);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

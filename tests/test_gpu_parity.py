@@ -1157,7 +1157,8 @@ def test_pass_a_histogram_kernel(mi, oracle, case):
     ix.close()
 
 
-@pytest.mark.parametrize("D,C,w", [(24, 1000, 7), (130, 700, 12), (128, 2049, 31), (260, 1536, 5), (64, 4100, 40), (16, 16390, 9), (100, 1000, 9), (128, 8192, 32), (128, 128, 3)])
+@pytest.mark.parametrize("D,C,w", [(24, 1000, 7), (130, 700, 12), (128, 2049, 31), (260, 1536, 5), (64, 4100, 40), (16, 16390, 9), (100, 1000, 9), (128, 8192, 32), (128, 128, 3),
+                                   (256, 1536, 6), (128, 4096, 8), (64, 900, 63)])
 def test_coarse_stage_group_minima_shapes(mi, oracle, D, C, w):
     """K1e/K1f (bf16-split MFMA dot products + group minima) on shapes that exercise its padding: D not a multiple
     of 32, more than one 128-wide k chunk (D > 128), C not a multiple of 128, C / 8 groups per thread > 1; clustered
@@ -1183,16 +1184,19 @@ def test_coarse_stage_group_minima_shapes(mi, oracle, D, C, w):
                         5.0 * rng.standard_normal((10, D))])
     dQ = torch.tensor(Q, dtype=torch.float64, device="cuda")
     res = {}
-    for v1 in (0, 1):
-        ix.set_option("coarse_v1", v1)
+    # (2: the exact stage by a block per query (k_coarse_select_list) also where the wave-per-query form (k_coarse_front_sel: D = 64,
+    #  128, 256, w < 64, at most 64 candidates) would have answered)
+    for v1 in (0, 1, 2):
+        ix.set_option("coarse_v1", v1 & 1)
+        ix.set_option("coarse_wave_sel", 0 if v1 == 2 else 1)
         cells = torch.empty(len(Q), w, dtype=torch.int32, device="cuda")
         cd = torch.empty(len(Q), w, dtype=torch.float64, device="cuda")
         nat.check(mi.lib().mmidx_coarse_device(ix._h, len(Q), dQ.data_ptr(), cells.data_ptr(), cd.data_ptr(), None))
         torch.cuda.synchronize()
         res[v1] = (cells.cpu().numpy(), cd.cpu().numpy())
     exp = np.stack([ref.nearest_coarse(q, w) for q in Q])
-    assert np.array_equal(res[0][0], exp) and np.array_equal(res[1][0], exp)
-    assert np.array_equal(res[0][1], res[1][1])
+    assert np.array_equal(res[0][0], exp) and np.array_equal(res[1][0], exp) and np.array_equal(res[2][0], exp)
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][1], res[2][1])
     # exact distances: sequential fp64 sums of the selected cells
     for qi in (0, 17, len(Q) - 1):
         for r in (0, w - 1):
