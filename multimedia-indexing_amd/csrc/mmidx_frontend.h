@@ -309,9 +309,16 @@ __global__ __launch_bounds__(256) void k_vlad_accum(const double *__restrict__ c
     // assignments in descriptor order: broadcast LDS reads)
     for (int d = tid; d < nd; d += 256) atomicAdd(cstart + nn[d] + 1, 1);
     __syncthreads();
-    if (tid == 0) {
-        cstart[0] = 0;
-        for (int c = 0; c < nc; c++) cstart[c + 1] += cstart[c];
+    if (tid < 64) {  // starts: a wave-wide scan of the counts (64 centroids per step), not 128 dependent LDS updates by one thread
+        u32 carry = 0;
+        for (int base = 0; base < nc; base += 64) {
+            const int c = base + tid;
+            const u32 cnt = c < nc ? (u32)cstart[c + 1] : 0u;
+            const u32 incl = wave_incl_scan_u32(cnt);
+            if (c < nc) cstart[c + 1] = (int)(carry + incl);
+            carry += wave_read_u32(incl, 63);
+        }
+        if (tid == 0) cstart[0] = 0;
     }
     __syncthreads();
     for (int c = tid; c < nc; c += 256) {
@@ -322,6 +329,55 @@ __global__ __launch_bounds__(256) void k_vlad_accum(const double *__restrict__ c
     __syncthreads();
     // phase 3: thread <-> (centroid, dim): a wave reads whole descriptor rows (coalesced), in descriptor order
     double ss = 0.0;
+    if constexpr (DL == 64) {
+        // 64-dimensional descriptors: a lane per dimension, a wave per quarter of the centroids.  The rows of a wave's centroids are
+        // one contiguous stretch of the grouped list: eight rows are requested together ACROSS centroid boundaries (an image has ~4
+        // descriptors per centroid: one centroid at a time left one load in flight per thread and 170 us per image block), then added
+        // in list order -- per element the same additions in the same order as before; the next centroid's coordinate is fetched
+        // while the current one's rows are added.
+        const int wv = tid >> 6, lane = tid & 63;
+        const int cpw = (nc + 3) >> 2;
+        const int c_lo = wv * cpw < nc ? wv * cpw : nc, c_hi = c_lo + cpw < nc ? c_lo + cpw : nc;
+        if (c_lo < c_hi) {
+            int c = c_lo, p = cstart[c_lo];
+            const int pe = cstart[c_hi];
+            int cend = cstart[c + 1];
+            double v = 0.0, cv = codebook[(size_t)c * 64 + lane];
+            double cvn = c + 1 < c_hi ? codebook[(size_t)(c + 1) * 64 + lane] : 0.0;
+            auto emit = [&]() {  // element (c, lane) is complete: power normalisation, next centroid
+                if (norms_on) {
+                    const double a = sqrt(fabs(v));  // normalizePower(0.5): signum(v) * pow(|v|, 0.5)   (Normalization.java:74-79)
+                    v = (v > 0.0) ? a : ((v < 0.0) ? -a : v);
+                    ss += v * v;
+                }
+                vout[(size_t)c * 64 + lane] = v;
+                c++;
+                v = 0.0;
+                cv = cvn;
+                if (c < c_hi) cend = cstart[c + 1];
+                if (c + 1 < c_hi) cvn = codebook[(size_t)(c + 1) * 64 + lane];
+            };
+            while (p < pe) {
+                constexpr int RU = 8;  // rows in flight per wave (16: more registers, fewer blocks per CU, measured slower)
+                const int n8 = pe - p < RU ? pe - p : RU;
+                double a[RU];
+#pragma unroll
+                for (int u = 0; u < RU; u++) {
+                    const int pu = u < n8 ? p + u : pe - 1;  // (loads run on a clamped index)
+                    a[u] = D[(size_t)lst[pu] * 64 + lane];
+                }
+#pragma unroll
+                for (int u = 0; u < RU; u++) {
+                    if (u < n8) {
+                        while (p + u >= cend) emit();  // (wave-uniform; centroids without descriptors come out as zeros)
+                        v += a[u] - cv;
+                    }
+                }
+                p += n8;
+            }
+            while (c < c_hi) emit();
+        }
+    } else
     for (int e = tid; e < veclen; e += 256) {
         const int c = e / dl, i = e - c * dl;
         const double cv = codebook[e];
