@@ -336,7 +336,12 @@ int mmidx_set_profiling(mmidx_index *h, int enabled);
  * the matrix cores), "smin_bf16" (0: without K3s's bf16 first stage), "coarse_dma_kc" (0: long vectors through K1e's register staging instead of the
  * LDS-DMA kernel), "no_union" (K3g's instances that rank the union of the verified candidates: -1 always, 1 never, 0 hint).  On a sharded handle: "shard_exchange" (0: partial lists stored into the owners' buffers over xGMI, 1: ncclSend /
  * ncclRecv), "tie_slots" (flagged queries per owner and replay round, 0 = no replay), "shard_max_round"; every other option goes
- * to every shard. */
+ * to every shard.  Round 4: "no_mfma" (1: pass B through K3g / K3f instead of the matrix-core bound K3m / K3mk), "mfma_sub" (codes per
+ * work item of K3m / K3mk, 0 = sized from the call), "mfma_qcap" (survivor records per launch; a small value sends queries through the
+ * redo path), "mfma_blocks", "mfma_kc_v1" (1: K3mk without LDS-DMA, k_scan_mfma_kc, also where k_scan_mfma_kc2 applies),
+ * "mfma_kc_tpw" (8 / 16 code tiles per wave of k_scan_mfma_kc), "lut_pre" (pass A's tables built by their own kernel),
+ * "coarse_wave_sel" (0: the coarse stage's exact selection always by a block per query instead of k_coarse_front_sel),
+ * "shard_pipeline" (0: no second stream / communicator for the query exchange of a sharded handle).  None of them changes a result. */
 int mmidx_set_option(mmidx_index *h, const char *name, int value);
 int mmidx_get_stats(mmidx_index *h, mmidx_stats *out);
 
