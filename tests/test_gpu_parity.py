@@ -1497,13 +1497,16 @@ def test_randomised_differential_fuzz():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("D,m", [(64, 8), (256, 16)])
 @pytest.mark.parametrize("scale,qscale", [(1e-25, 1.0), (1e-9, 1.0), (1e9, 1.0), (1e25, 1.0), (1.0, 1e6), (1e-160, 1.0), (1e140, 1.0)])
-def test_mfma_pass_b_magnitudes(mi, oracle, scale, qscale):
+def test_mfma_pass_b_magnitudes(mi, oracle, scale, qscale, D, m):
     """K3m scales residuals and codebook by powers of two before the fp16 rounding (per item / per index): data 25 orders of
     magnitude away from 1, queries far outside the data (residuals a million times the codebook's scale: the exponent difference
     between the two scales is limited, such queries go to the redo), and magnitudes whose squares leave fp32 or fp64's normal range.
-    The bound must never drop a true neighbour: ids and distance bits are the oracle's."""
-    D, m, C, n, w, k, ks = 64, 8, 6, 12000, 6, 20, 256
+    The bound must never drop a true neighbour: ids and distance bits are the oracle's.  D = 256: K3mk, whose residual scale is one
+    power of two per LAUNCH (from the largest centroid and query elements): one far query among ordinary ones coarsens every row's
+    scale, the certificate's subnormal term grows with it and the survivors are verified or redone -- never dropped."""
+    C, n, w, k, ks = 6, 12000 if D == 64 else 6000, 6, 20, 256
     rng = np.random.default_rng(11)
     mu = 0.5 * rng.standard_normal((C, D))
     base = mu[rng.integers(0, C, n)] + rng.standard_normal((n, D))
@@ -1519,4 +1522,7 @@ def test_mfma_pass_b_magnitudes(mi, oracle, scale, qscale):
     ref.add_vectors(base)
     Q = np.concatenate([0.5 * (base[:24] + base[100:124]), base[:24] + 0.01 * scale * rng.standard_normal((24, D))]) * qscale
     assert_same(ix.search_batch(k, Q), ref.search_batch(Q, k))
+    if qscale == 1.0:  # one query a million times the data's scale in the same call (K3mk: it sets the launch's residual scale)
+        Q2 = np.concatenate([Q[:40], 1e6 * Q[40:41], 1e-6 * Q[41:42]])
+        assert_same(ix.search_batch(k, Q2), ref.search_batch(Q2, k))
     ix.close()
