@@ -865,6 +865,7 @@ def test_union_instances_forced(mi, oracle, D, m, C, n, w, k, dup):
     (1024, 64, 6, 8000, 6, 30, 2, 1),     # K3mk at YFCC100MExample.java:85-90's shape: eight chunks, 64 x 16 (8 code bytes per lane load)
     (512, 32, 5, 9000, 5, 40, 0, 1),      # K3mk, 32 x 16: 8 code bytes per lane load
     (1024, 128, 4, 6000, 4, 10, 0, 1),    # K3mk, 128 x 8: four 8-byte loads per lane and tile
+    (256, 16, 3, 60000, 3, 50, 2, 1),     # K3mk, lists of ~20 k codes: items of eight 1024-code passes, several items per group, the chunk rotation across passes
 ])
 def test_mfma_pass_b(mi, oracle, D, m, C, n, w, k, tr, dup):
     """K3m (`k_scan_mfma` + `k_mfma_verify` + `k_mfma_redo`, csrc/mmidx_scan_mfma.h): pass B as a certified lower bound on the matrix
