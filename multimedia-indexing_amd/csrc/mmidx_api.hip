@@ -15,6 +15,7 @@
 #include "mmidx_scan_grp.h"
 #include "mmidx_scan_mfma.h"
 #include "mmidx_scan_mfma_kc.h"
+#include "mmidx_scan_mfma_cr.h"
 #include "mmidx_frontend.h"
 
 #include <algorithm>
@@ -304,6 +305,9 @@ struct mmidx_index {
     DevBuf<double> ws_lutpre;
     DevBuf<uint4> ws_surv;
     DevBuf<double> ws_R;               // RandomRotation: the kept pairs' exact rotated residuals [pairs][D]
+    DevBuf<int2> ws_lgrp;              // K3mc: per list {first group, groups}
+    DevBuf<unsigned char> ws_rows;     // K3mc: the pair slots' row records (MfmaRow)
+    int mfma_cr = 1;                   // option "mfma_cr": 0 = flat PQ through K3m also where K3mc applies
     DevBuf<u32> ws_defer;              // k_coarse_front_sel: count + list of the queries left to k_coarse_select_defer
     DevBuf<unsigned short> ws_R16;     // K3mk: the kept pairs' fp16 residuals [pairs][D]
     DevBuf<double> ws_nrow;            // ... and ||r||^2
@@ -1223,15 +1227,18 @@ int launch_mfma_kc2_scan_t(mmidx_index *h, const MfmaKcParams &KP, hipStream_t s
 
 // K3mk (mmidx_scan_mfma_kc.h): pass B through the matrix-core bound for vectors of several 128-dimension chunks.  Same contract as
 // launch_mfma_common (which dispatches here); returns 1 when it does not apply.
+// cr: K3mc (mmidx_scan_mfma_cr.h: D = 128, the codes resident, the list's groups streaming) instead of K3mk
 int launch_mfma_kc(mmidx_index *h, const ScanParams &S, ScanParams F, const SearchPlan &pl, int nlists, int nchunks_f, long long npairs, long long maxlen,
-                   hipStream_t st, long long nq, const double *flat_lut) {
-    if (h->transform == MMIDX_TR_ROTATION || (size_t)npairs * h->D * 2 > ((size_t)16 << 30) || h->m % 16 != 0 || h->m > 128) return 1;
-    constexpr int G = MFK_G;
+                   hipStream_t st, long long nq, const double *flat_lut, const bool cr = false) {
+    if (h->transform == MMIDX_TR_ROTATION || (size_t)npairs * h->D * 2 > ((size_t)16 << 30) || (!cr && h->m % 16 != 0) || h->m > 128) return 1;
+    const int G = cr ? MF_QG : MFK_G;
     const size_t nfb = (size_t)npairs * (size_t)std::max(nchunks_f, 1);
     HIPCK(h->ws_gdesc.reserve((size_t)npairs / G + (size_t)nlists + 8));
     HIPCK(h->ws_gfb.reserve(4 + 2 * nfb + 16));
+    if (cr) HIPCK(h->ws_lgrp.reserve((size_t)nlists + 1));
     hipLaunchKernelGGL(k_group_build, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, h->ws_pstart.p, nlists, G, h->ws_gdesc.p, h->ws_gfb.p,
-                       (u32 *)(h->ws_gfb.p + 1), (unsigned long long *)(h->d_counters + 7), h->pin_hint ? h->pin_hint + 1 : nullptr);
+                       (u32 *)(h->ws_gfb.p + 1), (unsigned long long *)(h->d_counters + 7), h->pin_hint ? h->pin_hint + 1 : nullptr,
+                       cr ? h->ws_lgrp.p : (int2 *)nullptr);
     HIPCK(hipGetLastError());
     // the DMA form (k_scan_mfma_kc2) where the lanes' code bytes come in aligned words: D a multiple of 256
     const int nb = 32 / h->dsub, quarter = h->m / 4;
@@ -1243,13 +1250,14 @@ int launch_mfma_kc(mmidx_index *h, const ScanParams &S, ScanParams F, const Sear
     int sub = h->mfma_sub > 0 ? ((h->mfma_sub + 63) & ~63) : 64 * tpw;
     if (cg) sub = h->mfma_sub > 0 ? std::min(sub, 1 << 20) : 8 * MFK2_TPW * (MFK2_NT / 64) * 16;  // k_scan_mfma_kc2 walks an item in passes of 1024 codes
     else sub = std::min(sub, 64 * tpw);  // (a wave holds at most TPW tiles' accumulators)
+    if (cr) sub = MFC_PIECE;
     const int nsub = (int)((maxlen + sub - 1) / sub);
     if ((long long)(npairs / G + nlists) * nsub > 0x7fffff00ll) return 1;
     HIPCK(h->ws_ghist.reserve((size_t)nq * 256));
     HIPCK(h->ws_T0.reserve((size_t)nq));
     HIPCK(h->ws_redo.reserve((size_t)nq));
     HIPCK(h->ws_psnap.reserve((size_t)nq));
-    HIPCK(h->ws_mfctl.reserve(32));
+    HIPCK(h->ws_mfctl.reserve(64));
     size_t qcap = h->mfma_qcap > 0 ? (size_t)h->mfma_qcap : std::min<size_t>((size_t)1 << 28, std::max<size_t>((size_t)1 << 20, (size_t)nq * 4096));
     HIPCK(h->ws_surv.reserve(qcap));
     HIPCK(h->ws_R16.reserve((size_t)npairs * h->D));
@@ -1269,9 +1277,9 @@ int launch_mfma_kc(mmidx_index *h, const ScanParams &S, ScanParams F, const Sear
         if (S.ivf) MP.S.coarse = h->d_coarseP;
     }
     MP.S.perm = nullptr;
-    // the launch's residual scale: |r_i| <= max |centroid element| + max |query element| (ctl words 16: query maximum, 20..21: scale)
-    u32 *d_qmax = h->ws_mfctl.p + 16;
-    int32_t *d_scale = (int32_t *)(h->ws_mfctl.p + 20);
+    // the launch's residual scale: |r_i| <= max |centroid element| + max |query element| (ctl words 40: query maximum, 44..45: scale)
+    u32 *d_qmax = h->ws_mfctl.p + 40;
+    int32_t *d_scale = (int32_t *)(h->ws_mfctl.p + 44);
     HIPCK(hipMemsetAsync(d_qmax, 0, sizeof(u32), st));
     hipLaunchKernelGGL(k_maxabs_f64, dim3(256), dim3(256), 0, st, S.Q, (long long)nq * h->D, d_qmax);
     float cmaxf = S.ivf ? (float)h->coarse_maxabs : 0.f;
@@ -1324,7 +1332,30 @@ int launch_mfma_kc(mmidx_index *h, const ScanParams &S, ScanParams F, const Sear
         HIPCK(hipEventRecord(mev[0], st));
     }
     int rc;
-    if (cg && h->dsub == 16) rc = cg == 8 ? launch_mfma_kc2_scan_t<16, 8>(h, KP, st) : launch_mfma_kc2_scan_t<16, 4>(h, KP, st);
+    if (cr) {
+        // three stages over disjoint pieces of every list (1/8, 2/8, 5/8): the thresholds tighten between them
+        HIPCK(h->ws_rows.reserve((size_t)npairs * sizeof(MfmaRow)));
+        MfmaCrParams CP{};
+        CP.lgrp = h->ws_lgrp.p;
+        CP.rows = (const MfmaRow *)h->ws_rows.p;
+        CP.nlists = nlists;
+        CP.npiece = nsub;
+        int blocks = h->mfma_blocks > 0 ? h->mfma_blocks : 2 * std::max(h->num_cus, 8);
+        blocks = std::max(8, (blocks + 7) & ~7);
+        static const int st_lo[3] = {0, 1, 3}, st_hi[3] = {1, 3, 8};
+        for (int sg = 0; sg < 3; sg++) {
+            CP.K = KP;
+            CP.st_lo = st_lo[sg];
+            CP.st_hi = st_hi[sg];
+            CP.cursor = h->ws_mfctl.p + (sg == 0 ? 8 : sg == 1 ? 24 : 32);
+            hipLaunchKernelGGL(k_cr_rows, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, KP, (MfmaRow *)h->ws_rows.p, (long long)npairs);
+            if (h->dsub == 16) hipLaunchKernelGGL((k_scan_mfma_cr<16>), dim3((unsigned)blocks), dim3(MFC_NT), 0, st, CP);
+            else hipLaunchKernelGGL((k_scan_mfma_cr<8>), dim3((unsigned)blocks), dim3(MFC_NT), 0, st, CP);
+            if (sg < 2) hipLaunchKernelGGL(k_ghist_tighten, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, MP, (long long)nq);
+            HIPCK(hipGetLastError());
+        }
+        rc = MMIDX_OK;
+    } else if (cg && h->dsub == 16) rc = cg == 8 ? launch_mfma_kc2_scan_t<16, 8>(h, KP, st) : launch_mfma_kc2_scan_t<16, 4>(h, KP, st);
     else if (cg) rc = launch_mfma_kc2_scan_t<8, 8>(h, KP, st);
     else if (h->dsub == 16) rc = tpw == 8 ? launch_mfma_kc_scan_t<16, 8>(h, KP, L.total, st) : launch_mfma_kc_scan_t<16, 16>(h, KP, L.total, st);
     else rc = tpw == 8 ? launch_mfma_kc_scan_t<8, 8>(h, KP, L.total, st) : launch_mfma_kc_scan_t<8, 16>(h, KP, L.total, st);
@@ -1335,7 +1366,7 @@ int launch_mfma_kc(mmidx_index *h, const ScanParams &S, ScanParams F, const Sear
 #define KC_VER(MM)                                                                                                     \
     case MM: rc = h->dsub == 16 ? launch_mfma_verify_t<MM, 16>(h, MP, st) : launch_mfma_verify_t<MM, 8>(h, MP, st); break;
     switch (h->m) {  // (16 lanes per survivor, m / 16 sub-quantizers each)
-        KC_VER(16) KC_VER(32) KC_VER(48) KC_VER(64) KC_VER(80) KC_VER(96) KC_VER(112) KC_VER(128)
+        KC_VER(8) KC_VER(16) KC_VER(32) KC_VER(48) KC_VER(64) KC_VER(80) KC_VER(96) KC_VER(112) KC_VER(128)
         default: break;
     }
 #undef KC_VER
@@ -1372,6 +1403,9 @@ int launch_mfma_common(mmidx_index *h, const ScanParams &S, ScanParams F, const 
         nq * 256 * 4 > (1ll << 31) || npairs >= 0x7fffff00ll || ((uintptr_t)S.Q & 15) != 0)
         return 1;
     if (h->D > 128) return launch_mfma_kc(h, S, F, pl, nlists, nchunks_f, npairs, maxlen, st, nq, flat_lut);
+    // flat PQ with many groups of queries over every chunk of the list: the codes resident, the groups streaming (K3mc)
+    if (h->mfma_cr && !S.ivf && h->D == 128 && (h->dsub == 8 || h->dsub == 16) && nq >= 4 * MF_QG && h->transform != MMIDX_TR_ROTATION)
+        return launch_mfma_kc(h, S, F, pl, nlists, nchunks_f, npairs, maxlen, st, nq, flat_lut, true);
     constexpr int G = MF_QG;
     const size_t nfb = (size_t)npairs * (size_t)std::max(nchunks_f, 1);
     HIPCK(h->ws_gdesc.reserve((size_t)npairs / G + (size_t)nlists + 8));
@@ -1397,7 +1431,7 @@ int launch_mfma_common(mmidx_index *h, const ScanParams &S, ScanParams F, const 
     HIPCK(h->ws_T0.reserve((size_t)nq));
     HIPCK(h->ws_redo.reserve((size_t)nq));
     HIPCK(h->ws_psnap.reserve((size_t)nq));
-    HIPCK(h->ws_mfctl.reserve(16));
+    HIPCK(h->ws_mfctl.reserve(64));
     size_t qcap = h->mfma_qcap > 0 ? (size_t)h->mfma_qcap : std::min<size_t>((size_t)1 << 28, std::max<size_t>((size_t)1 << 20, (size_t)nq * 2048));
     HIPCK(h->ws_surv.reserve(qcap));
     hipLaunchKernelGGL(k_mfma_prep, dim3((unsigned)std::min<long long>(4096, (nq * 64 + 255) / 256)), dim3(256), 0, st, (const int32_t *)h->ws_gfb.p, h->ws_ghist.p,
@@ -2443,6 +2477,8 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_R.release();
     h->ws_R16.release();
     h->ws_defer.release();
+    h->ws_lgrp.release();
+    h->ws_rows.release();
     h->ws_nrow.release();
     h->ws_lutpre.release();
     h->ws_mfctl.release();
@@ -3226,6 +3262,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->mfma_qcap = value > 0 ? value : 0;
     } else if (n == "coarse_wave_sel") {
         h->coarse_wave_sel = value != 0;
+    } else if (n == "mfma_cr") {
+        h->mfma_cr = value != 0;
     } else if (n == "mfma_kc_v1") {
         h->mfma_kc_v1 = value != 0;
     } else if (n == "mfma_kc_tpw") {

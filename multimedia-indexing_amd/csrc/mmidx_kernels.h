@@ -22,7 +22,7 @@ __device__ __forceinline__ double keyd(u64 k) { return __longlong_as_double((lon
 // The timing-experiment switches of rounds 1-3 (MMIDX_HIST_STOP / MMIDX_SCAN_STOP / MMIDX_SEL_STOP truncated builds, GRP_BIS,
 // GRP_TOUCH, GRP_TIMING_*, GRP_HALF_STATS, SMIN_TIMING) were removed from the kernels in round 4: what they measured is in
 // DESIGN_NOTEBOOK.md, the code in the history before commit "housekeeping: experiment switches".  What is left under #ifndef are
-// tunables with measured defaults (GRP_EPOCH, GRP_QMAX, MMIDX_K3H_PAIR ...) and K3m's MF_TIMING.
+// tunables with measured defaults (GRP_EPOCH, GRP_QMAX, MMIDX_K3H_PAIR ...); K3m's MF_TIMING went the same way at the end of round 4.
 // ------------------------------------------------------------------------------------------------
 // Block-wide bitonic sort of (key, val) pairs held in LDS, ascending by (key, val).  n must be a
 // power of two; every thread of the block must call it.

@@ -37,9 +37,6 @@ typedef float mf_f4 __attribute__((ext_vector_type(4)));
 #define MF_NT 256       // threads per block: four waves, each scanning its own code tiles against the item's queries
 #define MF_QG 64        // queries per item (four 16-row tiles)
 #define MF_ASTRIDE 272  // bytes per staged residual row: 256 + 16 (conflict-free 16-byte fragment reads)
-#ifndef MF_TIMING
-#define MF_TIMING 0     // timing experiments (results are wrong): 1 = no survivor handling, 2 = no MFMA, 3 = no gathers
-#endif
 
 struct MfmaParams {
     ScanParams S;              // Q, coarse (rows in TRANSFORMED order: the host passes permuted copies), cells, list_off, codes, order, T, pool_*, D, m, ks, w, ivf, poolq
@@ -183,7 +180,7 @@ __global__ __launch_bounds__(128) void k_pair_rotate(const double *__restrict__ 
 __global__ void k_mfma_prep(const int32_t *__restrict__ n_groups, u32 *__restrict__ ghist, unsigned char *__restrict__ redo, u32 *__restrict__ ctl,
                             const u64 *__restrict__ T, u64 *__restrict__ T0, const u32 *__restrict__ pool_cnt, u32 *__restrict__ snap, long long nq) {
     const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i0 < 16) ctl[i0] = 0;
+    if (i0 < 64) ctl[i0] = 0;  // [0] survivor count, [8..15] / [24..31] / [32..39] item cursors (K3mc: one set per stage), [40] [44..45] K3mk's scale words
     if (*n_groups == 0) return;
     const long long stride = (long long)gridDim.x * blockDim.x;
     uint4 *h4 = (uint4 *)ghist;
@@ -308,11 +305,7 @@ __device__ __forceinline__ void mf_scan_tiles(const MfmaParams &P, const mf_h8 (
                         B[h][j] = __builtin_bit_cast(mf_h8, both);
                     } else {
                         const u32 byte = (u32)(c[h] >> (8 * (j / (DSUB >= 8 ? DSUB / 8 : 1)))) & 0xFFu;
-#if MF_TIMING == 3
-                        const u32 addr = lane_base + ((u32)lane << 4);
-#else
                         const u32 addr = lane_base + (byte << 4);
-#endif
                         B[h][j] = *(const __attribute__((address_space(3))) mf_h8 *)(size_t)(addr + (u32)j * 4096u);
                     }
                 }
@@ -324,17 +317,12 @@ __device__ __forceinline__ void mf_scan_tiles(const MfmaParams &P, const mf_h8 (
             for (int h = 0; h < 2; h++) {
                 const float ci = x[h] * kinit;
                 const mf_f4 c4 = {ci, ci, ci, ci};
-#if MF_TIMING == 2
-#pragma unroll
-                for (int rt = 0; rt < NTL; rt++) acc[h][rt] = c4 + __builtin_bit_cast(mf_f4, B[h][rt % NJ]) * 1e-30f;
-#else
 #pragma unroll
                 for (int rt = 0; rt < NTL; rt++) acc[h][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[rt][0], B[h][0], c4, 0, 0, 0);
 #pragma unroll
                 for (int j = 1; j < NJ; j++)
 #pragma unroll
                     for (int rt = 0; rt < NTL; rt++) acc[h][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[rt][j], B[h][j], acc[h][rt], 0, 0, 0);
-#endif
             }
             // Pre-test: the largest of the lane's accumulators against the SMALLEST of its rows' constants -- v_max3 over the 4 NTL
             // registers and one compare (9 vector instructions per tile instead of 16 compares + 16 scalar ORs).  Conservative: a
@@ -348,10 +336,6 @@ __device__ __forceinline__ void mf_scan_tiles(const MfmaParams &P, const mf_h8 (
                 mxa = __builtin_fmaxf(mxa, acc[h][NTL - 1][3]);
                 any[h] = __builtin_amdgcn_ballot_w64(mxa >= thrmin);
             }
-#if MF_TIMING == 1
-            if ((any[0] | any[1]) == 0x123456789ull) s_touch[0] = 1;
-            any[0] = any[1] = 0;
-#endif
             if (any[0] | any[1]) {
                 // ---- survivors (about one per tile where far probes feed the queue).  Kept SMALL: an unrolled branch per accumulator
                 // register made this path ~400 instructions per tile (1250 cycles per survivor measured).  Each lane packs its

@@ -955,6 +955,23 @@ def test_mfma_flat_pq(mi, oracle, D, m, n, k, tr, chunk):
         assert_same(got, want)
         if not off:
             assert st["mfma_survivors"] > 0
+    if D == 128:
+        # K3mc (mmidx_scan_mfma_cr.h: the codes resident, the chunk's groups of queries streaming) takes flat PQ calls of 256 queries and
+        # more: 330 queries = five full groups and one of ten rows per chunk; with it, without it (K3m), and with a survivor list of 64
+        # records (redo path): the oracle's ids and distance bits every time
+        Q2 = np.concatenate([Q, base[100:200] + 0.05 * rng.standard_normal((100, D)), rng.standard_normal((130, D))])
+        want2 = ref.search_batch(Q2, k)
+        for cr, qcap in ((1, 0), (0, 0), (1, 64)):
+            ix.set_option("mfma_sub", 0)
+            ix.set_option("no_mfma", 0)
+            ix.set_option("mfma_cr", cr)
+            ix.set_option("mfma_qcap", qcap)
+            ix.set_profiling(True)
+            assert_same(ix.search_batch(k, Q2), want2)
+            st = ix.get_stats()
+            assert st["mfma_survivors"] > 0
+            if qcap:
+                assert st["mfma_redo_queries"] > 0
     ix.close()
 
 
