@@ -1285,7 +1285,9 @@ int launch_mfma_kc(mmidx_index *h, const ScanParams &S, ScanParams F, const Sear
     float cmaxf = S.ivf ? (float)h->coarse_maxabs : 0.f;
     if (S.ivf && (double)cmaxf < h->coarse_maxabs) cmaxf = std::nextafter(cmaxf, INFINITY);
     hipLaunchKernelGGL(k_resid_scale, dim3(1), dim3(1), 0, st, (const u32 *)d_qmax, cmaxf, h->pq_ep, d_scale);
-    hipLaunchKernelGGL(k_pair_resid16, dim3((unsigned)((npairs + 3) / 4)), dim3(256), 0, st, MP.S.Q, MP.S.coarse, S.cells, S.order, S.n_order, (long long)npairs, S.w,
+    // (K3mc on flat PQ: every chunk sees the same queries in the same order -- the rows of the first chunk's pairs serve all chunks)
+    const long long nrows = (cr && !S.ivf) ? nq : npairs;
+    hipLaunchKernelGGL(k_pair_resid16, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, st, MP.S.Q, MP.S.coarse, S.cells, S.order, S.n_order, (long long)nrows, S.w,
                        h->D, S.ivf, (const int32_t *)d_scale, h->ws_R16.p, h->ws_nrow.p);
     HIPCK(hipGetLastError());
     MP.pq16 = h->d_pq16;
@@ -1334,12 +1336,14 @@ int launch_mfma_kc(mmidx_index *h, const ScanParams &S, ScanParams F, const Sear
     int rc;
     if (cr) {
         // three stages over disjoint pieces of every list (1/8, 2/8, 5/8): the thresholds tighten between them
-        HIPCK(h->ws_rows.reserve((size_t)npairs * sizeof(MfmaRow)));
+        HIPCK(h->ws_rows.reserve((size_t)(nrows + 1) * sizeof(MfmaRow)));
         MfmaCrParams CP{};
         CP.lgrp = h->ws_lgrp.p;
         CP.rows = (const MfmaRow *)h->ws_rows.p;
         CP.nlists = nlists;
         CP.npiece = nsub;
+        CP.per_list_rows = !S.ivf;
+        CP.nrows = nrows;
         int blocks = h->mfma_blocks > 0 ? h->mfma_blocks : 2 * std::max(h->num_cus, 8);
         blocks = std::max(8, (blocks + 7) & ~7);
         static const int st_lo[3] = {0, 1, 3}, st_hi[3] = {1, 3, 8};
@@ -1348,7 +1352,7 @@ int launch_mfma_kc(mmidx_index *h, const ScanParams &S, ScanParams F, const Sear
             CP.st_lo = st_lo[sg];
             CP.st_hi = st_hi[sg];
             CP.cursor = h->ws_mfctl.p + (sg == 0 ? 8 : sg == 1 ? 24 : 32);
-            hipLaunchKernelGGL(k_cr_rows, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, KP, (MfmaRow *)h->ws_rows.p, (long long)npairs);
+            hipLaunchKernelGGL(k_cr_rows, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, st, KP, (MfmaRow *)h->ws_rows.p, (long long)nrows);
             if (h->dsub == 16) hipLaunchKernelGGL((k_scan_mfma_cr<16>), dim3((unsigned)blocks), dim3(MFC_NT), 0, st, CP);
             else hipLaunchKernelGGL((k_scan_mfma_cr<8>), dim3((unsigned)blocks), dim3(MFC_NT), 0, st, CP);
             if (sg < 2) hipLaunchKernelGGL(k_ghist_tighten, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, MP, (long long)nq);
@@ -1404,7 +1408,7 @@ int launch_mfma_common(mmidx_index *h, const ScanParams &S, ScanParams F, const 
         return 1;
     if (h->D > 128) return launch_mfma_kc(h, S, F, pl, nlists, nchunks_f, npairs, maxlen, st, nq, flat_lut);
     // flat PQ with many groups of queries over every chunk of the list: the codes resident, the groups streaming (K3mc)
-    if (h->mfma_cr && !S.ivf && h->D == 128 && (h->dsub == 8 || h->dsub == 16) && nq >= 4 * MF_QG && h->transform != MMIDX_TR_ROTATION)
+    if (h->mfma_cr && !S.ivf && h->D == 128 && (h->dsub == 8 || h->dsub == 16) && nq >= 4 * MF_QG && nq <= (long long)MFC_MAXG * MF_QG && h->transform != MMIDX_TR_ROTATION)
         return launch_mfma_kc(h, S, F, pl, nlists, nchunks_f, npairs, maxlen, st, nq, flat_lut, true);
     constexpr int G = MF_QG;
     const size_t nfb = (size_t)npairs * (size_t)std::max(nchunks_f, 1);

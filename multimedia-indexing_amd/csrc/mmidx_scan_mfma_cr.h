@@ -21,14 +21,18 @@
 #define MFC_NT 256
 #define MFC_TPW 4                         // code tiles per wave
 #define MFC_PIECE (MFC_TPW * 4 * 16)      // codes per item: 256
-#define MFC_MAXG 512                      // groups of a list the kernel keeps the descriptors of (the host checks)
+#define MFC_MAXG 256                      // groups of a list the kernel keeps the descriptors of (the host checks)
+#define MFC_BUF 256                       // survivor records a wave stages between flushes
 
 struct MfmaCrParams {
     MfmaKcParams K;          // (K.M.work is unused: the stages have their own cursors)
     const int2 *lgrp;        // per list: {first group in gdesc, number of groups}
-    const MfmaRow *rows;     // [pair slots] row records (k_cr_rows)
+    const MfmaRow *rows;     // [rows + 1] row records (k_cr_rows); the last one never survives
+    long long nrows;
     int nlists, npiece;      // pieces of MFC_PIECE codes in the longest list
     int st_lo, st_hi;        // this stage takes the pieces p with p % 8 in [st_lo, st_hi)
+    int per_list_rows;       // 1: R16 / rows are indexed by the pair's position WITHIN its list (flat PQ: every chunk sees the same queries in
+                             // the same order, so one copy of the rows serves all chunks and stays in L2), 0: by pair slot
     u32 *cursor;             // [8] per-XCD item cursors of this stage (zeroed by k_mfma_prep)
 };
 
@@ -37,6 +41,18 @@ __global__ __launch_bounds__(256) void k_cr_rows(const MfmaKcParams K, MfmaRow *
     const MfmaParams &P = K.M;
     const long long n = P.S.n_order ? (long long)*P.S.n_order : n_flat;
     const long long slot = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot == 0) {  // the record behind the last one: "never survives" (the rows of a group past its pairs are staged from it)
+        MfmaRow z;
+        z.thr = __int_as_float(0x7F800000);
+        z.cd = 0.f;
+        z.kq = 0.f;
+        z.cq = 0.f;
+        z.q = 0;
+        z.slot = 0;
+        z.inv0 = 0.f;
+        z.pad = 0;
+        rows[n_flat] = z;
+    }
     if (slot >= n) return;
     const int D = K.D;
     const double xmax = P.xmax;
@@ -113,22 +129,60 @@ __global__ __launch_bounds__(256) void k_ghist_tighten(const MfmaParams P, long 
     }
 }
 
+// LDS reads the compiler does not see as memory operations.  Its waitcnt pass puts a FULL vector-memory wait in front of an LDS read it
+// cannot prove disjoint from the LDS-DMA in flight -- and here DMA for the next groups is always in flight.  The reads below are
+// ordered by hand: lds_wait*() names the registers, so that their users cannot move above it.
+__device__ __forceinline__ mf_h8 lds_h8(const u32 addr, const int off) {
+    mf_h8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off));
+    return v;
+}
+__device__ __forceinline__ float lds_f32(const u32 addr, const int off) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off));
+    return v;
+}
+__device__ __forceinline__ void lds_wait4(mf_h8 &a, mf_h8 &b, mf_h8 &c, mf_h8 &d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void lds_wait16(float (&t)[16]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]), "+v"(t[8]), "+v"(t[9]), "+v"(t[10]),
+                   "+v"(t[11]), "+v"(t[12]), "+v"(t[13]), "+v"(t[14]), "+v"(t[15]));
+}
+
+// the wave's staged records -> its chunk of the global list + the queries' histograms of upper bounds.  A staged record carries its
+// query (w = q << 9 | bucket, bucket 511 = none): the rows it came from may have left the LDS by the time it is flushed.
+__device__ __forceinline__ void mfc_flush(const MfmaParams &P, MfmaChunk &ck, const uint4 *s_buf, const u32 nb, const int lane) {
+    mf_chunk_room(P, ck, nb, lane);
+    for (u32 i = (u32)lane; i < nb; i += 64) {
+        const uint4 r = s_buf[i];
+        const u32 q = r.w >> 9, bk = r.w & 0x1FFu;
+        const u32 off = ck.base + ck.used + i;
+        if (off < P.surv_cap) P.surv[off] = make_uint4(r.x, r.y, r.z, 0u);
+        else P.redo[q] = 1;
+        if (bk != 0x1FFu) atomicAdd(P.ghist + (size_t)q * 256 + bk, 1u);
+    }
+    ck.used += nb;
+}
+
 template <int DSUB>
 __global__ __launch_bounds__(MFC_NT, 2) void k_scan_mfma_cr(const MfmaCrParams C) {
     static_assert(DSUB == 8 || DSUB == 16, "sub-quantizers of 8 or 16 dimensions");
     constexpr int NTL = 4, NJ = 4, D = 128, M = D / DSUB, NB = 32 / DSUB, TPW = MFC_TPW, NW = MFC_NT / 64;
-    __shared__ __attribute__((aligned(1024))) unsigned char ab0[16384];
-    __shared__ __attribute__((aligned(1024))) unsigned char ab1[16384];
-    __shared__ __attribute__((aligned(1024))) MfmaRow s_row0[MF_QG];
-    __shared__ __attribute__((aligned(1024))) MfmaRow s_row1[MF_QG];
-    __shared__ uint4 s_bufs[NW * MF_BUF];
+    // three buffer sets (a group's 64 residual rows + 64 row records): the DMA runs two groups ahead of the matrix cores
+    // (one array per set: the compiler tells LDS-DMA targets apart by variable, and only a handful of them)
+    __shared__ __attribute__((aligned(1024))) unsigned char bs0[16384 + 2048];
+    __shared__ __attribute__((aligned(1024))) unsigned char bs1[16384 + 2048];
+    __shared__ __attribute__((aligned(1024))) unsigned char bs2[16384 + 2048];
+    __shared__ uint4 s_bufs[NW * MFC_BUF];
     __shared__ int2 s_gd[MFC_MAXG];  // the list's groups: {first pair slot, pairs}
     __shared__ u32 s_misc[8];
     const MfmaParams &P = C.K.M;
     MfmaChunk ck{0u, 0u, 0u};
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, g = lane >> 4;
-    uint4 *s_buf = s_bufs + (size_t)wv * MF_BUF;
+    uint4 *s_buf = s_bufs + (size_t)wv * MFC_BUF;
     const int nsel = C.st_hi - C.st_lo;
     const int pg = (C.npiece + 7) >> 3;
     const int ipl = pg * nsel;  // virtual items per list in this stage
@@ -172,20 +226,25 @@ __global__ __launch_bounds__(MFC_NT, 2) void k_scan_mfma_cr(const MfmaCrParams C
 
         // DMA of a group: its 64 residual rows (rows 16 i' .. of DMA instruction i' = 4 i + wv: unit u of row r in slot u ^ (r & 15))
         // and its row records (two kibibytes: waves 0 and 1)
-        auto stage = [&](unsigned char *ab, MfmaRow *rowb, const int first, const int np) {
+        int rbase = 0;
+        auto stage = [&](unsigned char *ab, const int first, const int np) {
+            unsigned char *rowb = ab + 16384;
+            const int fr = first - rbase;  // (row index of the group's first pair in R16 / rows)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int ii = i * NW + wv;  // kibibyte of the buffer: rows 4 ii .. 4 ii + 3
                 const int row = 4 * ii + (lane >> 4);
                 const int u = (lane & 15) ^ (row & 15);
-                const unsigned char *src = (const unsigned char *)(C.K.R16 + (size_t)(first + (row < np ? row : np - 1)) * D) + u * 16;
+                const unsigned char *src = (const unsigned char *)(C.K.R16 + (size_t)(fr + (row < np ? row : np - 1)) * D) + u * 16;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)(ab + ii * 1024), 16, 0, 0);
             }
-            if (wv < 2) {
-                const int row = wv * 32 + (lane >> 1);
-                const unsigned char *src = (const unsigned char *)(C.rows + (size_t)(first + (row < np ? row : np - 1))) + (lane & 1) * 16;
+            {   // (every wave issues FIVE instructions per group -- waves 2 and 3 repeat the records' halves -- so that one partial
+                //  vector-memory wait, 5 instructions per group still in flight, fits all waves)
+                const int w2 = wv & 1;
+                const int row = w2 * 32 + (lane >> 1);
+                const unsigned char *src = (const unsigned char *)(C.rows + (row < np ? (size_t)(fr + row) : (size_t)C.nrows)) + (lane & 1) * 16;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)((unsigned char *)rowb + wv * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(rowb + w2 * 1024), 16, 0, 0);
             }
         };
         // (the list's group descriptors go to LDS once: a global load in front of a group's DMA would be waited for right there -- the
@@ -194,11 +253,6 @@ __global__ __launch_bounds__(MFC_NT, 2) void k_scan_mfma_cr(const MfmaCrParams C
             const int4 t = P.gdesc[g0 + i];
             s_gd[i] = make_int2(t.y, t.z);
         }
-        {
-            const int4 t = P.gdesc[g0];
-            stage(ab0, s_row0, t.y, t.z);
-        }
-
         // ---- the wave's four tiles, decoded once: B fragments (unit NJ g + j of the code's concatenated centroids) and start values
         mf_h8 B[TPW][NJ];
         float ci[TPW];
@@ -218,22 +272,36 @@ __global__ __launch_bounds__(MFC_NT, 2) void k_scan_mfma_cr(const MfmaCrParams C
             ci[ti] = xn[pp] * kinit;
         }
 
+        // (every register load of the item is complete before the first DMA is issued: with DMA, stores and loads mixed in flight the
+        //  compiler treats the vector-memory counter as out of order and would put a full wait in front of every use of B)
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        const int4 gd0 = P.gdesc[g0];
+        rbase = C.per_list_rows ? gd0.y : 0;
+        stage(bs0, gd0.y, gd0.z);
+        if (ng > 1) {
+            const int4 t = P.gdesc[g0 + 1];
+            stage(bs1, t.y, t.z);
+        }
         u32 bufn = 0;
         // one group from a buffer pair
-        auto group = [&](const unsigned char *ab, const MfmaRow *rowb, const int first, const int np) {
-            // rows past the group's pairs are copies of its last row: their compare bits are masked.  Only the smallest of the lane's
-            // 16 row constants stays in a register (the pre-test); the survivor path reads them again.
-            u32 vmask = 0;
+        auto group = [&](const unsigned char *ab, const int first, const int np) {
+            const u32 ab_lds = (u32)(size_t)(__attribute__((address_space(3))) const unsigned char *)ab;
+            const u32 a_addr = ab_lds + (u32)n * 256u;            // + rt 4096, unit (NJ g + j) ^ n
+            const u32 r_addr = ab_lds + 16384u + (u32)(4 * g) * 32u;  // the lane's rows 4 g .. 4 g + 3 of a row tile (+ rt 512)
+            // the smallest of the lane's 16 row constants (the pre-test); rows past the group's pairs carry +inf
+            float th[16];
 #pragma unroll
-            for (int b = 0; b < NTL * 4; b++) vmask |= ((b >> 2) * 16 + 4 * g + (b & 3) < np) ? (1u << b) : 0u;
-            float thrmin = __int_as_float(0x7F800000);
-#pragma unroll
-            for (int b = 0; b < NTL * 4; b++) {
-                const float tb = rowb[(b >> 2) * 16 + 4 * g + (b & 3)].thr;
-                thrmin = ((vmask >> b) & 1u) ? __builtin_fminf(thrmin, tb) : thrmin;
-            }
+            for (int b = 0; b < 16; b++) th[b] = lds_f32(r_addr, (b >> 2) * 512 + (b & 3) * 32);
             const int ntl = (np + 15) >> 4;
-            // all four tiles at once, the k steps outermost: a step's four A fragments (16 registers) feed 16 matrix instructions
+            mf_h8 A[2][NTL];
+#pragma unroll
+            for (int rt = 0; rt < NTL; rt++) A[0][rt] = lds_h8(a_addr + (u32)(((NJ * g + 0) ^ n) << 4), rt * 4096);
+            lds_wait16(th);
+            float thrmin = th[0];
+#pragma unroll
+            for (int b = 1; b < 16; b++) thrmin = __builtin_fminf(thrmin, th[b]);
+            // all four tiles at once, the k steps outermost: a step's four A fragments (16 registers) feed 16 matrix instructions; the
+            // next step's fragments are requested before this step's matrix instructions
             mf_f4 acc[TPW][NTL];
 #pragma unroll
             for (int ti = 0; ti < TPW; ti++) {
@@ -243,14 +311,16 @@ __global__ __launch_bounds__(MFC_NT, 2) void k_scan_mfma_cr(const MfmaCrParams C
             }
 #pragma unroll
             for (int j = 0; j < NJ; j++) {
-                mf_h8 A[NTL];
+                lds_wait4(A[j & 1][0], A[j & 1][1], A[j & 1][2], A[j & 1][3]);
+                if (j + 1 < NJ) {
 #pragma unroll
-                for (int rt = 0; rt < NTL; rt++) A[rt] = *(const mf_h8 *)(ab + (rt * 16 + n) * 256 + (((NJ * g + j) ^ n) << 4));
+                    for (int rt = 0; rt < NTL; rt++) A[(j + 1) & 1][rt] = lds_h8(a_addr + (u32)(((NJ * g + j + 1) ^ n) << 4), rt * 4096);
+                }
 #pragma unroll
                 for (int rt = 0; rt < NTL; rt++) {
                     if (rt < ntl) {  // (wave-uniform)
 #pragma unroll
-                        for (int ti = 0; ti < TPW; ti++) acc[ti][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[rt], B[ti][j], acc[ti][rt], 0, 0, 0);
+                        for (int ti = 0; ti < TPW; ti++) acc[ti][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j & 1][rt], B[ti][j], acc[ti][rt], 0, 0, 0);
                     }
                 }
             }
@@ -268,17 +338,20 @@ __global__ __launch_bounds__(MFC_NT, 2) void k_scan_mfma_cr(const MfmaCrParams C
                     // ---- survivors: K3m's lane-level path ----
                     const long long pos = c0 + (long long)tt * 16 + n;
                     u32 bits = 0;
+                    {
+                        float t2[16];
 #pragma unroll
-                    for (int b = NTL * 4 - 1; b >= 0; b--) {
-                        const float tb = rowb[(b >> 2) * 16 + 4 * g + (b & 3)].thr;
-                        asm volatile("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(acc[h][b >> 2][b & 3]), "v"(tb) : "vcc");
+                        for (int b = 0; b < 16; b++) t2[b] = lds_f32(r_addr, (b >> 2) * 512 + (b & 3) * 32);
+                        lds_wait16(t2);
+#pragma unroll
+                        for (int b = NTL * 4 - 1; b >= 0; b--)
+                            asm volatile("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(acc[h][b >> 2][b & 3]), "v"(t2[b]) : "vcc");
                     }
-                    bits &= vmask;
                     if (pos >= c1) bits = 0;
                     u64 act = __builtin_amdgcn_ballot_w64(bits != 0);
                     while (act) {
-                        if (bufn > (u32)(MF_BUF - 64)) {  // (wave-uniform) room for one record per lane
-                            mf_flush(P, ck, s_buf, bufn, rowb, s_misc + 1, first, lane);
+                        if (bufn > (u32)(MFC_BUF - 64)) {  // (wave-uniform) room for one record per lane
+                            mfc_flush(P, ck, s_buf, bufn, lane);
                             bufn = 0;
                         }
                         if (bits) {
@@ -297,47 +370,52 @@ __global__ __launch_bounds__(MFC_NT, 2) void k_scan_mfma_cr(const MfmaCrParams C
                             for (int j = 0; j < 2; j++) v2[j] = (v4[2 * j + 1] & m2) | (v4[2 * j] & ~m2);
                             const float a = __int_as_float((int)((v2[1] & m3) | (v2[0] & ~m3)));
                             const int qs = (b >> 2) * 16 + 4 * g + (b & 3);
-                            const MfmaRow rw = rowb[qs];
+                            MfmaRow rw;
+                            {   // (the row record, by hand as well: two 16-byte reads)
+                                uint4 r0, r1;
+                                const u32 ra = ab_lds + 16384u + (u32)qs * 32u;
+                                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r0), "=&v"(r1) : "v"(ra));
+                                rw.thr = __int_as_float((int)r0.x);
+                                rw.cd = __int_as_float((int)r0.y);
+                                rw.kq = __int_as_float((int)r0.z);
+                                rw.cq = __int_as_float((int)r0.w);
+                                rw.q = (int)r1.x;
+                            }
                             const float lbf = fmaf(a, kd, rw.cd);
                             const float xb = fmaf(a, rw.kq, rw.cq);
-                            const u32 bk = (rw.kq != 0.f && xb < 255.f) ? (xb > 0.f ? (u32)(int)xb : 0u) : 0xFFFFFFFFu;
-                            s_buf[bufn + mf_mbcnt(act)] = make_uint4((u32)(first + qs), (u32)pos, (u32)__float_as_int(lbf), bk);
+                            const u32 bk = (rw.kq != 0.f && xb < 255.f) ? (xb > 0.f ? (u32)(int)xb : 0u) : 0x1FFu;
+                            s_buf[bufn + mf_mbcnt(act)] = make_uint4((u32)(first + qs), (u32)pos, (u32)__float_as_int(lbf), ((u32)rw.q << 9) | bk);
                         }
                         bufn += (u32)__popcll(act);
                         act = __builtin_amdgcn_ballot_w64(bits != 0);
                     }
                 }
             }
-            // (the records name their rows through THIS group's buffer: out before the buffer is refilled)
-            if (bufn) {
-                mf_flush(P, ck, s_buf, bufn, rowb, s_misc + 1, first, lane);
-                bufn = 0;
-            }
         };
-        for (int gi = 0; gi < ng; gi += 2) {
-            // every wave waits for ITS part of the group's DMA, then the barrier (explicit: see k_scan_mfma_kc2)
-            __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
-            if (gi + 1 < ng) {
-                const int2 t = s_gd[gi + 1];
-                stage(ab1, s_row1, __builtin_amdgcn_readfirstlane(t.x), __builtin_amdgcn_readfirstlane(t.y));
-            }
-            {
-                const int2 t = s_gd[gi];
-                group(ab0, s_row0, __builtin_amdgcn_readfirstlane(t.x), __builtin_amdgcn_readfirstlane(t.y));
-            }
-            if (gi + 1 >= ng) break;
-            __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
-            if (gi + 2 < ng) {
-                const int2 t = s_gd[gi + 2];
-                stage(ab0, s_row0, __builtin_amdgcn_readfirstlane(t.x), __builtin_amdgcn_readfirstlane(t.y));
-            }
-            {
-                const int2 t = s_gd[gi + 1];
-                group(ab1, s_row1, __builtin_amdgcn_readfirstlane(t.x), __builtin_amdgcn_readfirstlane(t.y));
-            }
+        // step gi: wait until at most the DMA of group gi + 1 is in flight (5 instructions; the counter is in order, and younger stores of
+        // the survivor path only make the wait stricter), barrier -- group gi has landed, nobody reads the buffer of group gi - 1 any
+        // more --, request group gi + 2 into that buffer, then the matrix work of group gi
+#define MFC_STEP(BA, NA, GI)                                                                                  \
+        {                                                                                                     \
+            if ((GI) + 1 < ng) __builtin_amdgcn_s_waitcnt(0x0075); /* vmcnt(5) lgkmcnt(0) */                    \
+            else __builtin_amdgcn_s_waitcnt(0x0070); /* vmcnt(0) lgkmcnt(0) */                                  \
+            __builtin_amdgcn_s_barrier(); /* (the bare barrier: __syncthreads() drains the vector-memory counter) */ \
+            if ((GI) + 2 < ng) {                                                                              \
+                const int2 t = s_gd[(GI) + 2];                                                                \
+                stage(NA, __builtin_amdgcn_readfirstlane(t.x), __builtin_amdgcn_readfirstlane(t.y));          \
+            }                                                                                                 \
+            const int2 tc = s_gd[GI];                                                                         \
+            group(BA, __builtin_amdgcn_readfirstlane(tc.x), __builtin_amdgcn_readfirstlane(tc.y));            \
         }
+        for (int gi = 0; gi < ng; gi += 3) {
+            MFC_STEP(bs0, bs2, gi)
+            if (gi + 1 >= ng) break;
+            MFC_STEP(bs1, bs0, gi + 1)
+            if (gi + 2 >= ng) break;
+            MFC_STEP(bs2, bs1, gi + 2)
+        }
+#undef MFC_STEP
+        if (bufn) mfc_flush(P, ck, s_buf, bufn, lane);
     }
     for (u32 i = ck.used + (u32)lane; i < ck.cap; i += 64)
         if (ck.base + i < P.surv_cap) P.surv[ck.base + i] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
