@@ -307,7 +307,8 @@ struct mmidx_index {
     DevBuf<double> ws_R;               // RandomRotation: the kept pairs' exact rotated residuals [pairs][D]
     DevBuf<int2> ws_lgrp;              // K3mc: per list {first group, groups}
     DevBuf<unsigned char> ws_rows;     // K3mc: the pair slots' row records (MfmaRow)
-    int mfma_cr = 1;                   // option "mfma_cr": 0 = flat PQ through K3m also where K3mc applies
+    int mfma_cr = 0;                   // option "mfma_cr": 1 = flat PQ calls of 256+ queries through K3mc (codes resident, groups streaming; measured
+                                       // slower than K3m so far: 1.56 against 1.21 ms per cfg2 batch -- DESIGN.md 5.3)
     DevBuf<u32> ws_defer;              // k_coarse_front_sel: count + list of the queries left to k_coarse_select_defer
     DevBuf<unsigned short> ws_R16;     // K3mk: the kept pairs' fp16 residuals [pairs][D]
     DevBuf<double> ws_nrow;            // ... and ||r||^2

@@ -8,7 +8,14 @@
 // (64 registers), gathered straight from the fp16 codebook in global memory (L2) -- and then walks the list's groups: a group's 64
 // fp16 residual rows (16 KiB, XOR-swizzled units) and its 64 row records (2 KiB: threshold, bound constants, query, slot) arrive by
 // LDS-DMA in the buffer pair that is not being read, its A fragments come from there by 16 conflict-free reads per lane, and 64
-// matrix instructions follow.  No random gather in the loop: the matrix cores bound it.
+// matrix instructions follow.  No random gather in the loop.
+//
+// STATE (end of round 4): parity-green, OFF by default (option "mfma_cr").  cfg2 (4096 queries, 1 M codes, m = 8): 1.56 ms per batch
+// against K3m's 1.21.  Timing builds: without survivors and DMA 0.90 ms (the 64 matrix instructions per wave and group are 45 % of a
+// step: barrier skew of four-wave blocks, LDS latency of the fragment reads), + DMA 1.04, + survivors 1.56 (≈ 14 survivors per
+// 64 x 256 block of pairs: most tiles take the slow path), and the stage-wise thresholds verify 2.6 x more codes than K3m's
+// continuously tightened ones (verification 0.25 against 0.12 ms).  What it took to get the loop free of full vector-memory waits is in
+// the comments below (explicit partial waits, bare barriers, LDS reads by hand, all register loads complete before the first DMA).
 //   * k_cr_rows, a thread per pair slot: the row records for the thresholds as they stand (everything K3m's phase (a) computes per
 //     row).  Thresholds therefore move BETWEEN launches, not inside one: the scan runs in three stages over disjoint pieces of every
 //     list (1/8, 2/8, 5/8 of the 256-code pieces), k_ghist_tighten (K3m's phase (c): k + 1 survivors' upper bounds at or below a
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(MFC_NT, 2) void k_scan_mfma_cr(const MfmaCrParams C
             const u32 ab_lds = (u32)(size_t)(__attribute__((address_space(3))) const unsigned char *)ab;
             const u32 a_addr = ab_lds + (u32)n * 256u;            // + rt 4096, unit (NJ g + j) ^ n
             const u32 r_addr = ab_lds + 16384u + (u32)(4 * g) * 32u;  // the lane's rows 4 g .. 4 g + 3 of a row tile (+ rt 512)
-            // the smallest of the lane's 16 row constants (the pre-test); rows past the group's pairs carry +inf
+            // the lane's 16 row constants and their minimum (the pre-test); rows past the group's pairs carry +inf
             float th[16];
 #pragma unroll
             for (int b = 0; b < 16; b++) th[b] = lds_f32(r_addr, (b >> 2) * 512 + (b & 3) * 32);
@@ -338,15 +345,9 @@ __global__ __launch_bounds__(MFC_NT, 2) void k_scan_mfma_cr(const MfmaCrParams C
                     // ---- survivors: K3m's lane-level path ----
                     const long long pos = c0 + (long long)tt * 16 + n;
                     u32 bits = 0;
-                    {
-                        float t2[16];
 #pragma unroll
-                        for (int b = 0; b < 16; b++) t2[b] = lds_f32(r_addr, (b >> 2) * 512 + (b & 3) * 32);
-                        lds_wait16(t2);
-#pragma unroll
-                        for (int b = NTL * 4 - 1; b >= 0; b--)
-                            asm volatile("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(acc[h][b >> 2][b & 3]), "v"(t2[b]) : "vcc");
-                    }
+                    for (int b = NTL * 4 - 1; b >= 0; b--)
+                        asm volatile("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(acc[h][b >> 2][b & 3]), "v"(th[b]) : "vcc");
                     if (pos >= c1) bits = 0;
                     u64 act = __builtin_amdgcn_ballot_w64(bits != 0);
                     while (act) {
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(MFC_NT, 2) void k_scan_mfma_cr(const MfmaCrParams C
             if ((GI) + 1 < ng) __builtin_amdgcn_s_waitcnt(0x0075); /* vmcnt(5) lgkmcnt(0) */                    \
             else __builtin_amdgcn_s_waitcnt(0x0070); /* vmcnt(0) lgkmcnt(0) */                                  \
             __builtin_amdgcn_s_barrier(); /* (the bare barrier: __syncthreads() drains the vector-memory counter) */ \
-            if ((GI) + 2 < ng) {                                                                              \
+            if ((GI) + 2 < ng) {                                                                \
                 const int2 t = s_gd[(GI) + 2];                                                                \
                 stage(NA, __builtin_amdgcn_readfirstlane(t.x), __builtin_amdgcn_readfirstlane(t.y));          \
             }                                                                                                 \

@@ -956,8 +956,8 @@ def test_mfma_flat_pq(mi, oracle, D, m, n, k, tr, chunk):
         if not off:
             assert st["mfma_survivors"] > 0
     if D == 128:
-        # K3mc (mmidx_scan_mfma_cr.h: the codes resident, the chunk's groups of queries streaming) takes flat PQ calls of 256 queries and
-        # more: 330 queries = five full groups and one of ten rows per chunk; with it, without it (K3m), and with a survivor list of 64
+        # K3mc (mmidx_scan_mfma_cr.h: the codes resident, the chunk's groups of queries streaming; option "mfma_cr", off by default) takes
+        # flat PQ calls of 256 queries and more: 330 queries = five full groups and one of ten rows per chunk; with it, without it (K3m), and with a survivor list of 64
         # records (redo path): the oracle's ids and distance bits every time
         Q2 = np.concatenate([Q, base[100:200] + 0.05 * rng.standard_normal((100, D)), rng.standard_normal((130, D))])
         want2 = ref.search_batch(Q2, k)
