@@ -386,12 +386,14 @@ def test_native_sharded_query_exchange_pipeline(mi, oracle, devices):
     ix.close()
 
 
+@pytest.mark.parametrize("D,m", [(64, 8), (256, 16)], ids=["k3m", "k3mk"])
 @pytest.mark.parametrize("devices", DEVS, ids=["rccl1", "virt2", "virt3"])
-def test_native_sharded_pass_b_on_the_matrix_cores(mi, oracle, devices):
-    """A shape K3m takes (8-dimensional sub-quantizers, D = 64): every shard's pass B -- under the all-reduced thresholds, answers as
-    sorted partial lists for the owners -- runs k_scan_mfma / k_mfma_verify; overlapping cells so that far probes are scanned, every
-    vector twice so that ties straddle shards.  The single queue's answer, with K3m and without."""
-    D, C_, m, ks, w, k = 64, 16, 8, 256, 7, 20
+def test_native_sharded_pass_b_on_the_matrix_cores(mi, oracle, devices, D, m):
+    """A shape K3m takes (8-dimensional sub-quantizers, D = 64) and one K3mk takes (D = 256, 16 x 16: the chunked form with LDS-DMA, and
+    the coarse stage's wave-per-query selection): every shard's pass B -- under the all-reduced thresholds, answers as sorted partial
+    lists for the owners -- runs the matrix-core bound and its verification; overlapping cells so that far probes are scanned, every
+    vector twice so that ties straddle shards.  The single queue's answer, with the bound and without."""
+    C_, ks, w, k = 16, 256, 7, 20
     rng = np.random.default_rng(3 + len(devices))
     mu = 0.5 * rng.standard_normal((C_, D))
     half = mu[rng.integers(0, C_, 6000)] + rng.standard_normal((6000, D))
