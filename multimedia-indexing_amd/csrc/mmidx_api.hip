@@ -310,6 +310,14 @@ struct mmidx_index {
     int mfma_cr = 0;                   // option "mfma_cr": 1 = flat PQ calls of 256+ queries through K3mc (codes resident, groups streaming; measured
                                        // slower than K3m so far: 1.56 against 1.21 ms per cfg2 batch -- DESIGN.md 5.3)
     DevBuf<u32> ws_defer;              // k_coarse_front_sel: count + list of the queries left to k_coarse_select_defer
+    // coarse-ahead pipelining of a large device call (search_common): the call runs in parts; the coarse stage of part i + 1 goes to a
+    // second stream while part i scans
+    int coarse_ahead = 0;              // option "coarse_ahead": n = 2 .. 7 parts (1: four); 0 = one part, one stream (default: measured slower, see search_common)
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_pipe[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    DevBuf<int32_t> ws_cells_all;      // [nq][w] the parts' selected cells
+    DevBuf<double> ws_cdsel_all;       // ... and their exact distances
+    double *cdsel_out = nullptr;       // where run_coarse leaves the selected cells' distances (null: ws_cdsel)
     DevBuf<unsigned short> ws_R16;     // K3mk: the kept pairs' fp16 residuals [pairs][D]
     DevBuf<double> ws_nrow;            // ... and ||r||^2
     double coarse_maxabs = 0.0;        // largest |centroid element| (set_coarse)
@@ -1659,7 +1667,7 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
         A.coarseT = h->d_coarseT;
         A.row_scratch = h->ws_cdist.p;
         A.cells = d_cells;
-        A.cdsel = h->ws_cdsel.p;
+        A.cdsel = h->cdsel_out ? h->cdsel_out : h->ws_cdsel.p;
         A.C = h->C;
         A.D = h->D;
         A.w = h->w;
@@ -1719,7 +1727,7 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
         A.coarseT = h->d_coarseT;
         A.row_scratch = h->ws_cdist.p;
         A.cells = d_cells;
-        A.cdsel = h->ws_cdsel.p;
+        A.cdsel = h->cdsel_out ? h->cdsel_out : h->ws_cdsel.p;
         A.C = h->C;
         A.D = h->D;
         A.w = h->w;
@@ -2244,6 +2252,56 @@ int search_common(mmidx_index *h, int k, int64_t nq, const double *dQ, const int
     SearchPlan pl;
     rc = make_plan(h, k, nq, pl, d_cells == nullptr);
     if (rc) return rc;
+    // Coarse-ahead pipelining (option "coarse_ahead", OFF by default): a large IVFPQ call runs in parts; while part i is scanned on the
+    // caller's stream, the coarse stage of part i + 1 (matrix-core dot products + the latency-bound certified selection: 0.22 of the
+    // headline step's 1.12 ms) runs on a second stream next to pass A (an LDS / vector-ALU bound kernel).  The parts' cells and exact
+    // cell distances go to their own arrays; everything else is the plain per-batch path with the cells given (what a sharded handle
+    // does with its shards).  Measured on the headline (16384 queries): 1.118 ms plain, 1.238 ms in two parts, 1.348 in three,
+    // 1.430 in four -- every part pays the step's 13 small launches (71 us) again, and pass A in pieces next to the coarse stage
+    // takes 2 x 0.474 ms instead of 0.81.  Bit-identical either way (test_coarse_ahead_pipelining).
+    if (h->coarse_ahead && ivf && !d_cells && mode == 0 && !sdc_tt && h->profiling != 1 && !h->debug_sync && !h->exact_coarse && nq >= 8192) {
+        const int P = h->coarse_ahead >= 2 && h->coarse_ahead <= 7 ? h->coarse_ahead : 4;
+        const int64_t per = ((nq + P - 1) / P + 127) & ~(int64_t)127;
+        if (per <= pl.qb) {
+            bool ok = true;
+            if (!h->stream2) ok = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) == hipSuccess;
+            for (int i = 0; ok && i < P + 1; i++)
+                if (!h->ev_pipe[i]) ok = hipEventCreateWithFlags(&h->ev_pipe[i], hipEventDisableTiming) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
+            if (ok) {
+                HIPCK(h->ws_cells_all.reserve((size_t)nq * h->w));
+                HIPCK(h->ws_cdsel_all.reserve((size_t)nq * h->w));
+                // part 0's coarse stage on the caller's stream (it also sizes the coarse workspaces: the parts are no larger)
+                h->cdsel_out = h->ws_cdsel_all.p;
+                rc = run_coarse(h, std::min(per, nq), dQ, h->ws_cells_all.p, st);
+                h->cdsel_out = nullptr;
+                if (rc) return rc;
+                if (h->cdsel_valid) {  // (the certified selection ran: the exact distances of the selected cells exist)
+                    HIPCK(hipEventRecord(h->ev_pipe[0], st));
+                    int part = 0;
+                    for (int64_t q0 = 0; q0 < nq; q0 += per, part++) {
+                        const int64_t nb = std::min(per, nq - q0), q1 = q0 + per;
+                        if (q1 < nq) {  // the next part's coarse stage: behind this part's (the coarse workspaces are shared), on stream 2
+                            const int64_t nb1 = std::min(per, nq - q1);
+                            HIPCK(hipStreamWaitEvent(h->stream2, h->ev_pipe[part], 0));
+                            h->cdsel_out = h->ws_cdsel_all.p + (size_t)q1 * h->w;
+                            rc = run_coarse(h, nb1, dQ + (size_t)q1 * h->D, h->ws_cells_all.p + (size_t)q1 * h->w, h->stream2);
+                            h->cdsel_out = nullptr;
+                            if (rc) return rc;
+                            HIPCK(hipEventRecord(h->ev_pipe[part + 1], h->stream2));
+                        }
+                        if (part > 0) HIPCK(hipStreamWaitEvent(st, h->ev_pipe[part], 0));
+                        rc = search_batch_device(h, pl, k, nb, dQ + (size_t)q0 * h->D, h->ws_cells_all.p + (size_t)q0 * h->w, mode,
+                                                 d_iid ? d_iid + (size_t)q0 * k : nullptr, d_dist ? d_dist + (size_t)q0 * k : nullptr, d_cnt + q0,
+                                                 nullptr, nullptr, 0, nullptr, st, nullptr, h->ws_cdsel_all.p + (size_t)q0 * h->w);
+                        if (rc) return rc;
+                    }
+                    h->cdsel_valid = false;
+                    return MMIDX_OK;
+                }
+            }
+        }
+    }
     for (int64_t q0 = 0; q0 < nq; q0 += pl.qb) {
         const int64_t nb = std::min<int64_t>(pl.qb, nq - q0);
         rc = search_batch_device(h, pl, k, nb, dQ + (size_t)q0 * h->D, d_cells ? d_cells + (size_t)q0 * h->w : nullptr, mode,
@@ -2482,6 +2540,17 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_R.release();
     h->ws_R16.release();
     h->ws_defer.release();
+    h->ws_cells_all.release();
+    h->ws_cdsel_all.release();
+    for (hipEvent_t &e : h->ev_pipe)
+        if (e) {
+            (void)hipEventDestroy(e);
+            e = nullptr;
+        }
+    if (h->stream2) {
+        (void)hipStreamDestroy(h->stream2);
+        h->stream2 = nullptr;
+    }
     h->ws_lgrp.release();
     h->ws_rows.release();
     h->ws_nrow.release();
@@ -3267,6 +3336,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->mfma_qcap = value > 0 ? value : 0;
     } else if (n == "coarse_wave_sel") {
         h->coarse_wave_sel = value != 0;
+    } else if (n == "coarse_ahead") {
+        h->coarse_ahead = value < 0 ? 0 : value;
     } else if (n == "mfma_cr") {
         h->mfma_cr = value != 0;
     } else if (n == "mfma_kc_v1") {

@@ -495,6 +495,40 @@ def test_large_batch_properties(mi):
     ix.close()
 
 
+def test_coarse_ahead_pipelining(mi, oracle):
+    """A device call of 8192 queries and more runs in four parts, the coarse stage of part i + 1 on a second stream while part i is
+    scanned (search_common; option "coarse_ahead").  9000 queries (three parts of 2304 and one of 2088), every vector twice (ties),
+    overlapping cells: with the pipelining and without it the answers are the same arrays bit for bit, and the oracle's on the
+    first and the last queries; twice in a row (the second call reuses streams, events and workspaces)."""
+    D, C, m, ks, n, w, k = 64, 600, 8, 256, 60000, 4, 20
+    rng = np.random.default_rng(19)
+    mu = 0.7 * rng.standard_normal((C, D))
+    half = mu[rng.integers(0, C, n // 2)] + 0.5 * rng.standard_normal((n // 2, D))
+    base = np.concatenate([half, half])[rng.permutation(n)]
+    ds = D // m
+    pq = np.stack([synth.kmeans((mu[rng.integers(0, C, 3000)] - base[:3000])[:, s * ds:(s + 1) * ds], ks, iters=2, seed=s) for s in range(m)])
+    ix = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    ix.loadCoarseQuantizer(mu)
+    ix.loadProductQuantizer(pq)
+    ix.setW(w)
+    ix.indexVectors([str(i) for i in range(n)], base)
+    Q = np.concatenate([base[rng.integers(0, n, 8000)] + 0.02 * rng.standard_normal((8000, D)), 0.5 * (base[:1000] + base[1000:2000])])
+    res = {}
+    for ahead in (1, 0, 1):
+        ix.set_option("coarse_ahead", ahead)
+        got = ix.search_batch(k, Q)
+        if ahead in res:
+            assert_same(got, res[ahead])
+        res[ahead] = got
+    assert_same(res[1], res[0])
+    ref = oracle_ivfpq(oracle, {"coarse": mu, "pq": pq}, D, m, ks, C, w)
+    ref.add_vectors(base)
+    sel = np.r_[0:150, 2250:2400, 8850:9000]  # (across the part boundaries at 2304 and in the last part)
+    want = ref.search_batch(Q[sel], k)
+    assert_same(tuple(a[sel] for a in res[1]), want)
+    ix.close()
+
+
 def _coarse_cells(mi, ix, Q):
     """computeNearestCoarseIndices through the device entry point (torch only holds the buffers)."""
     import torch
