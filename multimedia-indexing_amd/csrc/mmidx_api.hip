@@ -312,6 +312,8 @@ struct mmidx_index {
     DevBuf<u32> ws_defer;              // k_coarse_front_sel: count + list of the queries left to k_coarse_select_defer
     // coarse-ahead pipelining of a large device call (search_common): the call runs in parts; the coarse stage of part i + 1 goes to a
     // second stream while part i scans
+    int passb_small = 1;               // option "passb_small": 0 = pass B through K3m / K3g also when the call before kept at most 64 pairs
+    int hint_calls = 0;                // IVF pass-B stages launched so far (pin_hint[0] describes the last one)
     int coarse_ahead = 0;              // option "coarse_ahead": n = 2 .. 7 parts (1: four); 0 = one part, one stream (default: measured slower, see search_common)
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_pipe[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1550,6 +1552,18 @@ int launch_mfma_common(mmidx_index *h, const ScanParams &S, ScanParams F, const 
 // pass B over the sorted pairs (P.order / P.n_order as for K3f; per-cell counts and starts in ws_pcount / ws_pstart).
 // Returns 1 when K3g does not apply (the caller uses K3f).
 int launch_scan_grouped(mmidx_index *h, const ScanParams &P, const SearchPlan &pl, long long nq, long long npairs, hipStream_t st) {
+    // The call before kept (next to) no pair behind the coarse bound -- the separable benchmark: every call.  K3m would walk an empty
+    // pass B in six launches of ~5 us (group build, prep, scan, verification, redo, K3f tail: the host cannot know the count); K3f's
+    // looping kernel alone serves whatever the count turns out to be in ONE launch -- exactly, if slowly should the guess be wrong
+    // (the next call sees the real count).  Option "passb_small" = 0: off.
+    if (P.ivf && h->passb_small && h->pin_hint && h->hint_calls > 1 && h->code_bytes == 1 && h->ks <= 256 && (h->m == 8 || h->m == 16 || h->m == 32) &&
+        !h->no_filter && !P.sdc_tt && !h->debug_sync) {
+        const int32_t seen = *(volatile int32_t *)h->pin_hint;
+        if (seen >= 0 && seen <= 64) {
+            const unsigned gx = (unsigned)(((P.n_items + 7) / 8) * 8);
+            return launch_scan_filtered(h, P, pl, dim3(gx, (unsigned)pl.nchunks), st, -1);
+        }
+    }
     if (P.ivf) {
         const int rcm = launch_mfma_common(h, P, P, pl, h->C, pl.nchunks, npairs, h->max_list_len, st, nq, nullptr);
         if (rcm != 1) return rcm;
@@ -2105,6 +2119,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
             }
             DBG_SYNC("pair hist");
             hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, h->C, h->ws_pstart.p, h->ws_pcursor.p, h->pin_hint);
+            if (h->hint_calls < (1 << 30)) h->hint_calls++;  // (this call's count reaches pin_hint[0] when the kernel has run)
             DBG_SYNC("pair scan");
             hipLaunchKernelGGL(k_pair_scatter, dim3(g), dim3(256), 0, st, d_cells, P.w, 1, npairs, h->ws_pstart.p, h->ws_pcursor.p,
                                h->ws_order.p, h->ws_keep.p);
@@ -3336,6 +3351,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->mfma_qcap = value > 0 ? value : 0;
     } else if (n == "coarse_wave_sel") {
         h->coarse_wave_sel = value != 0;
+    } else if (n == "passb_small") {
+        h->passb_small = value != 0;
     } else if (n == "coarse_ahead") {
         h->coarse_ahead = value < 0 ? 0 : value;
     } else if (n == "mfma_cr") {

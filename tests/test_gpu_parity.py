@@ -495,6 +495,45 @@ def test_large_batch_properties(mi):
     ix.close()
 
 
+def test_pass_b_in_one_launch_after_an_empty_one(mi, oracle):
+    """When the call before kept at most 64 (query, probe) pairs behind the coarse bound, the next call's pass B is K3f's looping kernel
+    alone -- one launch instead of K3m's six over what is usually nothing (launch_scan_grouped; option "passb_small").  The guess can be
+    wrong: well separated cells and self-queries (every far pair pruned), THEN queries between the cells (every far pair kept) -- that
+    call is served by the one kernel, exactly; the call after it sees the real count and goes back to K3m.  The oracle's answers every
+    time, with the option and without."""
+    D, C, m, ks, n, w, k = 64, 40, 8, 256, 30000, 8, 20
+    rng = np.random.default_rng(23)
+    mu = 6.0 * rng.standard_normal((C, D))
+    lab = rng.integers(0, C, n)
+    base = mu[lab] + 0.3 * rng.standard_normal((n, D))
+    ds = D // m
+    pq = np.stack([synth.kmeans((mu[lab[:3000]] - base[:3000])[:, s * ds:(s + 1) * ds], ks, iters=2, seed=s) for s in range(m)])  # (the true residuals: a small Rmax)
+    ref = oracle_ivfpq(oracle, {"coarse": mu, "pq": pq}, D, m, ks, C, w)
+    ref.add_vectors(base)
+    Qself = base[:200] + 0.001 * rng.standard_normal((200, D))
+    Qmid = np.concatenate([0.5 * (mu[:20] + mu[20:40]), rng.standard_normal((30, D))])  # far from every cell: nothing can be pruned
+    want_self, want_mid = ref.search_batch(Qself, k), ref.search_batch(Qmid, k)
+    for small in (1, 0):
+        ix = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+        ix.loadCoarseQuantizer(mu)
+        ix.loadProductQuantizer(pq)
+        ix.setW(w)
+        ix.set_option("passb_small", small)
+        ix.indexVectors([str(i) for i in range(n)], base)
+        ix.set_profiling(True)
+        assert_same(ix.search_batch(k, Qself), want_self)   # (first call: no figure yet, K3m)
+        assert ix.get_stats()["passb_items_last"] <= 64
+        assert_same(ix.search_batch(k, Qself), want_self)   # the call before kept nothing: one launch
+        assert_same(ix.search_batch(k, Qmid), want_mid)     # ... and so does this one, with every pair kept
+        st = ix.get_stats()
+        assert st["passb_items_last"] > 64
+        if small:
+            assert st["mfma_survivors"] == 0                # (K3m has not run since the first call)
+        assert_same(ix.search_batch(k, Qmid), want_mid)     # the real count is known: K3m again
+        assert ix.get_stats()["mfma_survivors"] > 0
+        ix.close()
+
+
 def test_coarse_ahead_pipelining(mi, oracle):
     """A device call of 8192 queries and more runs in four parts, the coarse stage of part i + 1 on a second stream while part i is
     scanned (search_common; option "coarse_ahead").  9000 queries (three parts of 2304 and one of 2088), every vector twice (ties),
