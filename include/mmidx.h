@@ -342,9 +342,9 @@ int mmidx_set_profiling(mmidx_index *h, int enabled);
  * "mfma_kc_tpw" (8 / 16 code tiles per wave of k_scan_mfma_kc), "lut_pre" (pass A's tables built by their own kernel),
  * "coarse_wave_sel" (0: the coarse stage's exact selection always by a block per query instead of k_coarse_front_sel),
  * "passb_small" (0: pass B through K3m / K3g also when the call before kept at most 64 pairs; default 1: K3f's looping kernel alone,
- * one launch), "coarse_ahead" (n parts of a large device call with the next part's coarse stage on a second stream; 0 = off, the default: measured
- * slower), "mfma_cr" (1: flat PQ calls of 256+ queries through K3mc, mmidx_scan_mfma_cr.h; off by default: measured slower than K3m),
- * "shard_pipeline" (0: no second stream / communicator for the query exchange of a sharded handle).  None of them changes a result. */
+ * one launch),
+ * "shard_pipeline" (1: the query exchange of a sharded handle on a second stream / communicator; the default for in-process shards, off
+ * by default on two or more physical devices until a multi-device run has passed).  None of them changes a result. */
 int mmidx_set_option(mmidx_index *h, const char *name, int value);
 int mmidx_get_stats(mmidx_index *h, mmidx_stats *out);
 

@@ -15,7 +15,6 @@
 #include "mmidx_scan_grp.h"
 #include "mmidx_scan_mfma.h"
 #include "mmidx_scan_mfma_kc.h"
-#include "mmidx_scan_mfma_cr.h"
 #include "mmidx_frontend.h"
 
 #include <algorithm>
@@ -305,21 +304,11 @@ struct mmidx_index {
     DevBuf<double> ws_lutpre;
     DevBuf<uint4> ws_surv;
     DevBuf<double> ws_R;               // RandomRotation: the kept pairs' exact rotated residuals [pairs][D]
-    DevBuf<int2> ws_lgrp;              // K3mc: per list {first group, groups}
-    DevBuf<unsigned char> ws_rows;     // K3mc: the pair slots' row records (MfmaRow)
-    int mfma_cr = 0;                   // option "mfma_cr": 1 = flat PQ calls of 256+ queries through K3mc (codes resident, groups streaming; measured
-                                       // slower than K3m so far: 1.56 against 1.21 ms per cfg2 batch -- DESIGN.md 5.3)
     DevBuf<u32> ws_defer;              // k_coarse_front_sel: count + list of the queries left to k_coarse_select_defer
-    // coarse-ahead pipelining of a large device call (search_common): the call runs in parts; the coarse stage of part i + 1 goes to a
-    // second stream while part i scans
     int passb_small = 1;               // option "passb_small": 0 = pass B through K3m / K3g also when the call before kept at most 64 pairs
     int hint_calls = 0;                // IVF pass-B stages launched so far (pin_hint[0] describes the last one)
-    int coarse_ahead = 0;              // option "coarse_ahead": n = 2 .. 7 parts (1: four); 0 = one part, one stream (default: measured slower, see search_common)
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_pipe[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    DevBuf<int32_t> ws_cells_all;      // [nq][w] the parts' selected cells
-    DevBuf<double> ws_cdsel_all;       // ... and their exact distances
-    double *cdsel_out = nullptr;       // where run_coarse leaves the selected cells' distances (null: ws_cdsel)
+    int64_t hint_last_nq = -1, hint_prev_nq = -1;  // batch size and probes of the stage launched last / the one before it (whose count pin_hint[0] holds
+    int hint_last_w = -1, hint_prev_w = -1;        //  while the current call is being enqueued): "passb_small" trusts the hint for a like call only
     DevBuf<unsigned short> ws_R16;     // K3mk: the kept pairs' fp16 residuals [pairs][D]
     DevBuf<double> ws_nrow;            // ... and ||r||^2
     double coarse_maxabs = 0.0;        // largest |centroid element| (set_coarse)
@@ -1238,19 +1227,14 @@ int launch_mfma_kc2_scan_t(mmidx_index *h, const MfmaKcParams &KP, hipStream_t s
 
 // K3mk (mmidx_scan_mfma_kc.h): pass B through the matrix-core bound for vectors of several 128-dimension chunks.  Same contract as
 // launch_mfma_common (which dispatches here); returns 1 when it does not apply.
-// cr: K3mc (mmidx_scan_mfma_cr.h: D = 128, the codes resident, the list's groups streaming) instead of K3mk
 int launch_mfma_kc(mmidx_index *h, const ScanParams &S, ScanParams F, const SearchPlan &pl, int nlists, int nchunks_f, long long npairs, long long maxlen,
-                   hipStream_t st, long long nq, const double *flat_lut, const bool cr = false) {
-    if (h->transform == MMIDX_TR_ROTATION || (size_t)npairs * h->D * 2 > ((size_t)16 << 30) || (!cr && h->m % 16 != 0) || h->m > 128) return 1;
-    const int G = cr ? MF_QG : MFK_G;
+                   hipStream_t st, long long nq, const double *flat_lut) {
+    if (h->transform == MMIDX_TR_ROTATION || (size_t)npairs * h->D * 2 > ((size_t)16 << 30) || h->m % 16 != 0 || h->m > 128) return 1;
+    if (S.ivf && h->d_perm && !h->d_coarseP) return 1;  // (every applicability check ahead of the first launch)
+    const int G = MFK_G;
     const size_t nfb = (size_t)npairs * (size_t)std::max(nchunks_f, 1);
     HIPCK(h->ws_gdesc.reserve((size_t)npairs / G + (size_t)nlists + 8));
     HIPCK(h->ws_gfb.reserve(4 + 2 * nfb + 16));
-    if (cr) HIPCK(h->ws_lgrp.reserve((size_t)nlists + 1));
-    hipLaunchKernelGGL(k_group_build, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, h->ws_pstart.p, nlists, G, h->ws_gdesc.p, h->ws_gfb.p,
-                       (u32 *)(h->ws_gfb.p + 1), (unsigned long long *)(h->d_counters + 7), h->pin_hint ? h->pin_hint + 1 : nullptr,
-                       cr ? h->ws_lgrp.p : (int2 *)nullptr);
-    HIPCK(hipGetLastError());
     // the DMA form (k_scan_mfma_kc2) where the lanes' code bytes come in aligned words: D a multiple of 256
     const int nb = 32 / h->dsub, quarter = h->m / 4;
     int cg = 0;
@@ -1261,9 +1245,11 @@ int launch_mfma_kc(mmidx_index *h, const ScanParams &S, ScanParams F, const Sear
     int sub = h->mfma_sub > 0 ? ((h->mfma_sub + 63) & ~63) : 64 * tpw;
     if (cg) sub = h->mfma_sub > 0 ? std::min(sub, 1 << 20) : 8 * MFK2_TPW * (MFK2_NT / 64) * 16;  // k_scan_mfma_kc2 walks an item in passes of 1024 codes
     else sub = std::min(sub, 64 * tpw);  // (a wave holds at most TPW tiles' accumulators)
-    if (cr) sub = MFC_PIECE;
     const int nsub = (int)((maxlen + sub - 1) / sub);
     if ((long long)(npairs / G + nlists) * nsub > 0x7fffff00ll) return 1;
+    hipLaunchKernelGGL(k_group_build, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, h->ws_pstart.p, nlists, G, h->ws_gdesc.p, h->ws_gfb.p,
+                       (u32 *)(h->ws_gfb.p + 1), (unsigned long long *)(h->d_counters + 7), h->pin_hint ? h->pin_hint + 1 : nullptr);
+    HIPCK(hipGetLastError());
     HIPCK(h->ws_ghist.reserve((size_t)nq * 256));
     HIPCK(h->ws_T0.reserve((size_t)nq));
     HIPCK(h->ws_redo.reserve((size_t)nq));
@@ -1280,7 +1266,6 @@ int launch_mfma_kc(mmidx_index *h, const ScanParams &S, ScanParams F, const Sear
     MfmaParams &MP = KP.M;
     MP.S = S;
     if (h->d_perm) {
-        if (S.ivf && !h->d_coarseP) return 1;
         HIPCK(h->ws_Qp.reserve((size_t)nq * h->D));
         const long long tot = (long long)nq * h->D;
         hipLaunchKernelGGL(k_permute_cols, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, S.Q, h->d_perm, h->ws_Qp.p, h->D, (long long)nq);
@@ -1296,8 +1281,7 @@ int launch_mfma_kc(mmidx_index *h, const ScanParams &S, ScanParams F, const Sear
     float cmaxf = S.ivf ? (float)h->coarse_maxabs : 0.f;
     if (S.ivf && (double)cmaxf < h->coarse_maxabs) cmaxf = std::nextafter(cmaxf, INFINITY);
     hipLaunchKernelGGL(k_resid_scale, dim3(1), dim3(1), 0, st, (const u32 *)d_qmax, cmaxf, h->pq_ep, d_scale);
-    // (K3mc on flat PQ: every chunk sees the same queries in the same order -- the rows of the first chunk's pairs serve all chunks)
-    const long long nrows = (cr && !S.ivf) ? nq : npairs;
+    const long long nrows = npairs;
     hipLaunchKernelGGL(k_pair_resid16, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, st, MP.S.Q, MP.S.coarse, S.cells, S.order, S.n_order, (long long)nrows, S.w,
                        h->D, S.ivf, (const int32_t *)d_scale, h->ws_R16.p, h->ws_nrow.p);
     HIPCK(hipGetLastError());
@@ -1345,32 +1329,7 @@ int launch_mfma_kc(mmidx_index *h, const ScanParams &S, ScanParams F, const Sear
         HIPCK(hipEventRecord(mev[0], st));
     }
     int rc;
-    if (cr) {
-        // three stages over disjoint pieces of every list (1/8, 2/8, 5/8): the thresholds tighten between them
-        HIPCK(h->ws_rows.reserve((size_t)(nrows + 1) * sizeof(MfmaRow)));
-        MfmaCrParams CP{};
-        CP.lgrp = h->ws_lgrp.p;
-        CP.rows = (const MfmaRow *)h->ws_rows.p;
-        CP.nlists = nlists;
-        CP.npiece = nsub;
-        CP.per_list_rows = !S.ivf;
-        CP.nrows = nrows;
-        int blocks = h->mfma_blocks > 0 ? h->mfma_blocks : 2 * std::max(h->num_cus, 8);
-        blocks = std::max(8, (blocks + 7) & ~7);
-        static const int st_lo[3] = {0, 1, 3}, st_hi[3] = {1, 3, 8};
-        for (int sg = 0; sg < 3; sg++) {
-            CP.K = KP;
-            CP.st_lo = st_lo[sg];
-            CP.st_hi = st_hi[sg];
-            CP.cursor = h->ws_mfctl.p + (sg == 0 ? 8 : sg == 1 ? 24 : 32);
-            hipLaunchKernelGGL(k_cr_rows, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, st, KP, (MfmaRow *)h->ws_rows.p, (long long)nrows);
-            if (h->dsub == 16) hipLaunchKernelGGL((k_scan_mfma_cr<16>), dim3((unsigned)blocks), dim3(MFC_NT), 0, st, CP);
-            else hipLaunchKernelGGL((k_scan_mfma_cr<8>), dim3((unsigned)blocks), dim3(MFC_NT), 0, st, CP);
-            if (sg < 2) hipLaunchKernelGGL(k_ghist_tighten, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, MP, (long long)nq);
-            HIPCK(hipGetLastError());
-        }
-        rc = MMIDX_OK;
-    } else if (cg && h->dsub == 16) rc = cg == 8 ? launch_mfma_kc2_scan_t<16, 8>(h, KP, st) : launch_mfma_kc2_scan_t<16, 4>(h, KP, st);
+    if (cg && h->dsub == 16) rc = cg == 8 ? launch_mfma_kc2_scan_t<16, 8>(h, KP, st) : launch_mfma_kc2_scan_t<16, 4>(h, KP, st);
     else if (cg) rc = launch_mfma_kc2_scan_t<8, 8>(h, KP, st);
     else if (h->dsub == 16) rc = tpw == 8 ? launch_mfma_kc_scan_t<16, 8>(h, KP, L.total, st) : launch_mfma_kc_scan_t<16, 16>(h, KP, L.total, st);
     else rc = tpw == 8 ? launch_mfma_kc_scan_t<8, 8>(h, KP, L.total, st) : launch_mfma_kc_scan_t<8, 16>(h, KP, L.total, st);
@@ -1418,9 +1377,10 @@ int launch_mfma_common(mmidx_index *h, const ScanParams &S, ScanParams F, const 
         nq * 256 * 4 > (1ll << 31) || npairs >= 0x7fffff00ll || ((uintptr_t)S.Q & 15) != 0)
         return 1;
     if (h->D > 128) return launch_mfma_kc(h, S, F, pl, nlists, nchunks_f, npairs, maxlen, st, nq, flat_lut);
-    // flat PQ with many groups of queries over every chunk of the list: the codes resident, the groups streaming (K3mc)
-    if (h->mfma_cr && !S.ivf && h->D == 128 && (h->dsub == 8 || h->dsub == 16) && nq >= 4 * MF_QG && nq <= (long long)MFC_MAXG * MF_QG && h->transform != MMIDX_TR_ROTATION)
-        return launch_mfma_kc(h, S, F, pl, nlists, nchunks_f, npairs, maxlen, st, nq, flat_lut, true);
+    // (every applicability check ahead of the first launch: a fallback after k_group_build / k_mfma_prep would pay them twice and write
+    //  the hint words twice)
+    if (h->d_perm && S.ivf && !h->d_coarseP) return 1;
+    if (h->transform == MMIDX_TR_ROTATION && (!h->d_rot || (size_t)npairs * h->D * 8 > ((size_t)8 << 30))) return 1;
     constexpr int G = MF_QG;
     const size_t nfb = (size_t)npairs * (size_t)std::max(nchunks_f, 1);
     HIPCK(h->ws_gdesc.reserve((size_t)npairs / G + (size_t)nlists + 8));
@@ -1455,7 +1415,6 @@ int launch_mfma_common(mmidx_index *h, const ScanParams &S, ScanParams F, const 
     MfmaParams MP{};
     MP.S = S;
     if (h->d_perm) {  // rows in transformed order: contiguous loads (the centroids once per index, the queries once per call)
-        if (S.ivf && !h->d_coarseP) return 1;
         HIPCK(h->ws_Qp.reserve((size_t)nq * h->D));
         const long long tot = (long long)nq * h->D;
         hipLaunchKernelGGL(k_permute_cols, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, S.Q, h->d_perm, h->ws_Qp.p, h->D, (long long)nq);
@@ -1466,7 +1425,6 @@ int launch_mfma_common(mmidx_index *h, const ScanParams &S, ScanParams F, const 
     MP.R = nullptr;
     if (h->transform == MMIDX_TR_ROTATION) {
         // the pairs' exact rotated residuals, once per call (16 k multiply-adds per pair at D = 128 instead of one per survivor)
-        if (!h->d_rot || (size_t)npairs * h->D * 8 > ((size_t)8 << 30)) return 1;
         HIPCK(h->ws_R.reserve((size_t)npairs * h->D));
         hipLaunchKernelGGL(k_pair_rotate, dim3((unsigned)((npairs + 7) / 8)), dim3(128), 8 * (size_t)h->D * sizeof(double), st, S.Q, S.coarse, h->d_rot, S.cells,
                            S.order, S.n_order, (long long)npairs, S.w, h->D, S.ivf, h->ws_R.p);
@@ -1557,7 +1515,7 @@ int launch_scan_grouped(mmidx_index *h, const ScanParams &P, const SearchPlan &p
     // looping kernel alone serves whatever the count turns out to be in ONE launch -- exactly, if slowly should the guess be wrong
     // (the next call sees the real count).  Option "passb_small" = 0: off.
     if (P.ivf && h->passb_small && h->pin_hint && h->hint_calls > 1 && h->code_bytes == 1 && h->ks <= 256 && (h->m == 8 || h->m == 16 || h->m == 32) &&
-        !h->no_filter && !P.sdc_tt && !h->debug_sync) {
+        !h->no_filter && !P.sdc_tt && !h->debug_sync && h->hint_prev_nq == (int64_t)nq && h->hint_prev_w == P.w) {
         const int32_t seen = *(volatile int32_t *)h->pin_hint;
         if (seen >= 0 && seen <= 64) {
             const unsigned gx = (unsigned)(((P.n_items + 7) / 8) * 8);
@@ -1681,7 +1639,7 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
         A.coarseT = h->d_coarseT;
         A.row_scratch = h->ws_cdist.p;
         A.cells = d_cells;
-        A.cdsel = h->cdsel_out ? h->cdsel_out : h->ws_cdsel.p;
+        A.cdsel = h->ws_cdsel.p;
         A.C = h->C;
         A.D = h->D;
         A.w = h->w;
@@ -1741,7 +1699,7 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
         A.coarseT = h->d_coarseT;
         A.row_scratch = h->ws_cdist.p;
         A.cells = d_cells;
-        A.cdsel = h->cdsel_out ? h->cdsel_out : h->ws_cdsel.p;
+        A.cdsel = h->ws_cdsel.p;
         A.C = h->C;
         A.D = h->D;
         A.w = h->w;
@@ -2120,6 +2078,10 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
             DBG_SYNC("pair hist");
             hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, h->C, h->ws_pstart.p, h->ws_pcursor.p, h->pin_hint);
             if (h->hint_calls < (1 << 30)) h->hint_calls++;  // (this call's count reaches pin_hint[0] when the kernel has run)
+            h->hint_prev_nq = h->hint_last_nq;  // (what the count the next stage reads was measured on: the call before this one)
+            h->hint_prev_w = h->hint_last_w;
+            h->hint_last_nq = nq;
+            h->hint_last_w = P.w;
             DBG_SYNC("pair scan");
             hipLaunchKernelGGL(k_pair_scatter, dim3(g), dim3(256), 0, st, d_cells, P.w, 1, npairs, h->ws_pstart.p, h->ws_pcursor.p,
                                h->ws_order.p, h->ws_keep.p);
@@ -2267,56 +2229,6 @@ int search_common(mmidx_index *h, int k, int64_t nq, const double *dQ, const int
     SearchPlan pl;
     rc = make_plan(h, k, nq, pl, d_cells == nullptr);
     if (rc) return rc;
-    // Coarse-ahead pipelining (option "coarse_ahead", OFF by default): a large IVFPQ call runs in parts; while part i is scanned on the
-    // caller's stream, the coarse stage of part i + 1 (matrix-core dot products + the latency-bound certified selection: 0.22 of the
-    // headline step's 1.12 ms) runs on a second stream next to pass A (an LDS / vector-ALU bound kernel).  The parts' cells and exact
-    // cell distances go to their own arrays; everything else is the plain per-batch path with the cells given (what a sharded handle
-    // does with its shards).  Measured on the headline (16384 queries): 1.118 ms plain, 1.238 ms in two parts, 1.348 in three,
-    // 1.430 in four -- every part pays the step's 13 small launches (71 us) again, and pass A in pieces next to the coarse stage
-    // takes 2 x 0.474 ms instead of 0.81.  Bit-identical either way (test_coarse_ahead_pipelining).
-    if (h->coarse_ahead && ivf && !d_cells && mode == 0 && !sdc_tt && h->profiling != 1 && !h->debug_sync && !h->exact_coarse && nq >= 8192) {
-        const int P = h->coarse_ahead >= 2 && h->coarse_ahead <= 7 ? h->coarse_ahead : 4;
-        const int64_t per = ((nq + P - 1) / P + 127) & ~(int64_t)127;
-        if (per <= pl.qb) {
-            bool ok = true;
-            if (!h->stream2) ok = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) == hipSuccess;
-            for (int i = 0; ok && i < P + 1; i++)
-                if (!h->ev_pipe[i]) ok = hipEventCreateWithFlags(&h->ev_pipe[i], hipEventDisableTiming) == hipSuccess;
-            if (!ok) (void)hipGetLastError();
-            if (ok) {
-                HIPCK(h->ws_cells_all.reserve((size_t)nq * h->w));
-                HIPCK(h->ws_cdsel_all.reserve((size_t)nq * h->w));
-                // part 0's coarse stage on the caller's stream (it also sizes the coarse workspaces: the parts are no larger)
-                h->cdsel_out = h->ws_cdsel_all.p;
-                rc = run_coarse(h, std::min(per, nq), dQ, h->ws_cells_all.p, st);
-                h->cdsel_out = nullptr;
-                if (rc) return rc;
-                if (h->cdsel_valid) {  // (the certified selection ran: the exact distances of the selected cells exist)
-                    HIPCK(hipEventRecord(h->ev_pipe[0], st));
-                    int part = 0;
-                    for (int64_t q0 = 0; q0 < nq; q0 += per, part++) {
-                        const int64_t nb = std::min(per, nq - q0), q1 = q0 + per;
-                        if (q1 < nq) {  // the next part's coarse stage: behind this part's (the coarse workspaces are shared), on stream 2
-                            const int64_t nb1 = std::min(per, nq - q1);
-                            HIPCK(hipStreamWaitEvent(h->stream2, h->ev_pipe[part], 0));
-                            h->cdsel_out = h->ws_cdsel_all.p + (size_t)q1 * h->w;
-                            rc = run_coarse(h, nb1, dQ + (size_t)q1 * h->D, h->ws_cells_all.p + (size_t)q1 * h->w, h->stream2);
-                            h->cdsel_out = nullptr;
-                            if (rc) return rc;
-                            HIPCK(hipEventRecord(h->ev_pipe[part + 1], h->stream2));
-                        }
-                        if (part > 0) HIPCK(hipStreamWaitEvent(st, h->ev_pipe[part], 0));
-                        rc = search_batch_device(h, pl, k, nb, dQ + (size_t)q0 * h->D, h->ws_cells_all.p + (size_t)q0 * h->w, mode,
-                                                 d_iid ? d_iid + (size_t)q0 * k : nullptr, d_dist ? d_dist + (size_t)q0 * k : nullptr, d_cnt + q0,
-                                                 nullptr, nullptr, 0, nullptr, st, nullptr, h->ws_cdsel_all.p + (size_t)q0 * h->w);
-                        if (rc) return rc;
-                    }
-                    h->cdsel_valid = false;
-                    return MMIDX_OK;
-                }
-            }
-        }
-    }
     for (int64_t q0 = 0; q0 < nq; q0 += pl.qb) {
         const int64_t nb = std::min<int64_t>(pl.qb, nq - q0);
         rc = search_batch_device(h, pl, k, nb, dQ + (size_t)q0 * h->D, d_cells ? d_cells + (size_t)q0 * h->w : nullptr, mode,
@@ -2555,19 +2467,6 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_R.release();
     h->ws_R16.release();
     h->ws_defer.release();
-    h->ws_cells_all.release();
-    h->ws_cdsel_all.release();
-    for (hipEvent_t &e : h->ev_pipe)
-        if (e) {
-            (void)hipEventDestroy(e);
-            e = nullptr;
-        }
-    if (h->stream2) {
-        (void)hipStreamDestroy(h->stream2);
-        h->stream2 = nullptr;
-    }
-    h->ws_lgrp.release();
-    h->ws_rows.release();
     h->ws_nrow.release();
     h->ws_lutpre.release();
     h->ws_mfctl.release();
@@ -3353,10 +3252,6 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->coarse_wave_sel = value != 0;
     } else if (n == "passb_small") {
         h->passb_small = value != 0;
-    } else if (n == "coarse_ahead") {
-        h->coarse_ahead = value < 0 ? 0 : value;
-    } else if (n == "mfma_cr") {
-        h->mfma_cr = value != 0;
     } else if (n == "mfma_kc_v1") {
         h->mfma_kc_v1 = value != 0;
     } else if (n == "mfma_kc_tpw") {
@@ -3805,10 +3700,14 @@ int mmidx_vlad_create(int nvocab, const int32_t *ncent, int dl, const double *co
     v->exact = getenv("MMIDX_VLAD_EXACT") ? 1 : 0;
     for (int i = 0; i < nvocab; i++) {  // (a vocabulary the assignment kernels cannot take leaves its slot empty: k_vlad serves it)
         mmidx_index *a = nullptr;
-        if (ncent[i] >= 2 && mmidx_create(MMIDX_KIND_IVFPQ, dl, 1, 2, ncent[i], MMIDX_TR_NONE, nullptr, nullptr, device, &a) == MMIDX_OK &&
-            mmidx_set_coarse(a, codebooks + v->cb_off[(size_t)i]) != MMIDX_OK) {
-            mmidx_destroy(a);
-            a = nullptr;
+        if (ncent[i] >= 2) {
+            int rca = mmidx_create(MMIDX_KIND_IVFPQ, dl, 1, 2, ncent[i], MMIDX_TR_NONE, nullptr, nullptr, device, &a);
+            if (rca == MMIDX_OK) rca = mmidx_set_coarse(a, codebooks + v->cb_off[(size_t)i]);
+            if (rca != MMIDX_OK) {  // the slot falls back to k_vlad: not an error of this call, so no stale message either
+                if (a) mmidx_destroy(a);
+                a = nullptr;
+                g_err.clear();
+            }
         }
         v->asg.push_back(a);
     }

@@ -227,7 +227,7 @@ __global__ void k_flat_pairs(long long nq, int nch, long long chunk, long long n
 // single block; also zeroes the hand-back counter of this step
 __global__ __launch_bounds__(1024) void k_group_build(const int32_t *__restrict__ cnt, const int32_t *__restrict__ start, int C, int G,
                                                       int4 *__restrict__ gdesc, int32_t *__restrict__ n_groups, u32 *__restrict__ fb_count,
-                                                      unsigned long long *__restrict__ nver, int32_t *host_hint_ver, int2 *__restrict__ lgrp = nullptr) {
+                                                      unsigned long long *__restrict__ nver, int32_t *host_hint_ver) {
     __shared__ u32 s_wave[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0 && nver) {  // what the previous launch of k_scan_grp verified, for the host's choice of instance
@@ -264,7 +264,6 @@ __global__ __launch_bounds__(1024) void k_group_build(const int32_t *__restrict_
     u32 run = base + incl - sum;
     for (int c = lo; c < hi; c++) {
         const int n = cnt[c], st = start[c];
-        if (lgrp) lgrp[c] = make_int2((int)run, (n + G - 1) / G);  // (K3mc walks a list's groups)
         for (int o = 0; o < n; o += G) gdesc[run++] = make_int4(c, st + o, (n - o < G) ? n - o : G, 0);
     }
     if (tid == 1023) *n_groups = (int32_t)(base + incl);

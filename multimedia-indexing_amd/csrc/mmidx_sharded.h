@@ -273,6 +273,7 @@ struct ShardGroup {
     std::vector<hipStream_t> st2;   // the query exchange's streams
     std::vector<ncclComm_t> comm2;  // ... and communicators (null: in-process collectives)
     int pipeline = 1;               // option "shard_pipeline": 1 = query exchange on the second stream (overlapped), 0 = everything on one stream
+                                    // (default 1 for in-process shards, 0 for two or more physical devices: mmidx_create_sharded)
     bool rccl = false;       // collectives through RCCL (devices pairwise distinct); else in-process (virtual shards)
     bool peer_ok = true;     // every shard can store into every other shard's memory
     int exchange = 0;        // option "shard_exchange": 0 = pass B stores into the owners' buffers, 1 = ncclSend / ncclRecv of dense lists
@@ -1310,6 +1311,11 @@ int mmidx_create_sharded(int kind, int D, int m, int ks, int C, int transform, c
         nr = R->CommInitAll(g->comm2.data(), n_dev, devs);
         if (nr != ncclSuccess) return bail(fail(MMIDX_ERR_HIP, "ncclCommInitAll (second set) over %d devices failed: %s", n_dev, R->GetErrorString(nr)));
         g->rccl = true;
+        // Two communicators used concurrently per device can deadlock when the devices schedule the two collective kernels in different
+        // orders, and this form has never run on more than one physical GPU: on a real multi-device handle everything goes through the
+        // main stream / communicator until such a run has passed ("shard_pipeline" = 1 turns the overlap back on; in-process shards and
+        // the one-rank communicator keep it).
+        if (n_dev > 1) g->pipeline = 0;
     } else if (!g->peer_ok) {
         return bail(fail(MMIDX_ERR_UNSUPPORTED, "shards on repeated devices use in-process collectives, which need peer access between all of them"));
     }
