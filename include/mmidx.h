@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MMIDX_ABI_VERSION 6
+#define MMIDX_ABI_VERSION 7
 
 typedef struct mmidx_index mmidx_index; /* opaque handle: one index on one GPU */
 
@@ -316,6 +316,12 @@ typedef struct mmidx_stats {
     double mfma_scan_ms, mfma_verify_ms;
     int32_t mfma_launches;
     int32_t reserved0;
+    /* K3ma, pass A on the matrix cores (csrc/mmidx_scan_mfma_a.h; ABI version 7): calls whose pass A went through it, and with full
+     * profiling the durations of its four stages (HIP events): sweep 1 (k_scan_mfma<.., 1>), threshold selection (k_a1_select),
+     * sweep 2 (k_scan_mfma<.., 2>) and the exact verification (k_a1_verify), summed over those calls.  Its verified codes count in
+     * verified_codes / mfma_survivors, the queries it handed to the exact kernels in mfma_redo_queries. */
+    int64_t passa_mfma_launches;
+    double passa_mfma_sweep1_ms, passa_mfma_select_ms, passa_mfma_sweep2_ms, passa_mfma_verify_ms;
 } mmidx_stats;
 /* enabled: 0 off; 1 full (six events per search call and the code counters: every field below); 2 light (only the two
  * events around pass A: passa_ms / passa_launches -- an event record is a ~5 us bubble in the stream, so a throughput
@@ -342,7 +348,8 @@ int mmidx_set_profiling(mmidx_index *h, int enabled);
  * "mfma_kc_tpw" (8 / 16 code tiles per wave of k_scan_mfma_kc), "lut_pre" (pass A's tables built by their own kernel),
  * "coarse_wave_sel" (0: the coarse stage's exact selection always by a block per query instead of k_coarse_front_sel),
  * "passb_small" (0: pass B through K3m / K3g also when the call before kept at most 64 pairs; default 1: K3f's looping kernel alone,
- * one launch),
+ * one launch), "passa_mfma" (round 5, K3ma: pass A through the matrix-core bound in two sweeps -- 1 wherever the shape allows, 0 never,
+ * -1 = default: from 8 queries per list of a long-list index),
  * "shard_pipeline" (1: the query exchange of a sharded handle on a second stream / communicator; the default for in-process shards, off
  * by default on two or more physical devices until a multi-device run has passed).  None of them changes a result. */
 int mmidx_set_option(mmidx_index *h, const char *name, int value);

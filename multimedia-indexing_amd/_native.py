@@ -39,7 +39,9 @@ class Stats(C.Structure):
                 ("tie_fallbacks", C.c_int32), ("passa_ms", C.c_double), ("passa_codes", C.c_int64),
                 ("passa_launches", C.c_int32), ("passb_items_last", C.c_int32), ("verified_codes", C.c_int64),
                 ("mfma_survivors", C.c_int64), ("mfma_redo_queries", C.c_int64),
-                ("mfma_scan_ms", C.c_double), ("mfma_verify_ms", C.c_double), ("mfma_launches", C.c_int32), ("reserved0", C.c_int32)]
+                ("mfma_scan_ms", C.c_double), ("mfma_verify_ms", C.c_double), ("mfma_launches", C.c_int32), ("reserved0", C.c_int32),
+                ("passa_mfma_launches", C.c_int64), ("passa_mfma_sweep1_ms", C.c_double), ("passa_mfma_select_ms", C.c_double),
+                ("passa_mfma_sweep2_ms", C.c_double), ("passa_mfma_verify_ms", C.c_double)]
 
 
 def build(force=False):

@@ -15,6 +15,7 @@
 #include "mmidx_scan_grp.h"
 #include "mmidx_scan_mfma.h"
 #include "mmidx_scan_mfma_kc.h"
+#include "mmidx_scan_mfma_a.h"
 #include "mmidx_frontend.h"
 
 #include <algorithm>
@@ -327,6 +328,14 @@ struct mmidx_index {
     size_t ev_used = 0;
     std::vector<hipEvent_t> mf_ev;   // K3m, full profiling: groups of 3 (scan start, scan end, verification end)
     size_t mf_ev_used = 0;
+    // K3ma (pass A on the matrix cores, mmidx_scan_mfma_a.h)
+    int passa_mfma = -1;               // option "passa_mfma": 1 always (where the shape allows), 0 never, -1 = from 8 queries per list of a long-list index
+    DevBuf<float> ws_acand;            // [pairs][pieces][256] sweep 1's kept accumulator values
+    DevBuf<double2> ws_arowc;          // [pairs] upper-bound maps
+    DevBuf<unsigned char> ws_abm;      // [items][stride] sweep 2's compare masks
+    std::vector<hipEvent_t> a_ev;      // full profiling: groups of 5 (sweep 1 start / end, selection end, sweep 2 end, verification end)
+    size_t a_ev_used = 0;
+    long long a_launches = 0;
     u64 *d_counters = nullptr;       // [0] scan codes, [1] tie fallbacks, [2] codes of the probe-rank-0 lists (pass A), [3] verified codes (K3g); [4] add-validation flag
     int64_t host_codes = 0;          // PQ: nq * n, known on the host
     int32_t launches = 0;
@@ -1008,6 +1017,243 @@ int launch_grp_t(mmidx_index *h, const GrpParams &GP, size_t lds, hipStream_t st
     hipLaunchKernelGGL((k_scan_grp<M, G, DSUB, FLAT, UNION>), dim3((unsigned)blocks), dim3(GRP_NT), lds, st, GP);
     HIPCK(hipGetLastError());
     return MMIDX_OK;
+}
+
+// ---- K3ma (mmidx_scan_mfma_a.h): pass A through the matrix-core bound ---------------------------------------------------------
+template <int NJ, int DSUB, int MODE>
+int launch_mfma_a_scan_t(mmidx_index *h, const MfmaParams &MP, size_t lds, hipStream_t st) {
+    HIPCK(hipFuncSetAttribute((const void *)k_scan_mfma<NJ, DSUB, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int blocks = h->mfma_blocks;
+    if (blocks <= 0) {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_scan_mfma<NJ, DSUB, MODE>, MF_NT, lds) != hipSuccess || occ < 1) {
+            (void)hipGetLastError();
+            occ = 1;
+        }
+        blocks = occ * std::max(h->num_cus, 8);
+    }
+    blocks = std::max(8, (blocks + 7) & ~7);
+    hipLaunchKernelGGL((k_scan_mfma<NJ, DSUB, MODE>), dim3((unsigned)blocks), dim3(MF_NT), lds, st, MP);
+    HIPCK(hipGetLastError());
+    return MMIDX_OK;
+}
+template <int MODE>
+int launch_mfma_a_scan(mmidx_index *h, const MfmaParams &MP, size_t lds, hipStream_t st) {
+    const int nj = h->D / 32;
+    if (h->dsub == 4) return nj == 4 ? launch_mfma_a_scan_t<4, 4, MODE>(h, MP, lds, st) : nj == 2 ? launch_mfma_a_scan_t<2, 4, MODE>(h, MP, lds, st) : launch_mfma_a_scan_t<1, 4, MODE>(h, MP, lds, st);
+    if (h->dsub == 8) return nj == 4 ? launch_mfma_a_scan_t<4, 8, MODE>(h, MP, lds, st) : nj == 2 ? launch_mfma_a_scan_t<2, 8, MODE>(h, MP, lds, st) : launch_mfma_a_scan_t<1, 8, MODE>(h, MP, lds, st);
+    return nj == 4 ? launch_mfma_a_scan_t<4, 16, MODE>(h, MP, lds, st) : nj == 2 ? launch_mfma_a_scan_t<2, 16, MODE>(h, MP, lds, st) : launch_mfma_a_scan_t<1, 16, MODE>(h, MP, lds, st);
+}
+template <int M, int DSUB>
+int launch_a1_verify_t(mmidx_index *h, const MfmaParams &MP, hipStream_t st) {
+    const A1VLds L(DSUB);
+    HIPCK(hipFuncSetAttribute((const void *)k_a1_verify<M, DSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total));
+    const unsigned grid = (unsigned)(16 * std::max(h->num_cus, 8));
+    hipLaunchKernelGGL((k_a1_verify<M, DSUB>), dim3(grid), dim3(A1V_NT), L.total, st, MP);
+    HIPCK(hipGetLastError());
+    return MMIDX_OK;
+}
+
+// does pass A of this call go through K3ma?  (all the applicability checks: launch_passa_mfma itself must not fall back after its first launch)
+bool passa_mfma_applies(const mmidx_index *h, const ScanParams &P, const SearchPlan &pl, long long nq) {
+    if (h->passa_mfma == 0 || !P.ivf || h->no_mfma || !h->mfma_ok || !h->xn_valid || h->no_filter || P.sdc_tt || nq <= 0 || h->D > 128) return false;
+    if (pl.K1 > 128) return false;                                             // (a pair keeps 256 values per piece: K1 of them must be there)
+    if (h->max_list_len >= (1ll << 24) || nq * (long long)P.w >= 0x7fffff00ll || ((uintptr_t)P.Q & 15) != 0) return false;
+    if (h->d_perm && !h->d_coarseP) return false;
+    if (h->transform == MMIDX_TR_ROTATION && (!h->d_rot || (size_t)nq * h->D * 8 > ((size_t)8 << 30))) return false;
+    if (h->passa_mfma > 0) return true;
+    // from ~8 queries per nearest list, on an index of long lists (where K3h would run): a shard holding a part of the
+    // lists sees the same number of queries per LOCAL list
+    return nq >= 8ll * h->C && h->n_csr / std::max<int64_t>(1, h->nonempty_lists) >= 4096;
+}
+
+// Pass A of the whole sub-batch through K3ma; the thresholds land in P.T and the exact candidates in the pools as K3h leaves them.
+// Uses ws_pcount (zeroed by k_step_init; the caller zeroes it again for pass B), ws_pstart / ws_pcursor / ws_order / ws_gdesc / ws_gfb.
+int launch_passa_mfma(mmidx_index *h, const ScanParams &P, const SearchPlan &pl, long long nq, hipStream_t st) {
+    constexpr int G = MF_QG;
+    const int C = h->C;
+    const long long npairs = nq;  // (at most: the queries whose nearest list is non-empty here)
+    const size_t nfb = (size_t)npairs * (size_t)std::max(pl.nchunks, 1);
+    HIPCK(h->ws_pcount.reserve((size_t)C + 1));
+    HIPCK(h->ws_pstart.reserve((size_t)C + 1));
+    HIPCK(h->ws_pcursor.reserve((size_t)C));
+    HIPCK(h->ws_order.reserve((size_t)nq * (size_t)P.w));  // (pass B's size: its reserve later must not reallocate under these launches)
+    HIPCK(h->ws_gdesc.reserve((size_t)npairs / G + (size_t)C + 8));
+    HIPCK(h->ws_gfb.reserve(4 + 2 * nfb + 16));
+    // items: (group, piece); at most eight pieces per list (k_a1_select holds a pair's values in registers)
+    const long long maxlen = std::max<long long>(h->max_list_len, 1);
+    int sub = h->mfma_sub;
+    if (sub <= 0) {
+        const long long est_groups = npairs / G + std::min<long long>(npairs, std::max<int64_t>(1, h->nonempty_lists));
+        const long long want = 4ll * 2 * std::max(h->num_cus, 8);
+        long long pieces = std::max<long long>(1, std::min<long long>(8, (want + est_groups - 1) / est_groups));
+        long long sb = (maxlen + pieces - 1) / pieces;
+        sb = std::max<long long>(1024, sb);
+        sub = (int)((sb + 63) & ~63ll);
+    }
+    sub = (std::max(sub, 64) + 31) & ~31;
+    if ((maxlen + sub - 1) / sub > 8) sub = (int)((((maxlen + 7) / 8) + 31) & ~31ll);
+    const int nsub = (int)((maxlen + sub - 1) / sub);
+    const size_t max_groups = (size_t)npairs / G + (size_t)std::min<long long>(npairs, C) + 1;
+    const size_t bm_stride = (size_t)((sub + 31) / 32) * 256;
+    if (max_groups * (size_t)nsub * bm_stride > ((size_t)32 << 30)) return 1;
+    HIPCK(h->ws_T0.reserve((size_t)nq));
+    HIPCK(h->ws_redo.reserve((size_t)nq));
+    HIPCK(h->ws_psnap.reserve((size_t)nq));
+    HIPCK(h->ws_mfctl.reserve(64));
+    HIPCK(h->ws_acand.reserve((size_t)npairs * nsub * 256));
+    HIPCK(h->ws_arowc.reserve((size_t)npairs));
+    HIPCK(h->ws_abm.reserve(max_groups * (size_t)nsub * bm_stride));
+    if (h->d_perm) HIPCK(h->ws_Qp.reserve((size_t)nq * h->D));
+    if (h->transform == MMIDX_TR_ROTATION) HIPCK(h->ws_R.reserve((size_t)npairs * h->D));
+    // ---- the (query, probe 0) pairs by cell, groups of <= 64 ----
+    const unsigned gq = (unsigned)((nq + 255) / 256);
+    hipLaunchKernelGGL(k_a1_pair_count, dim3(gq), dim3(256), 0, st, P.cells, P.w, (long long)nq, P.list_off, h->ws_pcount.p, C);
+    hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, C, h->ws_pstart.p, h->ws_pcursor.p, (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_a1_pair_scatter, dim3(gq), dim3(256), 0, st, P.cells, P.w, (long long)nq, P.list_off, h->ws_pstart.p, h->ws_pcursor.p, h->ws_order.p);
+    hipLaunchKernelGGL(k_group_build, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, h->ws_pstart.p, C, G, h->ws_gdesc.p, h->ws_gfb.p, (u32 *)(h->ws_gfb.p + 1),
+                       (unsigned long long *)nullptr, (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_mfma_prep, dim3((unsigned)std::min<long long>(4096, (nq + 255) / 256)), dim3(256), 0, st, (const int32_t *)h->ws_gfb.p, (u32 *)nullptr,
+                       h->ws_redo.p, h->ws_mfctl.p, P.T, h->ws_T0.p, P.pool_cnt, h->ws_psnap.p, (long long)nq);
+    HIPCK(hipGetLastError());
+    DBG_SYNC("K3ma pair sort");
+    MfmaParams MP{};
+    MP.S = P;
+    MP.S.order = h->ws_order.p;
+    MP.S.n_order = h->ws_pstart.p + C;
+    if (h->d_perm) {
+        const long long tot = (long long)nq * h->D;
+        hipLaunchKernelGGL(k_permute_cols, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, P.Q, h->d_perm, h->ws_Qp.p, h->D, (long long)nq);
+        MP.S.Q = h->ws_Qp.p;
+        MP.S.coarse = h->d_coarseP;
+    }
+    MP.S.perm = nullptr;
+    MP.R = nullptr;
+    if (h->transform == MMIDX_TR_ROTATION) {
+        hipLaunchKernelGGL(k_pair_rotate, dim3((unsigned)((npairs + 7) / 8)), dim3(128), 8 * (size_t)h->D * sizeof(double), st, P.Q, P.coarse, h->d_rot, P.cells,
+                           MP.S.order, MP.S.n_order, (long long)npairs, P.w, h->D, 1, h->ws_R.p);
+        HIPCK(hipGetLastError());
+        MP.R = h->ws_R.p;
+    }
+    MP.pq16 = h->d_pq16;
+    MP.xn = h->xn.p;
+    MP.pq = h->d_pq;
+    MP.flat_lut = nullptr;
+    MP.gdesc = h->ws_gdesc.p;
+    MP.n_groups = h->ws_gfb.p;
+    MP.sub = sub;
+    MP.nsub = nsub;
+    MP.ep = h->pq_ep;
+    MP.xmax = h->rmax;
+    MP.ghist = nullptr;
+    MP.T0 = h->ws_T0.p;
+    MP.surv = nullptr;
+    MP.surv_cnt = h->ws_mfctl.p;
+    MP.surv_cap = 0;
+    MP.redo = h->ws_redo.p;
+    MP.pool_snap = h->ws_psnap.p;
+    MP.work = h->ws_mfctl.p + 8;
+    MP.a_work = h->ws_mfctl.p + 24;
+    MP.fb_count = (u32 *)(h->ws_gfb.p + 1);
+    MP.fb_items = h->ws_gfb.p + 4;
+    MP.fb_ch = h->ws_gfb.p + 4 + nfb;
+    MP.fb_chunk = pl.chunk;
+    MP.fb_nchunks = std::max(pl.nchunks, 1);
+    MP.npairs_flat = npairs;
+    MP.stat = (h->profiling == 1 || h->debug_sync) ? (unsigned long long *)(h->d_counters + 3) : nullptr;
+    MP.nver = (unsigned long long *)(h->d_counters + 7);
+    MP.a_cand = h->ws_acand.p;
+    MP.a_rowc = h->ws_arowc.p;
+    MP.a_bm = h->ws_abm.p;
+    MP.a_bm_stride = bm_stride;
+    const MfmaLds L(h->D);
+    hipEvent_t *aev = nullptr;
+    if (h->profiling == 1 && h->a_ev_used + 5 <= 5 * 4096) {
+        while (h->a_ev.size() < h->a_ev_used + 5) {
+            hipEvent_t e;
+            HIPCK(hipEventCreate(&e));
+            h->a_ev.push_back(e);
+        }
+        aev = h->a_ev.data() + h->a_ev_used;
+        h->a_ev_used += 5;
+        HIPCK(hipEventRecord(aev[0], st));
+    }
+    int rc = launch_mfma_a_scan<1>(h, MP, L.total, st);  // sweep 1: the slots' best four per pair
+    if (rc) return rc;
+    if (aev) HIPCK(hipEventRecord(aev[1], st));
+    DBG_SYNC("K3ma sweep 1");
+    {
+        const unsigned gs = (unsigned)((npairs + 3) / 4);
+        if (nsub <= 1) hipLaunchKernelGGL(k_a1_select<1>, dim3(gs), dim3(256), 0, st, MP);
+        else if (nsub <= 2) hipLaunchKernelGGL(k_a1_select<2>, dim3(gs), dim3(256), 0, st, MP);
+        else if (nsub <= 4) hipLaunchKernelGGL(k_a1_select<4>, dim3(gs), dim3(256), 0, st, MP);
+        else hipLaunchKernelGGL(k_a1_select<8>, dim3(gs), dim3(256), 0, st, MP);
+        HIPCK(hipGetLastError());
+    }
+    if (aev) HIPCK(hipEventRecord(aev[2], st));
+    DBG_SYNC("K3ma select");
+    if (h->debug_sync) HIPCK(hipMemsetAsync(h->ws_abm.p, 0, max_groups * (size_t)nsub * bm_stride, st));  // (the debug report below counts bits)
+    rc = launch_mfma_a_scan<2>(h, MP, L.total, st);  // sweep 2: compare masks
+    if (rc) return rc;
+    if (aev) HIPCK(hipEventRecord(aev[3], st));
+    DBG_SYNC("K3ma sweep 2");
+    if (h->dsub == 4) rc = h->m == 32 ? launch_a1_verify_t<32, 4>(h, MP, st) : h->m == 16 ? launch_a1_verify_t<16, 4>(h, MP, st) : launch_a1_verify_t<8, 4>(h, MP, st);
+    else if (h->dsub == 8) rc = h->m == 16 ? launch_a1_verify_t<16, 8>(h, MP, st) : h->m == 8 ? launch_a1_verify_t<8, 8>(h, MP, st) : launch_a1_verify_t<4, 8>(h, MP, st);
+    else rc = h->m == 8 ? launch_a1_verify_t<8, 16>(h, MP, st) : h->m == 4 ? launch_a1_verify_t<4, 16>(h, MP, st) : launch_a1_verify_t<2, 16>(h, MP, st);
+    if (rc) return rc;
+    if (aev) HIPCK(hipEventRecord(aev[4], st));
+    DBG_SYNC("K3ma verify");
+    h->a_launches++;
+    const long long span = std::max<long long>(npairs, nq);
+    hipLaunchKernelGGL(k_mfma_redo, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, st, MP, (long long)nq);
+    HIPCK(hipGetLastError());
+    DBG_SYNC("K3ma redo");
+    if (h->debug_sync) {
+        int32_t g2[2], np1 = 0;
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(g2, h->ws_gfb.p, sizeof(g2), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&np1, h->ws_pstart.p + C, 4, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[mmidx] K3ma: %d pairs in %d groups of <= %d x %d pieces of %d codes, %d (pair, chunk) items handed to K3f (bitmap stride %zu)\n", np1, g2[0], G, nsub, sub,
+                g2[1], bm_stride);
+        {
+            std::vector<unsigned char> hb(max_groups * (size_t)nsub * bm_stride);
+            std::vector<u32> pc((size_t)nq);
+            (void)hipMemcpy(hb.data(), h->ws_abm.p, hb.size(), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(pc.data(), P.pool_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost);
+            unsigned long long bits = 0, pool = 0;
+            for (unsigned char c : hb) bits += (unsigned)__builtin_popcount(c);
+            for (u32 c : pc) pool += c;
+            u64 cnt[1] = {0};
+            (void)hipMemcpy(cnt, h->d_counters + 3, 8, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[mmidx] K3ma: %llu bits set by sweep 2, %llu records verified so far (counter), %llu pool entries\n", bits, (unsigned long long)cnt[0], pool);
+            if (const char *dump = getenv("MMIDX_K3MA_DUMP")) {  // (debugging aid: groups, order, thresholds and the bitmap to a file)
+                FILE *f = fopen(dump, "wb");
+                if (f) {
+                    std::vector<int32_t> ord((size_t)std::max(np1, 1));
+                    std::vector<int4> gd((size_t)std::max(g2[0], 1));
+                    std::vector<u64> tt((size_t)nq);
+                    (void)hipMemcpy(ord.data(), h->ws_order.p, (size_t)np1 * 4, hipMemcpyDeviceToHost);
+                    (void)hipMemcpy(gd.data(), h->ws_gdesc.p, (size_t)g2[0] * 16, hipMemcpyDeviceToHost);
+                    (void)hipMemcpy(tt.data(), P.T, (size_t)nq * 8, hipMemcpyDeviceToHost);
+                    const long long hdr[8] = {np1, g2[0], nsub, sub, (long long)bm_stride, nq, P.w, 0};
+                    fwrite(hdr, 8, 8, f);
+                    fwrite(ord.data(), 4, (size_t)np1, f);
+                    fwrite(gd.data(), 16, (size_t)g2[0], f);
+                    fwrite(tt.data(), 8, (size_t)nq, f);
+                    fwrite(hb.data(), 1, (size_t)g2[0] * nsub * bm_stride, f);
+                    fclose(f);
+                }
+            }
+        }
+    }
+    // the queries handed back (device-side count; normally the few whose list is shorter than K1): K3f's looping kernel, from T = +inf
+    ScanParams F = P;
+    F.order = MP.fb_items;
+    F.n_order = (const int32_t *)MP.fb_count;
+    F.order_ch = MP.fb_ch;
+    F.n_items = (int)std::min<size_t>(nfb, (size_t)0x7fffff00);
+    F.xcd_remap = 0;
+    return launch_scan_filtered(h, F, pl, dim3((unsigned)F.n_items, 1), st, -1);
 }
 
 // pass B over the sorted pairs (P.order / P.n_order as for K3f; per-cell counts and starts in ws_pcount / ws_pstart).
@@ -1842,7 +2088,11 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
         //  measured faster: 1.23 vs ~1.4 ms per 8192 queries; MMIDX_PASSA_FILTER=1 switches)
         int rc = MMIDX_OK;
         if (phase != 2) {
-            if (h->passa_filter) {
+            if (two_pass && passa_mfma_applies(h, P, pl, (long long)nq)) {
+                // K3ma: >= 8 queries per nearest list -- the list-major matrix-core form (mmidx_scan_mfma_a.h)
+                rc = launch_passa_mfma(h, P, pl, (long long)nq, st);
+                pcount_zeroed = false;  // (its pair sort counted in ws_pcount)
+            } else if (h->passa_filter) {
                 rc = launch_scan_filtered(h, P, pl, dim3((unsigned)P.n_items, (unsigned)grid_chunks), st);
             } else if (!h->no_seed) {
                 rc = launch_scan_seeded(h, P, pl, dim3((unsigned)P.n_items, (unsigned)grid_chunks), st);
@@ -2469,6 +2719,11 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_defer.release();
     h->ws_nrow.release();
     h->ws_lutpre.release();
+    h->ws_acand.release();
+    h->ws_arowc.release();
+    h->ws_abm.release();
+    for (hipEvent_t e : h->a_ev) (void)hipEventDestroy(e);
+    h->a_ev.clear();
     h->ws_mfctl.release();
     h->ws_psnap.release();
     h->ws_redo.release();
@@ -3242,6 +3497,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->smin_pre = value < 0 ? -1 : (value != 0);
     } else if (n == "no_union") {  // K3g without the per-query histogram that lowers thresholds from the union over lists
         h->no_union = value < 0 ? -1 : (value != 0);
+    } else if (n == "passa_mfma") {  // K3ma: 1 always, 0 never, -1 by the batch (default)
+        h->passa_mfma = value;
     } else if (n == "no_mfma") {  // pass B through K3g / K3f instead of the matrix-core bound K3m
         h->no_mfma = value != 0;
     } else if (n == "mfma_sub") {
@@ -3280,6 +3537,8 @@ int mmidx_set_profiling(mmidx_index *h, int enabled) {
     h->stats = mmidx_stats{};
     h->ev_used = 0;
     h->mf_ev_used = 0;
+    h->a_ev_used = 0;
+    h->a_launches = 0;
     h->host_codes = 0;
     h->launches = 0;
     h->passa_launches = 0;
@@ -3336,6 +3595,21 @@ int mmidx_get_stats(mmidx_index *h, mmidx_stats *out) {
         s.mfma_launches += 1;
     }
     h->mf_ev_used = 0;
+    for (size_t g = 0; g + 5 <= h->a_ev_used; g += 5) {
+        float t1 = 0.f, t2 = 0.f, t3 = 0.f, t4 = 0.f;
+        HIPCK(hipEventSynchronize(h->a_ev[g + 4]));
+        HIPCK(hipEventElapsedTime(&t1, h->a_ev[g], h->a_ev[g + 1]));
+        HIPCK(hipEventElapsedTime(&t2, h->a_ev[g + 1], h->a_ev[g + 2]));
+        HIPCK(hipEventElapsedTime(&t3, h->a_ev[g + 2], h->a_ev[g + 3]));
+        HIPCK(hipEventElapsedTime(&t4, h->a_ev[g + 3], h->a_ev[g + 4]));
+        s.passa_mfma_sweep1_ms += t1;
+        s.passa_mfma_select_ms += t2;
+        s.passa_mfma_sweep2_ms += t3;
+        s.passa_mfma_verify_ms += t4;
+    }
+    h->a_ev_used = 0;
+    s.passa_mfma_launches = h->a_launches;
+    h->a_launches = 0;
     {
         u64 c2[2] = {0, 0};
         HIPCK(hipMemcpy(c2, h->d_counters + 12, sizeof(c2), hipMemcpyDeviceToHost));

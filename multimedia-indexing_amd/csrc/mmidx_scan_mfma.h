@@ -64,6 +64,12 @@ struct MfmaParams {
     long long npairs_flat;     // flat PQ: number of pairs in order[] (IVF: *S.n_order)
     unsigned long long *stat;  // null, or profiling counters: [0] += verified codes, [9] += survivors, [10] += queries handed back
     unsigned long long *nver;  // always: [0] += verified codes (host hint)
+    // K3ma (pass A on the matrix cores, MODE 1 of k_scan_mfma + k_a1_select + k_a1_verify; see the block comment above a1_scan_tiles)
+    float *a_cand;             // [pair slot][nsub][256] the (row, lane, wave) slots' largest accumulator values of the sweep (-inf: none)
+    double2 *a_rowc;           // [pair slot] {||r||^2 + err, -2 / s^2}: upper bound of a code's distance = x + y acc (NaN: the bound cannot serve the row)
+    unsigned char *a_bm;       // [item][a_bm_stride] sweep 2's compare masks: per tile pair and lane a u16 (<= 32 rows: 8 bits per tile) or u32
+    size_t a_bm_stride;        // bytes per item: ceil(sub / 32) * 256
+    u32 *a_work;               // [8] sweep 1's per-XCD item cursors (its own set: both sweeps are enqueued behind one k_mfma_prep)
 };
 
 #define MF_CHUNK 512    // survivor records a wave reserves at a time (one global atomic per chunk, not per tile)
@@ -183,8 +189,9 @@ __global__ void k_mfma_prep(const int32_t *__restrict__ n_groups, u32 *__restric
     if (i0 < 64) ctl[i0] = 0;  // [0] survivor count, [8..15] / [24..31] / [32..39] item cursors (K3mc: one set per stage), [40] [44..45] K3mk's scale words
     if (*n_groups == 0) return;
     const long long stride = (long long)gridDim.x * blockDim.x;
-    uint4 *h4 = (uint4 *)ghist;
-    for (long long i = i0; i < nq * 64; i += stride) h4[i] = make_uint4(0u, 0u, 0u, 0u);
+    uint4 *h4 = (uint4 *)ghist;  // (null: K3ma -- no threshold exists when its launch starts, so no bucket map either)
+    if (h4)
+        for (long long i = i0; i < nq * 64; i += stride) h4[i] = make_uint4(0u, 0u, 0u, 0u);
     for (long long i = i0; i < nq; i += stride) {
         redo[i] = 0;
         T0[i] = T[i];
@@ -397,7 +404,152 @@ __device__ __forceinline__ void mf_scan_tiles(const MfmaParams &P, const mf_h8 (
     if (bufn) mf_flush(P, ck, s_buf, bufn < MF_BUF ? bufn : MF_BUF, s_row, s_touch, first, lane);  // what is left at the end of the item
 }
 
-template <int NJ, int DSUB>
+// ---- K3ma: PASS A through the same bound (round 5) -------------------------------------------------------------------------
+// Pass A (the scan of every query's NEAREST list, IVFPQ.java:429-446 for probe 0) is what produces the thresholds everything above
+// compares against, so it cannot start from one.  With >= 8 queries per nearest list (a shard of the 8-GPU configuration, one GPU at
+// batches >= 65536) the list-major matrix-core form pays anyway, in two sweeps over the list and no bootstrap:
+//   MODE 1 (sweep 1): the accumulators acc = (r.x - ||x||^2 / 2) s^2 of every (query row, code); each (row, lane, wave) slot -- 64
+//     disjoint subsets of the list's codes per row -- keeps its FOUR largest in registers (one v_max + three v_med3 per accumulator,
+//     no compare against anything).  The item leaves rows x 256 values; k_a1_select takes the K1-th largest a* of a pair's values:
+//     K1 distinct codes have acc >= a*, hence d <= ||r||^2 + err - 2 a* / s^2 =: T, a valid threshold (rank ~ K1 + 3 of the list at
+//     K1 = 101: a slot holds more than four of the best 105 with probability 0.08);
+//   MODE 2 (sweep 2): the same accumulators against (||r||^2 - T - err) s^2 / 2; each lane packs its compares into a bit mask and
+//     the masks go to a dense bitmap of the item (one store per lane and two tiles): NO survivor path in the loop;
+//   k_a1_verify (mmidx_scan_mfma_a.h): a block per item turns the bitmap into (row, position) records and computes their exact
+//     distances sub-quantizer by sub-quantizer with the codebook slice in LDS -- the reference's operations in its order.
+// Two tiles of a step are neighbours (tiles 2 p, 2 p + 1 of the wave's pair p): their masks share a store.
+template <int NJ, int DSUB, int NTL, int MODE>
+__device__ __forceinline__ void a_scan_tiles(const mf_h8 (&A)[4][NJ], const float (&thr)[4][4], const unsigned char *codes, const float *xn, const long long c0,
+                                             const long long c1, const float kinit, const u32 lds_cb, float (&top)[NTL * 4][4], unsigned char *bm, const int lane,
+                                             const int wv) {
+    constexpr int D = NJ * 32, M = D / DSUB;
+    constexpr int NB = (NJ * 8 >= DSUB) ? NJ * 8 / DSUB : 1;  // code bytes per lane
+    const int n = lane & 15, g = lane >> 4;
+    const u32 boff = (u32)((NJ * g * 8) / DSUB);
+    const u32 lane_base = lds_cb + (u32)(NJ * g) * 4096u;
+    const int ntiles = (int)((c1 - c0 + 15) >> 4);
+    const int npt = (ntiles + 1) >> 1;  // tile pairs
+    const unsigned char *cbase = codes + (size_t)c0 * M + boff;
+    const float *xbase = xn + c0;
+    const u32 last = (u32)(c1 - c0 - 1);
+    typedef typename std::conditional<NB == 8, u64, u32>::type CW;
+    // (a position past the item's last code: the load runs on the last code, the start value is -inf -- such a column never enters a
+    //  slot's best four and never passes a compare)
+    auto load_tile = [&](int t, CW &cw, float &xv) {
+        const u32 p0 = (u32)t * 16u + (u32)n;
+        const u32 p = p0 < last ? p0 : last;
+        const unsigned char *cp = cbase + p * (u32)M;
+        if constexpr (NB == 8) cw = *(const u64 *)cp;
+        else if constexpr (NB == 4) cw = *(const u32 *)cp;
+        else if constexpr (NB == 2) cw = (u32) * (const unsigned short *)cp;
+        else cw = (u32)*cp;
+        const float x = xbase[p];
+        xv = p0 <= last ? x : __int_as_float(0x7F800000);  // (kinit < 0: the start value x kinit is -inf)
+    };
+    CW cw[4];
+    float xv[4];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        load_tile(2 * (wv + 4 * u), cw[2 * u], xv[2 * u]);
+        load_tile(2 * (wv + 4 * u) + 1, cw[2 * u + 1], xv[2 * u + 1]);
+    }
+    for (int pp = wv; pp < npt; pp += 8) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int pr = pp + 4 * u;
+            const CW c[2] = {cw[2 * u], cw[2 * u + 1]};
+            const float x[2] = {xv[2 * u], xv[2 * u + 1]};
+            load_tile(2 * (pr + 8), cw[2 * u], xv[2 * u]);
+            load_tile(2 * (pr + 8) + 1, cw[2 * u + 1], xv[2 * u + 1]);
+            if (pr >= npt) continue;  // (wave-uniform)
+            // the B fragments of tile h: the decode gathers (as mf_scan_tiles)
+            auto gather = [&](const CW ch, mf_h8 (&Bh)[NJ]) {
+#pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    if constexpr (DSUB == 4) {
+                        const u32 b0 = (u32)(ch >> (16 * j)) & 0xFFu, b1 = (u32)(ch >> (16 * j + 8)) & 0xFFu;
+                        typedef u64 __attribute__((address_space(3))) lds_u64;
+                        const u64 lo = *(const lds_u64 *)(size_t)(lane_base + (b0 << 4) + (u32)j * 4096u);
+                        const u64 hi = *(const lds_u64 *)(size_t)(lane_base + (b1 << 4) + 8u + (u32)j * 4096u);
+                        typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+                        const u64x2 both = {lo, hi};
+                        Bh[j] = __builtin_bit_cast(mf_h8, both);
+                    } else {
+                        const u32 byte = (u32)(ch >> (8 * (j / (DSUB >= 8 ? DSUB / 8 : 1)))) & 0xFFu;
+                        const u32 addr = lane_base + (byte << 4);
+                        Bh[j] = *(const __attribute__((address_space(3))) mf_h8 *)(size_t)(addr + (u32)j * 4096u);
+                    }
+                }
+            };
+            auto matmul = [&](const mf_h8 (&Bh)[NJ], const float xh, mf_f4 (&ah)[NTL]) {
+                const float ci = xh * kinit;
+                const mf_f4 c4 = {ci, ci, ci, ci};
+#pragma unroll
+                for (int rt = 0; rt < NTL; rt++) ah[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[rt][0], Bh[0], c4, 0, 0, 0);
+#pragma unroll
+                for (int j = 1; j < NJ; j++)
+#pragma unroll
+                    for (int rt = 0; rt < NTL; rt++) ah[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[rt][j], Bh[j], ah[rt], 0, 0, 0);
+            };
+            // the slot's four largest, kept sorted: with m1 >= m2 >= m3 >= m4 the new second is the median of {m1, m2, a} and so on
+            // (all four from the OLD values: independent instructions)
+            auto insert = [&](const mf_f4 (&ah)[NTL]) {
+#pragma unroll
+                for (int b = 0; b < NTL * 4; b++) {
+                    const float a = ah[b >> 2][b & 3];
+                    const float m1 = top[b][0], m2 = top[b][1], m3 = top[b][2], m4 = top[b][3];
+                    top[b][0] = __builtin_fmaxf(m1, a);
+                    top[b][1] = __builtin_amdgcn_fmed3f(m1, m2, a);
+                    top[b][2] = __builtin_amdgcn_fmed3f(m2, m3, a);
+                    top[b][3] = __builtin_amdgcn_fmed3f(m3, m4, a);
+                }
+            };
+            if constexpr (MODE == 1 && NTL >= 3) {
+                // (48 / 64 registers of kept values next to the 64 of the queries: one tile at a time, or the loop spills)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    mf_h8 B1[NJ];
+                    mf_f4 a1[NTL];
+                    gather(c[h], B1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    matmul(B1, x[h], a1);
+                    insert(a1);
+                }
+                continue;
+            }
+            mf_h8 B[2][NJ];
+            gather(c[0], B[0]);
+            gather(c[1], B[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mf_f4 acc[2][NTL];
+            matmul(B[0], x[0], acc[0]);
+            matmul(B[1], x[1], acc[1]);
+            if constexpr (MODE == 1) {
+                insert(acc[0]);
+                insert(acc[1]);
+            } else {
+                u32 bits[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    // bit rt * 4 + i: the lane's code passes row rt * 16 + 4 g + i.  Plain C++ on purpose: mf_scan_tiles packs its masks with
+                    // inline v_cmp + v_addc behind a v_max3 pre-test; HERE the compares are the first readers of the accumulators, and the
+                    // compiler inserts the wait states between a matrix instruction and a read of its result only for instructions it
+                    // knows -- inline assembly read registers 2 and 3 of the 8-pass v_mfma_f32_16x16x32_f16 before they were written
+                    // (rows 4 g + 2 and 4 g + 3 lost a third of their survivors).
+                    u32 bt = 0;
+#pragma unroll
+                    for (int b = 0; b < NTL * 4; b++) bt |= acc[h][b >> 2][b & 3] >= thr[b >> 2][b & 3] ? (1u << b) : 0u;
+                    bits[h] = bt;
+                }
+                if constexpr (NTL <= 2) ((unsigned short *)bm)[(size_t)pr * 64 + lane] = (unsigned short)(bits[0] | (bits[1] << 8));
+                else ((u32 *)bm)[(size_t)pr * 64 + lane] = bits[0] | (bits[1] << 16);
+            }
+        }
+    }
+}
+
+// MODE 0: pass B (and flat PQ's far chunks) with survivor records; MODE 1 / 2: the two sweeps of K3ma (above)
+template <int NJ, int DSUB, int MODE = 0>
 __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
     constexpr int D = NJ * 32;
     constexpr int DPT = D / 8;  // dimensions per thread in the residual phase: a thread is (row of 32, eighth of the dimensions)
@@ -424,7 +576,7 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
 
     for (;;) {
         if (tid == 0) {
-            s_misc[0] = atomicAdd(P.work + xcd, 1u);
+            s_misc[0] = atomicAdd((MODE == 1 ? P.a_work : P.work) + xcd, 1u);
             s_misc[1] = 0;
             s_misc[2] = 0;
             s_misc[8] = s_misc[9] = s_misc[10] = s_misc[11] = 0;
@@ -520,6 +672,16 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
                 const int row = h * 32 + (tid >> 3);
                 const int q = qq[h];
                 const double nr = nrp[h], nrm = sqrt(nr) * (1.0 + 1e-12);
+                if constexpr (MODE == 1) {  // (sweep 1 of K3ma: the pair's upper-bound map for k_a1_select -- the same error term as below)
+                    const double err1 = nrm * xmax * (4.02 * 0x1p-11 + 2.004 * gam) + xmax * xmax * (1.001 * gam + 0x1p-24) +
+                                        2.02 * sqrtD * 0x1p-14 * (xmax * inv_sr + nrm * inv_sp) + 2.0 * D * 0x1p-28 * inv_s2 +
+                                        0x1p-19 * (nr + xmax * xmax + 2.0 * nrm * xmax) + 1e-300;
+                    if (row < np && isub == 0) {
+                        const bool ok = scale_ok && (err1 < 1e300) && (nr < 1e300);
+                        P.a_rowc[first + row] = ok ? make_double2(nr + err1, -2.0 * inv_s2) : make_double2(__longlong_as_double(0x7FF8000000000000ll), 0.0);
+                    }
+                    continue;
+                }
                 // |acc / s^2 - (r.x - ||x||^2 / 2)| <= |r| xmax (2.01 2^-11 + 1.002 gam) + xmax^2 (0.5005 gam + 2^-25)
                 //                                       + 1.01 sqrt(D) 2^-14 (xmax / s_r + |r| / s_p) + D 2^-28 / s^2 :
                 //   fp16 inputs (an element's error is at most 2^-11 of itself -- after the fp32 step 1.001 of that -- or, where the
@@ -607,21 +769,48 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
 #pragma unroll
         for (int rt = 0; rt < 4; rt++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) thr[rt][i] = s_row[rt * 16 + 4 * (lane >> 4) + i].thr;
+            for (int i = 0; i < 4; i++) thr[rt][i] = MODE == 1 ? 0.f : s_row[rt * 16 + 4 * (lane >> 4) + i].thr;
 
         // ---- (b) the scan: every wave its own code tiles against all row tiles ----
-        uint4 *s_buf = (uint4 *)(s_stage + (size_t)wv * (MF_BUF * 16));  // (the staging area is idle until the next item)
-        u32 *s_wcnt = s_misc + 8 + wv;
-        switch (ntl) {
-            case 1: mf_scan_tiles<NJ, DSUB, 1>(P, A, thr, codes, xn, c0, c1, kinit, kd, lds_cb, s_row, s_misc + 1, s_buf, s_wcnt, first, ck, lane, wv); break;
-            case 2: mf_scan_tiles<NJ, DSUB, 2>(P, A, thr, codes, xn, c0, c1, kinit, kd, lds_cb, s_row, s_misc + 1, s_buf, s_wcnt, first, ck, lane, wv); break;
-            case 3: mf_scan_tiles<NJ, DSUB, 3>(P, A, thr, codes, xn, c0, c1, kinit, kd, lds_cb, s_row, s_misc + 1, s_buf, s_wcnt, first, ck, lane, wv); break;
-            default: mf_scan_tiles<NJ, DSUB, 4>(P, A, thr, codes, xn, c0, c1, kinit, kd, lds_cb, s_row, s_misc + 1, s_buf, s_wcnt, first, ck, lane, wv); break;
+        if constexpr (MODE == 0) {
+            uint4 *s_buf = (uint4 *)(s_stage + (size_t)wv * (MF_BUF * 16));  // (the staging area is idle until the next item)
+            u32 *s_wcnt = s_misc + 8 + wv;
+            switch (ntl) {
+                case 1: mf_scan_tiles<NJ, DSUB, 1>(P, A, thr, codes, xn, c0, c1, kinit, kd, lds_cb, s_row, s_misc + 1, s_buf, s_wcnt, first, ck, lane, wv); break;
+                case 2: mf_scan_tiles<NJ, DSUB, 2>(P, A, thr, codes, xn, c0, c1, kinit, kd, lds_cb, s_row, s_misc + 1, s_buf, s_wcnt, first, ck, lane, wv); break;
+                case 3: mf_scan_tiles<NJ, DSUB, 3>(P, A, thr, codes, xn, c0, c1, kinit, kd, lds_cb, s_row, s_misc + 1, s_buf, s_wcnt, first, ck, lane, wv); break;
+                default: mf_scan_tiles<NJ, DSUB, 4>(P, A, thr, codes, xn, c0, c1, kinit, kd, lds_cb, s_row, s_misc + 1, s_buf, s_wcnt, first, ck, lane, wv); break;
+            }
+        } else {
+            // K3ma.  MODE 1: the slots' best four -> a_cand[pair slot][piece][wave * 64 + 4 n ..]; MODE 2: the item's bitmap (a_bm_stride bytes per item)
+            unsigned char *bm = MODE == 2 ? P.a_bm + (size_t)v * P.a_bm_stride : nullptr;
+            const float ninf = -__int_as_float(0x7F800000);
+            auto run = [&](auto ntl_c) {
+                constexpr int NTL = decltype(ntl_c)::value;
+                float top[NTL * 4][4];
+#pragma unroll
+                for (int b = 0; b < NTL * 4; b++) top[b][0] = top[b][1] = top[b][2] = top[b][3] = ninf;
+                a_scan_tiles<NJ, DSUB, NTL, MODE>(A, thr, codes, xn, c0, c1, kinit, lds_cb, top, bm, lane, wv);
+                if constexpr (MODE == 1) {
+#pragma unroll
+                    for (int b = 0; b < NTL * 4; b++) {
+                        const int row = (b >> 2) * 16 + 4 * (lane >> 4) + (b & 3);
+                        if (row < np)
+                            *(float4 *)(P.a_cand + ((size_t)(first + row) * P.nsub + isub) * 256 + wv * 64 + (lane & 15) * 4) = make_float4(top[b][0], top[b][1], top[b][2], top[b][3]);
+                    }
+                }
+            };
+            switch (ntl) {
+                case 1: run(std::integral_constant<int, 1>{}); break;
+                case 2: run(std::integral_constant<int, 2>{}); break;
+                case 3: run(std::integral_constant<int, 3>{}); break;
+                default: run(std::integral_constant<int, 4>{}); break;
+            }
         }
         __syncthreads();
         // ---- (c) thresholds from the union of the survivors' upper bounds: K1 of them at or below a bucket's upper edge make
         //      that edge a valid threshold (K1 offers lie at or below it) for every later item of the query ----
-        {
+        if constexpr (MODE == 0) {
             const u64 tall = ((u64)s_misc[2] << 32) | (u64)s_misc[1];
             for (int qs = wv; qs < MF_QG; qs += MF_NT / 64) {
                 if (!((tall >> qs) & 1ull)) continue;  // (wave-uniform)
@@ -650,8 +839,9 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
         __syncthreads();  // LDS is reused by the next item
     }
     // the rest of the wave's last chunk: invalid records (k_mfma_verify skips them)
-    for (u32 i = ck.used + (u32)lane; i < ck.cap; i += 64)
-        if (ck.base + i < P.surv_cap) P.surv[ck.base + i] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+    if constexpr (MODE == 0)
+        for (u32 i = ck.used + (u32)lane; i < ck.cap; i += 64)
+            if (ck.base + i < P.surv_cap) P.surv[ck.base + i] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
 }
 
 // ---- exact distances of the survivors -------------------------------------------------------------------------------------

@@ -1148,6 +1148,11 @@ int sharded_get_stats(mmidx_index *h, mmidx_stats *out) {
         acc.mfma_scan_ms += s.mfma_scan_ms;
         acc.mfma_verify_ms += s.mfma_verify_ms;
         acc.mfma_launches += s.mfma_launches;
+        acc.passa_mfma_launches = std::max(acc.passa_mfma_launches, s.passa_mfma_launches);
+        acc.passa_mfma_sweep1_ms = std::max(acc.passa_mfma_sweep1_ms, s.passa_mfma_sweep1_ms);
+        acc.passa_mfma_select_ms = std::max(acc.passa_mfma_select_ms, s.passa_mfma_select_ms);
+        acc.passa_mfma_sweep2_ms = std::max(acc.passa_mfma_sweep2_ms, s.passa_mfma_sweep2_ms);
+        acc.passa_mfma_verify_ms = std::max(acc.passa_mfma_verify_ms, s.passa_mfma_verify_ms);
         acc.scan_launches = std::max(acc.scan_launches, s.scan_launches);
         acc.passa_launches = std::max(acc.passa_launches, s.passa_launches);
         acc.tie_fallbacks += s.tie_fallbacks;
