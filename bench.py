@@ -683,6 +683,11 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
     st = nat.Stats()
     chk(L.mmidx_get_stats(h, C.byref(st)))
     chk(L.mmidx_set_profiling(h, 0))
+    if st.passa_mfma_launches > 0:  # K3ma served pass A (batches of >= 8 queries per list): its stages, HIP events of the detail steps
+        nl = st.passa_mfma_launches
+        log(f"K3ma pass A per step: sweep 1 {st.passa_mfma_sweep1_ms / nl:.3f} ms, select {st.passa_mfma_select_ms / nl:.3f}, sweep 2 "
+            f"{st.passa_mfma_sweep2_ms / nl:.3f}, verify {st.passa_mfma_verify_ms / nl:.3f}; {st.verified_codes / max(1, detail_steps) / B:.1f} codes verified per query, "
+            f"{st.mfma_redo_queries / max(1, detail_steps):.1f} queries per step handed to the exact kernels")
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=f64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -330,9 +330,16 @@ struct mmidx_index {
     size_t mf_ev_used = 0;
     // K3ma (pass A on the matrix cores, mmidx_scan_mfma_a.h)
     int passa_mfma = -1;               // option "passa_mfma": 1 always (where the shape allows), 0 never, -1 = from 8 queries per list of a long-list index
+    int a_wide = 1;                    // option "passa_mfma_wide": 0 = K3ma's sweeps by the four-wave instance alone (A/B switch)
     DevBuf<float> ws_acand;            // [pairs][pieces][256] sweep 1's kept accumulator values
     DevBuf<double2> ws_arowc;          // [pairs] upper-bound maps
     DevBuf<unsigned char> ws_abm;      // [items][stride] sweep 2's compare masks
+    DevBuf<u32> ws_aicnt;              // [items + 1] their set bits per item, then the exclusive prefix
+    DevBuf<uint2> ws_arec;             // the flat record list {pair slot, position}
+    DevBuf<double> ws_arows;           // [pairs][D] exact residuals
+    DevBuf<int4> ws_ameta;             // [pairs] {query, rank, list start}
+    DevBuf<u64> ws_ametaT;             // [pairs] thresholds
+    DevBuf<uint2> ws_arnd;             // [rounds] slot ranges
     std::vector<hipEvent_t> a_ev;      // full profiling: groups of 5 (sweep 1 start / end, selection end, sweep 2 end, verification end)
     size_t a_ev_used = 0;
     long long a_launches = 0;
@@ -705,6 +712,18 @@ int launch_scan(const mmidx_index *h, const ScanParams &P, dim3 grid, size_t lds
     }
 }
 
+// the certified coarse stage (fp32 / bf16-split dot products + exact distances of the nominees) applies: run_coarse's own test
+bool coarse_certified(const mmidx_index *h, size_t *alds_out = nullptr, int *cch_out = nullptr) {
+    const size_t sel_fixed = (size_t)MMIDX_CSEL_CAP * 12 + (size_t)(h->w + 1) * 8 + (size_t)((h->w + 2) & ~1) * 4 + 16;
+    const size_t row_bytes = (size_t)(h->D + MMIDX_TERM_PAD) * 8;
+    int cch = MMIDX_CAND_CHUNK;
+    if (sel_fixed + (size_t)cch * row_bytes > 64 * 1024) cch = sel_fixed < 64 * 1024 ? (int)((64 * 1024 - sel_fixed) / row_bytes) : 0;
+    const size_t alds = sel_fixed + (size_t)std::max(cch, 1) * row_bytes;
+    if (alds_out) *alds_out = alds;
+    if (cch_out) *cch_out = cch;
+    return !h->exact_coarse && h->C >= MMIDX_BLOCK && h->w + 1 <= MMIDX_BLOCK && h->C <= 64 * MMIDX_BLOCK && h->w >= 1 && cch >= 1 && alds <= 64 * 1024;
+}
+
 struct SearchPlan;
 int launch_scan_seeded(const mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 grid, hipStream_t st);
 int launch_scan_filtered(const mmidx_index *h, ScanParams P, const SearchPlan &pl, dim3 grid, hipStream_t st, int main_grid = 0);
@@ -755,7 +774,10 @@ int make_plan(mmidx_index *h, int k, int64_t nq, SearchPlan &pl, bool need_coars
     int64_t qb = std::min<int64_t>(nq, (int64_t)(1 << 30) / std::max(nprobe, 1));
     const int64_t pool_bytes_q = (int64_t)pl.poolq * 16;
     qb = std::min<int64_t>(qb, std::max<int64_t>(1, (16ll << 30) / std::max<int64_t>(pool_bytes_q, 1)));
-    if (ivf && need_coarse) qb = std::min<int64_t>(qb, std::max<int64_t>(1, (2ll << 30) / ((int64_t)h->C * 8)));
+    // (the [nq][C] matrix of exact coarse distances: the exact path writes and reads all of it, the certified paths -- K1c ... K1f --
+    //  touch only the rows of queries that overflow their candidate lists, so theirs may be large: a batch of 131072 queries over
+    //  8192 cells reserves 8.6 GB of the 288)
+    if (ivf && need_coarse) qb = std::min<int64_t>(qb, std::max<int64_t>(1, ((coarse_certified(h) ? 16ll : 2ll) << 30) / ((int64_t)h->C * 8)));
     if (pl.glut) {  // one table per block in global scratch: at most 2 GiB of it
         const int64_t lut_bytes = (int64_t)h->m * h->ks * 8;
         qb = std::min<int64_t>(qb, std::max<int64_t>(1, (2ll << 30) / (lut_bytes * std::max(pl.nitems, 1))));
@@ -1020,22 +1042,35 @@ int launch_grp_t(mmidx_index *h, const GrpParams &GP, size_t lds, hipStream_t st
 }
 
 // ---- K3ma (mmidx_scan_mfma_a.h): pass A through the matrix-core bound ---------------------------------------------------------
-template <int NJ, int DSUB, int MODE>
-int launch_mfma_a_scan_t(mmidx_index *h, const MfmaParams &MP, size_t lds, hipStream_t st) {
-    HIPCK(hipFuncSetAttribute((const void *)k_scan_mfma<NJ, DSUB, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+template <int NJ, int DSUB, int MODE, int NWV>
+int launch_mfma_a_scan_w(mmidx_index *h, const MfmaParams &MP, size_t lds, hipStream_t st) {
+    HIPCK(hipFuncSetAttribute((const void *)k_scan_mfma<NJ, DSUB, MODE, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int blocks = h->mfma_blocks;
     if (blocks <= 0) {
         int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_scan_mfma<NJ, DSUB, MODE>, MF_NT, lds) != hipSuccess || occ < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_scan_mfma<NJ, DSUB, MODE, NWV>, NWV * 64, lds) != hipSuccess || occ < 1) {
             (void)hipGetLastError();
             occ = 1;
         }
         blocks = occ * std::max(h->num_cus, 8);
     }
     blocks = std::max(8, (blocks + 7) & ~7);
-    hipLaunchKernelGGL((k_scan_mfma<NJ, DSUB, MODE>), dim3((unsigned)blocks), dim3(MF_NT), lds, st, MP);
+    hipLaunchKernelGGL((k_scan_mfma<NJ, DSUB, MODE, NWV>), dim3((unsigned)blocks), dim3(NWV * 64), lds, st, MP);
     HIPCK(hipGetLastError());
     return MMIDX_OK;
+}
+// a sweep: the eight-wave instance over the items of <= 32 rows (where it is on), then the four-wave instance over the others.
+// Sweep 2 only: its loop fits 128 registers (1.27 -> 1.13 ms per 131072 queries); sweep 1 keeps 16 / 32 slot values next to the
+// fragments and reloads spilled registers inside the tile loop with eight waves (1.14 -> 2.66 ms), so it stays with four.
+template <int NJ, int DSUB, int MODE>
+int launch_mfma_a_scan_t(mmidx_index *h, const MfmaParams &MP, size_t lds, hipStream_t st) {
+    if constexpr (MODE == 2) {
+        if (MP.a_wide) {
+            const int rc = launch_mfma_a_scan_w<NJ, DSUB, MODE, 8>(h, MP, lds, st);
+            if (rc) return rc;
+        }
+    }
+    return launch_mfma_a_scan_w<NJ, DSUB, MODE, 4>(h, MP, lds, st);
 }
 template <int MODE>
 int launch_mfma_a_scan(mmidx_index *h, const MfmaParams &MP, size_t lds, hipStream_t st) {
@@ -1046,10 +1081,10 @@ int launch_mfma_a_scan(mmidx_index *h, const MfmaParams &MP, size_t lds, hipStre
 }
 template <int M, int DSUB>
 int launch_a1_verify_t(mmidx_index *h, const MfmaParams &MP, hipStream_t st) {
-    const A1VLds L(DSUB);
+    const A1VLds L(M, DSUB);
     HIPCK(hipFuncSetAttribute((const void *)k_a1_verify<M, DSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total));
-    const unsigned grid = (unsigned)(16 * std::max(h->num_cus, 8));
-    hipLaunchKernelGGL((k_a1_verify<M, DSUB>), dim3(grid), dim3(A1V_NT), L.total, st, MP);
+    const unsigned grid = (unsigned)std::max(h->num_cus, 8);  // (one block of sixteen waves per CU, walking the list)
+    hipLaunchKernelGGL((k_a1_verify<M, DSUB>), dim3(grid), dim3(A1V_NT(DSUB)), L.total, st, MP);
     HIPCK(hipGetLastError());
     return MMIDX_OK;
 }
@@ -1101,9 +1136,19 @@ int launch_passa_mfma(mmidx_index *h, const ScanParams &P, const SearchPlan &pl,
     HIPCK(h->ws_redo.reserve((size_t)nq));
     HIPCK(h->ws_psnap.reserve((size_t)nq));
     HIPCK(h->ws_mfctl.reserve(64));
-    HIPCK(h->ws_acand.reserve((size_t)npairs * nsub * 256));
+    const int cstride = 256;  // (512: sweep 1 by the eight-wave instance -- not used, see launch_mfma_a_scan_t)
+    HIPCK(h->ws_acand.reserve((size_t)npairs * nsub * cstride));
     HIPCK(h->ws_arowc.reserve((size_t)npairs));
     HIPCK(h->ws_abm.reserve(max_groups * (size_t)nsub * bm_stride));
+    HIPCK(h->ws_aicnt.reserve(max_groups * (size_t)nsub + 1));
+    // (about K1 + 10 % records per pair; the list holds 512 per pair -- what does not fit sends its queries to the exact kernels)
+    const size_t rec_cap = h->mfma_qcap > 0 ? (size_t)h->mfma_qcap : std::min<size_t>((size_t)0xFFFFF000u, std::max<size_t>((size_t)1 << 20, (size_t)npairs * 512));
+    HIPCK(h->ws_arec.reserve(rec_cap));
+    const int rnd_size = A1V_RND(h->dsub);
+    HIPCK(h->ws_arnd.reserve(rec_cap / (size_t)rnd_size + 2));
+    if (h->transform != MMIDX_TR_ROTATION) HIPCK(h->ws_arows.reserve((size_t)npairs * h->D));
+    HIPCK(h->ws_ameta.reserve((size_t)npairs));
+    HIPCK(h->ws_ametaT.reserve((size_t)npairs));
     if (h->d_perm) HIPCK(h->ws_Qp.reserve((size_t)nq * h->D));
     if (h->transform == MMIDX_TR_ROTATION) HIPCK(h->ws_R.reserve((size_t)npairs * h->D));
     // ---- the (query, probe 0) pairs by cell, groups of <= 64 ----
@@ -1153,7 +1198,9 @@ int launch_passa_mfma(mmidx_index *h, const ScanParams &P, const SearchPlan &pl,
     MP.redo = h->ws_redo.p;
     MP.pool_snap = h->ws_psnap.p;
     MP.work = h->ws_mfctl.p + 8;
-    MP.a_work = h->ws_mfctl.p + 24;
+    MP.a_work = h->ws_mfctl.p + 24;  // (sweep 1: words 24 .. 39; sweep 2: 8 .. 23)
+    MP.a_wide = 0;  // (sweep 1: every item through the four-wave instance; set for sweep 2 below)
+    MP.a_cstride = cstride;
     MP.fb_count = (u32 *)(h->ws_gfb.p + 1);
     MP.fb_items = h->ws_gfb.p + 4;
     MP.fb_ch = h->ws_gfb.p + 4 + nfb;
@@ -1166,6 +1213,14 @@ int launch_passa_mfma(mmidx_index *h, const ScanParams &P, const SearchPlan &pl,
     MP.a_rowc = h->ws_arowc.p;
     MP.a_bm = h->ws_abm.p;
     MP.a_bm_stride = bm_stride;
+    MP.a_icnt = h->ws_aicnt.p;
+    MP.a_rec = h->ws_arec.p;
+    MP.a_rec_cap = (u32)rec_cap;
+    MP.a_rows = h->transform == MMIDX_TR_ROTATION ? h->ws_R.p : h->ws_arows.p;
+    MP.a_meta = h->ws_ameta.p;
+    MP.a_metaT = h->ws_ametaT.p;
+    MP.a_rnd = h->ws_arnd.p;
+    MP.a_rnd_size = rnd_size;
     const MfmaLds L(h->D);
     hipEvent_t *aev = nullptr;
     if (h->profiling == 1 && h->a_ev_used + 5 <= 5 * 4096) {
@@ -1184,19 +1239,30 @@ int launch_passa_mfma(mmidx_index *h, const ScanParams &P, const SearchPlan &pl,
     DBG_SYNC("K3ma sweep 1");
     {
         const unsigned gs = (unsigned)((npairs + 3) / 4);
-        if (nsub <= 1) hipLaunchKernelGGL(k_a1_select<1>, dim3(gs), dim3(256), 0, st, MP);
-        else if (nsub <= 2) hipLaunchKernelGGL(k_a1_select<2>, dim3(gs), dim3(256), 0, st, MP);
-        else if (nsub <= 4) hipLaunchKernelGGL(k_a1_select<4>, dim3(gs), dim3(256), 0, st, MP);
-        else hipLaunchKernelGGL(k_a1_select<8>, dim3(gs), dim3(256), 0, st, MP);
+        const int chunks = nsub * (cstride >> 8);
+        if (chunks <= 1) hipLaunchKernelGGL(k_a1_select<1>, dim3(gs), dim3(256), 0, st, MP);
+        else if (chunks <= 2) hipLaunchKernelGGL(k_a1_select<2>, dim3(gs), dim3(256), 0, st, MP);
+        else if (chunks <= 4) hipLaunchKernelGGL(k_a1_select<4>, dim3(gs), dim3(256), 0, st, MP);
+        else if (chunks <= 8) hipLaunchKernelGGL(k_a1_select<8>, dim3(gs), dim3(256), 0, st, MP);
+        else hipLaunchKernelGGL(k_a1_select<16>, dim3(gs), dim3(256), 0, st, MP);
         HIPCK(hipGetLastError());
     }
     if (aev) HIPCK(hipEventRecord(aev[2], st));
     DBG_SYNC("K3ma select");
     if (h->debug_sync) HIPCK(hipMemsetAsync(h->ws_abm.p, 0, max_groups * (size_t)nsub * bm_stride, st));  // (the debug report below counts bits)
+    MP.a_wide = h->a_wide ? 1 : 0;
     rc = launch_mfma_a_scan<2>(h, MP, L.total, st);  // sweep 2: compare masks
     if (rc) return rc;
     if (aev) HIPCK(hipEventRecord(aev[3], st));
     DBG_SYNC("K3ma sweep 2");
+    {
+        const int tp = h->D / 2, per = std::max(1, 256 / std::min(tp, 256));
+        hipLaunchKernelGGL(k_a1_rows, dim3((unsigned)((npairs + per - 1) / per)), dim3(256), 0, st, MP, h->D);
+    }
+    hipLaunchKernelGGL(k_a1_item_scan, dim3(1), dim3(1024), 0, st, MP);
+    hipLaunchKernelGGL(k_a1_records, dim3((unsigned)(8 * std::max(h->num_cus, 8))), dim3(A1R_NT), 0, st, MP);
+    HIPCK(hipGetLastError());
+    DBG_SYNC("K3ma records");
     if (h->dsub == 4) rc = h->m == 32 ? launch_a1_verify_t<32, 4>(h, MP, st) : h->m == 16 ? launch_a1_verify_t<16, 4>(h, MP, st) : launch_a1_verify_t<8, 4>(h, MP, st);
     else if (h->dsub == 8) rc = h->m == 16 ? launch_a1_verify_t<16, 8>(h, MP, st) : h->m == 8 ? launch_a1_verify_t<8, 8>(h, MP, st) : launch_a1_verify_t<4, 8>(h, MP, st);
     else rc = h->m == 8 ? launch_a1_verify_t<8, 16>(h, MP, st) : h->m == 4 ? launch_a1_verify_t<4, 16>(h, MP, st) : launch_a1_verify_t<2, 16>(h, MP, st);
@@ -1837,11 +1903,9 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
     // where they fit a 64 KiB block, fewer for long vectors (D = 1024: 6 -- YFCC100MExample.java:85)
     const size_t sel_fixed = (size_t)MMIDX_CSEL_CAP * 12 + (size_t)(h->w + 1) * 8 + (size_t)((h->w + 2) & ~1) * 4 + 16;
     const size_t row_bytes = (size_t)(h->D + MMIDX_TERM_PAD) * 8;
-    int cch = MMIDX_CAND_CHUNK;
-    if (sel_fixed + (size_t)cch * row_bytes > 64 * 1024) cch = sel_fixed < 64 * 1024 ? (int)((64 * 1024 - sel_fixed) / row_bytes) : 0;
-    const size_t alds = sel_fixed + (size_t)std::max(cch, 1) * row_bytes;
-    const bool approx = !h->exact_coarse && h->C >= MMIDX_BLOCK && h->w + 1 <= MMIDX_BLOCK && h->C <= 64 * MMIDX_BLOCK &&
-                        h->w >= 1 && cch >= 1 && alds <= 64 * 1024;
+    int cch = 0;
+    size_t alds = 0;
+    const bool approx = coarse_certified(h, &alds, &cch);
     const size_t glds = sel_fixed + std::max<size_t>((size_t)std::max(cch, 1) * row_bytes, (size_t)MMIDX_BLOCK * 4);
     const int G = h->Cp / 8;
     if (approx && !h->coarse_v1 && h->d_Ch && G >= 4 * (h->w + 1) && glds <= 64 * 1024) {
@@ -2722,6 +2786,12 @@ int mmidx_destroy(mmidx_index *h) {
     h->ws_acand.release();
     h->ws_arowc.release();
     h->ws_abm.release();
+    h->ws_aicnt.release();
+    h->ws_arec.release();
+    h->ws_arows.release();
+    h->ws_ameta.release();
+    h->ws_ametaT.release();
+    h->ws_arnd.release();
     for (hipEvent_t e : h->a_ev) (void)hipEventDestroy(e);
     h->a_ev.clear();
     h->ws_mfctl.release();
@@ -3499,6 +3569,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->no_union = value < 0 ? -1 : (value != 0);
     } else if (n == "passa_mfma") {  // K3ma: 1 always, 0 never, -1 by the batch (default)
         h->passa_mfma = value;
+    } else if (n == "passa_mfma_wide") {
+        h->a_wide = value != 0;
     } else if (n == "no_mfma") {  // pass B through K3g / K3f instead of the matrix-core bound K3m
         h->no_mfma = value != 0;
     } else if (n == "mfma_sub") {

@@ -69,7 +69,18 @@ struct MfmaParams {
     double2 *a_rowc;           // [pair slot] {||r||^2 + err, -2 / s^2}: upper bound of a code's distance = x + y acc (NaN: the bound cannot serve the row)
     unsigned char *a_bm;       // [item][a_bm_stride] sweep 2's compare masks: per tile pair and lane a u16 (<= 32 rows: 8 bits per tile) or u32
     size_t a_bm_stride;        // bytes per item: ceil(sub / 32) * 256
-    u32 *a_work;               // [8] sweep 1's per-XCD item cursors (its own set: both sweeps are enqueued behind one k_mfma_prep)
+    u32 *a_work;               // [16] sweep 1's per-XCD item cursors (its own set: both sweeps are enqueued behind one k_mfma_prep; the
+                               // eight-wave instances use words 8 .. 15 of a_work / work)
+    int a_wide;                // 1: items of <= 32 rows go to the eight-wave instances
+    int a_cstride;             // floats per (pair slot, piece) of a_cand: 256, or 512 with the eight-wave instances
+    u32 *a_icnt;               // [items + 1] bits sweep 2 set per item (zeroed by sweep 1), then their exclusive prefix (k_a1_item_scan): [items] = total
+    uint2 *a_rec;              // the flat record list {pair slot, position in the index} in item order (k_a1_records), a_rec_cap entries
+    u32 a_rec_cap;
+    double *a_rows;            // [pair slot][D] the pairs' exact residuals c - q (k_a1_rows; rotation: = R)
+    int4 *a_meta;              // [pair slot] {query, probe rank, list start (low, high word)}
+    u64 *a_metaT;              // [pair slot] the query's threshold as k_a1_select left it
+    uint2 *a_rnd;              // [round of a_rnd_size records] {smallest, largest pair slot} (initialised by k_a1_item_scan, filled by k_a1_records)
+    int a_rnd_size;            // records per round of k_a1_verify (a power of two)
 };
 
 #define MF_CHUNK 512    // survivor records a wave reserves at a time (one global atomic per chunk, not per tile)
@@ -418,8 +429,8 @@ __device__ __forceinline__ void mf_scan_tiles(const MfmaParams &P, const mf_h8 (
 //   k_a1_verify (mmidx_scan_mfma_a.h): a block per item turns the bitmap into (row, position) records and computes their exact
 //     distances sub-quantizer by sub-quantizer with the codebook slice in LDS -- the reference's operations in its order.
 // Two tiles of a step are neighbours (tiles 2 p, 2 p + 1 of the wave's pair p): their masks share a store.
-template <int NJ, int DSUB, int NTL, int MODE>
-__device__ __forceinline__ void a_scan_tiles(const mf_h8 (&A)[4][NJ], const float (&thr)[4][4], const unsigned char *codes, const float *xn, const long long c0,
+template <int NJ, int DSUB, int NTL, int MODE, int NWV>
+__device__ __forceinline__ u32 a_scan_tiles(const mf_h8 (&A)[4][NJ], const float (&thr)[4][4], const unsigned char *codes, const float *xn, const long long c0,
                                              const long long c1, const float kinit, const u32 lds_cb, float (&top)[NTL * 4][4], unsigned char *bm, const int lane,
                                              const int wv) {
     constexpr int D = NJ * 32, M = D / DSUB;
@@ -448,19 +459,20 @@ __device__ __forceinline__ void a_scan_tiles(const mf_h8 (&A)[4][NJ], const floa
     };
     CW cw[4];
     float xv[4];
+    u32 nbits = 0;  // MODE 2: set bits of this lane (the item's total sizes its share of the record list)
 #pragma unroll
     for (int u = 0; u < 2; u++) {
-        load_tile(2 * (wv + 4 * u), cw[2 * u], xv[2 * u]);
-        load_tile(2 * (wv + 4 * u) + 1, cw[2 * u + 1], xv[2 * u + 1]);
+        load_tile(2 * (wv + NWV * u), cw[2 * u], xv[2 * u]);
+        load_tile(2 * (wv + NWV * u) + 1, cw[2 * u + 1], xv[2 * u + 1]);
     }
-    for (int pp = wv; pp < npt; pp += 8) {
+    for (int pp = wv; pp < npt; pp += 2 * NWV) {  // (the wave's tile pairs: wv, wv + NWV, ...; two of them per round of the loop)
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            const int pr = pp + 4 * u;
+            const int pr = pp + NWV * u;
             const CW c[2] = {cw[2 * u], cw[2 * u + 1]};
             const float x[2] = {xv[2 * u], xv[2 * u + 1]};
-            load_tile(2 * (pr + 8), cw[2 * u], xv[2 * u]);
-            load_tile(2 * (pr + 8) + 1, cw[2 * u + 1], xv[2 * u + 1]);
+            load_tile(2 * (pr + 2 * NWV), cw[2 * u], xv[2 * u]);
+            load_tile(2 * (pr + 2 * NWV) + 1, cw[2 * u + 1], xv[2 * u + 1]);
             if (pr >= npt) continue;  // (wave-uniform)
             // the B fragments of tile h: the decode gathers (as mf_scan_tiles)
             auto gather = [&](const CW ch, mf_h8 (&Bh)[NJ]) {
@@ -541,16 +553,25 @@ __device__ __forceinline__ void a_scan_tiles(const mf_h8 (&A)[4][NJ], const floa
                     for (int b = 0; b < NTL * 4; b++) bt |= acc[h][b >> 2][b & 3] >= thr[b >> 2][b & 3] ? (1u << b) : 0u;
                     bits[h] = bt;
                 }
-                if constexpr (NTL <= 2) ((unsigned short *)bm)[(size_t)pr * 64 + lane] = (unsigned short)(bits[0] | (bits[1] << 8));
-                else ((u32 *)bm)[(size_t)pr * 64 + lane] = bits[0] | (bits[1] << 16);
+                const u32 both = NTL <= 2 ? (bits[0] | (bits[1] << 8)) : (bits[0] | (bits[1] << 16));
+                if constexpr (NTL <= 2) ((unsigned short *)bm)[(size_t)pr * 64 + lane] = (unsigned short)both;
+                else ((u32 *)bm)[(size_t)pr * 64 + lane] = both;
+                nbits += (u32)__popc(both);
             }
         }
     }
+    return nbits;
 }
 
-// MODE 0: pass B (and flat PQ's far chunks) with survivor records; MODE 1 / 2: the two sweeps of K3ma (above)
-template <int NJ, int DSUB, int MODE = 0>
-__global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
+// MODE 0: pass B (and flat PQ's far chunks) with survivor records; MODE 1 / 2: the two sweeps of K3ma (above).
+// NWV = waves per block.  8 (K3ma only): the instance for items of at most 32 rows (NTL <= 2), which are most of pass A's -- their
+// queries, kept values and fragments fit 128 registers, so sixteen waves run per CU instead of eight and the decode gathers (LDS), the
+// matrix instructions and the slot updates / compares (VALU) of different waves overlap; it skips larger items, the four-wave
+// instance (launched behind it when P.a_wide is set) skips the small ones.  Waves 4 .. 7 take no part in the residual phase (a).
+template <int NJ, int DSUB, int MODE = 0, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void k_scan_mfma(const MfmaParams P) {  // (second figure: waves per SIMD the registers must allow)
+    constexpr int NT = NWV * 64;
+    static_assert(NWV == 4 || (NWV == 8 && MODE != 0), "eight waves: K3ma's sweeps only");
     constexpr int D = NJ * 32;
     constexpr int DPT = D / 8;  // dimensions per thread in the residual phase: a thread is (row of 32, eighth of the dimensions)
     static_assert(NJ == 1 || NJ == 2 || NJ == 4, "D = 32, 64 or 128");
@@ -567,7 +588,7 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
     const int nv = *P.n_groups * P.nsub;
     if (nv == 0) return;  // (the separable benchmark: the coarse bound left pass B nothing)
     // the fp16 codebook: once per block
-    for (int i = tid; i < D * 32; i += MF_NT) ((uint4 *)(smem + L.cb))[i] = ((const uint4 *)P.pq16)[i];
+    for (int i = tid; i < D * 32; i += NT) ((uint4 *)(smem + L.cb))[i] = ((const uint4 *)P.pq16)[i];
     const int per = (nv + 7) >> 3;
     const int xcd = blockIdx.x & 7;
     const double xmax = P.xmax;
@@ -576,7 +597,7 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
 
     for (;;) {
         if (tid == 0) {
-            s_misc[0] = atomicAdd((MODE == 1 ? P.a_work : P.work) + xcd, 1u);
+            s_misc[0] = atomicAdd((MODE == 1 ? P.a_work : P.work) + (NWV == 8 ? 8 : 0) + xcd, 1u);
             s_misc[1] = 0;
             s_misc[2] = 0;
             s_misc[8] = s_misc[9] = s_misc[10] = s_misc[11] = 0;
@@ -592,7 +613,12 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
         const long long beg = P.S.list_off[cell];
         const long long len = P.S.list_off[cell + 1] - beg;
         const long long c0 = (long long)isub * P.sub;
+        if (MODE != 0 && (NWV == 8 ? np > 32 : (P.a_wide && np <= 32))) {  // (block-uniform) the other instance's item
+            __syncthreads();
+            continue;
+        }
         if (c0 >= len) {
+            if (MODE == 1 && tid == 0) P.a_icnt[v] = 0;  // (an empty item of K3ma: no bits)
             __syncthreads();
             continue;
         }
@@ -602,18 +628,20 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
 
         // ---- (a) residuals of the item's pairs: thread (row = tid >> 3 of a half, eighth = tid & 7) ----
         // (loads on a clamped pair index, stores predicated: see the note at pair_keep() in mmidx_kernels.h)
+        const int ta = tid & 255;       // (eight waves: waves 4 .. 7 shadow waves 0 .. 3 here and store nothing)
+        const bool pa_act = tid < 256;
         double rv[2][DPT];
         double nrp[2];
         int qq[2];
         float mx = 0.f;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const int row = h * 32 + (tid >> 3);
+            const int row = h * 32 + (ta >> 3);
             const int tl = row < np ? row : np - 1;
             const int e = P.S.order[first + tl];
             const int q = e / P.S.w;
             qq[h] = q;
-            const int d0 = (tid & 7) * DPT;
+            const int d0 = (ta & 7) * DPT;
             double nr = 0.0;
             if (P.R) {
                 const double *rr = P.R + (size_t)(first + tl) * D + d0;
@@ -647,7 +675,7 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
         // the item's power-of-two scale: the largest |r_i| lands in [2^12, 2^13)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-        if (lane == 0) ((float *)s_misc)[4 + wv] = mx;
+        if (lane == 0 && wv < 4) ((float *)s_misc)[4 + wv] = mx;
         __syncthreads();
         mx = fmaxf(fmaxf(((float *)s_misc)[4], ((float *)s_misc)[5]), fmaxf(((float *)s_misc)[6], ((float *)s_misc)[7]));
         int er = 0;
@@ -666,7 +694,7 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
         const float kinit = (float)(-0.5 * s2);
         const float kd = (float)(-2.0 * inv_s2);  // (a power of two: exact)
         // per query: ||r||^2, the certified error term, the threshold constant, the histogram scale
-        if ((tid & 7) == 0) {
+        if (pa_act && (tid & 7) == 0) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int row = h * 32 + (tid >> 3);
@@ -739,7 +767,7 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
         mf_h8 A[4][NJ];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            if (h * 2 < ntl) {  // (block-uniform)
+            if (h * 2 < ntl && pa_act) {  // (block-uniform but for the shadow waves)
                 unsigned char *dst = s_stage + (size_t)(tid >> 3) * MF_ASTRIDE + (size_t)(tid & 7) * DPT * 2;
 #pragma unroll
                 for (int t = 0; t < DPT; t += 2) {
@@ -790,21 +818,36 @@ __global__ __launch_bounds__(MF_NT, 2) void k_scan_mfma(const MfmaParams P) {
                 float top[NTL * 4][4];
 #pragma unroll
                 for (int b = 0; b < NTL * 4; b++) top[b][0] = top[b][1] = top[b][2] = top[b][3] = ninf;
-                a_scan_tiles<NJ, DSUB, NTL, MODE>(A, thr, codes, xn, c0, c1, kinit, lds_cb, top, bm, lane, wv);
+                u32 nb = a_scan_tiles<NJ, DSUB, NTL, MODE, NWV>(A, thr, codes, xn, c0, c1, kinit, lds_cb, top, bm, lane, wv);
+                if constexpr (MODE == 2) {  // the item's bit count: one atomic per wave
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) nb += __shfl_xor(nb, off);
+                    if (lane == 0 && nb) atomicAdd(P.a_icnt + v, nb);
+                }
                 if constexpr (MODE == 1) {
+                    if (tid == 0) P.a_icnt[v] = 0;  // (sweep 2 counts its bits here)
 #pragma unroll
                     for (int b = 0; b < NTL * 4; b++) {
                         const int row = (b >> 2) * 16 + 4 * (lane >> 4) + (b & 3);
-                        if (row < np)
-                            *(float4 *)(P.a_cand + ((size_t)(first + row) * P.nsub + isub) * 256 + wv * 64 + (lane & 15) * 4) = make_float4(top[b][0], top[b][1], top[b][2], top[b][3]);
+                        if (row < np) {
+                            float *cp = P.a_cand + ((size_t)(first + row) * P.nsub + isub) * (size_t)P.a_cstride + wv * 64 + (lane & 15) * 4;
+                            *(float4 *)cp = make_float4(top[b][0], top[b][1], top[b][2], top[b][3]);
+                            // (four waves where the eight-wave instance sets the stride: the other half of the pair's slots stays empty)
+                            if (NWV == 4 && P.a_cstride > 256) *(float4 *)(cp + 256) = make_float4(ninf, ninf, ninf, ninf);
+                        }
                     }
                 }
             };
-            switch (ntl) {
-                case 1: run(std::integral_constant<int, 1>{}); break;
-                case 2: run(std::integral_constant<int, 2>{}); break;
-                case 3: run(std::integral_constant<int, 3>{}); break;
-                default: run(std::integral_constant<int, 4>{}); break;
+            if constexpr (NWV == 8) {  // (items of at most 32 rows)
+                if (ntl == 1) run(std::integral_constant<int, 1>{});
+                else run(std::integral_constant<int, 2>{});
+            } else {
+                switch (ntl) {
+                    case 1: run(std::integral_constant<int, 1>{}); break;
+                    case 2: run(std::integral_constant<int, 2>{}); break;
+                    case 3: run(std::integral_constant<int, 3>{}); break;
+                    default: run(std::integral_constant<int, 4>{}); break;
+                }
             }
         }
         __syncthreads();
