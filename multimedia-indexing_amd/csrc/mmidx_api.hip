@@ -1238,7 +1238,7 @@ int launch_passa_mfma(mmidx_index *h, const ScanParams &P, const SearchPlan &pl,
     if (aev) HIPCK(hipEventRecord(aev[1], st));
     DBG_SYNC("K3ma sweep 1");
     {
-        const unsigned gs = (unsigned)((npairs + 3) / 4);
+        const unsigned gs = (unsigned)std::min<long long>((npairs + 3) / 4, 32ll * std::max(h->num_cus, 8));  // (the kernel loops over the device-side count)
         const int chunks = nsub * (cstride >> 8);
         if (chunks <= 1) hipLaunchKernelGGL(k_a1_select<1>, dim3(gs), dim3(256), 0, st, MP);
         else if (chunks <= 2) hipLaunchKernelGGL(k_a1_select<2>, dim3(gs), dim3(256), 0, st, MP);
@@ -1257,7 +1257,7 @@ int launch_passa_mfma(mmidx_index *h, const ScanParams &P, const SearchPlan &pl,
     DBG_SYNC("K3ma sweep 2");
     {
         const int tp = h->D / 2, per = std::max(1, 256 / std::min(tp, 256));
-        hipLaunchKernelGGL(k_a1_rows, dim3((unsigned)((npairs + per - 1) / per)), dim3(256), 0, st, MP, h->D);
+        hipLaunchKernelGGL(k_a1_rows, dim3((unsigned)std::min<long long>((npairs + per - 1) / per, 32ll * std::max(h->num_cus, 8))), dim3(256), 0, st, MP, h->D);
     }
     hipLaunchKernelGGL(k_a1_item_scan, dim3(1), dim3(1024), 0, st, MP);
     hipLaunchKernelGGL(k_a1_records, dim3((unsigned)(8 * std::max(h->num_cus, 8))), dim3(A1R_NT), 0, st, MP);

@@ -50,10 +50,10 @@ __device__ __forceinline__ float a1_unkey(u32 k) { return __int_as_float((int)((
 // threshold.  Pairs with fewer than K1 values (short lists) or an unusable scale keep T = +inf and go to the redo.
 template <int NS>
 __global__ __launch_bounds__(256) void k_a1_select(const MfmaParams P) {
-    const long long slot = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = (int)(threadIdx.x & 63);
     const long long npairs = *P.S.n_order;
-    if (slot >= npairs) return;
+    // (a loop over the device-side pair count: a shard of a sharded handle holds an eighth of the pairs its grid would have to cover)
+    for (long long slot = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); slot < npairs; slot += (long long)gridDim.x * 4) {
     const int e = P.S.order[slot];
     const int q = e / P.S.w;
     const int cell = P.S.cells[e];
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_a1_select(const MfmaParams P) {
     // (chunks of 256 values: a piece is one, or two where the eight-wave sweep instance sets the stride)
     const int pieces = (int)(pieces_l < (long long)P.nsub ? pieces_l : (long long)P.nsub) * (P.a_cstride >> 8);
     const double2 rc = P.a_rowc[slot];
-    if (!(rc.x == rc.x)) return;
+    if (!(rc.x == rc.x)) continue;
     u32 key[4 * NS];
 #pragma unroll
     for (int j = 0; j < NS; j++) {
@@ -84,12 +84,13 @@ __global__ __launch_bounds__(256) void k_a1_select(const MfmaParams P) {
         for (int i = 0; i < 4 * NS; i++) cnt += (int)__popcll(__builtin_amdgcn_ballot_w64(key[i] >= t));
         if (cnt >= P.S.K1) K = t;  // (wave-uniform)
     }
-    if (K <= 0x007FFFFFu) return;  // fewer than K1 values
+    if (K <= 0x007FFFFFu) continue;  // fewer than K1 values
     const float a = a1_unkey(K);
-    if (!(a == a) || !(fabsf(a) < 3e38f)) return;
+    if (!(a == a) || !(fabsf(a) < 3e38f)) continue;
     const double ub = (rc.x + rc.y * (double)a) * (1.0 + 1e-12);
-    if (!(ub >= 0.0) || !(ub < 1e300)) return;
+    if (!(ub >= 0.0) || !(ub < 1e300)) continue;
     if (lane == 0) atomicMin(P.S.T + q, dkey(ub));
+    }
 }
 
 // ---- sweep 2's bits as a flat record list -----------------------------------------------------------------------------------------
@@ -127,9 +128,9 @@ __global__ __launch_bounds__(256) void k_a1_rows(const MfmaParams P, int D) {
     const long long npairs = *P.S.n_order;
     const int per = 256 / (D / 2 < 256 ? D / 2 : 256);  // pairs per block: a thread per 16 bytes of a row (D <= 128: 64 threads per pair)
     const int tp = D / 2;
-    const long long slot = (long long)blockIdx.x * per + threadIdx.x / tp;
     const int t = (threadIdx.x % tp) * 2;
-    if (slot >= npairs || threadIdx.x >= per * tp) return;
+    if (threadIdx.x >= per * tp) return;
+    for (long long slot = (long long)blockIdx.x * per + threadIdx.x / tp; slot < npairs; slot += (long long)gridDim.x * per) {
     const int e = P.S.order[slot];
     const int q = e / P.S.w;
     const int cell = P.S.cells[e];
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(256) void k_a1_rows(const MfmaParams P, int D) {
         const long long beg = P.S.list_off[cell];
         P.a_meta[slot] = make_int4(q, e - q * P.S.w, (int)(u32)beg, (int)(beg >> 32));
         P.a_metaT[slot] = P.S.T[q];  // (final: the kernel runs behind k_a1_select, and nothing lowers a threshold before pass A's verification is over)
+    }
     }
 }
 // k_a1_records: a block per item turns its bitmap -- per tile pair and lane the packed compares of a_scan_tiles<MODE 2>, read 16 bytes
