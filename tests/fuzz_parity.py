@@ -58,9 +58,11 @@ for case in range(cases):
     mfq = int(rng.choice([0, 0, 0, 8]))  # K3m: survivor records per launch (8: nearly every query goes through the redo path)
     kcv1 = int(rng.random() < 0.3)  # K3mk (D = 256 ... 2048): the form without LDS-DMA also where k_scan_mfma_kc2 applies
     wsel = int(rng.random() < 0.7)  # the coarse stage's exact selection by one wave per query (k_coarse_front_sel) where it applies
+    pam = int(rng.choice([-1, -1, 1, 1]))  # K3ma (pass A on the matrix cores, two sweeps): by the batch (never, at seven queries) / forced where the shape allows
+    pamw = int(rng.random() < 0.7)  # ... its second sweep by the eight-wave instance
     # the oracle's encoder is one thread ((C + ks) x D fp64 triples per vector): keep a case near a second of it
     n = max(1, min(n, int(1.5e9 / ((C + ks) * D))))
-    desc = dict(kind=kind, D=D, m=m, ks=ks, n=n, k=k, C=C, w=w, tr=tr, dup=dup, hist=hist, v1=v1, wide=wide, nogrp=nogrp, fused=fused, union=union, spre=spre, nomf=nomf, mfsub=mfsub, mfq=mfq, kcv1=kcv1, wsel=wsel)
+    desc = dict(kind=kind, D=D, m=m, ks=ks, n=n, k=k, C=C, w=w, tr=tr, dup=dup, hist=hist, v1=v1, wide=wide, nogrp=nogrp, fused=fused, union=union, spre=spre, nomf=nomf, mfsub=mfsub, mfq=mfq, kcv1=kcv1, wsel=wsel, pam=pam, pamw=pamw)
     try:
         nb = min(n, 3000)
         if kind == "ivfpq":
@@ -97,6 +99,8 @@ for case in range(cases):
         ix.set_option("mfma_kc_v1", kcv1)
         ix.set_option("mfma_kc_tpw", 16 if case % 7 == 3 else 8)
         ix.set_option("coarse_wave_sel", wsel)
+        ix.set_option("passa_mfma", pam)
+        ix.set_option("passa_mfma_wide", pamw)
         ix.set_option("smin_valu", int(case % 3 == 0))
         ix.set_option("smin_bf16", int(case % 4 != 1))
         ix.set_option("coarse_dma_kc", int(case % 5 != 2))  # (K1e' with LDS-DMA for vectors of several 128-dimension chunks)

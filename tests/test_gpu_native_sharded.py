@@ -414,3 +414,32 @@ def test_native_sharded_pass_b_on_the_matrix_cores(mi, oracle, devices, D, m):
         st = ix.get_stats()
         assert (st["mfma_survivors"] > 0) == (off == 0)
     ix.close()
+
+
+@pytest.mark.parametrize("devices", DEVS, ids=["rccl1", "virt2", "virt3"])
+def test_native_sharded_pass_a_on_the_matrix_cores(mi, oracle, devices):
+    """K3ma on every shard (option "passa_mfma" = 1; by default a shard takes it from 8 queries per list of the whole round's batch --
+    the regime of the 8-GPU configuration): each shard sorts the queries whose nearest list it holds by cell, runs the two sweeps and
+    the exact verification over them, the thresholds are MIN-reduced as after K3h.  Cells of ~1500 vectors, 300 queries (19 per list),
+    every vector twice so that ties straddle shards; k + 1 = 101.  The single queue's answer, with K3ma and without."""
+    D, m, C_, ks, w, k = 64, 8, 16, 256, 5, 100
+    rng = np.random.default_rng(11 + len(devices))
+    mu = 0.5 * rng.standard_normal((C_, D))
+    half = mu[rng.integers(0, C_, 12000)] + rng.standard_normal((12000, D))
+    base = np.concatenate([half, half])[rng.permutation(24000)]
+    ds = D // m
+    pq = np.stack([synth.kmeans((mu[rng.integers(0, C_, 3000)] - base[:3000])[:, s * ds:(s + 1) * ds], ks, iters=2, seed=s) for s in range(m)])
+    p = {"coarse": mu, "pq": pq}
+    ref = make_ref(oracle, p, D, m, ks, C_, w)
+    ref.add_vectors(base)
+    ix = make_sharded(mi, p, D, m, ks, C_, w, len(base), devices)
+    ix.indexVectors([str(i) for i in range(len(base))], base)
+    Q = np.concatenate([0.5 * (base[:40] + base[100:140]), base[200:440] + 0.01 * rng.standard_normal((240, D)), rng.standard_normal((20, D))])
+    want = ref.search_batch(Q, k)
+    for force in (1, 0):
+        ix.set_option("passa_mfma", force)
+        ix.set_profiling(True)
+        assert_same(ix.search_batch(k, Q), want)
+        st = ix.get_stats()
+        assert (st["passa_mfma_launches"] > 0) == (force == 1)
+    ix.close()
