@@ -5,6 +5,7 @@ import gr.iti.mklab.visual.datastructures.PQ;
 import gr.iti.mklab.visual.datastructures.PQ.TransformationType;
 import gr.iti.mklab.visual.utilities.Answer;
 import gr.iti.mklab.visual.utilities.RandomPermutation;
+import gr.iti.mklab.visual.utilities.RandomRotation;
 
 import java.io.BufferedReader;
 import java.io.File;
@@ -111,6 +112,25 @@ public class CrossCheck {
 			ix.indexVector(Integer.toString(i), base[i]);
 		dump(ix, queries, k, new File(outDir, name + ".answers.csv"));
 		ix.close();
+		if (t == TransformationType.RandomRotation) {
+			// the matrix is EJML's (RandomRotation.java:30-35; seed 1 as IVFPQ.java:136): rotating the unit vectors reveals its rows,
+			// and compare.py hands them to the oracle
+			RandomRotation rr = new RandomRotation(1, D);
+			PrintWriter pw = new PrintWriter(new File(outDir, name + ".rotation.csv"));
+			for (int i = 0; i < D; i++) {
+				double[] e = new double[D];
+				e[i] = 1.0;
+				double[] row = rr.rotate(e);
+				StringBuilder sb = new StringBuilder();
+				for (int j = 0; j < D; j++) {
+					if (j > 0)
+						sb.append(',');
+					sb.append(String.format("%016x", Double.doubleToLongBits(row[j])));
+				}
+				pw.println(sb);
+			}
+			pw.close();
+		}
 		System.out.println(name + ": " + base.length + " vectors indexed, " + queries.length + " queries answered");
 	}
 
