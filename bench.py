@@ -418,6 +418,8 @@ def main():
     ap.add_argument("--big-batch", type=int, default=131072,
                     help="queries per step of the `batch_131072` object (same index, one GPU: >= 8 queries per nearest list, pass A through K3ma; 0 = skip it)")
     ap.add_argument("--big-steps", type=int, default=10)
+    ap.add_argument("--dry-run-shards", type=int, default=8,
+                    help="N = 1 only: also run the `--gpus N` path with N in-process shards on this one device (`sharded_dry_run`; 0 = skip it)")
     ap.add_argument("--settle", type=int, default=24)
     ap.add_argument("--exhaustive-steps", type=int, default=3,
                     help="extra untimed-for-value steps with pruning off, reported as roofline_exhaustive (0 = skip)")
@@ -1091,6 +1093,42 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
         if isinstance(other, dict) and "error" not in other:
             other["cfg5_vlad_pca_ivfpq"] = cfg5
 
+    # ---------------------------------------------------------------- the 8-GPU configuration's code path on this one device
+    dry = None
+    if rank == 0 and single and args.dry_run_shards > 1 and os.environ.get("MMIDX_BENCH_VIRTUAL_SHARDS") != "1":
+        # `bench.py --gpus 8` exactly as the driver runs it, but with eight IN-PROCESS shards on device 0 (no xGMI, no RCCL: in-process
+        # collectives): what each rank of the 8-GPU run computes per round, and a parity-gated exercise of the sharded handle.  It is
+        # NOT a scaling measurement -- nothing here has run on more than one physical GPU.
+        try:
+            import subprocess
+            if h is not None:
+                chk(L.mmidx_destroy(h))
+                h = None
+            torch.cuda.empty_cache()
+            t0 = time.time()
+            ns = args.dry_run_shards
+            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(ns), "--steps", "6", "--warmup", "2", "--settle", "3", "--hard-steps", "0",
+                   "--spread-steps", "0", "--other-configs", "0", "--extras", "0", "--yfcc-n", "0", "--cfg5-images", "0", "--exhaustive-steps", "0",
+                   "--cpu-seconds", "2", "--dry-run-shards", "0", "--big-batch", "0", "--vectors", str(N), "--batch", str(args.batch)]
+            pr = subprocess.run(cmd, env=dict(os.environ, MMIDX_BENCH_VIRTUAL_SHARDS="1"), capture_output=True, text=True, timeout=420)
+            jl = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+            if pr.returncode == 0 and jl:
+                dj = json.loads(jl[-1])
+                k3 = [l for l in pr.stderr.splitlines() if "K3ma pass A per step" in l]
+                dry = {"n_virtual_shards": ns, "queries_per_s": dj["value"], "queries_per_round": dj["config"]["batch"], "ms_per_round": dj["ms_per_step"],
+                       "ms_per_shard_and_round": round(dj["ms_per_step"] / ns, 4), "parity": dj.get("parity"),
+                       "pass_a": k3[-1].split("] ", 1)[-1] if k3 else "K3h (K3ma off or not applicable)",
+                       "stage_ms_slowest_shard": {"coarse": dj["roofline_whole_search"]["coarse_ms_per_step"], "merge": dj["roofline_whole_search"]["merge_ms_per_step"]},
+                       "path": dj["config"]["multi_gpu_path"], "seconds": round(time.time() - t0, 1),
+                       "note": f"{ns} in-process shards on ONE device (MMIDX_BENCH_VIRTUAL_SHARDS=1): the kernels, the partition, the threshold exchange and the "
+                               "owner-side merge of the 8-GPU configuration run, sharing one GPU -- per-shard work per round, not a scaling figure; "
+                               "UNMEASURED on more than one physical GPU"}
+            else:
+                dry = {"error": f"rc {pr.returncode}", "stderr_tail": pr.stderr[-400:]}
+            log(f"sharded dry run ({ns} virtual shards) in {time.time() - t0:.1f}s: {dry.get('ms_per_shard_and_round')} ms per shard and round")
+        except Exception as e:  # noqa: BLE001
+            dry = {"error": repr(e)}
+
     if rank == 0:
         out = {
             "metric": "queries/sec @ recall@1, IVFPQ 100Mx128-d nprobe=32",
@@ -1114,7 +1152,7 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
             "recall_at_1": recall1, "recall_queries": ngt,
             "roofline": roofline, "roofline_whole_search": whole, "roofline_exhaustive": exhaustive,
             "cpu_baseline": cpu_baseline, "parity": parity, "batch_131072": big, "hard": hard, "spread": spread, "other_configs": other, "cfg5": cfg5, "yfcc": yfcc,
-            "host_path": host, "measured_ceilings": probes,
+            "host_path": host, "measured_ceilings": probes, "sharded_dry_run": dry,
         }
         print(json.dumps(out), file=json_out, flush=True)
         # every published figure once more in ONE short stderr line (<= 2 KB): a driver that keeps only the tail of a run still sees
@@ -1141,6 +1179,7 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
                 "spread": {"Mqps": mq(g(spread, "value")), "passB_ms": g(spread, "stage_ms_per_step", "pass_b"), "mfma_frac": g(spread, "roofline", "frac"),
                            "recall1": g(spread, "recall_at_1"), "parity": ok(g(spread, "parity"))},
                 "exhaustive_frac": g(exhaustive, "frac"),
+                "dry8": {"Mqps": mq(g(dry, "queries_per_s")), "ms_per_shard": g(dry, "ms_per_shard_and_round"), "parity": ok(g(dry, "parity"))},
                 "cfg1_Mqps": mq(g(other, "cfg1_linear_10k", "qps_gpu_host_buffers")), "cfg2_Mqps": mq(g(other, "cfg2_pq_adc_1M", "qps_gpu")),
                 "cfg3_Mqps": mq(g(other, "cfg3_ivfpq_1M", "qps_gpu")), "rot1M_Mqps": mq(g(other, "ivfpq_1M_random_rotation", "qps_gpu")),
                 "m128_Mqps": mq(g(other, "ivfpq_100k_1024d_m128", "qps_gpu")),
