@@ -394,7 +394,10 @@ int mmidx_vlad_create(int nvocab, const int32_t *ncent, int dl, const double *co
                       int normalizations_on, int device, mmidx_vlad **out);
 /* "exact" = 1: the one-kernel form (fp64 brute-force nearest centroid inside the image's block) instead of the default -- the
  * nearest centroid of every descriptor of the call by the encoder's certified bf16-MFMA argmin (identical result: first index wins,
- * AFA:136-155; flagged descriptors redone in fp64), then the ordered accumulation.  A/B and test switch (ABI version 6). */
+ * AFA:136-155; flagged descriptors redone in fp64), then the ordered accumulation.  A/B and test switch (ABI version 6).
+ * "two_pass" = 1 (ABI version 7): assignment and accumulation as two kernels (K8') also where the default one-kernel form K8''
+ * (k_vlad_fused: 64-dimensional descriptors, vocabularies of <= 128 centroids -- one pass over the descriptors, no host
+ * synchronisation inside mmidx_vlad_aggregate_device) applies. */
 int mmidx_vlad_set_option(mmidx_vlad *v, const char *name, int value);
 int mmidx_vlad_destroy(mmidx_vlad *v);
 int mmidx_vlad_vector_length(const mmidx_vlad *v, int *len_out);

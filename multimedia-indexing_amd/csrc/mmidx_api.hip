@@ -3928,6 +3928,7 @@ struct mmidx_vlad {
     std::vector<mmidx_index *> asg;
     DevBuf<int32_t> ws_nn;
     int exact = 0;  // option "exact" / MMIDX_VLAD_EXACT=1: the one-kernel form (k_vlad: fp64 brute-force assignment inside the block)
+    int two_pass = 0;  // option "two_pass": K8' also where K8'' (k_vlad_fused) applies
 };
 
 extern "C" {
@@ -4067,6 +4068,10 @@ int mmidx_vlad_set_option(mmidx_vlad *v, const char *name, int value) {
         v->exact = value != 0;
         return MMIDX_OK;
     }
+    if (std::string(name) == "two_pass") {  // K8' (assignment kernel + accumulation kernel) also where the one-kernel form K8'' applies (A/B switch)
+        v->two_pass = value != 0;
+        return MMIDX_OK;
+    }
     return fail(MMIDX_ERR_INVALID_ARG, "unknown option '%s'", name);
 }
 
@@ -4109,6 +4114,22 @@ int mmidx_vlad_aggregate_device(mmidx_vlad *v, int64_t nimg, const int64_t *d_de
     long long ndesc = -1;  // descriptors of the launch (read back once when the assignment runs as its own stage)
     for (int i = 0; i < v->nvocab; i++) {
         const int nc = v->nc[(size_t)i];
+        if (!v->exact && !v->two_pass && v->asg[(size_t)i] && d_descs && v->dl == 64 && nc <= 128) {
+            // K8'': one kernel, one pass over the descriptors in HBM, no host synchronisation (the flagged descriptors are redone by the
+            // image's own block): 64-dimensional descriptors, vocabularies of at most 128 centroids
+            const mmidx_index *a = v->asg[(size_t)i];
+            if (a->d_Ch && a->Cp == G16_BC && a->Dp >= 64 && a->Dp <= G16_KC) {
+                const size_t lf = 2 * (size_t)G16_BC * (64 * 2 + 16) + 2 * (size_t)maxnd * 4 + (size_t)((nc + 2) & ~1) * 4 + (size_t)(VF_FLAG_CAP + 2) * 4 + 32;
+                if (lf <= 160 * 1024) {
+                    HIPCK(hipFuncSetAttribute((const void *)k_vlad_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lf));
+                    hipLaunchKernelGGL(k_vlad_fused, dim3((unsigned)nimg), dim3(256), lf, st, v->d_cb + v->cb_off[(size_t)i], nc, maxnd, (const __bf16 *)a->d_Ch,
+                                       (const __bf16 *)a->d_Cl, a->d_cn_pad, a->cnorm_max, a->cn_max, a->Dp, (const long long *)d_desc_off, d_descs, d_out, v->veclen,
+                                       (int)v->cb_off[(size_t)i], v->norms);
+                    HIPCK(hipGetLastError());
+                    continue;
+                }
+            }
+        }
         if (!v->exact && v->asg[(size_t)i] && d_descs) {
             // K8': nearest centroid of EVERY descriptor on the matrix cores (certified, exact redo of the flagged few), then one
             // block per image for the ordered accumulation

@@ -412,6 +412,302 @@ __global__ __launch_bounds__(256) void k_vlad_accum(const double *__restrict__ c
     for (int e = tid; e < veclen; e += 256) vout[e] = (norm == 0.0) ? 1.0 : vout[e] / norm;
 }
 
+// K8'' (round 5): VLAD of an image in ONE kernel and one pass over its descriptors in HBM (VladAggregator.java:56-70).  K8' streamed
+// every descriptor twice -- the assignment kernel over all descriptors of the call, then a block per image for the ordered
+// accumulation -- with a host synchronisation between them (the number of flagged descriptors).  Here a block takes an image:
+//   (1) the vocabulary's bf16 head / tail tiles go to LDS once (<= 128 centroids: one tile of K6a');
+//   (2) 128 descriptors at a time: fp64 rows split to bf16 head / tail in registers, d~ = |c|^2 + |x|^2 - 2 x.c on
+//       v_mfma_f32_16x16x32_bf16 (three products), best / second best per row, certified as in k_assign_gmin16_t
+//       (second - best > 2 eps16); the descriptors the bound cannot certify (exact ties included, ~1e-4) are listed in LDS;
+//   (3) those are redone by the block itself in fp64, every sum in dimension order (computeNearestCentroid, AFA:136-155; strict
+//       '<': the first minimum wins) -- identical to the exact argmin, no host round trip;
+//   (4) phases 2-4 of k_vlad_accum: stable per-centroid lists, accumulation in DESCRIPTOR ORDER (the raw VLAD vector is bit-exact),
+//       power + L2.  The rows are read a second time here -- from L2 / the Infinity Cache: the block touched them microseconds ago
+//       (all resident blocks together hold ~130 MB of descriptors).  The row loads are double-buffered (eight rows requested while
+//       the previous eight are added).
+// 64-dimensional descriptors (SURF), vocabularies of <= 128 centroids; other shapes keep K8'.
+#define VF_FLAG_CAP 64
+__global__ __launch_bounds__(256, 2) void k_vlad_fused(const double *__restrict__ codebook, int nc, int maxnd, const __bf16 *__restrict__ Ch,
+                                                       const __bf16 *__restrict__ Cl, const double *__restrict__ cn, double cnorm_max, double cn_max, int Dp,
+                                                       const long long *__restrict__ desc_off, const double *__restrict__ descs, double *__restrict__ out,
+                                                       int out_stride, int out_shift, int norms_on) {
+    constexpr int DL = 64;
+    constexpr int BSTR = DL * 2 + 16;  // bytes per LDS row of the tiles: 64 bf16 + 16 (conflict-free 16-byte fragment reads); 36 KiB for both
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *Bh = smem, *Bl = smem + G16_BC * BSTR;
+    int *nn = (int *)(smem + 2 * G16_BC * BSTR);  // [maxnd]
+    int *lst = nn + maxnd;                              // [maxnd] descriptors grouped by centroid
+    int *cstart = lst + maxnd;                          // [nc + 1]
+    int *flg = cstart + ((nc + 2) & ~1);                // [0] count, [1 ..] flagged descriptors
+    double *red = (double *)(flg + VF_FLAG_CAP + 2);    // [4]
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const long long d0 = desc_off[img];
+    const int nd = (int)(desc_off[img + 1] - d0);
+    const double *Dg = descs + (size_t)d0 * DL;
+    double *vout = out + (size_t)img * out_stride + out_shift;
+    // ---- (1) the vocabulary's tiles (rows = centroids, DL / 8 units of 16 bytes each), counters ----
+    {
+        const int upr = DL >> 3;  // (Dp >= 64: the first 64 columns of a row)
+        for (int u = tid; u < G16_BC * upr; u += 256) {
+            const int row = u / upr, cu = u - row * upr;
+            const size_t src = (size_t)row * Dp + cu * 8;
+            *(uint4 *)(Bh + row * BSTR + cu * 16) = *(const uint4 *)(Ch + src);
+            *(uint4 *)(Bl + row * BSTR + cu * 16) = *(const uint4 *)(Cl + src);
+        }
+        for (int c = tid; c <= nc; c += 256) cstart[c] = 0;
+        if (tid == 0) flg[0] = 0;
+    }
+    __syncthreads();
+    float cn_c[8];
+#pragma unroll
+    for (int ct = 0; ct < 8; ct++) cn_c[ct] = (float)cn[ct * 16 + fr];
+    const float inf = __int_as_float(0x7f800000);
+    auto dppf = [](float v, int ctrl) -> float {
+        switch (ctrl) {
+            case 0: return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));
+            case 1: return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));
+            case 2: return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, true));
+            default: return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xf, 0xf, true));
+        }
+    };
+    auto dppi = [](int v, int ctrl) -> int {
+        switch (ctrl) {
+            case 0: return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);
+            case 1: return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);
+            case 2: return __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true);
+            default: return __builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true);
+        }
+    };
+    // ---- (2) certified assignment, 128 descriptors (32 per wave) at a time ----
+#ifdef VF_SKIP_ASSIGN
+    for (int d = tid; d < nd; d += 256) nn[d] = d & 127;
+#else
+    for (int s0 = 0; s0 < nd; s0 += G16_BQ) {
+        const int q0 = s0 + wave * 32;
+        if (q0 >= nd) continue;  // (wave-uniform; no barrier in this loop)
+        bf16x8 ah[2][2], al[2][2];
+        float xn_r[2][4];
+        double xrow[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++) {
+            int q = q0 + rt * 16 + fr;
+            q = q < nd ? q : nd - 1;
+            double pn = 0.0;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const double2 *xp = (const double2 *)(Dg + (size_t)q * DL + ks * 32 + fg * 8);
+                const double2 v0 = xp[0], v1 = xp[1], v2 = xp[2], v3 = xp[3];
+                const double vv[8] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y};
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float f = (float)vv[e];
+                    const __bf16 hh = (__bf16)f;
+                    ah[rt][ks][e] = hh;
+                    al[rt][ks][e] = (__bf16)(f - (float)hh);  // f - head is exact in fp32
+                    pn += vv[e] * vv[e];
+                }
+            }
+            pn += __shfl_xor(pn, 16);
+            pn += __shfl_xor(pn, 32);
+            xrow[rt] = pn * (1.0 + 1e-12);  // only ever used inside error bounds: rounded up
+#pragma unroll
+            for (int r = 0; r < 4; r++) xn_r[rt][r] = (float)__shfl(xrow[rt], 4 * fg + r);
+        }
+        f32x4 acc[2][8];
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int ct = 0; ct < 8; ct++) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+            for (int ct = 0; ct < 8; ct += 2) {
+                bf16x8 bh[2], bl[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int off = ((ct + u) * 16 + fr) * BSTR + (ks * 32 + fg * 8) * 2;
+                    bh[u] = *(const bf16x8 *)(Bh + off);
+                    bl[u] = *(const bf16x8 *)(Bl + off);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int rt = 0; rt < 2; rt++) {
+                        acc[rt][ct + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bh[u], acc[rt][ct + u], 0, 0, 0);
+                        acc[rt][ct + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt][ks], bl[u], acc[rt][ct + u], 0, 0, 0);
+                        acc[rt][ct + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt][ks], bh[u], acc[rt][ct + u], 0, 0, 0);
+                    }
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float m1 = inf, m2 = inf;
+                int ix = 0;
+#pragma unroll
+                for (int ct = 0; ct < 8; ct++) {
+                    const float dv = (cn_c[ct] + xn_r[rt][r]) - 2.0f * acc[rt][ct][r];
+                    const bool lt1 = dv < m1;
+                    m2 = lt1 ? m1 : (dv < m2 ? dv : m2);
+                    ix = lt1 ? ct * 16 + fr : ix;
+                    m1 = lt1 ? dv : m1;
+                }
+#pragma unroll
+                for (int step = 0; step < 4; step++) {  // the 16 lanes of a row: (best, its index, second best)
+                    const float o1 = dppf(m1, step), o2 = dppf(m2, step);
+                    const int oi = dppi(ix, step);
+                    const bool take = o1 < m1 || (o1 == m1 && oi < ix);
+                    const float hi1 = take ? m1 : o1;
+                    const float lo2 = o2 < m2 ? o2 : m2;
+                    m2 = hi1 < lo2 ? hi1 : lo2;
+                    ix = take ? oi : ix;
+                    m1 = take ? o1 : m1;
+                }
+                const int q = q0 + rt * 16 + 4 * fg + r;
+                const double xnd = __shfl(xrow[rt], 4 * fg + r);
+                if (fr == 0 && q < nd) {
+                    const double xnorm = sqrt(xnd), sumn = cnorm_max + xnorm;
+                    const double eps = (2.0 * 3.1 * 0x1p-16 * xnorm * cnorm_max + 2.0 * (3.0 * (double)Dp + 16.0) * 0x1p-22 * xnorm * cnorm_max +
+                                        1e-12 * (cn_max + xnd) + 0x1p-21 * sumn * sumn) * (1.0 + 1e-9);
+                    const bool sure = ((double)m2 - (double)m1) > 2.0 * eps && sumn * sumn < 1e37;
+                    nn[q] = ix < nc ? ix : nc - 1;
+                    if (!sure) {
+                        const int f = atomicAdd(flg, 1);
+                        if (f < VF_FLAG_CAP) flg[1 + f] = q;
+                    }
+                }
+            }
+    }
+#endif
+#ifdef VF_SKIP_ACCUM
+    return;
+#endif
+    __syncthreads();
+    // ---- (3) the flagged descriptors in fp64 (normally none or one).  More than the list holds: every descriptor is redone. ----
+    {
+        const int nf_raw = flg[0];
+        const bool all = nf_raw > VF_FLAG_CAP;
+        const int nf = all ? nd : nf_raw;
+        for (int f = wave; f < nf; f += 4) {
+            const int q = all ? f : flg[1 + f];
+            const double *x = Dg + (size_t)q * DL;
+            u64 bk = 0xFFFFFFFFFFFFFFFFull;
+            int bi = 0x7fffffff;
+            for (int c = lane; c < nc; c += 64) {
+                const double *cc = codebook + (size_t)c * DL;
+                double a = 0.0;
+                for (int j = 0; j < DL; j++) {
+                    const double df = cc[j] - x[j];
+                    a += df * df;
+                }
+                const u64 k = (u64)__double_as_longlong(a);
+                if (k < bk) {
+                    bk = k;
+                    bi = c;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const u64 ok = __shfl_xor(bk, off);
+                const int oi = __shfl_xor(bi, off);
+                if (ok < bk || (ok == bk && oi < bi)) {
+                    bk = ok;
+                    bi = oi;
+                }
+            }
+            if (lane == 0) nn[q] = bi < nc ? bi : 0;
+        }
+    }
+    __syncthreads();
+    // ---- (4) counts -> starts -> stable lists; ordered accumulation; power + L2 (as k_vlad_accum) ----
+    for (int d = tid; d < nd; d += 256) atomicAdd(cstart + nn[d] + 1, 1);
+    __syncthreads();
+    if (tid < 64) {
+        u32 carry = 0;
+        for (int base = 0; base < nc; base += 64) {
+            const int c = base + tid;
+            const u32 cnt = c < nc ? (u32)cstart[c + 1] : 0u;
+            const u32 incl = wave_incl_scan_u32(cnt);
+            if (c < nc) cstart[c + 1] = (int)(carry + incl);
+            carry += wave_read_u32(incl, 63);
+        }
+        if (tid == 0) cstart[0] = 0;
+    }
+    __syncthreads();
+    for (int c = tid; c < nc; c += 256) {
+        int p = cstart[c];
+        for (int d = 0; d < nd; d++)
+            if (nn[d] == c) lst[p++] = d;
+    }
+    __syncthreads();
+    double ss = 0.0;
+    {
+        const int cpw = (nc + 3) >> 2;
+        const int c_lo = wave * cpw < nc ? wave * cpw : nc, c_hi = c_lo + cpw < nc ? c_lo + cpw : nc;
+        if (c_lo < c_hi) {
+            int c = c_lo, p = cstart[c_lo];
+            const int pe = cstart[c_hi];
+            int cend = cstart[c + 1];
+            double v = 0.0, cv = codebook[(size_t)c * 64 + lane];
+            double cvn = c + 1 < c_hi ? codebook[(size_t)(c + 1) * 64 + lane] : 0.0;
+            auto emit = [&]() {  // element (c, lane) is complete: power normalisation, next centroid
+                if (norms_on) {
+                    const double a = sqrt(fabs(v));  // normalizePower(0.5)   (Normalization.java:74-79)
+                    v = (v > 0.0) ? a : ((v < 0.0) ? -a : v);
+                    ss += v * v;
+                }
+                vout[(size_t)c * 64 + lane] = v;
+                c++;
+                v = 0.0;
+                cv = cvn;
+                if (c < c_hi) cend = cstart[c + 1];
+                if (c + 1 < c_hi) cvn = codebook[(size_t)(c + 1) * 64 + lane];
+            };
+            constexpr int RU = 8;
+            double a[RU], b[RU];
+            auto fetch = [&](double (&dst)[RU], const int pp) {  // rows pp .. pp + 7 of the grouped list (clamped: always valid addresses)
+#pragma unroll
+                for (int u = 0; u < RU; u++) {
+                    const int pu = pp + u < pe ? pp + u : pe - 1;
+                    dst[u] = Dg[(size_t)lst[pu < 0 ? 0 : pu] * 64 + lane];
+                }
+            };
+            auto add8 = [&](const double (&src)[RU], const int pp) {
+                const int n8 = pe - pp < RU ? pe - pp : RU;
+#pragma unroll
+                for (int u = 0; u < RU; u++) {
+                    if (u < n8) {
+                        while (pp + u >= cend) emit();  // (wave-uniform; centroids without descriptors come out as zeros)
+                        v += src[u] - cv;
+                    }
+                }
+            };
+            if (p < pe) fetch(a, p);
+            while (p < pe) {  // two batches per round: one in flight while the other is added
+                if (p + RU < pe) fetch(b, p + RU);
+                add8(a, p);
+                p += RU;
+                if (p >= pe) break;
+                if (p + RU < pe) fetch(a, p + RU);
+                add8(b, p);
+                p += RU;
+            }
+            while (c < c_hi) emit();
+        }
+    }
+    if (!norms_on) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    const double norm = sqrt(red[0] + red[1] + red[2] + red[3]);
+    __syncthreads();
+    const int veclen = nc * 64;
+    for (int e = tid; e < veclen; e += 256) vout[e] = (norm == 0.0) ? 1.0 : vout[e] / norm;
+}
+
 // L2 over the concatenation when more than one vocabulary (VladAggregatorMultipleVocabularies.java:97-99)
 __global__ __launch_bounds__(256) void k_rows_normalize_l2_block(double *__restrict__ Y, int len) {
     __shared__ double red[4];

@@ -33,13 +33,17 @@ def test_vlad_raw_bit_exact(mi, oracle, nc, dl):
         if len(s):
             s /= np.linalg.norm(s, axis=1, keepdims=True)
     agg = mi.VladAggregator(cb)
-    for exact in (0, 1):  # 0: nearest centroids by the certified bf16-MFMA argmin over all descriptors of the call; 1: fp64 brute force in the block
+    # (0, 0): K8'' where it applies (dl = 64, <= 128 centroids: one kernel -- certified bf16-MFMA argmin, flagged descriptors redone in
+    # fp64 by the image's block, ordered accumulation), else K8'; (0, 1): K8' (assignment kernel over all descriptors of the call +
+    # accumulation kernel); (1, 0): fp64 brute force in the block
+    for exact, two in ((0, 0), (0, 1), (1, 0)):
         agg.set_option("exact", exact)
+        agg.set_option("two_pass", two)
         out = agg.aggregate_batch(sets)
         assert out.shape == (len(sets), nc * dl)
         for i, s in enumerate(sets):
             ref = oracle.vlad_aggregate(cb, s)
-            assert np.array_equal(out[i], ref), (exact, i)
+            assert np.array_equal(out[i], ref), (exact, two, i)
         assert np.array_equal(agg.aggregate(sets[3]), oracle.vlad_aggregate(cb, sets[3]))
     agg.close()
 
@@ -55,11 +59,17 @@ def test_vlad_assignment_ties_first_centroid_wins(mi, oracle):
     cb[10] = cb[50]
     sets = [np.concatenate([cb[[3, 50, 7]], cb[3:4] + 1e-9, rng.standard_normal((200, dl))]), cb[[40, 41, 10, 50]].copy()]
     agg = mi.VladAggregator(cb)
-    for exact in (0, 1):
+    for exact, two in ((0, 0), (0, 1), (1, 0)):
         agg.set_option("exact", exact)
+        agg.set_option("two_pass", two)
         out = agg.aggregate_batch(sets)
         for i, s in enumerate(sets):
-            assert np.array_equal(out[i], oracle.vlad_aggregate(cb, s)), (exact, i)
+            assert np.array_equal(out[i], oracle.vlad_aggregate(cb, s)), (exact, two, i)
+    # more uncertifiable descriptors in one image than the fused kernel's list holds (64): every descriptor of the image is redone
+    many = [np.concatenate([cb[[3, 50]]] * 60 + [rng.standard_normal((30, dl))])]
+    agg.set_option("exact", 0)
+    agg.set_option("two_pass", 0)
+    assert np.array_equal(agg.aggregate_batch(many)[0], oracle.vlad_aggregate(cb, many[0]))
     agg.close()
 
 
