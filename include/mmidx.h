@@ -354,6 +354,10 @@ int mmidx_set_profiling(mmidx_index *h, int enabled);
  * by default on two or more physical devices until a multi-device run has passed).  None of them changes a result. */
 int mmidx_set_option(mmidx_index *h, const char *name, int value);
 int mmidx_get_stats(mmidx_index *h, mmidx_stats *out);
+/* Which kernel family served each stage of the most recent search sub-batch of this handle (ABI version 7), as text:
+ * "coarse=<K1..>;pass_a=<K3 | K3h | K3ma | ..>;pre=<K3s | ->;pass_b=<K3m | K3mk | K3g | K3f.. | ->" (DESIGN.md section 5.0 lists the gates;
+ * tests/test_gpu_dispatch.py asserts the table).  A sharded handle reports its first shard.  Diagnostic: not a stable format. */
+int mmidx_get_dispatch(mmidx_index *h, char *out, int cap);
 
 /* Measured ceilings for the rooflines bench.py reports (csrc/mmidx_probe.hip; SURVEY 8d "secondary: LDS gather rate", A5):
  * mmidx_probe_lds_gather: the gather of the exact scan alone -- per code m random 8-byte LDS reads over 2 KiB rows, summed

@@ -127,6 +127,7 @@ SIGNATURES = {
     "mmidx_set_profiling": (C.c_int, [_vp, C.c_int]),
     "mmidx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "mmidx_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
+    "mmidx_get_dispatch": (C.c_int, [_vp, C.c_char_p, C.c_int]),
 }
 
 

@@ -328,6 +328,8 @@ struct mmidx_index {
     size_t ev_used = 0;
     std::vector<hipEvent_t> mf_ev;   // K3m, full profiling: groups of 3 (scan start, scan end, verification end)
     size_t mf_ev_used = 0;
+    // which kernel family served each stage of the most recent search sub-batch (mmidx_get_dispatch; host-side words, a few stores per call)
+    const char *disp_coarse = "-", *disp_passa = "-", *disp_passb = "-", *disp_pre = "-";
     // K3ma (pass A on the matrix cores, mmidx_scan_mfma_a.h)
     int passa_mfma = -1;               // option "passa_mfma": 1 always (where the shape allows), 0 never, -1 = from 8 queries per list of a long-list index
     int a_wide = 1;                    // option "passa_mfma_wide": 0 = K3ma's sweeps by the four-wave instance alone (A/B switch)
@@ -366,6 +368,7 @@ int sharded_distance(mmidx_index *h, int64_t n, const double *Q, const int32_t *
 int sharded_get_stats(mmidx_index *h, mmidx_stats *out);
 int sharded_set_option(mmidx_index *h, const char *name, int value);
 int sharded_for_each(mmidx_index *h, const std::function<int(mmidx_index *)> &f);
+const mmidx_index *sharded_first(const mmidx_index *h);
 int64_t sharded_total(const mmidx_index *h);
 constexpr int32_t MMIDX_IID_AUTO = INT32_MIN;  // sharded_add_vectors: number the vectors from the handle's total, read under its lock
 void sharded_destroy(mmidx_index *h);
@@ -1831,14 +1834,18 @@ int launch_scan_grouped(mmidx_index *h, const ScanParams &P, const SearchPlan &p
         const int32_t seen = *(volatile int32_t *)h->pin_hint;
         if (seen >= 0 && seen <= 64) {
             const unsigned gx = (unsigned)(((P.n_items + 7) / 8) * 8);
+            h->disp_passb = "K3f(one looping launch: the call before kept <= 64 pairs)";
             return launch_scan_filtered(h, P, pl, dim3(gx, (unsigned)pl.nchunks), st, -1);
         }
     }
     if (P.ivf) {
+        h->disp_passb = h->D > 128 ? "K3mk" : "K3m";
         const int rcm = launch_mfma_common(h, P, P, pl, h->C, pl.nchunks, npairs, h->max_list_len, st, nq, nullptr);
         if (rcm != 1) return rcm;
     }
+    h->disp_passb = "K3f";
     if (h->no_grp || !h->grp_valid || !h->d_pq32T || h->no_filter || P.sdc_tt || !P.ivf || h->max_list_len >= (1 << 24)) return 1;
+    h->disp_passb = "K3g";
     return launch_grouped_common(h, P, P, pl, h->C, pl.nchunks, npairs, st, nq);
 }
 
@@ -1888,10 +1895,13 @@ int launch_scan_grouped_flat(mmidx_index *h, const ScanParams &P, const SearchPl
         flat_lut = h->ws_flatlut.p;
     }
     if (mf_ok) {
+        h->disp_passb = h->D > 128 ? "K3mk" : "K3m";
         const int rcm = launch_mfma_common(h, S, P, pl, nch, 1, npairs, pl.chunk, st, nq, flat_lut);
         if (rcm != 1) return rcm;
     }
+    h->disp_passb = "K3f";
     if (!grp_ok) return 1;
+    h->disp_passb = "K3g";
     return launch_grouped_common(h, S, P, pl, nch, 1, npairs, st, nq, flat_lut);
 }
 
@@ -1967,6 +1977,7 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
             A.defer = h->ws_defer.p;
             const bool wave_sel = h->coarse_wave_sel && h->w < 64 && (h->D == 64 || h->D == 128 || h->D == 256);
             const unsigned fgrid = (unsigned)((nq + 3) / 4);
+            h->disp_coarse = wave_sel ? "K1e'+K1f(front_sel)" : "K1e'+K1f(front+select_list)";
             if (wave_sel && h->D == 128) hipLaunchKernelGGL((k_coarse_front_sel<8>), dim3(fgrid), dim3(MMIDX_BLOCK), 0, st, A);
             else if (wave_sel && h->D == 64) hipLaunchKernelGGL((k_coarse_front_sel<4>), dim3(fgrid), dim3(MMIDX_BLOCK), 0, st, A);
             else if (wave_sel) hipLaunchKernelGGL((k_coarse_front_sel<16>), dim3(fgrid), dim3(MMIDX_BLOCK), 0, st, A);
@@ -1979,17 +1990,23 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
                 hipLaunchKernelGGL(k_coarse_select_list<8>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), glds, st, A);
             else
                 hipLaunchKernelGGL(k_coarse_select_list<32>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), glds, st, A);
-        } else if (h->C <= 8 * MMIDX_BLOCK)
+        } else if (h->C <= 8 * MMIDX_BLOCK) {
+            h->disp_coarse = "K1e'+K1f(select_grp)";
             hipLaunchKernelGGL(k_coarse_select_grp<8>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), glds, st, A);
-        else if (h->C <= 32 * MMIDX_BLOCK)
+        }
+        else if (h->C <= 32 * MMIDX_BLOCK) {
+            h->disp_coarse = "K1e'+K1f(select_grp)";
             hipLaunchKernelGGL(k_coarse_select_grp<32>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), glds, st, A);
-        else
+        } else {
+            h->disp_coarse = "K1e'+K1f(select_grp)";
             hipLaunchKernelGGL(k_coarse_select_grp<64>, dim3((unsigned)nq), dim3(MMIDX_BLOCK), glds, st, A);
+        }
         HIPCK(hipGetLastError());
         h->cdsel_valid = true;
         return MMIDX_OK;
     }
     if (approx) {
+        h->disp_coarse = "K1c+K1d";
         // K1c + K1d: fp32 dot products for all centroids, fp64 only for the certified candidates
         HIPCK(h->ws_Q32.reserve((size_t)nq * h->D));
         HIPCK(h->ws_qn.reserve((size_t)nq));
@@ -2023,6 +2040,7 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
         h->cdsel_valid = true;
         return MMIDX_OK;
     }
+    h->disp_coarse = "K1a+K1b(exact)";
     dim3 g1((unsigned)((h->C + MMIDX_BLOCK - 1) / MMIDX_BLOCK), (unsigned)((nq + QT - 1) / QT));
     hipLaunchKernelGGL(k_coarse_dist<QT>, g1, dim3(MMIDX_BLOCK), 0, st, h->d_coarseT, dQ, h->ws_cdist.p, h->C, h->D, (int)nq);
     const size_t lds = (size_t)(h->w + 1) * 12 + 16;
@@ -2152,19 +2170,27 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
         //  measured faster: 1.23 vs ~1.4 ms per 8192 queries; MMIDX_PASSA_FILTER=1 switches)
         int rc = MMIDX_OK;
         if (phase != 2) {
+            h->disp_passb = "-";
+            h->disp_pre = "-";
+            if (!ivf) h->disp_coarse = "-";
             if (two_pass && passa_mfma_applies(h, P, pl, (long long)nq)) {
                 // K3ma: >= 8 queries per nearest list -- the list-major matrix-core form (mmidx_scan_mfma_a.h)
+                h->disp_passa = "K3ma";
                 rc = launch_passa_mfma(h, P, pl, (long long)nq, st);
                 pcount_zeroed = false;  // (its pair sort counted in ws_pcount)
             } else if (h->passa_filter) {
+                h->disp_passa = "K3f";
                 rc = launch_scan_filtered(h, P, pl, dim3((unsigned)P.n_items, (unsigned)grid_chunks), st);
             } else if (!h->no_seed) {
+                h->disp_passa = "K3seed";
                 rc = launch_scan_seeded(h, P, pl, dim3((unsigned)P.n_items, (unsigned)grid_chunks), st);
             } else if (two_pass && !sdc_tt && h->passa_hist != 0 &&
                        (h->passa_hist > 0 || h->n_csr / std::max<int64_t>(1, ivf ? h->nonempty_lists : 1) >= 4096) &&
                        (rc = launch_scan_hist(h, P, pl, dim3((unsigned)P.n_items, (unsigned)grid_chunks), st)) != 1) {
                 // (K3h ran -- its empty fallback launch is not counted as a scan launch -- or failed with rc > 1)
+                h->disp_passa = "K3h";
             } else {
+                h->disp_passa = pl.glut ? "K3(table in global scratch)" : (two_pass ? "K3" : "K3(single pass)");
                 rc = MMIDX_OK;
                 // one code per thread per segment: smaller candidate buffer -> a fourth block per CU
                 ScanParams PA = P;
@@ -2221,6 +2247,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
             P.nrank = P.w - 1;
             P.n_items = (int)(nq * P.nrank);
             P.xcd_remap = 0;
+            h->disp_passb = "K3f";
             rc = launch_scan_grouped_flat(h, P, pl, (long long)nq, st);
             if (rc == 1) rc = launch_scan_filtered(h, P, pl, dim3((unsigned)P.n_items, 1), st);
             if (rc) return rc;
@@ -2294,6 +2321,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
                 }
             }
             h->pre_on = use_pre;
+            h->disp_pre = use_pre ? "K3s" : "-";
             if (use_pre) {
                 HIPCK(h->ws_cand.reserve((size_t)npairs + 4));
                 HIPCK(h->ws_smin.reserve((size_t)npairs));
@@ -2413,6 +2441,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
             P.n_order = h->ws_pstart.p + h->C;
             P.n_items = (int)(nq * (P.w - 1));
             P.xcd_remap = 1;
+            h->disp_passb = "K3f";
             rc = launch_scan_grouped(h, P, pl, (long long)nq, npairs, st);
             if (rc == 1) {
                 const unsigned gx = (unsigned)(((P.n_items + 7) / 8) * 8);
@@ -3792,6 +3821,17 @@ int lookup_records(mmidx_index *h, int64_t n, const int32_t *iids, int32_t **d_p
     return MMIDX_OK;
 }
 }  // namespace
+
+int mmidx_get_dispatch(mmidx_index *h, char *out, int cap) {
+    if (!h || !out || cap < 1) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    const mmidx_index *s = h->grp ? sharded_first(h) : h;
+    // (launch_scan_filtered / launch_scan: K3f falls back to the exact scan K3 for shapes it has no instance of)
+    const bool k3f_ok = s->code_bytes == 1 && s->ks <= 256 && (s->m == 8 || s->m == 16 || s->m == 32) && !s->no_filter;
+    const char *pb = s->disp_passb;
+    if (!k3f_ok && pb[0] == 'K' && pb[1] == '3' && pb[2] == 'f') pb = "K3(exact scan: no K3f instance for this shape)";
+    snprintf(out, (size_t)cap, "coarse=%s;pass_a=%s;pre=%s;pass_b=%s", s->disp_coarse, s->disp_passa, s->disp_pre, pb);
+    return MMIDX_OK;
+}
 
 int mmidx_get_dims(const mmidx_index *h, int *D, int *m, int *ks, int *C, int *code_bytes) {
     if (!h) return fail(MMIDX_ERR_INVALID_ARG, "null handle");

@@ -247,7 +247,9 @@ __global__ __launch_bounds__(A1R_NT) void k_a1_records(const MfmaParams P) {
 // the pair records precomputed slot by slot, the NEXT round's records and slot range requested a round ahead, and the slices
 // double-buffered in LDS AND in registers (slice s + 2 is requested while slice s is used and slice s + 1, requested an iteration ago,
 // is stored: one barrier per sub-quantizer, two iterations for the L2 round trip; the loads carry no predicate -- behind a predicated
-// load the compiler waits for ALL outstanding loads).  Entries are 16 bytes apart from a multiple of 64 and rows 16 bytes apart from a
+// load the compiler waits for ALL outstanding loads).  (Two slices per barrier interval -- four LDS buffers, the next interval's two
+// slices requested while this one's are used -- measured SLOWER, 0.90 -> 1.23 ms: the store of the prefetched pair then waits for
+// loads issued in the same interval.)  Entries are 16 bytes apart from a multiple of 64 and rows 16 bytes apart from a
 // multiple of 256, so that the 16 lanes of a ds_read_b128 group spread over all banks (a 64-byte stride leaves them 4 slots).
 #define A1V_NT(dsub) ((dsub) >= 16 ? 512 : 1024)    // (16-dimensional entries: 64 registers of operands per record -- eight waves with 256 registers each)
 #define A1V_RND(dsub) ((dsub) >= 16 ? 512 : 2048)   // records per round

@@ -1164,6 +1164,8 @@ int sharded_get_stats(mmidx_index *h, mmidx_stats *out) {
     return MMIDX_OK;
 }
 
+const mmidx_index *sharded_first(const mmidx_index *h) { return h->grp->sub[0]; }
+
 int sharded_for_each(mmidx_index *h, const std::function<int(mmidx_index *)> &f) {
     for (mmidx_index *s : h->grp->sub) {
         int rc = f(s);

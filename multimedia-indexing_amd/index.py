@@ -373,6 +373,12 @@ class _PQBase(AbstractSearchStructure):
         N.check(N.lib().mmidx_get_stats(self._h, C.byref(s)))
         return {f: getattr(s, f) for f, _ in N.Stats._fields_}
 
+    def get_dispatch(self):
+        """which kernel family served each stage of the most recent search sub-batch: {"coarse": .., "pass_a": .., "pre": .., "pass_b": ..}"""
+        buf = C.create_string_buffer(512)
+        N.check(N.lib().mmidx_get_dispatch(self._h, buf, 512))
+        return dict(kv.split("=", 1) for kv in buf.value.decode().split(";"))
+
     @staticmethod
     def transformToByte(code):
         """PQ.transformToByte, PQ.java:552-558"""
