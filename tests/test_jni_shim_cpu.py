@@ -104,6 +104,9 @@ def test_java_crosscheck_tooling_round_trip(tmp_path):
         for dim in (3, 8, 128):
             f.write(",".join([str(dim)] + [str(int(x)) for x in o.random_permutation(1, dim)]) + "\n")
     for name in os.listdir(fx):
+        if not os.path.exists(os.path.join(fx, name, "expected.answers.csv")):  # (the RandomRotation case: tests/test_crosscheck_tools_cpu.py plays CrossCheck's part for it)
+            shutil.rmtree(os.path.join(fx, name))
+            continue
         shutil.copy(os.path.join(fx, name, "expected.answers.csv"), os.path.join(out, name + ".answers.csv"))
         meta = open(os.path.join(fx, name, "meta.csv")).read().strip().split(",")
         assert len(meta) == 9
