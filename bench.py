@@ -1187,7 +1187,7 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
                 "cfg5": {"pca_TF": g(cfg5, "pca_8192_to_128", "tflops_f64"), "pca_frac": g(cfg5, "pca_8192_to_128", "roofline", "frac"),
                          "vlad_Mimg": mq(g(cfg5, "vlad_surf64_128_centroids", "images_per_s")), "vlad_frac": g(cfg5, "vlad_surf64_128_centroids", "roofline", "frac"),
                          "fused_Mimg": mq(g(cfg5, "fused_descriptors_to_128d", "images_per_s")), "e2e_self_hit": g(cfg5, "end_to_end", "self_hit_rate"),
-                         "e2e_oracle_self_hit": g(cfg5, "end_to_end", "oracle_self_hit_rate")},
+                         "e2e_exact_self_hit": g(cfg5, "end_to_end", "exact_self_hit_rate")},
                 "yfcc": {kk: {"Mqps": mq(g(yfcc, kk, "queries_per_s")), "passA_frac": g(yfcc, kk, "roofline", "frac"),
                               "passB_ms": g(yfcc, kk, "stage_ms_per_step", "pass_b"), "passB_mfma_frac": g(yfcc, kk, "pass_b", "roofline", "frac"),
                               "parity": ok(g(yfcc, kk, "parity"))} for kk in ("w2", "w64", "w64_between_clusters")} if isinstance(yfcc, dict) and "error" not in yfcc else None}

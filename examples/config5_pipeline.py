@@ -168,6 +168,15 @@ def run_device(n_images=100_000, n_queries=256, k=10, seed=0, cells=1024, w=8, c
     Qd = torch.empty(nq, nc_out, dtype=torch.float64, device=dev)
     nat.check(L.mmidx_vectorize_device(vlad._h, pca._h, nq, qoff.data_ptr(), qd.data_ptr(), qmx, Qd.data_ptr(), stream))
     torch.cuda.synchronize()
+    # what the DATA allows: the exact fp64 nearest neighbour (Linear semantics) of every query among the 128-d vectors -- is it the
+    # image the query was re-rendered from?  (the engine's self-hit rate below cannot exceed what 16-byte codes make of this)
+    xn = (X * X).sum(1)
+    exact_hits = 0
+    for q0 in range(0, nq, 256):
+        dd = xn[None, :] - 2.0 * (Qd[q0:q0 + 256] @ X.T)
+        exact_hits += int((dd.argmin(1) == torch.arange(q0, min(q0 + 256, nq), device=dev)).sum().item())
+    exact_self_hit = exact_hits / max(1, nq)
+    del xn
     Xh, Q = X.cpu().numpy(), Qd.cpu().numpy()
     D, m, ks = nc_out, 16, 256
     t0 = time.time()
@@ -188,6 +197,10 @@ def run_device(n_images=100_000, n_queries=256, k=10, seed=0, cells=1024, w=8, c
     iids, dists, counts = ix.search_batch(k, Q)
     t_search = time.time() - t0
     out = {"images": n_images, "queries": int(nq), "k": k, "self_hit_rate": float(np.mean(iids[:, 0] == np.arange(nq))),
+           "exact_self_hit_rate": exact_self_hit,
+           "self_hit_note": "self_hit_rate: IVFPQ top-1 = the re-rendered image; exact_self_hit_rate: the same with exact fp64 brute force over the 128-d vectors "
+                            "(what the synthetic data allows before any quantization); engine and oracle agree bit for bit on this pipeline "
+                            "(tests/test_gpu_frontend.py::test_config5_pipeline_end_to_end)",
            "images_per_s_front_end": round(n_images / t_front, 1),
            "seconds": {"synthesis_and_front_end": round(t_front, 2), "learn_quantizers": round(t_learn, 2), "index": round(t_index, 3),
                        "search": round(t_search, 4)}}

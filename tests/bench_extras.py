@@ -10,6 +10,7 @@
 """
 import ctypes as C
 import importlib
+import json
 import os
 import subprocess
 import sys
@@ -153,14 +154,23 @@ def cfg5(L, nat, mi, images_e2e=1_000_000, device=0):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / R
     vb = float(tot) * dl * 8
+    try:
+        vtr = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "hbm_traffic.json"))).get("vlad", {})
+    except Exception:  # noqa: BLE001
+        vtr = {}
     out["vlad_surf64_128_centroids"] = {"images": nimg, "descriptors": tot, "ms": round(dt * 1e3, 3), "images_per_s": round(nimg / dt, 1),
                                         "f64_triples_per_s": round(tot * ncent * dl / dt, 1),
-                                        "roofline": {"bound": "hbm", "kernel": "k_assign_gmin16_t<true> (nearest centroid of every descriptor: bf16-split MFMA, certified, "
-                                                                             "fp64 rows split in registers) + k_vlad_accum (ordered accumulation)",
+                                        "roofline": {"bound": "hbm", "kernel": "k_vlad_fused (K8'': a block per image -- nearest centroid of its descriptors by the certified bf16-split MFMA "
+                                                                             "argmin, flagged ones redone in fp64 in the block, ordered accumulation, power + L2)",
                                                      "achieved": round(vb / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(vb / dt / 8e12, 4),
-                                                     "algorithmic_bytes_per_launch": vb, "traffic": None,
-                                                     "note": "algorithmic bytes = the descriptors once (n x 64 x 8); the two kernels each stream them (the accumulation needs "
-                                                             "every assignment of an image first), so 0.5 is this formulation's ceiling; round 3's one-kernel fp64 brute force: 0.94 M images/s"}}
+                                                     "algorithmic_bytes_per_launch": vb,
+                                                     "traffic": vtr.get("k_vlad_fused_fetch_bytes_per_launch") if vtr.get("descriptors") == tot else None,
+                                                     "traffic_written": vtr.get("k_vlad_fused_write_bytes_per_launch") if vtr.get("descriptors") == tot else None,
+                                                     "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 / WRITE_SIZE, separate pass: profiles/r05_vlad_pmc_kernels.txt)",
+                                                     "note": "algorithmic bytes = the descriptors once (n x 64 x 8).  One kernel and no host synchronisation, but the block reads its "
+                                                             "image's rows twice (assignment, then accumulation in centroid-grouped order) and the second read reaches the fabric "
+                                                             "again (FETCH_SIZE = 2.3 x algorithmic); 70 % of the wave cycles are waits at three blocks per CU: latency-bound "
+                                                             "phases inside a block (DESIGN.md 5.5).  Round 4's two kernels: 4.8 M images/s; round 3's fp64 brute force: 0.94 M"}}
     hp2 = C.c_void_p()
     mean_v = V.mean(0).cpu().numpy()
     nat.check(L.mmidx_pca_create(nc, ss, 1, mean_v.ctypes.data, eig_h.ctypes.data, Vt_h.ctypes.data, device, C.byref(hp2)))

@@ -217,12 +217,20 @@ def run(n=95_213_780, D=1024, m=64, ks=256, Cc=8192, k=30, ws=(2, 64), batch=409
         # over a 128 KiB table): algorithmic bytes = m x the codes of the nearest lists / its launch time (HIP events of the profiled steps)
         pa_ms = st.passa_ms / max(1, st.passa_launches)
         pa_bytes = float(m) * st.passa_codes / max(1, st.passa_launches)
+        try:  # physical HBM bytes per launch: separate rocprofv3 --pmc FETCH_SIZE passes of this workload (x 2 on gfx950), profiles/
+            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get("yfcc", {})
+        except Exception:  # noqa: BLE001
+            tj = {}
+        same_wl = (n, D, m, Cc, batch) == tuple(tj.get("workload", ())) if tj else False
         if pa_ms > 0:
             gbps = pa_bytes / (pa_ms * 1e-3) / 1e9
             r["roofline"] = {"bound": "hbm", "kernel": "k_scan_hist<64, 256, 1024> (pass A)", "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s",
-                             "frac": round(gbps / 8000.0, 4), "algorithmic_bytes_per_launch": pa_bytes, "avg_launch_ms": round(pa_ms, 4), "traffic": None,
-                             "note": "bound by the LDS gather of the exact fp64 table (64 random 8-byte reads per code) and by the exposed table build "
-                                     "(2 MiB of codebook per query from L2, one block per CU), not by HBM: DESIGN.md 5.13"}
+                             "frac": round(gbps / 8000.0, 4), "algorithmic_bytes_per_launch": pa_bytes, "avg_launch_ms": round(pa_ms, 4),
+                             "traffic": tj.get("k_scan_hist_fetch_bytes_per_launch") if same_wl else None,
+                             "traffic_source": "profiles/hbm_traffic.json (FETCH_SIZE x 2, separate pass)" if same_wl else None,
+                             "note": "bound by the LDS gather of the exact fp64 table (64 random 8-byte reads per code: 5 LDS cycles per wave-read with its "
+                                     "bank conflicts = 0.4 of the HBM peak at 64-byte codes); the table itself comes prebuilt from k_lut_pre (128 KiB per "
+                                     "query copied into LDS: 3 us of a 64 us item), not by HBM: DESIGN.md 5.2"}
         pb_ms_ = (st.scan_ms - st.passa_ms) / nd
         if int(st.passb_items_last) > 0 and pb_ms_ > 0:
             far_codes = (st.scan_codes - st.passa_codes) / nd  # codes of every probed far list (scanned or not)
@@ -237,7 +245,8 @@ def run(n=95_213_780, D=1024, m=64, ks=256, Cc=8192, k=30, ws=(2, 64), batch=409
                 kept = int(st.passb_items_last) / max(1.0, batch * (w - 1.0))
                 tf = 2.0 * D * far_codes * kept / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
                 r["pass_b"]["roofline"] = {"bound": "mfma", "kernel": "k_scan_mfma_kc2 (K3mk)", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                                           "frac": round(tf / 2500.0, 4), "avg_launch_ms": round(scan_ms, 3), "traffic": None,
+                                           "frac": round(tf / 2500.0, 4), "avg_launch_ms": round(scan_ms, 3),
+                                           "traffic": tj.get("k_scan_mfma_kc2_fetch_bytes_per_launch") if (same_wl and w == 64 and kept > 0.9) else None,
                                            "note": "fp16 MFMA lower bound over all codes of the kept pairs' lists; co-limited by the LDS gather of the "
                                                    "decoded codebook rows (16 bytes per code, 8 dimensions and 32 queries; ~3-way bank conflicts "
                                                    "of random 16-byte rows), DESIGN.md 5.3"}
