@@ -1978,9 +1978,9 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
             const bool wave_sel = h->coarse_wave_sel && h->w < 64 && (h->D == 64 || h->D == 128 || h->D == 256);
             const unsigned fgrid = (unsigned)((nq + 3) / 4);
             h->disp_coarse = wave_sel ? "K1e'+K1f(front_sel)" : "K1e'+K1f(front+select_list)";
-            if (wave_sel && h->D == 128) hipLaunchKernelGGL((k_coarse_front_sel<8>), dim3(fgrid), dim3(MMIDX_BLOCK), 0, st, A);
-            else if (wave_sel && h->D == 64) hipLaunchKernelGGL((k_coarse_front_sel<4>), dim3(fgrid), dim3(MMIDX_BLOCK), 0, st, A);
-            else if (wave_sel) hipLaunchKernelGGL((k_coarse_front_sel<16>), dim3(fgrid), dim3(MMIDX_BLOCK), 0, st, A);
+            if (wave_sel && h->D == 128) hipLaunchKernelGGL((k_coarse_front_sel<8>), dim3((unsigned)nq), dim3(64), 0, st, A);  // (a wave a block)
+            else if (wave_sel && h->D == 64) hipLaunchKernelGGL((k_coarse_front_sel<4>), dim3((unsigned)nq), dim3(64), 0, st, A);
+            else if (wave_sel) hipLaunchKernelGGL((k_coarse_front_sel<16>), dim3((unsigned)nq), dim3(64), 0, st, A);
             else hipLaunchKernelGGL(k_coarse_front, dim3(fgrid), dim3(MMIDX_BLOCK), 0, st, A);
             if (wave_sel) {
                 const unsigned dgrid = (unsigned)std::min<long long>(nq, 2ll * std::max(h->num_cus, 8));

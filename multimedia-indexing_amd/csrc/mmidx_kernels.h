@@ -1855,9 +1855,9 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_front(const ApproxSel A)
     for (int i = 0; i < GPL; i++) {
         const int g = lane + 64 * i;
         const int gc = g < G ? g : G - 1;
-        const float2 v = A.gpair[(size_t)q * G + gc];  // (unconditional load on a clamped index)
-        m1[i] = g < G ? (v.x < 0.0f ? 0.0f : v.x) : inf;  // exact distances are >= 0
-        ry[i] = g < G ? v.y : inf;
+        const float2 v = A.gpair[(size_t)q * G + gc];  // (a load on a clamped index whose value every lane uses: see k_coarse_front_sel)
+        m1[i] = fmaxf(v.x, g < G ? 0.0f : inf);  // exact distances are >= 0; a group past the end never qualifies
+        ry[i] = v.y;
         km[i & 3] = m1[i] < km[i & 3] ? m1[i] : km[i & 3];
     }
     // ---- tau: the R-th smallest of the 256 partial minima (R distinct centroids lie at or below it): bisection on the bit
@@ -1918,20 +1918,18 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_front(const ApproxSel A)
 // query, 24 rows of terms through LDS, then one lane per candidate adding them up while 230 lanes wait).  NJB = D / 16 blocks of
 // dimensions; the keys are the staged form's bit for bit (same operations in the same order).  The queries it cannot serve keep their
 // candidate list and are appended to A.defer: k_coarse_select_defer (k_coarse_select_list over that list) answers them.
+// A block is ONE wave: the queries' lifetimes differ by a factor of three (33 to 64 candidates, hits and misses of their rows), and in
+// a block of four a finished wave's registers and LDS waited for the slowest one -- 67 % of the wave slots busy, 84 -> 62 us.
 template <int NJB>
-__global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_front_sel(const ApproxSel A) {
+__global__ __launch_bounds__(64, 4) void k_coarse_front_sel(const ApproxSel A) {
     constexpr int GPL = 16;  // groups per lane: G <= 1024 (the host checks)
-    constexpr int NW = MMIDX_BLOCK / 64;
-    __shared__ double s_terms[NW][16][65];
-    __shared__ u64 s_ckey[NW][64], s_selk[NW][64];
-    __shared__ u32 s_cidx[NW][64];
-    __shared__ int s_seli[NW][64];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int q = (int)blockIdx.x * NW + wv;
-    if (q >= A.nq) return;  // (wave-uniform; the kernel has no block barrier)
-    u64 *ckey = s_ckey[wv], *sel_k = s_selk[wv];
-    u32 *cidx = s_cidx[wv];
-    int *sel_i = s_seli[wv];
+    __shared__ __attribute__((aligned(16))) double s_terms[16][65];  // the exact stage's tile; the keys and the selection live in it afterwards
+    __shared__ u32 s_cidx[64];
+    const int lane = threadIdx.x;
+    const int q = (int)blockIdx.x;
+    u64 *ckey = (u64 *)&s_terms[0][0], *sel_k = ckey + 64;
+    u32 *cidx = s_cidx;
+    int *sel_i = (int *)(sel_k + 64);
     const int C = A.C, w = A.w, G = A.G, D = A.D;
     const int R = w + 1;
     const double qn = A.qn[q];
@@ -1942,6 +1940,12 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_front_sel(const ApproxSe
     const float inf = __int_as_float(0x7f800000);
     u32 *list = A.clist + (size_t)q * MMIDX_CLIST;
     u32 n = 0;  // wave-uniform
+#ifdef CFS_TIMING
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, t0 = __builtin_readcyclecounter(), t1;
+#define CFS_TICK(i) do { t1 = __builtin_readcyclecounter(); tacc[i] += t1 - t0; t0 = t1; } while (0)
+#else
+#define CFS_TICK(i) do { } while (0)
+#endif
     {
         float m1[GPL], ry[GPL];
         float km[4] = {inf, inf, inf, inf};
@@ -1949,9 +1953,12 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_front_sel(const ApproxSe
         for (int i = 0; i < GPL; i++) {
             const int g = lane + 64 * i;
             const int gc = g < G ? g : G - 1;
-            const float2 v = A.gpair[(size_t)q * G + gc];  // (unconditional load on a clamped index)
-            m1[i] = g < G ? (v.x < 0.0f ? 0.0f : v.x) : inf;  // exact distances are >= 0
-            ry[i] = g < G ? v.y : inf;
+            const float2 v = A.gpair[(size_t)q * G + gc];
+            // (a load on a clamped index ...
+            // ... whose value every lane USES: written as selects of v the compiler sank each load into its own `g < G` block with a
+            //     full wait behind it -- sixteen memory round trips in a row, a quarter of this kernel's time)
+            m1[i] = fmaxf(v.x, g < G ? 0.0f : inf);  // exact distances are >= 0; a group past the end never qualifies
+            ry[i] = v.y;                              // (read only for a group that qualifies)
             km[i & 3] = m1[i] < km[i & 3] ? m1[i] : km[i & 3];
         }
         // ---- tau: the R-th smallest of the 256 partial minima, by bisection on the bit patterns (as k_coarse_front)
@@ -1961,7 +1968,10 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_front_sel(const ApproxSe
                       k2 = (u32)__float_as_int(km[2]) & 0x7fffffffu, k3 = (u32)__float_as_int(km[3]) & 0x7fffffffu;
             const u32 mn01 = k0 < k1 ? k0 : k1, mn23 = k2 < k3 ? k2 : k3, mx01 = k0 < k1 ? k1 : k0, mx23 = k2 < k3 ? k3 : k2;
             u32 lo_k = wave_min_u32(mn01 < mn23 ? mn01 : mn23), hi_k = wave_max_u32(mx01 < mx23 ? mx23 : mx01);
-            while (lo_k < hi_k) {
+            CFS_TICK(0);
+            // (hi_k always has >= R values at or under it: stopping 12 bits early leaves a tau at most 2^-11 above the R-th smallest --
+            //  a few candidates more at most, the exact stage decides either way -- and saves a dozen dependent rounds)
+            while (hi_k - lo_k > 0xFFFu) {
                 const u32 mid = lo_k + ((hi_k - lo_k) >> 1);
                 const int c = (int)__popcll(__builtin_amdgcn_ballot_w64(k0 <= mid)) + (int)__popcll(__builtin_amdgcn_ballot_w64(k1 <= mid)) +
                               (int)__popcll(__builtin_amdgcn_ballot_w64(k2 <= mid)) + (int)__popcll(__builtin_amdgcn_ballot_w64(k3 <= mid));
@@ -1970,6 +1980,7 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_front_sel(const ApproxSe
             }
             tau = __int_as_float((int)hi_k);
         }
+        CFS_TICK(1);
         const double cut = ((double)tau + eps16) + eps16;
         if (!(cut < (double)inf) || !(sumn * sumn < 1e37)) {  // nothing can be certified: the exact row
             if (lane == 0) {
@@ -1978,38 +1989,93 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_front_sel(const ApproxSe
             }
             return;
         }
-        // ---- candidates (as k_coarse_front), the first 64 also into the wave's LDS list
+        // ---- candidates (as k_coarse_front; their order is immaterial: the ranking below is by (distance, index)) into the wave's LDS
+        //      list.  A group whose runner-up qualifies as well (rare: two of the w + 1 nearest in one group of 8) is only noted here
+        //      and expanded afterwards from a reload; the global list is written only for a query that is handed on, by a compact
+        //      loop over reloaded pairs (~40 scattered stores less for every other query, and a tenth of the code).
         const u64 lane_lt = (1ull << lane) - 1ull;
-        auto push = [&](const bool pass, const int c) {
+        float cutf = (float)cut;  // the largest float at or under the cut: x <= cutf exactly when (double)x <= cut
+        if ((double)cutf > cut) cutf = __int_as_float(__float_as_int(cutf) - 1);  // (cut > 0 and finite)
+        // (one compare per group and bit masks first, then a loop over the groups that qualified -- one per lane and round, three or
+        //  four rounds for ~40 of 1024 groups -- instead of sixteen rounds of ballots and prefix counts)
+        u32 allm = 0, hotm = 0, a1lo = 0, a1hi = 0;  // a1 of group i: three bits at 3 i of a1hi:a1lo (ten groups in the low word)
+#pragma unroll
+        for (int i = 0; i < GPL; i++) {
+            const u32 rb = (u32)__float_as_int(ry[i]);
+            const float m2 = __int_as_float((int)(rb & ~7u));  // rounded towards zero: never above the true runner-up
+            const bool hot = m1[i] <= cutf;
+            hotm |= hot ? 1u << i : 0u;
+            allm |= (hot && m2 <= cutf) ? 1u << i : 0u;
+            if (i < 10) a1lo |= (rb & 7u) << (3 * i);
+            else a1hi |= (rb & 7u) << (3 * (i - 10));
+        }
+        while (__builtin_amdgcn_ballot_w64(hotm != 0)) {  // (wave-uniform)
+            const bool act = hotm != 0;
+            const int i = act ? __ffs(hotm) - 1 : 0;
+            hotm &= hotm - 1;
+            const int a1 = (int)((i < 10 ? a1lo >> (3 * i) : a1hi >> (3 * (i - 10))) & 7u);
+            const int g = lane + 64 * i;
+            const int c = (g >> 4) * G16_BC + (g & 15) + 16 * a1;  // column ct of the group is centroid cb + 16 ct
+            const bool pass = act && c < C;
             const u64 mask = __builtin_amdgcn_ballot_w64(pass);
             if (pass) {
                 const u32 slot = n + (u32)__popcll(mask & lane_lt);
-                if (slot < MMIDX_CLIST - 1) list[1 + slot] = (u32)c;
                 if (slot < 64) cidx[slot] = (u32)c;
             }
             n += (u32)__popcll(mask);
-        };
-#pragma unroll
-        for (int i = 0; i < GPL; i++) {
-            const int g = lane + 64 * i;
-            const int cb = (g >> 4) * G16_BC + (g & 15);  // column ct of the group is centroid cb + 16 ct
-            const int a1 = __float_as_int(ry[i]) & 7;
-            const float m2 = __int_as_float(__float_as_int(ry[i]) & ~7);  // rounded towards zero: never above the true runner-up
-            const bool hot = (double)m1[i] <= cut;
-            push(hot && cb + 16 * a1 < C, cb + 16 * a1);
-            const bool all = hot && (double)m2 <= cut;
-            if (__builtin_amdgcn_ballot_w64(all)) {  // rare: two of the w+1 nearest in one group of 8
-#pragma unroll
-                for (int ct = 0; ct < 8; ct++) push(all && ct != a1 && cb + 16 * ct < C, cb + 16 * ct);
+        }
+        if (__builtin_amdgcn_ballot_w64(allm != 0)) {  // (wave-uniform)
+            u32 *cnt = (u32 *)sel_i;                     // (free until the ranking)
+            if (lane == 0) *cnt = n;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (u32 mm = allm; mm; mm &= mm - 1) {
+                const int g = lane + 64 * (__ffs(mm) - 1);
+                const int cb = (g >> 4) * G16_BC + (g & 15);
+                const int a1 = __float_as_int(A.gpair[(size_t)q * G + g].y) & 7;
+                for (int ct = 0; ct < 8; ct++)
+                    if (ct != a1 && cb + 16 * ct < C) {
+                        const u32 slot = atomicAdd(cnt, 1u);
+                        if (slot < 64) cidx[slot] = (u32)(cb + 16 * ct);
+                    }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            n = (u32)__builtin_amdgcn_readfirstlane((int)*(volatile u32 *)cnt);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (cnt sits in the tile's memory)
+            __builtin_amdgcn_wave_barrier();
         }
-    }
-    if (n > 64 || (int)n < R) {  // (fewer than w + 1 candidates cannot happen with a valid cut; k_coarse_select_list's business either way)
-        if (lane == 0) {
-            list[0] = n <= MMIDX_CLIST - 1 ? n : (u32)(MMIDX_CSEL_CAP + 1);
-            A.defer[1 + atomicAdd(A.defer, 1u)] = (u32)q;
+        CFS_TICK(2);
+        if (n > 64 || (int)n < R) {  // (fewer than w + 1 candidates cannot happen with a valid cut; k_coarse_select_list's business either way)
+            n = 0;
+#pragma unroll 1
+            for (int i = 0; i < GPL; i++) {
+                const int g = lane + 64 * i;
+                const float2 v = A.gpair[(size_t)q * G + (g < G ? g : G - 1)];
+                const int cb = (g >> 4) * G16_BC + (g & 15);
+                const int a1 = __float_as_int(v.y) & 7;
+                const float m2 = __int_as_float(__float_as_int(v.y) & ~7);
+                const bool hot = g < G && (double)fmaxf(v.x, 0.0f) <= cut;
+                const bool all = hot && (double)m2 <= cut;
+#pragma unroll 1
+                for (int ct = 0; ct < 8; ct++) {
+                    const bool pass = hot && (ct == a1 || all) && cb + 16 * ct < C;
+                    const u64 mask = __builtin_amdgcn_ballot_w64(pass);
+                    if (pass) {
+                        const u32 slot = n + (u32)__popcll(mask & lane_lt);
+                        if (slot < MMIDX_CLIST - 1) list[1 + slot] = (u32)(cb + 16 * ct);
+                    }
+                    n += (u32)__popcll(mask);
+                }
+            }
+            if (lane == 0) {
+                list[0] = n <= MMIDX_CLIST - 1 ? n : (u32)(MMIDX_CSEL_CAP + 1);
+                A.defer[1 + atomicAdd(A.defer, 1u)] = (u32)q;
+            }
+            return;
         }
-        return;
     }
     __builtin_amdgcn_wave_barrier();
     // ---- exact distances: a LANE per candidate adds the terms (c_j - q_j)^2 in dimension order (IVFPQ.java:583); the terms of 16
@@ -2017,76 +2083,90 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_front_sel(const ApproxSe
     //      128-byte line of a candidate's row, 8 candidates per load instruction); the next 16 dimensions' rows are requested before
     //      the current ones are summed
     {
-        double(*terms)[65] = s_terms[wv];  // [16][64 + 1]: lane c reads terms[j][c] (consecutive banks), the 8 lanes of a row write two apart
+        double(*terms)[65] = s_terms;  // [16][64 + 1]: lane c reads terms[j][c] (consecutive banks), the 8 lanes of a row write two apart
         const int cl = lane >> 3, jp = lane & 7;
         const int ng = ((int)n + 7) >> 3;  // load instructions per 16 dimensions (<= 8)
-        const double *rowp[8];
-#pragma unroll
-        for (int gq = 0; gq < 8; gq++) {
-            const int ci = gq * 8 + cl;
-            const int cc = ci < (int)n ? ci : (int)n - 1;  // (loads run on a clamped index)
-            rowp[gq] = A.coarse + (size_t)cidx[cc] * (u32)D + 2 * jp;
-        }
-        const double *qp = A.Q + (size_t)q * D + 2 * jp;
-        double2 cur[8], nxt[8], qc, qx;
-#pragma unroll
-        for (int gq = 0; gq < 8; gq++) {
-            cur[gq] = make_double2(0.0, 0.0);
-            if (gq < ng) cur[gq] = *(const double2 *)(rowp[gq]);
-        }
-        qc = *(const double2 *)qp;
+        // (Asking for all lines of all candidate rows up front -- 40 % of them miss the L2: 8192 rows are 8 MiB against 4 MiB per XCD -- was
+        //  tried with LDS-DMA loads into a sink: 89 -> 101 us per 16384 queries, the extra requests cost more than the misses they hid.)
+        const unsigned char *cbase = (const unsigned char *)A.coarse;  // (wave-uniform base + a 32-bit byte offset per lane + a constant:
+        const unsigned char *qbase = (const unsigned char *)(A.Q + (size_t)q * D);  //  no address arithmetic inside the steps)
+        const u32 qo = 16u * (u32)jp;
         double acc = 0.0;
-#pragma unroll 1
-        for (int jb = 0; jb < NJB; jb++) {
-            if (jb + 1 < NJB) {
+        // NG = load instructions per block of 16 dimensions, a compile-time bound on ceil(n / 8): every load of an instance is
+        // unconditional (clamped candidates), every step of it unrolled -- the waits are counted, not full
+        auto exact = [&](auto ngc) {
+            constexpr int NG = decltype(ngc)::value;
+            u32 rowb[NG];  // (byte offsets: C * D * 8 < 2^32 for every C this kernel takes)
 #pragma unroll
-                for (int gq = 0; gq < 8; gq++) {
-                    nxt[gq] = make_double2(0.0, 0.0);
-                    if (gq < ng) nxt[gq] = *(const double2 *)(rowp[gq] + (jb + 1) * 16);
-                }
-                qx = *(const double2 *)(qp + (jb + 1) * 16);
+            for (int gq = 0; gq < NG; gq++) {
+                const int ci = gq * 8 + cl;
+                const int cc = ci < (int)n ? ci : (int)n - 1;
+                rowb[gq] = (cidx[cc] * (u32)D + 2u * (u32)jp) * 8u;
             }
+            double2 buf[2][NG], qv[2];
 #pragma unroll
-            for (int gq = 0; gq < 8; gq++) {
-                if (gq < ng) {
-                    const double d0 = cur[gq].x - qc.x, d1 = cur[gq].y - qc.y;
-                    terms[2 * jp][gq * 8 + cl] = d0 * d0;
+            for (int gq = 0; gq < NG; gq++) buf[0][gq] = *(const double2 *)(cbase + rowb[gq]);
+            qv[0] = *(const double2 *)(qbase + qo);
+#pragma unroll
+            for (int jb = 0; jb < NJB; jb++) {
+                const int cu = jb & 1, nx = cu ^ 1;
+                if (jb + 1 < NJB) {  // the next block's rows into the other register set first (two sets, no copies)
+#pragma unroll
+                    for (int gq = 0; gq < NG; gq++) buf[nx][gq] = *(const double2 *)(cbase + rowb[gq] + (jb + 1) * 128);
+                    qv[nx] = *(const double2 *)(qbase + qo + (jb + 1) * 128);
+                }
+#pragma unroll
+                for (int gq = 0; gq < NG; gq++) {
+                    const double d0 = buf[cu][gq].x - qv[cu].x, d1 = buf[cu][gq].y - qv[cu].y;
+                    terms[2 * jp][gq * 8 + cl] = d0 * d0;  // (columns >= n: copies of the last candidate, never read back)
                     terms[2 * jp + 1][gq * 8 + cl] = d1 * d1;
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    double tv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) tv[j] = terms[8 * h + j][lane];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc += tv[j];  // (lane >= n: junk, never used)
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            {
-                double tv[16];
-#pragma unroll
-                for (int j = 0; j < 16; j++) tv[j] = terms[j][lane];
-#pragma unroll
-                for (int j = 0; j < 16; j++) acc += tv[j];  // (lane >= n: junk, never used)
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int gq = 0; gq < 8; gq++) cur[gq] = nxt[gq];
-            qc = qx;
-        }
-        if (lane < (int)n) ckey[lane] = dkey(acc);
+        };
+        if (ng <= 4) exact(std::integral_constant<int, 4>());
+        else if (ng <= 6) exact(std::integral_constant<int, 6>());
+        else exact(std::integral_constant<int, 8>());
+        ckey[lane] = lane < (int)n ? dkey(acc) : MMIDX_KEY_MAX;
     }
+    CFS_TICK(3);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // ---- ranking by (distance, index) in registers, bounded-queue rule: coarse_select_finish's n <= 64 branch, a lane for a thread
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- ranking by (distance, index), bounded-queue rule: coarse_select_finish's n <= 64 branch, a lane for a thread.  Every lane
+    //      counts the keys under its own from broadcast LDS reads, eight a round (lanes past n hold the largest key); equal keys show
+    //      as two lanes with one rank and send the wave through the slower (key, index, lane) count.
     {
         const bool have = lane < (int)n;
-        const u64 mk = have ? ckey[lane] : MMIDX_KEY_MAX;
+        const u64 mk = ckey[lane];
         const u32 mv = have ? cidx[lane] : 0xFFFFFFFFu;
-        int rank = 0, eqc = 0;
-        for (int j = 0; j < (int)n; j++) {
-            const u32 olo = wave_read_u32((u32)mk, j), ohi = wave_read_u32((u32)(mk >> 32), j);
-            const u64 ok = ((u64)ohi << 32) | olo;
-            rank += ok < mk;
-            eqc += ok == mk;
+        int rank = 0;
+        for (int j = 0; j < (int)n; j += 8) {
+            u64 ok[8];
+#pragma unroll
+            for (int t = 0; t < 8; t++) ok[t] = ckey[j + t];
+#pragma unroll
+            for (int t = 0; t < 8; t++) rank += ok[t] < mk;
         }
-        if (__builtin_amdgcn_ballot_w64(have && eqc > 1)) {  // wave-uniform
+        if (have) sel_i[rank] = lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const bool dup = have && sel_i[rank] != lane;
+        if (__builtin_amdgcn_ballot_w64(dup)) {  // wave-uniform
             rank = 0;
             for (int j = 0; j < (int)n; j++) {
                 const u32 olo = wave_read_u32((u32)mk, j), ohi = wave_read_u32((u32)(mk >> 32), j), ov = wave_read_u32(mv, j);
@@ -2105,6 +2185,11 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_front_sel(const ApproxSe
         }
     }
     __builtin_amdgcn_wave_barrier();
+    CFS_TICK(4);
+#ifdef CFS_TIMING
+    if (lane == 0 && (q & 4095) == 77)
+        printf("[cfs] q %d n %u: cycles load+min %llu bisect %llu push %llu exact %llu rank %llu\n", q, n, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4]);
+#endif
     bool plain;
     {
         const bool eq = lane < w && sel_k[lane] == sel_k[lane + 1];
