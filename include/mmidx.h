@@ -342,7 +342,8 @@ int mmidx_set_profiling(mmidx_index *h, int enabled);
  * the matrix cores), "smin_bf16" (0: without K3s's bf16 first stage), "coarse_dma_kc" (0: long vectors through K1e's register staging instead of the
  * LDS-DMA kernel), "no_union" (K3g's instances that rank the union of the verified candidates: -1 always, 1 never, 0 hint).  On a sharded handle: "shard_exchange" (0: partial lists stored into the owners' buffers over xGMI, 1: ncclSend /
  * ncclRecv), "tie_slots" (flagged queries per owner and replay round, 0 = no replay), "shard_max_round"; every other option goes
- * to every shard.  Round 4: "no_mfma" (1: pass B through K3g / K3f instead of the matrix-core bound K3m / K3mk), "mfma_sub" (codes per
+ * to every shard.  Round 5: "no_split_table" (1: an exact table of twice the LDS -- m = 128 byte codes -- stays in global scratch instead
+ * of being taken in two sweeps with half of it in LDS, k_scan_split).  Round 4: "no_mfma" (1: pass B through K3g / K3f instead of the matrix-core bound K3m / K3mk), "mfma_sub" (codes per
  * work item of K3m / K3mk, 0 = sized from the call), "mfma_qcap" (survivor records per launch; a small value sends queries through the
  * redo path), "mfma_blocks", "mfma_kc_v1" (1: K3mk without LDS-DMA, k_scan_mfma_kc, also where k_scan_mfma_kc2 applies),
  * "mfma_kc_tpw" (8 / 16 code tiles per wave of k_scan_mfma_kc), "lut_pre" (pass A's tables built by their own kernel),

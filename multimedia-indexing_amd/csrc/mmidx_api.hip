@@ -298,6 +298,7 @@ struct mmidx_index {
     int pq_ep = 0;
     double pq_maxabs = 0.0;            // largest |codebook element| (set_pq)
     int no_mfma = 0;                   // option "no_mfma" = 1: pass B through K3g / K3f (A/B switch)
+    int no_split_table = 0;            // option "no_split_table" = 1: a table of twice the LDS (m = 128) stays in global scratch (A/B switch)
     int mfma_sub = 0;                  // option "mfma_sub": codes per K3m item (0 = sized from the call)
     int mfma_qcap = 0;                 // option "mfma_qcap": survivor records per launch (0 = sized from the call; tests force the redo path)
     int mfma_blocks = 0;               // option "mfma_blocks": persistent blocks (0 = occupancy x CUs)
@@ -671,6 +672,16 @@ int launch_scan(const mmidx_index *h, const ScanParams &P, dim3 grid, size_t lds
         if ((size_t)grid.x * grid.y > h->glut_slots) return fail(MMIDX_ERR_UNSUPPORTED, "lookup-table scratch too small for %u x %u blocks", grid.x, grid.y);
         if (P.cap < P.K1 + MMIDX_SEG) return fail(MMIDX_ERR_UNSUPPORTED, "candidate buffer of %d entries too small for k + 1 = %d and a %d-code segment", P.cap, P.K1, MMIDX_SEG);
         const size_t l = lds - (size_t)h->m * h->ks * 8;
+        // twice the LDS (m = 128 byte codes): two sweeps with half the table in LDS each (k_scan_split); cap >= K1 + 512 covers its
+        // 512-code segments, a chunk's partial sums fit the block's table slot
+        if (!P.sdc_tt && !h->no_split_table && h->code_bytes == 1 && h->ks == 256 && h->m == 128 && P.chunk <= h->m * h->ks &&
+            l + (size_t)64 * 256 * 8 <= 160 * 1024) {
+            const size_t sl = l + (size_t)64 * 256 * 8;
+            HIPCK(hipFuncSetAttribute((const void *)k_scan_split<128, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl));
+            hipLaunchKernelGGL((k_scan_split<128, 512>), grid, dim3(512), sl, st, P);
+            HIPCK(hipGetLastError());
+            return MMIDX_OK;
+        }
         if (P.sdc_tt) return launch_scan_t<0, unsigned char, 2, MMIDX_BLOCK, true, true>(P, grid, l, st);
         if (h->code_bytes == 1) return launch_scan_t<0, unsigned char, 2, MMIDX_BLOCK, false, true>(P, grid, l, st);
         return launch_scan_t<0, unsigned short, 2, MMIDX_BLOCK, false, true>(P, grid, l, st);
@@ -2042,7 +2053,11 @@ int run_coarse(mmidx_index *h, int64_t nq, const double *dQ, int32_t *d_cells, h
     }
     h->disp_coarse = "K1a+K1b(exact)";
     dim3 g1((unsigned)((h->C + MMIDX_BLOCK - 1) / MMIDX_BLOCK), (unsigned)((nq + QT - 1) / QT));
-    hipLaunchKernelGGL(k_coarse_dist<QT>, g1, dim3(MMIDX_BLOCK), 0, st, h->d_coarseT, dQ, h->ws_cdist.p, h->C, h->D, (int)nq);
+    if ((int64_t)g1.x * g1.y < 2048) {  // few centroids and queries: a query a block, so that the chip has blocks to run
+        g1.y = (unsigned)nq;
+        hipLaunchKernelGGL(k_coarse_dist<1>, g1, dim3(MMIDX_BLOCK), 0, st, h->d_coarseT, dQ, h->ws_cdist.p, h->C, h->D, (int)nq);
+    } else
+        hipLaunchKernelGGL(k_coarse_dist<QT>, g1, dim3(MMIDX_BLOCK), 0, st, h->d_coarseT, dQ, h->ws_cdist.p, h->C, h->D, (int)nq);
     const size_t lds = (size_t)(h->w + 1) * 12 + 16;
     if (lds > 64 * 1024) return fail(MMIDX_ERR_UNSUPPORTED, "w = %d too large", h->w);
     const bool fast = h->C >= MMIDX_BLOCK && h->w + 1 <= MMIDX_BLOCK && h->C <= 64 * MMIDX_BLOCK;
@@ -2190,7 +2205,8 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
                 // (K3h ran -- its empty fallback launch is not counted as a scan launch -- or failed with rc > 1)
                 h->disp_passa = "K3h";
             } else {
-                h->disp_passa = pl.glut ? "K3(table in global scratch)" : (two_pass ? "K3" : "K3(single pass)");
+                h->disp_passa = pl.glut ? ((!h->no_split_table && h->code_bytes == 1 && h->ks == 256 && h->m == 128) ? "K3(table in two halves)" : "K3(table in global scratch)")
+                                        : (two_pass ? "K3" : "K3(single pass)");
                 rc = MMIDX_OK;
                 // one code per thread per segment: smaller candidate buffer -> a fourth block per CU
                 ScanParams PA = P;
@@ -3600,6 +3616,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->passa_mfma = value;
     } else if (n == "passa_mfma_wide") {
         h->a_wide = value != 0;
+    } else if (n == "no_split_table") {  // m = 128: the table-in-global kernels instead of k_scan_split
+        h->no_split_table = value != 0;
     } else if (n == "no_mfma") {  // pass B through K3g / K3f instead of the matrix-core bound K3m
         h->no_mfma = value != 0;
     } else if (n == "mfma_sub") {

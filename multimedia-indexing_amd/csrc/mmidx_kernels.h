@@ -108,7 +108,22 @@ __global__ __launch_bounds__(MMIDX_BLOCK) void k_coarse_dist(const double *__res
     double acc[QT];
 #pragma unroll
     for (int t = 0; t < QT; t++) acc[t] = 0.0;
-    for (int j = 0; j < D; j++) {
+    int j = 0;
+    for (; j + 8 <= D; j += 8) {  // eight rows of the table in flight (one at a time, every step was a memory round trip: 1024-d, 430 us)
+        double cj[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) cj[u] = coarseT[(size_t)(j + u) * C + cc];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+#pragma unroll
+            for (int t = 0; t < QT; t++) {
+                const int q = (q0 + t < nq) ? q0 + t : nq - 1;
+                const double df = cj[u] - Q[(size_t)q * D + j + u];
+                acc[t] += df * df;
+            }
+        }
+    }
+    for (; j < D; j++) {
         const double cj = coarseT[(size_t)j * C + cc];
 #pragma unroll
         for (int t = 0; t < QT; t++) {
@@ -2705,6 +2720,143 @@ __global__ __launch_bounds__(NT) void k_scan(const ScanParams P) {
             const int leader = __ffsll((long long)mask) - 1;
             if ((tid & 63) == leader) base = atomicAdd(P.pool_cnt + q, (u32)__popcll(mask));
             base = wave_read_u32(base, leader);  // (v_readlane: no trip through the LDS pipe)
+            if (pass) {
+                const u32 slot = base + (u32)__popcll(mask & lane_lt);
+                if (slot < (u32)P.poolq) {
+                    P.pool_key[(size_t)q * P.poolq + slot] = bkey[i];
+                    P.pool_val[(size_t)q * P.poolq + slot] = ((u64)pr << 32) | (u64)bval[i];
+                }
+            }
+        }
+    }
+}
+
+// K3 for an exact table of twice the LDS (m = 128 byte codes: 128 x 256 x 8 B = 256 KiB -- Example.java:74 names a pq_1024_128x8
+// codebook): the sum over the sub-quantizers is taken in TWO sweeps over the item's codes, each with half the table in LDS.  Sweep 1
+// leaves every code's partial sum over s = 0 .. M/2 - 1 (from 0.0, s ascending) in the block's slice of the global scratch that
+// the table-in-global kernels use; sweep 2 continues each from there over s = M/2 .. M - 1 -- the same additions in the same order
+// as one pass over a whole table (IVFPQ.java:435-438), so the same bits -- and feeds K3's candidate buffer.  The table-in-global
+// form (k_scan<0, .., GLUT>) read every code byte and every table entry through global loads: 0.76 ms per 1024 queries of the
+// 100 k x 1024-d shape; this one 0.1 ms.
+template <int M, int NT>
+__global__ __launch_bounds__(NT) void k_scan_split(const ScanParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int H = M / 2;
+    const int ks = P.ks, D = P.D;
+    double *lut = (double *)smem;                  // [H * ks]
+    double *vec = lut + (size_t)H * ks;            // [D] or [2 D]
+    u64 *bkey = (u64 *)(vec + (P.transform ? 2 : 1) * (size_t)D);
+    u32 *bval = (u32 *)(bkey + P.cap);
+    u32 *s_cnt = bval + P.cap;
+    int item = blockIdx.x;
+    const int n_items = P.order ? *P.n_order : P.n_items;
+    if (P.xcd_remap) {
+        const int per = (n_items + 7) >> 3;
+        if ((int)(blockIdx.x >> 3) >= per) return;
+        item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    }
+    if (item >= n_items) return;
+    int q, pr;
+    if (P.order) {
+        const int e = P.order[item];
+        q = e / P.w;
+        pr = e - q * P.w;
+    } else {
+        q = item / P.nrank;
+        pr = P.rank_lo + (item - q * P.nrank);
+    }
+    const int ch = P.order_ch ? P.order_ch[item] : (P.ivf ? (int)blockIdx.y : pr);
+    int cell = 0;
+    if (P.ivf) {
+        cell = P.cells[(size_t)q * P.w + pr];
+        if (cell < 0) return;
+    }
+    const int64_t beg = P.list_off[cell];
+    const int64_t len = P.list_off[cell + 1] - beg;
+    int64_t c0 = (int64_t)ch * P.chunk;
+    if (c0 >= len) return;
+    int64_t c1 = (c0 + P.chunk < len) ? c0 + P.chunk : len;
+    c0 = c0 < (int64_t)P.code_lo ? (int64_t)P.code_lo : c0;
+    c1 = c1 > (int64_t)P.code_hi ? (int64_t)P.code_hi : c1;
+    if (c0 >= c1) return;
+    const int tid = threadIdx.x;
+    const unsigned char *codes = (const unsigned char *)P.codes + (size_t)beg * M;
+    double *part = P.glut + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)M * ks;  // [<= chunk <= M * ks] (the host checks)
+    if (tid == 0) s_cnt[0] = 0;
+    const double *tr = query_vector(P, q, cell, vec);
+    build_lut_any(lut, tr, P.pqT, H, ks, P.dsub);
+    __syncthreads();
+    // ---- sweep 1: s = 0 .. H - 1
+    for (int64_t i0 = c0; i0 < c1; i0 += 2 * NT) {
+        CodeVec<H, unsigned char> cv[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int64_t i = i0 + u * NT + tid;
+            cv[u].load(codes + (size_t)(i < c1 ? i : c1 - 1) * M);
+        }
+        double d[2] = {0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < H; s++) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) d[u] += lut[s * ks + cv[u].get(s)];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int64_t i = i0 + u * NT + tid;
+            if (i < c1) part[i - c0] = d[u];
+        }
+    }
+    __syncthreads();
+    build_lut_any(lut, tr + (size_t)H * P.dsub, P.pqT + (size_t)H * P.dsub * ks, H, ks, P.dsub);
+    u64 *Tq = P.T + q;
+    u64 T = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    // ---- sweep 2: s = H .. M - 1 on top of the partial sums; K3's candidate buffer from here on
+    const int limit = P.cap - NT;
+    const u64 lane_lt = (1ull << (tid & 63)) - 1ull;
+    for (int64_t seg = c0; seg < c1; seg += NT) {
+        const int64_t i = seg + tid;
+        const int64_t ic = i < c1 ? i : c1 - 1;
+        CodeVec<H, unsigned char> cv;
+        cv.load(codes + (size_t)ic * M + H);
+        double d = part[ic - c0];
+#pragma unroll
+        for (int s = 0; s < H; s++) d += lut[s * ks + cv.get(s)];
+        const u64 key = dkey(d);
+        const bool pass = (i < c1) && key <= T;
+        const u64 mask = __ballot(pass);
+        if (mask) {
+            u32 base = 0;
+            const int leader = __ffsll((long long)mask) - 1;
+            if ((tid & 63) == leader) base = atomicAdd(s_cnt, (u32)__popcll(mask));
+            base = wave_read_u32(base, leader);
+            if (pass) {
+                const u32 slot = base + (u32)__popcll(mask & lane_lt);
+                bkey[slot] = key;
+                bval[slot] = (u32)i;
+            }
+        }
+        __syncthreads();
+        const bool need = (int)*s_cnt > limit;  // uniform: nobody writes s_cnt until the barrier below
+        __syncthreads();
+        if (need) {
+            scan_prune(bkey, bval, s_cnt, P.K1, Tq);
+            T = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if ((int)*s_cnt > P.K1) scan_prune(bkey, bval, s_cnt, P.K1, Tq);
+    T = __hip_atomic_load(Tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int n = (int)*s_cnt;
+    for (int base0 = 0; base0 < n; base0 += NT) {
+        const int i = base0 + tid;
+        const bool pass = (i < n) && bkey[i] <= T;
+        const u64 mask = __ballot(pass);
+        if (mask) {
+            u32 base = 0;
+            const int leader = __ffsll((long long)mask) - 1;
+            if ((tid & 63) == leader) base = atomicAdd(P.pool_cnt + q, (u32)__popcll(mask));
+            base = wave_read_u32(base, leader);
             if (pass) {
                 const u32 slot = base + (u32)__popcll(mask & lane_lt);
                 if (slot < (u32)P.poolq) {

@@ -31,7 +31,7 @@ ROWS = [
     # short codes (ks > 256): the exact scan everywhere
     ("ivfpq", 32, 4, 512, 6, 6, 12000, 20, 10, 0, {}, ("K1a+K1b(exact)", "K3", "-", "K3(exact scan: no K3f instance for this shape)")),
     # m = 128 (Example.java:74 names pq_1024_128x8): the lookup table lives in global scratch for pass A, K3mk behind it (K3s sits out: its fp32 tables exist for m in {8, 16, 32, 64})
-    ("ivfpq", 1024, 128, 256, 6, 6, 6000, 12, 10, 0, {}, ("K1a+K1b(exact)", "K3(table in global scratch)", "-", "K3mk")),
+    ("ivfpq", 1024, 128, 256, 6, 6, 6000, 12, 10, 0, {}, ("K1a+K1b(exact)", "K3(table in two halves)", "-", "K3mk")),
     # K3m switched off: K3g
     ("ivfpq", 128, 16, 256, 8, 4, 40000, 30, 100, 0, {"no_mfma": 1}, ("K1a+K1b(exact)", "K3h", "-", "K3g")),
     # flat PQ (cfg2's shape at small scale): chunk 0 through K3h, the others through K3m
