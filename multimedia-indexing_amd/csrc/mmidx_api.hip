@@ -4178,9 +4178,9 @@ int mmidx_vlad_aggregate_device(mmidx_vlad *v, int64_t nimg, const int64_t *d_de
             const mmidx_index *a = v->asg[(size_t)i];
             if (a->d_Ch && a->Cp == G16_BC && a->Dp >= 64 && a->Dp <= G16_KC) {
                 const size_t lf = 2 * (size_t)G16_BC * (64 * 2 + 16) + 2 * (size_t)maxnd * 4 + (size_t)((nc + 2) & ~1) * 4 + (size_t)(VF_FLAG_CAP + 2) * 4 + 32;
-                if (lf <= 160 * 1024) {
+                if (lf <= 160 * 1024 && a->d_coarseT) {
                     HIPCK(hipFuncSetAttribute((const void *)k_vlad_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lf));
-                    hipLaunchKernelGGL(k_vlad_fused, dim3((unsigned)nimg), dim3(256), lf, st, v->d_cb + v->cb_off[(size_t)i], nc, maxnd, (const __bf16 *)a->d_Ch,
+                    hipLaunchKernelGGL(k_vlad_fused, dim3((unsigned)nimg), dim3(256), lf, st, v->d_cb + v->cb_off[(size_t)i], (const double *)a->d_coarseT, nc, maxnd, (const __bf16 *)a->d_Ch,
                                        (const __bf16 *)a->d_Cl, a->d_cn_pad, a->cnorm_max, a->cn_max, a->Dp, (const long long *)d_desc_off, d_descs, d_out, v->veclen,
                                        (int)v->cb_off[(size_t)i], v->norms);
                     HIPCK(hipGetLastError());

@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void k_vlad_accum(const double *__restrict__ c
 //       the previous eight are added).
 // 64-dimensional descriptors (SURF), vocabularies of <= 128 centroids; other shapes keep K8'.
 #define VF_FLAG_CAP 64
-__global__ __launch_bounds__(256, 2) void k_vlad_fused(const double *__restrict__ codebook, int nc, int maxnd, const __bf16 *__restrict__ Ch,
+__global__ __launch_bounds__(256, 3) void k_vlad_fused(const double *__restrict__ codebook, const double *__restrict__ codebookT, int nc, int maxnd, const __bf16 *__restrict__ Ch,
                                                        const __bf16 *__restrict__ Cl, const double *__restrict__ cn, double cnorm_max, double cn_max, int Dp,
                                                        const long long *__restrict__ desc_off, const double *__restrict__ descs, double *__restrict__ out,
                                                        int out_stride, int out_shift, int norms_on) {
@@ -592,21 +592,33 @@ __global__ __launch_bounds__(256, 2) void k_vlad_fused(const double *__restrict_
         const int nf = all ? nd : nf_raw;
         for (int f = wave; f < nf; f += 4) {
             const int q = all ? f : flg[1 + f];
-            const double *x = Dg + (size_t)q * DL;
-            u64 bk = 0xFFFFFFFFFFFFFFFFull;
-            int bi = 0x7fffffff;
-            for (int c = lane; c < nc; c += 64) {
-                const double *cc = codebook + (size_t)c * DL;
-                double a = 0.0;
-                for (int j = 0; j < DL; j++) {
-                    const double df = cc[j] - x[j];
-                    a += df * df;
+            const double *x = Dg + (size_t)q * DL;  // (wave-uniform: scalar loads)
+            // a lane a centroid (two of them), the TRANSPOSED codebook: a dimension of all centroids is one coalesced load, eight in
+            // flight (row-major it was a 512-byte stride between lanes and a round trip per dimension: 40 k cycles per flagged descriptor,
+            // with the whole block waiting behind the barrier)
+            const int c0 = lane < nc ? lane : nc - 1, c1 = lane + 64 < nc ? lane + 64 : nc - 1;
+            double a0 = 0.0, a1 = 0.0;
+            for (int j = 0; j < DL; j += 8) {
+                double t0v[8], t1v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    t0v[u] = codebookT[(size_t)(j + u) * nc + c0];
+                    t1v[u] = codebookT[(size_t)(j + u) * nc + c1];
                 }
-                const u64 k = (u64)__double_as_longlong(a);
-                if (k < bk) {
-                    bk = k;
-                    bi = c;
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const double xv = x[j + u];
+                    const double e0 = t0v[u] - xv, e1 = t1v[u] - xv;
+                    a0 += e0 * e0;
+                    a1 += e1 * e1;
                 }
+            }
+            u64 bk = lane < nc ? (u64)__double_as_longlong(a0) : 0xFFFFFFFFFFFFFFFFull;
+            int bi = lane < nc ? lane : 0x7fffffff;
+            const u64 k1 = (u64)__double_as_longlong(a1);
+            if (lane + 64 < nc && k1 < bk) {
+                bk = k1;
+                bi = lane + 64;
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
@@ -621,91 +633,104 @@ __global__ __launch_bounds__(256, 2) void k_vlad_fused(const double *__restrict_
         }
     }
     __syncthreads();
-    // ---- (4) counts -> starts -> stable lists; ordered accumulation; power + L2 (as k_vlad_accum) ----
-    for (int d = tid; d < nd; d += 256) atomicAdd(cstart + nn[d] + 1, 1);
-    __syncthreads();
-    if (tid < 64) {
-        u32 carry = 0;
-        for (int base = 0; base < nc; base += 64) {
-            const int c = base + tid;
-            const u32 cnt = c < nc ? (u32)cstart[c + 1] : 0u;
-            const u32 incl = wave_incl_scan_u32(cnt);
-            if (c < nc) cstart[c + 1] = (int)(carry + incl);
-            carry += wave_read_u32(incl, 63);
-        }
-        if (tid == 0) cstart[0] = 0;
-    }
-    __syncthreads();
-    for (int c = tid; c < nc; c += 256) {
-        int p = cstart[c];
-        for (int d = 0; d < nd; d++)
-            if (nn[d] == c) lst[p++] = d;
-    }
-    __syncthreads();
-    double ss = 0.0;
+    // ---- (4) ordered accumulation, power + L2.  A wave owns the centroids c = wave (mod 4) -- interleaved: popular centroids spread
+    //      over the waves -- and keeps their 64-element sums in REGISTERS (a lane a dimension); it lists its own descriptors in
+    //      descriptor order (two ballot passes over nn[]) and walks that list: the sum of a centroid receives its descriptors in
+    //      ascending order whatever the other centroids do in between (vlad[nn*dl+j] += desc[j] - centroid[nn][j],
+    //      VladAggregator.java:63-67) -- no per-centroid lists (a 500-step LDS chain per thread), no centroid boundaries in the loop,
+    //      and the vector is written ONCE, normalised (it had been written raw, read back and rewritten).
+    constexpr int CPW = 32;  // centroids per wave (nc <= 128): centroid 4 k + wave is the wave's k-th
     {
-        const int cpw = (nc + 3) >> 2;
-        const int c_lo = wave * cpw < nc ? wave * cpw : nc, c_hi = c_lo + cpw < nc ? c_lo + cpw : nc;
-        if (c_lo < c_hi) {
-            int c = c_lo, p = cstart[c_lo];
-            const int pe = cstart[c_hi];
-            int cend = cstart[c + 1];
-            double v = 0.0, cv = codebook[(size_t)c * 64 + lane];
-            double cvn = c + 1 < c_hi ? codebook[(size_t)(c + 1) * 64 + lane] : 0.0;
-            auto emit = [&]() {  // element (c, lane) is complete: power normalisation, next centroid
-                if (norms_on) {
-                    const double a = sqrt(fabs(v));  // normalizePower(0.5)   (Normalization.java:74-79)
-                    v = (v > 0.0) ? a : ((v < 0.0) ? -a : v);
-                    ss += v * v;
-                }
-                vout[(size_t)c * 64 + lane] = v;
-                c++;
-                v = 0.0;
-                cv = cvn;
-                if (c < c_hi) cend = cstart[c + 1];
-                if (c + 1 < c_hi) cvn = codebook[(size_t)(c + 1) * 64 + lane];
-            };
-            constexpr int RU = 8;
-            double a[RU], b[RU];
-            auto fetch = [&](double (&dst)[RU], const int pp) {  // rows pp .. pp + 7 of the grouped list (clamped: always valid addresses)
+        int mine = 0;
+        for (int d0 = 0; d0 < nd; d0 += 64) {
+            const int d = d0 + lane;
+            mine += (int)__popcll(__builtin_amdgcn_ballot_w64(d < nd && (nn[d < nd ? d : nd - 1] & 3) == wave));
+        }
+        if (lane == 0) cstart[wave] = mine;
+    }
+    __syncthreads();
+    int p = 0;
+    for (int w2 = 0; w2 < wave; w2++) p += cstart[w2];
+    const int pe = p + cstart[wave];
+    {
+        int run = p;
+        const u64 lane_lt = (1ull << lane) - 1ull;
+        for (int d0 = 0; d0 < nd; d0 += 64) {
+            const int d = d0 + lane;
+            const int c = nn[d < nd ? d : nd - 1];
+            const bool own = d < nd && (c & 3) == wave;
+            const u64 mk = __builtin_amdgcn_ballot_w64(own);
+            if (own) lst[run + (int)__popcll(mk & lane_lt)] = d | ((c >> 2) << 24);  // (nd < 2^24)
+            run += (int)__popcll(mk);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // (a wave reads its own segment of lst[] only)
+    double acc[CPW];  // (the centroids' own rows would be another 64 registers: they are requested with the descriptor rows -- L1 / L2 hits)
 #pragma unroll
-                for (int u = 0; u < RU; u++) {
-                    const int pu = pp + u < pe ? pp + u : pe - 1;
-                    dst[u] = Dg[(size_t)lst[pu < 0 ? 0 : pu] * 64 + lane];
-                }
-            };
-            auto add8 = [&](const double (&src)[RU], const int pp) {
-                const int n8 = pe - pp < RU ? pe - pp : RU;
+    for (int c = 0; c < CPW; c++) acc[c] = 0.0;
+    const double *cbw = codebook + (size_t)wave * 64 + lane;  // centroid 4 k + wave, element lane: cbw[256 k]
+    {
+        constexpr int RU = 8;
+        double ra[RU], rb[RU], ca[RU], cb[RU];
+        int ea[RU], eb[RU];
+        auto fetch = [&](double (&dst)[RU], double (&cen)[RU], int (&ent)[RU], const int pp) {  // rows of entries pp .. pp + 7 (clamped: always valid addresses)
 #pragma unroll
-                for (int u = 0; u < RU; u++) {
-                    if (u < n8) {
-                        while (pp + u >= cend) emit();  // (wave-uniform; centroids without descriptors come out as zeros)
-                        v += src[u] - cv;
+            for (int u = 0; u < RU; u++) {
+                const int pu = pp + u < pe ? pp + u : pe - 1;
+                ent[u] = __builtin_amdgcn_readfirstlane(lst[pu < 0 ? 0 : pu]);
+                dst[u] = Dg[(size_t)(ent[u] & 0xFFFFFF) * 64 + lane];
+                cen[u] = cbw[(size_t)(ent[u] >> 24) * 256];
+            }
+        };
+        auto add8 = [&](const double (&src)[RU], const double (&cen)[RU], const int (&ent)[RU], const int pp) {
+            const int n8 = pe - pp < RU ? pe - pp : RU;
+#pragma unroll
+            for (int u = 0; u < RU; u++) {
+                if (u < n8) {  // (wave-uniform)
+                    switch (ent[u] >> 24) {  // (wave-uniform: the entry came through readfirstlane)
+#define VF_CASE(k) case k: acc[k] += src[u] - cen[u]; break;
+                        VF_CASE(0) VF_CASE(1) VF_CASE(2) VF_CASE(3) VF_CASE(4) VF_CASE(5) VF_CASE(6) VF_CASE(7)
+                        VF_CASE(8) VF_CASE(9) VF_CASE(10) VF_CASE(11) VF_CASE(12) VF_CASE(13) VF_CASE(14) VF_CASE(15)
+                        VF_CASE(16) VF_CASE(17) VF_CASE(18) VF_CASE(19) VF_CASE(20) VF_CASE(21) VF_CASE(22) VF_CASE(23)
+                        VF_CASE(24) VF_CASE(25) VF_CASE(26) VF_CASE(27) VF_CASE(28) VF_CASE(29) VF_CASE(30) VF_CASE(31)
+#undef VF_CASE
+                        default: break;
                     }
                 }
-            };
-            if (p < pe) fetch(a, p);
-            while (p < pe) {  // two batches per round: one in flight while the other is added
-                if (p + RU < pe) fetch(b, p + RU);
-                add8(a, p);
-                p += RU;
-                if (p >= pe) break;
-                if (p + RU < pe) fetch(a, p + RU);
-                add8(b, p);
-                p += RU;
             }
-            while (c < c_hi) emit();
+        };
+        if (p < pe) fetch(ra, ca, ea, p);
+        while (p < pe) {  // two batches per round: one in flight while the other is added
+            if (p + RU < pe) fetch(rb, cb, eb, p + RU);
+            add8(ra, ca, ea, p);
+            p += RU;
+            if (p >= pe) break;
+            if (p + RU < pe) fetch(ra, ca, ea, p + RU);
+            add8(rb, cb, eb, p);
+            p += RU;
         }
     }
-    if (!norms_on) return;
+    double ss = 0.0;
+    if (norms_on) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
-    if (lane == 0) red[wave] = ss;
-    __syncthreads();
-    const double norm = sqrt(red[0] + red[1] + red[2] + red[3]);
-    __syncthreads();
-    const int veclen = nc * 64;
-    for (int e = tid; e < veclen; e += 256) vout[e] = (norm == 0.0) ? 1.0 : vout[e] / norm;
+        for (int c = 0; c < CPW; c++) {
+            const double a = sqrt(fabs(acc[c]));  // normalizePower(0.5): signum(v) * pow(|v|, 0.5)   (Normalization.java:74-79)
+            acc[c] = (acc[c] > 0.0) ? a : ((acc[c] < 0.0) ? -a : acc[c]);
+            if (4 * c + wave < nc) ss += acc[c] * acc[c];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+    }
+    const double norm = norms_on ? sqrt(red[0] + red[1] + red[2] + red[3]) : 1.0;
+#pragma unroll
+    for (int c = 0; c < CPW; c++) {
+        const int cg = 4 * c + wave;
+        if (cg < nc) vout[(size_t)cg * 64 + lane] = !norms_on ? acc[c] : ((norm == 0.0) ? 1.0 : acc[c] / norm);
+    }
 }
 
 // L2 over the concatenation when more than one vocabulary (VladAggregatorMultipleVocabularies.java:97-99)
