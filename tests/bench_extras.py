@@ -166,11 +166,11 @@ def cfg5(L, nat, mi, images_e2e=1_000_000, device=0):
                                                      "algorithmic_bytes_per_launch": vb,
                                                      "traffic": vtr.get("k_vlad_fused_fetch_bytes_per_launch") if vtr.get("descriptors") == tot else None,
                                                      "traffic_written": vtr.get("k_vlad_fused_write_bytes_per_launch") if vtr.get("descriptors") == tot else None,
-                                                     "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 / WRITE_SIZE, separate pass: profiles/r05_vlad_pmc_kernels.txt)",
-                                                     "note": "algorithmic bytes = the descriptors once (n x 64 x 8).  One kernel and no host synchronisation, but the block reads its "
-                                                             "image's rows twice (assignment, then accumulation in centroid-grouped order) and the second read reaches the fabric "
-                                                             "again (FETCH_SIZE = 2.3 x algorithmic); 70 % of the wave cycles are waits at three blocks per CU: latency-bound "
-                                                             "phases inside a block (DESIGN.md 5.5).  Round 4's two kernels: 4.8 M images/s; round 3's fp64 brute force: 0.94 M"}}
+                                                     "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 / WRITE_SIZE, separate pass: profiles/r05b_vlad_pmc_kernels.txt)",
+                                                     "note": "algorithmic bytes = the descriptors once (n x 64 x 8).  One kernel and no host synchronisation; the block reads its "
+                                                             "image's rows twice (assignment, then the ordered accumulation into the waves' register sums) and the second read reaches "
+                                                             "the fabric again; the vector is written once.  Latency-bound phases inside a block at three blocks per CU "
+                                                             "(DESIGN.md 5.5).  Round 4's two kernels: 4.8 M images/s; round 3's fp64 brute force: 0.94 M"}}
     hp2 = C.c_void_p()
     mean_v = V.mean(0).cpu().numpy()
     nat.check(L.mmidx_pca_create(nc, ss, 1, mean_v.ctypes.data, eig_h.ctypes.data, Vt_h.ctypes.data, device, C.byref(hp2)))
