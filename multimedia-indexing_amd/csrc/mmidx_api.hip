@@ -2530,25 +2530,27 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
         TP.iid_out = d_iid;
         TP.dist_out = d_dist;
         TP.k = k;
+        TP.nq = (int)nq;
+        const unsigned tgrid = (unsigned)std::min<int64_t>((nq + MMIDX_BLOCK - 1) / MMIDX_BLOCK, 4096);  // (a block reads MMIDX_BLOCK flags at once; flagged queries are rare)
         const size_t tlds = (P.glut ? 0 : (size_t)h->m * h->ks * 8) + 2 * (size_t)h->D * 8;
         if (P.glut) {  // (the table in global scratch: one slot per query of the sub-batch)
             if ((size_t)nq > h->glut_slots) return fail(MMIDX_ERR_UNSUPPORTED, "lookup-table scratch too small for the tie replay");
             if (sdc_tt) {
-                hipLaunchKernelGGL((k_tie_resolve<unsigned char, true, true>), dim3((unsigned)nq), dim3(MMIDX_BLOCK), tlds, st, TP);
+                hipLaunchKernelGGL((k_tie_resolve<unsigned char, true, true>), dim3(tgrid), dim3(MMIDX_BLOCK), tlds, st, TP);
             } else if (h->code_bytes == 1) {
-                hipLaunchKernelGGL((k_tie_resolve<unsigned char, false, true>), dim3((unsigned)nq), dim3(MMIDX_BLOCK), tlds, st, TP);
+                hipLaunchKernelGGL((k_tie_resolve<unsigned char, false, true>), dim3(tgrid), dim3(MMIDX_BLOCK), tlds, st, TP);
             } else {
-                hipLaunchKernelGGL((k_tie_resolve<unsigned short, false, true>), dim3((unsigned)nq), dim3(MMIDX_BLOCK), tlds, st, TP);
+                hipLaunchKernelGGL((k_tie_resolve<unsigned short, false, true>), dim3(tgrid), dim3(MMIDX_BLOCK), tlds, st, TP);
             }
         } else if (sdc_tt) {
             HIPCK(hipFuncSetAttribute((const void *)k_tie_resolve<unsigned char, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
-            hipLaunchKernelGGL((k_tie_resolve<unsigned char, true>), dim3((unsigned)nq), dim3(MMIDX_BLOCK), tlds, st, TP);
+            hipLaunchKernelGGL((k_tie_resolve<unsigned char, true>), dim3(tgrid), dim3(MMIDX_BLOCK), tlds, st, TP);
         } else if (h->code_bytes == 1) {
             HIPCK(hipFuncSetAttribute((const void *)k_tie_resolve<unsigned char, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
-            hipLaunchKernelGGL((k_tie_resolve<unsigned char, false>), dim3((unsigned)nq), dim3(MMIDX_BLOCK), tlds, st, TP);
+            hipLaunchKernelGGL((k_tie_resolve<unsigned char, false>), dim3(tgrid), dim3(MMIDX_BLOCK), tlds, st, TP);
         } else {
             HIPCK(hipFuncSetAttribute((const void *)k_tie_resolve<unsigned short, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
-            hipLaunchKernelGGL((k_tie_resolve<unsigned short, false>), dim3((unsigned)nq), dim3(MMIDX_BLOCK), tlds, st, TP);
+            hipLaunchKernelGGL((k_tie_resolve<unsigned short, false>), dim3(tgrid), dim3(MMIDX_BLOCK), tlds, st, TP);
         }
         HIPCK(hipGetLastError());
     }
