@@ -1939,12 +1939,12 @@ template <int NJB>
 __global__ __launch_bounds__(64, 4) void k_coarse_front_sel(const ApproxSel A) {
     constexpr int GPL = 16;  // groups per lane: G <= 1024 (the host checks)
     __shared__ __attribute__((aligned(16))) double s_terms[16][65];  // the exact stage's tile; the keys and the selection live in it afterwards
-    __shared__ u32 s_cidx[64];
+    __shared__ u32 s_cidx[128];  // up to 128 candidates: the exact stage takes them 64 at a time
     const int lane = threadIdx.x;
     const int q = (int)blockIdx.x;
-    u64 *ckey = (u64 *)&s_terms[0][0], *sel_k = ckey + 64;
+    u64 *ckey = (u64 *)&s_terms[0][0], *sel_k = ckey + 128;
     u32 *cidx = s_cidx;
-    int *sel_i = (int *)(sel_k + 64);
+    int *sel_i = (int *)(sel_k + 64);  // [128] (ranks of up to 128 candidates pass through it)
     const int C = A.C, w = A.w, G = A.G, D = A.D;
     const int R = w + 1;
     const double qn = A.qn[q];
@@ -2035,7 +2035,7 @@ __global__ __launch_bounds__(64, 4) void k_coarse_front_sel(const ApproxSel A) {
             const u64 mask = __builtin_amdgcn_ballot_w64(pass);
             if (pass) {
                 const u32 slot = n + (u32)__popcll(mask & lane_lt);
-                if (slot < 64) cidx[slot] = (u32)c;
+                if (slot < 128) cidx[slot] = (u32)c;
             }
             n += (u32)__popcll(mask);
         }
@@ -2052,7 +2052,7 @@ __global__ __launch_bounds__(64, 4) void k_coarse_front_sel(const ApproxSel A) {
                 for (int ct = 0; ct < 8; ct++)
                     if (ct != a1 && cb + 16 * ct < C) {
                         const u32 slot = atomicAdd(cnt, 1u);
-                        if (slot < 64) cidx[slot] = (u32)(cb + 16 * ct);
+                        if (slot < 128) cidx[slot] = (u32)(cb + 16 * ct);
                     }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2063,7 +2063,7 @@ __global__ __launch_bounds__(64, 4) void k_coarse_front_sel(const ApproxSel A) {
             __builtin_amdgcn_wave_barrier();
         }
         CFS_TICK(2);
-        if (n > 64 || (int)n < R) {  // (fewer than w + 1 candidates cannot happen with a valid cut; k_coarse_select_list's business either way)
+        if (n > 128 || (int)n < R) {  // (fewer than w + 1 candidates cannot happen with a valid cut; k_coarse_select_list's business either way)
             n = 0;
 #pragma unroll 1
             for (int i = 0; i < GPL; i++) {
@@ -2100,62 +2100,72 @@ __global__ __launch_bounds__(64, 4) void k_coarse_front_sel(const ApproxSel A) {
     {
         double(*terms)[65] = s_terms;  // [16][64 + 1]: lane c reads terms[j][c] (consecutive banks), the 8 lanes of a row write two apart
         const int cl = lane >> 3, jp = lane & 7;
-        const int ng = ((int)n + 7) >> 3;  // load instructions per 16 dimensions (<= 8)
         // (Asking for all lines of all candidate rows up front -- 40 % of them miss the L2: 8192 rows are 8 MiB against 4 MiB per XCD -- was
         //  tried with LDS-DMA loads into a sink: 89 -> 101 us per 16384 queries, the extra requests cost more than the misses they hid.)
         const unsigned char *cbase = (const unsigned char *)A.coarse;  // (wave-uniform base + a 32-bit byte offset per lane + a constant:
         const unsigned char *qbase = (const unsigned char *)(A.Q + (size_t)q * D);  //  no address arithmetic inside the steps)
         const u32 qo = 16u * (u32)jp;
-        double acc = 0.0;
-        // NG = load instructions per block of 16 dimensions, a compile-time bound on ceil(n / 8): every load of an instance is
-        // unconditional (clamped candidates), every step of it unrolled -- the waits are counted, not full
-        auto exact = [&](auto ngc) {
-            constexpr int NG = decltype(ngc)::value;
-            u32 rowb[NG];  // (byte offsets: C * D * 8 < 2^32 for every C this kernel takes)
-#pragma unroll
-            for (int gq = 0; gq < NG; gq++) {
-                const int ci = gq * 8 + cl;
-                const int cc = ci < (int)n ? ci : (int)n - 1;
-                rowb[gq] = (cidx[cc] * (u32)D + 2u * (u32)jp) * 8u;
-            }
-            double2 buf[2][NG], qv[2];
-#pragma unroll
-            for (int gq = 0; gq < NG; gq++) buf[0][gq] = *(const double2 *)(cbase + rowb[gq]);
-            qv[0] = *(const double2 *)(qbase + qo);
-#pragma unroll
-            for (int jb = 0; jb < NJB; jb++) {
-                const int cu = jb & 1, nx = cu ^ 1;
-                if (jb + 1 < NJB) {  // the next block's rows into the other register set first (two sets, no copies)
-#pragma unroll
-                    for (int gq = 0; gq < NG; gq++) buf[nx][gq] = *(const double2 *)(cbase + rowb[gq] + (jb + 1) * 128);
-                    qv[nx] = *(const double2 *)(qbase + qo + (jb + 1) * 128);
-                }
+        // NG = load instructions per block of 16 dimensions, a compile-time bound on ceil(candidates / 8): every load of an instance is
+        // unconditional (clamped candidates), every step of it unrolled -- the waits are counted, not full.  Candidates base .. base + 63
+        // (more than 64 -- a few queries in a hundred at w = 32 -- take a second pass instead of the block-per-query kernel, whose
+        // single launch for them cost 17 us of every step).
+        u64 key0 = MMIDX_KEY_MAX, key1 = MMIDX_KEY_MAX;
+        for (int base = 0; base < (int)n; base += 64) {
+            const int cn = (int)n - base < 64 ? (int)n - base : 64;
+            const int ng = (cn + 7) >> 3;
+            double acc = 0.0;
+            auto exact = [&](auto ngc) {
+                constexpr int NG = decltype(ngc)::value;
+                u32 rowb[NG];  // (byte offsets: C * D * 8 < 2^32 for every C this kernel takes)
 #pragma unroll
                 for (int gq = 0; gq < NG; gq++) {
-                    const double d0 = buf[cu][gq].x - qv[cu].x, d1 = buf[cu][gq].y - qv[cu].y;
-                    terms[2 * jp][gq * 8 + cl] = d0 * d0;  // (columns >= n: copies of the last candidate, never read back)
-                    terms[2 * jp + 1][gq * 8 + cl] = d1 * d1;
+                    const int ci = gq * 8 + cl;
+                    const int cc = ci < cn ? ci : cn - 1;
+                    rowb[gq] = (cidx[base + cc] * (u32)D + 2u * (u32)jp) * 8u;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                double2 buf[2][NG], qv[2];
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    double tv[8];
+                for (int gq = 0; gq < NG; gq++) buf[0][gq] = *(const double2 *)(cbase + rowb[gq]);
+                qv[0] = *(const double2 *)(qbase + qo);
 #pragma unroll
-                    for (int j = 0; j < 8; j++) tv[j] = terms[8 * h + j][lane];
+                for (int jb = 0; jb < NJB; jb++) {
+                    const int cu = jb & 1, nx = cu ^ 1;
+                    if (jb + 1 < NJB) {  // the next block's rows into the other register set first (two sets, no copies)
 #pragma unroll
-                    for (int j = 0; j < 8; j++) acc += tv[j];  // (lane >= n: junk, never used)
+                        for (int gq = 0; gq < NG; gq++) buf[nx][gq] = *(const double2 *)(cbase + rowb[gq] + (jb + 1) * 128);
+                        qv[nx] = *(const double2 *)(qbase + qo + (jb + 1) * 128);
+                    }
+#pragma unroll
+                    for (int gq = 0; gq < NG; gq++) {
+                        const double d0 = buf[cu][gq].x - qv[cu].x, d1 = buf[cu][gq].y - qv[cu].y;
+                        terms[2 * jp][gq * 8 + cl] = d0 * d0;  // (columns >= cn: copies of the last candidate, never read back)
+                        terms[2 * jp + 1][gq * 8 + cl] = d1 * d1;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        double tv[8];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) tv[j] = terms[8 * h + j][lane];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) acc += tv[j];  // (lane >= cn: junk, never used)
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-        };
-        if (ng <= 4) exact(std::integral_constant<int, 4>());
-        else if (ng <= 6) exact(std::integral_constant<int, 6>());
-        else exact(std::integral_constant<int, 8>());
-        ckey[lane] = lane < (int)n ? dkey(acc) : MMIDX_KEY_MAX;
+            };
+            if (ng <= 4) exact(std::integral_constant<int, 4>());
+            else if (ng <= 6) exact(std::integral_constant<int, 6>());
+            else exact(std::integral_constant<int, 8>());
+            const u64 kk = lane < cn ? dkey(acc) : MMIDX_KEY_MAX;
+            if (base == 0) key0 = kk;
+            else key1 = kk;
+        }
+        ckey[lane] = key0;  // (the tile is free: the keys move in)
+        ckey[64 + lane] = key1;
     }
     CFS_TICK(3);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2165,40 +2175,65 @@ __global__ __launch_bounds__(64, 4) void k_coarse_front_sel(const ApproxSel A) {
     //      counts the keys under its own from broadcast LDS reads, eight a round (lanes past n hold the largest key); equal keys show
     //      as two lanes with one rank and send the wave through the slower (key, index, lane) count.
     {
-        const bool have = lane < (int)n;
-        const u64 mk = ckey[lane];
-        const u32 mv = have ? cidx[lane] : 0xFFFFFFFFu;
-        int rank = 0;
-        for (int j = 0; j < (int)n; j += 8) {
-            u64 ok[8];
+        const bool have0 = lane < (int)n, have1 = lane + 64 < (int)n;
+        const u64 mk0 = ckey[lane], mk1 = ckey[64 + lane];
+        const u32 mv0 = have0 ? cidx[lane] : 0xFFFFFFFFu, mv1 = have1 ? cidx[64 + lane] : 0xFFFFFFFFu;
+        int rank0 = 0, rank1 = 0;
+        if (n <= 64) {
+            for (int j = 0; j < (int)n; j += 8) {
+                u64 ok[8];
 #pragma unroll
-            for (int t = 0; t < 8; t++) ok[t] = ckey[j + t];
+                for (int t = 0; t < 8; t++) ok[t] = ckey[j + t];
 #pragma unroll
-            for (int t = 0; t < 8; t++) rank += ok[t] < mk;
+                for (int t = 0; t < 8; t++) rank0 += ok[t] < mk0;
+            }
+        } else {
+            for (int j = 0; j < (int)n; j += 8) {
+                u64 ok[8];
+#pragma unroll
+                for (int t = 0; t < 8; t++) ok[t] = ckey[j + t];
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    rank0 += ok[t] < mk0;
+                    rank1 += ok[t] < mk1;
+                }
+            }
         }
-        if (have) sel_i[rank] = lane;
+        if (have0) sel_i[rank0] = lane;
+        if (have1) sel_i[rank1] = lane + 64;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const bool dup = have && sel_i[rank] != lane;
-        if (__builtin_amdgcn_ballot_w64(dup)) {  // wave-uniform
-            rank = 0;
+        const bool dup = (have0 && sel_i[rank0] != lane) || (have1 && sel_i[rank1] != lane + 64);
+        if (__builtin_amdgcn_ballot_w64(dup)) {  // wave-uniform: equal keys somewhere -- (key, index, position) decides
+            rank0 = rank1 = 0;
             for (int j = 0; j < (int)n; j++) {
-                const u32 olo = wave_read_u32((u32)mk, j), ohi = wave_read_u32((u32)(mk >> 32), j), ov = wave_read_u32(mv, j);
-                const u64 ok = ((u64)ohi << 32) | olo;
-                rank += (ok < mk) || (ok == mk && (ov < mv || (ov == mv && j < lane)));
+                const u64 ok = ckey[j];
+                const u32 ov = cidx[j];
+                rank0 += (ok < mk0) || (ok == mk0 && (ov < mv0 || (ov == mv0 && j < lane)));
+                rank1 += (ok < mk1) || (ok == mk1 && (ov < mv1 || (ov == mv1 && j < lane + 64)));
             }
         }
-        __builtin_amdgcn_wave_barrier();  // (every lane has read its entry before any lane writes)
-        if (have) {
-            ckey[rank] = mk;
-            cidx[rank] = mv;
-            if (rank < R) {
-                sel_k[rank] = mk;
-                sel_i[rank] = (int)mv;
-            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // (every lane has read the entries before any lane writes)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (have0) {
+            ckey[rank0] = mk0;
+            cidx[rank0] = mv0;
+            if (rank0 < R) sel_k[rank0] = mk0;
         }
+        if (have1) {
+            ckey[rank1] = mk1;
+            cidx[rank1] = mv1;
+            if (rank1 < R) sel_k[rank1] = mk1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // (sel_i held the ranks' owners until here)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (have0 && rank0 < R) sel_i[rank0] = (int)mv0;
+        if (have1 && rank1 < R) sel_i[rank1] = (int)mv1;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     CFS_TICK(4);
 #ifdef CFS_TIMING
