@@ -43,9 +43,9 @@ def main(tag):
     head = rows(P("headline"))
     hist = pick(head, "FETCH_SIZE", "k_scan_hist<16, 256, 256>")
     out = {
-        "source": "profiles/%s_{headline,b131k,vlad,yfcc}_pmc_kernels.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, tools/profile_%s.sh parts 2-3; "
+        "source": "profiles/%s_{headline,b131k,vlad,yfcc}_pmc_kernels.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, tools/profile_r05.sh parts 2-3 with this tag; "
                   "KiB x 1024, reads x 2: the gfx950 correction for streaming reads, MI355X_MICROARCH.md section HBM); hard / spread pass B: "
-                  "profiles/r04_hard_pmc_kernels.txt, profiles/r04_spread_pmc_kernels.txt (K3m unchanged since)" % (tag, tag),
+                  "profiles/r04_hard_pmc_kernels.txt, profiles/r04_spread_pmc_kernels.txt (K3m unchanged since)" % (tag,),
         "workload": old["workload"],
         "k_scan_hist_fetch_kib_per_step": hist,
         "k_scan_launches_per_step": 2,
