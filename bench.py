@@ -879,7 +879,7 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
                             "traffic_source": "profiles/hbm_traffic.json: FETCH_SIZE x 2 of the two sweep kernels, separate rocprofv3 --pmc pass" if isinstance(tr, dict) else None,
                             "note": "16 queries per list fill ONE 16-row tile: per tile of 16 codes 4 matrix instructions stand against 4 random 16-byte "
                                     "decode gathers and ~50-65 vector instructions (slot updates / compares, addresses), which bound the sweeps "
-                                    "(profiles/r05_b131k_pmc_kernels.txt); the algorithmic byte rate exceeds the HBM rate because a list is read once for "
+                                    "(profiles/r05b_b131k_pmc_kernels.txt); the algorithmic byte rate exceeds the HBM rate because a list is read once for "
                                     "all the queries that probe it (physical traffic: `traffic`)"},
                "parity": par}
         log(f"batch {big_B}: {res['value'] / 1e6:.2f} M q/s, {res['ms_per_step']} ms per step, pass A {pa_ms_b:.3f} ms (sweeps {sweeps_ms:.3f}), parity {par}")
