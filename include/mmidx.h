@@ -351,6 +351,8 @@ int mmidx_set_profiling(mmidx_index *h, int enabled);
  * "passb_small" (0: pass B through K3m / K3g also when the call before kept at most 64 pairs; default 1: K3f's looping kernel alone,
  * one launch), "passa_mfma" (round 5, K3ma: pass A through the matrix-core bound in two sweeps -- 1 wherever the shape allows, 0 never,
  * -1 = default: from 8 queries per list of a long-list index),
+ * "shard_route_host" (round 5; 1: mmidx_add_vectors_sliced_device sends its records through the host as before round 5 instead of routing
+ * them between the devices),
  * "shard_pipeline" (1: the query exchange of a sharded handle on a second stream / communicator; the default for in-process shards, off
  * by default on two or more physical devices until a multi-device run has passed).  None of them changes a result. */
 int mmidx_set_option(mmidx_index *h, const char *name, int value);

@@ -232,6 +232,8 @@ struct ShardBufs {  // everything on the shard's device
     DevBuf<double> X;           // add / encode staging
     DevBuf<int32_t> ecell;
     DevBuf<unsigned char> ecode;
+    DevBuf<int32_t> rblk, rcell, riid;  // device-side routing of a round's records (sharded_add_vectors): block counts / offsets, the shard's own records
+    DevBuf<unsigned char> rcode;
     int32_t *pin_nflag = nullptr;  // pinned host words: [0] flagged queries of the round, [1] the round's sequence number
     int32_t seq = 0;
     ShardDest *pin_dest = nullptr; // pinned host copy of `dest` (what was last uploaded: re-sent only when a pointer changed)
@@ -254,6 +256,7 @@ struct ShardBufs {  // everything on the shard's device
         pk.release(); rpk.release(); cells.release(); pc.release(); rpc.release(); oiid.release(); ocnt.release(); flag.release();
         nflag.release(); rows_own.release(); fq_own.release(); fq.release(); counts.release(); pB.release(); ties.release();
         tmp.release(); dest.release(); X.release(); ecell.release(); ecode.release();
+        rblk.release(); rcell.release(); riid.release(); rcode.release();
         if (pin_nflag) (void)hipHostFree(pin_nflag);
         pin_nflag = nullptr;
         if (pin_dest) (void)hipHostFree(pin_dest);
@@ -276,6 +279,7 @@ struct ShardGroup {
                                     // (default 1 for in-process shards, 0 for two or more physical devices: mmidx_create_sharded)
     bool rccl = false;       // collectives through RCCL (devices pairwise distinct); else in-process (virtual shards)
     bool peer_ok = true;     // every shard can store into every other shard's memory
+    int route_host = 0;      // option "shard_route_host": 1 = mmidx_add_vectors_sliced_device routes its records through the host (A/B switch)
     int exchange = 0;        // option "shard_exchange": 0 = pass B stores into the owners' buffers, 1 = ncclSend / ncclRecv of dense lists
     int tie_slots = 32;      // option "tie_slots": flagged queries replayed per owner and round
     int64_t max_round = 262144;  // option "shard_max_round": queries per collective round over all shards
@@ -825,7 +829,7 @@ int sharded_search(mmidx_index *h, int k, int64_t nq, const double *Q, int32_t *
 // ---- indexing ----------------------------------------------------------------------------------------------------------
 // Encodes rows [lo, hi) of a round on worker r: X from the host (Xh, the round's first row) or from the shard's device
 // (dX_own: the slice itself).  cells / codes (stored form) of the whole round land in the host arrays hc / hk.
-int shard_encode_slice(ShardGroup *g, int r, const double *Xh, const double *dX_own, int64_t lo, int64_t hi, int32_t *hc, unsigned char *hk) {
+int shard_encode_slice(ShardGroup *g, int r, const double *Xh, const double *dX_own, int64_t lo, int64_t hi, int32_t *hc, unsigned char *hk) {  // hc == null: the records stay on the device
     mmidx_index *s = g->sub[(size_t)r];
     ShardBufs &B = g->buf[(size_t)r];
     hipStream_t st = g->st[(size_t)r];
@@ -842,10 +846,156 @@ int shard_encode_slice(ShardGroup *g, int r, const double *Xh, const double *dX_
     HIPCK(B.ecode.reserve((size_t)n * cb));
     int rc = mmidx_encode_device(s, n, dX, B.ecell.p, B.ecode.p, st);
     if (rc) return rc;
-    HIPCK(hipMemcpyAsync(hc + lo, B.ecell.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    HIPCK(hipMemcpyAsync(hk + (size_t)lo * cb, B.ecode.p, (size_t)n * cb, hipMemcpyDeviceToHost, st));
+    if (hc) {
+        HIPCK(hipMemcpyAsync(hc + lo, B.ecell.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        HIPCK(hipMemcpyAsync(hk + (size_t)lo * cb, B.ecode.p, (size_t)n * cb, hipMemcpyDeviceToHost, st));
+    }
     HIPCK(hipStreamSynchronize(st));
     return MMIDX_OK;
+}
+
+// ---- device-side routing of a round's records (round 5) ---------------------------------------------------------------------------
+// Every shard has encoded its slice on its own device (ecell / ecode of ShardBufs).  Shard r picks ITS records (cell mod n == r) out
+// of all slices, in batch order -- the order in which the reference appends to a list (invertedLists[c].add, IVFPQ.java:337-346) --
+// with three small kernels on its own device, reading the peers' slices over xGMI (peer access; the same device for in-process
+// shards): per-block counts, one block scan, a stable scatter into (iid, cell, code) arrays that mmidx_add_codes_device takes.
+// Until round 5 every slice went to the host, every shard walked all of the round's records there, and its share came back.
+#define ROUTE_MAXW 64
+#define ROUTE_BLK 4096  // records per block: 256 threads x 16 consecutive records (a thread's records stay in order)
+struct RouteSrc {
+    const int32_t *cell[ROUTE_MAXW];
+    const unsigned char *code[ROUTE_MAXW];
+    long long n[ROUTE_MAXW], lo[ROUTE_MAXW];  // rows of slice s; its first row's index in the batch
+    int blk0[ROUTE_MAXW + 1];                 // first block of slice s
+    int W, r, cb;
+};
+__device__ __forceinline__ int route_slice(const RouteSrc &S, int b) {
+    int s = 0;
+    while (s + 1 < S.W && b >= S.blk0[s + 1]) s++;
+    return s;
+}
+__global__ __launch_bounds__(256) void k_route_count(const RouteSrc S, int32_t *__restrict__ blkcnt) {
+    __shared__ int s_w[4];
+    const int b = blockIdx.x, s = route_slice(S, b), tid = threadIdx.x;
+    const long long i0 = (long long)(b - S.blk0[s]) * ROUTE_BLK + (long long)tid * 16;
+    int c = 0;
+    for (int u = 0; u < 16; u++) {
+        const long long i = i0 + u;
+        if (i < S.n[s]) {
+            const int cell = S.cell[s][i];
+            c += (cell >= 0 && cell % S.W == S.r);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((tid & 63) == 0) s_w[tid >> 6] = c;
+    __syncthreads();
+    if (tid == 0) blkcnt[b] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+// exclusive scan of the block counts in place; blk[nblk] = total
+__global__ __launch_bounds__(1024) void k_route_scan(int32_t *__restrict__ blk, int nblk) {
+    __shared__ u32 s_wave[16];
+    __shared__ u32 s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblk; base += 1024) {
+        const int i = base + tid;
+        const u32 c = i < nblk ? (u32)blk[i] : 0u;
+        const u32 incl = wave_incl_scan_u32(c);
+        if (lane == 63) s_wave[wv] = incl;
+        __syncthreads();
+        u32 before = s_carry;
+#pragma unroll
+        for (int j = 0; j < 16; j++) before += (j < wv) ? s_wave[j] : 0u;
+        if (i < nblk) blk[i] = (int32_t)(before + incl - c);
+        __syncthreads();
+        if (tid == 1023) s_carry = before + incl;
+        __syncthreads();
+    }
+    if (tid == 0) blk[nblk] = (int32_t)s_carry;
+}
+__global__ __launch_bounds__(256) void k_route_scatter(const RouteSrc S, const int32_t *__restrict__ blkoff, int32_t iid0, int32_t *__restrict__ oiid,
+                                                       int32_t *__restrict__ ocell, unsigned char *__restrict__ ocode) {
+    __shared__ u32 s_w[4];
+    const int b = blockIdx.x, s = route_slice(S, b), tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long i0 = (long long)(b - S.blk0[s]) * ROUTE_BLK + (long long)tid * 16;
+    int cells[16];
+    u32 c = 0;
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        const long long i = i0 + u;
+        cells[u] = i < S.n[s] ? S.cell[s][i] : -1;
+        c += (cells[u] >= 0 && cells[u] % S.W == S.r);
+    }
+    const u32 incl = wave_incl_scan_u32(c);
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    u32 o = (u32)blkoff[b] + incl - c;
+    for (int j = 0; j < 4; j++) o += (j < wv) ? s_w[j] : 0u;
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        if (cells[u] >= 0 && cells[u] % S.W == S.r) {
+            const long long i = i0 + u;
+            oiid[o] = (int32_t)(iid0 + S.lo[s] + i);
+            ocell[o] = cells[u];
+            const unsigned char *src = S.code[s] + (size_t)i * S.cb;
+            unsigned char *dst = ocode + (size_t)o * S.cb;
+            if ((S.cb & 15) == 0)
+                for (int t = 0; t < S.cb; t += 16) *(uint4 *)(dst + t) = *(const uint4 *)(src + t);
+            else
+                for (int t = 0; t < S.cb; t++) dst[t] = src[t];
+            o++;
+        }
+    }
+}
+
+// worker r's part of a device-routed round: count, reserve (all shards, then a barrier), scatter, append
+int shard_route_device(ShardGroup *g, int r, const std::vector<int64_t> &lo, int32_t iid0) {
+    mmidx_index *s = g->sub[(size_t)r];
+    ShardBufs &B = g->buf[(size_t)r];
+    hipStream_t st = g->st[(size_t)r];
+    const int W = g->n;
+    RouteSrc S{};
+    S.W = W;
+    S.r = r;
+    S.cb = s->m * s->code_bytes;
+    int nblk = 0;
+    for (int q = 0; q < W; q++) {
+        S.cell[q] = g->buf[(size_t)q].ecell.p;
+        S.code[q] = g->buf[(size_t)q].ecode.p;
+        S.n[q] = lo[(size_t)q + 1] - lo[(size_t)q];
+        S.lo[q] = lo[(size_t)q];
+        S.blk0[q] = nblk;
+        nblk += (int)((S.n[q] + ROUTE_BLK - 1) / ROUTE_BLK);
+    }
+    S.blk0[W] = nblk;
+    int32_t mine = 0;
+    if (nblk > 0) {
+        HIPCK(B.rblk.reserve((size_t)nblk + 2));
+        hipLaunchKernelGGL(k_route_count, dim3((unsigned)nblk), dim3(256), 0, st, S, B.rblk.p);
+        hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(1024), 0, st, B.rblk.p, nblk);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(&mine, B.rblk.p + nblk, 4, hipMemcpyDeviceToHost, st));
+        HIPCK(hipStreamSynchronize(st));
+    }
+    // all or nothing: every shard makes room for its share of the round first (the one step of an append that can fail for lack of
+    // memory); a shard that cannot aborts the barrier and nobody appends
+    {
+        std::lock_guard<std::recursive_mutex> alk(s->add_mu);
+        int rc = ensure_pending(s, mine);
+        if (rc) return rc;
+        if (mine > 0) {
+            HIPCK(B.riid.reserve((size_t)mine));
+            HIPCK(B.rcell.reserve((size_t)mine));
+            HIPCK(B.rcode.reserve((size_t)mine * (size_t)S.cb + 16));
+        }
+    }
+    BARRIER(g);
+    if (mine == 0) return MMIDX_OK;
+    hipLaunchKernelGGL(k_route_scatter, dim3((unsigned)nblk), dim3(256), 0, st, S, B.rblk.p, iid0, B.riid.p, B.rcell.p, B.rcode.p);
+    HIPCK(hipGetLastError());
+    return mmidx_add_codes_device(s, mine, B.riid.p, B.rcell.p, B.rcode.p, st);
 }
 
 // Appends the records of a round that belong to worker r's lists (cell mod n == r), in row order = arrival order
@@ -893,6 +1043,18 @@ int sharded_add_vectors(mmidx_index *h, int64_t n, const double *X, const double
     const int W = g->n;
     const size_t cb = (size_t)h->m * h->code_bytes;
     const int64_t R = X ? (int64_t)W * (1 << 18) : n;  // host batches in rounds; device slices in one
+    // device slices, nothing asked back, ids numbered by the library: the records never leave the devices (peer access between distinct
+    // devices; option "shard_route_host" = 1: the host path)
+    if (dXs && !X && !iids && !cell_out && !code_out && g->peer_ok && !g->route_host && W <= ROUTE_MAXW && h->kind == MMIDX_KIND_IVFPQ) {
+        std::vector<int64_t> lo((size_t)W + 1, 0);
+        for (int r = 0; r < W; r++) lo[(size_t)r + 1] = lo[(size_t)r] + ns[r];
+        return shard_run(g, [=, &lo](int r) -> int {
+            int rc2 = shard_encode_slice(g, r, nullptr, dXs[r], lo[(size_t)r], lo[(size_t)r + 1], nullptr, nullptr);
+            if (rc2) return rc2;
+            BARRIER(g);  // every slice's records are in place
+            return shard_route_device(g, r, lo, iid0);
+        });
+    }
     std::vector<int32_t> hc_own;
     std::vector<unsigned char> hk_own;
     for (int64_t i0 = 0; i0 < n; i0 += R) {
@@ -1195,6 +1357,11 @@ int sharded_set_option(mmidx_index *h, const char *name, int value) {
     }
     if (n == "combine") {
         g->comb.enabled = value != 0;
+        return MMIDX_OK;
+    }
+    if (n == "shard_route_host") {
+        std::lock_guard<std::mutex> lk(g->call_mu);
+        g->route_host = value != 0;
         return MMIDX_OK;
     }
     if (n == "shard_pipeline") {  // 1: the query exchange on the shards' second streams (overlapped); 0: one stream per shard (A/B switch)

@@ -188,6 +188,43 @@ def test_native_sharded_smin_prefilter(mi, oracle, devices, tr):
     ix.close()
 
 
+@pytest.mark.parametrize("S,m,route_host", [(3, 8, 0), (3, 8, 1), (4, 5, 0), (8, 16, 0)])
+def test_native_sharded_device_side_routing(mi, oracle, S, m, route_host):
+    """mmidx_add_vectors_sliced_device keeps the records on the devices (round 5): every shard picks its own (cell mod S) out of all
+    slices in batch order -- count, scan, stable scatter, mmidx_add_codes_device.  Uneven and empty slices, slices that straddle the
+    4096-record blocks, 5-byte codes (the byte-wise copy) and 16-byte ones (the 16-byte copy); the lists -- ids in arrival order,
+    codes -- equal those of a plain handle fed the same batches, and so do the search results.  `shard_route_host` = 1: the host path."""
+    import torch
+
+    L, nat = mi.lib(), importlib.import_module("multimedia-indexing_amd._native")
+    D, C_, ks, n, w, k = 80, 37, 256, 21000, 5, 10
+    p = synth.make_ivfpq_problem(n=n, D=D, C=C_, m=m, ks=ks, nq=30, seed=9, iters=2)
+    plain = mi.IVFPQ(D, n, False, "", m, ks, 0, C_, 512)
+    plain.loadCoarseQuantizer(p["coarse"])
+    plain.loadProductQuantizer(p["pq"])
+    plain.setW(w)
+    plain.indexVectors([str(i) for i in range(n)], p["base"])
+    ix = make_sharded(mi, p, D, m, ks, C_, w, n, [0] * S)
+    ix.set_option("shard_route_host", route_host)
+    X = torch.tensor(p["base"], dtype=torch.float64, device="cuda")
+    rng = np.random.default_rng(S)
+    for i0, i1 in ((0, 9000), (9000, 9001), (9001, n)):
+        cuts = np.sort(np.concatenate([[i0, i1], rng.integers(i0, i1 + 1, S - 1)])).astype(np.int64)
+        if i1 - i0 > 5000:
+            cuts[1] = cuts[0]  # an empty slice
+        parts = [X[cuts[r]:cuts[r + 1]].contiguous() if cuts[r + 1] > cuts[r] else X[:1].contiguous() for r in range(S)]
+        ns = (C.c_int64 * S)(*[int(cuts[r + 1] - cuts[r]) for r in range(S)])
+        ptrs = (C.c_void_p * S)(*[t.data_ptr() for t in parts])
+        torch.cuda.synchronize()
+        nat.check(L.mmidx_add_vectors_sliced_device(ix._h, ns, ptrs, int(i0)))
+    a, b = plain.export(), ix.export()
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert_same(ix.search_batch(k, p["queries"]), plain.search_batch(k, p["queries"]))
+    ix.close()
+    plain.close()
+
+
 @pytest.mark.parametrize("S", [1, 2])
 def test_native_sharded_sliced_device_entry_points(mi, oracle, S):
     """The device-resident forms: slice r of the batch lives in the HBM of shard r's device (torch tensors as plumbing)."""
