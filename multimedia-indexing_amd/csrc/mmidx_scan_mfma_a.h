@@ -185,16 +185,39 @@ __global__ __launch_bounds__(A1R_NT) void k_a1_records(const MfmaParams P) {
         const int wpl = ntl <= 2 ? 8 : 4;                 // words per 16-byte load
         const int nload = npt * 64 / wpl;                 // (64 words per tile pair)
         u32 mine = 0;
-        for (int l = tid; l < nload; l += 4 * A1R_NT) {  // (four loads in flight: one at a time the loop is a chain of L2 round trips)
-            uint4 a[4];
+        // Up to 16 loads per thread (a piece of <= 16384 codes with <= 32 rows: the usual item is ONE piece of ~12 k codes, 12 loads per
+        // thread): ALL of them in flight at once and kept in registers for the walk below.  (Four at a time and a second read of every
+        // word inside the walk, the item was fifteen memory round trips in a row: 110 k cycles, 263 us per 131072 queries.)
+        constexpr int KEEP = 16;
+        const bool small = nload <= KEEP * A1R_NT;  // (block-uniform)
+        const int nu = (nload + A1R_NT - 1) / A1R_NT;
+        uint4 keep[KEEP];
+        if (small) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int lu = l + u * A1R_NT;
-                a[u] = ((const uint4 *)bm)[lu < nload ? lu : l];
+            for (int u = 0; u < KEEP; u++) {
+                keep[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (u < nu) {  // (block-uniform)
+                    const int lu = tid + u * A1R_NT;
+                    keep[u] = ((const uint4 *)bm)[lu < nload ? lu : tid];
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (l + u * A1R_NT < nload) mine += (u32)(__popc(a[u].x) + __popc(a[u].y) + __popc(a[u].z) + __popc(a[u].w));
+            for (int u = 0; u < KEEP; u++) {
+                if (tid + u * A1R_NT >= nload) keep[u] = make_uint4(0u, 0u, 0u, 0u);
+                mine += (u32)(__popc(keep[u].x) + __popc(keep[u].y) + __popc(keep[u].z) + __popc(keep[u].w));
+            }
+        } else {
+            for (int l = tid; l < nload; l += 4 * A1R_NT) {  // (four loads in flight: one at a time the loop is a chain of L2 round trips)
+                uint4 a[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int lu = l + u * A1R_NT;
+                    a[u] = ((const uint4 *)bm)[lu < nload ? lu : l];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (l + u * A1R_NT < nload) mine += (u32)(__popc(a[u].x) + __popc(a[u].y) + __popc(a[u].z) + __popc(a[u].w));
+            }
         }
         const u32 incl = wave_incl_scan_u32(mine);
         __syncthreads();  // (s_wave of the previous item has been read)
@@ -206,9 +229,8 @@ __global__ __launch_bounds__(A1R_NT) void k_a1_records(const MfmaParams P) {
         if (!mine) continue;  // (no barrier below)
         // the set bits of a 16-byte load, 64 at a time (the masks are sparse -- ~1 % of the bits --: walking the words costs a branch per
         // word and lane, 0.35 ms per 131072 queries; walking the bits costs nothing for an empty word)
-        for (int l = tid; l < nload; l += A1R_NT) {
-            const uint4 a = ((const uint4 *)bm)[l];
-            if (!(a.x | a.y | a.z | a.w)) continue;
+        auto walk = [&](const int l, const uint4 a) {
+            if (!(a.x | a.y | a.z | a.w)) return;
 #pragma unroll
             for (int hq = 0; hq < 2; hq++) {
                 u64 w64 = hq ? (((u64)a.w << 32) | (u64)a.z) : (((u64)a.y << 32) | (u64)a.x);
@@ -229,6 +251,13 @@ __global__ __launch_bounds__(A1R_NT) void k_a1_records(const MfmaParams P) {
                     P.a_rec[o++] = make_uint2((u32)(first + (b >> 2) * 16 + 4 * g + (b & 3)), posb + (u32)((2 * pr + h) * 16 + n));
                 }
             }
+        };
+        if (small) {
+#pragma unroll
+            for (int u = 0; u < KEEP; u++)
+                if (u < nu) walk(tid + u * A1R_NT, keep[u]);  // (words past the item's end are zero)
+        } else {
+            for (int l = tid; l < nload; l += A1R_NT) walk(l, ((const uint4 *)bm)[l]);
         }
     }
 }
