@@ -31,8 +31,10 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for case in range(cases):
     kind = rng.choice(["ivfpq", "ivfpq", "pq"])
-    m = int(rng.choice([1, 2, 4, 8, 16, 32, 6, 64]))
+    m = int(rng.choice([1, 2, 4, 8, 16, 32, 6, 64, 128]))  # (128 x 256 byte codes: the table of twice the LDS, k_scan_split)
     dsub = int(rng.choice([1, 2, 4, 8, 16, 3]))
+    if m == 128 and dsub > 4:
+        dsub = int(rng.choice([1, 2, 4]))  # (keeps the oracle's encoder and the k-means short)
     if m == 64 and dsub > 8 and rng.random() < 0.5:
         dsub = 4  # (keeps most of the 64 x 16 cases' k-means short; YFCC's own 64 x 16 stays in the mix)
     D = m * dsub
@@ -60,9 +62,10 @@ for case in range(cases):
     wsel = int(rng.random() < 0.7)  # the coarse stage's exact selection by one wave per query (k_coarse_front_sel) where it applies
     pam = int(rng.choice([-1, -1, 1, 1]))  # K3ma (pass A on the matrix cores, two sweeps): by the batch (never, at seven queries) / forced where the shape allows
     pamw = int(rng.random() < 0.7)  # ... its second sweep by the eight-wave instance
+    nosplit = int(rng.random() < 0.25)  # m = 128: the table-in-global kernels instead of k_scan_split
     # the oracle's encoder is one thread ((C + ks) x D fp64 triples per vector): keep a case near a second of it
     n = max(1, min(n, int(1.5e9 / ((C + ks) * D))))
-    desc = dict(kind=kind, D=D, m=m, ks=ks, n=n, k=k, C=C, w=w, tr=tr, dup=dup, hist=hist, v1=v1, wide=wide, nogrp=nogrp, fused=fused, union=union, spre=spre, nomf=nomf, mfsub=mfsub, mfq=mfq, kcv1=kcv1, wsel=wsel, pam=pam, pamw=pamw)
+    desc = dict(kind=kind, D=D, m=m, ks=ks, n=n, k=k, C=C, w=w, tr=tr, dup=dup, hist=hist, v1=v1, wide=wide, nogrp=nogrp, fused=fused, union=union, spre=spre, nomf=nomf, nosplit=nosplit, mfsub=mfsub, mfq=mfq, kcv1=kcv1, wsel=wsel, pam=pam, pamw=pamw)
     try:
         nb = min(n, 3000)
         if kind == "ivfpq":
@@ -101,6 +104,7 @@ for case in range(cases):
         ix.set_option("coarse_wave_sel", wsel)
         ix.set_option("passa_mfma", pam)
         ix.set_option("passa_mfma_wide", pamw)
+        ix.set_option("no_split_table", nosplit)
         ix.set_option("smin_valu", int(case % 3 == 0))
         ix.set_option("smin_bf16", int(case % 4 != 1))
         ix.set_option("coarse_dma_kc", int(case % 5 != 2))  # (K1e' with LDS-DMA for vectors of several 128-dimension chunks)
