@@ -425,6 +425,8 @@ def main():
                     help="extra untimed-for-value steps with pruning off, reported as roofline_exhaustive (0 = skip)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
                     help="mmidx_set_option(NAME, INT) on the index before the timed steps (kernel A/B switches)")
+    ap.add_argument("--extra-out", default=os.path.join(ROOT, "bench_extra.json"),
+                    help="file that receives every side measurement (hard / spread / other configs / cfg5 / yfcc / host path ...); the JSON line names it")
     ap.add_argument("--dump", default="", metavar="PREFIX", help="write batch 0's answers of every rank to PREFIX.rank<r>.npz")
     ap.add_argument("--sharded-self-test", action="store_true",
                     help="(internal) build a small index on the sharded handle over --gpus devices and on a plain handle, compare the answers, exit 0 / 1")
@@ -1109,16 +1111,24 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
             ns = args.dry_run_shards
             cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(ns), "--steps", "6", "--warmup", "2", "--settle", "3", "--hard-steps", "0",
                    "--spread-steps", "0", "--other-configs", "0", "--extras", "0", "--yfcc-n", "0", "--cfg5-images", "0", "--exhaustive-steps", "0",
-                   "--cpu-seconds", "2", "--dry-run-shards", "0", "--big-batch", "0", "--vectors", str(N), "--batch", str(args.batch)]
+                   "--cpu-seconds", "2", "--dry-run-shards", "0", "--big-batch", "0", "--vectors", str(N), "--batch", str(args.batch),
+                   "--extra-out", args.extra_out + ".dry_run"]
             pr = subprocess.run(cmd, env=dict(os.environ, MMIDX_BENCH_VIRTUAL_SHARDS="1"), capture_output=True, text=True, timeout=420)
             jl = [l for l in pr.stdout.splitlines() if l.startswith("{")]
             if pr.returncode == 0 and jl:
                 dj = json.loads(jl[-1])
+                try:  # (the child's side objects live in its own extras file)
+                    dx = json.load(open(args.extra_out + ".dry_run"))
+                    os.remove(args.extra_out + ".dry_run")
+                except (OSError, ValueError):
+                    dx = {}
                 k3 = [l for l in pr.stderr.splitlines() if "K3ma pass A per step" in l]
                 dry = {"n_virtual_shards": ns, "queries_per_s": dj["value"], "queries_per_round": dj["config"]["batch"], "ms_per_round": dj["ms_per_step"],
                        "ms_per_shard_and_round": round(dj["ms_per_step"] / ns, 4), "parity": dj.get("parity"),
                        "pass_a": k3[-1].split("] ", 1)[-1] if k3 else "K3h (K3ma off or not applicable)",
-                       "stage_ms_slowest_shard": {"coarse": dj["roofline_whole_search"]["coarse_ms_per_step"], "merge": dj["roofline_whole_search"]["merge_ms_per_step"]},
+                       "stage_ms_slowest_shard": {"coarse": dx.get("roofline_whole_search", {}).get("coarse_ms_per_step"),
+                                                  "merge": dx.get("roofline_whole_search", {}).get("merge_ms_per_step")},
+                       "shard_info": dx.get("shard_info"),
                        "path": dj["config"]["multi_gpu_path"], "seconds": round(time.time() - t0, 1),
                        "note": f"{ns} in-process shards on ONE device (MMIDX_BENCH_VIRTUAL_SHARDS=1): the kernels, the partition, the threshold exchange and the "
                                "owner-side merge of the 8-GPU configuration run, sharing one GPU -- per-shard work per round, not a scaling figure; "
@@ -1153,10 +1163,16 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
             "roofline": roofline, "roofline_whole_search": whole, "roofline_exhaustive": exhaustive,
             "cpu_baseline": cpu_baseline, "parity": parity, "batch_131072": big, "hard": hard, "spread": spread, "other_configs": other, "cfg5": cfg5, "yfcc": yfcc,
             "host_path": host, "measured_ceilings": probes, "sharded_dry_run": dry,
+            # the figures a reader should see NEXT to the headline: what a Java caller reaches through the JNI shim
+            # (mmidx_search: host arrays in, host arrays out, synchronous) and what the engine does when the far probes have to be scanned
+            "host_buffers_qps": (host or {}).get("nq16384", {}).get("queries_per_s") if isinstance(host, dict) else None,
+            "hard_qps": hard.get("value") if isinstance(hard, dict) else None,
+            "spread_qps": spread.get("value") if isinstance(spread, dict) else None,
+            "batch_131072_qps": big.get("value") if isinstance(big, dict) else None,
+            "sharded_dry_run_ms_per_shard": dry.get("ms_per_shard_and_round") if isinstance(dry, dict) else None,
         }
-        print(json.dumps(out), file=json_out, flush=True)
-        # every published figure once more in ONE short stderr line (<= 2 KB): a driver that keeps only the tail of a run still sees
-        # them, whatever the length of the JSON line
+        # every published figure once more as short brace-free `key=value` text on stderr BEFORE the result line (tests/bench_emit.py):
+        # the result line is the last thing either stream carries
         def g(o, *ks):
             for kk in ks:
                 if not isinstance(o, dict) or kk not in o or o[kk] is None:
@@ -1191,13 +1207,14 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
                 "yfcc": {kk: {"Mqps": mq(g(yfcc, kk, "queries_per_s")), "passA_frac": g(yfcc, kk, "roofline", "frac"),
                               "passB_ms": g(yfcc, kk, "stage_ms_per_step", "pass_b"), "passB_mfma_frac": g(yfcc, kk, "pass_b", "roofline", "frac"),
                               "parity": ok(g(yfcc, kk, "parity"))} for kk in ("w2", "w64", "w64_between_clusters")} if isinstance(yfcc, dict) and "error" not in yfcc else None}
-        line = json.dumps(summ, separators=(",", ":"))
-        log("summary: " + (line if len(line) <= 2000 else line[:1997] + "..."))
     if h is not None:
         chk(L.mmidx_destroy(h))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # side measurements -> bench_extra.json; text summary -> stderr; the ONE JSON line -> stdout, last
+        importlib.import_module("bench_emit").emit(out, json_out=json_out, err=sys.stderr, extra_path=args.extra_out, summary=summ)
 
 
 if __name__ == "__main__":
