@@ -16,6 +16,7 @@
 #include "mmidx_scan_mfma.h"
 #include "mmidx_scan_mfma_kc.h"
 #include "mmidx_scan_mfma_a.h"
+#include "mmidx_scan_q.h"
 #include "mmidx_frontend.h"
 
 #include <algorithm>
@@ -332,6 +333,8 @@ struct mmidx_index {
     // which kernel family served each stage of the most recent search sub-batch (mmidx_get_dispatch; host-side words, a few stores per call)
     const char *disp_coarse = "-", *disp_passa = "-", *disp_passb = "-", *disp_pre = "-";
     // K3ma (pass A on the matrix cores, mmidx_scan_mfma_a.h)
+    int passa_q = -1;                  // option "passa_q": K3q (mmidx_scan_q.h) 1 always (where the shape allows), 0 never, -1 = from 1.25 queries per non-empty list of a long-list index
+    double *d_pqstat = nullptr;        // K3q: [m * dsub] mean_j p_sj[t], then [m] mean_j ||p_sj||^2
     int passa_mfma = -1;               // option "passa_mfma": 1 always (where the shape allows), 0 never, -1 = from 8 queries per list of a long-list index
     int a_wide = 1;                    // option "passa_mfma_wide": 0 = K3ma's sweeps by the four-wave instance alone (A/B switch)
     DevBuf<float> ws_acand;            // [pairs][pieces][256] sweep 1's kept accumulator values
@@ -1101,6 +1104,100 @@ int launch_a1_verify_t(mmidx_index *h, const MfmaParams &MP, hipStream_t st) {
     hipLaunchKernelGGL((k_a1_verify<M, DSUB>), dim3(grid), dim3(A1V_NT(DSUB)), L.total, st, MP);
     HIPCK(hipGetLastError());
     return MMIDX_OK;
+}
+
+
+// ---- K3q (mmidx_scan_q.h): pass A on integers, up to four queries of a nearest list per block -----------------------------------
+// does pass A of this call go through K3q?
+bool passa_q_applies(const mmidx_index *h, const ScanParams &P, const SearchPlan &pl, long long nq) {
+    if (h->passa_q == 0 || !P.ivf || P.sdc_tt || nq <= 0 || !h->d_pqstat) return false;
+    if (h->code_bytes != 1 || h->ks != 256 || h->m != 16 || (h->dsub != 4 && h->dsub != 8 && h->dsub != 16)) return false;
+    if (pl.K1 + 40 > MMIDX_Q_HKQ) return false;  // (~K1 + 10 candidates per query, and room for ties)
+    if (h->max_list_len >= (1ll << 24) || nq * (long long)P.w >= 0x7fffff00ll) return false;
+    if (h->transform == MMIDX_TR_ROTATION && !h->d_rot) return false;
+    if (h->transform == MMIDX_TR_PERMUTATION && !h->d_perm) return false;
+    if (h->passa_q > 0) return true;
+    // a block costs the same for one query as for four: from ~1.25 queries per non-empty list the shared scan beats K3h's one block per
+    // query; long lists only (K3h's gate)
+    return 4 * nq >= 5 * std::max<int64_t>(1, h->nonempty_lists) && h->n_csr / std::max<int64_t>(1, h->nonempty_lists) >= 4096;
+}
+
+template <int M, int DSUB>
+int launch_q_t(const QParams &QP, unsigned grid, size_t lds, hipStream_t st) {
+    static int static_lds = -1;  // (the table is addressed from LDS address 0, byte_x8: the kernel must not own static LDS)
+    if (static_lds < 0) {
+        hipFuncAttributes fa{};
+        HIPCK(hipFuncGetAttributes(&fa, (const void *)k_scan_q<M, DSUB>));
+        static_lds = (int)fa.sharedSizeBytes;
+    }
+    if (static_lds != 0) return fail(MMIDX_ERR_UNSUPPORTED, "k_scan_q owns %d bytes of static LDS: its table is not at LDS address 0", static_lds);
+    HIPCK(hipFuncSetAttribute((const void *)k_scan_q<M, DSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_scan_q<M, DSUB>), dim3(grid), dim3(256), lds, st, QP);
+    HIPCK(hipGetLastError());
+    return MMIDX_OK;
+}
+
+// Pass A of the whole sub-batch through K3q; thresholds in P.T, exact candidates in the pools, as K3h leaves them; the queries it hands
+// back (ties, an unusable scale) go through the exact kernel K3.  Uses ws_pcount (the caller zeroes it again for pass B), ws_pstart /
+// ws_pcursor / ws_order / ws_gdesc / ws_gfb / ws_fb.
+int launch_passa_q(mmidx_index *h, const ScanParams &P, const SearchPlan &pl, long long nq, hipStream_t st) {
+    constexpr int G = MMIDX_Q_G;
+    const int C = h->C;
+    const size_t nfb = (size_t)nq * (size_t)std::max(pl.nchunks, 1);
+    HIPCK(h->ws_pcount.reserve((size_t)C + 1));
+    HIPCK(h->ws_pstart.reserve((size_t)C + 1));
+    HIPCK(h->ws_pcursor.reserve((size_t)C));
+    HIPCK(h->ws_order.reserve((size_t)nq * (size_t)P.w));  // (pass B's size: its reserve later must not reallocate under these launches)
+    const size_t max_groups = (size_t)nq / G + (size_t)std::min<long long>(nq, C) + 8;
+    HIPCK(h->ws_gdesc.reserve(max_groups));
+    HIPCK(h->ws_gfb.reserve(8));
+    if (h->ws_fb.cap < 2 * nfb + 4) {
+        HIPCK(h->ws_fb.reserve(2 * nfb + 4));
+        HIPCK(hipMemsetAsync(h->ws_fb.p, 0, 4 * sizeof(int32_t), st));
+    }
+    // the (query, probe 0) pairs by cell, groups of <= 4
+    const unsigned gq = (unsigned)((nq + 255) / 256);
+    hipLaunchKernelGGL(k_a1_pair_count, dim3(gq), dim3(256), 0, st, P.cells, P.w, (long long)nq, P.list_off, h->ws_pcount.p, C);
+    hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, C, h->ws_pstart.p, h->ws_pcursor.p, (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_a1_pair_scatter, dim3(gq), dim3(256), 0, st, P.cells, P.w, (long long)nq, P.list_off, h->ws_pstart.p, h->ws_pcursor.p, h->ws_order.p);
+    hipLaunchKernelGGL(k_group_build, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, h->ws_pstart.p, C, G, h->ws_gdesc.p, h->ws_gfb.p, (u32 *)(h->ws_gfb.p + 1),
+                       (unsigned long long *)nullptr, (int32_t *)nullptr);
+    HIPCK(hipGetLastError());
+    QParams QP{};
+    QP.S = P;
+    QP.S.order = h->ws_order.p;
+    QP.S.n_order = h->ws_pstart.p + C;
+    QP.S.rot = h->d_rot;
+    QP.S.perm = h->d_perm;
+    QP.S.fb_count = (u32 *)h->ws_fb.p;
+    QP.S.fb_items = h->ws_fb.p + 4;
+    QP.S.fb_ch = h->ws_fb.p + 4 + nfb;
+    QP.gdesc = h->ws_gdesc.p;
+    QP.n_groups = h->ws_gfb.p;
+    QP.pq = h->d_pq;
+    QP.pqstat = h->d_pqstat;
+    QP.timing = nullptr;
+    const QLds L(h->m, h->D);
+    // grid: the host's upper bound of the group count (the blocks beyond the device-side count leave at once)
+    const unsigned grid = (unsigned)std::min<size_t>(max_groups, (size_t)nq);
+    int rc;
+    switch (h->dsub) {
+        case 4: rc = launch_q_t<16, 4>(QP, grid, L.total, st); break;
+        case 8: rc = launch_q_t<16, 8>(QP, grid, L.total, st); break;
+        default: rc = launch_q_t<16, 16>(QP, grid, L.total, st); break;
+    }
+    if (rc) return rc;
+    // the handed-back queries (device-side count; normally none: the blocks exit at once)
+    ScanParams F = P;
+    F.cap = pl.cap;
+    F.fb_count = QP.S.fb_count;
+    F.fb_items = QP.S.fb_items;
+    F.fb_ch = QP.S.fb_ch;
+    F.order = QP.S.fb_items;
+    F.n_order = (const int32_t *)QP.S.fb_count;
+    F.order_ch = P.ivf ? QP.S.fb_ch : nullptr;
+    F.n_items = (int)nfb;
+    return launch_scan(h, F, dim3((unsigned)nfb, 1), pl.lds, st);
 }
 
 // does pass A of this call go through K3ma?  (all the applicability checks: launch_passa_mfma itself must not fall back after its first launch)
@@ -2188,7 +2285,12 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
             h->disp_passb = "-";
             h->disp_pre = "-";
             if (!ivf) h->disp_coarse = "-";
-            if (two_pass && passa_mfma_applies(h, P, pl, (long long)nq)) {
+            if (two_pass && passa_q_applies(h, P, pl, (long long)nq) && !(h->passa_mfma > 0 && passa_mfma_applies(h, P, pl, (long long)nq))) {
+                // K3q: the queries of a nearest list four to a block, decided on integers (mmidx_scan_q.h)
+                h->disp_passa = "K3q";
+                rc = launch_passa_q(h, P, pl, (long long)nq, st);
+                pcount_zeroed = false;  // (its pair sort counted in ws_pcount)
+            } else if (two_pass && passa_mfma_applies(h, P, pl, (long long)nq)) {
                 // K3ma: >= 8 queries per nearest list -- the list-major matrix-core form (mmidx_scan_mfma_a.h)
                 h->disp_passa = "K3ma";
                 rc = launch_passa_mfma(h, P, pl, (long long)nq, st);
@@ -2816,6 +2918,7 @@ int mmidx_destroy(mmidx_index *h) {
     if (h->pin_grpx) (void)hipHostFree(h->pin_grpx);
     h->ws_T0.release();
     h->ws_inv.release();
+    if (h->d_pqstat) (void)hipFree(h->d_pqstat);
     if (h->d_pq32T) (void)hipFree(h->d_pq32T);
     if (h->d_pn32) (void)hipFree(h->d_pn32);
     if (h->d_pnmax) (void)hipFree(h->d_pnmax);
@@ -2964,6 +3067,21 @@ int mmidx_set_pq(mmidx_index *h, const double *pq) {
         r2 += mx;
     }
     h->rmax = std::sqrt(r2) * (1.0 + 1e-12);
+    {  // K3q's scale: per-row mean vector and mean squared norm of the codebook (a scale only: no result depends on them)
+        std::vector<double> stt((size_t)h->m * h->dsub + h->m, 0.0);
+        for (int s = 0; s < h->m; s++)
+            for (int j = 0; j < h->ks; j++) {
+                double nn = 0.0;
+                for (int t = 0; t < h->dsub; t++) {
+                    const double v = pq[((size_t)s * h->ks + j) * h->dsub + t];
+                    stt[(size_t)s * h->dsub + t] += v / h->ks;
+                    nn += v * v;
+                }
+                stt[(size_t)h->m * h->dsub + s] += nn / h->ks;
+            }
+        if (!h->d_pqstat) HIPCK(hipMalloc((void **)&h->d_pqstat, stt.size() * sizeof(double)));
+        HIPCK(hipMemcpy(h->d_pqstat, stt.data(), stt.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     h->pq_set = true;
     h->grp_valid = false;
     return MMIDX_OK;
@@ -3614,6 +3732,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->smin_pre = value < 0 ? -1 : (value != 0);
     } else if (n == "no_union") {  // K3g without the per-query histogram that lowers thresholds from the union over lists
         h->no_union = value < 0 ? -1 : (value != 0);
+    } else if (n == "passa_q") {  // K3q: 1 always, 0 never, -1 by the batch (default)
+        h->passa_q = value;
     } else if (n == "passa_mfma") {  // K3ma: 1 always, 0 never, -1 by the batch (default)
         h->passa_mfma = value;
     } else if (n == "passa_mfma_wide") {

@@ -1,0 +1,456 @@
+// mmidx_scan_q.h -- K3q: pass A decided on integers, up to four queries of a nearest list per block (round 6).
+//
+// K3h (k_scan_hist, mmidx_kernels.h) adds up sixteen random 8-byte fp64 table entries for EVERY code of EVERY query's nearest list:
+// 32 lanes of a ds_read_b64 over 32 bank pairs collide ~3 x, 6.5 LDS cycles per wave-gather, 0.64 ms of LDS time per 16384 lists of
+// 12 k codes -- the kernel sat at 0.48 of the HBM peak for five rounds whatever was done around the gather.  But only ~1 % of a list
+// can be among a query's k+1 nearest, and a batch brings several queries to the same list (two on average at 16384 queries over 8192
+// lists).  K3q finds out WHICH codes can matter from a quantised table that four queries share, and sums only those exactly:
+//
+//   tab[s][j] = { q_0, q_1, q_2, q_3 },   q_i = min(4095, floor(LUT_i[s][j] * 4000 / qr_i))        (4 x u16 = one 8-byte word)
+//
+// LUT_i = query i's exact fp64 table (IVFPQ.java:525-538: the same subtractions, squares and additions, t ascending from 0.0), qr_i a
+// scale of the order of the query's typical distance to a code (closed form from the residual and the codebook's per-row mean vector
+// and mean squared norm: the mean distance to a code with independent uniform entries).  ONE ds_read_b64 per (code, sub-quantizer)
+// at the address K3h reads its fp64 entry from -- row + 8 x code byte -- serves four queries; the four partial sums ride in two
+// 32-bit accumulators (16 x 4095 < 65536: the halves never carry).  Per (query, code): 1.6 LDS cycles and 0.75 vector instructions
+// instead of 6.5 and 2; and a list is read from HBM once per block, not once per query.
+//
+// Why integers decide.  For a code c and a query let a(c) = sum_s q[s][code_s] and Y(c) = D(c) * 4000 / qr, D the real-number sum
+// of the code's table entries.  floor() loses less than one unit per entry and saturation only lowers:
+//       Y(c) - 16 - 1e-9 < a(c) <= Y(c) + 1e-9      if no entry of c is saturated (a(c) < 4095 guarantees that),
+//                           a(c) <= Y(c) + 1e-9      always,
+// so   a(c2) >= a(c1) + 18, c1 unsaturated   =>   D(c2) - D(c1) > 2 qr / 4000   =>   d(c2) > d(c1) for the fp64 sums as well (their
+// rounding is 2^-49 relative).  Hence: if K1 codes of the list have a <= a* < 4095, every code with a > a* + 17 is STRICTLY farther
+// than K1 codes of the list -- it cannot be among the k+1 nearest under any tie rule -- and never needs to be summed.
+//
+// The scan has no threshold, no branch and no bookkeeping in memory: every lane keeps, per query, the SIX smallest keys
+// (a << 16 | step) of the codes it has seen (position = 256 step + thread) in registers -- a sorted insertion is one v_min and five
+// v_med3.  A lane sees 1 / 256 of the list, ~0.4 of a query's ~110 candidates; that a lane holds more than six of them has
+// probability ~1e-5 per query, is detected (its sixth key is within the candidate range) and sends the query to the exact kernel.
+// After the scan wave i takes query i: a* = the K1-th smallest a among the block's 1536 kept keys (a bisection with ballots), the
+// candidates = the kept keys with a <= a* + 17.  They are re-loaded and summed exactly, a thread per candidate, straight from the
+// fp64 codebook in the reference's order (IVFPQ.java:531-534 inside :435-438 -- the bits of the table lookup).  T = the largest sum
+// among the candidates with a <= a* (at least K1 of them); every candidate with d <= T goes to the query's pool.  A code that is not
+// a candidate is strictly farther than all of those, so the pool holds exactly the codes with d <= T, with their exact distances:
+// what K3h publishes, for a threshold that is as valid and about as tight.
+//
+// Handed back to the exact kernel (K3, as K3h does): a query with more than Q_HKQ candidates (massive ties), one whose K1-th
+// smallest a is saturated (a scale that turned out too small), one with a lane that may have dropped a candidate, or whose scale is
+// unusable (zero / non-finite).  Results never depend on the scale or on any of the heuristics.
+#pragma once
+#ifndef Q_STOP
+#define Q_STOP 0
+#endif
+
+#define MMIDX_Q_G 4        // queries per block
+#define MMIDX_Q_SLOTS 6    // keys a lane keeps per query
+#define MMIDX_Q_HKQ 192    // most candidates of one query the final phase takes (< 255: an emitted candidate's pool slot rides in a byte)
+#ifndef MMIDX_Q_U
+#define MMIDX_Q_U 8
+#endif
+//        // codes per lane per round of the scan loop
+#define MMIDX_Q_SCALE 4000.0
+#ifndef Q_STAGSEL
+#define Q_STAGSEL (blockIdx.x >> 8)
+#endif
+#ifndef Q_WPS
+#define Q_WPS 3
+#endif
+#ifndef Q_TU
+#define Q_TU 4  // table rows in flight per thread
+#endif
+#ifndef Q_FU
+#define Q_FU 4  // codebook rows in flight per candidate
+#endif
+
+struct QParams {
+    ScanParams S;             // Q, coarse, pqT, perm, rot, cells, list_off, codes, order (pairs sorted by cell), T, pool_*, fb_*, D, m, dsub, w, transform, K1, poolq
+    const int4 *gdesc;        // per group: {cell, first index into order[], number of pairs (1 .. G), 0}
+    const int32_t *n_groups;  // device-side count
+    const double *pq;         // [m][ks][dsub] (file order): a candidate's rows
+    const double *pqstat;     // [m * dsub] mean_j p_sj[t], then [m] mean_j ||p_sj||^2
+    unsigned long long *timing;  // Q_TIMING builds: cycles per phase, summed over the blocks' thread 0
+};
+
+typedef unsigned int q_u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const q_u32x2 lds_cuint2;
+
+// LDS layout, shared by host (size) and device (offsets)
+struct QLds {
+    size_t tab, res, misc, cent, total;
+    __host__ __device__ QLds(int M, int D) {
+        size_t o = 0;
+        tab = o; o += (size_t)M * 2048;                               // [M][256] x {4 x u16}; LDS address 0 (byte_x8 addressing).  After the scan: the kept keys
+                                                                      // [G][SLOTS * 256] (24 KiB, needs M >= 12), then the candidates' exact sums [G * HKQ] u64
+        res = o; o += (size_t)MMIDX_Q_G * D * 8;                      // the queries' residuals, transformed (fp64); first: raw residuals (rotation)
+        misc = o; o += 64 * 8;                                        // see the kernel
+        cent = o; o += (size_t)MMIDX_Q_G * MMIDX_Q_HKQ * 4;           // the candidates: (evidence << 31 | position), later (pool slot << 24 | position)
+        total = (o + 15) & ~(size_t)15;
+    }
+};
+
+__device__ __forceinline__ u32 q_med3(u32 a, u32 b, u32 c) {
+    u32 r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ double wave_sum_f64(double x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+    return x;
+}
+
+#ifdef Q_TIMING
+#define Q_T(n) do { if (tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(QP.timing + (n), t_ - qt_last); qt_last = t_; } } while (0)
+#else
+#define Q_T(n) do {} while (0)
+#endif
+template <int M, int DSUB>
+__global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int G = MMIDX_Q_G, NT = 256, WV = 4, U = MMIDX_Q_U, HKQ = MMIDX_Q_HKQ, NS = MMIDX_Q_SLOTS;
+    static_assert(G == WV, "wave i takes query i in the selection");
+    static_assert(M * 2048 >= G * NS * 256 * 4 + 0, "the kept keys re-use the table");
+    const ScanParams &P = QP.S;
+    const int D = P.D;
+    const QLds L(M, D);
+    double *s_r = (double *)(smem + L.res);        // [G][D]
+    // misc (64 x 8 bytes): words [0..3] a* per query (int; -1: no evidence), [4..7] hand-back flags, [8..11] candidates, [12..15] entries to emit,
+    // [16..19] pool bases; doubles [16..19] 4000 / qr; u64 [20..23] largest evidence sum
+    int *s_astar = (int *)(smem + L.misc);
+    u32 *s_flag = (u32 *)(smem + L.misc) + 4;
+    u32 *s_kept = (u32 *)(smem + L.misc) + 8;
+    u32 *s_emit = (u32 *)(smem + L.misc) + 12;
+    u32 *s_base = (u32 *)(smem + L.misc) + 16;
+    double *s_inv = (double *)(smem + L.misc) + 16;
+    u64 *s_max = (u64 *)(smem + L.misc) + 20;
+    u32 *cent = (u32 *)(smem + L.cent);            // [G][HKQ]
+
+    if ((int)blockIdx.x >= *QP.n_groups) return;
+#ifdef Q_STAGGER
+    // the first generation of blocks starts together and every block takes about as long: without an offset the three blocks of a CU
+    // build their tables together, scan together (the LDS pipe's phase) and sum their candidates together (a latency phase) for the whole launch
+    if (blockIdx.x < 768u && (Q_STAGSEL) != 0u) {
+        const unsigned long long t0 = __builtin_readcyclecounter(), wait = (unsigned long long)(Q_STAGSEL) * (unsigned long long)(Q_STAGGER);
+        while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
+    const int4 gd = QP.gdesc[blockIdx.x];
+    const int cell = gd.x, ng = gd.z;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef Q_TIMING
+    unsigned long long qt_last = __builtin_readcyclecounter();
+#endif
+    int qid[G];
+#pragma unroll
+    for (int i = 0; i < G; i++) qid[i] = P.order[gd.y + (i < ng ? i : 0)] / P.w;
+    const int64_t beg = P.list_off[cell];
+    const u32 n_seg = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(P.list_off[cell + 1] - beg));  // (< 2^24: the host checks)
+    if (n_seg == 0) return;
+    const unsigned char *codes0;  // (rebuilt from the kernel argument: a pointer made from integers would be FLAT-addressed)
+    {
+        const u64 e0 = (u64)beg;
+        const u32 lo32 = (u32)__builtin_amdgcn_readfirstlane((int)(u32)e0), hi32 = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(e0 >> 32));
+        codes0 = (const unsigned char *)P.codes + (size_t)(((u64)hi32 << 32) | lo32) * M;
+    }
+    auto fetch = [&](CodeVec<M, unsigned char> &dst, const u32 i) {
+        const u32 ic = i < n_seg ? i : n_seg - 1u;
+        dst.load(codes0 + ic * (u32)M);  // (32-bit offset from a uniform base; past the end: the list's last code, never used)
+    };
+    // the first round's codes leave now: they are back before the table is built
+    CodeVec<M, unsigned char> X0[U], X1[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) fetch(X0[u], (u32)u * NT + (u32)tid);
+
+    for (int i = tid; i < 128; i += NT) ((u32 *)(smem + L.misc))[i] = 0;
+    __syncthreads();
+    // ---- residuals centroid - q (IVFPQ.java:645), permuted / rotated as the index says; wave i <-> query i ------------------
+    {
+        const int i = wv;
+        const double *qrow = P.Q + (size_t)qid[i] * D, *crow = P.coarse + (size_t)cell * D;
+        if (P.transform == 1) {  // RandomRotation.rotate: out = v (1 x D) . R (D x D), sequential over the row index (RandomRotation.java:44-49)
+            double *raw = (double *)smem + (size_t)i * D;  // (the table region: not built yet)
+            for (int d = lane; d < D; d += 64) raw[d] = crow[d] - qrow[d];
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+            for (int j = lane; j < D; j += 64) {
+                double total = 0.0;
+                for (int k = 0; k < D; k++) total += raw[k] * P.rot[(size_t)k * D + j];
+                s_r[(size_t)i * D + j] = total;
+            }
+        } else {
+            for (int d = lane; d < D; d += 64) {
+                const int src = P.transform == 2 ? P.perm[d] : d;  // RandomPermutation.permute: out[i] = v[perm[i]]
+                s_r[(size_t)i * D + d] = crow[src] - qrow[src];
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        // scale: the mean distance to a code with independent uniform entries, sum_d (r_d^2 - 2 r_d mu_d) + sum_s nu_s
+        double part = 0.0;
+        for (int d = lane; d < D; d += 64) {
+            const double r = s_r[(size_t)i * D + d];
+            part += r * r - 2.0 * r * QP.pqstat[d];
+        }
+        if (lane < M) part += QP.pqstat[M * DSUB + lane];
+        const double qr = wave_sum_f64(part);
+        const bool ok = i < ng && qr > 0.0 && qr < 1e300 && (MMIDX_Q_SCALE / qr) < 1e300;
+        if (lane == 0) {
+            s_inv[i] = ok ? MMIDX_Q_SCALE / qr : 0.0;
+            if (i < ng && !ok) s_flag[i] = 1u;
+        }
+    }
+    __syncthreads();
+    Q_T(0);
+    // ---- the table: thread j <-> entry j of every row; the exact entries of the four queries, quantised and packed -----------------
+    {
+        double inv[G];
+#pragma unroll
+        for (int i = 0; i < G; i++) inv[i] = s_inv[i];
+#pragma unroll Q_TU
+        for (int s = 0; s < M; s++) {
+            double p[DSUB];
+#pragma unroll
+            for (int t = 0; t < DSUB; t++) p[t] = P.pqT[((size_t)s * DSUB + t) * 256 + tid];
+            u32 qv[G];
+#pragma unroll
+            for (int i = 0; i < G; i++) {
+                const double *tv = s_r + (size_t)i * D + s * DSUB;
+                double acc = 0.0;
+#pragma unroll
+                for (int t = 0; t < DSUB; t++) {
+                    const double df = tv[t] - p[t];
+                    acc += df * df;
+                }
+                const double x = acc * inv[i];  // >= 0
+                qv[i] = (x >= 4095.0) ? 4095u : (u32)x;
+            }
+            *(uint2 *)(smem + (size_t)s * 2048 + (size_t)tid * 8) = make_uint2(qv[0] | (qv[1] << 16), qv[2] | (qv[3] << 16));
+        }
+    }
+    __syncthreads();
+#if Q_STOP == 1
+    return;
+#endif
+
+    Q_T(1);
+    // ---- scan: lookups and sorted insertions, nothing else --------------------------------------------------------------------
+    u32 slot[G][NS];
+#pragma unroll
+    for (int i = 0; i < G; i++)
+#pragma unroll
+        for (int k = 0; k < NS; k++) slot[i][k] = 0xFFFFFFFFu;
+    auto lookup = [&](const CodeVec<M, unsigned char> &cv, u32 &lo, u32 &hi) {
+        lo = 0;
+        hi = 0;
+#pragma unroll
+        for (int s = 0; s < M; s++) {
+            const q_u32x2 e = *(lds_cuint2 *)(size_t)(byte_x8(cv.wd[s >> 2], s & 3) + (u32)s * 2048u);
+            lo += e.x;
+            hi += e.y;
+        }
+    };
+    auto insert = [&](u32 (&sl)[NS], const u32 k) {  // sl ascending; k in, the largest out
+        u32 prev = sl[0];
+        sl[0] = prev < k ? prev : k;
+#pragma unroll
+        for (int j = 1; j < NS; j++) {
+            const u32 cur = sl[j];
+            sl[j] = q_med3(prev, cur, k);
+            prev = cur;
+        }
+    };
+    auto keep = [&](const u32 lo, const u32 hi, const u32 step, const bool inb) {
+        // keys (a << 16 | step); a code past the end of the list must not enter (its key: all ones)
+        const u32 k0 = inb ? ((lo << 16) | step) : 0xFFFFFFFFu, k1 = inb ? ((lo & 0xFFFF0000u) | step) : 0xFFFFFFFFu;
+        const u32 k2 = inb ? ((hi << 16) | step) : 0xFFFFFFFFu, k3 = inb ? ((hi & 0xFFFF0000u) | step) : 0xFFFFFFFFu;
+        insert(slot[0], k0);
+        insert(slot[1], k1);
+        insert(slot[2], k2);
+        insert(slot[3], k3);
+    };
+    // full rounds: every position is inside the list
+    u32 seg = 0;
+#pragma unroll 1
+    for (; seg + (u32)U * NT <= n_seg; seg += (u32)U * NT) {
+#pragma unroll
+        for (int u = 0; u < U; u++) fetch(X1[u], seg + (u32)(U + u) * NT + (u32)tid);
+#pragma unroll
+        for (int h4 = 0; h4 < U; h4 += 4) {  // four independent lookup chains at a time
+            u32 lo[4], hi[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) lookup(X0[h4 + u], lo[u], hi[u]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) keep(lo[u], hi[u], (seg >> 8) + (u32)(h4 + u), true);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) X0[u] = X1[u];
+    }
+    // the rest of the list (fewer than U codes per lane; X0 holds them, clamped past the end)
+#pragma unroll 1
+    for (int u = 0; u < U; u++) {
+        if (seg + (u32)u * NT >= n_seg) break;
+        u32 lo, hi;
+        CodeVec<M, unsigned char> cv = X0[0];
+#pragma unroll
+        for (int v = 1; v < U; v++)
+            if (v == u) cv = X0[v];
+        lookup(cv, lo, hi);
+        keep(lo, hi, (seg >> 8) + (u32)u, seg + (u32)u * NT + (u32)tid < n_seg);
+    }
+    __syncthreads();  // (every wave is done with the table: it becomes the key list)
+    Q_T(2);
+#if Q_STOP == 2
+    return;
+#endif
+    // ---- selection: wave i takes query i -- a* = the K1-th smallest a of the 256 x NS kept keys, candidates = keys with a <= a* + 17 ----
+    u32 *skeys = (u32 *)smem;  // [G][NS * 256]
+#pragma unroll
+    for (int i = 0; i < G; i++)
+#pragma unroll
+        for (int k = 0; k < NS; k++) skeys[(size_t)i * NS * 256 + (size_t)k * 256 + tid] = slot[i][k];
+    __syncthreads();
+    if (wv < ng && s_flag[wv] == 0u) {
+        const int i = wv;
+        constexpr int KPL = NS * 4;  // keys per lane
+        u32 kk[KPL];
+        u32 nvalid = 0;
+#pragma unroll
+        for (int k = 0; k < KPL; k++) {
+            kk[k] = skeys[(size_t)i * NS * 256 + (size_t)k * 64 + lane];
+            nvalid += (u32)__popcll(__builtin_amdgcn_ballot_w64(kk[k] != 0xFFFFFFFFu));
+        }
+        int astar = -1;
+        u32 cut = 0xFFFFu;  // candidates: a <= cut (no evidence: every kept key of a list this short)
+        bool bad = false;
+        if (nvalid >= (u32)P.K1) {
+            u32 lo_a = 0, hi_a = 0xFFFFu;  // smallest A with at least K1 keys of a <= A  (a = 0xFFFF only in the all-ones key)
+            while (lo_a < hi_a) {
+                const u32 mid = lo_a + ((hi_a - lo_a) >> 1);
+                u32 c = 0;
+#pragma unroll
+                for (int k = 0; k < KPL; k++) c += (u32)__popcll(__builtin_amdgcn_ballot_w64((kk[k] >> 16) <= mid));
+                if (c >= (u32)P.K1) hi_a = mid;
+                else lo_a = mid + 1;
+            }
+            if (lo_a >= 4095u) bad = true;  // the evidence would include saturated codes: the scale was too small
+            astar = (int)lo_a;
+            cut = lo_a + 17u;
+        }
+        // a lane whose largest kept key is a candidate may have dropped one (keys k = (NS - 1) * 4 .. are the lanes' sixth)
+#pragma unroll
+        for (int k = (NS - 1) * 4; k < KPL; k++) bad |= __builtin_amdgcn_ballot_w64(kk[k] != 0xFFFFFFFFu && (kk[k] >> 16) <= cut) != 0ull;
+        u32 cnt = 0;
+        const u64 lane_lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int k = 0; k < KPL; k++) {
+            const bool c = kk[k] != 0xFFFFFFFFu && (kk[k] >> 16) <= cut;
+            const u64 mask = __builtin_amdgcn_ballot_w64(c);
+            const u32 at = cnt + (u32)__popcll(mask & lane_lt);
+            // position = 256 step + owner thread (the key's index in the list: k * 64 + lane, mod 256)
+            if (c && at < (u32)HKQ) cent[i * HKQ + at] = (((kk[k] & 0xFFFFu) << 8) | (u32)((k * 64 + lane) & 255)) | (((int)(kk[k] >> 16) <= astar) ? 0x80000000u : 0u);
+            cnt += (u32)__popcll(mask);
+        }
+        if (cnt > (u32)HKQ) bad = true;
+        if (lane == 0) {
+            s_astar[i] = astar;
+            s_kept[i] = bad ? 0u : cnt;
+            if (bad) s_flag[i] = 1u;
+#ifdef Q_DEBUG
+            printf("[K3q] q %d cell %d n_seg %u nvalid %u a* %d cut %u cnt %u bad %d inv %g\n", qid[i], cell, n_seg, nvalid, astar, cut, cnt, (int)bad, s_inv[i]);
+#endif
+        }
+    }
+    __syncthreads();
+    Q_T(3);
+    bool live[G];
+    u32 first[G + 1];
+    first[0] = 0;
+#pragma unroll
+    for (int i = 0; i < G; i++) {
+        live[i] = i < ng && s_flag[i] == 0u;
+        if (i < ng && !live[i] && tid == 0) {  // this query's pair goes to the exact kernel, chunk by chunk of the list
+            const u32 nch = (n_seg + (u32)P.chunk - 1u) / (u32)P.chunk;
+            const u32 sl = atomicAdd(P.fb_count, nch);
+            for (u32 c = 0; c < nch; c++) {
+                P.fb_items[sl + c] = qid[i] * P.w;
+                P.fb_ch[sl + c] = (int32_t)c;
+            }
+        }
+        first[i + 1] = first[i] + (live[i] ? s_kept[i] : 0u);
+    }
+    const u32 ncand = first[G];
+    if (ncand == 0) return;  // block-uniform
+    // ---- exact sums, a thread per candidate: d = sum_s [ sum_t (r[s dsub + t] - pq[s][code_s][t])^2 ], t then s ascending from 0.0 ------
+    u64 *ckey = (u64 *)smem;  // [ncand] (the key list is dead: every wave passed the barrier above after reading it)
+#pragma unroll 1
+    for (u32 idx = (u32)tid; idx < ncand; idx += NT) {
+        int i = 0;
+#pragma unroll
+        for (int k = 1; k < G; k++) i += (idx >= first[k]) ? 1 : 0;
+        const u32 v = cent[i * HKQ + (idx - (i == 0 ? first[0] : (i == 1 ? first[1] : (i == 2 ? first[2] : first[3]))))];
+        CodeVec<M, unsigned char> cv;
+        cv.load(codes0 + (v & 0xFFFFFFu) * (u32)M);
+        const double *tv = s_r + (size_t)i * D;
+        double d = 0.0;
+#pragma unroll Q_FU
+        for (int s = 0; s < M; s++) {
+            const double *row = QP.pq + ((size_t)s * 256 + (size_t)cv.get(s)) * DSUB;
+            double p[DSUB];
+#pragma unroll
+            for (int t = 0; t < DSUB; t++) p[t] = row[t];
+            double acc = 0.0;
+#pragma unroll
+            for (int t = 0; t < DSUB; t++) {
+                const double df = tv[s * DSUB + t] - p[t];
+                acc += df * df;
+            }
+            d = s == 0 ? acc : d + acc;  // (0.0 + x == x: the first entry itself)
+        }
+        const u64 key = dkey(d);
+        ckey[idx] = key;
+        if (v & 0x80000000u) atomicMax(s_max + i, key);  // evidence codes: at least K1 per query
+    }
+    __syncthreads();
+    Q_T(4);
+    // T_i = the largest evidence sum; publish every candidate at or under it (and under a threshold another shard may have published)
+    u64 Te[G];
+#pragma unroll
+    for (int i = 0; i < G; i++) {
+        const bool has_T = live[i] && s_astar[i] >= 0;
+        const u64 Tl = has_T ? s_max[i] : MMIDX_KEY_MAX;  // (a list of fewer than K1 codes: everything, no threshold)
+        const u64 Tg = __hip_atomic_load(P.T + qid[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        Te[i] = Tl < Tg ? Tl : Tg;
+        if (has_T && tid == 0) atomicMin(P.T + qid[i], Tl);
+    }
+    // (an emitted candidate keeps its pool slot in the entry's top byte, 0xFF = not emitted)
+#pragma unroll 1
+    for (u32 idx = (u32)tid; idx < ncand; idx += NT) {
+        int i = 0;
+#pragma unroll
+        for (int k = 1; k < G; k++) i += (idx >= first[k]) ? 1 : 0;
+        const u64 te = i == 0 ? Te[0] : (i == 1 ? Te[1] : (i == 2 ? Te[2] : Te[3]));
+        u32 *ce = cent + i * HKQ + (idx - (i == 0 ? first[0] : (i == 1 ? first[1] : (i == 2 ? first[2] : first[3]))));
+        const u32 v = *ce & 0xFFFFFFu;
+        const u32 sl = ckey[idx] <= te ? atomicAdd(s_emit + i, 1u) : 0xFFu;  // (< HKQ = 192 < 255)
+        *ce = v | (sl << 24);
+    }
+    __syncthreads();
+    if (tid < G && s_emit[tid]) s_base[tid] = atomicAdd(P.pool_cnt + qid[tid], s_emit[tid]);
+    __syncthreads();
+#pragma unroll 1
+    for (u32 idx = (u32)tid; idx < ncand; idx += NT) {
+        int i = 0;
+#pragma unroll
+        for (int k = 1; k < G; k++) i += (idx >= first[k]) ? 1 : 0;
+        const u32 v = cent[i * HKQ + (idx - (i == 0 ? first[0] : (i == 1 ? first[1] : (i == 2 ? first[2] : first[3]))))];
+        if ((v >> 24) == 0xFFu) continue;
+        const int qq = i == 0 ? qid[0] : (i == 1 ? qid[1] : (i == 2 ? qid[2] : qid[3]));
+        const u32 sl = s_base[i] + (v >> 24);
+        if (sl < (u32)P.poolq) {
+            P.pool_key[(size_t)qq * P.poolq + sl] = ckey[idx];
+            P.pool_val[(size_t)qq * P.poolq + sl] = (u64)(v & 0xFFFFFFu);  // (probe rank 0)
+        }
+    }
+    Q_T(5);
+}

@@ -3,7 +3,7 @@
 Every row builds a small index of the given shape, runs one batch search (parity with the oracle on a few queries: the kernel that
 ran must also be right) and compares the kernel families the library reports for the coarse stage, pass A, the pair pre-filter and
 pass B with the documented ones.  The gates live in csrc/mmidx_api.hip (run_coarse, search_batch_device, launch_scan_grouped,
-launch_mfma_common, launch_mfma_kc, passa_mfma_applies); a change there has to change this table and DESIGN.md with it."""
+launch_mfma_common, launch_mfma_kc, passa_q_applies, passa_mfma_applies); a change there has to change this table and DESIGN.md with it."""
 import numpy as np
 import pytest
 
@@ -16,14 +16,18 @@ pytestmark = pytest.mark.gpu
 ROWS = [
     # IVFPQ, the headline's shape at small scale: short lists (K3h takes lists of >= 4096 codes on average)
     ("ivfpq", 128, 16, 256, 300, 8, 60000, 50, 10, 0, {}, ("K1e'+K1f(front_sel)", "K3", "-", "K3m")),
-    # ... long lists: K3h; few queries per list
-    ("ivfpq", 128, 16, 256, 8, 4, 40000, 30, 100, 0, {}, ("K1a+K1b(exact)", "K3h", "-", "K3m")),
-    # ... >= 8 queries per list of a long-list index: K3ma
-    ("ivfpq", 128, 16, 256, 8, 4, 40000, 80, 100, 0, {}, ("K1a+K1b(exact)", "K3ma", "-", "K3m")),
-    # ... k + 1 > 128: K3ma does not apply
+    # ... long lists, from 1.25 queries per non-empty list: K3q (round 6: four queries of a list per block, decided on integers)
+    ("ivfpq", 128, 16, 256, 8, 4, 40000, 30, 100, 0, {}, ("K1a+K1b(exact)", "K3q", "-", "K3m")),
+    # ... fewer queries than that: K3h, a block per query
+    ("ivfpq", 128, 16, 256, 8, 4, 40000, 6, 100, 0, {}, ("K1a+K1b(exact)", "K3h", "-", "K3m")),
+    # ... K3q switched off: K3h; and from 8 queries per list K3ma
+    ("ivfpq", 128, 16, 256, 8, 4, 40000, 30, 100, 0, {"passa_q": 0}, ("K1a+K1b(exact)", "K3h", "-", "K3m")),
+    ("ivfpq", 128, 16, 256, 8, 4, 40000, 80, 100, 0, {"passa_q": 0}, ("K1a+K1b(exact)", "K3ma", "-", "K3m")),
+    ("ivfpq", 128, 16, 256, 8, 4, 40000, 80, 100, 0, {}, ("K1a+K1b(exact)", "K3q", "-", "K3m")),
+    # ... k + 1 > 152: neither K3q (192 candidates per query at most) nor K3ma (k + 1 <= 128) applies
     ("ivfpq", 128, 16, 256, 8, 4, 40000, 80, 200, 0, {}, ("K1a+K1b(exact)", "K3h", "-", "K3m")),
-    # RandomRotation at D = 128: K3m serves it (k_pair_rotate)
-    ("ivfpq", 128, 16, 256, 8, 4, 40000, 30, 20, 1, {}, ("K1a+K1b(exact)", "K3h", "-", "K3m")),
+    # RandomRotation at D = 128: K3q rotates its residuals itself, K3m serves pass B (k_pair_rotate)
+    ("ivfpq", 128, 16, 256, 8, 4, 40000, 30, 20, 1, {}, ("K1a+K1b(exact)", "K3q", "-", "K3m")),
     # the 1024-d 64 x 256 shape (YFCC100MExample.java:85-90), RandomPermutation: K3h<64>, K3s in front of K3mk
     ("ivfpq", 1024, 64, 256, 6, 6, 30000, 20, 30, 2, {}, ("K1a+K1b(exact)", "K3h", "K3s", "K3mk")),
     # 12-dimensional sub-quantizers: outside K3m (dsub in {4, 8, 16}); K3g's generic instance takes them
@@ -33,7 +37,7 @@ ROWS = [
     # m = 128 (Example.java:74 names pq_1024_128x8): the lookup table lives in global scratch for pass A, K3mk behind it (K3s sits out: its fp32 tables exist for m in {8, 16, 32, 64})
     ("ivfpq", 1024, 128, 256, 6, 6, 6000, 12, 10, 0, {}, ("K1a+K1b(exact)", "K3(table in two halves)", "-", "K3mk")),
     # K3m switched off: K3g
-    ("ivfpq", 128, 16, 256, 8, 4, 40000, 30, 100, 0, {"no_mfma": 1}, ("K1a+K1b(exact)", "K3h", "-", "K3g")),
+    ("ivfpq", 128, 16, 256, 8, 4, 40000, 30, 100, 0, {"no_mfma": 1}, ("K1a+K1b(exact)", "K3q", "-", "K3g")),
     # flat PQ (cfg2's shape at small scale): chunk 0 through K3h, the others through K3m
     ("pq", 128, 8, 256, 0, 0, 80000, 40, 100, 0, {}, ("-", "K3h", "-", "K3m")),
     # w = 1: a single pass
