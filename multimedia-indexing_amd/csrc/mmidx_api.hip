@@ -1187,6 +1187,13 @@ int launch_passa_q(mmidx_index *h, const ScanParams &P, const SearchPlan &pl, lo
         default: rc = launch_q_t<16, 16>(QP, grid, L.total, st); break;
     }
     if (rc) return rc;
+    if (h->debug_sync) {
+        int32_t c4[4], ng = 0;
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(c4, h->ws_fb.p, sizeof(c4), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&ng, h->ws_gfb.p, sizeof(ng), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[mmidx] K3q: %lld queries in %d groups (grid %u, lds %zu); %d (query, chunk) items handed back to K3\n", nq, ng, grid, L.total, c4[0]);
+    }
     // the handed-back queries (device-side count; normally none: the blocks exit at once)
     ScanParams F = P;
     F.cap = pl.cap;

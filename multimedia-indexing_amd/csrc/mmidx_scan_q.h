@@ -59,8 +59,8 @@
 #ifndef Q_TU
 #define Q_TU 4  // table rows in flight per thread
 #endif
-#ifndef Q_FU
-#define Q_FU 4  // codebook rows in flight per candidate
+#ifndef Q_FR
+#define Q_FR 4  // codebook rows in flight per candidate
 #endif
 
 struct QParams {
@@ -77,7 +77,7 @@ typedef __attribute__((address_space(3))) const q_u32x2 lds_cuint2;
 
 // LDS layout, shared by host (size) and device (offsets)
 struct QLds {
-    size_t tab, res, misc, cent, total;
+    size_t tab, res, misc, cent, sel, total;
     __host__ __device__ QLds(int M, int D) {
         size_t o = 0;
         tab = o; o += (size_t)M * 2048;                               // [M][256] x {4 x u16}; LDS address 0 (byte_x8 addressing).  After the scan: the kept keys
@@ -85,6 +85,7 @@ struct QLds {
         res = o; o += (size_t)MMIDX_Q_G * D * 8;                      // the queries' residuals, transformed (fp64); first: raw residuals (rotation)
         misc = o; o += 64 * 8;                                        // see the kernel
         cent = o; o += (size_t)MMIDX_Q_G * MMIDX_Q_HKQ * 4;           // the candidates: (evidence << 31 | position), later (pool slot << 24 | position)
+        sel = o; o += (size_t)MMIDX_Q_G * MMIDX_Q_SLOTS * 256 * 2;    // the kept keys' a values (u16): the selection's input
         total = (o + 15) & ~(size_t)15;
     }
 };
@@ -110,13 +111,13 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int G = MMIDX_Q_G, NT = 256, WV = 4, U = MMIDX_Q_U, HKQ = MMIDX_Q_HKQ, NS = MMIDX_Q_SLOTS;
     static_assert(G == WV, "wave i takes query i in the selection");
-    static_assert(M * 2048 >= G * NS * 256 * 4 + 0, "the kept keys re-use the table");
+    static_assert(M * 2048 >= G * MMIDX_Q_HKQ * 8, "the candidates' exact sums re-use the table");
     const ScanParams &P = QP.S;
     const int D = P.D;
     const QLds L(M, D);
     double *s_r = (double *)(smem + L.res);        // [G][D]
     // misc (64 x 8 bytes): words [0..3] a* per query (int; -1: no evidence), [4..7] hand-back flags, [8..11] candidates, [12..15] entries to emit,
-    // [16..19] pool bases; doubles [16..19] 4000 / qr; u64 [20..23] largest evidence sum
+    // [16..19] pool bases, [24..27] a* + 17; doubles [16..19] 4000 / qr; u64 [20..23] largest evidence sum
     int *s_astar = (int *)(smem + L.misc);
     u32 *s_flag = (u32 *)(smem + L.misc) + 4;
     u32 *s_kept = (u32 *)(smem + L.misc) + 8;
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
     u32 *s_base = (u32 *)(smem + L.misc) + 16;
     double *s_inv = (double *)(smem + L.misc) + 16;
     u64 *s_max = (u64 *)(smem + L.misc) + 20;
+    u32 *s_cut = (u32 *)(smem + L.misc) + 24;      // [24..27]: a* + 17 per query
     u32 *cent = (u32 *)(smem + L.cent);            // [G][HKQ]
 
     if ((int)blockIdx.x >= *QP.n_groups) return;
@@ -298,38 +300,41 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
         lookup(cv, lo, hi);
         keep(lo, hi, (seg >> 8) + (u32)u, seg + (u32)u * NT + (u32)tid < n_seg);
     }
-    __syncthreads();  // (every wave is done with the table: it becomes the key list)
     Q_T(2);
 #if Q_STOP == 2
     return;
 #endif
-    // ---- selection: wave i takes query i -- a* = the K1-th smallest a of the 256 x NS kept keys, candidates = keys with a <= a* + 17 ----
-    u32 *skeys = (u32 *)smem;  // [G][NS * 256]
+    // ---- selection: wave i takes query i -- a* = the K1-th smallest a among the 256 x NS kept keys (their a values, u16, side by side
+    //      in LDS), candidates = every code with a <= a* + 17.  The table stays intact: a lane that may have dropped a candidate
+    //      (its sixth key is within the range) walks its own codes again. -----------------------------------------------------------
+    unsigned short *sa = (unsigned short *)(smem + L.sel);  // [G][NS * 256]
 #pragma unroll
     for (int i = 0; i < G; i++)
 #pragma unroll
-        for (int k = 0; k < NS; k++) skeys[(size_t)i * NS * 256 + (size_t)k * 256 + tid] = slot[i][k];
+        for (int k = 0; k < NS; k++) sa[(size_t)i * NS * 256 + (size_t)k * 256 + tid] = (unsigned short)(slot[i][k] >> 16);
     __syncthreads();
     if (wv < ng && s_flag[wv] == 0u) {
         const int i = wv;
-        constexpr int KPL = NS * 4;  // keys per lane
-        u32 kk[KPL];
+        constexpr int WPL = NS * 2;  // dwords (pairs of values) per lane
+        u32 kk[WPL];
+#pragma unroll
+        for (int k = 0; k < WPL; k++) kk[k] = ((const u32 *)(sa + (size_t)i * NS * 256))[k * 64 + lane];
+        // (a = 0xFFFF only in the all-ones key of an empty slot; a real sum is at most 16 x 4095)
         u32 nvalid = 0;
 #pragma unroll
-        for (int k = 0; k < KPL; k++) {
-            kk[k] = skeys[(size_t)i * NS * 256 + (size_t)k * 64 + lane];
-            nvalid += (u32)__popcll(__builtin_amdgcn_ballot_w64(kk[k] != 0xFFFFFFFFu));
-        }
+        for (int k = 0; k < WPL; k++)
+            nvalid += (u32)__popcll(__builtin_amdgcn_ballot_w64((kk[k] & 0xFFFFu) != 0xFFFFu)) + (u32)__popcll(__builtin_amdgcn_ballot_w64((kk[k] >> 16) != 0xFFFFu));
         int astar = -1;
-        u32 cut = 0xFFFFu;  // candidates: a <= cut (no evidence: every kept key of a list this short)
+        u32 cut = 0xFFFEu;  // (no evidence: every kept key of a list this short)
         bool bad = false;
         if (nvalid >= (u32)P.K1) {
-            u32 lo_a = 0, hi_a = 0xFFFFu;  // smallest A with at least K1 keys of a <= A  (a = 0xFFFF only in the all-ones key)
+            u32 lo_a = 0, hi_a = 0xFFFEu;  // smallest A with at least K1 values <= A
             while (lo_a < hi_a) {
                 const u32 mid = lo_a + ((hi_a - lo_a) >> 1);
                 u32 c = 0;
 #pragma unroll
-                for (int k = 0; k < KPL; k++) c += (u32)__popcll(__builtin_amdgcn_ballot_w64((kk[k] >> 16) <= mid));
+                for (int k = 0; k < WPL; k++)
+                    c += (u32)__popcll(__builtin_amdgcn_ballot_w64((kk[k] & 0xFFFFu) <= mid)) + (u32)__popcll(__builtin_amdgcn_ballot_w64((kk[k] >> 16) <= mid));
                 if (c >= (u32)P.K1) hi_a = mid;
                 else lo_a = mid + 1;
             }
@@ -337,28 +342,40 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
             astar = (int)lo_a;
             cut = lo_a + 17u;
         }
-        // a lane whose largest kept key is a candidate may have dropped one (keys k = (NS - 1) * 4 .. are the lanes' sixth)
-#pragma unroll
-        for (int k = (NS - 1) * 4; k < KPL; k++) bad |= __builtin_amdgcn_ballot_w64(kk[k] != 0xFFFFFFFFu && (kk[k] >> 16) <= cut) != 0ull;
-        u32 cnt = 0;
-        const u64 lane_lt = (1ull << lane) - 1ull;
-#pragma unroll
-        for (int k = 0; k < KPL; k++) {
-            const bool c = kk[k] != 0xFFFFFFFFu && (kk[k] >> 16) <= cut;
-            const u64 mask = __builtin_amdgcn_ballot_w64(c);
-            const u32 at = cnt + (u32)__popcll(mask & lane_lt);
-            // position = 256 step + owner thread (the key's index in the list: k * 64 + lane, mod 256)
-            if (c && at < (u32)HKQ) cent[i * HKQ + at] = (((kk[k] & 0xFFFFu) << 8) | (u32)((k * 64 + lane) & 255)) | (((int)(kk[k] >> 16) <= astar) ? 0x80000000u : 0u);
-            cnt += (u32)__popcll(mask);
-        }
-        if (cnt > (u32)HKQ) bad = true;
         if (lane == 0) {
             s_astar[i] = astar;
-            s_kept[i] = bad ? 0u : cnt;
+            s_cut[i] = cut;
             if (bad) s_flag[i] = 1u;
-#ifdef Q_DEBUG
-            printf("[K3q] q %d cell %d n_seg %u nvalid %u a* %d cut %u cnt %u bad %d inv %g\n", qid[i], cell, n_seg, nvalid, astar, cut, cnt, (int)bad, s_inv[i]);
-#endif
+        }
+    }
+    __syncthreads();
+    // every lane: its kept keys within the range -> the query's candidate list; a lane whose sixth key is within the range rescues
+    {
+#pragma unroll
+        for (int i = 0; i < G; i++) {
+            if (i >= ng || s_flag[i] != 0u) continue;  // block-uniform
+            const u32 cut = s_cut[i];
+            const int astar = s_astar[i];
+            auto push = [&](const u32 a, const u32 pos) {
+                const u32 at = atomicAdd(s_kept + i, 1u);
+                if (at < (u32)HKQ) cent[i * HKQ + at] = pos | (((int)a <= astar) ? 0x80000000u : 0u);
+            };
+#pragma unroll
+            for (int k = 0; k < NS; k++) {
+                const u32 key = slot[i][k];
+                if (key != 0xFFFFFFFFu && (key >> 16) <= cut) push(key >> 16, ((key & 0xFFFFu) << 8) | (u32)tid);
+            }
+            const u32 last = slot[i][NS - 1];
+            if (last != 0xFFFFFFFFu && (last >> 16) <= cut) {  // (~1e-5 of the lanes) this lane may have dropped candidates: its codes once more
+                for (u32 step = 0; step * NT + (u32)tid < n_seg; step++) {
+                    CodeVec<M, unsigned char> cv;
+                    cv.load(codes0 + (step * NT + (u32)tid) * (u32)M);
+                    u32 lo, hi;
+                    lookup(cv, lo, hi);
+                    const u32 a = (i & 1) ? ((i < 2 ? lo : hi) >> 16) : ((i < 2 ? lo : hi) & 0xFFFFu);
+                    if (a <= cut && ((a << 16) | step) > last) push(a, (step << 8) | (u32)tid);  // (keys up to `last` are in the slots)
+                }
+            }
         }
     }
     __syncthreads();
@@ -368,7 +385,7 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
     first[0] = 0;
 #pragma unroll
     for (int i = 0; i < G; i++) {
-        live[i] = i < ng && s_flag[i] == 0u;
+        live[i] = i < ng && s_flag[i] == 0u && s_kept[i] <= (u32)HKQ;
         if (i < ng && !live[i] && tid == 0) {  // this query's pair goes to the exact kernel, chunk by chunk of the list
             const u32 nch = (n_seg + (u32)P.chunk - 1u) / (u32)P.chunk;
             const u32 sl = atomicAdd(P.fb_count, nch);
@@ -381,35 +398,68 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
     }
     const u32 ncand = first[G];
     if (ncand == 0) return;  // block-uniform
-    // ---- exact sums, a thread per candidate: d = sum_s [ sum_t (r[s dsub + t] - pq[s][code_s][t])^2 ], t then s ascending from 0.0 ------
-    u64 *ckey = (u64 *)smem;  // [ncand] (the key list is dead: every wave passed the barrier above after reading it)
+    // ---- exact sums, a thread per candidate: d = sum_s [ sum_t (r[s dsub + t] - pq[s][code_s][t])^2 ], t then s ascending from 0.0.
+    //      Two candidates per thread side by side, their codes requested together, Q_FR codebook rows of each in flight ---------------
+    u64 *ckey = (u64 *)smem;  // [ncand] (the table is dead: every wave passed the barrier above after its last lookup)
+    {
+        const u32 ia = (u32)tid, ib = (u32)tid + NT, ic = (u32)tid + 2 * NT;
+        auto which = [&](const u32 idx) -> int {
+            int i = 0;
+#pragma unroll
+            for (int k = 1; k < G; k++) i += (idx >= first[k]) ? 1 : 0;
+            return i;
+        };
+        auto entry_of = [&](const u32 idx, const int i) -> u32 { return cent[i * HKQ + (idx - (i == 0 ? first[0] : (i == 1 ? first[1] : (i == 2 ? first[2] : first[3]))))]; };
+        auto sum2 = [&](const u32 i0, const u32 i1) {  // candidates i0 and i1 (i1 may be past the end)
+            const bool h0 = i0 < ncand, h1 = i1 < ncand;
+            if (!__builtin_amdgcn_ballot_w64(h0)) return;
+            const int q0 = h0 ? which(i0) : 0, q1 = h1 ? which(i1) : 0;
+            const u32 v0 = h0 ? entry_of(i0, q0) : 0u, v1 = h1 ? entry_of(i1, q1) : 0u;
+            CodeVec<M, unsigned char> c0v, c1v;
+            c0v.load(codes0 + (v0 & 0xFFFFFFu) * (u32)M);
+            c1v.load(codes0 + (v1 & 0xFFFFFFu) * (u32)M);
+            const double *t0 = s_r + (size_t)q0 * D, *t1 = s_r + (size_t)q1 * D;
+            double d0 = 0.0, d1 = 0.0;
 #pragma unroll 1
-    for (u32 idx = (u32)tid; idx < ncand; idx += NT) {
-        int i = 0;
+            for (int s0 = 0; s0 < M; s0 += Q_FR) {
+                double p0[Q_FR][DSUB], p1[Q_FR][DSUB];
 #pragma unroll
-        for (int k = 1; k < G; k++) i += (idx >= first[k]) ? 1 : 0;
-        const u32 v = cent[i * HKQ + (idx - (i == 0 ? first[0] : (i == 1 ? first[1] : (i == 2 ? first[2] : first[3]))))];
-        CodeVec<M, unsigned char> cv;
-        cv.load(codes0 + (v & 0xFFFFFFu) * (u32)M);
-        const double *tv = s_r + (size_t)i * D;
-        double d = 0.0;
-#pragma unroll Q_FU
-        for (int s = 0; s < M; s++) {
-            const double *row = QP.pq + ((size_t)s * 256 + (size_t)cv.get(s)) * DSUB;
-            double p[DSUB];
+                for (int j = 0; j < Q_FR; j++) {
+                    const u32 b0 = (c0v.wd[(s0 + j) >> 2] >> (8 * ((s0 + j) & 3))) & 0xffu, b1 = (c1v.wd[(s0 + j) >> 2] >> (8 * ((s0 + j) & 3))) & 0xffu;
+                    const double *r0 = QP.pq + ((size_t)(s0 + j) * 256 + (size_t)b0) * DSUB;
+                    const double *r1 = QP.pq + ((size_t)(s0 + j) * 256 + (size_t)b1) * DSUB;
 #pragma unroll
-            for (int t = 0; t < DSUB; t++) p[t] = row[t];
-            double acc = 0.0;
+                    for (int t = 0; t < DSUB; t++) {
+                        p0[j][t] = r0[t];
+                        p1[j][t] = r1[t];
+                    }
+                }
 #pragma unroll
-            for (int t = 0; t < DSUB; t++) {
-                const double df = tv[s * DSUB + t] - p[t];
-                acc += df * df;
+                for (int j = 0; j < Q_FR; j++) {
+                    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                    for (int t = 0; t < DSUB; t++) {
+                        const double f0 = t0[(s0 + j) * DSUB + t] - p0[j][t], f1 = t1[(s0 + j) * DSUB + t] - p1[j][t];
+                        a0 += f0 * f0;
+                        a1 += f1 * f1;
+                    }
+                    d0 = (s0 + j) == 0 ? a0 : d0 + a0;  // (0.0 + x == x: the first entry itself)
+                    d1 = (s0 + j) == 0 ? a1 : d1 + a1;
+                }
             }
-            d = s == 0 ? acc : d + acc;  // (0.0 + x == x: the first entry itself)
-        }
-        const u64 key = dkey(d);
-        ckey[idx] = key;
-        if (v & 0x80000000u) atomicMax(s_max + i, key);  // evidence codes: at least K1 per query
+            if (h0) {
+                ckey[i0] = dkey(d0);
+                if (v0 & 0x80000000u) atomicMax(s_max + q0, dkey(d0));  // evidence codes: at least K1 per query
+            }
+            if (h1) {
+                ckey[i1] = dkey(d1);
+                if (v1 & 0x80000000u) atomicMax(s_max + q1, dkey(d1));
+            }
+        };
+        // (two candidates side by side measured no faster than one after the other: 0.78 against 0.73 ms per 7525 groups)
+        sum2(ia, 0xFFFFFFFFu);
+        sum2(ib, 0xFFFFFFFFu);
+        sum2(ic, 0xFFFFFFFFu);
     }
     __syncthreads();
     Q_T(4);

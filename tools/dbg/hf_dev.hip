@@ -231,6 +231,9 @@ int main(int argc, char **argv) {
         hipFuncAttributes fa{};
         CHECK(hipFuncGetAttributes(&fa, (const void *)k_scan_q<16, HD / 16>));
         timeit([&]() { hipLaunchKernelGGL((k_scan_q<16, HD / 16>), dim3(ngr), dim3(256), L.total, nullptr, QP); }, rf);
+        int occ = 0;
+        CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_scan_q<16, HD / 16>, 256, L.total));
+        printf("occupancy: %d blocks per CU\n", occ);
         printf("K3q : %.3f ms  (%d groups, lds %zu, static lds %zu, %d VGPRs, %d queries handed back)  %.0f GB/s of codes (algorithmic: every query's list)\n", rf.ms, ngr, L.total,
                (size_t)fa.sharedSizeBytes, fa.numRegs, rf.fb, (double)nq * avg * 16 / rf.ms / 1e6);
         unsigned long long tim[8];
