@@ -349,6 +349,16 @@ def oracle_of_index(cx, h, coarse_h, pq_h):
     ref.set_pq(pq_h)
     ref.set_w(a.w)
     ref.load_lists(off, iids, codes)
+    # the duplicate-code rate of every generated index (a sample of 64 lists, exact within them)
+    try:
+        from tie_census import duplicate_code_rate
+
+        rs = np.random.default_rng(7)
+        lists = rs.choice(a.cells, size=min(64, a.cells), replace=False)
+        rate, seen = duplicate_code_rate(off, codes, lists)
+        ref.dup_info = {"duplicate_code_rate": rate, "codes_examined": seen, "lists_examined": int(len(lists))}
+    except Exception as e:  # noqa: BLE001
+        ref.dup_info = {"error": repr(e)}
     return ref
 
 
@@ -889,7 +899,7 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
 
     big = None
     # ---------------------------------------------------------------- CPU baseline + parity gate (headline index)
-    cpu_baseline, parity = None, None
+    cpu_baseline, parity, ties = None, None, None
     cores, logical, quota, cpu_model = usable_cpus()
     if rank == 0 and (world == 1 or native) and not args.no_cpu:
         t0 = time.time()
@@ -920,6 +930,18 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
                         "one_thread": {"value": round(n1 / one_t, 2), "unit": "queries/s", "queries": n1,
                                        "same_results_as_threaded": one_ok}}
         parity = parity_of(res_iid, res_dist, rid, rd)
+        # ... and the exact ties among the top-(k + 1) of a parity sample: does the gate lean on the LingPipe assumption A1?
+        try:
+            from tie_census import tie_census
+
+            nt = int(min(nsamp, 2048))
+            _, td, _ = ref.search_batch(Qh[:nt], k + 1, nthreads=cores)
+            ties = dict(tie_census(td, k), **getattr(ref, "dup_info", {}))
+            ties["engine_tie_replays_per_step"] = int(st.tie_fallbacks) // max(1, detail_steps)
+            ties["note"] = ("oracle top-(k+1) of the first %d parity queries; a tie at k would make MEMBERSHIP depend on assumption A1, a tie inside "
+                            "the ORDER of the tied ids (tests/test_queue_rules_cpu.py)" % nt)
+        except Exception as e:  # noqa: BLE001
+            ties = {"error": repr(e)}
         if big_B > 0:
             try:
                 big = big_batch(ref)
@@ -1165,6 +1187,7 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
             "host_path": host, "measured_ceilings": probes, "sharded_dry_run": dry,
             # the figures a reader should see NEXT to the headline: what a Java caller reaches through the JNI shim
             # (mmidx_search: host arrays in, host arrays out, synchronous) and what the engine does when the far probes have to be scanned
+            "ties": ties,
             "host_buffers_qps": (host or {}).get("nq16384", {}).get("queries_per_s") if isinstance(host, dict) else None,
             "hard_qps": hard.get("value") if isinstance(hard, dict) else None,
             "spread_qps": spread.get("value") if isinstance(spread, dict) else None,

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MMIDX_ABI_VERSION 7
+#define MMIDX_ABI_VERSION 8
 
 typedef struct mmidx_index mmidx_index; /* opaque handle: one index on one GPU */
 
@@ -121,6 +121,14 @@ int mmidx_sync_index(mmidx_index *h);
  * getInvertedListId :865 read the same records from BDB): list_off_out[nlists+1],
  * iids_out[n], codes_out[n][m] in stored form.  iids_out / codes_out may be NULL. */
 int mmidx_export(mmidx_index *h, int64_t *list_off_out, int32_t *iids_out, void *codes_out);
+/* native flat snapshot for fast restart alongside BDB (ABI 8).  mmidx_save writes what mmidx_export returns -- header
+ * (magic "MMIDXSN1", version, kind, D, m, ks, C, code width, transform, n), list_off[nlists + 1], iids[n], codes[n][m] in stored
+ * form, little-endian -- to `path` (through path.tmp + rename).  mmidx_load fills an EMPTY handle of the same shape (quantizers set
+ * as after the constructor) from such a file: the work of loadIndexInMemory (IVFPQ.java:680-728, PQ.java:436-483) without the
+ * BDB cursor; every list keeps its arrival order.  A shape mismatch, a damaged file or a non-empty index is MMIDX_ERR_INVALID_ARG.
+ * Ids (String <-> iid) stay where they are: in the Java side's BDB. */
+int mmidx_save(mmidx_index *h, const char *path);
+int mmidx_load(mmidx_index *h, const char *path);
 
 /* ---- per-id utilities of IVFPQ / PQ ----------------------------------------------------------------
  * mmidx_get_dims: the constructor arguments of the handle (vectorLength, numSubVectors, numProductCentroids,

@@ -78,6 +78,8 @@ SIGNATURES = {
     "mmidx_assign_device": (C.c_int, [_vp, C.c_int64, _dp, _i32p, _vp]),
     "mmidx_sync_index": (C.c_int, [_vp]),
     "mmidx_export": (C.c_int, [_vp, _vp, _i32p, _vp]),
+    "mmidx_save": (C.c_int, [_vp, C.c_char_p]),
+    "mmidx_load": (C.c_int, [_vp, C.c_char_p]),
     "mmidx_get_dims": (C.c_int, [_vp] + [C.POINTER(C.c_int)] * 5),
     "mmidx_get_codes": (C.c_int, [_vp, C.c_int64, _i32p, _i32p, _vp]),
     "mmidx_distance": (C.c_int, [_vp, C.c_int64, _dp, _i32p, _dp]),

@@ -4089,6 +4089,112 @@ int mmidx_export(mmidx_index *h, int64_t *list_off_out, int32_t *iids_out, void 
     return MMIDX_OK;
 }
 
+// ---- native flat snapshot (fast restart alongside BDB; the load path it replaces: IVFPQ.java:680-728, PQ.java:436-483) ----
+// File: header, list_off[nlists + 1] (int64), iids[n] (int32), codes[n][m] in stored form -- exactly what mmidx_export returns, so a
+// list keeps its arrival order (= the reference's offer order).  Little-endian, no padding between the arrays.
+struct MmidxSnapHeader {
+    char magic[8];  // "MMIDXSN1"
+    uint32_t version, kind, D, m, ks, C, code_bytes, transform;
+    uint64_t n, nlists;
+};
+
+int mmidx_save(mmidx_index *h, const char *path) {
+    if (!h || !path) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    int64_t n = 0;
+    int rc = mmidx_size(h, &n);
+    if (rc) return rc;
+    int D = 0, m = 0, ks = 0, C = 0, cb = 0;
+    rc = mmidx_get_dims(h, &D, &m, &ks, &C, &cb);
+    if (rc) return rc;
+    const int64_t nlists = h->kind == MMIDX_KIND_IVFPQ ? C : 1;
+    std::vector<int64_t> off((size_t)nlists + 1, 0);
+    std::vector<int32_t> iids((size_t)n);
+    std::vector<unsigned char> codes((size_t)n * m * cb);
+    rc = mmidx_export(h, off.data(), n ? iids.data() : nullptr, n ? (void *)codes.data() : nullptr);
+    if (rc) return rc;
+    if (off[(size_t)nlists] != n) return fail(MMIDX_ERR_HIP, "export returned %lld records, the index holds %lld", (long long)off[(size_t)nlists], (long long)n);
+    MmidxSnapHeader hd{};
+    memcpy(hd.magic, "MMIDXSN1", 8);
+    hd.version = 1;
+    hd.kind = (uint32_t)h->kind;
+    hd.D = (uint32_t)D;
+    hd.m = (uint32_t)m;
+    hd.ks = (uint32_t)ks;
+    hd.C = (uint32_t)C;
+    hd.code_bytes = (uint32_t)cb;
+    hd.transform = (uint32_t)h->transform;
+    hd.n = (uint64_t)n;
+    hd.nlists = (uint64_t)nlists;
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return fail(MMIDX_ERR_INVALID_ARG, "cannot open %s for writing", tmp.c_str());
+    bool ok = fwrite(&hd, sizeof(hd), 1, f) == 1 && fwrite(off.data(), 8, off.size(), f) == off.size();
+    ok = ok && (n == 0 || (fwrite(iids.data(), 4, iids.size(), f) == iids.size() && fwrite(codes.data(), 1, codes.size(), f) == codes.size()));
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), path) != 0) {
+        (void)remove(tmp.c_str());
+        return fail(MMIDX_ERR_INVALID_ARG, "writing the snapshot %s failed", path);
+    }
+    return MMIDX_OK;
+}
+
+int mmidx_load(mmidx_index *h, const char *path) {
+    if (!h || !path) return fail(MMIDX_ERR_INVALID_ARG, "null argument");
+    int64_t have = 0;
+    int rc = mmidx_size(h, &have);
+    if (rc) return rc;
+    if (have != 0) return fail(MMIDX_ERR_INVALID_ARG, "mmidx_load needs an empty index (this one holds %lld records)", (long long)have);
+    int D = 0, m = 0, ks = 0, C = 0, cb = 0;
+    rc = mmidx_get_dims(h, &D, &m, &ks, &C, &cb);
+    if (rc) return rc;
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(MMIDX_ERR_INVALID_ARG, "cannot open the snapshot %s", path);
+    MmidxSnapHeader hd{};
+    const bool hok = fread(&hd, sizeof(hd), 1, f) == 1 && memcmp(hd.magic, "MMIDXSN1", 8) == 0 && hd.version == 1;
+    const int64_t nlists = h->kind == MMIDX_KIND_IVFPQ ? C : 1;
+    if (!hok || hd.kind != (uint32_t)h->kind || hd.D != (uint32_t)D || hd.m != (uint32_t)m || hd.ks != (uint32_t)ks || hd.C != (uint32_t)C ||
+        hd.code_bytes != (uint32_t)cb || hd.transform != (uint32_t)h->transform || hd.nlists != (uint64_t)nlists) {
+        fclose(f);
+        return fail(MMIDX_ERR_INVALID_ARG, "%s is not a snapshot of an index of this shape (kind / D / m / ks / C / code width / transform)", path);
+    }
+    std::vector<int64_t> off((size_t)nlists + 1);
+    bool ok = fread(off.data(), 8, off.size(), f) == off.size() && off[0] == 0 && off[(size_t)nlists] == (int64_t)hd.n;
+    for (int64_t c = 0; ok && c < nlists; c++) ok = off[(size_t)c] <= off[(size_t)c + 1];
+    if (!ok) {
+        fclose(f);
+        return fail(MMIDX_ERR_INVALID_ARG, "%s: damaged list offsets", path);
+    }
+    const int64_t n = (int64_t)hd.n;
+    const size_t rec = (size_t)m * cb;
+    // records go in list-major, in pieces of <= 16 M (the lists keep their order: mmidx_add_codes appends in the order given)
+    const int64_t piece = 16ll << 20;
+    std::vector<int32_t> iids, cells;
+    std::vector<unsigned char> codes;
+    const long data0 = ftell(f);
+    int64_t c = 0;
+    for (int64_t p0 = 0; p0 < n && ok; p0 += piece) {
+        const int64_t pn = std::min(piece, n - p0);
+        iids.resize((size_t)pn);
+        cells.resize((size_t)pn);
+        codes.resize((size_t)pn * rec);
+        ok = fseek(f, data0 + (long)(p0 * 4), SEEK_SET) == 0 && fread(iids.data(), 4, (size_t)pn, f) == (size_t)pn;
+        ok = ok && fseek(f, data0 + (long)(n * 4) + (long)((size_t)p0 * rec), SEEK_SET) == 0 && fread(codes.data(), 1, codes.size(), f) == codes.size();
+        if (!ok) break;
+        for (int64_t i = 0; i < pn; i++) {
+            while (p0 + i >= off[(size_t)c + 1]) c++;
+            cells[(size_t)i] = (int32_t)c;
+        }
+        rc = mmidx_add_codes(h, pn, iids.data(), h->kind == MMIDX_KIND_IVFPQ ? cells.data() : nullptr, codes.data());
+        if (rc) {
+            fclose(f);
+            return rc;
+        }
+    }
+    fclose(f);
+    if (!ok) return fail(MMIDX_ERR_INVALID_ARG, "%s: truncated snapshot", path);
+    return mmidx_sync_index(h);
+}
+
 }  // extern "C"
 
 // =================================================================================================

@@ -10,6 +10,8 @@ here by plain dicts.  All vector arithmetic happens in libmmidx_hip.so on the GP
 import ctypes as C
 import time
 
+import os
+
 import numpy as np
 
 from . import _native as N
@@ -293,26 +295,21 @@ class _PQBase(AbstractSearchStructure):
         return off, iids, codes
 
     def saveSnapshot(self, filename):
-        """Flat snapshot of the in-memory index for fast restart: the list-major
-        arrays loadIndexInMemory builds (IVFPQ.java:680-728) plus the id map; the BDB environment stays
-        the system of record on the Java side."""
-        off, iids, codes = self.export()
+        """Flat snapshot of the in-memory index for fast restart: the library's own file (mmidx_save: the
+        list-major arrays loadIndexInMemory builds, IVFPQ.java:680-728) plus, next to it, the id map this mirror keeps where the
+        Java side keeps its BDB environment (`filename`.ids.npz)."""
+        N.check(N.lib().mmidx_save(self._h, os.fsencode(filename)))
+        iids = np.array(sorted(self._iid_to_id), np.int32)
         # ids as a fixed-width unicode array: loadable without pickle (an untrusted snapshot must not be able to run code)
-        ids = np.array([str(self._iid_to_id.get(int(i), int(i))) for i in iids], dtype=str)
-        np.savez(filename, list_off=off, iids=iids, codes=codes, ids=ids, load_counter=np.int64(self.loadCounter))
+        ids = np.array([str(self._iid_to_id[int(i)]) for i in iids], dtype=str)
+        np.savez(str(filename) + ".ids.npz", iids=iids, ids=ids, load_counter=np.int64(self.loadCounter))
 
     def loadSnapshot(self, filename):
-        """Inverse of saveSnapshot on an empty index of the same shape (quantizers loaded separately,
-        as after the reference's constructor)."""
-        z = np.load(filename, allow_pickle=False)
-        off, iids, codes, ids = z["list_off"], z["iids"], z["codes"], z["ids"]
-        nl = len(off) - 1
-        cells = np.repeat(np.arange(nl, dtype=np.int32), np.diff(off).astype(np.int64))
-        iids = np.ascontiguousarray(iids, np.int32)
-        codes = np.ascontiguousarray(codes, self._code_dtype)
-        N.check(N.lib().mmidx_add_codes(self._h, len(iids), iids.ctypes.data,
-                                        cells.ctypes.data if self._kind == N.KIND_IVFPQ else None, codes.ctypes.data))
-        for i, name in zip(iids, ids):
+        """Inverse of saveSnapshot on an empty index of the same shape (quantizers loaded separately, as after the reference's
+        constructor): mmidx_load for the records, the sidecar for the id map."""
+        N.check(N.lib().mmidx_load(self._h, os.fsencode(filename)))
+        z = np.load(str(filename) + ".ids.npz", allow_pickle=False)
+        for i, name in zip(z["iids"], z["ids"]):
             self._iid_to_id[int(i)] = str(name)
             self._id_to_iid[str(name)] = int(i)
         self.loadCounter = int(z["load_counter"])

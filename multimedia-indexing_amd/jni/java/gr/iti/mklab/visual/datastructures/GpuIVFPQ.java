@@ -255,6 +255,21 @@ public class GpuIVFPQ extends AbstractSearchStructure {
 		}
 	}
 
+	/**
+	 * Native flat snapshot of the in-memory index (SURVEY 8 f1): what {@link #loadIndexInMemory()} builds from the BDB cursor --
+	 * list offsets, internal ids and stored codes -- written by the library in one piece (mmidx_save). The BDB environment stays
+	 * the system of record for the id map; a restart that finds a snapshot as recent as the database calls
+	 * {@link #loadSnapshot(String)} instead of walking the cursor (IVFPQ.java:680-728).
+	 */
+	public synchronized void saveSnapshot(String filename) throws Exception {
+		MmidxNative.saveSnapshot(handle, filename);
+	}
+
+	/** fills the (empty) device index from a file written by {@link #saveSnapshot(String)}; quantizers must be loaded first */
+	public synchronized void loadSnapshot(String filename) throws Exception {
+		MmidxNative.loadSnapshot(handle, filename);
+	}
+
 	private void appendPersistentIndex(int listId, byte[] code) { // IVFPQ.java:760-772, unchanged
 		TupleOutput output = new TupleOutput();
 		output.writeInt(listId);

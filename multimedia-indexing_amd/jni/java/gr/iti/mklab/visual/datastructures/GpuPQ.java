@@ -166,4 +166,13 @@ public class GpuPQ extends AbstractSearchStructure {
 		iidToPqDB.close();
 		MmidxNative.destroy(handle);
 	}
+
+	/** native flat snapshot (mmidx_save / mmidx_load): the arrays loadIndexInMemory builds (PQ.java:436-483), for a fast restart */
+	public synchronized void saveSnapshot(String filename) throws Exception {
+		MmidxNative.saveSnapshot(handle, filename);
+	}
+
+	public synchronized void loadSnapshot(String filename) throws Exception {
+		MmidxNative.loadSnapshot(handle, filename);
+	}
 }

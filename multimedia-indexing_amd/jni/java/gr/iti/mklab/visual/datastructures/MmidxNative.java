@@ -62,6 +62,11 @@ public final class MmidxNative {
 
 	public static native void listSizes(long handle, int[] out) throws Exception;
 
+	/** mmidx_save / mmidx_load (ABI 8): the native flat snapshot -- list offsets, iids and stored codes as loadIndexInMemory builds them */
+	public static native void saveSnapshot(long handle, String path) throws Exception;
+
+	public static native void loadSnapshot(long handle, String path) throws Exception;
+
 	/** mmidx_get_stats as {total_ms, coarse_ms, scan_ms, merge_ms, scan_codes, scan_launches, tie_fallbacks} */
 	public static native void stats(long handle, double[] out7) throws Exception;
 

@@ -316,6 +316,36 @@ done:
     (*env)->ReleaseIntArrayElements(env, out, o, 0);
 }
 
+/* native flat snapshot (mmidx_save / mmidx_load, ABI 8): the fast-restart path next to loadIndexInMemory's BDB cursor
+ * (IVFPQ.java:680-728, PQ.java:436-483).  The id map stays in BDB. */
+JNIEXPORT void JNICALL JFN(saveSnapshot)(JNIEnv *env, jclass c, jlong h, jstring path) {
+    const char *p;
+    (void)c;
+    if (!path) {
+        throw_status(env, MMIDX_ERR_INVALID_ARG);
+        return;
+    }
+    p = (*env)->GetStringUTFChars(env, path, NULL);
+    if (!p) return; /* OutOfMemoryError pending */
+    CHECK(mmidx_save(H(h), p));
+done:
+    (*env)->ReleaseStringUTFChars(env, path, p);
+}
+
+JNIEXPORT void JNICALL JFN(loadSnapshot)(JNIEnv *env, jclass c, jlong h, jstring path) {
+    const char *p;
+    (void)c;
+    if (!path) {
+        throw_status(env, MMIDX_ERR_INVALID_ARG);
+        return;
+    }
+    p = (*env)->GetStringUTFChars(env, path, NULL);
+    if (!p) return;
+    CHECK(mmidx_load(H(h), p));
+done:
+    (*env)->ReleaseStringUTFChars(env, path, p);
+}
+
 /* outputIndexingTimesInternal (ASS:718-729): the native side's accumulated statistics, as
  * {total_ms, coarse_ms, scan_ms, merge_ms, scan_codes, scan_launches, tie_fallbacks} */
 JNIEXPORT void JNICALL JFN(stats)(JNIEnv *env, jclass c, jlong h, jdoubleArray out7) {

@@ -31,6 +31,16 @@
  *   - last() = worst kept, poll() = remove best, iteration / toArray = best -> worst.
  * Kept as a sorted array: key (distance ascending, insertion counter descending).
  * ---------------------------------------------------------------------------------------- */
+/* The two behaviours above that cannot be read off the reference tree (LingPipe is a jar): what happens to a candidate EQUAL to
+ * the current worst, and how equal entries are ordered.  Rule 0 is assumption A1.  Rules 1 and 2 are the two plausible
+ * alternatives; they exist so that tests can show which answers do NOT depend on the assumption (tests/test_queue_rules_cpu.py):
+ *   1  accept-equal-to-worst: offer() rejects only when o.distance > worst.distance (the evicted entry is still last());
+ *   2  earlier-inserted-first among equals (a new entry goes BEHIND its equals; last() is then the LATEST inserted equal-worst).
+ * Process-wide, set before any search; the product never sees it. */
+static int g_queue_rule = 0;
+void mmo_set_queue_rule(int rule) { g_queue_rule = (rule == 1 || rule == 2) ? rule : 0; }
+int mmo_get_queue_rule(void) { return g_queue_rule; }
+
 struct mmo_bpq {
     int cap, size;
     long long next_ins;
@@ -66,9 +76,9 @@ double mmo_bpq_last_dist(const mmo_bpq *q) { return q->dist[q->size - 1]; }
  * existing entries of equal distance. */
 static void bpq_insert(mmo_bpq *q, int id, double dist) {
     int lo = 0, hi = q->size;
-    while (lo < hi) { /* first position whose dist >= new dist */
+    while (lo < hi) { /* first position whose dist >= new dist (rule 2: > new dist, behind its equals) */
         int mid = (lo + hi) >> 1;
-        if (q->dist[mid] < dist) lo = mid + 1;
+        if (q->dist[mid] < dist || (g_queue_rule == 2 && q->dist[mid] == dist)) lo = mid + 1;
         else hi = mid;
     }
     int n = q->size - lo;
@@ -86,8 +96,8 @@ int mmo_bpq_offer(mmo_bpq *q, int id, double dist) {
         bpq_insert(q, id, dist);
         return 1;
     }
-    /* Result.compare(o, last) <= 0  <=>  !(o.dist < last.dist) */
-    if (!(dist < q->dist[q->size - 1])) return 0;
+    /* Result.compare(o, last) <= 0  <=>  !(o.dist < last.dist)   (rule 1: < 0, an equal candidate gets in) */
+    if (g_queue_rule == 1 ? (dist > q->dist[q->size - 1]) : !(dist < q->dist[q->size - 1])) return 0;
     q->size--; /* remove last(): worst distance, earliest inserted among equals */
     bpq_insert(q, id, dist);
     return 1;

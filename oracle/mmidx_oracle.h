@@ -34,6 +34,9 @@ extern "C" {
 /* ---- bounded priority queue (LingPipe BoundedPriorityQueue<Result> + Result comparator) ---- */
 /* J/utilities/Result.java:38-45 : smaller distance = higher priority. Assumption A1 for ties. */
 typedef struct mmo_bpq mmo_bpq;
+/* queue rule: 0 = assumption A1 (default), 1 = accept-equal-to-worst, 2 = earlier-inserted-first among equals (tests only) */
+void mmo_set_queue_rule(int rule);
+int mmo_get_queue_rule(void);
 mmo_bpq *mmo_bpq_new(int max_size);
 void mmo_bpq_free(mmo_bpq *q);
 void mmo_bpq_clear(mmo_bpq *q);

@@ -38,6 +38,8 @@ def lib():
         "mmo_bpq_new": (vp, [C.c_int]),
         "mmo_bpq_free": (None, [vp]),
         "mmo_bpq_offer": (C.c_int, [vp, C.c_int, C.c_double]),
+        "mmo_set_queue_rule": (None, [C.c_int]),
+        "mmo_get_queue_rule": (C.c_int, []),
         "mmo_bpq_size": (C.c_int, [vp]),
         "mmo_bpq_last_dist": (C.c_double, [vp]),
         "mmo_bpq_poll": (C.c_int, [vp, ip, dp]),
@@ -135,6 +137,20 @@ class BPQ:
         lib().mmo_bpq_to_arrays(self._h, ids.ctypes.data_as(C.POINTER(C.c_int)),
                                 ds.ctypes.data_as(C.POINTER(C.c_double)))
         return ids, ds
+
+
+QUEUE_RULE_A1, QUEUE_RULE_ACCEPT_EQUAL, QUEUE_RULE_EARLIER_FIRST = 0, 1, 2
+
+
+def set_queue_rule(rule):
+    """process-wide: which of the three plausible LingPipe BoundedPriorityQueue behaviours every bounded queue of the oracle follows
+    (0 = assumption A1, the default; 1 = accept-equal-to-worst; 2 = earlier-inserted-first among equals) -- for the tests that show
+    which answers do not depend on the assumption"""
+    lib().mmo_set_queue_rule(int(rule))
+
+
+def get_queue_rule():
+    return int(lib().mmo_get_queue_rule())
 
 
 def jdk_first_next_int(seed):

@@ -73,6 +73,21 @@ def timed_search(ix, Q, k, reps=5):
     return B / dt, iid.cpu().numpy(), dd.cpu().numpy(), cc.cpu().numpy()
 
 
+def ties_of(ref, off, codes, Qs, k, nthreads):
+    """duplicate-code rate of the generated index (a sample of lists, or the flat list) and exact ties among the
+    top-(k + 1) of the parity queries (a tie at k: membership would depend on the LingPipe assumption A1)"""
+    try:
+        from tie_census import duplicate_code_rate, tie_census
+
+        nl = len(off) - 1
+        lists = np.random.default_rng(7).choice(nl, size=min(64, nl), replace=False)
+        rate, seen = duplicate_code_rate(off, codes, lists)
+        _, td, _ = ref.search_batch(Qs, k + 1, nthreads=nthreads)
+        return dict(tie_census(td, k), duplicate_code_rate=rate, codes_examined=seen)
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
+
+
 def run_all():
     """cfg1-3 at their stated sizes; returns the dict bench.py publishes as `other_configs`"""
     out = {}
@@ -98,7 +113,7 @@ def run_all():
     cpu_qps, cpu_nt, (rid, rd, rc) = cpu_best(lambda nt: ref.search_batch(Q[:ns], k, nthreads=nt), ns)
     out["cfg2_pq_adc_1M"] = {"qps_gpu": round(qps, 1), "index_s": round(t_index, 2), "ids_match": bool(np.array_equal(iid[:ns], rid)),
                              "max_abs_ddist": float(np.max(np.abs(dd[:ns] - rd))), "cpu_qps": round(cpu_qps, 1), "cpu_threads": cpu_nt,
-                             "algorithmic_GBps": round(qps * N * m / 1e9, 1)}
+                             "algorithmic_GBps": round(qps * N * m / 1e9, 1), "ties": ties_of(ref, off, codes_e, Q[:ns], k, cpu_nt)}
     ix.close()
     del ref
 
@@ -129,7 +144,7 @@ def run_all():
     cpu_qps, cpu_nt, (rid, rd, rc) = cpu_best(lambda nt: ref.search_batch(Q[:ns], k, nthreads=nt), ns)
     out["cfg3_ivfpq_1M"] = {"qps_gpu": round(qps, 1), "index_s": round(t_index, 2), "recall_at_1": float(np.mean(iid[:, 0] == qi)),
                             "ids_match": bool(np.array_equal(iid[:ns], rid)), "max_abs_ddist": float(np.max(np.abs(dd[:ns] - rd))),
-                            "cpu_qps": round(cpu_qps, 1), "cpu_threads": cpu_nt}
+                            "cpu_qps": round(cpu_qps, 1), "cpu_threads": cpu_nt, "ties": ties_of(ref, off, codes_e, Q[:ns], k, cpu_nt)}
     ix.close()
 
     # ---- the same shape behind a RandomRotation (IVFPQ.java:420-421, RandomRotation.java:44-49), cells that overlap (sigma 0.6) so that

@@ -23,6 +23,7 @@ typedef jarray jlongArray;
 typedef jarray jbyteArray;
 typedef jarray jshortArray;
 typedef jarray jdoubleArray;
+typedef jobject jstring;
 #define JNIEXPORT __attribute__((visibility("default")))
 #define JNICALL
 #define JNI_ABORT 2
@@ -44,5 +45,7 @@ struct JNINativeInterface_ {
     void (*ReleaseDoubleArrayElements)(JNIEnv *, jdoubleArray, jdouble *, jint);
     void (*SetIntArrayRegion)(JNIEnv *, jintArray, jsize, jsize, const jint *);
     void (*SetDoubleArrayRegion)(JNIEnv *, jdoubleArray, jsize, jsize, const jdouble *);
+    const char *(*GetStringUTFChars)(JNIEnv *, jstring, jboolean *);
+    void (*ReleaseStringUTFChars)(JNIEnv *, jstring, const char *);
 };
 #endif

@@ -33,7 +33,7 @@ def test_header_symbols_exported(mi):
     from importlib import import_module
     nat = import_module("multimedia-indexing_amd._native")
     assert sorted(nat.SIGNATURES) == names
-    assert L.mmidx_abi_version() == 7
+    assert L.mmidx_abi_version() == 8
 
 
 def test_argument_errors_without_touching_the_gpu(mi):

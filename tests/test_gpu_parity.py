@@ -8,6 +8,8 @@ import importlib
 
 import ctypes
 
+import os
+
 import numpy as np
 import pytest
 
@@ -1096,7 +1098,7 @@ def test_snapshot_roundtrip(mi, oracle, tmp_path):
         ix.loadProductQuantizer(p["pq"])
         ix.setW(w)
     a.indexVectors([f"im{i}" for i in range(n)], p["base"])
-    f = str(tmp_path / "snap.npz")
+    f = str(tmp_path / "snap.mmidx")
     a.saveSnapshot(f)
     b.loadSnapshot(f)
     assert b.size() == n and b.getLoadCounter() == n and np.array_equal(a.listSizes(), b.listSizes())
@@ -1105,6 +1107,61 @@ def test_snapshot_roundtrip(mi, oracle, tmp_path):
     assert b.computeNearestNeighbors(k, p["queries"][0]).getIds() == a.computeNearestNeighbors(k, p["queries"][0]).getIds()
     assert b.indexVector("im5", p["base"][5]) is False  # duplicate id known after the reload
     a.close()
+    b.close()
+
+
+def test_native_snapshot_reload_1m_against_the_oracle(mi, oracle, tmp_path):
+    """mmidx_save / mmidx_load (ABI 8, the fast-restart path next to loadIndexInMemory, IVFPQ.java:680-728): one million codes are
+    written by one handle and read by a FRESH one; the reloaded index is compared with the ORACLE holding the same records (not
+    with the first handle): list sizes, exported lists (order inside a list = arrival order), ids and distance bits of a search.
+    Also: a shape mismatch, a non-empty target and a truncated file are refused."""
+    D, C, m, ks, n, w, k, nq = 64, 128, 16, 256, 1_000_000, 8, 20, 64
+    rng = np.random.default_rng(5)
+    coarse = rng.standard_normal((C, D))
+    pq = 0.3 * rng.standard_normal((m, ks, D // m))
+    # records straight as codes (indexPQCode, IVFPQ.java:357-386): a million encodes on the CPU oracle would take minutes
+    cells = rng.integers(0, C, n).astype(np.int32)
+    codes = rng.integers(0, ks, (n, m)).astype(np.int32)
+    stored = (codes - 128).astype(np.int8)
+    iids = np.arange(n, dtype=np.int32)
+    a = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    a.loadCoarseQuantizer(coarse)
+    a.loadProductQuantizer(pq)
+    a.setW(w)
+    N = mi._native
+    N.check(N.lib().mmidx_add_codes(a._h, n, iids.ctypes.data, cells.ctypes.data, stored.ctypes.data))
+    f = str(tmp_path / "big.mmidx")
+    N.check(N.lib().mmidx_save(a._h, f.encode()))
+    a.close()
+    assert os.path.getsize(f) == 56 + 8 * (C + 1) + 4 * n + m * n
+    b = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    b.loadCoarseQuantizer(coarse)
+    b.loadProductQuantizer(pq)
+    b.setW(w)
+    N.check(N.lib().mmidx_load(b._h, f.encode()))
+    ref = oracle.OracleIndex(oracle.KIND_IVFPQ, D, m, ks, C)
+    ref.set_coarse(coarse)
+    ref.set_pq(pq)
+    ref.set_w(w)
+    order = np.argsort(cells, kind="stable")  # list-major, arrival order inside a list
+    ref.load_lists(np.concatenate([[0], np.cumsum(np.bincount(cells, minlength=C))]).astype(np.int64), iids[order], stored[order])
+    assert b.size() == n and np.array_equal(b.listSizes(), ref.list_sizes())
+    off, eid, ecodes = b.export()
+    assert np.array_equal(eid, iids[order]) and np.array_equal(ecodes, stored[order])
+    Q = coarse[cells[:nq]] + 0.3 * rng.standard_normal((nq, D))
+    got = b.search_batch(k, Q)
+    exp = ref.search_batch(Q, k, nthreads=4)
+    assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1]) and np.array_equal(got[2], exp[2])
+    # refused: a non-empty index, another shape, a damaged file
+    assert N.lib().mmidx_load(b._h, f.encode()) == N.ERR_INVALID_ARG
+    c = mi.IVFPQ(D, n, False, "", m, ks, 0, C // 2, 512)
+    assert N.lib().mmidx_load(c._h, f.encode()) == N.ERR_INVALID_ARG
+    c.close()
+    g = str(tmp_path / "cut.mmidx")
+    open(g, "wb").write(open(f, "rb").read()[:1 << 20])
+    d = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    assert N.lib().mmidx_load(d._h, g.encode()) == N.ERR_INVALID_ARG
+    d.close()
     b.close()
 
 

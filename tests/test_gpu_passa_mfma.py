@@ -132,8 +132,9 @@ def test_passa_mfma_magnitudes(mi, oracle, scale):
 
 
 def test_passa_mfma_default_gate(mi, oracle):
-    """The default (-1) takes K3ma from 8 queries per list of a long-list index and leaves smaller batches to K3h: 4 cells of
-    ~5000 vectors, 40 queries (10 per list: K3ma) and 20 queries (K3h) -- same answers, and the statistics say which ran."""
+    """With K3q switched off (round 6: it serves every batch from 1.25 queries per list by default), K3ma's own gate (-1) takes pass A
+    from 8 queries per list of a long-list index and leaves smaller batches to K3h: 4 cells of ~5000 vectors, 40 queries (10 per
+    list: K3ma) and 20 queries (K3h) -- same answers, and the statistics say which ran.  With K3q on, neither runs."""
     D, m, C, n, w, k, ks = 128, 16, 4, 20000, 2, 100, 256
     rng = np.random.default_rng(3)
     mu, base, pq = _problem(rng, D, m, C, n)
@@ -145,10 +146,12 @@ def test_passa_mfma_default_gate(mi, oracle):
     ix.indexVectors([str(i) for i in range(n)], base)
     ref.add_vectors(base)
     Q = base[:40] + 0.01 * rng.standard_normal((40, D))
-    for nq, ran in ((40, 1), (20, 0)):
+    for passa_q, nq, ran, name in ((0, 40, 1, "K3ma"), (0, 20, 0, "K3h"), (-1, 40, 0, "K3q"), (-1, 20, 0, "K3q")):
+        ix.set_option("passa_q", passa_q)
         ix.set_profiling(True)
         got = ix.search_batch(k, Q[:nq])
         st = ix.get_stats()
         assert_same(got, ref.search_batch(Q[:nq], k))
         assert st["passa_mfma_launches"] == ran
+        assert ix.get_dispatch()["pass_a"] == name
     ix.close()

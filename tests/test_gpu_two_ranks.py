@@ -16,6 +16,13 @@ COMMON = ["--vectors", "3000000", "--cells", "512", "--w", "8", "--chunk", "5000
           "--settle", "2", "--no-cpu", "--gt", "0", "--hard-steps", "0", "--spread-steps", "0", "--other-configs", "0", "--exhaustive-steps", "0", "--extras", "0"]
 
 
+def _result_line(out):
+    """the bench contract: the LAST line of the output is the result object"""
+    import json
+
+    return json.loads([ln for ln in out.splitlines() if ln.strip()][-1])
+
+
 def _run(cmd, env):
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -37,7 +44,7 @@ def test_two_ranks_on_one_gpu_match_the_single_index(tmp_path, sigma, ranks):
     env2 = dict(env, MMIDX_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
                 "--master-port", str(port), "bench.py", "--gpus", str(ranks), "--batch", str(2048 // ranks), "--sigma", sigma, "--dump", two] + COMMON, env2)
-    assert f'"n_gpus": {ranks}' in out
+    assert _result_line(out)["n_gpus"] == ranks
     ref = np.load(one + ".rank0.npz")
     parts = [np.load(f"{two}.rank{r}.npz") for r in range(ranks)]
     for key in ("cnt", "iid", "dist"):
@@ -66,7 +73,8 @@ def test_native_sharded_bench_path_under_torchrun(tmp_path, sigma, ranks):
     env2 = dict(env, MMIDX_BENCH_VIRTUAL_SHARDS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
                 "--master-port", str(port), "bench.py", "--gpus", str(ranks), "--batch", "1024", "--sigma", sigma, "--dump", nat] + COMMON, env2)
-    assert f'"n_gpus": {ranks}' in out and "native sharded handle" in out and '"native_fallback_reason": null' in out
+    res = _result_line(out)
+    assert res["n_gpus"] == ranks and "native sharded handle" in res["config"]["multi_gpu_path"] and res["config"]["native_fallback_reason"] is None
     ref = np.load(one + ".rank0.npz")
     got = np.load(nat + ".rank0.npz")
     for key in ("cnt", "iid", "dist"):
