@@ -794,7 +794,15 @@ int make_plan(mmidx_index *h, int k, int64_t nq, SearchPlan &pl, bool need_coars
     // (the [nq][C] matrix of exact coarse distances: the exact path writes and reads all of it, the certified paths -- K1c ... K1f --
     //  touch only the rows of queries that overflow their candidate lists, so theirs may be large: a batch of 131072 queries over
     //  8192 cells reserves 8.6 GB of the 288)
-    if (ivf && need_coarse) qb = std::min<int64_t>(qb, std::max<int64_t>(1, ((coarse_certified(h) ? 16ll : 2ll) << 30) / ((int64_t)h->C * 8)));
+    if (ivf && need_coarse) {
+        int64_t cap_bytes = (coarse_certified(h) ? 16ll : 2ll) << 30;
+        // (never more than a quarter of what the device has free right now: a smaller GPU, or one shared with a framework's
+        //  allocator, takes sub-batches instead of hipErrorOutOfMemory -- ADVICE r5)
+        size_t free_b = 0, total_b = 0;
+        if (cap_bytes > (2ll << 30) && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            cap_bytes = std::max<int64_t>(2ll << 30, std::min<int64_t>(cap_bytes, (int64_t)(free_b / 4)));
+        qb = std::min<int64_t>(qb, std::max<int64_t>(1, cap_bytes / ((int64_t)h->C * 8)));
+    }
     if (pl.glut) {  // one table per block in global scratch: at most 2 GiB of it
         const int64_t lut_bytes = (int64_t)h->m * h->ks * 8;
         qb = std::min<int64_t>(qb, std::max<int64_t>(1, (2ll << 30) / (lut_bytes * std::max(pl.nitems, 1))));
@@ -1207,6 +1215,38 @@ int launch_passa_q(mmidx_index *h, const ScanParams &P, const SearchPlan &pl, lo
     return launch_scan(h, F, dim3((unsigned)nfb, 1), pl.lds, st);
 }
 
+// K3ma's items: (group, piece of <= sub codes); at most eight pieces per list (k_a1_select holds a pair's values in registers).  The
+// sweep-2 bitmap is max_groups x nsub x bm_stride bytes; when that exceeds 32 GiB (one very long list on an index of many cells) K3ma
+// does not apply -- decided HERE, by passa_mfma_applies, so that the caller takes the K3q / K3h branch instead of failing the search
+// (ADVICE r5).
+struct PassaMfmaShape {
+    int sub, nsub;
+    size_t max_groups, bm_stride;
+    bool fits;
+};
+PassaMfmaShape passa_mfma_shape(const mmidx_index *h, long long npairs) {
+    constexpr int G = MF_QG;
+    PassaMfmaShape S{};
+    const long long maxlen = std::max<long long>(h->max_list_len, 1);
+    int sub = h->mfma_sub;
+    if (sub <= 0) {
+        const long long est_groups = npairs / G + std::min<long long>(npairs, std::max<int64_t>(1, h->nonempty_lists));
+        const long long want = 4ll * 2 * std::max(h->num_cus, 8);
+        long long pieces = std::max<long long>(1, std::min<long long>(8, (want + est_groups - 1) / est_groups));
+        long long sb = (maxlen + pieces - 1) / pieces;
+        sb = std::max<long long>(1024, sb);
+        sub = (int)((sb + 63) & ~63ll);
+    }
+    sub = (std::max(sub, 64) + 31) & ~31;
+    if ((maxlen + sub - 1) / sub > 8) sub = (int)((((maxlen + 7) / 8) + 31) & ~31ll);
+    S.sub = sub;
+    S.nsub = (int)((maxlen + sub - 1) / sub);
+    S.max_groups = (size_t)npairs / G + (size_t)std::min<long long>(npairs, h->C) + 1;
+    S.bm_stride = (size_t)((sub + 31) / 32) * 256;
+    S.fits = S.max_groups * (size_t)S.nsub * S.bm_stride <= ((size_t)32 << 30);
+    return S;
+}
+
 // does pass A of this call go through K3ma?  (all the applicability checks: launch_passa_mfma itself must not fall back after its first launch)
 bool passa_mfma_applies(const mmidx_index *h, const ScanParams &P, const SearchPlan &pl, long long nq) {
     if (h->passa_mfma == 0 || !P.ivf || h->no_mfma || !h->mfma_ok || !h->xn_valid || h->no_filter || P.sdc_tt || nq <= 0 || h->D > 128) return false;
@@ -1214,6 +1254,7 @@ bool passa_mfma_applies(const mmidx_index *h, const ScanParams &P, const SearchP
     if (h->max_list_len >= (1ll << 24) || nq * (long long)P.w >= 0x7fffff00ll || ((uintptr_t)P.Q & 15) != 0) return false;
     if (h->d_perm && !h->d_coarseP) return false;
     if (h->transform == MMIDX_TR_ROTATION && (!h->d_rot || (size_t)nq * h->D * 8 > ((size_t)8 << 30))) return false;
+    if (!passa_mfma_shape(h, nq).fits) return false;  // (the sweep-2 bitmap would exceed 32 GiB: one very long list)
     if (h->passa_mfma > 0) return true;
     // from ~8 queries per nearest list, on an index of long lists (where K3h would run): a shard holding a part of the
     // lists sees the same number of queries per LOCAL list
@@ -1233,23 +1274,10 @@ int launch_passa_mfma(mmidx_index *h, const ScanParams &P, const SearchPlan &pl,
     HIPCK(h->ws_order.reserve((size_t)nq * (size_t)P.w));  // (pass B's size: its reserve later must not reallocate under these launches)
     HIPCK(h->ws_gdesc.reserve((size_t)npairs / G + (size_t)C + 8));
     HIPCK(h->ws_gfb.reserve(4 + 2 * nfb + 16));
-    // items: (group, piece); at most eight pieces per list (k_a1_select holds a pair's values in registers)
-    const long long maxlen = std::max<long long>(h->max_list_len, 1);
-    int sub = h->mfma_sub;
-    if (sub <= 0) {
-        const long long est_groups = npairs / G + std::min<long long>(npairs, std::max<int64_t>(1, h->nonempty_lists));
-        const long long want = 4ll * 2 * std::max(h->num_cus, 8);
-        long long pieces = std::max<long long>(1, std::min<long long>(8, (want + est_groups - 1) / est_groups));
-        long long sb = (maxlen + pieces - 1) / pieces;
-        sb = std::max<long long>(1024, sb);
-        sub = (int)((sb + 63) & ~63ll);
-    }
-    sub = (std::max(sub, 64) + 31) & ~31;
-    if ((maxlen + sub - 1) / sub > 8) sub = (int)((((maxlen + 7) / 8) + 31) & ~31ll);
-    const int nsub = (int)((maxlen + sub - 1) / sub);
-    const size_t max_groups = (size_t)npairs / G + (size_t)std::min<long long>(npairs, C) + 1;
-    const size_t bm_stride = (size_t)((sub + 31) / 32) * 256;
-    if (max_groups * (size_t)nsub * bm_stride > ((size_t)32 << 30)) return 1;
+    const PassaMfmaShape SH = passa_mfma_shape(h, npairs);
+    if (!SH.fits) return fail(MMIDX_ERR_UNSUPPORTED, "K3ma's bitmap does not fit (passa_mfma_applies must have said so)");
+    const int sub = SH.sub, nsub = SH.nsub;
+    const size_t max_groups = SH.max_groups, bm_stride = SH.bm_stride;
     HIPCK(h->ws_T0.reserve((size_t)nq));
     HIPCK(h->ws_redo.reserve((size_t)nq));
     HIPCK(h->ws_psnap.reserve((size_t)nq));

@@ -108,12 +108,16 @@ __global__ __launch_bounds__(1024) void k_a1_item_scan(const MfmaParams P) {
         const u32 incl = wave_incl_scan_u32(c);
         if (lane == 63) s_wave[wv] = incl;
         __syncthreads();
-        u32 before = s_carry;
+        // (saturating: duplicate-heavy long lists with many queries per list can set more than 2^32 bits in one call; a wrapped prefix
+        //  would let items write overlapping record ranges.  Past the cap every item goes to the redo)
+        unsigned long long before = s_carry;
 #pragma unroll
         for (int j = 0; j < 16; j++) before += (j < wv) ? s_wave[j] : 0u;
-        if (i < nv) P.a_icnt[i] = before + incl - c;
+        const unsigned long long sat = 0xFFFFFFFFull;
+        const unsigned long long mine = before + incl - c;
+        if (i < nv) P.a_icnt[i] = (u32)(mine < sat ? mine : sat);
         __syncthreads();
-        if (tid == 1023) s_carry = before + incl;
+        if (tid == 1023) s_carry = (u32)(before + incl < sat ? before + incl : sat);
         __syncthreads();
     }
     if (tid == 0) P.a_icnt[nv] = s_carry;
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(A1R_NT) void k_a1_records(const MfmaParams P) {
                 keep[u] = make_uint4(0u, 0u, 0u, 0u);
                 if (u < nu) {  // (block-uniform)
                     const int lu = tid + u * A1R_NT;
-                    keep[u] = ((const uint4 *)bm)[lu < nload ? lu : tid];
+                    keep[u] = ((const uint4 *)bm)[lu < nload ? lu : 0];  // (clamped inside the item's own slice; the value is zeroed below)
                 }
             }
 #pragma unroll

@@ -279,7 +279,8 @@ struct ShardGroup {
                                     // (default 1 for in-process shards, 0 for two or more physical devices: mmidx_create_sharded)
     bool rccl = false;       // collectives through RCCL (devices pairwise distinct); else in-process (virtual shards)
     bool peer_ok = true;     // every shard can store into every other shard's memory
-    int route_host = 0;      // option "shard_route_host": 1 = mmidx_add_vectors_sliced_device routes its records through the host (A/B switch)
+    int route_host = 0;      // option "shard_route_host": 1 = mmidx_add_vectors_sliced_device routes its records through the host (A/B switch;
+                             // default 1 on two or more physical devices until a multi-GPU run has passed: mmidx_create_sharded)
     int exchange = 0;        // option "shard_exchange": 0 = pass B stores into the owners' buffers, 1 = ncclSend / ncclRecv of dense lists
     int tie_slots = 32;      // option "tie_slots": flagged queries replayed per owner and round
     int64_t max_round = 262144;  // option "shard_max_round": queries per collective round over all shards
@@ -1489,7 +1490,12 @@ int mmidx_create_sharded(int kind, int D, int m, int ks, int C, int transform, c
         // orders, and this form has never run on more than one physical GPU: on a real multi-device handle everything goes through the
         // main stream / communicator until such a run has passed ("shard_pipeline" = 1 turns the overlap back on; in-process shards and
         // the one-rank communicator keep it).
-        if (n_dev > 1) g->pipeline = 0;
+        if (n_dev > 1) {
+            g->pipeline = 0;
+            // ... and the appended records are routed through the host: the device-side routing (kernels of shard r reading the peers'
+            // slices over xGMI) has only run between in-process shards of one device; "shard_route_host" = 0 opts in
+            g->route_host = 1;
+        }
     } else if (!g->peer_ok) {
         return bail(fail(MMIDX_ERR_UNSUPPORTED, "shards on repeated devices use in-process collectives, which need peer access between all of them"));
     }
