@@ -613,8 +613,25 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
     nq_total = B * args.nbatches
     big_B = args.big_batch if (world == 1 and not native and not args.force_sharded and args.big_batch > B) else 0
     nq_total = max(nq_total, big_B)
+    rccl_ranks = None
     if native:
         h, Q = build_index_native(cx, mu, args.sigma, coarse_h, pq_h, nq_total, ndev)
+        # the first thing a multi-GPU record should prove: how many shards the handle has, on which devices, and whether its
+        # collectives run on RCCL (one rank per device inside the library) -- straight from mmidx_shard_info
+        try:
+            nsh = C.c_int(0)
+            chk(L.mmidx_shard_count(h, C.byref(nsh)))
+            devs_seen, rccl_flag = [], 0
+            for r_ in range(nsh.value):
+                dv, sz, ur = C.c_int(0), C.c_int64(0), C.c_int(0)
+                chk(L.mmidx_shard_info(h, r_, C.byref(dv), C.byref(sz), C.byref(ur)))
+                devs_seen.append(dv.value)
+                rccl_flag = max(rccl_flag, ur.value)
+            rccl_ranks = {"shards": nsh.value, "devices": devs_seen, "distinct_devices": len(set(devs_seen)), "uses_rccl": bool(rccl_flag),
+                          "rccl_ranks": nsh.value if rccl_flag else 0}
+            log(f"native sharded handle: {rccl_ranks}")
+        except Exception as e:  # noqa: BLE001
+            rccl_ranks = {"error": repr(e)}
     else:
         h, Q = build_index(cx, mu, args.sigma, coarse_h, pq_h, nq_total, sharded_build=not single)
     Qb = [Q[i * B:(i + 1) * B].contiguous() for i in range(args.nbatches)]
@@ -764,14 +781,24 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
     traffic = None
     traffic_passa = None
     traffic_source = None
+    # which kernel family served pass A of the timed steps (mmidx_get_dispatch; K3q since round 6 from 1.25 queries per non-empty list)
+    passa_kernel = "?"
+    try:
+        buf = C.create_string_buffer(512)
+        chk(L.mmidx_get_dispatch(h, buf, 512))
+        passa_kernel = dict(kv.split("=", 1) for kv in buf.value.decode().split(";")).get("pass_a", "?")
+    except Exception:  # noqa: BLE001
+        pass
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
         wl = tj["workload"]
         if world == 1 and (wl["n"], wl["dim"], wl["cells"], wl["nprobe"], wl["m"], wl["k"]) == (N, D, Cc, w, m, k) and args.sigma == 0.15:
-            traffic = tj["hbm_bytes_per_query"] * B / max(1, launches / max(1, detail_steps))
-            traffic_passa = tj["k_scan_hist_fetch_kib_per_step"] * 1024.0 * 2.0 * B / wl["batch"]
-            traffic_source = "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE x 2 (gfx950 correction) of this workload, collected in a " \
-                             "separate pass -- not measured in this run"
+            pa = tj.get("pass_a", {}).get(passa_kernel)  # {fetch_kib_per_step, write_kib_per_step, kernel, source}
+            if pa is not None:
+                traffic_passa = (pa["fetch_kib_per_step"] * 2.0 + pa.get("write_kib_per_step", 0.0)) * 1024.0 * B / wl["batch"]
+                traffic = traffic_passa
+                traffic_source = ("profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE of %s on this workload, "
+                                  "separate pass (%s) -- not measured in this run" % (pa.get("kernel", passa_kernel), pa.get("source", "profiles/")))
     except Exception:
         traffic = None
     # The dominant kernel of the headline step is pass A (k_scan_hist: every query's nearest list, read and summed exactly:
@@ -792,14 +819,22 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
                     "peak_source": "mmidx_probe_lds_gather(m, 3 chains): the scan loop with only the gather and the adds left, measured in this run",
                     "wave_gathers_per_s_peak": probes[f"lds_gather_m{m}_chains3"]["wave_gathers_per_s"]}
     if sharded is None and st.passa_launches > 0:
-        roofline = {"bound": "hbm", "kernel": "k_scan_hist (pass A: the exact scan of every query's nearest list; the launch also "
-                                               "carries its empty hand-back launch)",
+        kdesc = {"K3q": "k_scan_q (K3q, pass A: every query's nearest list, four queries of a list per block -- packed u16 tables, integer "
+                        "top-6 per lane, exact fp64 sums for ~K1 + 10 candidates per query; the launch carries its pair sort and its empty hand-back launch)",
+                 "K3h": "k_scan_hist (K3h, pass A: the exact scan of every query's nearest list, a block per query; the launch also carries its empty "
+                        "hand-back launch)",
+                 "K3ma": "k_scan_mfma<.., 1/2> + k_a1_* (K3ma, pass A on the matrix cores)"}.get(passa_kernel, passa_kernel)
+        knote = {"K3q": "algorithmic bytes = m x the codes of EVERY query's nearest list (SURVEY 8d); K3q reads a list from HBM once per block of up to "
+                        "four queries, so the physical traffic (`traffic`) is below the algorithmic figure; the scan is bound by the LDS gather of the packed "
+                        "table (one random 8-byte read per code and sub-quantizer for four queries) and the VALU work of the sorted insertions, DESIGN.md 5.2",
+                 "K3h": "limited by the LDS gather (16 fp64 table entries per code, ~60 % of its LDS cycles are bank conflicts) and the VALU work around it "
+                        "(both pipes ~75 % busy, profiles/), not by HBM"}.get(passa_kernel, "")
+        roofline = {"bound": "hbm", "kernel": kdesc, "pass_a_kernel": passa_kernel,
                     "achieved": round(pa_ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(pa_ach / 8000.0, 4),
                     "frac_of_measured_copy_ceiling": round(pa_ach / 6290.0, 4), "traffic": traffic_passa, "traffic_source": traffic_source,
                     "algorithmic_bytes_per_launch": pa_bytes, "avg_launch_ms": round(pa_ms, 4), "launches": int(st_light.passa_launches),
-                    "lds": lds_roof,
-                    "note": "limited by the LDS gather (16 fp64 table entries per code, ~60 % of its LDS cycles are bank conflicts) "
-                            "and the VALU work around it (both pipes ~75 % busy, profiles/), not by HBM"}
+                    "lds": lds_roof if passa_kernel == "K3h" else None,
+                    "note": knote}
     else:
         roofline = None
     # the whole search in algorithmic bytes (every probed list counted, although the coarse bound and the lower-bound filter
@@ -870,29 +905,44 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
             tr = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get("batch_131072")
         except Exception:  # noqa: BLE001
             pass
+        k3ma = sd.passa_mfma_launches > 0
+        if k3ma:
+            roof = {"bound": "mfma", "kernel": "k_scan_mfma<.., 1> + k_scan_mfma<.., 2> (K3ma's two sweeps over every query's nearest list: fp16 MFMA "
+                                              "bound, list-major, a code decoded once per <= 64 queries)",
+                    "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+                    "flops_per_step": flops, "sweeps_ms": round(sweeps_ms, 4),
+                    "algorithmic_bytes_per_step": alg, "pass_a_algorithmic_GBps": round(alg / (pa_ms_b * 1e-3) / 1e9, 1) if pa_ms_b > 0 else None,
+                    "pass_a_frac_of_hbm_peak_algorithmic": round(alg / (pa_ms_b * 1e-3) / 8e12, 4) if pa_ms_b > 0 else None,
+                    "traffic": tr.get("sweeps_fetch_bytes_per_step") if isinstance(tr, dict) else None,
+                    "traffic_source": "profiles/hbm_traffic.json: FETCH_SIZE x 2 of the two sweep kernels, separate rocprofv3 --pmc pass" if isinstance(tr, dict) else None,
+                    "note": "16 queries per list fill ONE 16-row tile: per tile of 16 codes 4 matrix instructions stand against 4 random 16-byte "
+                            "decode gathers and ~50-65 vector instructions (slot updates / compares, addresses), which bound the sweeps "
+                            "(profiles/r05b_b131k_pmc_kernels.txt); the algorithmic byte rate exceeds the HBM rate because a list is read once for "
+                            "all the queries that probe it (physical traffic: `traffic`)"}
+        else:  # K3q (the default since round 6): four queries of a list per block
+            ach = alg / (pa_ms_b * 1e-3) / 1e9 if pa_ms_b > 0 else 0.0
+            kq = tr.get("k_scan_q") if isinstance(tr, dict) else None
+            roof = {"bound": "hbm", "kernel": "k_scan_q (K3q: every query's nearest list, four queries of a list per block; pair sort and empty hand-back launch included)",
+                    "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+                    "algorithmic_bytes_per_step": alg, "avg_launch_ms": round(pa_ms_b, 4),
+                    "traffic": (kq["fetch_kib_per_step"] * 2048.0 + kq.get("write_kib_per_step", 0.0) * 1024.0) if isinstance(kq, dict) else None,
+                    "traffic_source": "profiles/hbm_traffic.json batch_131072.k_scan_q: FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc pass" if isinstance(kq, dict) else None,
+                    "note": "algorithmic bytes = m x the codes of every query's nearest list; 16 queries per list = four blocks per list, each streaming it "
+                            "(the later ones from L2 / MALL): the physical traffic is a fraction of the algorithmic figure and the fraction of the HBM peak "
+                            "can exceed 1.  The kernel is bound by its LDS gathers and VALU work, not by HBM (DESIGN.md 5.2)"}
         res = {"value": round(big_B * args.big_steps / el, 1), "unit": "queries/s", "steps": args.big_steps, "batch": big_B,
                "ms_per_step": round(el / args.big_steps * 1e3, 4), "queries_per_nearest_list": round(big_B / Cc, 2),
+               "pass_a_kernel": "K3ma" if k3ma else "K3q",
                "passa_mfma_launches_per_step": round(sd.passa_mfma_launches / nd, 2),
                "stage_ms_per_step": {"coarse": round(sd.coarse_ms / nd, 4), "pass_a": round(sd.passa_ms / nd, 4),
                                      "pass_a_timed_region": round(pa_ms_b, 4), "scan_all": round(sd.scan_ms / nd, 4), "merge": round(sd.merge_ms / nd, 4)},
                "pass_a_stages_ms": {"sweep1": round(sd.passa_mfma_sweep1_ms / nl, 4), "select": round(sd.passa_mfma_select_ms / nl, 4),
                                     "sweep2": round(sd.passa_mfma_sweep2_ms / nl, 4),
-                                    "rows_records_verify": round(sd.passa_mfma_verify_ms / nl, 4)},
+                                    "rows_records_verify": round(sd.passa_mfma_verify_ms / nl, 4)} if k3ma else None,
                "verified_codes_per_query": round(sd.verified_codes / nd / big_B, 2),
                "queries_handed_to_exact_kernels_per_step": round(sd.mfma_redo_queries / nd, 2),
                "recall_at_1": rec1, "recall_queries": ngt,
-               "roofline": {"bound": "mfma", "kernel": "k_scan_mfma<.., 1> + k_scan_mfma<.., 2> (K3ma's two sweeps over every query's nearest list: fp16 MFMA "
-                                                       "bound, list-major, a code decoded once per <= 64 queries)",
-                            "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
-                            "flops_per_step": flops, "sweeps_ms": round(sweeps_ms, 4),
-                            "algorithmic_bytes_per_step": alg, "pass_a_algorithmic_GBps": round(alg / (pa_ms_b * 1e-3) / 1e9, 1) if pa_ms_b > 0 else None,
-                            "pass_a_frac_of_hbm_peak_algorithmic": round(alg / (pa_ms_b * 1e-3) / 8e12, 4) if pa_ms_b > 0 else None,
-                            "traffic": tr.get("sweeps_fetch_bytes_per_step") if isinstance(tr, dict) else None,
-                            "traffic_source": "profiles/hbm_traffic.json: FETCH_SIZE x 2 of the two sweep kernels, separate rocprofv3 --pmc pass" if isinstance(tr, dict) else None,
-                            "note": "16 queries per list fill ONE 16-row tile: per tile of 16 codes 4 matrix instructions stand against 4 random 16-byte "
-                                    "decode gathers and ~50-65 vector instructions (slot updates / compares, addresses), which bound the sweeps "
-                                    "(profiles/r05b_b131k_pmc_kernels.txt); the algorithmic byte rate exceeds the HBM rate because a list is read once for "
-                                    "all the queries that probe it (physical traffic: `traffic`)"},
+               "roofline": roof,
                "parity": par}
         log(f"batch {big_B}: {res['value'] / 1e6:.2f} M q/s, {res['ms_per_step']} ms per step, pass A {pa_ms_b:.3f} ms (sweeps {sweeps_ms:.3f}), parity {par}")
         return res
@@ -955,6 +1005,72 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
             big = big_batch(None)
         except Exception as e:  # noqa: BLE001
             big = {"error": repr(e)}
+    # ---------------------------------------------------------------- how even would the 8-GPU partition be?  
+    # whole inverted lists go to shard `cell mod n`: a round's work per shard = the (query, probed list) pairs whose list lives there.
+    # Counted from this index's own coarse stage -- a measurement of the partition, not of a multi-GPU run.
+    balance = None
+    if rank == 0 and single and h is not None:
+        try:
+            balance = {}
+            for nqb in sorted({B, big_B} - {0}):
+                Qx = Q[:nqb].contiguous()
+                cells_t = torch.empty(nqb, w, dtype=torch.int32, device=dev)
+                chk(L.mmidx_coarse_device(h, nqb, Qx.data_ptr(), cells_t.data_ptr(), None, stream))
+                torch.cuda.synchronize()
+                cl = cells_t.cpu().numpy()
+                row = {}
+                for ns_ in (2, 4, 8):
+                    near = np.bincount(cl[:, 0] % ns_, minlength=ns_).astype(np.float64)
+                    allp = np.bincount((cl % ns_).ravel(), minlength=ns_).astype(np.float64)
+                    row[f"shards_{ns_}"] = {"nearest_list_pairs_max_over_mean": round(float(near.max() / near.mean()), 4),
+                                            "all_probed_pairs_max_over_mean": round(float(allp.max() / allp.mean()), 4)}
+                balance[f"queries_{nqb}"] = row
+            balance["note"] = ("pairs per shard under the `cell mod n` partition of whole lists, from this index's coarse stage on the headline queries: "
+                               "pass A's load = nearest-list pairs (the coarse bound drops the far probes on this generator), pass B's = all probed pairs")
+        except Exception as e:  # noqa: BLE001
+            balance = {"error": repr(e)}
+    # ---------------------------------------------------------------- restart through the native snapshot (ABI 8: mmidx_save / mmidx_load)
+    snapshot = None
+    if rank == 0 and single and args.extras and h is not None:
+        import tempfile
+
+        snap_path = os.path.join(tempfile.gettempdir(), f"mmidx_bench_{os.getpid()}.snap")
+        h2 = C.c_void_p()
+        try:
+            t0 = time.time()
+            chk(L.mmidx_save(h, snap_path.encode()))
+            t_save = time.time() - t0
+            nbytes = os.path.getsize(snap_path)
+            chk(L.mmidx_create(nat.KIND_IVFPQ, D, m, ks, Cc, 0, None, None, local, C.byref(h2)))
+            chk(L.mmidx_set_coarse(h2, coarse_h.ctypes.data))
+            chk(L.mmidx_set_pq(h2, pq_h.ctypes.data))
+            chk(L.mmidx_set_w(h2, w))
+            t0 = time.time()
+            chk(L.mmidx_load(h2, snap_path.encode()))
+            t_load = time.time() - t0
+            # the reloaded index answers as the first one (the oracle comparison at this size is the parity gate above, and
+            # tests/test_gpu_parity.py::test_native_snapshot_reload_1m_against_the_oracle at 1 M)
+            i2 = torch.empty(B, k, dtype=torch.int32, device=dev)
+            d2 = torch.empty(B, k, dtype=f64, device=dev)
+            c2 = torch.empty(B, dtype=torch.int32, device=dev)
+            chk(L.mmidx_search_device(h2, k, B, Qb[0].data_ptr(), i2.data_ptr(), d2.data_ptr(), c2.data_ptr(), stream))
+            torch.cuda.synchronize()
+            same = bool(np.array_equal(i2.cpu().numpy(), res_iid) and np.array_equal(d2.cpu().numpy(), res_dist))
+            snapshot = {"records": int(N), "file_bytes": int(nbytes), "save_s": round(t_save, 2), "load_s": round(t_load, 2),
+                        "same_answers_as_the_saved_index": same,
+                        "note": "mmidx_save: export + one sequential write; mmidx_load: read + mmidx_add_codes in pieces of 16 M records + the CSR build "
+                                "(the path GpuIVFPQ.loadSnapshot takes instead of loadIndexInMemory's BDB cursor, IVFPQ.java:680-728)"}
+            log(f"snapshot: {snapshot}")
+        except Exception as e:  # noqa: BLE001
+            snapshot = {"error": repr(e)}
+        finally:
+            if h2:
+                L.mmidx_destroy(h2)
+            try:
+                os.remove(snap_path)
+            except OSError:
+                pass
+            torch.cuda.empty_cache()
     # ---------------------------------------------------------------- the boundary's own path: host buffers, caller threads
     host = None
     if rank == 0 and single and args.extras:
@@ -1173,7 +1289,7 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
                        "multi_gpu_path": ("native sharded handle (mmidx_create_sharded): one process, one host thread + one RCCL communicator per device "
                                           "inside libmmidx_hip.so" if native else
                                           ("none" if world == 1 and not args.force_sharded else "torch.distributed, one process per GPU (multimedia-indexing_amd/sharded.py)")),
-                       "native_fallback_reason": fallback_reason,
+                       "native_fallback_reason": fallback_reason, "rccl_ranks": rccl_ranks,
                        "sharding": "single GPU" if world == 1 and not native else
                                    (f"whole inverted lists, cell mod {world}; every shard owns batch/{world} queries; per step: RCCL all-gather of query vectors + probe "
                                     f"cells, RCCL MIN all-reduce of thresholds, partial top-(k+1) lists stored into the owner's HBM over xGMI (peer access), merge + "
@@ -1184,7 +1300,7 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
             "recall_at_1": recall1, "recall_queries": ngt,
             "roofline": roofline, "roofline_whole_search": whole, "roofline_exhaustive": exhaustive,
             "cpu_baseline": cpu_baseline, "parity": parity, "batch_131072": big, "hard": hard, "spread": spread, "other_configs": other, "cfg5": cfg5, "yfcc": yfcc,
-            "host_path": host, "measured_ceilings": probes, "sharded_dry_run": dry,
+            "host_path": host, "measured_ceilings": probes, "sharded_dry_run": dry, "shard_balance": balance, "snapshot_restart": snapshot,
             # the figures a reader should see NEXT to the headline: what a Java caller reaches through the JNI shim
             # (mmidx_search: host arrays in, host arrays out, synchronous) and what the engine does when the far probes have to be scanned
             "ties": ties,

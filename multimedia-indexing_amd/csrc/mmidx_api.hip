@@ -333,6 +333,7 @@ struct mmidx_index {
     // which kernel family served each stage of the most recent search sub-batch (mmidx_get_dispatch; host-side words, a few stores per call)
     const char *disp_coarse = "-", *disp_passa = "-", *disp_passb = "-", *disp_pre = "-";
     // K3ma (pass A on the matrix cores, mmidx_scan_mfma_a.h)
+    hipEvent_t host_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // mmidx_search (host buffers): the answers' slices on their way back
     int passa_q = -1;                  // option "passa_q": K3q (mmidx_scan_q.h) 1 always (where the shape allows), 0 never, -1 = from 1.25 queries per non-empty list of a long-list index
     double *d_pqstat = nullptr;        // K3q: [m * dsub] mean_j p_sj[t], then [m] mean_j ||p_sj||^2
     int passa_mfma = -1;               // option "passa_mfma": 1 always (where the shape allows), 0 never, -1 = from 8 queries per list of a long-list index
@@ -1166,10 +1167,8 @@ int launch_passa_q(mmidx_index *h, const ScanParams &P, const SearchPlan &pl, lo
     // the (query, probe 0) pairs by cell, groups of <= 4
     const unsigned gq = (unsigned)((nq + 255) / 256);
     hipLaunchKernelGGL(k_a1_pair_count, dim3(gq), dim3(256), 0, st, P.cells, P.w, (long long)nq, P.list_off, h->ws_pcount.p, C);
-    hipLaunchKernelGGL(k_pair_scan, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, C, h->ws_pstart.p, h->ws_pcursor.p, (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_q_scan_groups, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, C, G, h->ws_pstart.p, h->ws_pcursor.p, h->ws_gdesc.p, h->ws_gfb.p);
     hipLaunchKernelGGL(k_a1_pair_scatter, dim3(gq), dim3(256), 0, st, P.cells, P.w, (long long)nq, P.list_off, h->ws_pstart.p, h->ws_pcursor.p, h->ws_order.p);
-    hipLaunchKernelGGL(k_group_build, dim3(1), dim3(1024), 0, st, h->ws_pcount.p, h->ws_pstart.p, C, G, h->ws_gdesc.p, h->ws_gfb.p, (u32 *)(h->ws_gfb.p + 1),
-                       (unsigned long long *)nullptr, (int32_t *)nullptr);
     HIPCK(hipGetLastError());
     QParams QP{};
     QP.S = P;
@@ -1187,7 +1186,7 @@ int launch_passa_q(mmidx_index *h, const ScanParams &P, const SearchPlan &pl, lo
     QP.timing = nullptr;
     const QLds L(h->m, h->D);
     // grid: the host's upper bound of the group count (the blocks beyond the device-side count leave at once)
-    const unsigned grid = (unsigned)std::min<size_t>(max_groups, (size_t)nq);
+    const unsigned grid = (unsigned)((std::min<size_t>(max_groups, (size_t)nq) + 7 + 7) & ~(size_t)7);  // (eight ranges of ceil(groups / 8): k_scan_q's XCD map)
     int rc;
     switch (h->dsub) {
         case 4: rc = launch_q_t<16, 4>(QP, grid, L.total, st); break;
@@ -2953,6 +2952,8 @@ int mmidx_destroy(mmidx_index *h) {
     if (h->pin_grpx) (void)hipHostFree(h->pin_grpx);
     h->ws_T0.release();
     h->ws_inv.release();
+    for (int e = 0; e < 4; e++)
+        if (h->host_ev[e]) (void)hipEventDestroy(h->host_ev[e]);
     if (h->d_pqstat) (void)hipFree(h->d_pqstat);
     if (h->d_pq32T) (void)hipFree(h->d_pq32T);
     if (h->d_pn32) (void)hipFree(h->d_pn32);
@@ -3428,30 +3429,56 @@ static int search_host_batch(mmidx_index *h, SearchReq *const *batch, size_t nb)
         return MMIDX_OK;
     }
     unsigned char *hin = h->pin_stage, *hout = h->pin_stage + in_bytes;
-    {
-        size_t off = 0;
-        for (size_t i = 0; i < nb; i++) {
-            const size_t b = (size_t)batch[i]->nq * h->D * 8;
-            memcpy(hin + off, batch[i]->Q, b);
-            off += b;
-        }
-    }
     HIPCK(h->ws_Q.reserve((size_t)tot * h->D));
     HIPCK(h->ws_out.reserve(od + oi + oc));
     double *d_dist = (double *)h->ws_out.p;
     int32_t *d_iid = (int32_t *)(h->ws_out.p + od), *d_cnt = (int32_t *)(h->ws_out.p + od + oi);
-    HIPCK(hipMemcpyAsync(h->ws_Q.p, hin, in_bytes, hipMemcpyHostToDevice, h->stream));
+    // stage in: request by request (pieces of <= 4 MiB); every piece's DMA runs while the next piece is copied into the pinned buffer
+    {
+        const size_t piece = (size_t)4 << 20;
+        size_t off = 0;
+        for (size_t i = 0; i < nb; i++) {
+            const size_t b = (size_t)batch[i]->nq * h->D * 8;
+            for (size_t p0 = 0; p0 < b; p0 += piece) {
+                const size_t pb = std::min(piece, b - p0);
+                memcpy(hin + off, (const unsigned char *)batch[i]->Q + p0, pb);
+                HIPCK(hipMemcpyAsync((unsigned char *)h->ws_Q.p + off, hin + off, pb, hipMemcpyHostToDevice, h->stream));
+                off += pb;
+            }
+        }
+    }
     rc = search_common(h, k, tot, h->ws_Q.p, nullptr, 0, d_iid, d_dist, d_cnt, nullptr, nullptr, h->stream);
     if (rc) return rc;
-    HIPCK(hipMemcpyAsync(hout, h->ws_out.p, od + oi + oc, hipMemcpyDeviceToHost, h->stream));
-    HIPCK(hipStreamSynchronize(h->stream));
-    int64_t q0 = 0;
-    for (size_t i = 0; i < nb; i++) {
-        const int64_t nq = batch[i]->nq;
-        memcpy(batch[i]->dist, hout + (size_t)q0 * k * 8, (size_t)nq * k * 8);
-        memcpy(batch[i]->iid, hout + od + (size_t)q0 * k * 4, (size_t)nq * k * 4);
-        memcpy(batch[i]->cnt, hout + od + oi + (size_t)q0 * 4, (size_t)nq * 4);
-        q0 += nq;
+    // stage out: the answers come back in up to four slices of whole requests; a slice is copied to the callers' arrays while the
+    // next one is still on the bus (events between the slices; the handle keeps them)
+    constexpr int NSL = 4;
+    if (!h->host_ev[0]) {
+        for (int e = 0; e < NSL; e++) HIPCK(hipEventCreateWithFlags(&h->host_ev[e], hipEventDisableTiming));
+    }
+    std::vector<int64_t> req_q0(nb + 1, 0);  // first query of every request in the combined batch
+    for (size_t i = 0; i < nb; i++) req_q0[i + 1] = req_q0[i] + batch[i]->nq;
+    const int64_t per = std::max<int64_t>(256, (tot + NSL - 1) / NSL);
+    for (int e = 0; e < NSL; e++) {
+        const int64_t a = std::min<int64_t>(tot, (int64_t)e * per), b = e == NSL - 1 ? tot : std::min<int64_t>(tot, (int64_t)(e + 1) * per);
+        if (b > a) {
+            HIPCK(hipMemcpyAsync(hout + (size_t)a * k * 8, (unsigned char *)d_dist + (size_t)a * k * 8, (size_t)(b - a) * k * 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCK(hipMemcpyAsync(hout + od + (size_t)a * k * 4, (unsigned char *)d_iid + (size_t)a * k * 4, (size_t)(b - a) * k * 4, hipMemcpyDeviceToHost, h->stream));
+            HIPCK(hipMemcpyAsync(hout + od + oi + (size_t)a * 4, (unsigned char *)d_cnt + (size_t)a * 4, (size_t)(b - a) * 4, hipMemcpyDeviceToHost, h->stream));
+        }
+        HIPCK(hipEventRecord(h->host_ev[e], h->stream));
+    }
+    size_t ri = 0;
+    for (int e = 0; e < NSL; e++) {
+        const int64_t a = std::min<int64_t>(tot, (int64_t)e * per), b = e == NSL - 1 ? tot : std::min<int64_t>(tot, (int64_t)(e + 1) * per);
+        HIPCK(hipEventSynchronize(h->host_ev[e]));
+        for (int64_t g0 = a; g0 < b;) {  // the part of [a, b) that belongs to request ri
+            while (req_q0[ri + 1] <= g0) ri++;
+            const int64_t g1 = std::min<int64_t>(b, req_q0[ri + 1]), lo = g0 - req_q0[ri], n = g1 - g0;
+            memcpy(batch[ri]->dist + (size_t)lo * k, hout + (size_t)g0 * k * 8, (size_t)n * k * 8);
+            memcpy(batch[ri]->iid + (size_t)lo * k, hout + od + (size_t)g0 * k * 4, (size_t)n * k * 4);
+            memcpy(batch[ri]->cnt + lo, hout + od + oi + (size_t)g0 * 4, (size_t)n * 4);
+            g0 = g1;
+        }
     }
     return MMIDX_OK;
 }

@@ -8,7 +8,7 @@
 //
 //   tab[s][j] = { q_0, q_1, q_2, q_3 },   q_i = min(4095, floor(LUT_i[s][j] * 4000 / qr_i))        (4 x u16 = one 8-byte word)
 //
-// LUT_i = query i's exact fp64 table (IVFPQ.java:525-538: the same subtractions, squares and additions, t ascending from 0.0), qr_i a
+// LUT_i = query i's fp64 table (IVFPQ.java:525-538, t ascending from 0.0; with fused multiply-adds: see the table build), qr_i a
 // scale of the order of the query's typical distance to a code (closed form from the residual and the codebook's per-row mean vector
 // and mean squared norm: the mean distance to a code with independent uniform entries).  ONE ds_read_b64 per (code, sub-quantizer)
 // at the address K3h reads its fp64 entry from -- row + 8 x code byte -- serves four queries; the four partial sums ride in two
@@ -101,6 +101,47 @@ __device__ __forceinline__ double wave_sum_f64(double x) {
     return x;
 }
 
+// K3q's pair sort, middle step: the exclusive prefix of the per-cell pair counts (start[], cursor[] = 0: k_pair_scan's work) AND the
+// groups of <= G pairs per cell (gdesc[], their number: k_group_build's work) in ONE single-block launch -- each of the two walks the
+// same C counters and costs ~12 us of latency on its own.
+__global__ __launch_bounds__(1024) void k_q_scan_groups(const int32_t *__restrict__ cnt, int C, int G, int32_t *__restrict__ start, int32_t *__restrict__ cursor,
+                                                        int4 *__restrict__ gdesc, int32_t *__restrict__ n_groups) {
+    __shared__ u32 s_wa[16], s_wb[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per = (C + 1023) / 1024;
+    const int lo = tid * per, hi = (lo + per < C) ? lo + per : C;
+    u32 sa = 0, sb = 0;
+    for (int c = lo; c < hi; c++) {
+        const u32 n = (u32)cnt[c];
+        sa += n;
+        sb += (n + (u32)G - 1u) / (u32)G;
+    }
+    const u32 ia = wave_incl_scan_u32(sa), ib = wave_incl_scan_u32(sb);
+    if (lane == 63) {
+        s_wa[wv] = ia;
+        s_wb[wv] = ib;
+    }
+    __syncthreads();
+    u32 ba = 0, bb = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        ba += (i < wv) ? s_wa[i] : 0u;
+        bb += (i < wv) ? s_wb[i] : 0u;
+    }
+    u32 ra = ba + ia - sa, rb = bb + ib - sb;  // exclusive prefixes of this thread's range
+    for (int c = lo; c < hi; c++) {
+        const int n = cnt[c];
+        start[c] = (int32_t)ra;
+        cursor[c] = 0;
+        for (int o = 0; o < n; o += G) gdesc[rb++] = make_int4(c, (int)ra + o, (n - o < G) ? n - o : G, 0);
+        ra += (u32)n;
+    }
+    if (tid == 1023) {
+        start[C] = (int32_t)(ba + ia);
+        *n_groups = (int32_t)(bb + ib);
+    }
+}
+
 #ifdef Q_TIMING
 #define Q_T(n) do { if (tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(QP.timing + (n), t_ - qt_last); qt_last = t_; } } while (0)
 #else
@@ -128,16 +169,12 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
     u32 *s_cut = (u32 *)(smem + L.misc) + 24;      // [24..27]: a* + 17 per query
     u32 *cent = (u32 *)(smem + L.cent);            // [G][HKQ]
 
-    if ((int)blockIdx.x >= *QP.n_groups) return;
-#ifdef Q_STAGGER
-    // the first generation of blocks starts together and every block takes about as long: without an offset the three blocks of a CU
-    // build their tables together, scan together (the LDS pipe's phase) and sum their candidates together (a latency phase) for the whole launch
-    if (blockIdx.x < 768u && (Q_STAGSEL) != 0u) {
-        const unsigned long long t0 = __builtin_readcyclecounter(), wait = (unsigned long long)(Q_STAGSEL) * (unsigned long long)(Q_STAGGER);
-        while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-    }
-#endif
-    const int4 gd = QP.gdesc[blockIdx.x];
+    // block -> group, in order.  (Dealing the groups to the XCDs in eight contiguous ranges -- so that the two to four blocks of one list
+    // share an L2 -- was measured: 0.765 against 0.750 ms per 7525 groups, 3.52 against 3.47 ms per 35796; the kernel is not bound by
+    // the code stream, and neighbouring blocks in one phase of the kernel on one XCD cost more than the L2 hits bring.)
+    const int grp = (int)blockIdx.x;
+    if (grp >= *QP.n_groups) return;
+    const int4 gd = QP.gdesc[grp];
     const int cell = gd.x, ng = gd.z;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 #ifdef Q_TIMING
@@ -218,11 +255,14 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
 #pragma unroll
             for (int i = 0; i < G; i++) {
                 const double *tv = s_r + (size_t)i * D + s * DSUB;
+                // (fused multiply-adds: these entries only feed the integer table, where one more rounding in 2^53 per step is nothing
+                //  next to the two units of margin in "a(c2) >= a(c1) + 18"; the candidates' exact sums below use the reference's
+                //  separate multiplications and additions)
                 double acc = 0.0;
 #pragma unroll
                 for (int t = 0; t < DSUB; t++) {
                     const double df = tv[t] - p[t];
-                    acc += df * df;
+                    acc = __builtin_fma(df, df, acc);
                 }
                 const double x = acc * inv[i];  // >= 0
                 qv[i] = (x >= 4095.0) ? 4095u : (u32)x;

@@ -18,7 +18,7 @@ MAX_LINE = 8000
 CORE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
              "dtype", "data", "config", "recall_at_1", "recall_queries", "roofline", "cpu_baseline", "parity", "ties",
              "host_buffers_qps", "hard_qps", "spread_qps", "batch_131072_qps", "sharded_dry_run_ms_per_shard")
-ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms",
+ROOFLINE_KEYS = ("bound", "kernel", "pass_a_kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms",
                  "launches", "traffic_source", "lds_conflict_ratio")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "cpu_model")
 CONFIG_KEYS = ("workload", "n", "dim", "cells", "nprobe", "m", "ks", "k", "batch", "batch_per_gpu", "mixture_sigma", "multi_gpu_path",
@@ -39,7 +39,7 @@ def split(out):
     extra = {k: v for k, v in out.items() if k not in CORE_KEYS}
     if isinstance(out.get("roofline"), dict):
         core["roofline"] = _pick(out["roofline"], ROOFLINE_KEYS)
-        core["roofline"]["kernel"] = _short(core["roofline"].get("kernel"), 120)
+        core["roofline"]["kernel"] = _short(core["roofline"].get("kernel"), 200)
         core["roofline"]["traffic_source"] = _short(core["roofline"].get("traffic_source"), 160)
         extra["roofline_full"] = out["roofline"]
     if isinstance(out.get("cpu_baseline"), dict):

@@ -230,7 +230,7 @@ int main(int argc, char **argv) {
         CHECK(hipFuncSetAttribute((const void *)k_scan_q<16, HD / 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total));
         hipFuncAttributes fa{};
         CHECK(hipFuncGetAttributes(&fa, (const void *)k_scan_q<16, HD / 16>));
-        timeit([&]() { hipLaunchKernelGGL((k_scan_q<16, HD / 16>), dim3(ngr), dim3(256), L.total, nullptr, QP); }, rf);
+        timeit([&]() { hipLaunchKernelGGL((k_scan_q<16, HD / 16>), dim3((ngr + 14) & ~7), dim3(256), L.total, nullptr, QP); }, rf);
         int occ = 0;
         CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_scan_q<16, HD / 16>, 256, L.total));
         printf("occupancy: %d blocks per CU\n", occ);
