@@ -15,8 +15,14 @@ def test_hbm_traffic_json_has_what_the_benches_read():
     assert (wl["n"], wl["dim"], wl["cells"], wl["nprobe"], wl["m"], wl["k"], wl["batch"]) == (100_000_000, 128, 8192, 32, 16, 100, 16384)
     for key in ("hbm_bytes_per_query", "k_scan_hist_fetch_kib_per_step", "hard_pass_b_fetch_bytes_per_launch", "spread_pass_b_fetch_bytes_per_launch"):
         assert tj[key] > 0, key
-    # pass A reads every query's nearest list about once: 0.9 .. 1.5 x the algorithmic 12.2 k codes x 16 bytes per query
-    assert 0.9 < tj["hbm_bytes_per_query"] / (100_000_000 / 8192 * 16) < 1.5
+    # pass A by kernel family (round 6): K3h reads every query's nearest list about once (0.9 .. 1.5 x the algorithmic 12.2 k codes x
+    # 16 bytes per query); K3q reads a list once per block of up to four queries (two queries per list at this batch: 0.4 .. 0.9 x)
+    alg = 100_000_000 / 8192 * 16
+    pa = tj["pass_a"]
+    assert 0.9 < pa["K3h"]["fetch_kib_per_step"] * 2048 / wl["batch"] / alg < 1.5
+    assert 0.4 < (pa["K3q"]["fetch_kib_per_step"] * 2048 + pa["K3q"]["write_kib_per_step"] * 1024) / wl["batch"] / alg < 0.9
+    assert abs(tj["hbm_bytes_per_query"] * wl["batch"] - (pa["K3q"]["fetch_kib_per_step"] * 2048 + pa["K3q"]["write_kib_per_step"] * 1024)) < wl["batch"]
+    assert tj["batch_131072"]["k_scan_q"]["fetch_kib_per_step"] > 0
     b = tj["batch_131072"]
     assert b["workload"]["batch"] == 131072 and b["sweeps_fetch_bytes_per_step"] > 2 * 1_600_000_000  # two sweeps over 1.6 GB of codes
     v = tj["vlad"]
