@@ -799,9 +799,11 @@ int make_plan(mmidx_index *h, int k, int64_t nq, SearchPlan &pl, bool need_coars
         int64_t cap_bytes = (coarse_certified(h) ? 16ll : 2ll) << 30;
         // (never more than a quarter of what the device has free right now: a smaller GPU, or one shared with a framework's
         //  allocator, takes sub-batches instead of hipErrorOutOfMemory -- ADVICE r5)
-        size_t free_b = 0, total_b = 0;
-        if (cap_bytes > (2ll << 30) && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            cap_bytes = std::max<int64_t>(2ll << 30, std::min<int64_t>(cap_bytes, (int64_t)(free_b / 4)));
+        // (asked only when the scratch of this call would pass 2 GiB: hipMemGetInfo is a driver round trip)
+        if (cap_bytes > (2ll << 30) && (int64_t)nq * h->C * 8 > (2ll << 30)) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) cap_bytes = std::max<int64_t>(2ll << 30, std::min<int64_t>(cap_bytes, (int64_t)(free_b / 4)));
+        }
         qb = std::min<int64_t>(qb, std::max<int64_t>(1, cap_bytes / ((int64_t)h->C * 8)));
     }
     if (pl.glut) {  // one table per block in global scratch: at most 2 GiB of it

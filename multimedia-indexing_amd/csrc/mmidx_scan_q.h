@@ -80,12 +80,13 @@ struct QLds {
     size_t tab, res, misc, cent, sel, total;
     __host__ __device__ QLds(int M, int D) {
         size_t o = 0;
-        tab = o; o += (size_t)M * 2048;                               // [M][256] x {4 x u16}; LDS address 0 (byte_x8 addressing).  After the scan: the kept keys
-                                                                      // [G][SLOTS * 256] (24 KiB, needs M >= 12), then the candidates' exact sums [G * HKQ] u64
+        tab = o; o += (size_t)M * 2048;                               // [M][256] x {4 x u16}; LDS address 0 (byte_x8 addressing).  After the scan: sel (below),
+                                                                      // then the candidates' exact sums [G * HKQ] u64
         res = o; o += (size_t)MMIDX_Q_G * D * 8;                      // the queries' residuals, transformed (fp64); first: raw residuals (rotation)
         misc = o; o += 64 * 8;                                        // see the kernel
         cent = o; o += (size_t)MMIDX_Q_G * MMIDX_Q_HKQ * 4;           // the candidates: (evidence << 31 | position), later (pool slot << 24 | position)
-        sel = o; o += (size_t)MMIDX_Q_G * MMIDX_Q_SLOTS * 256 * 2;    // the kept keys' a values (u16): the selection's input
+        sel = tab;                                                    // the kept keys' a values (u16) [G][SLOTS * 256]: the selection's input, OVER the table
+                                                                      // (12 KiB of its 32; a block with a lane to rescue builds the table again)
         total = (o + 15) & ~(size_t)15;
     }
 };
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
     __syncthreads();
     Q_T(0);
     // ---- the table: thread j <-> entry j of every row; the exact entries of the four queries, quantised and packed -----------------
-    {
+    auto build_table = [&]() {
         double inv[G];
 #pragma unroll
         for (int i = 0; i < G; i++) inv[i] = s_inv[i];
@@ -269,7 +270,8 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
             }
             *(uint2 *)(smem + (size_t)s * 2048 + (size_t)tid * 8) = make_uint2(qv[0] | (qv[1] << 16), qv[2] | (qv[3] << 16));
         }
-    }
+    };
+    build_table();
     __syncthreads();
 #if Q_STOP == 1
     return;
@@ -345,9 +347,12 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
     return;
 #endif
     // ---- selection: wave i takes query i -- a* = the K1-th smallest a among the 256 x NS kept keys (their a values, u16, side by side
-    //      in LDS), candidates = every code with a <= a* + 17.  The table stays intact: a lane that may have dropped a candidate
-    //      (its sixth key is within the range) walks its own codes again. -----------------------------------------------------------
+    //      in LDS, over the table), candidates = every code with a <= a* + 17.  A lane that may have dropped a candidate (its sixth key
+    //      is within the range, ~1e-5 of the lanes) walks its own codes again -- against the table, which its block builds once more. ----
+    static_assert(M * 2048 >= G * MMIDX_Q_SLOTS * 256 * 2, "the selection's input re-uses the table");
     unsigned short *sa = (unsigned short *)(smem + L.sel);  // [G][NS * 256]
+    u32 *s_resc = (u32 *)(smem + L.misc) + 28;              // some lane of the block has codes to walk again
+    __syncthreads();  // (every wave is past its last lookup)
 #pragma unroll
     for (int i = 0; i < G; i++)
 #pragma unroll
@@ -389,31 +394,41 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
         }
     }
     __syncthreads();
-    // every lane: its kept keys within the range -> the query's candidate list; a lane whose sixth key is within the range rescues
-    {
+    // every lane: its kept keys within the range -> the query's candidate list
+    auto push = [&](const int i, const u32 a, const u32 pos) {
+        const u32 at = atomicAdd(s_kept + i, 1u);
+        if (at < (u32)HKQ) cent[i * HKQ + at] = pos | (((int)a <= s_astar[i]) ? 0x80000000u : 0u);
+    };
+    u32 rmask = 0;  // the queries this lane has to walk its codes again for
 #pragma unroll
-        for (int i = 0; i < G; i++) {
-            if (i >= ng || s_flag[i] != 0u) continue;  // block-uniform
-            const u32 cut = s_cut[i];
-            const int astar = s_astar[i];
-            auto push = [&](const u32 a, const u32 pos) {
-                const u32 at = atomicAdd(s_kept + i, 1u);
-                if (at < (u32)HKQ) cent[i * HKQ + at] = pos | (((int)a <= astar) ? 0x80000000u : 0u);
-            };
+    for (int i = 0; i < G; i++) {
+        if (i >= ng || s_flag[i] != 0u) continue;  // block-uniform
+        const u32 cut = s_cut[i];
 #pragma unroll
-            for (int k = 0; k < NS; k++) {
-                const u32 key = slot[i][k];
-                if (key != 0xFFFFFFFFu && (key >> 16) <= cut) push(key >> 16, ((key & 0xFFFFu) << 8) | (u32)tid);
-            }
-            const u32 last = slot[i][NS - 1];
-            if (last != 0xFFFFFFFFu && (last >> 16) <= cut) {  // (~1e-5 of the lanes) this lane may have dropped candidates: its codes once more
+        for (int k = 0; k < NS; k++) {
+            const u32 key = slot[i][k];
+            if (key != 0xFFFFFFFFu && (key >> 16) <= cut) push(i, key >> 16, ((key & 0xFFFFu) << 8) | (u32)tid);
+        }
+        const u32 last = slot[i][NS - 1];
+        if (last != 0xFFFFFFFFu && (last >> 16) <= cut) rmask |= 1u << i;
+    }
+    if (rmask) *s_resc = 1u;
+    __syncthreads();
+    if (*s_resc) {  // block-uniform, about one block in a hundred
+        build_table();  // (the same instructions on the same inputs: the same table)
+        __syncthreads();
+        if (rmask) {
+#pragma unroll
+            for (int i = 0; i < G; i++) {
+                if (!((rmask >> i) & 1u)) continue;
+                const u32 cut = s_cut[i], last = slot[i][NS - 1];
                 for (u32 step = 0; step * NT + (u32)tid < n_seg; step++) {
                     CodeVec<M, unsigned char> cv;
                     cv.load(codes0 + (step * NT + (u32)tid) * (u32)M);
                     u32 lo, hi;
                     lookup(cv, lo, hi);
                     const u32 a = (i & 1) ? ((i < 2 ? lo : hi) >> 16) : ((i < 2 ? lo : hi) & 0xFFFFu);
-                    if (a <= cut && ((a << 16) | step) > last) push(a, (step << 8) | (u32)tid);  // (keys up to `last` are in the slots)
+                    if (a <= cut && ((a << 16) | step) > last) push(i, a, (step << 8) | (u32)tid);  // (keys up to `last` are in the slots)
                 }
             }
         }
