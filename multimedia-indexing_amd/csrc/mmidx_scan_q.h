@@ -54,7 +54,7 @@
 #define Q_STAGSEL (blockIdx.x >> 8)
 #endif
 #ifndef Q_WPS
-#define Q_WPS 3
+#define Q_WPS 4
 #endif
 #ifndef Q_TU
 #define Q_TU 4  // table rows in flight per thread
@@ -74,6 +74,7 @@ struct QParams {
 
 typedef unsigned int q_u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const q_u32x2 lds_cuint2;
+typedef __attribute__((address_space(3))) const unsigned int lds_cu32;
 
 // LDS layout, shared by host (size) and device (offsets)
 struct QLds {
@@ -94,6 +95,19 @@ struct QLds {
 __device__ __forceinline__ u32 q_med3(u32 a, u32 b, u32 c) {
     u32 r;
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// (byte b of w) << SH in one VALU instruction (SDWA byte select; see byte_x8 in mmidx_kernels.h)
+template <int SH>
+__device__ __forceinline__ u32 q_byte_shl(u32 w, int b) {
+    u32 r;
+    const u32 sh = (u32)SH;
+    switch (b & 3) {
+        case 0: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "s"(sh), "v"(w)); break;
+        case 1: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "s"(sh), "v"(w)); break;
+        case 2: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "s"(sh), "v"(w)); break;
+        default: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "s"(sh), "v"(w)); break;
+    }
     return r;
 }
 __device__ __forceinline__ double wave_sum_f64(double x) {
@@ -148,9 +162,10 @@ __global__ __launch_bounds__(1024) void k_q_scan_groups(const int32_t *__restric
 #else
 #define Q_T(n) do {} while (0)
 #endif
-template <int M, int DSUB>
-__global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// One group.  GA = the queries the block is compiled for: 4, or 2 for a group of one or two pairs (six in ten at the headline batch:
+// two queries per list on average) -- half the table (4-byte entries, ds_read_b32), half the insertions, half the table's arithmetic.
+template <int M, int DSUB, int GA>
+__device__ __forceinline__ void q_scan_group(const QParams &QP, const int4 gd, unsigned char *smem) {
     constexpr int G = MMIDX_Q_G, NT = 256, WV = 4, U = MMIDX_Q_U, HKQ = MMIDX_Q_HKQ, NS = MMIDX_Q_SLOTS;
     static_assert(G == WV, "wave i takes query i in the selection");
     static_assert(M * 2048 >= G * MMIDX_Q_HKQ * 8, "the candidates' exact sums re-use the table");
@@ -170,12 +185,6 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
     u32 *s_cut = (u32 *)(smem + L.misc) + 24;      // [24..27]: a* + 17 per query
     u32 *cent = (u32 *)(smem + L.cent);            // [G][HKQ]
 
-    // block -> group, in order.  (Dealing the groups to the XCDs in eight contiguous ranges -- so that the two to four blocks of one list
-    // share an L2 -- was measured: 0.765 against 0.750 ms per 7525 groups, 3.52 against 3.47 ms per 35796; the kernel is not bound by
-    // the code stream, and neighbouring blocks in one phase of the kernel on one XCD cost more than the L2 hits bring.)
-    const int grp = (int)blockIdx.x;
-    if (grp >= *QP.n_groups) return;
-    const int4 gd = QP.gdesc[grp];
     const int cell = gd.x, ng = gd.z;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 #ifdef Q_TIMING
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
         codes0 = (const unsigned char *)P.codes + (size_t)(((u64)hi32 << 32) | lo32) * M;
     }
     auto fetch = [&](CodeVec<M, unsigned char> &dst, const u32 i) {
-        const u32 ic = i < n_seg ? i : n_seg - 1u;
+        const u32 ic = min(i, n_seg - 1u);
         dst.load(codes0 + ic * (u32)M);  // (32-bit offset from a uniform base; past the end: the list's last code, never used)
     };
     // the first round's codes leave now: they are back before the table is built
@@ -202,10 +211,19 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
 #pragma unroll
     for (int u = 0; u < U; u++) fetch(X0[u], (u32)u * NT + (u32)tid);
 
+    // the table's input: Q_TU rows of the transposed codebook at a time (thread j <-> entry j of every row)
+    static_assert(M % Q_TU == 0, "the table is built Q_TU rows at a time");
+    auto load_rows = [&](double (&p)[Q_TU][DSUB], const int s0) {
+#pragma unroll
+        for (int j = 0; j < Q_TU; j++)
+#pragma unroll
+            for (int t = 0; t < DSUB; t++) p[j][t] = P.pqT[((size_t)(s0 + j) * DSUB + t) * 256 + tid];
+    };
+
     for (int i = tid; i < 128; i += NT) ((u32 *)(smem + L.misc))[i] = 0;
     __syncthreads();
     // ---- residuals centroid - q (IVFPQ.java:645), permuted / rotated as the index says; wave i <-> query i ------------------
-    {
+    if (wv < GA) {
         const int i = wv;
         const double *qrow = P.Q + (size_t)qid[i] * D, *crow = P.coarse + (size_t)cell * D;
         if (P.transform == 1) {  // RandomRotation.rotate: out = v (1 x D) . R (D x D), sequential over the row index (RandomRotation.java:44-49)
@@ -243,18 +261,16 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
     __syncthreads();
     Q_T(0);
     // ---- the table: thread j <-> entry j of every row; the exact entries of the four queries, quantised and packed -----------------
-    auto build_table = [&]() {
-        double inv[G];
+    auto calc_rows = [&](const double (&p)[Q_TU][DSUB], const int s0) {
+        double inv[GA];
 #pragma unroll
-        for (int i = 0; i < G; i++) inv[i] = s_inv[i];
-#pragma unroll Q_TU
-        for (int s = 0; s < M; s++) {
-            double p[DSUB];
+        for (int i = 0; i < GA; i++) inv[i] = s_inv[i];
 #pragma unroll
-            for (int t = 0; t < DSUB; t++) p[t] = P.pqT[((size_t)s * DSUB + t) * 256 + tid];
-            u32 qv[G];
+        for (int j = 0; j < Q_TU; j++) {
+            const int s = s0 + j;
+            u32 qv[GA];
 #pragma unroll
-            for (int i = 0; i < G; i++) {
+            for (int i = 0; i < GA; i++) {
                 const double *tv = s_r + (size_t)i * D + s * DSUB;
                 // (fused multiply-adds: these entries only feed the integer table, where one more rounding in 2^53 per step is nothing
                 //  next to the two units of margin in "a(c2) >= a(c1) + 18"; the candidates' exact sums below use the reference's
@@ -262,16 +278,27 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
                 double acc = 0.0;
 #pragma unroll
                 for (int t = 0; t < DSUB; t++) {
-                    const double df = tv[t] - p[t];
+                    const double df = tv[t] - p[j][t];
                     acc = __builtin_fma(df, df, acc);
                 }
                 const double x = acc * inv[i];  // >= 0
                 qv[i] = (x >= 4095.0) ? 4095u : (u32)x;
             }
-            *(uint2 *)(smem + (size_t)s * 2048 + (size_t)tid * 8) = make_uint2(qv[0] | (qv[1] << 16), qv[2] | (qv[3] << 16));
+            if constexpr (GA == 4) *(uint2 *)(smem + (size_t)s * 2048 + (size_t)tid * 8) = make_uint2(qv[0] | (qv[1] << 16), qv[2] | (qv[3] << 16));
+            else *(u32 *)(smem + (size_t)s * 1024 + (size_t)tid * 4) = qv[0] | (qv[1] << 16);
         }
     };
-    build_table();
+    auto build_table = [&](const int from) {  // rows from ... M - 1
+#pragma unroll 1
+        for (int s0 = from; s0 < M; s0 += Q_TU) {
+            double pB[Q_TU][DSUB];
+            load_rows(pB, s0);
+            calc_rows(pB, s0);
+        }
+    };
+    // (the first rows requested before the residuals -- one round trip less on paper -- measured 0.648 against 0.635 ms: 64 more live
+    //  registers through the residual phase)
+    build_table(0);
     __syncthreads();
 #if Q_STOP == 1
     return;
@@ -279,9 +306,9 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
 
     Q_T(1);
     // ---- scan: lookups and sorted insertions, nothing else --------------------------------------------------------------------
-    u32 slot[G][NS];
+    u32 slot[GA][NS];
 #pragma unroll
-    for (int i = 0; i < G; i++)
+    for (int i = 0; i < GA; i++)
 #pragma unroll
         for (int k = 0; k < NS; k++) slot[i][k] = 0xFFFFFFFFu;
     auto lookup = [&](const CodeVec<M, unsigned char> &cv, u32 &lo, u32 &hi) {
@@ -289,9 +316,13 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
         hi = 0;
 #pragma unroll
         for (int s = 0; s < M; s++) {
-            const q_u32x2 e = *(lds_cuint2 *)(size_t)(byte_x8(cv.wd[s >> 2], s & 3) + (u32)s * 2048u);
-            lo += e.x;
-            hi += e.y;
+            if constexpr (GA == 4) {
+                const q_u32x2 e = *(lds_cuint2 *)(size_t)(q_byte_shl<3>(cv.wd[s >> 2], s & 3) + (u32)s * 2048u);
+                lo += e.x;
+                hi += e.y;
+            } else {
+                lo += *(lds_cu32 *)(size_t)(q_byte_shl<2>(cv.wd[s >> 2], s & 3) + (u32)s * 1024u);
+            }
         }
     };
     auto insert = [&](u32 (&sl)[NS], const u32 k) {  // sl ascending; k in, the largest out
@@ -306,27 +337,44 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
     };
     auto keep = [&](const u32 lo, const u32 hi, const u32 step, const bool inb) {
         // keys (a << 16 | step); a code past the end of the list must not enter (its key: all ones)
-        const u32 k0 = inb ? ((lo << 16) | step) : 0xFFFFFFFFu, k1 = inb ? ((lo & 0xFFFF0000u) | step) : 0xFFFFFFFFu;
-        const u32 k2 = inb ? ((hi << 16) | step) : 0xFFFFFFFFu, k3 = inb ? ((hi & 0xFFFF0000u) | step) : 0xFFFFFFFFu;
+        // (step is wave-uniform and < 2^16: v_bfi_b32 takes it from its SGPR -- (mask & a) | (~mask & step))
+        auto bfi = [](const u32 a, const u32 st) {
+            u32 r;
+            const u32 mask = 0xFFFF0000u;
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "s"(st));
+            return r;
+        };
+        const u32 k0 = inb ? ((lo << 16) | step) : 0xFFFFFFFFu, k1 = inb ? bfi(lo, step) : 0xFFFFFFFFu;
         insert(slot[0], k0);
         insert(slot[1], k1);
-        insert(slot[2], k2);
-        insert(slot[3], k3);
+        if constexpr (GA == 4) {
+            const u32 k2 = inb ? ((hi << 16) | step) : 0xFFFFFFFFu, k3 = inb ? bfi(hi, step) : 0xFFFFFFFFu;
+            insert(slot[2], k2);
+            insert(slot[3], k3);
+        }
     };
-    // full rounds: every position is inside the list
+    // full rounds: every position is inside the list.  Two rounds per trip, the two code buffers changing roles (no register copies)
     u32 seg = 0;
-#pragma unroll 1
-    for (; seg + (u32)U * NT <= n_seg; seg += (u32)U * NT) {
+    auto round = [&](CodeVec<M, unsigned char> (&cur)[U], CodeVec<M, unsigned char> (&nxt)[U]) {
 #pragma unroll
-        for (int u = 0; u < U; u++) fetch(X1[u], seg + (u32)(U + u) * NT + (u32)tid);
+        for (int u = 0; u < U; u++) fetch(nxt[u], seg + (u32)(U + u) * NT + (u32)tid);
 #pragma unroll
         for (int h4 = 0; h4 < U; h4 += 4) {  // four independent lookup chains at a time
             u32 lo[4], hi[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) lookup(X0[h4 + u], lo[u], hi[u]);
+            for (int u = 0; u < 4; u++) lookup(cur[h4 + u], lo[u], hi[u]);
 #pragma unroll
             for (int u = 0; u < 4; u++) keep(lo[u], hi[u], (seg >> 8) + (u32)(h4 + u), true);
         }
+        seg += (u32)U * NT;
+    };
+#pragma unroll 1
+    while (seg + 2u * U * NT <= n_seg) {
+        round(X0, X1);
+        round(X1, X0);
+    }
+    if (seg + (u32)U * NT <= n_seg) {
+        round(X0, X1);
 #pragma unroll
         for (int u = 0; u < U; u++) X0[u] = X1[u];
     }
@@ -354,7 +402,7 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
     u32 *s_resc = (u32 *)(smem + L.misc) + 28;              // some lane of the block has codes to walk again
     __syncthreads();  // (every wave is past its last lookup)
 #pragma unroll
-    for (int i = 0; i < G; i++)
+    for (int i = 0; i < GA; i++)
 #pragma unroll
         for (int k = 0; k < NS; k++) sa[(size_t)i * NS * 256 + (size_t)k * 256 + tid] = (unsigned short)(slot[i][k] >> 16);
     __syncthreads();
@@ -401,7 +449,7 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
     };
     u32 rmask = 0;  // the queries this lane has to walk its codes again for
 #pragma unroll
-    for (int i = 0; i < G; i++) {
+    for (int i = 0; i < GA; i++) {
         if (i >= ng || s_flag[i] != 0u) continue;  // block-uniform
         const u32 cut = s_cut[i];
 #pragma unroll
@@ -415,11 +463,11 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
     if (rmask) *s_resc = 1u;
     __syncthreads();
     if (*s_resc) {  // block-uniform, about one block in a hundred
-        build_table();  // (the same instructions on the same inputs: the same table)
+        build_table(0);  // (the same instructions on the same inputs: the same table)
         __syncthreads();
         if (rmask) {
 #pragma unroll
-            for (int i = 0; i < G; i++) {
+            for (int i = 0; i < GA; i++) {
                 if (!((rmask >> i) & 1u)) continue;
                 const u32 cut = s_cut[i], last = slot[i][NS - 1];
                 for (u32 step = 0; step * NT + (u32)tid < n_seg; step++) {
@@ -558,4 +606,20 @@ __global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
         }
     }
     Q_T(5);
+}
+
+template <int M, int DSUB>
+__global__ __launch_bounds__(256, Q_WPS) void k_scan_q(const QParams QP) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // block -> group, in order.  (Dealing the groups to the XCDs in eight contiguous ranges -- so that the two to four blocks of one list
+    // share an L2 -- was measured: 0.765 against 0.750 ms per 7525 groups, 3.52 against 3.47 ms per 35796; the kernel is not bound by
+    // the code stream, and neighbouring blocks in one phase of the kernel on one XCD cost more than the L2 hits bring.)
+    const int grp = (int)blockIdx.x;
+    if (grp >= *QP.n_groups) return;
+    const int4 gd = QP.gdesc[grp];
+#ifndef Q_NO_GA2
+    if (gd.z <= 2) q_scan_group<M, DSUB, 2>(QP, gd, smem);
+    else
+#endif
+        q_scan_group<M, DSUB, 4>(QP, gd, smem);
 }
