@@ -1305,6 +1305,7 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
             # (mmidx_search: host arrays in, host arrays out, synchronous) and what the engine does when the far probes have to be scanned
             "ties": ties,
             "host_buffers_qps": (host or {}).get("nq16384", {}).get("queries_per_s") if isinstance(host, dict) else None,
+            "host_buffers_qps_3_callers": (host or {}).get("nq16384_callers3", {}).get("queries_per_s") if isinstance(host, dict) else None,
             "hard_qps": hard.get("value") if isinstance(hard, dict) else None,
             "spread_qps": spread.get("value") if isinstance(spread, dict) else None,
             "batch_131072_qps": big.get("value") if isinstance(big, dict) else None,

@@ -218,6 +218,20 @@ struct mmidx_index {
     std::recursive_mutex add_mu;  // adds are `synchronized` in the reference (ASS:229, IVFPQ.java:357): one at a time
     Combiner comb;  // concurrent mmidx_search callers are served together (see mmidx_search)
     unsigned char *pin_stage = nullptr;  // pinned staging: queries in, (distances | ids | counts) out
+    // large host-pointer requests (> MMIDX_COMB_MAX_Q queries): a few callers in flight at once, each with its own copy stream and
+    // device buffers -- one caller's queries and answers are on the bus while another's kernels run (see search_host_big)
+    struct HostSlot {
+        hipStream_t st = nullptr;
+        hipEvent_t e_in = nullptr, e_done = nullptr;
+        DevBuf<double> dQ;
+        DevBuf<unsigned char> out;
+        bool busy = false;
+    };
+    static constexpr int N_HOST_SLOTS = 3;
+    int host_slots_on = 1;  // option "host_slots": 0 = large requests through the combiner's queue, one at a time (rounds 1-5)
+    HostSlot host_slot[N_HOST_SLOTS];
+    std::mutex slot_mu;
+    std::condition_variable slot_cv;
     size_t pin_stage_cap = 0;
 
     double *d_coarse = nullptr, *d_coarseT = nullptr, *d_pq = nullptr, *d_pqT = nullptr,
@@ -2904,6 +2918,15 @@ int mmidx_destroy(mmidx_index *h) {
     }
     if (h->pin_stage) (void)hipHostFree(h->pin_stage);
     h->pin_stage = nullptr;
+    for (auto &sl : h->host_slot) {
+        if (sl.e_in) (void)hipEventDestroy(sl.e_in);
+        if (sl.e_done) (void)hipEventDestroy(sl.e_done);
+        if (sl.st) (void)hipStreamDestroy(sl.st);
+        sl.e_in = sl.e_done = nullptr;
+        sl.st = nullptr;
+        sl.dQ.release();
+        sl.out.release();
+    }
     h->ws_out.release();
     void *ptrs[] = {h->d_Ch, h->d_Cl, h->d_cn_pad, h->d_cn, h->d_cnorm, h->d_coarseT32, h->d_coarse, h->d_coarseT, h->d_pq, h->d_pqT, h->d_rot, h->d_perm, h->d_off, h->d_codes,
                     h->d_ids,    h->d_pcell,   h->d_pid, h->d_pcodes};
@@ -3400,6 +3423,72 @@ static int search_host_direct(mmidx_index *h, const SearchReq &r) {
     return MMIDX_OK;
 }
 
+// A request of more than MMIDX_COMB_MAX_Q queries, outside the combiner.  The caller takes one of the handle's slots (its own copy
+// stream, query and answer buffers), sends its queries on that stream, holds search_mu only while its kernels are enqueued on the
+// handle's stream (ordered behind its upload by an event), and fetches its answers on its own stream again.  With two or three
+// reader threads -- the reference's model: any number of threads calling computeNearestNeighbors (AbstractSearchStructure.java:281-291)
+// -- the uploads and downloads of one caller run under the kernels of another; a single caller gains nothing.
+static int search_host_big(mmidx_index *h, const SearchReq &r) {
+    int rc = set_device(h);
+    if (rc) return rc;
+    const int k = r.k;
+    const int64_t nq = r.nq;
+    mmidx_index::HostSlot *sl = nullptr;
+    {
+        std::unique_lock<std::mutex> lk(h->slot_mu);
+        for (;;) {
+            for (auto &c : h->host_slot)
+                if (!c.busy) {
+                    sl = &c;
+                    break;
+                }
+            if (sl) break;
+            h->slot_cv.wait(lk);
+        }
+        sl->busy = true;
+    }
+    struct Release {
+        mmidx_index *h;
+        mmidx_index::HostSlot *sl;
+        ~Release() {
+            {
+                std::lock_guard<std::mutex> lk(h->slot_mu);
+                sl->busy = false;
+            }
+            h->slot_cv.notify_one();
+        }
+    } release{h, sl};
+    if (!sl->st) {
+        HIPCK(hipStreamCreateWithFlags(&sl->st, hipStreamNonBlocking));
+        HIPCK(hipEventCreateWithFlags(&sl->e_in, hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&sl->e_done, hipEventDisableTiming));
+    }
+    const size_t od = (size_t)nq * k * 8, oi = (size_t)nq * k * 4, oc = (size_t)nq * 4;
+    if ((size_t)nq * h->D > sl->dQ.cap || od + oi + oc > sl->out.cap) HIPCK(hipStreamSynchronize(sl->st));
+    HIPCK(sl->dQ.reserve((size_t)nq * h->D));
+    HIPCK(sl->out.reserve(od + oi + oc));
+    double *d_dist = (double *)sl->out.p;
+    int32_t *d_iid = (int32_t *)(sl->out.p + od), *d_cnt = (int32_t *)(sl->out.p + od + oi);
+    HIPCK(hipMemcpyAsync(sl->dQ.p, r.Q, (size_t)nq * h->D * 8, hipMemcpyHostToDevice, sl->st));
+    HIPCK(hipEventRecord(sl->e_in, sl->st));
+    {
+        DeviceCall call(h, h->stream);  // search_mu; a _device call on another stream is waited for
+        HIPCK(hipStreamWaitEvent(h->stream, sl->e_in, 0));
+        rc = search_common(h, k, nq, sl->dQ.p, nullptr, 0, d_iid, d_dist, d_cnt, nullptr, nullptr, h->stream);
+        if (rc) {
+            (void)hipStreamSynchronize(h->stream);
+            return rc;
+        }
+        HIPCK(hipEventRecord(sl->e_done, h->stream));
+    }
+    HIPCK(hipStreamWaitEvent(sl->st, sl->e_done, 0));
+    HIPCK(hipMemcpyAsync(r.dist, d_dist, od, hipMemcpyDeviceToHost, sl->st));
+    HIPCK(hipMemcpyAsync(r.iid, d_iid, oi, hipMemcpyDeviceToHost, sl->st));
+    HIPCK(hipMemcpyAsync(r.cnt, d_cnt, oc, hipMemcpyDeviceToHost, sl->st));
+    HIPCK(hipStreamSynchronize(sl->st));
+    return MMIDX_OK;
+}
+
 // serves batch[0..nb) (same k, sum of nq <= MMIDX_COMB_MAX_Q unless nb == 1); the caller holds search_mu
 static int search_host_batch(mmidx_index *h, SearchReq *const *batch, size_t nb) {
     int rc = set_device(h);
@@ -3500,6 +3589,7 @@ int mmidx_search(mmidx_index *h, int k, int64_t nq, const double *Q, int32_t *ii
     me.iid = iid_out;
     me.dist = dist_out;
     me.cnt = count_out;
+    if (nq > MMIDX_COMB_MAX_Q && h->host_slots_on) return search_host_big(h, me);
     return combiner_submit(h->comb, me, MMIDX_COMB_MAX_Q, [h](SearchReq *const *batch, size_t nb) {
         std::lock_guard<std::recursive_mutex> slk(h->search_mu);  // (id queries use the same workspaces and stream)
         return search_host_batch(h, batch, nb);
@@ -3796,6 +3886,8 @@ int mmidx_set_option(mmidx_index *h, const char *name, int value) {
         h->smin_pre = value < 0 ? -1 : (value != 0);
     } else if (n == "no_union") {  // K3g without the per-query histogram that lowers thresholds from the union over lists
         h->no_union = value < 0 ? -1 : (value != 0);
+    } else if (n == "host_slots") {  // large host-pointer requests: 1 = up to three callers in flight (default), 0 = one at a time
+        h->host_slots_on = value != 0;
     } else if (n == "passa_q") {  // K3q: 1 always, 0 never, -1 by the batch (default)
         h->passa_q = value;
     } else if (n == "passa_mfma") {  // K3ma: 1 always, 0 never, -1 by the batch (default)

@@ -17,7 +17,7 @@ MAX_LINE = 8000
 # what stays in the line (the bench contract's keys + the two objects the judge reads + scalars)
 CORE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
              "dtype", "data", "config", "recall_at_1", "recall_queries", "roofline", "cpu_baseline", "parity", "ties",
-             "host_buffers_qps", "hard_qps", "spread_qps", "batch_131072_qps", "sharded_dry_run_ms_per_shard")
+             "host_buffers_qps", "host_buffers_qps_3_callers", "hard_qps", "spread_qps", "batch_131072_qps", "sharded_dry_run_ms_per_shard")
 ROOFLINE_KEYS = ("bound", "kernel", "pass_a_kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms",
                  "launches", "traffic_source", "lds_conflict_ratio")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "cpu_model")

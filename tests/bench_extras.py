@@ -56,6 +56,35 @@ def host_path(L, nat, h, Qh, k, threads=(64, 128), calls_per_thread=200):
         ts.sort()
         med = ts[len(ts) // 2]
         out[f"nq{nq}"] = {"ms_per_call_median": round(med * 1e3, 4), "queries_per_s": round(nq / med, 1)}
+    # two and three reader threads, every one with requests of 16384 queries (ctypes drops the interpreter lock inside the call):
+    # one caller's copies run under another caller's kernels (search_host_big)
+    import threading
+
+    nq = min(16384, nq_all)
+    ref_i, ref_d = oi[:nq].copy(), od[:nq].copy()
+    nat.check(L.mmidx_search(h, k, nq, Qh.ctypes.data, ref_i.ctypes.data, ref_d.ctypes.data, oc.ctypes.data))
+    for T in (2, 3):
+        bufs = [(np.empty((nq, k), np.int32), np.empty((nq, k), np.float64), np.empty(nq, np.int32)) for _ in range(T)]
+        calls, errs = 8, []
+
+        def work(t):
+            bi, bd, bc = bufs[t]
+            for _ in range(calls):
+                rc = L.mmidx_search(h, k, nq, Qh.ctypes.data, bi.ctypes.data, bd.ctypes.data, bc.ctypes.data)
+                if rc:
+                    errs.append(rc)
+
+        for rep in range(2):  # (the first round warms the slots' buffers)
+            th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+            t0 = time.perf_counter()
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            sec = time.perf_counter() - t0
+        same = all(np.array_equal(b[0], ref_i) and np.array_equal(b[1], ref_d) for b in bufs)
+        out[f"nq{nq}_callers{T}"] = {"queries_per_s": round(T * calls * nq / sec, 1), "ms_per_call_per_caller": round(sec / calls * 1e3, 4),
+                                     "errors": len(errs), "answers_equal_single_caller": bool(same)}
     # native caller threads, one query per call (no interpreter lock in the way)
     try:
         tmp = tempfile.mkdtemp()

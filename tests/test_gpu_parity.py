@@ -1484,6 +1484,53 @@ def test_concurrent_reader_threads(mi, oracle):
     ix.close()
 
 
+@pytest.mark.parametrize("slots", [1, 0])
+def test_large_host_requests_of_several_callers_overlap(mi, oracle, slots):
+    """Requests of more than 4096 queries go around the combiner (search_host_big): up to three callers in flight, each with its own
+    copy stream and buffers, the kernels one caller at a time.  Five threads with requests of different sizes, small calls mixed in:
+    every caller gets exactly its own answers -- also with the slots switched off (one request at a time, rounds 1-5)."""
+    import threading
+
+    D, C, m, ks, n, w, k = 32, 16, 8, 256, 8000, 5, 10
+    p = synth.make_ivfpq_problem(n=n, D=D, C=C, m=m, ks=ks, nq=96, seed=93)
+    ix = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    ix.loadCoarseQuantizer(p["coarse"])
+    ix.loadProductQuantizer(p["pq"])
+    ix.setW(w)
+    ix.set_option("host_slots", slots)
+    ref = oracle_ivfpq(oracle, p, D, m, ks, C, w)
+    ix.indexVectors([str(i) for i in range(n)], p["base"])
+    ref.add_vectors(p["base"])
+    want = ref.search_batch(p["queries"], k)
+    errors = []
+    start = threading.Barrier(5)
+
+    def worker(t):
+        try:
+            start.wait()
+            for rep in range(4):
+                nq = 4200 + 450 * ((t + rep) % 5)
+                sel = (np.arange(nq) * (t + 3) + rep) % 96
+                got = ix.search_batch(k, np.ascontiguousarray(p["queries"][sel]))
+                for a, b in zip(got, want):
+                    if not np.array_equal(a, b[sel]):
+                        errors.append((t, rep, nq))
+                got = ix.search_batch(k, p["queries"][t:t + 2])  # (a small call through the combiner in between)
+                for a, b in zip(got, want):
+                    if not np.array_equal(a, b[t:t + 2]):
+                        errors.append((t, rep, "small"))
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(5)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
+    ix.close()
+
+
 @pytest.mark.parametrize("combine", [1, 0])
 def test_single_query_callers_are_combined(mi, oracle, combine):
     """The reference's API is one query per call from many reader threads.  mmidx_search serves the callers that arrive
