@@ -1263,7 +1263,7 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
                 k3 = [l for l in pr.stderr.splitlines() if "K3ma pass A per step" in l]
                 dry = {"n_virtual_shards": ns, "queries_per_s": dj["value"], "queries_per_round": dj["config"]["batch"], "ms_per_round": dj["ms_per_step"],
                        "ms_per_shard_and_round": round(dj["ms_per_step"] / ns, 4), "parity": dj.get("parity"),
-                       "pass_a": k3[-1].split("] ", 1)[-1] if k3 else "K3h (K3ma off or not applicable)",
+                       "pass_a": k3[-1].split("] ", 1)[-1] if k3 else "%s (the first shard's dispatch, mmidx_get_dispatch)" % (dj.get("roofline") or {}).get("pass_a_kernel", "?"),
                        "stage_ms_slowest_shard": {"coarse": dx.get("roofline_whole_search", {}).get("coarse_ms_per_step"),
                                                   "merge": dx.get("roofline_whole_search", {}).get("merge_ms_per_step")},
                        "shard_info": dx.get("shard_info"),

@@ -3548,9 +3548,11 @@ static int search_host_batch(mmidx_index *h, SearchReq *const *batch, size_t nb)
     }
     std::vector<int64_t> req_q0(nb + 1, 0);  // first query of every request in the combined batch
     for (size_t i = 0; i < nb; i++) req_q0[i + 1] = req_q0[i] + batch[i]->nq;
-    const int64_t per = std::max<int64_t>(256, (tot + NSL - 1) / NSL);
-    for (int e = 0; e < NSL; e++) {
-        const int64_t a = std::min<int64_t>(tot, (int64_t)e * per), b = e == NSL - 1 ? tot : std::min<int64_t>(tot, (int64_t)(e + 1) * per);
+    // (slices of >= 2 MiB of answers: the combined single-query callers get ONE copy and one wait, as before round 6)
+    const int nsl = (int)std::min<size_t>(NSL, std::max<size_t>(1, (od + oi + oc) / ((size_t)2 << 20)));
+    const int64_t per = (tot + nsl - 1) / nsl;
+    for (int e = 0; e < nsl; e++) {
+        const int64_t a = std::min<int64_t>(tot, (int64_t)e * per), b = e == nsl - 1 ? tot : std::min<int64_t>(tot, (int64_t)(e + 1) * per);
         if (b > a) {
             HIPCK(hipMemcpyAsync(hout + (size_t)a * k * 8, (unsigned char *)d_dist + (size_t)a * k * 8, (size_t)(b - a) * k * 8, hipMemcpyDeviceToHost, h->stream));
             HIPCK(hipMemcpyAsync(hout + od + (size_t)a * k * 4, (unsigned char *)d_iid + (size_t)a * k * 4, (size_t)(b - a) * k * 4, hipMemcpyDeviceToHost, h->stream));
@@ -3559,8 +3561,8 @@ static int search_host_batch(mmidx_index *h, SearchReq *const *batch, size_t nb)
         HIPCK(hipEventRecord(h->host_ev[e], h->stream));
     }
     size_t ri = 0;
-    for (int e = 0; e < NSL; e++) {
-        const int64_t a = std::min<int64_t>(tot, (int64_t)e * per), b = e == NSL - 1 ? tot : std::min<int64_t>(tot, (int64_t)(e + 1) * per);
+    for (int e = 0; e < nsl; e++) {
+        const int64_t a = std::min<int64_t>(tot, (int64_t)e * per), b = e == nsl - 1 ? tot : std::min<int64_t>(tot, (int64_t)(e + 1) * per);
         HIPCK(hipEventSynchronize(h->host_ev[e]));
         for (int64_t g0 = a; g0 < b;) {  // the part of [a, b) that belongs to request ri
             while (req_q0[ri + 1] <= g0) ri++;
