@@ -3524,19 +3524,24 @@ static int search_host_batch(mmidx_index *h, SearchReq *const *batch, size_t nb)
     HIPCK(h->ws_out.reserve(od + oi + oc));
     double *d_dist = (double *)h->ws_out.p;
     int32_t *d_iid = (int32_t *)(h->ws_out.p + od), *d_cnt = (int32_t *)(h->ws_out.p + od + oi);
-    // stage in: request by request (pieces of <= 4 MiB); every piece's DMA runs while the next piece is copied into the pinned buffer
+    // stage in: the requests side by side in the pinned buffer; a DMA leaves whenever 4 MiB have gathered (it runs while the next
+    // piece is copied) -- ONE for a batch of single-query callers
     {
         const size_t piece = (size_t)4 << 20;
-        size_t off = 0;
+        size_t off = 0, sent = 0;
         for (size_t i = 0; i < nb; i++) {
             const size_t b = (size_t)batch[i]->nq * h->D * 8;
             for (size_t p0 = 0; p0 < b; p0 += piece) {
                 const size_t pb = std::min(piece, b - p0);
                 memcpy(hin + off, (const unsigned char *)batch[i]->Q + p0, pb);
-                HIPCK(hipMemcpyAsync((unsigned char *)h->ws_Q.p + off, hin + off, pb, hipMemcpyHostToDevice, h->stream));
                 off += pb;
+                if (off - sent >= piece) {
+                    HIPCK(hipMemcpyAsync((unsigned char *)h->ws_Q.p + sent, hin + sent, off - sent, hipMemcpyHostToDevice, h->stream));
+                    sent = off;
+                }
             }
         }
+        if (off > sent) HIPCK(hipMemcpyAsync((unsigned char *)h->ws_Q.p + sent, hin + sent, off - sent, hipMemcpyHostToDevice, h->stream));
     }
     rc = search_common(h, k, tot, h->ws_Q.p, nullptr, 0, d_iid, d_dist, d_cnt, nullptr, nullptr, h->stream);
     if (rc) return rc;

@@ -1332,6 +1332,52 @@ def test_pass_a_histogram_kernel_other_widths(mi, oracle, m, D, k):
     ix.close()
 
 
+@pytest.mark.parametrize("nq", [1, 2, 3, 4, 7])
+def test_pass_a_integer_kernel_lane_with_more_candidates_than_slots(mi, oracle, nq):
+    """K3q keeps six keys per lane and query; a lane sees the list positions p = lane (mod 256).  Here the 40 codes nearest to the
+    queries are INSERTED at positions 7, 263, 519, ... of the queries' list, so lane 7 holds far more than six of every query's
+    K1 = 21 best: its sixth key lies within the cut, the block builds its table again and the lane walks its codes once more
+    (mmidx_scan_q.h: the rescue).  One and two queries take the two-query body, three and four the four-query body, seven two groups."""
+    D, C, m, ks, w, k = 128, 2, 16, 256, 2, 20  # (w = 2: the two-pass search; one pass would be the exact kernel K3)
+    n_list = 10400
+    p = synth.make_ivfpq_problem(n=6000, D=D, C=C, m=m, ks=ks, nq=8, seed=606)
+    rng = np.random.default_rng(607)
+    c0 = p["coarse"][0]
+    V = c0 + 0.25 * rng.standard_normal((n_list, D))
+    q0 = c0 + 0.25 * rng.standard_normal(D)
+    Q = q0 + 0.002 * rng.standard_normal((nq, D))
+    # the ADC order of the list for q0, from a scratch oracle index in arbitrary order
+    tmp = oracle_ivfpq(oracle, p, D, m, ks, C, w)
+    cells, _ = tmp.encode_batch(V)
+    V = V[cells == 0]
+    n0 = len(V)
+    assert n0 > 10240
+    tmp.add_vectors(V)
+    near = tmp.search_batch(q0[None, :], 40)[0][0]
+    rest = np.setdiff1d(np.arange(n0), near)
+    order = np.empty(n0, np.int64)
+    slots = 7 + 256 * np.arange(40)
+    order[slots] = near
+    order[np.setdiff1d(np.arange(n0), slots)] = rest
+    far = p["coarse"][1] + 0.25 * rng.standard_normal((300, D))  # (the other cell's list, appended behind: ids n0 ...)
+    far = far[tmp.encode_batch(far)[0] == 1]
+    Vo = np.concatenate([V[order], far])
+    ix = mi.IVFPQ(D, len(Vo), False, "", m, ks, 0, C, 512)
+    ix.loadCoarseQuantizer(p["coarse"])
+    ix.loadProductQuantizer(p["pq"])
+    ix.setW(w)
+    ix.set_option("passa_q", 1)
+    ref = oracle_ivfpq(oracle, p, D, m, ks, C, w)
+    ix.indexVectors([str(i) for i in range(len(Vo))], Vo)
+    ref.add_vectors(Vo)
+    got = ix.search_batch(k, Q)
+    assert ix.get_dispatch()["pass_a"].startswith("K3q")
+    assert_same(got, ref.search_batch(Q, k))
+    # (the construction holds: the queries' best 21 sit on lane 7's positions)
+    assert np.all(np.isin(got[0][:, :12], slots))
+    ix.close()
+
+
 @pytest.mark.parametrize("name", ["ivfpq_small.npz", "ivfpq_perm.npz", "ivfpq_ties.npz", "pq_small.npz"])
 def test_golden_fixtures_gpu(mi, name):
     """HIP path against the COMMITTED answers of tests/golden/ (no live oracle in the loop): encode output, neighbour
