@@ -350,6 +350,7 @@ struct mmidx_index {
     hipEvent_t host_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // mmidx_search (host buffers): the answers' slices on their way back
     int passa_q = -1;                  // option "passa_q": K3q (mmidx_scan_q.h) 1 always (where the shape allows), 0 never, -1 = from 1.25 queries per non-empty list of a long-list index
     double *d_pqstat = nullptr;        // K3q: [m * dsub] mean_j p_sj[t], then [m] mean_j ||p_sj||^2
+    float *d_pqT32 = nullptr;          // K3q: the transposed codebook in fp32, dimension pairs side by side [m][dsub / 2][256][2] (ks = 256, even dsub)
     int passa_mfma = -1;               // option "passa_mfma": 1 always (where the shape allows), 0 never, -1 = from 8 queries per list of a long-list index
     int a_wide = 1;                    // option "passa_mfma_wide": 0 = K3ma's sweeps by the four-wave instance alone (A/B switch)
     DevBuf<float> ws_acand;            // [pairs][pieces][256] sweep 1's kept accumulator values
@@ -1135,7 +1136,7 @@ int launch_a1_verify_t(mmidx_index *h, const MfmaParams &MP, hipStream_t st) {
 // ---- K3q (mmidx_scan_q.h): pass A on integers, up to four queries of a nearest list per block -----------------------------------
 // does pass A of this call go through K3q?
 bool passa_q_applies(const mmidx_index *h, const ScanParams &P, const SearchPlan &pl, long long nq) {
-    if (h->passa_q == 0 || !P.ivf || P.sdc_tt || nq <= 0 || !h->d_pqstat) return false;
+    if (h->passa_q == 0 || !P.ivf || P.sdc_tt || nq <= 0 || !h->d_pqstat || !h->d_pqT32) return false;
     if (h->code_bytes != 1 || h->ks != 256 || h->m != 16 || (h->dsub != 4 && h->dsub != 8 && h->dsub != 16)) return false;
     if (pl.K1 + 40 > MMIDX_Q_HKQ) return false;  // (~K1 + 10 candidates per query, and room for ties)
     if (h->max_list_len >= (1ll << 24) || nq * (long long)P.w >= 0x7fffff00ll) return false;
@@ -1199,6 +1200,8 @@ int launch_passa_q(mmidx_index *h, const ScanParams &P, const SearchPlan &pl, lo
     QP.n_groups = h->ws_gfb.p;
     QP.pq = h->d_pq;
     QP.pqstat = h->d_pqstat;
+    QP.pqT32 = h->d_pqT32;
+    QP.pmax = h->rmax;
     QP.timing = nullptr;
     const QLds L(h->m, h->D);
     // grid: the host's upper bound of the group count (the blocks beyond the device-side count leave at once)
@@ -2980,6 +2983,7 @@ int mmidx_destroy(mmidx_index *h) {
     for (int e = 0; e < 4; e++)
         if (h->host_ev[e]) (void)hipEventDestroy(h->host_ev[e]);
     if (h->d_pqstat) (void)hipFree(h->d_pqstat);
+    if (h->d_pqT32) (void)hipFree(h->d_pqT32);
     if (h->d_pq32T) (void)hipFree(h->d_pq32T);
     if (h->d_pn32) (void)hipFree(h->d_pn32);
     if (h->d_pnmax) (void)hipFree(h->d_pnmax);
@@ -3142,6 +3146,17 @@ int mmidx_set_pq(mmidx_index *h, const double *pq) {
             }
         if (!h->d_pqstat) HIPCK(hipMalloc((void **)&h->d_pqstat, stt.size() * sizeof(double)));
         HIPCK(hipMemcpy(h->d_pqstat, stt.data(), stt.size() * sizeof(double), hipMemcpyHostToDevice));
+        if (h->d_pqT32) (void)hipFree(h->d_pqT32);
+        h->d_pqT32 = nullptr;
+        if (h->ks == 256 && h->dsub % 2 == 0) {
+            std::vector<float> t32(n);
+            for (int s = 0; s < h->m; s++)
+                for (int j = 0; j < 256; j++)
+                    for (int t = 0; t < h->dsub; t++)
+                        t32[(((size_t)s * (h->dsub / 2) + t / 2) * 256 + j) * 2 + (t & 1)] = (float)pq[((size_t)s * h->ks + j) * h->dsub + t];
+            HIPCK(hipMalloc((void **)&h->d_pqT32, n * sizeof(float)));
+            HIPCK(hipMemcpy(h->d_pqT32, t32.data(), n * sizeof(float), hipMemcpyHostToDevice));
+        }
     }
     h->pq_set = true;
     h->grp_valid = false;

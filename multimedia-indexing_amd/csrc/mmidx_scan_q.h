@@ -38,6 +38,7 @@
 // smallest a is saturated (a scale that turned out too small), one with a lane that may have dropped a candidate, or whose scale is
 // unusable (zero / non-finite).  Results never depend on the scale or on any of the heuristics.
 #pragma once
+#include <type_traits>
 #ifndef Q_STOP
 #define Q_STOP 0
 #endif
@@ -57,7 +58,7 @@
 #define Q_WPS 4
 #endif
 #ifndef Q_TU
-#define Q_TU 4  // table rows in flight per thread
+#define Q_TU 4  // table rows in flight per thread (fp32 pairs: 4 registers a row at dsub = 8; 2, 4 and 8 measured the same)
 #endif
 #ifndef Q_FR
 #define Q_FR 4  // codebook rows in flight per candidate
@@ -69,6 +70,8 @@ struct QParams {
     const int32_t *n_groups;  // device-side count
     const double *pq;         // [m][ks][dsub] (file order): a candidate's rows
     const double *pqstat;     // [m * dsub] mean_j p_sj[t], then [m] mean_j ||p_sj||^2
+    const float *pqT32;       // the transposed codebook in fp32, two dimensions side by side: [m][dsub / 2][256] x {p[2 t2], p[2 t2 + 1]} (the table's input)
+    double pmax;              // >= ||x|| of every code: sqrt(sum_s max_j ||p_sj||^2) (the fp32 table's error bound)
     unsigned long long *timing;  // Q_TIMING builds: cycles per phase, summed over the blocks' thread 0
 };
 
@@ -85,7 +88,11 @@ struct QLds {
                                                                       // then the candidates' exact sums [G * HKQ] u64
         res = o; o += (size_t)MMIDX_Q_G * D * 8;                      // the queries' residuals, transformed (fp64); first: raw residuals (rotation)
         misc = o; o += 64 * 8;                                        // see the kernel
-        cent = o; o += (size_t)MMIDX_Q_G * MMIDX_Q_HKQ * 4;           // the candidates: (evidence << 31 | position), later (pool slot << 24 | position)
+        cent = o;                                                     // the candidates: (evidence << 31 | position), later (pool slot << 24 | position);
+        {                                                             // before the scan: the residuals in fp32, [D] x {r0, r1, r2, r3} (the table's input)
+            const size_t a = (size_t)MMIDX_Q_G * MMIDX_Q_HKQ * 4, b = (size_t)D * 16;
+            o += a > b ? a : b;
+        }
         sel = tab;                                                    // the kept keys' a values (u16) [G][SLOTS * 256]: the selection's input, OVER the table
                                                                       // (12 KiB of its 32; a block with a lane to rescue builds the table again)
         total = (o + 15) & ~(size_t)15;
@@ -96,6 +103,29 @@ __device__ __forceinline__ u32 q_med3(u32 a, u32 b, u32 c) {
     u32 r;
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
+}
+typedef float q_f2 __attribute__((ext_vector_type(2)));
+typedef float q_f4 __attribute__((ext_vector_type(4)));
+// packed fp32 (two queries per instruction): r - p.lo / r - p.hi in both halves, fused multiply-add, product
+__device__ __forceinline__ q_f2 q_pk_sub_lo(q_f2 r, q_f2 p) {
+    q_f2 d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(r), "v"(p));
+    return d;
+}
+__device__ __forceinline__ q_f2 q_pk_sub_hi(q_f2 r, q_f2 p) {
+    q_f2 d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(r), "v"(p));
+    return d;
+}
+__device__ __forceinline__ q_f2 q_pk_fma(q_f2 a, q_f2 b, q_f2 c) {
+    q_f2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ q_f2 q_pk_mul(q_f2 a, q_f2 b) {
+    q_f2 d;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
 }
 // (byte b of w) << SH in one VALU instruction (SDWA byte select; see byte_x8 in mmidx_kernels.h)
 template <int SH>
@@ -213,12 +243,14 @@ __device__ __forceinline__ void q_scan_group(const QParams &QP, const int4 gd, u
 
     // the table's input: Q_TU rows of the transposed codebook at a time (thread j <-> entry j of every row)
     static_assert(M % Q_TU == 0, "the table is built Q_TU rows at a time");
-    auto load_rows = [&](double (&p)[Q_TU][DSUB], const int s0) {
+    static_assert(DSUB % 2 == 0, "two dimensions per load");
+    auto load_rows = [&](q_f2 (&p)[Q_TU][DSUB / 2], const int s0) {
 #pragma unroll
         for (int j = 0; j < Q_TU; j++)
 #pragma unroll
-            for (int t = 0; t < DSUB; t++) p[j][t] = P.pqT[((size_t)(s0 + j) * DSUB + t) * 256 + tid];
+            for (int t2 = 0; t2 < DSUB / 2; t2++) p[j][t2] = ((const q_f2 *)QP.pqT32)[((size_t)(s0 + j) * (DSUB / 2) + t2) * 256 + tid];
     };
+    float *r32 = (float *)(smem + L.cent);  // [D][4]: the residuals of the block's queries in fp32 (until the scan is over)
 
     for (int i = tid; i < 128; i += NT) ((u32 *)(smem + L.misc))[i] = 0;
     __syncthreads();
@@ -245,14 +277,21 @@ __device__ __forceinline__ void q_scan_group(const QParams &QP, const int4 gd, u
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
         // scale: the mean distance to a code with independent uniform entries, sum_d (r_d^2 - 2 r_d mu_d) + sum_s nu_s
-        double part = 0.0;
+        double part = 0.0, rr = 0.0;
         for (int d = lane; d < D; d += 64) {
             const double r = s_r[(size_t)i * D + d];
             part += r * r - 2.0 * r * QP.pqstat[d];
+            rr += r * r;
+            r32[d * 4 + i] = (float)r;
         }
         if (lane < M) part += QP.pqstat[M * DSUB + lane];
         const double qr = wave_sum_f64(part);
-        const bool ok = i < ng && qr > 0.0 && qr < 1e300 && (MMIDX_Q_SCALE / qr) < 1e300;
+        // the table is computed in fp32 from fp32 copies of residual and codebook: per code that matters (scaled distance <= 4128) its
+        // scaled entries are off by at most 2 u sqrt(4128 scale) (||r|| + max ||x||) + 0.004 in total, u = 2^-24; a
+        // query for which that is not under 0.25 units -- or whose magnitudes leave fp32's comfortable range -- goes to the exact kernel
+        const double rnx = sqrt(wave_sum_f64(rr)) + QP.pmax;
+        const bool fits = qr > 1e-24 && qr < 1e24 && rnx < 1e15 && 2.0 * 5.9604644775390625e-8 * sqrt(4128.0 * (MMIDX_Q_SCALE / qr)) * rnx <= 0.25;
+        const bool ok = i < ng && fits;
         if (lane == 0) {
             s_inv[i] = ok ? MMIDX_Q_SCALE / qr : 0.0;
             if (i < ng && !ok) s_flag[i] = 1u;
@@ -261,44 +300,63 @@ __device__ __forceinline__ void q_scan_group(const QParams &QP, const int4 gd, u
     __syncthreads();
     Q_T(0);
     // ---- the table: thread j <-> entry j of every row; the exact entries of the four queries, quantised and packed -----------------
-    auto calc_rows = [&](const double (&p)[Q_TU][DSUB], const int s0) {
-        double inv[GA];
+    // fp32, two queries per instruction: df = r - p (v_pk_add_f32, the codebook value broadcast to both halves), acc = df df + acc
+    // (v_pk_fma_f32), x = acc (4000 / qr), q = min(4095, floor(x)).  FROM_LDS: the residuals from their fp32 copies (the first build);
+    // else converted from the fp64 residuals on the way (the rescue's rebuild, the copies' place taken: the same values, the same table)
+    auto calc_rows = [&](const q_f2 (&p)[Q_TU][DSUB / 2], const int s0, auto from_lds) {
+        constexpr bool FROM_LDS = decltype(from_lds)::value;
+        q_f2 inv2[GA / 2];
 #pragma unroll
-        for (int i = 0; i < GA; i++) inv[i] = s_inv[i];
+        for (int h = 0; h < GA / 2; h++) inv2[h] = q_f2{(float)s_inv[2 * h], (float)s_inv[2 * h + 1]};
 #pragma unroll
         for (int j = 0; j < Q_TU; j++) {
             const int s = s0 + j;
+            q_f2 acc[GA / 2];
+#pragma unroll
+            for (int h = 0; h < GA / 2; h++) acc[h] = q_f2{0.0f, 0.0f};
+#pragma unroll
+            for (int t = 0; t < DSUB; t++) {
+                q_f2 rv[GA / 2];
+                if constexpr (FROM_LDS) {
+                    if constexpr (GA == 4) {
+                        const q_f4 r4 = *(const q_f4 *)(r32 + (size_t)(s * DSUB + t) * 4);
+                        rv[0] = q_f2{r4.x, r4.y};
+                        rv[1] = q_f2{r4.z, r4.w};
+                    } else {
+                        rv[0] = *(const q_f2 *)(r32 + (size_t)(s * DSUB + t) * 4);
+                    }
+                } else {
+#pragma unroll
+                    for (int h = 0; h < GA / 2; h++) rv[h] = q_f2{(float)s_r[(size_t)(2 * h) * D + s * DSUB + t], (float)s_r[(size_t)(2 * h + 1) * D + s * DSUB + t]};
+                }
+#pragma unroll
+                for (int h = 0; h < GA / 2; h++) {
+                    const q_f2 df = (t & 1) ? q_pk_sub_hi(rv[h], p[j][t >> 1]) : q_pk_sub_lo(rv[h], p[j][t >> 1]);
+                    acc[h] = q_pk_fma(df, df, acc[h]);
+                }
+            }
             u32 qv[GA];
 #pragma unroll
-            for (int i = 0; i < GA; i++) {
-                const double *tv = s_r + (size_t)i * D + s * DSUB;
-                // (fused multiply-adds: these entries only feed the integer table, where one more rounding in 2^53 per step is nothing
-                //  next to the two units of margin in "a(c2) >= a(c1) + 18"; the candidates' exact sums below use the reference's
-                //  separate multiplications and additions)
-                double acc = 0.0;
-#pragma unroll
-                for (int t = 0; t < DSUB; t++) {
-                    const double df = tv[t] - p[j][t];
-                    acc = __builtin_fma(df, df, acc);
-                }
-                const double x = acc * inv[i];  // >= 0
-                qv[i] = (x >= 4095.0) ? 4095u : (u32)x;
+            for (int h = 0; h < GA / 2; h++) {
+                const q_f2 x = q_pk_mul(acc[h], inv2[h]);  // >= 0 (or +inf: saturated)
+                qv[2 * h] = (u32)__builtin_fminf(x.x, 4095.0f);  // (a NaN -- inf x 0, a flagged query's column -- gives 4095)
+                qv[2 * h + 1] = (u32)__builtin_fminf(x.y, 4095.0f);
             }
             if constexpr (GA == 4) *(uint2 *)(smem + (size_t)s * 2048 + (size_t)tid * 8) = make_uint2(qv[0] | (qv[1] << 16), qv[2] | (qv[3] << 16));
             else *(u32 *)(smem + (size_t)s * 1024 + (size_t)tid * 4) = qv[0] | (qv[1] << 16);
         }
     };
-    auto build_table = [&](const int from) {  // rows from ... M - 1
+    auto build_table = [&](auto from_lds) {
 #pragma unroll 1
-        for (int s0 = from; s0 < M; s0 += Q_TU) {
-            double pB[Q_TU][DSUB];
+        for (int s0 = 0; s0 < M; s0 += Q_TU) {
+            q_f2 pB[Q_TU][DSUB / 2];
             load_rows(pB, s0);
-            calc_rows(pB, s0);
+            calc_rows(pB, s0, from_lds);
         }
     };
     // (the first rows requested before the residuals -- one round trip less on paper -- measured 0.648 against 0.635 ms: 64 more live
     //  registers through the residual phase)
-    build_table(0);
+    build_table(std::true_type{});
     __syncthreads();
 #if Q_STOP == 1
     return;
@@ -463,7 +521,7 @@ __device__ __forceinline__ void q_scan_group(const QParams &QP, const int4 gd, u
     if (rmask) *s_resc = 1u;
     __syncthreads();
     if (*s_resc) {  // block-uniform, about one block in a hundred
-        build_table(0);  // (the same instructions on the same inputs: the same table)
+        build_table(std::false_type{});  // (the same instructions on the same values: the same table)
         __syncthreads();
         if (rmask) {
 #pragma unroll

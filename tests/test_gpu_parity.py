@@ -1332,6 +1332,36 @@ def test_pass_a_histogram_kernel_other_widths(mi, oracle, m, D, k):
     ix.close()
 
 
+@pytest.mark.parametrize("offset", [0.0, 100.0, 1e5])
+def test_pass_a_integer_kernel_fp32_table_guard(mi, oracle, offset):
+    """K3q builds its integer table in fp32 from fp32 copies of residual and codebook; a per-query bound on what that can cost
+    (2 u sqrt(4128 scale) (||r|| + max ||x||) <= 0.25 table units) decides whether the query may use it.  A codebook -- and with it
+    the residuals -- far from the origin with a small spread is what the bound is for: offset 100 passes it with a visible error
+    (0.07 units), offset 1e5 fails it and every query goes to the exact kernel; the answers are the oracle's either way."""
+    D, C, m, ks, w, k = 128, 2, 16, 256, 2, 30
+    rng = np.random.default_rng(int(offset) + 11)
+    coarse = rng.standard_normal((C, D))
+    pq = offset + rng.standard_normal((m, ks, D // m))
+    n = 9000
+    base = -offset + 1.5 * rng.standard_normal((n, D))  # residuals c - v = offset + noise: the codebook's neighbourhood
+    ix = mi.IVFPQ(D, n, False, "", m, ks, 0, C, 512)
+    ix.loadCoarseQuantizer(coarse)
+    ix.loadProductQuantizer(pq)
+    ix.setW(w)
+    ix.set_option("passa_q", 1)
+    ref = oracle.OracleIndex(oracle.KIND_IVFPQ, D, m, ks, C)
+    ref.set_coarse(coarse)
+    ref.set_pq(pq)
+    ref.set_w(w)
+    ix.indexVectors([str(i) for i in range(n)], base)
+    ref.add_vectors(base)
+    Q = base[rng.choice(n, 24, replace=False)] + 0.05 * rng.standard_normal((24, D))
+    got = ix.search_batch(k, Q)
+    assert ix.get_dispatch()["pass_a"].startswith("K3q")
+    assert_same(got, ref.search_batch(Q, k))
+    ix.close()
+
+
 @pytest.mark.parametrize("nq", [1, 2, 3, 4, 7])
 def test_pass_a_integer_kernel_lane_with_more_candidates_than_slots(mi, oracle, nq):
     """K3q keeps six keys per lane and query; a lane sees the list positions p = lane (mod 256).  Here the 40 codes nearest to the

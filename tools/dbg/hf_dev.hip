@@ -222,6 +222,28 @@ int main(int argc, char **argv) {
         QP.n_groups = d_ng;
         QP.pq = d_pq;
         QP.pqstat = d_pqstat;
+        {
+            std::vector<float> t32(pq.size());
+            double r2 = 0.0;
+            for (int s = 0; s < M; s++) {
+                double mx = 0.0;
+                for (int j = 0; j < ks; j++) {
+                    double nn = 0.0;
+                    for (int t = 0; t < dsub; t++) {
+                        const double v = pq[((size_t)s * ks + j) * dsub + t];
+                        t32[(((size_t)s * (dsub / 2) + t / 2) * 256 + j) * 2 + (t & 1)] = (float)v;
+                        nn += v * v;
+                    }
+                    mx = std::max(mx, nn);
+                }
+                r2 += mx;
+            }
+            float *d_t32;
+            CHECK(hipMalloc((void **)&d_t32, t32.size() * 4));
+            CHECK(hipMemcpy(d_t32, t32.data(), t32.size() * 4, hipMemcpyHostToDevice));
+            QP.pqT32 = d_t32;
+            QP.pmax = std::sqrt(r2) * (1.0 + 1e-12);
+        }
         unsigned long long *d_tim;
         CHECK(hipMalloc((void **)&d_tim, 64));
         CHECK(hipMemset(d_tim, 0, 64));
