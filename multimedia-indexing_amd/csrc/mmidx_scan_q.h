@@ -354,8 +354,8 @@ __device__ __forceinline__ void q_scan_group(const QParams &QP, const int4 gd, u
             calc_rows(pB, s0, from_lds);
         }
     };
-    // (the first rows requested before the residuals -- one round trip less on paper -- measured 0.648 against 0.635 ms: 64 more live
-    //  registers through the residual phase)
+    // (the first rows requested before the residuals -- one round trip less on paper -- measured slower twice: 0.648 against 0.635 ms
+    //  with fp64 rows, 0.576 against 0.563 ms with the fp32 pairs)
     build_table(std::true_type{});
     __syncthreads();
 #if Q_STOP == 1
