@@ -920,16 +920,22 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
                             "(profiles/r05b_b131k_pmc_kernels.txt); the algorithmic byte rate exceeds the HBM rate because a list is read once for "
                             "all the queries that probe it (physical traffic: `traffic`)"}
         else:  # K3q (the default since round 6): four queries of a list per block
-            ach = alg / (pa_ms_b * 1e-3) / 1e9 if pa_ms_b > 0 else 0.0
+            # at 16 queries per list the per-QUERY byte count (m x the codes of the query's nearest list) counts a list sixteen times; what a
+            # launch has to read once is the lists the batch touches, once per block of four queries -- `achieved` is priced on that
+            # (bytes the blocks request = algorithmic / 4 queries per block), the per-query figure stays beside it
+            blk = alg / 4.0
+            ach = blk / (pa_ms_b * 1e-3) / 1e9 if pa_ms_b > 0 else 0.0
             kq = tr.get("k_scan_q") if isinstance(tr, dict) else None
             roof = {"bound": "hbm", "kernel": "k_scan_q (K3q: every query's nearest list, four queries of a list per block; pair sort and empty hand-back launch included)",
                     "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
-                    "algorithmic_bytes_per_step": alg, "avg_launch_ms": round(pa_ms_b, 4),
+                    "algorithmic_bytes_per_step": blk, "per_query_bytes_per_step": alg,
+                    "per_query_GBps": round(alg / (pa_ms_b * 1e-3) / 1e9, 1) if pa_ms_b > 0 else None, "avg_launch_ms": round(pa_ms_b, 4),
                     "traffic": (kq["fetch_kib_per_step"] * 2048.0 + kq.get("write_kib_per_step", 0.0) * 1024.0) if isinstance(kq, dict) else None,
                     "traffic_source": "profiles/hbm_traffic.json batch_131072.k_scan_q: FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc pass" if isinstance(kq, dict) else None,
-                    "note": "algorithmic bytes = m x the codes of every query's nearest list; 16 queries per list = four blocks per list, each streaming it "
-                            "(the later ones from L2 / MALL): the physical traffic is a fraction of the algorithmic figure and the fraction of the HBM peak "
-                            "can exceed 1.  The kernel is bound by its LDS gathers and VALU work, not by HBM (DESIGN.md 5.2)"}
+                    "note": "algorithmic bytes = m x the codes of every BLOCK's list (16 queries per list = four blocks per list, each streaming it, the "
+                            "later ones mostly from L2 / MALL: `traffic`); per query (m x the codes of its nearest list, the headline's definition) the "
+                            "rate is `per_query_GBps`, above the HBM peak because a list serves four queries per read.  The kernel is bound by its LDS "
+                            "reads and vector work, not by HBM (DESIGN.md 5.2)"}
         res = {"value": round(big_B * args.big_steps / el, 1), "unit": "queries/s", "steps": args.big_steps, "batch": big_B,
                "ms_per_step": round(el / args.big_steps * 1e3, 4), "queries_per_nearest_list": round(big_B / Cc, 2),
                "pass_a_kernel": "K3ma" if k3ma else "K3q",
@@ -1329,7 +1335,7 @@ def run(cx, args, json_out, native, ndev, dist, rank, world, local, fallback_rea
         summ = {"headline_Mqps": mq(qps), "ms": round(ms_per_step, 4), "passA_ms": g(roofline, "avg_launch_ms"), "passA_frac": g(roofline, "frac"),
                 "recall1": recall1, "parity": ok(parity), "cpu_qps": g(cpu_baseline, "value"), "cores": cores,
                 "b131072": {"Mqps": mq(g(big, "value")), "ms": g(big, "ms_per_step"), "passA_ms": g(big, "stage_ms_per_step", "pass_a_timed_region"),
-                            "sweeps_ms": g(big, "roofline", "sweeps_ms"), "mfma_frac": g(big, "roofline", "frac"), "parity": ok(g(big, "parity"))},
+                            "sweeps_ms": g(big, "roofline", "sweeps_ms"), "passA_frac": g(big, "roofline", "frac"), "parity": ok(g(big, "parity"))},
                 "hard": {"Mqps": mq(g(hard, "value")), "passB_ms": g(hard, "stage_ms_per_step", "pass_b"), "mfma_frac": g(hard, "roofline", "frac"),
                          "parity": ok(g(hard, "parity"))},
                 "spread": {"Mqps": mq(g(spread, "value")), "passB_ms": g(spread, "stage_ms_per_step", "pass_b"), "mfma_frac": g(spread, "roofline", "frac"),
