@@ -2342,7 +2342,7 @@ int search_batch_device(mmidx_index *h, const SearchPlan &pl, int k, int64_t nq,
                 // K3q: the queries of a nearest list four to a block, decided on integers (mmidx_scan_q.h)
                 h->disp_passa = "K3q";
                 rc = launch_passa_q(h, P, pl, (long long)nq, st);
-                pcount_zeroed = false;  // (its pair sort counted in ws_pcount)
+                // (its pair sort counted in ws_pcount -- and k_q_scan_groups zeroed the counters again: pcount_zeroed stands)
             } else if (two_pass && passa_mfma_applies(h, P, pl, (long long)nq)) {
                 // K3ma: >= 8 queries per nearest list -- the list-major matrix-core form (mmidx_scan_mfma_a.h)
                 h->disp_passa = "K3ma";

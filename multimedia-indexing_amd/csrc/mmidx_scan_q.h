@@ -148,18 +148,25 @@ __device__ __forceinline__ double wave_sum_f64(double x) {
 
 // K3q's pair sort, middle step: the exclusive prefix of the per-cell pair counts (start[], cursor[] = 0: k_pair_scan's work) AND the
 // groups of <= G pairs per cell (gdesc[], their number: k_group_build's work) in ONE single-block launch -- each of the two walks the
-// same C counters and costs ~12 us of latency on its own.
-__global__ __launch_bounds__(1024) void k_q_scan_groups(const int32_t *__restrict__ cnt, int C, int G, int32_t *__restrict__ start, int32_t *__restrict__ cursor,
+// same C counters and costs ~12 us of latency on its own.  It leaves the counters ZEROED.
+__global__ __launch_bounds__(1024) void k_q_scan_groups(int32_t *__restrict__ cnt, int C, int G, int32_t *__restrict__ start, int32_t *__restrict__ cursor,
                                                         int4 *__restrict__ gdesc, int32_t *__restrict__ n_groups) {
     __shared__ u32 s_wa[16], s_wb[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int per = (C + 1023) / 1024;
     const int lo = tid * per, hi = (lo + per < C) ? lo + per : C;
+    // a thread's counters eight at a time: eight loads in flight, one round trip (one after the other they were eight -- 16 us per launch
+    // at C = 8192); up to eight per thread (C <= 8192) stay in registers for the second walk
+    int v[8];
     u32 sa = 0, sb = 0;
-    for (int c = lo; c < hi; c++) {
-        const u32 n = (u32)cnt[c];
-        sa += n;
-        sb += (n + (u32)G - 1u) / (u32)G;
+    for (int b0 = lo; b0 < hi; b0 += 8) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = b0 + i < hi ? cnt[b0 + i] : 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            sa += (u32)v[i];
+            sb += ((u32)v[i] + (u32)G - 1u) / (u32)G;
+        }
     }
     const u32 ia = wave_incl_scan_u32(sa), ib = wave_incl_scan_u32(sb);
     if (lane == 63) {
@@ -174,12 +181,22 @@ __global__ __launch_bounds__(1024) void k_q_scan_groups(const int32_t *__restric
         bb += (i < wv) ? s_wb[i] : 0u;
     }
     u32 ra = ba + ia - sa, rb = bb + ib - sb;  // exclusive prefixes of this thread's range
-    for (int c = lo; c < hi; c++) {
-        const int n = cnt[c];
-        start[c] = (int32_t)ra;
-        cursor[c] = 0;
-        for (int o = 0; o < n; o += G) gdesc[rb++] = make_int4(c, (int)ra + o, (n - o < G) ? n - o : G, 0);
-        ra += (u32)n;
+    for (int b0 = lo; b0 < hi; b0 += 8) {
+        if (per > 8) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = b0 + i < hi ? cnt[b0 + i] : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int c = b0 + i;
+            if (c >= hi) break;
+            const int n = v[i];
+            cnt[c] = 0;  // (pass B's pair sort counts in the same array: it finds it zeroed, no memset in between)
+            start[c] = (int32_t)ra;
+            cursor[c] = 0;
+            for (int o = 0; o < n; o += G) gdesc[rb++] = make_int4(c, (int)ra + o, (n - o < G) ? n - o : G, 0);
+            ra += (u32)n;
+        }
     }
     if (tid == 1023) {
         start[C] = (int32_t)(ba + ia);
