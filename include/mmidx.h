@@ -362,7 +362,12 @@ int mmidx_set_profiling(mmidx_index *h, int enabled);
  * "shard_route_host" (round 5; 1: mmidx_add_vectors_sliced_device sends its records through the host as before round 5 instead of routing
  * them between the devices),
  * "shard_pipeline" (1: the query exchange of a sharded handle on a second stream / communicator; the default for in-process shards, off
- * by default on two or more physical devices until a multi-device run has passed).  None of them changes a result. */
+ * by default on two or more physical devices until a multi-device run has passed).  Round 6: "passa_q" (K3q, pass A decided on packed
+ * integer table sums with four queries of a nearest list per block, mmidx_scan_q.h: 1 wherever the shape allows -- IVFPQ, byte codes,
+ * ks = 256, m = 16, dsub in {4, 8, 16}, k <= 151 --, 0 never, -1 = default: from 1.25 queries per non-empty list of a long-list index),
+ * "host_slots" (default 1: host-pointer searches of more than 4096 queries from several threads take one of three slots -- own copy
+ * stream and buffers -- and hold the handle's lock only while their kernels are enqueued; 0: one request at a time).
+ * None of them changes a result. */
 int mmidx_set_option(mmidx_index *h, const char *name, int value);
 int mmidx_get_stats(mmidx_index *h, mmidx_stats *out);
 /* Which kernel family served each stage of the most recent search sub-batch of this handle (ABI version 7), as text:
