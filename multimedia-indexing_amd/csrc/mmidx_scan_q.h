@@ -161,9 +161,10 @@ __global__ __launch_bounds__(1024) void k_q_scan_groups(int32_t *__restrict__ cn
     u32 sa = 0, sb = 0;
     for (int b0 = lo; b0 < hi; b0 += 8) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) v[i] = b0 + i < hi ? cnt[b0 + i] : 0;
+        for (int i = 0; i < 8; i++) v[i] = cnt[b0 + i < hi ? b0 + i : hi - 1];  // (unconditional loads: the compiler counts them)
 #pragma unroll
         for (int i = 0; i < 8; i++) {
+            v[i] = b0 + i < hi ? v[i] : 0;
             sa += (u32)v[i];
             sb += ((u32)v[i] + (u32)G - 1u) / (u32)G;
         }
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(1024) void k_q_scan_groups(int32_t *__restrict__ cn
     for (int b0 = lo; b0 < hi; b0 += 8) {
         if (per > 8) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) v[i] = b0 + i < hi ? cnt[b0 + i] : 0;
+            for (int i = 0; i < 8; i++) v[i] = cnt[b0 + i < hi ? b0 + i : hi - 1];
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(1024) void k_q_scan_groups(int32_t *__restrict__ cn
         }
     }
     if (tid == 1023) {
+        cnt[C] = 0;  // (the pairs' total, k_a1_pair_count's: k_pair_scan leaves at once when pass B's sort finds it zero)
         start[C] = (int32_t)(ba + ia);
         *n_groups = (int32_t)(bb + ib);
     }
