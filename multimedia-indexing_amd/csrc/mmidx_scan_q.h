@@ -60,6 +60,9 @@
 #ifndef Q_TU
 #define Q_TU 4  // table rows in flight per thread (fp32 pairs: 4 registers a row at dsub = 8; 2, 4 and 8 measured the same)
 #endif
+#ifndef Q_CH
+#define Q_CH 4  // independent lookup chains of the scan (2 / 4 / 8: 0.558 / 0.565 / 0.564 ms per 7525 groups -- no difference)
+#endif
 #ifndef Q_FR
 #define Q_FR 2  // codebook rows in flight per candidate (1 / 2 / 4: 0.567 / 0.550 / 0.556 ms per 7525 groups)
 #endif
@@ -452,12 +455,12 @@ __device__ __forceinline__ void q_scan_group(const QParams &QP, const int4 gd, u
 #pragma unroll
         for (int u = 0; u < U; u++) fetch(nxt[u], seg + (u32)(U + u) * NT + (u32)tid);
 #pragma unroll
-        for (int h4 = 0; h4 < U; h4 += 4) {  // four independent lookup chains at a time
-            u32 lo[4], hi[4];
+        for (int h4 = 0; h4 < U; h4 += Q_CH) {  // Q_CH independent lookup chains at a time
+            u32 lo[Q_CH], hi[Q_CH];
 #pragma unroll
-            for (int u = 0; u < 4; u++) lookup(cur[h4 + u], lo[u], hi[u]);
+            for (int u = 0; u < Q_CH; u++) lookup(cur[h4 + u], lo[u], hi[u]);
 #pragma unroll
-            for (int u = 0; u < 4; u++) keep(lo[u], hi[u], (seg >> 8) + (u32)(h4 + u), true);
+            for (int u = 0; u < Q_CH; u++) keep(lo[u], hi[u], (seg >> 8) + (u32)(h4 + u), true);
         }
         seg += (u32)U * NT;
     };
