@@ -63,9 +63,19 @@ for case in range(cases):
     pam = int(rng.choice([-1, -1, 1, 1]))  # K3ma (pass A on the matrix cores, two sweeps): by the batch (never, at seven queries) / forced where the shape allows
     pamw = int(rng.random() < 0.7)  # ... its second sweep by the eight-wave instance
     nosplit = int(rng.random() < 0.25)  # m = 128: the table-in-global kernels instead of k_scan_split
+    paq = int(rng.choice([-1, 1, 1, 0]))  # K3q (round 6: pass A decided on integer table sums): by the batch / forced where the shape allows / off
+    q_shape = kind == "ivfpq" and rng.random() < 0.3  # ... and three cases in ten of the IVFPQ draws get a shape it takes: 16 x 256 byte codes, k <= 151
+    if q_shape:
+        m, dsub, ks = 16, int(rng.choice([4, 8, 16])), 256
+        D = m * dsub
+        k = int(rng.choice([1, 2, 10, 100, 101, 151]))
+        C = int(rng.choice([1, 2, 7, 40]))
+        w = int(rng.integers(1, C + 1))
+        tr = int(rng.choice([0, 0, 2, 1]))
+        paq = 1
     # the oracle's encoder is one thread ((C + ks) x D fp64 triples per vector): keep a case near a second of it
     n = max(1, min(n, int(1.5e9 / ((C + ks) * D))))
-    desc = dict(kind=kind, D=D, m=m, ks=ks, n=n, k=k, C=C, w=w, tr=tr, dup=dup, hist=hist, v1=v1, wide=wide, nogrp=nogrp, fused=fused, union=union, spre=spre, nomf=nomf, nosplit=nosplit, mfsub=mfsub, mfq=mfq, kcv1=kcv1, wsel=wsel, pam=pam, pamw=pamw)
+    desc = dict(kind=kind, D=D, m=m, ks=ks, n=n, k=k, C=C, w=w, tr=tr, dup=dup, hist=hist, v1=v1, wide=wide, nogrp=nogrp, fused=fused, union=union, spre=spre, nomf=nomf, nosplit=nosplit, mfsub=mfsub, mfq=mfq, kcv1=kcv1, wsel=wsel, pam=pam, pamw=pamw, paq=paq)
     try:
         nb = min(n, 3000)
         if kind == "ivfpq":
@@ -102,7 +112,8 @@ for case in range(cases):
         ix.set_option("mfma_kc_v1", kcv1)
         ix.set_option("mfma_kc_tpw", 16 if case % 7 == 3 else 8)
         ix.set_option("coarse_wave_sel", wsel)
-        ix.set_option("passa_mfma", pam)
+        ix.set_option("passa_mfma", pam if not q_shape else -1)
+        ix.set_option("passa_q", paq)
         ix.set_option("passa_mfma_wide", pamw)
         ix.set_option("no_split_table", nosplit)
         ix.set_option("smin_valu", int(case % 3 == 0))
@@ -114,7 +125,8 @@ for case in range(cases):
             ix.search_batch(min(k, 3), base[:2])  # a search between the two adds: the CSR is rebuilt incrementally
         ix.indexVectors([str(i) for i in range(half, n)], base[half:])
         ref.add_vectors(base)
-        Q = np.concatenate([base[rng.integers(0, n, 4)] + 0.01 * rng.standard_normal((4, D)), p["queries"][:3]])
+        nself = 24 if q_shape else 4  # (K3q: several queries per list -- groups of one to four pairs, several groups per list)
+        Q = np.concatenate([base[rng.integers(0, n, nself)] + 0.01 * rng.standard_normal((nself, D)), p["queries"][:3]])
         got = ix.search_batch(k, Q)
         want = ref.search_batch(Q, k)
         # ids, counts and distance BITS, rotation included: the kernels rotate in the oracle's order (sequential over the
