@@ -102,3 +102,39 @@ def test_the_guard_trips_where_fp32_cannot_hold_the_table():
     r, pq, qr, pmax = _case(rng, 16, 8, 256, 0.0, 1.0, 1.0)
     G = 2.0 * U * np.sqrt(4128.0 * SCALE / qr) * (np.linalg.norm(r) + pmax)
     assert G < 5e-3  # (the generated benchmarks: three orders of magnitude of room)
+
+
+@pytest.mark.parametrize("offset,K1,n", [(0.0, 101, 12000), (0.0, 21, 3000), (50.0, 101, 12000), (0.0, 152, 6000)])
+def test_integer_selection_keeps_every_code_at_or_under_its_threshold(offset, K1, n):
+    """K3q's rule, replayed whole: a* = the K1-th smallest integer sum, candidates = codes with a <= a* + 17, T = the largest exact
+    distance among the candidates with a <= a* (at least K1 of them).  Claim: no code outside the candidates has an
+    exact distance <= T -- so the pool K3q publishes (candidates with d <= T) is exactly {codes with d <= T}, what the exact kernel
+    K3h publishes for the same T.  Exact distances: the fp64 table summed in sub-quantizer order (IVFPQ.java:435-438)."""
+    m, dsub, ks = 16, 8, 256
+    rng = np.random.default_rng(K1 + n)
+    for rep in range(4):
+        r, pq, qr, pmax = _case(rng, m, dsub, ks, offset, 1.0, 1.0)
+        G = 2.0 * U * np.sqrt(4128.0 * SCALE / qr) * (np.linalg.norm(r) + pmax)
+        assert G <= 0.25
+        x = _table_entries(r, pq, qr)
+        q = np.minimum(np.floor(x), 4095.0).astype(np.int64)  # the u16 entries
+        lut = ((r.reshape(m, 1, dsub) - pq) ** 2).sum(-1)  # fp64 (the order of the inner sum does not matter for this claim)
+        codes = rng.integers(0, ks, (n, m))
+        # a cluster of near codes, as a list around the query has: perturb the best code of every row
+        best = np.argsort(lut, axis=1)[:, :24]
+        codes[: n // 8] = best[np.arange(m), rng.integers(0, 24, (n // 8, m))]
+        rows = np.arange(m)
+        a = q[rows, codes].sum(-1)
+        d = np.zeros(n)
+        for s in range(m):  # sub-quantizer order
+            d = d + lut[s, codes[:, s]]
+        astar = np.sort(a)[K1 - 1]
+        assert astar < 4095  # (else the kernel hands the query back)
+        cand = a <= astar + 17
+        evid = a <= astar
+        assert evid.sum() >= K1
+        T = d[evid].max()
+        outside = ~cand
+        assert not np.any(d[outside] <= T), (float(d[outside].min()), float(T))
+        # and the pool holds at least K1 entries, at most the candidates
+        assert K1 <= int((d[cand] <= T).sum()) <= int(cand.sum())
